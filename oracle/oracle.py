@@ -1,0 +1,297 @@
+"""ctypes binding of liboracle.so (the C restatement of the reference's CPU path).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+All field elements are numpy uint64 arrays of 4 little-endian limbs in Montgomery form (R = 2^256),
+i.e. the reference's in-memory representation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FR, FQ = 0, 1
+U64P = C.POINTER(C.c_uint64)
+U8P = C.POINTER(C.c_uint8)
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("kg_oracle.c", "kg_oracle_curve.inc", "kg_oracle_groth16.inc")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.kgo_fft_new.restype = C.c_void_p
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(U64P)
+
+
+def _u8(a):
+    return None if a is None else a.ctypes.data_as(U8P)
+
+
+def _arr(x, shape=None):
+    a = np.ascontiguousarray(x, dtype=np.uint64)
+    return a if shape is None else a.reshape(shape)
+
+
+# ---- field ------------------------------------------------------------------------------------
+def _bin(name):
+    def f(fd, a, b):
+        a, b = _arr(a), _arr(b)
+        o = np.empty(4, dtype=np.uint64)
+        getattr(lib(), name)(fd, _p(a), _p(b), _p(o))
+        return o
+    return f
+
+
+def _un(name):
+    def f(fd, a):
+        a = _arr(a)
+        o = np.empty(4, dtype=np.uint64)
+        getattr(lib(), name)(fd, _p(a), _p(o))
+        return o
+    return f
+
+
+f_add, f_sub, f_mul = _bin("kgo_f_add"), _bin("kgo_f_sub"), _bin("kgo_f_mul")
+f_double, f_neg, f_square = _un("kgo_f_double"), _un("kgo_f_neg"), _un("kgo_f_square")
+f_to_mont, f_from_mont = _un("kgo_f_to_mont"), _un("kgo_f_from_mont")
+
+
+def f_mont(fd, a8):
+    a8 = _arr(a8)
+    o = np.empty(4, dtype=np.uint64)
+    lib().kgo_f_mont(fd, _p(a8), _p(o))
+    return o
+
+
+def f_from_u512(fd, a8):
+    a8 = _arr(a8)
+    o = np.empty(4, dtype=np.uint64)
+    lib().kgo_f_from_u512(fd, _p(a8), _p(o))
+    return o
+
+
+def f_invert(fd, a):
+    a = _arr(a)
+    o = np.zeros(4, dtype=np.uint64)
+    ok = lib().kgo_f_invert(fd, _p(a), _p(o))
+    return o if ok else None
+
+
+def f_pow(fd, a, e):
+    a, e = _arr(a), _arr(e)
+    o = np.empty(4, dtype=np.uint64)
+    lib().kgo_f_pow(fd, _p(a), _p(e), _p(o))
+    return o
+
+
+def f_consts(fd):
+    o = np.empty(17, dtype=np.uint64)
+    lib().kgo_f_consts(fd, _p(o))
+    return {"p": o[0:4].copy(), "inv": int(o[4]), "r": o[5:9].copy(), "r2": o[9:13].copy(), "r3": o[13:17].copy()}
+
+
+def f_vec_mul(fd, a, b):
+    a, b = _arr(a), _arr(b)
+    o = np.empty_like(a)
+    lib().kgo_f_vec_mul(fd, _p(a), _p(b), _p(o), C.c_size_t(a.size // 4))
+    return o
+
+
+def f2_mul(a, b):
+    a, b = _arr(a), _arr(b)
+    o = np.empty(8, dtype=np.uint64)
+    lib().kgo_f2_mul(_p(a), _p(b), _p(o))
+    return o
+
+
+def f2_square(a):
+    a = _arr(a)
+    o = np.empty(8, dtype=np.uint64)
+    lib().kgo_f2_square(_p(a), _p(o))
+    return o
+
+
+def f2_invert(a):
+    a = _arr(a)
+    o = np.zeros(8, dtype=np.uint64)
+    return o if lib().kgo_f2_invert(_p(a), _p(o)) else None
+
+
+# ---- curves: "g1" (bn254 G1), "gk" (Grumpkin), "g2" (bn254 G2) -----------------------------------
+NB = {"g1": 4, "gk": 4, "g2": 8}
+
+
+def _fn(cv, name):
+    return getattr(lib(), f"{cv}_kgo_{name}")
+
+
+def generator(cv):
+    o = np.empty(2 * NB[cv], dtype=np.uint64)
+    _fn(cv, "generator")(_p(o))
+    return o
+
+
+def curve_b(cv):
+    b, b3 = np.empty(NB[cv], dtype=np.uint64), np.empty(NB[cv], dtype=np.uint64)
+    _fn(cv, "curve_b")(_p(b), _p(b3))
+    return b, b3
+
+
+def is_on_curve(cv, xy, inf=0):
+    xy = _arr(xy)
+    return bool(_fn(cv, "is_on_curve")(_p(xy), int(inf)))
+
+
+def add_affine(cv, a, ainf, b, binf):
+    a, b = _arr(a), _arr(b)
+    o = np.empty(3 * NB[cv], dtype=np.uint64)
+    _fn(cv, "add_affine")(_p(a), int(ainf), _p(b), int(binf), _p(o))
+    return o
+
+
+def double_affine(cv, a):
+    a = _arr(a)
+    o = np.empty(3 * NB[cv], dtype=np.uint64)
+    _fn(cv, "double_affine")(_p(a), _p(o))
+    return o
+
+
+def add_mixed(cv, a, ainf, p):
+    a, p = _arr(a), _arr(p)
+    o = np.empty(3 * NB[cv], dtype=np.uint64)
+    _fn(cv, "add_mixed")(_p(a), int(ainf), _p(p), _p(o))
+    return o
+
+
+def add_projective(cv, p, q):
+    p, q = _arr(p), _arr(q)
+    o = np.empty(3 * NB[cv], dtype=np.uint64)
+    _fn(cv, "add_projective")(_p(p), _p(q), _p(o))
+    return o
+
+
+def double_projective(cv, p):
+    p = _arr(p)
+    o = np.empty(3 * NB[cv], dtype=np.uint64)
+    _fn(cv, "double_projective")(_p(p), _p(o))
+    return o
+
+
+def scalar_point(cv, p, k_mont):
+    p, k = _arr(p), _arr(k_mont)
+    o = np.empty(3 * NB[cv], dtype=np.uint64)
+    _fn(cv, "scalar_point")(_p(p), _p(k), _p(o))
+    return o
+
+
+def to_affine(cv, p):
+    p = _arr(p)
+    xy = np.empty(2 * NB[cv], dtype=np.uint64)
+    inf = np.zeros(1, dtype=np.uint8)
+    _fn(cv, "to_affine")(_p(p), _p(xy), _u8(inf))
+    return xy, int(inf[0])
+
+
+def msm(cv, bases, scalars, inf=None, threads=1):
+    """groth16::msm_curve_addition restated; returns the PROJECTIVE result (3*NB limbs), n = min(len)."""
+    bases, scalars = _arr(bases), _arr(scalars)
+    n = min(bases.size // (2 * NB[cv]), scalars.size // 4)
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+    o = np.empty(3 * NB[cv], dtype=np.uint64)
+    _fn(cv, "msm")(_p(bases), _u8(inf), _p(scalars), C.c_size_t(n), _p(o), int(threads))
+    return o
+
+
+def commit_naive(cv, bases, scalars, inf=None):
+    """nova PedersenCommitment::commit restated (naive NAF scalar muls); returns (xy, inf)."""
+    bases, scalars = _arr(bases), _arr(scalars)
+    n = min(bases.size // (2 * NB[cv]), scalars.size // 4)
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+    xy = np.empty(2 * NB[cv], dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    _fn(cv, "commit_naive")(_p(bases), _u8(inf), _p(scalars), C.c_size_t(n), _p(xy), _u8(oinf))
+    return xy, int(oinf[0])
+
+
+# ---- Fft<Fr> ------------------------------------------------------------------------------------
+class Fft:
+    """groth16::fft::Fft<Fr> restated; operates on (n, 4) uint64 arrays, returns new arrays."""
+
+    def __init__(self, k: int):
+        self.k, self.n = k, 1 << k
+        self._h = C.c_void_p(lib().kgo_fft_new(k))
+        if not self._h:
+            raise ValueError("k out of range")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kgo_fft_free(self._h)
+            self._h = None
+
+    def _pad(self, v):
+        v = _arr(v).reshape(-1, 4)
+        out = np.zeros((self.n, 4), dtype=np.uint64)
+        out[: min(len(v), self.n)] = v[: self.n]
+        return out
+
+    def _run(self, name, v, threads):
+        d = self._pad(v)
+        getattr(lib(), name)(self._h, _p(d), int(threads))
+        return d
+
+    def dft(self, v, threads=1):
+        return self._run("kgo_fft_dft", v, threads)
+
+    def idft(self, v, threads=1):
+        return self._run("kgo_fft_idft", v, threads)
+
+    def coset_dft(self, v, threads=1):
+        return self._run("kgo_fft_coset_dft", v, threads)
+
+    def coset_idft(self, v, threads=1):
+        return self._run("kgo_fft_coset_idft", v, threads)
+
+    def divide_by_z_on_coset(self, v):
+        d = self._pad(v)
+        lib().kgo_fft_divide_by_z_on_coset(self._h, _p(d))
+        return d
+
+
+def fr_vec(name, a, b):
+    a, b = _arr(a), _arr(b)
+    o = np.empty_like(a)
+    getattr(lib(), f"kgo_fr_vec_{name}")(_p(a), _p(b), _p(o), C.c_size_t(a.size // 4))
+    return o
+
+
+# ---- synthetic inputs ---------------------------------------------------------------------------
+def gen_scalars(fd, seed, start, n):
+    o = np.empty((n, 4), dtype=np.uint64)
+    lib().kgo_gen_scalars(fd, C.c_uint64(seed), C.c_size_t(start), C.c_size_t(n), _p(o))
+    return o
+
+
+def gen_bases(curve, seed, start, n, threads=8):
+    """curve: 0 = bn254 G1, 1 = Grumpkin.  Returns (n, 8) Montgomery x|y."""
+    o = np.empty((n, 8), dtype=np.uint64)
+    lib().kgo_gen_bases_mt(curve, C.c_uint64(seed), C.c_size_t(start), C.c_size_t(n), _p(o), int(threads))
+    return o
