@@ -1,0 +1,129 @@
+// curve.h -- short-Weierstrass a = 0 point arithmetic (BN254 G1 / G2, Grumpkin) for the MSM kernels.
+//
+// The reference accumulates buckets in homogeneous projective coordinates with the branchy formulas of
+// zkstd/src/arithmetic/points/weierstrass.rs:6-163 (add_affine_point / add_mixed_point /
+// add_projective_point / double_*).  MSM and commitment outputs are compared as AFFINE points (the unique
+// canonical value), so the device is free to use a cheaper system: XYZZ coordinates
+// (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; EFD "xyzz": madd-2008-s 8M+2S, add-2008-s 12M+2S, dbl-2008-s-1).
+// The exceptional cases the reference branches on (identity operands, equal x => doubling or identity;
+// weierstrass.rs:7-24, 64-86, 102-123) are all handled here, because CRS bases do contain identities and
+// repeated points (groth16/src/zksnark.rs:62-64,177-185).
+//
+// Everything is a template over the field type F (Fq, Fr, Fq2, or their FpChecked shadows); the lazy
+// add/sub/norm discipline of fp29.h is written out explicitly and machine-checked in tests/host/.
+#pragma once
+#include "fp29.h"
+
+namespace kg {
+
+template <class F>
+struct Affine {   // never the identity: identity bases are filtered by the caller via their flag
+  F x, y;
+};
+
+// identity <=> ZZ == 0 (exactly zero limbs; every path that produces the identity writes zeros)
+template <class F>
+struct XYZZ {
+  F x, y, zz, zzz;
+  static KG_HD XYZZ identity() { return {F::zero(), F::zero(), F::zero(), F::zero()}; }
+};
+
+template <class F>
+KG_HD bool is_identity(const XYZZ<F>& p) { return is_zero_2p(p.zz); }
+
+template <class F>
+KG_HD XYZZ<F> from_affine(const Affine<F>& a) { return {a.x, a.y, F::one(), F::one()}; }
+
+// 2 * (affine point)  (dbl-mdbl-2008-s-1).  In a prime-order group y != 0, result is never the identity
+// for G1/Grumpkin; for G2 inputs in the r-torsion the same holds.
+template <class F>
+KG_HD XYZZ<F> double_affine(const Affine<F>& a) {
+  F u = norm(dbl(a.y));                 // 2y
+  F v = sqr(u);                         // 4y^2
+  F w = mul(u, v);                      // 8y^3
+  F s = mul(a.x, v);                    // 4xy^2
+  F xx = sqr(a.x);
+  F m = norm(add(dbl(xx), xx));         // 3x^2
+  F x3 = vred(norm(sub<4, 1>(sqr(m), norm(dbl(s)))));
+  F y3 = vred(norm(sub<4, 1>(mul(m, norm(sub<4, 1>(s, x3))), mul(w, a.y))));
+  return {x3, y3, v, w};
+}
+
+// 2 * P  (dbl-2008-s-1)
+template <class F>
+KG_HD XYZZ<F> double_xyzz(const XYZZ<F>& p) {
+  if (is_identity(p)) return p;
+  F u = norm(dbl(p.y));
+  F v = sqr(u);
+  F w = mul(u, v);
+  F s = mul(p.x, v);
+  F xx = sqr(p.x);
+  F m = norm(add(dbl(xx), xx));
+  F x3 = vred(norm(sub<4, 1>(sqr(m), norm(dbl(s)))));
+  F y3 = vred(norm(sub<4, 1>(mul(m, norm(sub<4, 1>(s, x3))), mul(w, p.y))));
+  return {x3, y3, mul(v, p.zz), mul(w, p.zzz)};
+}
+
+// P + (affine a)  (madd-2008-s); a is not the identity.
+// Invariant on stored XYZZ coordinates: normalised limbs, every coordinate < 2p (X, Y < 1.06p via vred).
+template <class F>
+KG_HD XYZZ<F> add_mixed(const XYZZ<F>& p, const Affine<F>& a) {
+  if (is_identity(p)) return from_affine(a);
+  F u2 = mul(a.x, p.zz);
+  F s2 = mul(a.y, p.zzz);
+  F pp_ = norm(sub<4, 1>(u2, p.x));     // P = U2 - X1
+  F r = norm(sub<4, 1>(s2, p.y));       // R = S2 - Y1
+  F pp = sqr(pp_);
+  if (is_zero_2p(pp)) {                 // same x: doubling or inverse (weierstrass.rs:75-81)
+    if (is_zero(r)) return double_affine(a);
+    return XYZZ<F>::identity();
+  }
+  F ppp = mul(pp_, pp);
+  F q = mul(p.x, pp);
+  F x3 = vred(norm(sub<4, 1>(sqr(r), norm(add(ppp, dbl(q))))));
+  F y3 = vred(norm(sub<4, 1>(mul(r, norm(sub<4, 1>(q, x3))), mul(p.y, ppp))));
+  return {x3, y3, mul(p.zz, pp), mul(p.zzz, ppp)};
+}
+
+// P + Q  (add-2008-s)
+template <class F>
+KG_HD XYZZ<F> add_xyzz(const XYZZ<F>& p, const XYZZ<F>& q_) {
+  if (is_identity(p)) return q_;
+  if (is_identity(q_)) return p;
+  F u1 = mul(p.x, q_.zz);
+  F u2 = mul(q_.x, p.zz);
+  F s1 = mul(p.y, q_.zzz);
+  F s2 = mul(q_.y, p.zzz);
+  F pp_ = norm(sub<4, 1>(u2, u1));
+  F r = norm(sub<4, 1>(s2, s1));
+  F pp = sqr(pp_);
+  if (is_zero_2p(pp)) {                 // weierstrass.rs:114-120
+    if (is_zero(r)) return double_xyzz(p);
+    return XYZZ<F>::identity();
+  }
+  F ppp = mul(pp_, pp);
+  F q = mul(u1, pp);
+  F x3 = vred(norm(sub<4, 1>(sqr(r), norm(add(ppp, dbl(q))))));
+  F y3 = vred(norm(sub<4, 1>(mul(r, norm(sub<4, 1>(q, x3))), mul(s1, ppp))));
+  return {x3, y3, mul(mul(p.zz, q_.zz), pp), mul(mul(p.zzz, q_.zzz), ppp)};
+}
+
+// -P
+template <class F>
+KG_HD XYZZ<F> neg_xyzz(const XYZZ<F>& p) { return {p.x, vred(norm(sub<4, 1>(F::zero(), p.y))), p.zz, p.zzz}; }
+template <class F>
+KG_HD Affine<F> neg_affine(const Affine<F>& a) { return {a.x, vred(norm(sub<4, 1>(F::zero(), a.y)))}; }
+
+// XYZZ -> affine (x = X/ZZ, y = Y/ZZZ); returns false for the identity.  One field inversion
+// (the reference's to_affine, macros/curve/weierstrass.rs:57-66, does the same with z^-1).
+template <class F>
+KG_HD bool to_affine(const XYZZ<F>& p, Affine<F>& out) {
+  if (is_identity(p)) return false;
+  F zi = inv(p.zzz);                    // ZZZ^-1
+  F zzi = mul(mul(zi, zi), sqr(p.zz));  // ZZ^-1 = ZZZ^-2 * ZZ^2   (ZZ^3 = ZZZ^2)
+  out.x = mul(p.x, zzi);
+  out.y = mul(p.y, zi);
+  return true;
+}
+
+}  // namespace kg

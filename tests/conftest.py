@@ -1,0 +1,40 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running CPU test")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def pyoracle():
+    from oracle import pyoracle as P
+    return P
+
+
+@pytest.fixture(scope="session")
+def hostlib():
+    """The device arithmetic templates compiled for the host (tests/host/hosttest.cpp)."""
+    import ctypes
+    d = os.path.join(ROOT, "tests", "host")
+    so = os.path.join(d, "libhosttest.so")
+    srcs = [os.path.join(d, "hosttest.cpp")] + [
+        os.path.join(ROOT, "kogarashi_amd", "csrc", f) for f in ("fp29.h", "fp29_checked.h", "curve.h", "fp_consts.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]])
+    return ctypes.CDLL(so)

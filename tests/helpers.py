@@ -1,0 +1,46 @@
+"""Shared helpers for the parity tests (numpy <-> big-int conversions)."""
+import ctypes as C
+
+import numpy as np
+
+from oracle import pyoracle as P
+
+U32P = C.POINTER(C.c_uint32)
+U64P = C.POINTER(C.c_uint64)
+U8P = C.POINTER(C.c_uint8)
+
+
+def p32(a):
+    return a.ctypes.data_as(U32P)
+
+
+def L(x):
+    return np.array(P.limbs(x), dtype=np.uint64)
+
+
+def I(a):
+    return P.from_limbs([int(v) for v in a])
+
+
+def pt_to_np(cur, pt):
+    """affine big-int point -> reference-form limbs (x | y), zeros for the identity."""
+    p = cur.p
+    if pt is None:
+        return np.zeros(16 if cur.ext else 8, dtype=np.uint64)
+    if cur.ext:
+        x, y = pt
+        return np.concatenate([L(P.to_mont(v, p)) for v in (x.a, x.b, y.a, y.b)])
+    return np.concatenate([L(P.to_mont(pt[0], p)), L(P.to_mont(pt[1], p))])
+
+
+def np_to_pt(cur, xy, inf):
+    p = cur.p
+    if inf:
+        return None
+    if cur.ext:
+        v = [P.from_mont(I(xy[4 * i:4 * i + 4]), p) for i in range(4)]
+        return (P.Fq2(v[0], v[1]), P.Fq2(v[2], v[3]))
+    return (P.from_mont(I(xy[:4]), p), P.from_mont(I(xy[4:]), p))
+
+
+CURVES = {"g1": (0, P.G1, 0), "gk": (1, P.GRUMPKIN, 1), "g2": (2, P.G2, 0)}  # name -> (id, pycurve, scalar field id)

@@ -1,0 +1,116 @@
+// hosttest.cpp -- compiles the DEVICE arithmetic templates (fp29.h, curve.h) for the host with g++ so the
+// CPU test-suite can check them against the oracle without a GPU, and runs every formula once more with the
+// bound-tracking FpChecked shadow type (aborts on any possible overflow).  Test infrastructure only.
+#include <cstring>
+#include <vector>
+#include "../../kogarashi_amd/csrc/fp29.h"
+#include "../../kogarashi_amd/csrc/fp29_checked.h"
+#include "../../kogarashi_amd/csrc/curve.h"
+
+using namespace kg;
+
+template <class F> struct Conv;   // reference-form words <-> field type (plain or checked)
+template <class P> struct Conv<Fp<P>> {
+  static Fp<P> in(const uint32_t* w) { return from_ref<P>(w); }
+  static void out(const Fp<P>& a, uint32_t* w) { to_ref(a, w); }
+  static constexpr int W = 8;
+};
+template <class P> struct Conv<FpChecked<P>> {
+  static FpChecked<P> in(const uint32_t* w) {
+    FpChecked<P> raw = FpChecked<P>::wrap(limbs_from_words<P>(w), 5.4);   // any 256-bit input
+    return mul(raw, FpChecked<P>::from_const(P::C_FROM_REF));
+  }
+  static void out(const FpChecked<P>& a, uint32_t* w) {
+    words_from_limbs(reduce_2p(mul(a, FpChecked<P>::from_const(P::C_TO_REF))).v, w);
+  }
+  static constexpr int W = 8;
+};
+template <class F> struct Conv<Fp2<F>> {
+  static Fp2<F> in(const uint32_t* w) { return {Conv<F>::in(w), Conv<F>::in(w + 8)}; }
+  static void out(const Fp2<F>& a, uint32_t* w) { Conv<F>::out(a.c0, w); Conv<F>::out(a.c1, w + 8); }
+  static constexpr int W = 16;
+};
+
+template <class F> static F xsub(const F& a, const F& b) { return norm(sub<4, 1>(a, b)); }
+
+// op: 0 mul, 1 sqr, 2 add, 3 sub, 4 neg, 5 dbl, 6 inv, 7 (a*b+a*a) via lazy chain, 8 identity round trip
+template <class F>
+static void field_ops(int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n) {
+  const int W = Conv<F>::W;
+  for (size_t i = 0; i < n; ++i) {
+    F x = Conv<F>::in(a + W * i), y = Conv<F>::in(b + W * i), r = x;
+    switch (op) {
+      case 0: r = mul(x, y); break;
+      case 1: r = sqr(x); break;
+      case 2: r = norm(add(x, y)); break;
+      case 3: r = xsub(x, y); break;
+      case 4: r = xsub(F::zero(), x); break;
+      case 5: r = norm(dbl(x)); break;
+      case 6: r = inv(x); break;
+      case 7: r = mul(norm(add(mul(x, y), sqr(x))), F::one()); break;
+      case 8: r = x; break;
+    }
+    Conv<F>::out(r, o + W * i);
+  }
+}
+
+extern "C" {
+// field: 0 Fr, 1 Fq, 2 Fq2 ; checked: run with the bound-tracking shadow type
+void ht_field_ops(int field, int checked, int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n) {
+  if (field == 0) { if (checked) field_ops<FrC>(op, a, b, o, n); else field_ops<Fr>(op, a, b, o, n); }
+  else if (field == 1) { if (checked) field_ops<FqC>(op, a, b, o, n); else field_ops<Fq>(op, a, b, o, n); }
+  else { if (checked) field_ops<Fq2C>(op, a, b, o, n); else field_ops<Fq2>(op, a, b, o, n); }
+}
+void ht_ref_to_int(int field, const uint32_t* a, uint32_t* o, size_t n) {
+  for (size_t i = 0; i < n; ++i) { if (field == 0) ref_to_int<FrParams>(a + 8 * i, o + 8 * i); else ref_to_int<FqParams>(a + 8 * i, o + 8 * i); }
+}
+void ht_int_to_ref(int field, const uint32_t* a, uint32_t* o, size_t n) {
+  for (size_t i = 0; i < n; ++i) { if (field == 0) int_to_ref<FrParams>(a + 8 * i, o + 8 * i); else int_to_ref<FqParams>(a + 8 * i, o + 8 * i); }
+}
+}
+
+// ---- curve ----------------------------------------------------------------------------------------
+template <class F>
+static Affine<F> ld_aff(const uint32_t* xy) { return {Conv<F>::in(xy), Conv<F>::in(xy + Conv<F>::W)}; }
+template <class F>
+static int st_aff(const XYZZ<F>& p, uint32_t* xy) {
+  Affine<F> a;
+  if (!to_affine(p, a)) { std::memset(xy, 0, 8 * Conv<F>::W); return 1; }
+  Conv<F>::out(a.x, xy); Conv<F>::out(a.y, xy + Conv<F>::W);
+  return 0;
+}
+// mode 0: left fold with add_mixed; 1: pairwise tree with add_xyzz; 2: fold of add_xyzz(from_affine);
+// 3: sum_i 2*P_i via double_affine + add_xyzz; 4: double_xyzz applied `n` times to point 0; 5: fold, negated
+template <class F>
+static int curve_sum(int mode, const uint32_t* pts, const uint8_t* inf, size_t n, uint32_t* out_xy) {
+  const int W2 = 2 * Conv<F>::W;
+  XYZZ<F> acc = XYZZ<F>::identity();
+  if (mode == 0 || mode == 5) {
+    for (size_t i = 0; i < n; ++i) if (!inf || !inf[i]) acc = add_mixed(acc, ld_aff<F>(pts + W2 * i));
+    if (mode == 5) acc = neg_xyzz(acc);
+  } else if (mode == 1) {
+    std::vector<XYZZ<F>> v;
+    for (size_t i = 0; i < n; ++i) v.push_back((inf && inf[i]) ? XYZZ<F>::identity() : from_affine(ld_aff<F>(pts + W2 * i)));
+    while (v.size() > 1) {
+      std::vector<XYZZ<F>> w;
+      for (size_t i = 0; i + 1 < v.size(); i += 2) w.push_back(add_xyzz(v[i], v[i + 1]));
+      if (v.size() & 1) w.push_back(v.back());
+      v.swap(w);
+    }
+    if (!v.empty()) acc = v[0];
+  } else if (mode == 2) {
+    for (size_t i = 0; i < n; ++i) if (!inf || !inf[i]) acc = add_xyzz(acc, from_affine(ld_aff<F>(pts + W2 * i)));
+  } else if (mode == 3) {
+    for (size_t i = 0; i < n; ++i) if (!inf || !inf[i]) acc = add_xyzz(double_affine(ld_aff<F>(pts + W2 * i)), acc);
+  } else if (mode == 4) {
+    acc = from_affine(ld_aff<F>(pts));
+    for (size_t i = 0; i < n; ++i) acc = double_xyzz(acc);
+  }
+  return st_aff(acc, out_xy);
+}
+extern "C" int ht_curve_sum(int curve, int checked, int mode, const uint32_t* pts, const uint8_t* inf, size_t n, uint32_t* out_xy) {
+  // curve: 0 G1 (Fq), 1 Grumpkin (Fr), 2 G2 (Fq2)
+  if (curve == 0) return checked ? curve_sum<FqC>(mode, pts, inf, n, out_xy) : curve_sum<Fq>(mode, pts, inf, n, out_xy);
+  if (curve == 1) return checked ? curve_sum<FrC>(mode, pts, inf, n, out_xy) : curve_sum<Fr>(mode, pts, inf, n, out_xy);
+  return checked ? curve_sum<Fq2C>(mode, pts, inf, n, out_xy) : curve_sum<Fq2>(mode, pts, inf, n, out_xy);
+}

@@ -1,0 +1,109 @@
+"""The device arithmetic (fp29.h / curve.h) compiled for the host, checked against the oracle.
+
+Every case runs twice: with the plain types the kernels use, and with the bound-tracking FpChecked shadow,
+which aborts the process if any 64-bit column, 32-bit limb or Montgomery value bound could overflow."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from helpers import CURVES, U8P, np_to_pt, p32, pt_to_np
+
+SEED = 0x4B6F676172617368
+
+
+def field_ops(H, field, checked, op, a, b):
+    o = np.empty_like(a)
+    H.ht_field_ops(field, checked, op, p32(a.view(np.uint32)), p32(b.view(np.uint32)), p32(o.view(np.uint32)), C.c_size_t(a.shape[0]))
+    return o
+
+
+@pytest.mark.parametrize("fd", [0, 1])
+def test_prime_field_ops_match_oracle(hostlib, oracle, fd):
+    O, n = oracle, 1500
+    a, b = O.gen_scalars(fd, SEED + 1, 0, n), O.gen_scalars(fd, SEED + 2, 0, n)
+    c = O.f_consts(fd)
+    a[0] = 0; b[1] = 0; a[2] = c["r"]; a[3] = O.f_neg(fd, c["r"]); b[3] = a[3]; a[4] = a[5]; b[4] = a[5]
+    pm1 = c["p"].copy(); pm1[0] -= 1
+    a[6] = O.f_to_mont(fd, pm1); b[6] = a[6]            # (p-1)*(p-1)
+    ops = {0: lambda x, y: O.f_mul(fd, x, y), 1: lambda x, y: O.f_square(fd, x), 2: lambda x, y: O.f_add(fd, x, y),
+           3: lambda x, y: O.f_sub(fd, x, y), 4: lambda x, y: O.f_neg(fd, x), 5: lambda x, y: O.f_double(fd, x),
+           7: lambda x, y: O.f_add(fd, O.f_mul(fd, x, y), O.f_square(fd, x)), 8: lambda x, y: x}
+    for op, f in ops.items():
+        exp = np.stack([f(a[i], b[i]) for i in range(n)])
+        for chk in (0, 1):
+            got = field_ops(hostlib, fd, chk, op, a, b)
+            assert (got == exp).all(), (fd, op, chk)
+    m = 40
+    exp = np.stack([O.f_invert(fd, a[i]) if a[i].any() else np.zeros(4, dtype=np.uint64) for i in range(m)])
+    for chk in (0, 1):
+        assert (field_ops(hostlib, fd, chk, 6, a[:m].copy(), b[:m].copy()) == exp).all()
+
+
+@pytest.mark.parametrize("fd", [0, 1])
+def test_montgomery_domain_conversions(hostlib, oracle, fd):
+    O, n = oracle, 500
+    a = O.gen_scalars(fd, SEED + 3, 0, n)
+    a[0] = 0
+    o = np.empty_like(a)
+    hostlib.ht_ref_to_int(fd, p32(a.view(np.uint32)), p32(o.view(np.uint32)), C.c_size_t(n))
+    assert (o == np.stack([O.f_from_mont(fd, a[i]) for i in range(n)])).all()
+    o2 = np.empty_like(a)
+    hostlib.ht_int_to_ref(fd, p32(o.view(np.uint32)), p32(o2.view(np.uint32)), C.c_size_t(n))
+    assert (o2 == a).all()
+
+
+def test_fq2_ops_match_oracle(hostlib, oracle):
+    O, n = oracle, 600
+    a = np.concatenate([O.gen_scalars(1, SEED + 3, 0, n), O.gen_scalars(1, SEED + 4, 0, n)], axis=1)
+    b = np.concatenate([O.gen_scalars(1, SEED + 5, 0, n), O.gen_scalars(1, SEED + 6, 0, n)], axis=1)
+    a[0] = 0; b[1, :4] = 0; a[2, 4:] = 0; b[3] = a[3]
+    for op, f in {0: lambda x, y: O.f2_mul(x, y), 1: lambda x, y: O.f2_square(x)}.items():
+        exp = np.stack([f(a[i], b[i]) for i in range(n)])
+        for chk in (0, 1):
+            assert (field_ops(hostlib, 2, chk, op, a, b) == exp).all(), (op, chk)
+    exp = np.stack([O.f2_invert(a[i]) for i in range(3, 15)])
+    for chk in (0, 1):
+        assert (field_ops(hostlib, 2, chk, 6, a[3:15].copy(), b[3:15].copy()) == exp).all()
+
+
+def curve_sum(H, cid, cur, chk, mode, pts, inf):
+    arr = np.stack([pt_to_np(cur, pt) for pt in pts])
+    infa = np.array(inf, dtype=np.uint8)
+    out = np.zeros(arr.shape[1], dtype=np.uint64)
+    r = H.ht_curve_sum(cid, chk, mode, p32(arr.view(np.uint32)), infa.ctypes.data_as(U8P), C.c_size_t(len(pts)), p32(out.view(np.uint32)))
+    return np_to_pt(cur, out, r)
+
+
+@pytest.mark.parametrize("name", ["g1", "gk", "g2"])
+def test_xyzz_point_formulas_match_bigint_oracle(hostlib, pyoracle, name):
+    """Group-law cases of the reference's curve_test! (zkstd/src/macros/curve/weierstrass/test.rs:2-224) plus the
+    exceptional branches of weierstrass.rs (equal points, inverse points, identities in the input)."""
+    P = pyoracle
+    cid, cur, _ = CURVES[name]
+    rnd = random.Random(5)
+    if cur.ext:
+        base = [cur.mul(cur.gen, rnd.randrange(1, cur.n)) for _ in range(5)]
+    else:
+        base = [P.base_at(cur, SEED + 100, i) for i in range(10)]
+    A, B = base[0], base[1]
+    cases = [base, [A, A], [A, cur.neg(A)], [A, A, A], [A, B, cur.neg(A), cur.neg(B)], [A, B, cur.add(A, B)],
+             [A, B, cur.neg(cur.add(A, B))], [cur.add(A, A), A, A], [cur.add(A, A), cur.neg(A), cur.neg(A)], [A],
+             [A, B, A, B, A, B, A], base + base, base + [cur.neg(x) for x in base]]
+    for ci, pts in enumerate(cases):
+        for some_inf in (False, True):
+            inf = [0] * len(pts)
+            if some_inf and len(pts) > 2:
+                inf[1] = 1; inf[-1] = 1
+            exp = None
+            for pt, f in zip(pts, inf):
+                if not f:
+                    exp = cur.add(exp, pt)
+            for chk in (0, 1):
+                for mode in (0, 1, 2):
+                    assert curve_sum(hostlib, cid, cur, chk, mode, pts, inf) == exp, (name, ci, some_inf, chk, mode)
+                assert curve_sum(hostlib, cid, cur, chk, 5, pts, inf) == cur.neg(exp)
+                assert curve_sum(hostlib, cid, cur, chk, 3, pts, inf) == cur.add(exp, exp), (name, ci, "dbl")
+    for chk in (0, 1):
+        assert curve_sum(hostlib, cid, cur, chk, 4, [A] * 5, [0] * 5) == cur.mul(A, 32)
