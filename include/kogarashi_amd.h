@@ -1,0 +1,120 @@
+/*
+ * kogarashi_amd.h -- C ABI of the MI355X (gfx950) proving backend for Kogarashi's MSM + NTT hot path.
+ *
+ * The reference has no FFI boundary: the path sits behind crate-internal generic Rust
+ * functions.  Each entry point below names the reference function it replaces; INTEGRATION.md shows the
+ * Rust `extern "C"` shim a maintainer adds behind a cargo feature.
+ *
+ * Data formats (identical to the reference's in-memory representation):
+ *   field element  : 4 x uint64 little-endian limbs, Montgomery form (x * 2^256 mod p), fully reduced
+ *                    (bn254/src/fr.rs:71, bn254/src/fq.rs:48)
+ *   G1 / Grumpkin affine base : 8 x uint64 = x | y, plus one uint8 infinity flag in a separate array
+ *                    (bn254/src/g1.rs:18-22 is repr(Rust): the shim marshals x, y, is_infinity explicitly)
+ *   G2 affine base : 16 x uint64 = x.c0 | x.c1 | y.c0 | y.c1 (+ flag)         (bn254/src/g2.rs:16-20)
+ *   point outputs  : projective (x, y, z) in the reference's homogeneous coordinates, normalised so that
+ *                    z = 1 (or (0, 1, 0) for the identity) -- i.e. to_extended(to_affine(result)),
+ *                    macros/curve/weierstrass.rs:33-66.  The reference's own (X:Y:Z) triple depends on its
+ *                    summation order; equality there is by cross-multiplication (group.rs:89-97).
+ *
+ * Pointers named d_* are DEVICE pointers (from kg_malloc, or any HIP allocation of the same device, e.g. a
+ * torch tensor's data_ptr()); pointers named h_* / out_* are host pointers.
+ * All functions return KG_OK (0) or a negative kg_status; none aborts.  Calls on one kg_ctx are
+ * serialised by the caller; distinct contexts may be used from distinct threads.
+ */
+#ifndef KOGARASHI_AMD_H
+#define KOGARASHI_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  KG_OK = 0,
+  KG_ERR_NO_DEVICE = -1,   /* no gfx950 device visible / HIP runtime failed to initialise */
+  KG_ERR_BAD_ARG = -2,     /* null pointer, bad length, log_n out of range, unknown enum */
+  KG_ERR_OOM = -3,         /* device allocation failed */
+  KG_ERR_HIP = -4,         /* a HIP call or kernel launch failed (see kg_last_error) */
+  KG_ERR_UNSUPPORTED = -5
+} kg_status;
+
+/* field / curve selectors */
+enum { KG_FR = 0, KG_FQ = 1 };                       /* bn254 scalar field r, base field q */
+enum { KG_G1 = 0, KG_GRUMPKIN = 1, KG_G2 = 2 };      /* curve ids */
+
+typedef struct kg_ctx kg_ctx;
+
+int kg_version(void);
+int kg_device_count(void);
+const char* kg_strerror(int status);
+
+/* One context per (process, GPU): owns a stream, twiddle caches and MSM work space. */
+int kg_ctx_create(int device, kg_ctx** out);
+void kg_ctx_destroy(kg_ctx* ctx);
+const char* kg_last_error(kg_ctx* ctx);
+/* Launch on a caller-owned HIP stream (e.g. torch's current stream) instead of the context's own. */
+int kg_ctx_set_stream(kg_ctx* ctx, void* hip_stream);
+int kg_ctx_sync(kg_ctx* ctx);
+
+/* device memory plumbing so that non-HIP hosts (Rust shim, ctypes) never link the HIP runtime */
+int kg_malloc(kg_ctx* ctx, size_t bytes, void** d_ptr);
+int kg_free(kg_ctx* ctx, void* d_ptr);
+int kg_memcpy_h2d(kg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int kg_memcpy_d2h(kg_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int kg_memcpy_d2d(kg_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+
+/* ---- field vectors -------------------------------------------------------------------------------
+ * Element-wise ops on n field elements (device).  Replaces the Montgomery limb functions
+ * zkstd/src/arithmetic/limbs/bits_256/normal.rs:4-31 (add), 34-53 (sub), 56-80 (double), 83-121 (mul),
+ * 124-166 (square), 170-184 (neg), 256-270 (invert) and, for Fr vectors, the point-wise polynomial ops
+ * groth16/src/poly.rs:168-195.  `out` may alias an input. */
+typedef enum { KG_OP_ADD = 0, KG_OP_SUB = 1, KG_OP_MUL = 2, KG_OP_SQUARE = 3, KG_OP_NEG = 4, KG_OP_DOUBLE = 5,
+               KG_OP_INVERT = 6, KG_OP_FROM_MONT = 7, KG_OP_TO_MONT = 8 } kg_field_op;
+int kg_field_vec_op(kg_ctx* ctx, int field, int op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n);
+/* out[i] = a[i] * s  (s: one element, HOST pointer); fft.rs:104,150-154 */
+int kg_field_vec_scale(kg_ctx* ctx, int field, const uint64_t* d_a, const uint64_t* h_s, uint64_t* d_out, size_t n);
+
+/* ---- NTT -------------------------------------------------------------------------------------------
+ * groth16/src/fft.rs: Fft::<Fr>::dft (:92-97), idft (:100-106), coset_dft (:109-116), coset_idft (:119-127),
+ * divide_by_z_on_coset (:150-154).  d_data holds n = 2^log_n elements, natural order in and out, in
+ * place; 1 <= log_n <= 28 (S = 28, bn254/src/fr.rs:53).  The caller zero-pads (prepare_fft :157-162). */
+int kg_ntt_bn254_fr(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n, int inverse, int coset);
+int kg_fr_divide_by_z_on_coset(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n);
+
+/* ---- MSM -------------------------------------------------------------------------------------------
+ * groth16/src/msm.rs:6-48 msm_curve_addition(bases, coeffs): sum_i coeffs[i] * bases[i] over n pairs
+ * (n = min(len), resolved by the caller, msm.rs:25).  d_inf may be NULL (no identity bases).
+ * Scalars: Fr for KG_G1 / KG_G2, Fq for KG_GRUMPKIN (nova/src/driver.rs:9-42).
+ * out_xyz: HOST, 12 (G1, Grumpkin) or 24 (G2) uint64.  n == 0 yields the identity. */
+int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars,
+           size_t n, uint64_t* out_xyz);
+/* Same with HOST inputs (uploads, runs, frees): the call shape of the Rust slices. */
+int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars,
+                size_t n, uint64_t* out_xyz);
+/* nova/src/pedersen.rs:15-20 PedersenCommitment::commit: affine(sum_i m[i] * g[i]).
+ * out_xy: HOST, 8 or 16 uint64; *out_inf = 1 for the identity (then out_xy = (0, 1)). */
+int kg_commit(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars,
+              size_t n, uint64_t* out_xy, uint8_t* out_inf);
+/* Per-GPU partial for the sharded commit: the un-normalised device result (raw window sums) is reduced on
+ * the host to ONE affine partial; ranks exchange these (RCCL all_gather of 17/33 words) and add them with
+ * kg_points_sum_affine.  See DESIGN.md "Multi-GPU". */
+int kg_points_sum_affine(kg_ctx* ctx, int curve, const uint64_t* h_points_xy, const uint8_t* h_inf, size_t count,
+                         uint64_t* out_xy, uint8_t* out_inf);
+/* Tuning knob: window width c (0 = automatic). */
+int kg_msm_set_window(kg_ctx* ctx, int c);
+
+/* ---- deterministic synthetic inputs (identical streams in oracle/) -------------------- */
+int kg_gen_scalars(kg_ctx* ctx, int field, uint64_t seed, size_t start, size_t n, uint64_t* d_out);
+int kg_gen_bases(kg_ctx* ctx, int curve, uint64_t seed, size_t start, size_t n, uint64_t* d_out); /* G1, Grumpkin */
+
+/* ---- timing: when enabled, the library brackets its device phases with HIP events on its stream ------ */
+int kg_profile_enable(kg_ctx* ctx, int on);
+/* phases of the most recent call; returns the count written (<= cap); names are static strings */
+int kg_profile_last(kg_ctx* ctx, const char** names, float* ms, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOGARASHI_AMD_H */

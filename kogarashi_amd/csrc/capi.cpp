@@ -1,0 +1,172 @@
+// capi.cpp -- context management and memory plumbing of the C ABI (include/kogarashi_amd.h).
+#include "common.h"
+
+using namespace kg;
+
+namespace kg {
+int ensure_ws(kg_ctx* c, size_t bytes) {
+  if (bytes <= c->ws_bytes) return KG_OK;
+  if (c->ws) { hipStreamSynchronize(c->stream); hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
+  size_t want = bytes + bytes / 8;
+  hipError_t e = hipMalloc(&c->ws, want);
+  if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "workspace allocation", e);
+  c->ws_bytes = want;
+  return KG_OK;
+}
+int ensure_ws2(kg_ctx* c, size_t bytes) {
+  if (bytes <= c->ws2_bytes) return KG_OK;
+  if (c->ws2) { hipStreamSynchronize(c->stream); hipFree(c->ws2); c->ws2 = nullptr; c->ws2_bytes = 0; }
+  hipError_t e = hipMalloc(&c->ws2, bytes);
+  if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "ntt buffer allocation", e);
+  c->ws2_bytes = bytes;
+  return KG_OK;
+}
+int ensure_pinned(kg_ctx* c, size_t bytes) {
+  if (bytes <= c->h_pinned_bytes) return KG_OK;
+  if (c->h_pinned) hipHostFree(c->h_pinned);
+  c->h_pinned = nullptr; c->h_pinned_bytes = 0;
+  hipError_t e = hipHostMalloc(&c->h_pinned, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "pinned staging allocation", e);
+  c->h_pinned_bytes = bytes;
+  return KG_OK;
+}
+
+static hipEvent_t next_event(kg_ctx* c) {
+  if (c->event_next == c->event_pool.size()) {
+    hipEvent_t e;
+    hipEventCreate(&e);
+    c->event_pool.push_back(e);
+  }
+  return c->event_pool[c->event_next++];
+}
+void prof_reset(kg_ctx* c) { c->phases.clear(); c->event_next = 0; }
+PhaseScope::PhaseScope(kg_ctx* ctx, const char* name) : c(ctx) {
+  if (!c->prof) return;
+  kg_ctx::Phase p{name, next_event(c), next_event(c)};
+  hipEventRecord(p.e0, c->stream);
+  idx = (int)c->phases.size();
+  c->phases.push_back(p);
+}
+void PhaseScope::end() {
+  if (idx >= 0) hipEventRecord(c->phases[idx].e1, c->stream);
+  idx = -1;
+}
+void tw_cache_free(kg_ctx* c);   // ntt.hip
+}  // namespace kg
+
+extern "C" {
+
+int kg_version(void) { return 1; }
+
+int kg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* kg_strerror(int s) {
+  switch (s) {
+    case KG_OK: return "ok";
+    case KG_ERR_NO_DEVICE: return "no HIP device";
+    case KG_ERR_BAD_ARG: return "bad argument";
+    case KG_ERR_OOM: return "out of device memory";
+    case KG_ERR_HIP: return "HIP runtime error";
+    case KG_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+  }
+}
+
+int kg_ctx_create(int device, kg_ctx** out) {
+  if (!out) return KG_ERR_BAD_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return KG_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return KG_ERR_BAD_ARG;
+  if (hipSetDevice(device) != hipSuccess) return KG_ERR_NO_DEVICE;
+  kg_ctx* c = new kg_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KG_ERR_HIP; }
+  c->stream = c->own_stream;
+  *out = c;
+  return KG_OK;
+}
+
+void kg_ctx_destroy(kg_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  tw_cache_free(c);
+  if (c->ws) hipFree(c->ws);
+  if (c->ws2) hipFree(c->ws2);
+  if (c->h_pinned) hipHostFree(c->h_pinned);
+  for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
+  if (c->own_stream) hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* kg_last_error(kg_ctx* c) { return c ? c->last_error.c_str() : "null context"; }
+
+int kg_ctx_set_stream(kg_ctx* c, void* s) {
+  if (!c) return KG_ERR_BAD_ARG;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return KG_OK;
+}
+int kg_ctx_sync(kg_ctx* c) {
+  if (!c) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipStreamSynchronize(c->stream));
+  return KG_OK;
+}
+int kg_malloc(kg_ctx* c, size_t bytes, void** p) {
+  if (!c || !p) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipSetDevice(c->device));
+  KG_HIP(c, hipMalloc(p, bytes ? bytes : 1));
+  return KG_OK;
+}
+int kg_free(kg_ctx* c, void* p) {
+  if (!c) return KG_ERR_BAD_ARG;
+  if (p) KG_HIP(c, hipFree(p));
+  return KG_OK;
+}
+int kg_memcpy_h2d(kg_ctx* c, void* d, const void* h, size_t bytes) {
+  if (!c || (bytes && (!d || !h))) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+  KG_HIP(c, hipStreamSynchronize(c->stream));
+  return KG_OK;
+}
+int kg_memcpy_d2h(kg_ctx* c, void* h, const void* d, size_t bytes) {
+  if (!c || (bytes && (!d || !h))) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  KG_HIP(c, hipStreamSynchronize(c->stream));
+  return KG_OK;
+}
+int kg_memcpy_d2d(kg_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || (bytes && (!dst || !src))) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return KG_OK;
+}
+int kg_msm_set_window(kg_ctx* c, int w) {
+  if (!c || w < 0 || w > 16) return KG_ERR_BAD_ARG;
+  c->msm_window = w;
+  return KG_OK;
+}
+int kg_profile_enable(kg_ctx* c, int on) {
+  if (!c) return KG_ERR_BAD_ARG;
+  c->prof = on != 0;
+  return KG_OK;
+}
+int kg_profile_last(kg_ctx* c, const char** names, float* ms, int cap) {
+  if (!c) return KG_ERR_BAD_ARG;
+  hipStreamSynchronize(c->stream);
+  int n = 0;
+  for (auto& p : c->phases) {
+    if (n >= cap) break;
+    float t = 0;
+    if (hipEventElapsedTime(&t, p.e0, p.e1) != hipSuccess) t = -1.f;
+    if (names) names[n] = p.name;
+    if (ms) ms[n] = t;
+    ++n;
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+// common.h -- context, error plumbing and device-side layout helpers shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "../../include/kogarashi_amd.h"
+#include "curve.h"
+
+struct kg_tw_cache;   // ntt.hip
+
+struct kg_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;          // stream every launch goes to
+  std::string last_error;
+  int msm_window = 0;                    // 0 = auto
+  // grow-only scratch
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  void* ws2 = nullptr;                   // NTT ping-pong buffer
+  size_t ws2_bytes = 0;
+  void* h_pinned = nullptr;              // small pinned staging buffer for results
+  size_t h_pinned_bytes = 0;
+  std::vector<kg_tw_cache*> tw;          // per-(log_n, inverse) twiddle tables
+  // profiling
+  bool prof = false;
+  struct Phase { const char* name; hipEvent_t e0, e1; };
+  std::vector<Phase> phases;
+  std::vector<hipEvent_t> event_pool;
+  size_t event_next = 0;
+};
+
+namespace kg {
+
+inline int set_err(kg_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+  if (c) {
+    c->last_error = what;
+    if (e != hipSuccess) { c->last_error += ": "; c->last_error += hipGetErrorString(e); }
+  }
+  return code;
+}
+#define KG_HIP(ctx, call)                                                        \
+  do {                                                                           \
+    hipError_t e__ = (call);                                                     \
+    if (e__ != hipSuccess) return kg::set_err(ctx, e__ == hipErrorOutOfMemory ? KG_ERR_OOM : KG_ERR_HIP, #call, e__); \
+  } while (0)
+#define KG_TRY(call)            \
+  do {                          \
+    int s__ = (call);           \
+    if (s__ != KG_OK) return s__; \
+  } while (0)
+
+int ensure_ws(kg_ctx* c, size_t bytes);
+int ensure_ws2(kg_ctx* c, size_t bytes);
+int ensure_pinned(kg_ctx* c, size_t bytes);
+
+// RAII-free phase timer: PhaseScope p(ctx, "name"); ... p.end();
+struct PhaseScope {
+  kg_ctx* c; int idx = -1;
+  PhaseScope(kg_ctx* ctx, const char* name);
+  void end();
+};
+void prof_reset(kg_ctx* c);
+
+// ---- device-side layouts ------------------------------------------------------------------------
+// A field element in the ABI: 8 x u32 words (4 x u64 LE).  Loaded/stored as two 16-byte vectors.
+struct alignas(16) Words8 { uint32_t w[8]; };
+
+__device__ __forceinline__ void load_words(const uint64_t* base, size_t elem, uint32_t w[8]) {
+  const uint4* p = reinterpret_cast<const uint4*>(base) + 2 * elem;
+  uint4 a = p[0], b = p[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void store_words(uint64_t* base, size_t elem, const uint32_t w[8]) {
+  uint4* p = reinterpret_cast<uint4*>(base) + 2 * elem;
+  p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// Raw 9-limb storage of internal values in scratch memory, structure-of-arrays: word k of element i lives at
+// base[k * stride + i], so a wave touches 64 consecutive dwords per limb (fully coalesced).
+template <class F> struct RawIO;
+template <class P> struct RawIO<Fp<P>> {
+  static constexpr int NW = 9;
+  static __device__ __forceinline__ Fp<P> load(const uint32_t* base, size_t stride, size_t i) {
+    Fp<P> r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.l[k] = base[(size_t)k * stride + i];
+    return r;
+  }
+  static __device__ __forceinline__ void store(uint32_t* base, size_t stride, size_t i, const Fp<P>& a) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) base[(size_t)k * stride + i] = a.l[k];
+  }
+};
+template <class F> struct RawIO<Fp2<F>> {
+  static constexpr int NW = 18;
+  static __device__ __forceinline__ Fp2<F> load(const uint32_t* base, size_t stride, size_t i) {
+    return {RawIO<F>::load(base, stride, i), RawIO<F>::load(base + 9 * stride, stride, i)};
+  }
+  static __device__ __forceinline__ void store(uint32_t* base, size_t stride, size_t i, const Fp2<F>& a) {
+    RawIO<F>::store(base, stride, i, a.c0);
+    RawIO<F>::store(base + 9 * stride, stride, i, a.c1);
+  }
+};
+template <class F>
+struct PointIO {
+  static constexpr int NW = 4 * RawIO<F>::NW;
+  static __device__ __forceinline__ XYZZ<F> load(const uint32_t* base, size_t stride, size_t i) {
+    constexpr int E = RawIO<F>::NW;
+    return {RawIO<F>::load(base, stride, i), RawIO<F>::load(base + (size_t)E * stride, stride, i),
+            RawIO<F>::load(base + (size_t)2 * E * stride, stride, i), RawIO<F>::load(base + (size_t)3 * E * stride, stride, i)};
+  }
+  static __device__ __forceinline__ void store(uint32_t* base, size_t stride, size_t i, const XYZZ<F>& p) {
+    constexpr int E = RawIO<F>::NW;
+    RawIO<F>::store(base, stride, i, p.x);
+    RawIO<F>::store(base + (size_t)E * stride, stride, i, p.y);
+    RawIO<F>::store(base + (size_t)2 * E * stride, stride, i, p.zz);
+    RawIO<F>::store(base + (size_t)3 * E * stride, stride, i, p.zzz);
+  }
+};
+
+// ABI <-> internal for whole base-field elements (Fq, Fr: 8 words; Fq2: 16 words)
+template <class F> struct RefIO;
+template <class P> struct RefIO<Fp<P>> {
+  static constexpr int W64 = 4;
+  static __device__ __forceinline__ Fp<P> load(const uint64_t* p) {
+    uint32_t w[8];
+    load_words(p, 0, w);
+    return from_ref<P>(w);
+  }
+};
+template <class F> struct RefIO<Fp2<F>> {
+  static constexpr int W64 = 8;
+  static __device__ __forceinline__ Fp2<F> load(const uint64_t* p) { return {RefIO<F>::load(p), RefIO<F>::load(p + 4)}; }
+};
+
+}  // namespace kg

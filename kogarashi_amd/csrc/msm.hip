@@ -1,0 +1,525 @@
+// msm.hip -- Pippenger bucket MSM for BN254 G1 / G2 and Grumpkin on gfx950.
+//
+// Replaces groth16/src/msm.rs:6-48 (msm_curve_addition: unsigned c-bit windows, one rayon task per window,
+// serial bucket fill, summation by parts, c*i doublings per window) and, behind kg_commit, the naive
+// scalar-mul fold of nova/src/pedersen.rs:15-20.  Output parity is on the AFFINE sum, so the
+// device pipeline is its own design:
+//
+//   prep      scalars -> canonical integers k (one Montgomery product) biased by H = sum_w 2^(wc+c-1), so
+//             every window's SIGNED digit is a plain bit-field of k+H (halves the bucket count);
+//             bases -> internal Montgomery form, packed 64 B/point, identity flag folded into a spare bit
+//   count     one workgroup per (scalar chunk, window): the window's whole histogram (2^(c-1) counters,
+//   scan      up to 128 KiB) lives in LDS -- a single-pass counting sort with a 15-bit digit
+//   scatter   -> per-bucket lists of (point index | sign)
+//   accumulate one lane per bucket: XYZZ += +-P over its list (madd, 8M+2S), bases gathered through L2/MALL
+//   reduce    sum_b b*B_b by log2(B) halving levels (pair sums + odd-index sums = bit planes of b); depth
+//             c-1 point additions instead of the reference's 2*2^c-long serial chain
+//   finish    the c*W bit-plane sums go to the host, which runs the 255-step double-and-add (host_fp.h)
+//
+// Algorithmic HBM bytes: 96 B/pair (G1, Grumpkin), 160 B/pair (G2): SURVEY.md 8d.
+#include "common.h"
+#include "host_fp.h"
+
+using namespace kg;
+
+namespace {
+
+struct G1Cfg { using F = Fq; using SP = FrParams; using HF = HostFq; static constexpr int E64 = 4; };
+struct GkCfg { using F = Fr; using SP = FqParams; using HF = HostFr; static constexpr int E64 = 4; };
+struct G2Cfg { using F = Fq2; using SP = FrParams; using HF = HostFq2; static constexpr int E64 = 8; };
+
+constexpr uint32_t INF_BIT = 0x80000000u;   // bit 255 of the packed x coordinate marks an identity base
+
+// ---------------------------------------------------------------------------------------------------
+// prep
+// ---------------------------------------------------------------------------------------------------
+// kt: structure-of-arrays, word j of scalar i at kt[j * n + i]
+template <class SP>
+__global__ void __launch_bounds__(256) k_prep_scalars(const uint64_t* __restrict__ scalars, size_t n, Words8 H,
+                                                      uint32_t* __restrict__ kt) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8], k[8];
+  load_words(scalars, i, w);
+  ref_to_int<SP>(w, k);
+  uint64_t cy = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    uint64_t s = (uint64_t)k[j] + H.w[j] + cy;
+    kt[(size_t)j * n + i] = (uint32_t)s;
+    cy = s >> 32;
+  }
+}
+
+template <class P>
+__device__ __forceinline__ void pack_internal(const Fp<P>& a, uint32_t w[8]) { words_from_limbs(reduce_2p(a), w); }
+template <class P>
+__device__ __forceinline__ Fp<P> unpack_internal(const uint32_t w[8]) { return limbs_from_words<P>(w); }
+
+template <class F> struct BaseIO;
+template <class P> struct BaseIO<Fp<P>> {
+  static constexpr int W = 8;   // u32 words per packed base-field element
+  static __device__ __forceinline__ void convert(const uint64_t* src, uint32_t* dst) {   // ABI -> packed internal
+    uint32_t w[8], o[8];
+    load_words(src, 0, w);
+    pack_internal(from_ref<P>(w), o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j] = o[j];
+  }
+  static __device__ __forceinline__ Fp<P> load(const uint32_t* src) {
+    const uint4* p = reinterpret_cast<const uint4*>(src);
+    uint4 a = p[0], b = p[1];
+    uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w & ~INF_BIT};
+    return unpack_internal<P>(w);
+  }
+};
+template <class F> struct BaseIO<Fp2<F>> {
+  static constexpr int W = 16;
+  static __device__ __forceinline__ void convert(const uint64_t* src, uint32_t* dst) {
+    BaseIO<F>::convert(src, dst);
+    BaseIO<F>::convert(src + 4, dst + 8);
+  }
+  static __device__ __forceinline__ Fp2<F> load(const uint32_t* src) { return {BaseIO<F>::load(src), BaseIO<F>::load(src + 8)}; }
+};
+
+// bases: ABI affine (x | y) -> packed internal (x | y), 2*W words per point; identity flag -> INF_BIT of x
+template <class F>
+__global__ void __launch_bounds__(256) k_prep_bases(const uint64_t* __restrict__ bases, const uint8_t* __restrict__ inf, size_t n,
+                                                    uint32_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int W = BaseIO<F>::W;
+  uint32_t buf[2 * W];
+  BaseIO<F>::convert(bases + (size_t)i * W, buf);            // W u32 words == W/2 u64 words per element
+  BaseIO<F>::convert(bases + (size_t)i * W + W / 2, buf + W);
+  if (inf && inf[i]) buf[7] |= INF_BIT;
+  uint4* dst = reinterpret_cast<uint4*>(out + (size_t)i * 2 * W);
+#pragma unroll
+  for (int j = 0; j < 2 * W / 4; ++j) dst[j] = make_uint4(buf[4 * j], buf[4 * j + 1], buf[4 * j + 2], buf[4 * j + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// signed window digit of the biased scalar: returns bucket id + 1 (0 = skip) and the sign
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t window_digit(const uint32_t* __restrict__ kt, size_t n, size_t i, int w, int c, int W, bool& negative) {
+  const int o = w * c;
+  const int j = o >> 5, sh = o & 31;
+  uint64_t v = kt[(size_t)j * n + i];
+  if (j + 1 < 8) v |= (uint64_t)kt[(size_t)(j + 1) * n + i] << 32;
+  uint32_t e = (uint32_t)(v >> sh);
+  if (w == W - 1) {            // top window: unsigned remainder (no bias term was added for it)
+    negative = false;
+    return e & 0x1ffffu;
+  }
+  e &= (1u << c) - 1u;
+  const int32_t d = (int32_t)e - (int32_t)(1u << (c - 1));
+  negative = d < 0;
+  return (uint32_t)(d < 0 ? -d : d);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// counting sort by (window, bucket): histogram of one (chunk, window) in LDS
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_count(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len,
+                                                uint32_t* __restrict__ cnt) {
+  extern __shared__ uint32_t hist[];
+  const int B = 1 << (c - 1);
+  const int ch = blockIdx.x, w = blockIdx.y, nch = gridDim.x;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)ch * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    bool neg;
+    uint32_t m = window_digit(kt, n, i, w, c, W, neg);
+    if (m) atomicAdd(&hist[m - 1], 1u);
+  }
+  __syncthreads();
+  uint32_t* dst = cnt + ((size_t)w * nch + ch) * B;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) dst[b] = hist[b];
+}
+
+// per (window, bucket): exclusive prefix over chunks (in place) and the bucket's total
+__global__ void __launch_bounds__(256) k_scan_chunks(uint32_t* __restrict__ cnt, int W, int nch, int B, uint32_t* __restrict__ bsize) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)W * B) return;
+  const int w = (int)(t / B), b = (int)(t % B);
+  uint32_t run = 0;
+  for (int ch = 0; ch < nch; ++ch) {
+    uint32_t* p = cnt + ((size_t)w * nch + ch) * B + b;
+    uint32_t v = *p;
+    *p = run;
+    run += v;
+  }
+  bsize[t] = run;
+}
+
+// per window: exclusive prefix of bucket sizes -> bucket start inside the window's sorted list
+__global__ void __launch_bounds__(1024) k_scan_buckets(const uint32_t* __restrict__ bsize, int B, uint32_t* __restrict__ bstart) {
+  __shared__ uint32_t part[1024];
+  const int w = blockIdx.x, T = blockDim.x;
+  const int per = (B + T - 1) / T;
+  const int lo = threadIdx.x * per, hi = lo + per < B ? lo + per : B;
+  uint32_t s = 0;
+  for (int b = lo; b < hi; ++b) s += bsize[(size_t)w * B + b];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < T; d <<= 1) {           // Hillis-Steele inclusive scan
+    uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - s;
+  for (int b = lo; b < hi; ++b) {
+    bstart[(size_t)w * B + b] = run;
+    run += bsize[(size_t)w * B + b];
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_scatter(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len,
+                                                  const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bstart,
+                                                  uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t off[];
+  const int B = 1 << (c - 1);
+  const int ch = blockIdx.x, w = blockIdx.y, nch = gridDim.x;
+  const uint32_t* src = cnt + ((size_t)w * nch + ch) * B;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) off[b] = src[b] + bstart[(size_t)w * B + b];
+  __syncthreads();
+  const size_t lo = (size_t)ch * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
+  uint32_t* dst = sorted + (size_t)w * n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    bool neg;
+    uint32_t m = window_digit(kt, n, i, w, c, W, neg);
+    if (m) {
+      uint32_t pos = atomicAdd(&off[m - 1], 1u);
+      dst[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bucket accumulation: one lane per (window, bucket)
+// ---------------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ pbases, const uint32_t* __restrict__ sorted,
+                                                   const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bsize,
+                                                   size_t n, int W, int B, uint32_t* __restrict__ buckets) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)W * B;
+  if (t >= total) return;
+  const size_t w = t / B;
+  const uint32_t* list = sorted + w * n + bstart[t];
+  const uint32_t len = bsize[t];
+  constexpr int PW = 2 * BaseIO<F>::W;
+  XYZZ<F> acc = XYZZ<F>::identity();
+  for (uint32_t j = 0; j < len; ++j) {
+    const uint32_t e = list[j];
+    const uint32_t* src = pbases + (size_t)(e & 0x7fffffffu) * PW;
+    if (src[7] & INF_BIT) continue;                      // identity base (msm.rs:58-64 adds it as a no-op)
+    Affine<F> a{BaseIO<F>::load(src), BaseIO<F>::load(src + BaseIO<F>::W)};
+    if (e & 0x80000000u) a = neg_affine(a);
+    acc = add_mixed(acc, a);
+  }
+  PointIO<F>::store(buckets, total, t, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bucket reduction by halving.  Arrays per window at level s: A (pair sums so far) and T_0..T_{s-1}
+// (odd-index sums), each of length 2*n_out; the level emits A', the halved T's and a new T_s = odd items of A.
+// After log2(B) levels every array has length 1: T_l = sum of buckets whose (index) bit l is set, A = sum of
+// all buckets; sum_b (b+1)*B_b = A + sum_l 2^l T_l.
+// Layout: point (window w, array a, item i) at index (w * narr + a) * len + i of a PointIO buffer.
+// ---------------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(64) k_halve(const uint32_t* __restrict__ in, size_t in_stride, uint32_t* __restrict__ out, size_t out_stride,
+                                              int W, int narr_in, uint32_t n_out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per_w = (size_t)narr_in * n_out;
+  if (t >= per_w * W) return;
+  const int w = (int)(t / per_w);
+  const size_t r = t % per_w;
+  const int a = (int)(r / n_out);
+  const uint32_t i = (uint32_t)(r % n_out);
+  const int narr_out = narr_in + 1;
+  const size_t src = ((size_t)w * narr_in + a) * (2 * (size_t)n_out) + 2 * (size_t)i;
+  XYZZ<F> p0 = PointIO<F>::load(in, in_stride, src);
+  XYZZ<F> p1 = PointIO<F>::load(in, in_stride, src + 1);
+  PointIO<F>::store(out, out_stride, ((size_t)w * narr_out + a) * n_out + i, add_xyzz(p0, p1));
+  if (a == 0) PointIO<F>::store(out, out_stride, ((size_t)w * narr_out + narr_in) * n_out + i, p1);
+}
+
+// raw internal XYZZ -> ABI words (x | y | zz | zzz), array-of-structures for the D2H copy
+template <class P>
+__device__ __forceinline__ void export_el(const Fp<P>& a, uint64_t* dst) {
+  uint32_t w[8];
+  to_ref(a, w);
+  store_words(dst, 0, w);
+}
+template <class F>
+__device__ __forceinline__ void export_el(const Fp2<F>& a, uint64_t* dst) { export_el(a.c0, dst); export_el(a.c1, dst + 4); }
+template <class F, int E64>
+__global__ void __launch_bounds__(64) k_export(const uint32_t* __restrict__ in, size_t stride, size_t count, uint64_t* __restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  XYZZ<F> p = PointIO<F>::load(in, stride, t);
+  uint64_t* dst = out + t * 4 * E64;
+  export_el(p.x, dst);
+  export_el(p.y, dst + E64);
+  export_el(p.zz, dst + 2 * E64);
+  export_el(p.zzz, dst + 3 * E64);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+int pick_window(size_t n, int forced) {
+  if (forced) return forced;
+  int lg = 0;
+  while (((size_t)1 << (lg + 1)) <= n) ++lg;      // floor(log2 n)
+  int c = lg - 4;
+  if (c < 2) c = 2;
+  if (c > 16) c = 16;
+  return c;
+}
+
+template <class HF> struct HostIO;
+template <class P> struct HostIO<HostFp<P>> {
+  static HostFp<P> load(const uint64_t* w) { return HostFp<P>::from_words(w); }
+  static void store(const HostFp<P>& a, uint64_t* w) { a.to_words(w); }
+};
+template <class F> struct HostIO<Fp2<F>> {
+  static Fp2<F> load(const uint64_t* w) { return {HostIO<F>::load(w), HostIO<F>::load(w + 4)}; }
+  static void store(const Fp2<F>& a, uint64_t* w) { HostIO<F>::store(a.c0, w); HostIO<F>::store(a.c1, w + 4); }
+};
+
+template <class Cfg>
+XYZZ<typename Cfg::HF> host_load_point(const uint64_t* p) {
+  using HF = typename Cfg::HF;
+  constexpr int E = Cfg::E64;
+  return {HostIO<HF>::load(p), HostIO<HF>::load(p + E), HostIO<HF>::load(p + 2 * E), HostIO<HF>::load(p + 3 * E)};
+}
+
+template <class Cfg>
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Device pipeline; leaves W*c exported XYZZ points in ctx->h_pinned and returns the host-side partial sum.
+template <class Cfg>
+int msm_device(kg_ctx* ctx, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,
+               XYZZ<typename Cfg::HF>& result) {
+  using F = typename Cfg::F;
+  using HF = typename Cfg::HF;
+  result = XYZZ<HF>::identity();
+  if (n == 0) return KG_OK;
+  if (n >= ((size_t)1 << 31)) return set_err(ctx, KG_ERR_BAD_ARG, "msm length above 2^31 - 1");
+  KG_HIP(ctx, hipSetDevice(ctx->device));
+  prof_reset(ctx);
+
+  const int c = pick_window(n, ctx->msm_window);
+  const int W = (255 + c - 1) / c;
+  const int B = 1 << (c - 1);
+  int nch = (int)((n + 16383) / 16384);
+  if (nch > 16) nch = 16;
+  if (nch < 1) nch = 1;
+  const size_t chunk_len = (n + nch - 1) / nch;
+  constexpr int PW = 2 * BaseIO<F>::W;              // packed words per base
+  constexpr int NW = PointIO<F>::NW;                // raw words per XYZZ point
+
+  // work space carve-up
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_kt = carve(n * 32);
+  const size_t o_pb = carve(n * PW * 4);
+  const size_t o_cnt = carve((size_t)W * nch * B * 4);
+  const size_t o_bsize = carve((size_t)W * B * 4);
+  const size_t o_bstart = carve((size_t)W * B * 4);
+  const size_t o_sorted = carve((size_t)W * n * 4);
+  const size_t npts = (size_t)W * B;
+  const size_t o_p0 = carve(npts * NW * 4);
+  const size_t o_p1 = carve(npts * NW * 4);
+  const size_t nexp = (size_t)W * c;
+  const size_t o_exp = carve(nexp * 4 * Cfg::E64 * 8);
+  KG_TRY(ensure_ws(ctx, off));
+  KG_TRY(ensure_pinned(ctx, nexp * 4 * Cfg::E64 * 8));
+  char* ws = (char*)ctx->ws;
+  uint32_t* kt = (uint32_t*)(ws + o_kt);
+  uint32_t* pb = (uint32_t*)(ws + o_pb);
+  uint32_t* cnt = (uint32_t*)(ws + o_cnt);
+  uint32_t* bsize = (uint32_t*)(ws + o_bsize);
+  uint32_t* bstart = (uint32_t*)(ws + o_bstart);
+  uint32_t* sorted = (uint32_t*)(ws + o_sorted);
+  uint32_t* pbuf[2] = {(uint32_t*)(ws + o_p0), (uint32_t*)(ws + o_p1)};
+  uint64_t* d_exp = (uint64_t*)(ws + o_exp);
+  hipStream_t st = ctx->stream;
+
+  // bias H = sum_{w < W-1} 2^(w*c + c - 1)
+  Words8 H;
+  for (int j = 0; j < 8; ++j) H.w[j] = 0;
+  for (int w = 0; w < W - 1; ++w) {
+    int bit = w * c + c - 1;
+    H.w[bit >> 5] |= 1u << (bit & 31);
+  }
+
+  {
+    PhaseScope ph(ctx, "prep");
+    hipLaunchKernelGGL(k_prep_scalars<typename Cfg::SP>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
+    hipLaunchKernelGGL(k_prep_bases<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_bases, d_inf, n, pb);
+    ph.end();
+  }
+  {
+    PhaseScope ph(ctx, "sort");
+    const size_t lds = (size_t)B * 4;
+    if (lds > 48 * 1024) {      // the whole-window histogram needs more than the default dynamic LDS limit
+      KG_HIP(ctx, hipFuncSetAttribute((const void*)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      KG_HIP(ctx, hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(k_count, dim3(nch, W), dim3(1024), lds, st, kt, n, c, W, chunk_len, cnt);
+    hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, cnt, W, nch, B, bsize);
+    hipLaunchKernelGGL(k_scan_buckets, dim3(W), dim3(1024), 0, st, bsize, B, bstart);
+    hipLaunchKernelGGL(k_scatter, dim3(nch, W), dim3(1024), lds, st, kt, n, c, W, chunk_len, cnt, bstart, sorted);
+    ph.end();
+  }
+  {
+    PhaseScope ph(ctx, "accumulate");
+    hipLaunchKernelGGL(k_accumulate<F>, dim3((unsigned)((npts + 63) / 64)), dim3(64), 0, st, pb, sorted, bstart, bsize, n, W, B, pbuf[0]);
+    ph.end();
+  }
+  int cur = 0;
+  {
+    PhaseScope ph(ctx, "reduce");
+    size_t in_stride = npts;                     // level 0 reads the bucket array: stride = W*B items
+    int narr = 1;
+    for (uint32_t n_out = (uint32_t)B / 2; n_out >= 1; n_out /= 2) {
+      const size_t tasks = (size_t)W * narr * n_out;
+      const size_t out_stride = (size_t)W * (narr + 1) * n_out;
+      hipLaunchKernelGGL(k_halve<F>, dim3((unsigned)((tasks + 63) / 64)), dim3(64), 0, st, pbuf[cur], in_stride, pbuf[cur ^ 1], out_stride,
+                         W, narr, n_out);
+      cur ^= 1;
+      in_stride = out_stride;
+      ++narr;
+      if (n_out == 1) break;
+    }
+    // now: W windows x narr (= c) single points, stride W*c
+    hipLaunchKernelGGL((k_export<F, Cfg::E64>), dim3((unsigned)((nexp + 63) / 64)), dim3(64), 0, st, pbuf[cur], nexp, nexp, d_exp);
+    ph.end();
+  }
+  KG_HIP(ctx, hipGetLastError());
+  KG_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, d_exp, nexp * 4 * Cfg::E64 * 8, hipMemcpyDeviceToHost, st));
+  KG_HIP(ctx, hipStreamSynchronize(st));
+
+  // host finish: window w contributes 2^(w*c) * (A_w + sum_l 2^l T_{w,l}); array 0 = A, array 1 + l = T_l.
+  // (B == 1, c == 1: no halving ran; the single "array" is the bucket itself.)
+  const uint64_t* hp = (const uint64_t*)ctx->h_pinned;
+  constexpr int PE = 4 * Cfg::E64;
+  XYZZ<HF> acc = XYZZ<HF>::identity();
+  const int nbits = (W - 1) * c + c;             // highest bit position + 1
+  for (int bit = nbits - 1; bit >= 0; --bit) {
+    acc = double_xyzz(acc);
+    const int w = bit / c, l = bit % c;
+    if (l < c - 1 || c == 1) {
+      // T_l exists for l = 0..c-2 (array 1 + l); for c == 1 there are no T arrays
+      if (c > 1) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c + 1 + l) * PE));
+    }
+    if (l == 0) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c) * PE));
+  }
+  result = acc;
+  return KG_OK;
+}
+
+template <class Cfg>
+void store_projective(const XYZZ<typename Cfg::HF>& p, uint64_t* out_xyz) {
+  using HF = typename Cfg::HF;
+  constexpr int E = Cfg::E64;
+  Affine<HF> a;
+  if (!to_affine(p, a)) {                        // (0, 1, 0): macros/curve/weierstrass/group.rs:106-110
+    HostIO<HF>::store(HF::zero(), out_xyz);
+    HostIO<HF>::store(HF::one(), out_xyz + E);
+    HostIO<HF>::store(HF::zero(), out_xyz + 2 * E);
+    return;
+  }
+  HostIO<HF>::store(a.x, out_xyz);
+  HostIO<HF>::store(a.y, out_xyz + E);
+  HostIO<HF>::store(HF::one(), out_xyz + 2 * E);
+}
+
+template <class Cfg>
+int msm_impl(kg_ctx* ctx, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
+  XYZZ<typename Cfg::HF> r;
+  KG_TRY(msm_device<Cfg>(ctx, d_bases, d_inf, d_scalars, n, r));
+  store_projective<Cfg>(r, out_xyz);
+  return KG_OK;
+}
+
+template <class Cfg>
+int sum_affine_impl(const uint64_t* pts, const uint8_t* inf, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
+  using HF = typename Cfg::HF;
+  constexpr int E = Cfg::E64;
+  XYZZ<HF> acc = XYZZ<HF>::identity();
+  for (size_t i = 0; i < count; ++i) {
+    if (inf && inf[i]) continue;
+    Affine<HF> a{HostIO<HF>::load(pts + i * 2 * E), HostIO<HF>::load(pts + i * 2 * E + E)};
+    acc = add_mixed(acc, a);
+  }
+  uint64_t xyz[3 * 8];
+  store_projective<Cfg>(acc, xyz);
+  std::memcpy(out_xy, xyz, 2 * E * 8);
+  *out_inf = is_identity(acc) ? 1 : 0;
+  return KG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
+  if (!ctx || !out_xyz || (n && (!d_bases || !d_scalars))) return KG_ERR_BAD_ARG;
+  switch (curve) {
+    case KG_G1: return msm_impl<G1Cfg>(ctx, d_bases, d_inf, d_scalars, n, out_xyz);
+    case KG_GRUMPKIN: return msm_impl<GkCfg>(ctx, d_bases, d_inf, d_scalars, n, out_xyz);
+    case KG_G2: return msm_impl<G2Cfg>(ctx, d_bases, d_inf, d_scalars, n, out_xyz);
+    default: return KG_ERR_BAD_ARG;
+  }
+}
+
+int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars, size_t n, uint64_t* out_xyz) {
+  if (!ctx || !out_xyz || (n && (!h_bases || !h_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
+  if (n == 0) return kg_msm(ctx, curve, nullptr, nullptr, nullptr, 0, out_xyz);
+  const size_t bb = n * (curve == KG_G2 ? 128 : 64);
+  void *db = nullptr, *ds = nullptr, *di = nullptr;
+  int rc = kg_malloc(ctx, bb, &db);
+  if (rc == KG_OK) rc = kg_malloc(ctx, n * 32, &ds);
+  if (rc == KG_OK && h_inf) rc = kg_malloc(ctx, n, &di);
+  if (rc == KG_OK) rc = kg_memcpy_h2d(ctx, db, h_bases, bb);
+  if (rc == KG_OK) rc = kg_memcpy_h2d(ctx, ds, h_scalars, n * 32);
+  if (rc == KG_OK && h_inf) rc = kg_memcpy_h2d(ctx, di, h_inf, n);
+  if (rc == KG_OK) rc = kg_msm(ctx, curve, (const uint64_t*)db, (const uint8_t*)di, (const uint64_t*)ds, n, out_xyz);
+  if (db) hipFree(db);
+  if (ds) hipFree(ds);
+  if (di) hipFree(di);
+  return rc;
+}
+
+int kg_commit(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,
+              uint64_t* out_xy, uint8_t* out_inf) {
+  if (!ctx || !out_xy || !out_inf || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
+  uint64_t xyz[24];
+  KG_TRY(kg_msm(ctx, curve, d_bases, d_inf, d_scalars, n, xyz));
+  const int E = curve == KG_G2 ? 8 : 4;
+  std::memcpy(out_xy, xyz, 2 * E * 8);
+  bool z0 = true;
+  for (int i = 0; i < E; ++i) z0 = z0 && xyz[2 * E + i] == 0;
+  *out_inf = z0 ? 1 : 0;
+  return KG_OK;
+}
+
+int kg_points_sum_affine(kg_ctx* ctx, int curve, const uint64_t* pts, const uint8_t* inf, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
+  (void)ctx;
+  if (!out_xy || !out_inf || (count && !pts)) return KG_ERR_BAD_ARG;
+  switch (curve) {
+    case KG_G1: return sum_affine_impl<G1Cfg>(pts, inf, count, out_xy, out_inf);
+    case KG_GRUMPKIN: return sum_affine_impl<GkCfg>(pts, inf, count, out_xy, out_inf);
+    case KG_G2: return sum_affine_impl<G2Cfg>(pts, inf, count, out_xy, out_inf);
+    default: return KG_ERR_BAD_ARG;
+  }
+}
+
+}  // extern "C"

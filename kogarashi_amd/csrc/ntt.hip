@@ -1,0 +1,354 @@
+// ntt.hip -- radix-2 Fr NTT on gfx950, natural order in and out.
+//
+// Replaces groth16/src/fft.rs: Fft::new (:27-89: the reference re-materialises n/2 + n/2 + n + n table
+// entries per proof), prepare_fft (:157-162, bit-reversal swaps), classic_fft_arithmetic (:166-192, recursive
+// DIT) and butterfly_arithmetic (:195-218).  dft(v)[i] = sum_j v[j] w^(ij) with w = ROOT_OF_UNITY^(2^(28-k)).
+//
+// Decomposition n = n1*n2*n3 (each factor <= 2^8..2^10; Cooley-Tukey index map j = j1*n2*n3 + j2*n3 + j3,
+// i = i1 + n1*i2 + n1*n2*i3), so no separate bit-reversal pass exists and every step is one HBM round trip:
+//   step A  n1-point DFTs down columns (stride n2*n3), 8 adjacent columns per workgroup, then * w_n^(i1*c)
+//   step B  n2-point DFTs at stride n3 inside each i1 slab, in place, then * w_n^(n1*i2*j3)
+//   step C  n3-point DFTs along contiguous rows, written transposed (8 adjacent i1 = 256 B per row of the output)
+// A tile (<= 2048 elements = 72 KiB of 29-bit limbs, structure-of-arrays) lives in LDS for all log2(m) butterfly
+// stages; two workgroups share a CU's 160 KiB.  Data never leaves the caller's Montgomery domain: the
+// transform is linear and twiddles are multiplied in as internal-form constants (fp29.h), so there is no
+// domain conversion, only a limb re-packing at load/store.
+// Algorithmic HBM bytes: 64 B/element; this design moves 64 B/element per step.
+#include "common.h"
+
+using namespace kg;
+
+struct kg_tw_cache {
+  uint32_t log_n;
+  int inverse;
+  uint32_t lo_bits;
+  uint32_t* small = nullptr;   // w_1024^e, e < 512          [e][9]
+  uint32_t* lo = nullptr;      // w_n^e, e < 2^lo_bits        [e][9]
+  uint32_t* hi = nullptr;      // w_n^(e << lo_bits)          [e][9]
+  uint32_t* cos_lo = nullptr;  // g^(+-e) (g = 7), e < 2^lo_bits, for the coset shift [* n^-1 when inverse]
+  uint32_t* cos_hi = nullptr;  // g^(+-(e << lo_bits))
+  uint32_t* zinv = nullptr;    // (7^n - 1)^-1, one entry (fft.rs:141-154)
+};
+
+namespace {
+
+constexpr int TILE = 2048;            // elements per workgroup tile
+constexpr int NT = 256;               // threads per workgroup
+constexpr int SMALL_LOG = 10;         // largest in-LDS DFT: 2^10
+
+__device__ __forceinline__ Fr ld_tw(const uint32_t* __restrict__ tab, size_t e) {
+  Fr r;
+  const uint32_t* p = tab + e * 9;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r.l[k] = p[k];
+  return r;
+}
+__device__ __forceinline__ void st_tw(uint32_t* tab, size_t e, const Fr& a) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) tab[e * 9 + k] = a.l[k];
+}
+
+// base = ROOT_OF_UNITY^(+-1) squared (28 - log) times  => primitive 2^log-th root (fft.rs:34,44)
+__device__ Fr root_of(uint32_t log, int inverse) {
+  Fr g = Fr::from_const(inverse ? FrParams::ROOT_OF_UNITY_INV : FrParams::ROOT_OF_UNITY);
+  for (uint32_t i = log; i < 28; ++i) g = sqr(g);
+  return g;
+}
+__device__ Fr pow_u64(Fr base, uint64_t e) {
+  Fr r = Fr::one();
+  while (e) {
+    if (e & 1) r = mul(r, base);
+    base = sqr(base);
+    e >>= 1;
+  }
+  return r;
+}
+
+// kind 0: small (root of order 2^10, e < 512); 1: lo; 2: hi; 3: coset lo; 4: coset hi
+__global__ void __launch_bounds__(64) k_build_table(int kind, uint32_t log_n, int inverse, uint32_t lo_bits, uint32_t count, uint32_t* __restrict__ tab) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  Fr v;
+  if (kind == 0) v = pow_u64(root_of(SMALL_LOG, inverse), e);
+  else if (kind == 1) v = pow_u64(root_of(log_n, inverse), e);
+  else if (kind == 2) v = pow_u64(root_of(log_n, inverse), (uint64_t)e << lo_bits);
+  else {
+    Fr g = Fr::from_const(inverse ? FrParams::GEN7_INV : FrParams::GEN7);   // fft.rs:56,64
+    v = pow_u64(g, kind == 3 ? (uint64_t)e : ((uint64_t)e << lo_bits));
+    if (kind == 3 && inverse) {            // fold n^-1 (fft.rs:86,104) into the low table (always multiplied in)
+      uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      w[0] = log_n < 32 ? (1u << log_n) : 0;
+      Fr nn = from_int<FrParams>(w);
+      v = mul(v, inv(nn));
+    }
+  }
+  st_tw(tab, e, v);
+}
+
+struct StepArgs {
+  const uint64_t* in;
+  uint64_t* out;
+  uint32_t log_m;        // DFT size of this step
+  uint32_t log_tc;       // tile columns
+  uint64_t inner;        // col flavour: contiguous run length (elements)
+  uint64_t mult;         // col flavour: twiddle exponent multiplier; 0 = no twiddle
+  uint64_t n1;           // row flavour: i1 extent;  n2 = G / n1
+  uint64_t G;            // number of independent DFTs (= n / m)
+  uint32_t lo_bits;
+  const uint32_t* tw_small;
+  const uint32_t* tw_lo;
+  const uint32_t* tw_hi;
+  uint64_t scale_mode;   // 0 none; 1: multiply input element j by cos table at exponent j (coset dft, fft.rs:109-116)
+                         // 2: multiply output element i by cos table at exponent i (coset idft / n^-1, fft.rs:104,119-127)
+  const uint32_t* cos_lo;
+  const uint32_t* cos_hi;
+};
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t bits) { return __brev(v) >> (32 - bits); }
+
+__device__ __forceinline__ Fr two_level(const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi, uint32_t lo_bits, uint64_t e) {
+  const uint64_t el = e & ((1ull << lo_bits) - 1), eh = e >> lo_bits;
+  Fr a = ld_tw(lo, el);
+  if (eh == 0) return a;
+  return mul(a, ld_tw(hi, eh));
+}
+
+// LDS tile, structure-of-arrays: limb k of tile element e at lds[k * TILE + e]
+template <bool ROW>
+__device__ __forceinline__ uint32_t tile_index(uint32_t r, uint32_t col, uint32_t log_m, uint32_t log_tc) {
+  // col flavour: columns fastest (global loads run along columns); row flavour: rows fastest, odd pitch
+  if (ROW) return col * ((1u << log_m) + 1u) + r;
+  return (r << log_tc) + col;
+}
+constexpr int LDS_WORDS = 9 * (TILE + 8);
+
+__device__ __forceinline__ Fr lds_load(const uint32_t* lds, uint32_t e) {
+  Fr r;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r.l[k] = lds[k * (TILE + 8) + e];
+  return r;
+}
+__device__ __forceinline__ void lds_store(uint32_t* lds, uint32_t e, const Fr& a) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) lds[k * (TILE + 8) + e] = a.l[k];
+}
+
+template <bool ROW>
+__global__ void __launch_bounds__(NT, 2) k_ntt_step(StepArgs A) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t m = 1u << A.log_m, tc = 1u << A.log_tc;
+  const uint64_t g0 = (uint64_t)blockIdx.x << A.log_tc;
+  const uint32_t tile_elems = m << A.log_tc;
+
+  // ---- load (limb re-packing only), bit-reversed row placement for the DIT stages -------------------
+  for (uint32_t idx = threadIdx.x; idx < tile_elems; idx += NT) {
+    uint32_t r, col;
+    uint64_t addr;
+    if (ROW) {
+      r = idx & (m - 1); col = idx >> A.log_m;
+      const uint64_t g = g0 + col, i1 = g % A.n1, i2 = g / A.n1, n2 = A.G / A.n1;
+      addr = ((i1 * n2 + i2) << A.log_m) + r;
+    } else {
+      col = idx & (tc - 1); r = idx >> A.log_tc;
+      const uint64_t g = g0 + col;
+      addr = (g / A.inner) * ((uint64_t)m * A.inner) + (uint64_t)r * A.inner + (g % A.inner);
+    }
+    uint32_t w[8];
+    load_words(A.in, addr, w);
+    Fr v = limbs_from_words<FrParams>(w);
+    if (A.scale_mode == 1) v = mul(v, two_level(A.cos_lo, A.cos_hi, A.lo_bits, addr));
+    lds_store(lds, tile_index<ROW>(bitrev(r, A.log_m), col, A.log_m, A.log_tc), v);
+  }
+  __syncthreads();
+
+  // ---- log2(m) radix-2 DIT stages in LDS (butterfly_arithmetic, fft.rs:195-218) -----------------------
+  const uint32_t nbf = tile_elems >> 1;
+  for (uint32_t s = 1; s <= A.log_m; ++s) {
+    const uint32_t half = 1u << (s - 1);
+    for (uint32_t bt = threadIdx.x; bt < nbf; bt += NT) {
+      uint32_t col, pidx;
+      if (ROW) { pidx = bt & ((m >> 1) - 1); col = bt >> (A.log_m - 1); }
+      else { col = bt & (tc - 1); pidx = bt >> A.log_tc; }
+      const uint32_t j = pidx & (half - 1);
+      const uint32_t r0 = ((pidx >> (s - 1)) << s) + j, r1 = r0 + half;
+      const uint32_t e0 = tile_index<ROW>(r0, col, A.log_m, A.log_tc), e1 = tile_index<ROW>(r1, col, A.log_m, A.log_tc);
+      Fr a = lds_load(lds, e0), b = lds_load(lds, e1);
+      Fr t = mul(b, ld_tw(A.tw_small, (size_t)j << (SMALL_LOG - s)));     // w_{2^s}^j = w_1024^(j * 2^(10-s))
+      lds_store(lds, e0, norm(add(a, t)));
+      lds_store(lds, e1, norm(sub<4, 1>(a, t)));
+    }
+    __syncthreads();
+  }
+
+  // ---- store: inter-step twiddle (or a plain value reduction), canonicalise, re-pack ------------------
+  for (uint32_t idx = threadIdx.x; idx < tile_elems; idx += NT) {
+    uint32_t r, col;
+    uint64_t addr;
+    Fr v;
+    if (ROW) {
+      col = idx & (tc - 1); r = idx >> A.log_tc;           // adjacent lanes -> adjacent i1 -> contiguous output
+      addr = (g0 + col) + A.G * (uint64_t)r;
+      v = lds_load(lds, tile_index<ROW>(r, col, A.log_m, A.log_tc));
+      if (A.scale_mode == 2) v = mul(v, two_level(A.cos_lo, A.cos_hi, A.lo_bits, addr));
+      else v = vred(v);
+    } else {
+      col = idx & (tc - 1); r = idx >> A.log_tc;
+      const uint64_t g = g0 + col;
+      addr = (g / A.inner) * ((uint64_t)m * A.inner) + (uint64_t)r * A.inner + (g % A.inner);
+      v = lds_load(lds, tile_index<ROW>(r, col, A.log_m, A.log_tc));
+      if (A.mult) v = mul(v, two_level(A.tw_lo, A.tw_hi, A.lo_bits, (uint64_t)r * (g % A.inner) * A.mult));
+      else v = vred(v);
+    }
+    uint32_t w[8];
+    words_from_limbs(reduce_2p(v), w);
+    store_words(A.out, addr, w);
+  }
+}
+
+// data[i] *= c   (c: one internal-form constant in device memory)
+__global__ void __launch_bounds__(256) k_scale_const(uint64_t* __restrict__ data, size_t n, const uint32_t* __restrict__ c) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words(data, i, w);
+  Fr v = mul(limbs_from_words<FrParams>(w), ld_tw(c, 0));
+  words_from_limbs(reduce_2p(v), w);
+  store_words(data, i, w);
+}
+// (7^n - 1)^-1 for n = 2^log_n
+__global__ void k_build_zinv(uint32_t log_n, uint32_t* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Fr g = Fr::from_const(FrParams::GEN7);
+  for (uint32_t i = 0; i < log_n; ++i) g = sqr(g);
+  st_tw(out, 0, inv(norm(sub<4, 1>(g, Fr::one()))));
+}
+
+int get_tables(kg_ctx* ctx, uint32_t log_n, int inverse, kg_tw_cache** out) {
+  for (kg_tw_cache* t : ctx->tw)
+    if (t->log_n == log_n && t->inverse == inverse) { *out = t; return KG_OK; }
+  kg_tw_cache* t = new kg_tw_cache();
+  t->log_n = log_n; t->inverse = inverse;
+  t->lo_bits = (log_n + 1) / 2;
+  const uint32_t n_lo = 1u << t->lo_bits, n_hi = 1u << (log_n - t->lo_bits);
+  auto alloc = [&](uint32_t** p, size_t entries) { return hipMalloc((void**)p, entries * 36); };
+  if (alloc(&t->small, 512) != hipSuccess || alloc(&t->lo, n_lo) != hipSuccess || alloc(&t->hi, n_hi) != hipSuccess ||
+      alloc(&t->cos_lo, n_lo) != hipSuccess || alloc(&t->cos_hi, n_hi) != hipSuccess || alloc(&t->zinv, 1) != hipSuccess) {
+    delete t;
+    return set_err(ctx, KG_ERR_OOM, "twiddle table allocation");
+  }
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(k_build_table, dim3(8), dim3(64), 0, st, 0, log_n, inverse, t->lo_bits, 512u, t->small);
+  hipLaunchKernelGGL(k_build_table, dim3((n_lo + 63) / 64), dim3(64), 0, st, 1, log_n, inverse, t->lo_bits, n_lo, t->lo);
+  hipLaunchKernelGGL(k_build_table, dim3((n_hi + 63) / 64), dim3(64), 0, st, 2, log_n, inverse, t->lo_bits, n_hi, t->hi);
+  hipLaunchKernelGGL(k_build_table, dim3((n_lo + 63) / 64), dim3(64), 0, st, 3, log_n, inverse, t->lo_bits, n_lo, t->cos_lo);
+  hipLaunchKernelGGL(k_build_table, dim3((n_hi + 63) / 64), dim3(64), 0, st, 4, log_n, inverse, t->lo_bits, n_hi, t->cos_hi);
+  hipLaunchKernelGGL(k_build_zinv, dim3(1), dim3(64), 0, st, log_n, t->zinv);
+  KG_HIP(ctx, hipGetLastError());
+  ctx->tw.push_back(t);
+  *out = t;
+  return KG_OK;
+}
+
+}  // namespace
+
+namespace kg {
+void tw_cache_free(kg_ctx* c) {
+  for (kg_tw_cache* t : c->tw) {
+    hipFree(t->small); hipFree(t->lo); hipFree(t->hi); hipFree(t->cos_lo); hipFree(t->cos_hi); hipFree(t->zinv);
+    delete t;
+  }
+  c->tw.clear();
+}
+}  // namespace kg
+
+extern "C" {
+
+int kg_ntt_bn254_fr(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n, int inverse, int coset) {
+  if (!ctx || !d_data || log_n < 1 || log_n > 28) return KG_ERR_BAD_ARG;
+  KG_HIP(ctx, hipSetDevice(ctx->device));
+  prof_reset(ctx);
+  inverse = inverse ? 1 : 0;
+  kg_tw_cache* T;
+  KG_TRY(get_tables(ctx, log_n, inverse, &T));
+  const uint64_t n = 1ull << log_n;
+  hipStream_t st = ctx->stream;
+  const size_t lds_bytes = (size_t)LDS_WORDS * 4;
+  KG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  KG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+
+  // factor log_n into at most three steps of <= 8 bits (<= 10 for log_n > 24)
+  uint32_t k1 = 0, k2 = 0, k3 = 0;
+  const uint32_t cap = log_n > 24 ? SMALL_LOG : 8;
+  if (log_n <= cap) k3 = log_n;
+  else if (log_n <= 2 * cap) { k1 = (log_n + 1) / 2; k3 = log_n - k1; }
+  else { k1 = (log_n + 2) / 3; k2 = (log_n - k1 + 1) / 2; k3 = log_n - k1 - k2; }
+  const uint64_t n1 = 1ull << k1, n2 = 1ull << k2, n3 = 1ull << k3;
+
+  StepArgs base{};
+  base.lo_bits = T->lo_bits; base.tw_small = T->small; base.tw_lo = T->lo; base.tw_hi = T->hi;
+  base.cos_lo = T->cos_lo; base.cos_hi = T->cos_hi;
+  auto tile_cols = [&](uint32_t log_m, uint64_t limit) {
+    uint32_t l = 11 - log_m;                 // TILE = 2^11 elements
+    if (l > 3) l = 3;
+    while ((1ull << l) > limit) --l;
+    return l;
+  };
+  const bool pre_scale = coset && !inverse;          // coset_dft: * 7^j before the transform
+  const bool post_scale = inverse != 0;              // idft: * n^-1 ; coset_idft: * n^-1 * 7^-i
+  // plain idft (no coset) scales by the constant n^-1 in a separate pass below.
+
+  uint64_t* tmp = nullptr;
+  if (k1) {
+    KG_TRY(ensure_ws2(ctx, n * 32));
+    tmp = (uint64_t*)ctx->ws2;
+  }
+  PhaseScope ph(ctx, "ntt");
+  if (k1) {
+    // step A: data -> tmp
+    StepArgs a = base;
+    a.in = d_data; a.out = tmp; a.log_m = k1; a.inner = n >> k1; a.mult = 1; a.G = n >> k1; a.n1 = 1;
+    a.log_tc = tile_cols(k1, a.inner);
+    a.scale_mode = pre_scale ? 1 : 0;
+    hipLaunchKernelGGL(k_ntt_step<false>, dim3((unsigned)(a.G >> a.log_tc)), dim3(NT), lds_bytes, st, a);
+    if (k2) {
+      // step B: tmp in place
+      StepArgs b = base;
+      b.in = tmp; b.out = tmp; b.log_m = k2; b.inner = n3; b.mult = n1; b.G = n >> k2; b.n1 = 1;
+      b.log_tc = tile_cols(k2, b.inner);
+      hipLaunchKernelGGL(k_ntt_step<false>, dim3((unsigned)(b.G >> b.log_tc)), dim3(NT), lds_bytes, st, b);
+    }
+    // step C: tmp -> data (transposed write)
+    StepArgs c = base;
+    c.in = tmp; c.out = d_data; c.log_m = k3; c.G = n >> k3; c.n1 = n1;
+    c.log_tc = tile_cols(k3, n1);
+    c.scale_mode = (post_scale && coset) ? 2 : 0;
+    hipLaunchKernelGGL(k_ntt_step<true>, dim3((unsigned)(c.G >> c.log_tc)), dim3(NT), lds_bytes, st, c);
+  } else {
+    StepArgs c = base;
+    c.in = d_data; c.out = d_data; c.log_m = k3; c.G = 1; c.n1 = 1; c.log_tc = 0;
+    c.scale_mode = pre_scale ? 1 : ((post_scale && coset) ? 2 : 0);
+    hipLaunchKernelGGL(k_ntt_step<true>, dim3(1), dim3(NT), lds_bytes, st, c);
+  }
+  ph.end();
+  KG_HIP(ctx, hipGetLastError());
+  if (post_scale && !coset) {
+    // plain idft: * n^-1 (fft.rs:104); cos_lo[0] of the inverse tables is 7^0 * n^-1
+    hipLaunchKernelGGL(k_scale_const, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_data, (size_t)n, T->cos_lo);
+    KG_HIP(ctx, hipGetLastError());
+  }
+  return KG_OK;
+}
+
+int kg_fr_divide_by_z_on_coset(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n) {
+  // fft.rs:150-154: every evaluation * (7^n - 1)^-1
+  if (!ctx || !d_data || log_n < 1 || log_n > 28) return KG_ERR_BAD_ARG;
+  KG_HIP(ctx, hipSetDevice(ctx->device));
+  kg_tw_cache* T;
+  KG_TRY(get_tables(ctx, log_n, 0, &T));
+  const size_t n = (size_t)1 << log_n;
+  hipLaunchKernelGGL(k_scale_const, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_data, n, T->zinv);
+  KG_HIP(ctx, hipGetLastError());
+  return KG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+"""ctypes binding of libkogarashi_amd.so (the C ABI in include/kogarashi_amd.h).
+
+There is deliberately NO fallback: if the HIP library is missing or no gfx950 device is visible, every entry
+point raises.  Device memory is handled through the ABI's own kg_malloc / kg_memcpy_* (or through torch
+tensors' data_ptr() in bench.py); numpy arrays cross the boundary as host pointers."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libkogarashi_amd.so")
+
+KG_FR, KG_FQ = 0, 1
+KG_G1, KG_GRUMPKIN, KG_G2 = 0, 1, 2
+OPS = {"add": 0, "sub": 1, "mul": 2, "square": 3, "neg": 4, "double": 5, "invert": 6, "from_mont": 7, "to_mont": 8}
+EXPORTS = [
+    "kg_version", "kg_device_count", "kg_strerror", "kg_ctx_create", "kg_ctx_destroy", "kg_last_error", "kg_ctx_set_stream",
+    "kg_ctx_sync", "kg_malloc", "kg_free", "kg_memcpy_h2d", "kg_memcpy_d2h", "kg_memcpy_d2d", "kg_field_vec_op",
+    "kg_field_vec_scale", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_msm", "kg_msm_host", "kg_commit",
+    "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
+]
+
+
+class KogarashiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads the shared library; raises if it has not been built (python -m kogarashi_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise KogarashiError(f"{SO_PATH} is missing: build it with `python -m kogarashi_amd.build` (hipcc, gfx950)")
+        _lib = C.CDLL(SO_PATH)
+        _lib.kg_strerror.restype = C.c_char_p
+        _lib.kg_last_error.restype = C.c_char_p
+        _lib.kg_last_error.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _vp(x):
+    return C.c_void_p(int(x) if x else 0)
+
+
+class Context:
+    """One kg_ctx: a GPU, a stream, cached twiddles and MSM work space."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.kg_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise KogarashiError(f"kg_ctx_create(device={device}) failed: {self._lib.kg_strerror(rc).decode()} "
+                                 "(the HIP extension needs a visible MI355X; there is no CPU path)")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.kg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise KogarashiError(f"{what}: {self._lib.kg_strerror(rc).decode()} [{self._lib.kg_last_error(self._h).decode()}]")
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def set_stream(self, hip_stream_ptr: int):
+        self._chk(self._lib.kg_ctx_set_stream(self._h, _vp(hip_stream_ptr)), "kg_ctx_set_stream")
+
+    def sync(self):
+        self._chk(self._lib.kg_ctx_sync(self._h), "kg_ctx_sync")
+
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._chk(self._lib.kg_malloc(self._h, C.c_size_t(nbytes), C.byref(p)), "kg_malloc")
+        return p.value
+
+    def free(self, dptr: int):
+        self._chk(self._lib.kg_free(self._h, _vp(dptr)), "kg_free")
+
+    def upload(self, arr: np.ndarray) -> "DeviceArray":
+        arr = np.ascontiguousarray(arr)
+        d = DeviceArray(self, arr.nbytes, arr.shape, arr.dtype)
+        if arr.nbytes:
+            self._chk(self._lib.kg_memcpy_h2d(self._h, _vp(d.ptr), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)), "kg_memcpy_h2d")
+        return d
+
+    def empty(self, shape, dtype=np.uint64) -> "DeviceArray":
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return DeviceArray(self, nbytes, tuple(shape), np.dtype(dtype))
+
+    def download(self, d: "DeviceArray") -> np.ndarray:
+        out = np.empty(d.shape, dtype=d.dtype)
+        if out.nbytes:
+            self._chk(self._lib.kg_memcpy_d2h(self._h, out.ctypes.data_as(C.c_void_p), _vp(d.ptr), C.c_size_t(out.nbytes)), "kg_memcpy_d2h")
+        return out
+
+    # ---- raw entry points (device pointers as ints) ------------------------------------------------
+    def field_vec_op(self, field: int, op: str, a: int, b: int, out: int, n: int):
+        self._chk(self._lib.kg_field_vec_op(self._h, field, OPS[op], _vp(a), _vp(b), _vp(out), C.c_size_t(n)), "kg_field_vec_op")
+
+    def field_vec_scale(self, field: int, a: int, s: np.ndarray, out: int, n: int):
+        s = np.ascontiguousarray(s, dtype=np.uint64)
+        self._chk(self._lib.kg_field_vec_scale(self._h, field, _vp(a), s.ctypes.data_as(C.c_void_p), _vp(out), C.c_size_t(n)), "kg_field_vec_scale")
+
+    def ntt(self, data: int, log_n: int, inverse: bool, coset: bool):
+        self._chk(self._lib.kg_ntt_bn254_fr(self._h, _vp(data), C.c_uint32(log_n), int(bool(inverse)), int(bool(coset))), "kg_ntt_bn254_fr")
+
+    def divide_by_z_on_coset(self, data: int, log_n: int):
+        self._chk(self._lib.kg_fr_divide_by_z_on_coset(self._h, _vp(data), C.c_uint32(log_n)), "kg_fr_divide_by_z_on_coset")
+
+    def msm(self, curve: int, bases: int, inf: int, scalars: int, n: int) -> np.ndarray:
+        out = np.zeros(24 if curve == KG_G2 else 12, dtype=np.uint64)
+        self._chk(self._lib.kg_msm(self._h, curve, _vp(bases), _vp(inf), _vp(scalars), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)), "kg_msm")
+        return out
+
+    def msm_host(self, curve: int, bases: np.ndarray, inf, scalars: np.ndarray, n: int) -> np.ndarray:
+        out = np.zeros(24 if curve == KG_G2 else 12, dtype=np.uint64)
+        bases = np.ascontiguousarray(bases, dtype=np.uint64)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        ip = None
+        if inf is not None:
+            inf = np.ascontiguousarray(inf, dtype=np.uint8)
+            ip = inf.ctypes.data_as(C.c_void_p)
+        self._chk(self._lib.kg_msm_host(self._h, curve, bases.ctypes.data_as(C.c_void_p), ip, scalars.ctypes.data_as(C.c_void_p),
+                                        C.c_size_t(n), out.ctypes.data_as(C.c_void_p)), "kg_msm_host")
+        return out
+
+    def commit(self, curve: int, bases: int, inf: int, scalars: int, n: int):
+        xy = np.zeros(16 if curve == KG_G2 else 8, dtype=np.uint64)
+        oi = C.c_uint8(0)
+        self._chk(self._lib.kg_commit(self._h, curve, _vp(bases), _vp(inf), _vp(scalars), C.c_size_t(n), xy.ctypes.data_as(C.c_void_p), C.byref(oi)), "kg_commit")
+        return xy, int(oi.value)
+
+    def points_sum_affine(self, curve: int, pts: np.ndarray, inf: np.ndarray):
+        pts = np.ascontiguousarray(pts, dtype=np.uint64)
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+        xy = np.zeros(16 if curve == KG_G2 else 8, dtype=np.uint64)
+        oi = C.c_uint8(0)
+        self._chk(self._lib.kg_points_sum_affine(self._h, curve, pts.ctypes.data_as(C.c_void_p), inf.ctypes.data_as(C.c_void_p),
+                                                 C.c_size_t(len(inf)), xy.ctypes.data_as(C.c_void_p), C.byref(oi)), "kg_points_sum_affine")
+        return xy, int(oi.value)
+
+    def set_msm_window(self, c: int):
+        self._chk(self._lib.kg_msm_set_window(self._h, int(c)), "kg_msm_set_window")
+
+    def gen_scalars(self, field: int, seed: int, start: int, n: int, out: int):
+        self._chk(self._lib.kg_gen_scalars(self._h, field, C.c_uint64(seed), C.c_size_t(start), C.c_size_t(n), _vp(out)), "kg_gen_scalars")
+
+    def gen_bases(self, curve: int, seed: int, start: int, n: int, out: int):
+        self._chk(self._lib.kg_gen_bases(self._h, curve, C.c_uint64(seed), C.c_size_t(start), C.c_size_t(n), _vp(out)), "kg_gen_bases")
+
+    def profile_enable(self, on: bool = True):
+        self._chk(self._lib.kg_profile_enable(self._h, int(on)), "kg_profile_enable")
+
+    def profile_last(self) -> dict:
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = self._lib.kg_profile_last(self._h, names, ms, 16)
+        return {names[i].decode(): float(ms[i]) for i in range(max(n, 0))}
+
+
+class DeviceArray:
+    """A device allocation owned by a Context (freed on garbage collection)."""
+
+    def __init__(self, ctx: Context, nbytes: int, shape, dtype):
+        self.ctx, self.nbytes, self.shape, self.dtype = ctx, nbytes, tuple(shape), np.dtype(dtype)
+        self.ptr = ctx.malloc(max(nbytes, 1))
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx._h:
+                self.ctx.free(self.ptr)
+        except Exception:
+            pass
+        self.ptr = 0
+
+    def numpy(self) -> np.ndarray:
+        return self.ctx.download(self)

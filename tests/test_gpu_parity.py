@@ -1,0 +1,178 @@
+"""GPU parity tests proper: every call goes through the C ABI (kogarashi_amd.lib -> libkogarashi_amd.so) and is
+compared bit-for-bit with the oracle (oracle/kg_oracle.c, the restatement of the reference's CPU path) on the same
+seeded inputs.  Field outputs: canonical Montgomery limbs.  MSM / commit outputs: affine points."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x4B6F676172617368
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import kogarashi_amd as K
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+def aff(O, cv, proj):
+    xy, inf = O.to_affine(cv, proj)
+    return (None if inf else xy.tobytes())
+
+
+def gpu_aff(out, nb):
+    """ABI projective output (x, y, z) with z in {0, 1}: -> affine bytes / None"""
+    z = out[2 * nb:3 * nb]
+    return None if not z.any() else out[:2 * nb].tobytes()
+
+
+@pytest.mark.parametrize("fd", [0, 1])
+def test_field_vector_ops(ctx, oracle, fd):
+    O, n = oracle, 4096
+    a, b = O.gen_scalars(fd, SEED + 1, 0, n), O.gen_scalars(fd, SEED + 2, 0, n)
+    c = O.f_consts(fd)
+    pm1 = c["p"].copy(); pm1[0] -= 1
+    a[0] = 0; b[1] = 0; a[2] = c["r"]; a[3] = O.f_to_mont(fd, pm1); b[3] = a[3]; a[4] = a[5]; b[4] = a[5]
+    da, db, do = ctx.upload(a), ctx.upload(b), ctx.empty((n, 4))
+    exp = {"add": O.f_add, "sub": O.f_sub, "mul": O.f_mul}
+    for op, f in exp.items():
+        ctx.field_vec_op(fd, op, da.ptr, db.ptr, do.ptr, n)
+        got = do.numpy()
+        want = np.stack([f(fd, a[i], b[i]) for i in range(n)])
+        assert (got == want).all(), op
+    for op, f in {"square": O.f_square, "neg": O.f_neg, "double": O.f_double, "from_mont": O.f_from_mont}.items():
+        ctx.field_vec_op(fd, op, da.ptr, 0, do.ptr, n)
+        got = do.numpy()
+        want = np.stack([f(fd, a[i]) for i in range(n)])
+        assert (got == want).all(), op
+    m = 64
+    ctx.field_vec_op(fd, "invert", da.ptr, 0, do.ptr, m)
+    got = do.numpy()[:m]
+    want = np.stack([O.f_invert(fd, a[i]) if a[i].any() else np.zeros(4, dtype=np.uint64) for i in range(m)])
+    assert (got == want).all()
+    # a * a^-1 = 1 (field_test!, zkstd/src/macros/field/test.rs)
+    ctx.field_vec_op(fd, "mul", da.ptr, do.ptr, do.ptr, m)
+    got = do.numpy()[:m]
+    assert all((got[i] == c["r"]).all() for i in range(m) if a[i].any())
+    s = O.gen_scalars(fd, SEED + 3, 0, 1)[0]
+    ctx.field_vec_scale(fd, da.ptr, s, do.ptr, n)
+    assert (do.numpy() == np.stack([O.f_mul(fd, a[i], s) for i in range(n)])).all()
+
+
+def test_generators_match_oracle(ctx, oracle):
+    O = oracle
+    for fd in (0, 1):
+        d = ctx.empty((1000, 4))
+        ctx.gen_scalars(fd, SEED + 9, 17, 1000, d.ptr)
+        assert (d.numpy() == O.gen_scalars(fd, SEED + 9, 17, 1000)).all()
+    for curve in (0, 1):
+        d = ctx.empty((300, 8))
+        ctx.gen_bases(curve, SEED + 10, 5, 300, d.ptr)
+        assert (d.numpy() == O.gen_bases(curve, SEED + 10, 5, 300)).all()
+
+
+def edge_mix(O, cv, curve, sfd, n, seed):
+    bases = O.gen_bases(curve, seed, 0, n)
+    scal = O.gen_scalars(sfd, seed + 1, 0, n)
+    inf = np.zeros(n, dtype=np.uint8)
+    if n >= 8:
+        inf[2] = 1                                   # identity base
+        scal[1] = 0                                  # zero scalar
+        bases[3] = bases[0]                          # duplicate point
+        bases[5] = bases[4]                          # P and (-1)*P below
+        scal[6] = scal[7]; bases[6] = bases[7]       # same point, same scalar
+        one = O.f_consts(sfd)["r"]
+        scal[4] = one                                # scalar 1
+        scal[5] = O.f_neg(sfd, one)                  # scalar -1
+    return bases, scal, inf
+
+
+@pytest.mark.parametrize("cv,curve,sfd", [("g1", 0, 0), ("gk", 1, 1)])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 31, 32, 33, 257, 1024, 5000])
+def test_msm_matches_oracle(ctx, oracle, cv, curve, sfd, n):
+    O = oracle
+    bases, scal, inf = edge_mix(O, cv, curve, sfd, n, SEED + 20 + n)
+    want = aff(O, cv, O.msm(cv, bases, scal, inf, threads=8))
+    got = ctx.msm_host(curve, bases, inf, scal, n)
+    assert gpu_aff(got, 4) == want
+    # without flags
+    want = aff(O, cv, O.msm(cv, bases, scal, None, threads=8))
+    assert gpu_aff(ctx.msm_host(curve, bases, None, scal, n), 4) == want
+
+
+def test_msm_special_sums(ctx, oracle):
+    """all-zero scalars, all-identity bases, P + (-P), k*P + (r-k)*P, empty input (msm.rs edge behaviour)."""
+    O = oracle
+    n = 64
+    bases = O.gen_bases(0, SEED + 40, 0, n)
+    scal = O.gen_scalars(0, SEED + 41, 0, n)
+    ident = lambda out: gpu_aff(out, 4) is None
+    assert ident(ctx.msm_host(0, bases, None, np.zeros_like(scal), n))
+    assert ident(ctx.msm_host(0, bases, np.ones(n, dtype=np.uint8), scal, n))
+    assert ident(ctx.msm_host(0, bases[:0], None, scal[:0], 0))
+    b2 = np.stack([bases[0], bases[0]]); s2 = np.stack([scal[0], O.f_neg(0, scal[0])])
+    assert ident(ctx.msm_host(0, b2, None, s2, 2))
+    nb = bases[0].copy(); nb[4:] = O.f_neg(1, bases[0, 4:])
+    assert ident(ctx.msm_host(0, np.stack([bases[0], nb]), None, np.stack([scal[0], scal[0]]), 2))
+    # identity output is (0, 1, 0) in Montgomery form (group.rs:106-110)
+    out = ctx.msm_host(0, bases, None, np.zeros_like(scal), n)
+    assert not out[:4].any() and (out[4:8] == O.f_consts(1)["r"]).all() and not out[8:].any()
+
+
+@pytest.mark.parametrize("c", [2, 5, 8, 11, 13])
+def test_msm_window_widths(ctx, oracle, c):
+    O, n = oracle, 700
+    bases, scal, inf = edge_mix(O, "g1", 0, 0, n, SEED + 60)
+    want = aff(O, "g1", O.msm("g1", bases, scal, inf, threads=8))
+    ctx.set_msm_window(c)
+    try:
+        assert gpu_aff(ctx.msm_host(0, bases, inf, scal, n), 4) == want
+    finally:
+        ctx.set_msm_window(0)
+
+
+def test_msm_g2_matches_oracle(ctx, oracle):
+    O, n = oracle, 48
+    g = O.generator("g2")
+    one = np.concatenate([O.f_consts(1)["r"], np.zeros(4, dtype=np.uint64)])
+    gen_proj = np.concatenate([g, one])
+    ks = O.gen_scalars(0, SEED + 70, 0, n)
+    bases = np.stack([O.to_affine("g2", O.scalar_point("g2", gen_proj, ks[i]))[0] for i in range(n)])
+    scal = O.gen_scalars(0, SEED + 71, 0, n)
+    inf = np.zeros(n, dtype=np.uint8); inf[3] = 1; scal[2] = 0; bases[5] = bases[4]
+    want = aff(O, "g2", O.msm("g2", bases, scal, inf, threads=8))
+    assert gpu_aff(ctx.msm_host(2, bases, inf, scal, n), 8) == want
+
+
+def test_commit_matches_naive_pedersen(ctx, oracle):
+    """nova PedersenCommitment::commit (naive NAF scalar muls in the reference) vs the device MSM, both curves."""
+    import kogarashi_amd as K
+    O = oracle
+    for name, cv, curve, sfd in (("g1", "g1", 0, 0), ("grumpkin", "gk", 1, 1)):
+        n = 40
+        g = O.gen_bases(curve, SEED + 80, 0, n + 1)           # key size 2^k + 1 (pedersen.rs:10-13)
+        m = O.gen_scalars(sfd, SEED + 81, 0, n)
+        want_xy, want_inf = O.commit_naive(cv, g, m)
+        pc = K.PedersenCommitment(g, curve=name, ctx=ctx)
+        xy, inf = pc.commit(m)
+        assert inf == want_inf and (xy == want_xy).all()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 8, 9, 10, 12, 13, 16, 17, 18])
+def test_ntt_matches_oracle(ctx, oracle, k):
+    import kogarashi_amd as K
+    O = oracle
+    n = 1 << k
+    v = O.gen_scalars(0, SEED + 100 + k, 0, n)
+    fo, fg = O.Fft(k), K.Fft(k, ctx=ctx)
+    assert (fg.dft(v) == fo.dft(v, threads=8)).all()
+    assert (fg.idft(v) == fo.idft(v, threads=8)).all()
+    assert (fg.coset_dft(v) == fo.coset_dft(v, threads=8)).all()
+    assert (fg.coset_idft(v) == fo.coset_idft(v, threads=8)).all()
+    assert (fg.divide_by_z_on_coset(v) == fo.divide_by_z_on_coset(v)).all()
+    # ragged input: shorter than n is zero padded (prepare_fft)
+    assert (fg.dft(v[: n // 2 + 1]) == fo.dft(v[: n // 2 + 1])).all()
+    # idft(dft(v)) == v (fft_transformation_test, fft.rs:246-257)
+    assert (fg.idft(fg.dft(v)) == v).all()
