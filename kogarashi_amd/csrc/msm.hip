@@ -198,21 +198,168 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint32_t* __restrict__ k
 }
 
 // ---------------------------------------------------------------------------------------------------
-// bucket accumulation: one lane per (window, bucket)
+// bucket accumulation, load balanced.  A bucket's list is cut into tasks of at most T entries; one lane per
+// task.  Real witnesses are heavily skewed (0/1 scalars put ~n points in one bucket; the top window has few
+// buckets), so partial sums of one bucket are re-summed in further rounds (T2 partials per lane) until every
+// bucket owns a single point.  With uniform scalars every bucket is one task and no extra round runs.
 // ---------------------------------------------------------------------------------------------------
-template <class F>
-__global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ pbases, const uint32_t* __restrict__ sorted,
-                                                   const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bsize,
-                                                   size_t n, int W, int B, uint32_t* __restrict__ buckets) {
+struct Level {            // one round's task bookkeeping, all device pointers
+  const uint32_t* cnt;    // [W*B] tasks of each bucket in this round
+  const uint32_t* rel;    // [W*B] exclusive prefix of cnt inside the window
+  const uint32_t* base;   // [W+1] first task of each window; base[W] = total
+};
+
+// tasks per bucket for item counts `in` and a segment length T; block-reduced maximum of `in`
+__global__ void __launch_bounds__(1024) k_task_count(const uint32_t* __restrict__ in, size_t total, uint32_t T,
+                                                     uint32_t* __restrict__ ntask, uint32_t* __restrict__ maxv) {
+  __shared__ uint32_t red[16];
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)W * B;
-  if (t >= total) return;
-  const size_t w = t / B;
-  const uint32_t* list = sorted + w * n + bstart[t];
-  const uint32_t len = bsize[t];
+  uint32_t v = 0;
+  if (t < total) {
+    v = in[t];
+    ntask[t] = (v + T - 1) / T;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t m = 0;
+    for (unsigned i = 0; i < (blockDim.x >> 6); ++i) m = red[i] > m ? red[i] : m;
+    if (m) atomicMax(maxv, m);
+  }
+}
+
+// per window: exclusive prefix of `in` -> rel, window total -> row_total[w]
+__global__ void __launch_bounds__(1024) k_scan_rows(const uint32_t* __restrict__ in, int B, uint32_t* __restrict__ rel,
+                                                    uint32_t* __restrict__ row_total) {
+  __shared__ uint32_t part[1024];
+  const int w = blockIdx.x, T = blockDim.x;
+  const int per = (B + T - 1) / T;
+  const int lo = threadIdx.x * per, hi = lo + per < B ? lo + per : B;
+  uint32_t s = 0;
+  for (int b = lo; b < hi; ++b) s += in[(size_t)w * B + b];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < T; d <<= 1) {
+    uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - s;
+  for (int b = lo; b < hi; ++b) {
+    rel[(size_t)w * B + b] = run;
+    run += in[(size_t)w * B + b];
+  }
+  if (threadIdx.x == T - 1 && row_total) row_total[w] = part[T - 1];
+}
+// base[w] = sum_{w' < w} row_total[w'], base[W] = grand total; info[0] = grand total, info[1] = *maxv
+__global__ void k_row_bases(const uint32_t* __restrict__ row_total, int W, uint32_t* __restrict__ base, const uint32_t* __restrict__ maxv,
+                            uint32_t* __restrict__ info) {
+  if (threadIdx.x || blockIdx.x) return;
+  uint32_t run = 0;
+  for (int w = 0; w < W; ++w) { base[w] = run; run += row_total[w]; }
+  base[W] = run;
+  info[0] = run;
+  info[1] = maxv ? *maxv : 0;
+}
+
+// ---- order tasks by length (longest first) so the 64 lanes of a wave run equally long loops ---------------
+// key = min(length, 255); bins are laid out in DESCENDING key order.  One lane per bucket: a bucket contributes
+// ntask-1 full tasks (length T) and one remainder.
+constexpr int LEN_BINS = 256;
+__device__ __forceinline__ uint32_t len_key(uint32_t len) { return len > 255u ? 255u : len; }
+
+__global__ void __launch_bounds__(1024) k_len_hist(const uint32_t* __restrict__ bsize, const uint32_t* __restrict__ ntask, size_t total, uint32_t T,
+                                                   uint32_t* __restrict__ ghist) {
+  __shared__ uint32_t h[LEN_BINS];
+  if (threadIdx.x < LEN_BINS) h[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < total) {
+    const uint32_t nt = ntask[t];
+    if (nt) {
+      const uint32_t rem = bsize[t] - (nt - 1) * T;
+      atomicAdd(&h[len_key(rem)], 1u);
+      if (nt > 1) atomicAdd(&h[len_key(T)], nt - 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < LEN_BINS && h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
+}
+// cursor[k] = number of tasks with a larger key (descending layout)
+__global__ void k_len_scan(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ cursor) {
+  if (threadIdx.x || blockIdx.x) return;
+  uint32_t run = 0;
+  for (int k = LEN_BINS - 1; k >= 0; --k) { cursor[k] = run; run += ghist[k]; }
+}
+__global__ void __launch_bounds__(1024) k_len_scatter(const uint32_t* __restrict__ bsize, const uint32_t* __restrict__ ntask,
+                                                      const uint32_t* __restrict__ rel, const uint32_t* __restrict__ base, size_t total, int B,
+                                                      uint32_t T, uint32_t* __restrict__ cursor, uint32_t* __restrict__ task_bkt,
+                                                      uint32_t* __restrict__ task_id) {
+  __shared__ uint32_t h[LEN_BINS], start[LEN_BINS], fill[LEN_BINS];
+  if (threadIdx.x < LEN_BINS) { h[threadIdx.x] = 0; fill[threadIdx.x] = 0; }
+  __syncthreads();
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t nt = 0, rem = 0;
+  if (t < total) {
+    nt = ntask[t];
+    if (nt) {
+      rem = bsize[t] - (nt - 1) * T;
+      atomicAdd(&h[len_key(rem)], 1u);
+      if (nt > 1) atomicAdd(&h[len_key(T)], nt - 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < LEN_BINS && h[threadIdx.x]) start[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
+  __syncthreads();
+  if (nt) {
+    const uint32_t first = base[t / B] + rel[t];
+    const uint32_t kf = len_key(T);
+    for (uint32_t sgm = 0; sgm + 1 < nt; ++sgm) {
+      const uint32_t pos = start[kf] + atomicAdd(&fill[kf], 1u);
+      task_bkt[pos] = (uint32_t)t;
+      task_id[pos] = first + sgm;
+    }
+    const uint32_t kr = len_key(rem);
+    const uint32_t pos = start[kr] + atomicAdd(&fill[kr], 1u);
+    task_bkt[pos] = (uint32_t)t;
+    task_id[pos] = first + nt - 1;
+  }
+}
+
+// task id -> (window, bucket, segment index)
+__device__ __forceinline__ void locate_task(const Level& L, int W, int B, uint32_t t, int& w, int& b, uint32_t& seg) {
+  int lo = 0, hi = W;                        // last w with base[w] <= t
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (L.base[mid] <= t) lo = mid; else hi = mid; }
+  w = lo;
+  const uint32_t x = t - L.base[w];
+  const uint32_t* rel = L.rel + (size_t)w * B;
+  lo = 0; hi = B;                            // last b with rel[b] <= x  (that bucket is never empty)
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (rel[mid] <= x) lo = mid; else hi = mid; }
+  b = lo;
+  seg = x - rel[b];
+}
+
+// round 1: lists of (base index | sign) -> partial XYZZ per task; lane p runs the p-th longest task
+template <class F>
+__global__ void __launch_bounds__(64) k_acc_tasks(const uint32_t* __restrict__ pbases, const uint32_t* __restrict__ sorted,
+                                                  const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bsize, Level L,
+                                                  const uint32_t* __restrict__ task_bkt, const uint32_t* __restrict__ task_id,
+                                                  size_t n, int W, int B, uint32_t T, uint32_t* __restrict__ partial, size_t pstride) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= L.base[W]) return;
+  const size_t bi = task_bkt[p];
+  const uint32_t t = task_id[p];
+  const int w = (int)(bi / B);
+  const uint32_t seg = t - L.base[w] - L.rel[bi];
+  const uint32_t len_all = bsize[bi];
+  const uint32_t lo = seg * T, hi = lo + T < len_all ? lo + T : len_all;
+  const uint32_t* list = sorted + (size_t)w * n + bstart[bi];
   constexpr int PW = 2 * BaseIO<F>::W;
   XYZZ<F> acc = XYZZ<F>::identity();
-  for (uint32_t j = 0; j < len; ++j) {
+  for (uint32_t j = lo; j < hi; ++j) {
     const uint32_t e = list[j];
     const uint32_t* src = pbases + (size_t)(e & 0x7fffffffu) * PW;
     if (src[7] & INF_BIT) continue;                      // identity base (msm.rs:58-64 adds it as a no-op)
@@ -220,7 +367,38 @@ __global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ 
     if (e & 0x80000000u) a = neg_affine(a);
     acc = add_mixed(acc, a);
   }
-  PointIO<F>::store(buckets, total, t, acc);
+  PointIO<F>::store(partial, pstride, t, acc);
+}
+
+// round r > 1: partial sums of the previous round (grouped by bucket through Lin) -> fewer partial sums
+template <class F>
+__global__ void __launch_bounds__(64) k_sum_tasks(const uint32_t* __restrict__ pin, size_t in_stride, Level Lin, Level L, int W, int B, uint32_t T2,
+                                                  uint32_t* __restrict__ pout, size_t out_stride) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= L.base[W]) return;
+  int w, b;
+  uint32_t seg;
+  locate_task(L, W, B, t, w, b, seg);
+  const size_t bi = (size_t)w * B + b;
+  const uint32_t len_all = Lin.cnt[bi];
+  const uint32_t lo = seg * T2, hi = lo + T2 < len_all ? lo + T2 : len_all;
+  const size_t first = (size_t)Lin.base[w] + Lin.rel[bi];
+  XYZZ<F> acc = PointIO<F>::load(pin, in_stride, first + lo);
+  for (uint32_t j = lo + 1; j < hi; ++j) acc = add_xyzz(acc, PointIO<F>::load(pin, in_stride, first + j));
+  PointIO<F>::store(pout, out_stride, t, acc);
+}
+
+// final: dense bucket array for the halving reduction
+template <class F>
+__global__ void __launch_bounds__(256) k_gather_buckets(const uint32_t* __restrict__ pin, size_t in_stride, Level L, int W, int B,
+                                                        uint32_t* __restrict__ buckets) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)W * B;
+  if (t >= total) return;
+  const int w = (int)(t / B);
+  XYZZ<F> p = XYZZ<F>::identity();
+  if (L.cnt[t]) p = PointIO<F>::load(pin, in_stride, (size_t)L.base[w] + L.rel[t]);
+  PointIO<F>::store(buckets, total, t, p);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -338,8 +516,26 @@ int msm_device(kg_ctx* ctx, const uint64_t* d_bases, const uint8_t* d_inf, const
   const size_t o_p1 = carve(npts * NW * 4);
   const size_t nexp = (size_t)W * c;
   const size_t o_exp = carve(nexp * 4 * Cfg::E64 * 8);
+  // task bookkeeping: two levels (ping-pong) of cnt / rel / base, row totals, max word, info words
+  uint32_t T = (uint32_t)(2 * (n / B) + 32);
+  if (T < 64) T = 64;
+  if (T > 4096) T = 4096;
+  const uint32_t T2 = 16;
+  const size_t part_cap = (size_t)W * ((n + T - 1) / T) + npts;     // upper bound on round-1 tasks
+  size_t o_lcnt[2], o_lrel[2], o_lbase[2], o_part[2];
+  for (int i = 0; i < 2; ++i) {
+    o_lcnt[i] = carve(npts * 4);
+    o_lrel[i] = carve(npts * 4);
+    o_lbase[i] = carve((size_t)(W + 1) * 4);
+    o_part[i] = carve(part_cap * NW * 4);
+  }
+  const size_t o_rowtot = carve((size_t)W * 4);
+  const size_t o_misc = carve(64);
+  const size_t o_lenh = carve(2 * LEN_BINS * 4);
+  const size_t o_tbkt = carve(part_cap * 4);
+  const size_t o_tid = carve(part_cap * 4);
   KG_TRY(ensure_ws(ctx, off));
-  KG_TRY(ensure_pinned(ctx, nexp * 4 * Cfg::E64 * 8));
+  KG_TRY(ensure_pinned(ctx, nexp * 4 * Cfg::E64 * 8 + 64));
   char* ws = (char*)ctx->ws;
   uint32_t* kt = (uint32_t*)(ws + o_kt);
   uint32_t* pb = (uint32_t*)(ws + o_pb);
@@ -380,7 +576,51 @@ int msm_device(kg_ctx* ctx, const uint64_t* d_bases, const uint8_t* d_inf, const
   }
   {
     PhaseScope ph(ctx, "accumulate");
-    hipLaunchKernelGGL(k_accumulate<F>, dim3((unsigned)((npts + 63) / 64)), dim3(64), 0, st, pb, sorted, bstart, bsize, n, W, B, pbuf[0]);
+    uint32_t* lcnt[2] = {(uint32_t*)(ws + o_lcnt[0]), (uint32_t*)(ws + o_lcnt[1])};
+    uint32_t* lrel[2] = {(uint32_t*)(ws + o_lrel[0]), (uint32_t*)(ws + o_lrel[1])};
+    uint32_t* lbase[2] = {(uint32_t*)(ws + o_lbase[0]), (uint32_t*)(ws + o_lbase[1])};
+    uint32_t* part[2] = {(uint32_t*)(ws + o_part[0]), (uint32_t*)(ws + o_part[1])};
+    uint32_t* rowtot = (uint32_t*)(ws + o_rowtot);
+    uint32_t* misc = (uint32_t*)(ws + o_misc);          // [0] max bucket size, [4..5] info
+    uint32_t* h_info = (uint32_t*)((char*)ctx->h_pinned + nexp * 4 * Cfg::E64 * 8);
+    uint32_t* lenh = (uint32_t*)(ws + o_lenh);          // [0..255] histogram, [256..511] cursors
+    uint32_t* task_bkt = (uint32_t*)(ws + o_tbkt);
+    uint32_t* task_id = (uint32_t*)(ws + o_tid);
+    KG_HIP(ctx, hipMemsetAsync(misc, 0, 64, st));
+    KG_HIP(ctx, hipMemsetAsync(lenh, 0, 2 * LEN_BINS * 4, st));
+    const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
+    hipLaunchKernelGGL(k_task_count, dim3(g1024), dim3(1024), 0, st, bsize, npts, T, lcnt[0], misc);
+    hipLaunchKernelGGL(k_scan_rows, dim3(W), dim3(1024), 0, st, lcnt[0], B, lrel[0], rowtot);
+    hipLaunchKernelGGL(k_row_bases, dim3(1), dim3(64), 0, st, rowtot, W, lbase[0], misc, misc + 4);
+    hipLaunchKernelGGL(k_len_hist, dim3(g1024), dim3(1024), 0, st, bsize, lcnt[0], npts, T, lenh);
+    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(64), 0, st, lenh, lenh + LEN_BINS);
+    hipLaunchKernelGGL(k_len_scatter, dim3(g1024), dim3(1024), 0, st, bsize, lcnt[0], lrel[0], lbase[0], npts, B, T, lenh + LEN_BINS, task_bkt, task_id);
+    KG_HIP(ctx, hipMemcpyAsync(h_info, misc + 4, 8, hipMemcpyDeviceToHost, st));
+    KG_HIP(ctx, hipStreamSynchronize(st));
+    uint32_t ntasks = h_info[0];
+    uint32_t max_cnt = (h_info[1] + T - 1) / T;          // most tasks any bucket has
+    if (ntasks > part_cap) return set_err(ctx, KG_ERR_HIP, "task count exceeds its bound");
+    int lv = 0;
+    Level L{lcnt[0], lrel[0], lbase[0]};
+    if (ntasks)
+      hipLaunchKernelGGL(k_acc_tasks<F>, dim3((ntasks + 63) / 64), dim3(64), 0, st, pb, sorted, bstart, bsize, L, task_bkt, task_id, n, W, B, T, part[0], part_cap);
+    int pcur = 0;
+    while (max_cnt > 1) {
+      const int nx = lv ^ 1;
+      hipLaunchKernelGGL(k_task_count, dim3(g1024), dim3(1024), 0, st, lcnt[lv], npts, T2, lcnt[nx], misc + 8);
+      hipLaunchKernelGGL(k_scan_rows, dim3(W), dim3(1024), 0, st, lcnt[nx], B, lrel[nx], rowtot);
+      hipLaunchKernelGGL(k_row_bases, dim3(1), dim3(64), 0, st, rowtot, W, lbase[nx], (const uint32_t*)nullptr, misc + 4);
+      KG_HIP(ctx, hipMemcpyAsync(h_info, misc + 4, 8, hipMemcpyDeviceToHost, st));
+      KG_HIP(ctx, hipStreamSynchronize(st));
+      const uint32_t nt2 = h_info[0];
+      Level Lin{lcnt[lv], lrel[lv], lbase[lv]}, Lout{lcnt[nx], lrel[nx], lbase[nx]};
+      hipLaunchKernelGGL(k_sum_tasks<F>, dim3((nt2 + 63) / 64), dim3(64), 0, st, part[pcur], part_cap, Lin, Lout, W, B, T2, part[pcur ^ 1], part_cap);
+      pcur ^= 1;
+      lv = nx;
+      max_cnt = (max_cnt + T2 - 1) / T2;
+    }
+    Level Lf{lcnt[lv], lrel[lv], lbase[lv]};
+    hipLaunchKernelGGL(k_gather_buckets<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, part[pcur], part_cap, Lf, W, B, pbuf[0]);
     ph.end();
   }
   int cur = 0;

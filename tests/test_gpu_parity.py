@@ -176,3 +176,32 @@ def test_ntt_matches_oracle(ctx, oracle, k):
     assert (fg.dft(v[: n // 2 + 1]) == fo.dft(v[: n // 2 + 1])).all()
     # idft(dft(v)) == v (fft_transformation_test, fft.rs:246-257)
     assert (fg.idft(fg.dft(v)) == v).all()
+
+
+@pytest.mark.parametrize("c", [0, 3, 7, 14])
+def test_msm_skewed_scalars(ctx, oracle, c):
+    """Witness-like scalars (mostly 0 / 1 / small / -1, groth16 aux vectors): a few buckets hold almost every point,
+    which exercises the multi-round partial-sum path of the load-balanced accumulation."""
+    O, n = oracle, 20000
+    rng = np.random.default_rng(7)
+    bases = O.gen_bases(0, SEED + 90, 0, n)
+    scal = O.gen_scalars(0, SEED + 91, 0, n)
+    one = O.f_consts(0)["r"]
+    kind = rng.integers(0, 10, n)
+    small = [O.f_to_mont(0, np.array([v, 0, 0, 0], dtype=np.uint64)) for v in range(0, 9)]
+    for i in range(n):
+        if kind[i] < 4:
+            scal[i] = one
+        elif kind[i] < 6:
+            scal[i] = 0
+        elif kind[i] < 8:
+            scal[i] = small[int(rng.integers(2, 9))]
+        elif kind[i] == 8:
+            scal[i] = O.f_neg(0, one)
+    bases[100:200] = bases[100]                      # one point repeated 100 times
+    want = aff(O, "g1", O.msm("g1", bases, scal, None, threads=8))
+    ctx.set_msm_window(c)
+    try:
+        assert gpu_aff(ctx.msm_host(0, bases, None, scal, n), 4) == want
+    finally:
+        ctx.set_msm_window(0)
