@@ -68,17 +68,15 @@ def main():
     ctx.gen_scalars(K.KG_FR, SEED + 2, rank * n, n, scalars.data_ptr())
     torch.cuda.synchronize()
 
+    from kogarashi_amd import dist as kdist
+
     def step():
         out = ctx.msm(K.KG_G1, bases.data_ptr(), 0, scalars.data_ptr(), n)
+        xy, inf = out[:8], int(not out[8:].any())
         if world > 1:
-            # exchange step: all ranks learn every partial (x | y | inf flag), each adds them locally
-            mine = torch.from_numpy(np.concatenate([out[:8], out[8:9]]).astype(np.int64)).to(dev)
-            allp = torch.empty(world * 9, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(allp, mine)
-            h = allp.cpu().numpy().astype(np.uint64).reshape(world, 9)
-            xy, inf = ctx.points_sum_affine(K.KG_G1, np.ascontiguousarray(h[:, :8]), (h[:, 8] == 0).astype(np.uint8))
-            return xy, inf
-        return out[:8], int(not out[8:].any())
+            # exchange step: one all_gather of 9 words per rank over RCCL, every rank adds the partial sums
+            xy, inf = kdist.combine_partials(ctx, K.KG_G1, xy, inf, device=dev)
+        return xy, inf
 
     def barrier():
         if world > 1:

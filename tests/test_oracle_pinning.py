@@ -1,0 +1,175 @@
+"""Pins the CPU oracle (oracle/kg_oracle.c) before it is trusted as the checker:
+ 1. every constant the reference holds for this path (quoted here as data, with file:line),
+ 2. the reference's own algebraic test properties (field_test!, curve_test!, msm test, fft tests),
+ 3. the committed golden vectors from the independent big-integer implementation (tests/golden/)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import CURVES, I, L, np_to_pt, pt_to_np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SEED = 0x4B6F676172617368
+
+
+def gold(name):
+    with open(os.path.join(GOLD, name + ".json")) as f:
+        return json.load(f)
+
+
+# constants exactly as written in the reference sources (little-endian u64 limbs)
+REF = {
+    "fr_modulus": [0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029],   # bn254/src/fr.rs:11-16
+    "fr_r": [0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f],         # fr.rs:25-30
+    "fr_r2": [0x1bb8e645ae216da7, 0x53fe3ab1e35c59e3, 0x8c49833d53bb8085, 0x0216d0b17f4e44a5],        # fr.rs:34-39
+    "fr_r3": [0x5e94d8e1b4bf0040, 0x2a489cbe1cfbb6b8, 0x893cc664a19fcfed, 0x0cf8594b7fcc657c],        # fr.rs:43-48
+    "fr_inv": 0xc2e1f593efffffff,                                                                      # fr.rs:51
+    "fr_root_raw": [0xd34f1ed960c37c9c, 0x3215cf6dd39329c8, 0x98865ea93dd31f74, 0x03ddb9f5166d18b7],  # fr.rs:60-65
+    "fq_modulus": [0x3c208c16d87cfd47, 0x97816a916871ca8d, 0xb85045b68181585d, 0x30644e72e131a029],   # bn254/src/fq.rs:10-15
+    "fq_r": [0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f],         # fq.rs:20-25
+    "fq_r2": [0xf32cfc5b538afa89, 0xb5e71911d44501fb, 0x47ab1eff0a417ff6, 0x06d89f71cab8351f],        # fq.rs:28-33
+    "fq_r3": [0xb1cd6dafda1530df, 0x62f210e6a7283db6, 0xef7f0b0c0ada0afb, 0x20fd6e902d592544],        # fq.rs:36-41
+    "fq_inv": 0x87d20782e4866389,                                                                      # fq.rs:44
+    "grumpkin_gen_y": [0x11b2dff1448c41d8, 0x23d3446f21c77dc3, 0xaa7b8cf435dfafbb, 0x14b34cf69dc25d68],  # grumpkin/src/params.rs:5-10
+    "grumpkin_b": [0xdd7056026000005a, 0x223fa97acb319311, 0xcc388229877910c0, 0x034394632b724eaa],     # grumpkin/src/params.rs:13-18
+}
+
+
+def test_reference_constants(oracle, pyoracle):
+    O, P = oracle, pyoracle
+    for fd, tag, p in ((0, "fr", P.R_MOD), (1, "fq", P.Q_MOD)):
+        c = O.f_consts(fd)
+        assert [int(v) for v in c["p"]] == REF[f"{tag}_modulus"] and I(c["p"]) == p
+        assert [int(v) for v in c["r"]] == REF[f"{tag}_r"] and I(c["r"]) == (1 << 256) % p
+        assert [int(v) for v in c["r2"]] == REF[f"{tag}_r2"] and I(c["r2"]) == pow(2, 512, p)
+        assert [int(v) for v in c["r3"]] == REF[f"{tag}_r3"] and I(c["r3"]) == pow(2, 768, p)
+        assert c["inv"] == REF[f"{tag}_inv"] == (-pow(p, -1, 1 << 64)) % (1 << 64)
+        # Fr::one() == R through the oracle's own to_mont_form (represent.rs:10-12)
+        assert (O.f_to_mont(fd, L(1)) == c["r"]).all()
+    # test_root_of_unity (bn254/src/fr.rs:315-320): ROOT_OF_UNITY^(2^28) == 1, and its order is exactly 2^28
+    root = O.f_to_mont(0, np.array(REF["fr_root_raw"], dtype=np.uint64))
+    x = root
+    for i in range(28):
+        if i == 27:
+            assert not (x == O.f_consts(0)["r"]).all()
+        x = O.f_square(0, x)
+    assert (x == O.f_consts(0)["r"]).all()
+    assert I(REF["fr_root_raw"]) == pow(7, (P.R_MOD - 1) >> 28, P.R_MOD)      # GENERATOR^t (fr.rs:55-59)
+    # generators / curve constants (bn254/src/params.rs:8-57, grumpkin/src/params.rs:4-19)
+    g1 = O.generator("g1")
+    assert (g1[:4] == O.f_consts(1)["r"]).all() and (g1[4:] == O.f_to_mont(1, L(2))).all()
+    gk = O.generator("gk")
+    assert (gk[:4] == O.f_consts(0)["r"]).all() and [int(v) for v in gk[4:]] == REF["grumpkin_gen_y"]
+    b, b3 = O.curve_b("gk")
+    assert [int(v) for v in b] == REF["grumpkin_b"] and P.from_mont(I(b), P.R_MOD) == P.R_MOD - 17
+    for cv in ("g1", "gk", "g2"):
+        assert O.is_on_curve(cv, O.generator(cv))
+        assert np_to_pt(CURVES[cv][1], O.generator(cv), 0) == CURVES[cv][1].gen
+
+
+@pytest.mark.parametrize("fd,tag", [(0, "fr"), (1, "fq")])
+def test_field_golden(oracle, pyoracle, fd, tag):
+    O, P = oracle, pyoracle
+    p = P.R_MOD if fd == 0 else P.Q_MOD
+    m = lambda h: L(P.to_mont(int(h, 16), p))
+    for row in gold("field")[tag]:
+        a, b = m(row["a"]), m(row["b"])
+        assert (O.f_add(fd, a, b) == m(row["add"])).all() and (O.f_sub(fd, a, b) == m(row["sub"])).all()
+        assert (O.f_mul(fd, a, b) == m(row["mul"])).all() and (O.f_square(fd, a) == m(row["sqr"])).all()
+        assert (O.f_neg(fd, a) == m(row["neg"])).all() and (O.f_double(fd, a) == m(row["dbl"])).all()
+        inv = O.f_invert(fd, a)
+        assert (inv is None) == (row["inv"] is None) and (inv is None or (inv == m(row["inv"])).all())
+        assert I(O.f_from_mont(fd, a)) == int(row["a"], 16)
+
+
+def gpt(cur, v):
+    if v is None:
+        return None
+    from oracle.pyoracle import Fq2
+    x = [int(h, 16) for h in v]
+    return (Fq2(x[0], x[1]), Fq2(x[2], x[3])) if cur.ext else (x[0], x[1])
+
+
+@pytest.mark.parametrize("cv", ["g1", "gk", "g2"])
+def test_point_golden_and_group_laws(oracle, cv):
+    O = oracle
+    _, cur, sfd = CURVES[cv]
+    g = gold("points")[cv]
+    nb = 8 if cur.ext else 4
+    one = np.concatenate([O.f_consts(1 if cv != "gk" else 0)["r"], np.zeros(nb - 4, dtype=np.uint64)])
+    proj = lambda pt: np.concatenate([pt_to_np(cur, pt), one]) if pt is not None else np.concatenate([np.zeros(nb, dtype=np.uint64), one, np.zeros(nb, dtype=np.uint64)])
+    for row in g["add"]:
+        p, q, s = gpt(cur, row["p"]), gpt(cur, row["q"]), gpt(cur, row["sum"])
+        got = O.add_affine(cv, pt_to_np(cur, p), p is None, pt_to_np(cur, q), q is None)
+        assert np_to_pt(cur, *O.to_affine(cv, got)) == s
+        got = O.add_mixed(cv, pt_to_np(cur, p), p is None, proj(q))
+        assert np_to_pt(cur, *O.to_affine(cv, got)) == s
+        got = O.add_projective(cv, proj(p), proj(q))
+        assert np_to_pt(cur, *O.to_affine(cv, got)) == s
+    # curve_test!: 7g + 16g = 23g via NAF scalar_point (zkstd/src/macros/curve/weierstrass/test.rs)
+    gen = proj(cur.gen)
+    k = lambda v: O.f_to_mont(sfd, L(v))
+    s7, s16, s23 = (O.scalar_point(cv, gen, k(v)) for v in (7, 16, 23))
+    assert np_to_pt(cur, *O.to_affine(cv, s23)) == gpt(cur, g["gen_times_23"])
+    assert np_to_pt(cur, *O.to_affine(cv, O.add_projective(cv, s7, s16))) == gpt(cur, g["seven_plus_sixteen"]) == gpt(cur, g["gen_times_23"])
+    # 8a == double^3(a)
+    d = gen
+    for _ in range(3):
+        d = O.double_projective(cv, d)
+    assert O.to_affine(cv, d)[0].tobytes() == O.to_affine(cv, O.scalar_point(cv, gen, k(8)))[0].tobytes()
+
+
+@pytest.mark.parametrize("cv", ["g1", "gk", "g2"])
+def test_msm_golden(oracle, pyoracle, cv):
+    O, P = oracle, pyoracle
+    _, cur, sfd = CURVES[cv]
+    sp = P.R_MOD if sfd == 0 else P.Q_MOD
+    for case in gold("msm")[cv]:
+        bases = np.stack([pt_to_np(cur, gpt(cur, b)) for b in case["bases"]])
+        scal = np.stack([L(P.to_mont(int(h, 16), sp)) for h in case["scalars"]])
+        inf = np.array(case["inf"], dtype=np.uint8)
+        for threads in (1, 4):
+            got = O.msm(cv, bases, scal, inf, threads=threads)
+            assert np_to_pt(cur, *O.to_affine(cv, got)) == gpt(cur, case["sum"]), (cv, case["n"])
+        if len(case["scalars"]) == len(case["bases"]):
+            xy, oi = O.commit_naive(cv, bases, scal, inf)
+            assert np_to_pt(cur, xy, oi) == gpt(cur, case["sum"])
+
+
+def test_msm_equals_naive_sum_like_reference_test(oracle):
+    """multi_scalar_multiplication_test (groth16/src/msm.rs:118-135): Pippenger == sum of independent scalar muls, n = 32."""
+    O = oracle
+    n = 32
+    bases, scal = O.gen_bases(0, SEED + 5, 0, n), O.gen_scalars(0, SEED + 6, 0, n)
+    xy, inf = O.commit_naive("g1", bases, scal)
+    axy, ainf = O.to_affine("g1", O.msm("g1", bases, scal))
+    assert inf == ainf == 0 and (xy == axy).all()
+
+
+def test_ntt_golden_and_fft_properties(oracle, pyoracle):
+    O, P = oracle, pyoracle
+    m = lambda hs: np.stack([L(P.to_mont(int(h, 16), P.R_MOD)) for h in hs])
+    for case in gold("ntt"):
+        f = O.Fft(case["k"])
+        v = m(case["v"])
+        assert (f.dft(v) == m(case["dft"])).all() and (f.idft(v) == m(case["idft"])).all()
+        assert (f.coset_dft(v) == m(case["coset_dft"])).all() and (f.coset_idft(v) == m(case["coset_idft"])).all()
+        assert (f.divide_by_z_on_coset(v) == m(case["divide_by_z_on_coset"])).all()
+        assert (f.dft(v, threads=4) == m(case["dft"])).all()
+    # fft_transformation_test (fft.rs:246-257), k = 10
+    v = O.gen_scalars(0, SEED + 7, 0, 1 << 10)
+    f = O.Fft(10)
+    assert (f.idft(f.dft(v)) == v).all()
+    # fft_multiplication_test (fft.rs:259-291): FFT product == schoolbook, k = 5
+    a, b = O.gen_scalars(0, SEED + 8, 0, 16), O.gen_scalars(0, SEED + 9, 0, 16)
+    f5 = O.Fft(5)
+    prod = f5.idft(O.fr_vec("mul", f5.dft(a), f5.dft(b)))
+    ai = [P.from_mont(I(x), P.R_MOD) for x in a]
+    bi = [P.from_mont(I(x), P.R_MOD) for x in b]
+    want = [0] * 32
+    for i, x in enumerate(ai):
+        for j, y in enumerate(bi):
+            want[i + j] = (want[i + j] + x * y) % P.R_MOD
+    assert [P.from_mont(I(x), P.R_MOD) for x in prod] == want
