@@ -37,7 +37,8 @@ typedef enum {
   KG_ERR_BAD_ARG = -2,     /* null pointer, bad length, log_n out of range, unknown enum */
   KG_ERR_OOM = -3,         /* device allocation failed */
   KG_ERR_HIP = -4,         /* a HIP call or kernel launch failed (see kg_last_error) */
-  KG_ERR_UNSUPPORTED = -5
+  KG_ERR_UNSUPPORTED = -5,
+  KG_ERR_CRS = -6          /* delta is the identity: Error::ProverSubVersionCrsAttack (groth16/src/prover.rs:67-69) */
 } kg_status;
 
 /* field / curve selectors */
@@ -104,6 +105,34 @@ int kg_points_sum_affine(kg_ctx* ctx, int curve, const uint64_t* h_points_xy, co
                          uint64_t* out_xy, uint8_t* out_inf);
 /* Tuning knob: window width c (0 = automatic). */
 int kg_msm_set_window(kg_ctx* ctx, int c);
+
+/* ---- fixed-base multiples ------------------------------------------------------------------------
+ * out[i] = affine(generator * k[i]): the `(g * scalar).into()` of the CRS construction (groth16/src/zksnark.rs:57,
+ * 168-187), of VerifyingKey (zksnark.rs:104-112) and of Group::random (macros/curve/weierstrass/group.rs:39-41,
+ * used by PedersenCommitment::new, nova/src/pedersen.rs:10-13).  d_k: n scalars of the curve's scalar field;
+ * d_out_xy: n x (8 | 16) words; d_out_inf: n flags (k = 0 gives the identity, stored as (0, 1) + flag 1). */
+int kg_fixed_base_mul(kg_ctx* ctx, int curve, const uint64_t* d_k, size_t n, uint64_t* d_out_xy, uint8_t* d_out_inf);
+
+/* ---- Groth16 prover --------------------------------------------------------------------------------
+ * groth16/src/prover.rs:20-99 Prover::create_proof after circuit synthesis.  The CRS (groth16/src/params.rs:6-28)
+ * is resident on the device; vk elements needed for the proof assembly are host affine points. */
+typedef struct {
+  size_t m, l, m_l_1;                               /* cs.m(), cs.l(), cs.m_l_1() (zkstd/src/r1cs.rs:30-40) */
+  const uint64_t* d_h;    const uint8_t* d_h_inf;    /* m - 1 G1            */
+  const uint64_t* d_l;    const uint8_t* d_l_inf;    /* m_l_1 G1            */
+  const uint64_t* d_a;    const uint8_t* d_a_inf;    /* l + m_l_1 G1        */
+  const uint64_t* d_b_g1; const uint8_t* d_b_g1_inf; /* l + m_l_1 G1        */
+  const uint64_t* d_b_g2; const uint8_t* d_b_g2_inf; /* l + m_l_1 G2        */
+  uint64_t alpha_g1[8], beta_g1[8], delta_g1[8];    /* vk, affine x | y    */
+  uint64_t beta_g2[16], delta_g2[16];
+  uint8_t delta_g1_inf, delta_g2_inf;
+} kg_groth16_crs;
+/* d_a_eval / d_b_eval / d_c_eval: cs.evaluate() (m elements each); d_x = cs.x() (l), d_w = cs.w() (m_l_1);
+ * r, s: HOST, the prover's blinding scalars (the reference draws them from its RNG, prover.rs:71-72).
+ * proof_out: HOST, A (8) | B (16) | C (8) words, affine; proof_inf[3] identity flags. */
+int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
+                           const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
+                           const uint64_t* s, uint64_t* proof_out, uint8_t* proof_inf);
 
 /* ---- deterministic synthetic inputs (identical streams in oracle/) -------------------- */
 int kg_gen_scalars(kg_ctx* ctx, int field, uint64_t seed, size_t start, size_t n, uint64_t* d_out);

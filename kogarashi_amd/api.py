@@ -5,12 +5,13 @@ Montgomery limbs (the reference's `Fr([u64; 4])` / `Fq`), points are (x | y) row
   msm_curve_addition(bases, coeffs)            groth16/src/msm.rs:6-48
   Fft(k).dft / idft / coset_dft / coset_idft / divide_by_z_on_coset      groth16/src/fft.rs:27-154
   PedersenCommitment(g).commit(m)              nova/src/pedersen.rs:10-20
+  Prover(params).create_proof(...)             groth16/src/prover.rs:14-99
 """
 from __future__ import annotations
 
 import numpy as np
 
-from .lib import KG_FQ, KG_FR, KG_G1, KG_G2, KG_GRUMPKIN, Context
+from .lib import KG_FQ, KG_FR, KG_G1, KG_G2, KG_GRUMPKIN, Context, Groth16Crs
 
 _default_ctx = None
 CURVE_IDS = {"g1": KG_G1, "grumpkin": KG_GRUMPKIN, "gk": KG_GRUMPKIN, "g2": KG_G2}
@@ -100,3 +101,45 @@ class PedersenCommitment:
         n = min(len(m), self.len)
         d = self.ctx.upload(m[:n])
         return self.ctx.commit(self.cid, self._g.ptr, self._inf.ptr if self._inf else 0, d.ptr, n)
+
+
+class Prover:
+    """groth16::Prover { params }: the CRS (groth16/src/params.rs:6-28) is uploaded once and stays resident.
+
+    params: dict with "h", "l", "a", "b_g1" (G1 rows x|y), "b_g2" (G2 rows), optional "<name>_inf" flag arrays,
+    "vk_g1" = rows alpha_g1, beta_g1, delta_g1 and "vk_g2" = rows beta_g2, delta_g2 (affine), optional
+    "delta_g1_inf"/"delta_g2_inf"."""
+
+    def __init__(self, params: dict, m: int, l: int, m_l_1: int, ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+        self.m, self.l, self.m_l_1 = m, l, m_l_1
+        self._keep = []
+        crs = Groth16Crs()
+        crs.m, crs.l, crs.m_l_1 = m, l, m_l_1
+        for name, w in (("h", 8), ("l", 8), ("a", 8), ("b_g1", 8), ("b_g2", 16)):
+            arr = np.ascontiguousarray(params[name], dtype=np.uint64).reshape(-1, w)
+            d = self.ctx.upload(arr)
+            self._keep.append(d)
+            setattr(crs, "d_" + name, d.ptr)
+            inf = params.get(name + "_inf")
+            if inf is not None and np.any(inf):
+                di = self.ctx.upload(np.ascontiguousarray(inf, dtype=np.uint8))
+                self._keep.append(di)
+                setattr(crs, "d_" + name + "_inf", di.ptr)
+        g1 = np.ascontiguousarray(params["vk_g1"], dtype=np.uint64).reshape(-1, 8)
+        g2 = np.ascontiguousarray(params["vk_g2"], dtype=np.uint64).reshape(-1, 16)
+        for i in range(8):
+            crs.alpha_g1[i], crs.beta_g1[i], crs.delta_g1[i] = int(g1[0, i]), int(g1[1, i]), int(g1[2, i])
+        for i in range(16):
+            crs.beta_g2[i], crs.delta_g2[i] = int(g2[0, i]), int(g2[1, i])
+        crs.delta_g1_inf = int(bool(params.get("delta_g1_inf", 0)))
+        crs.delta_g2_inf = int(bool(params.get("delta_g2_inf", 0)))
+        self.crs = crs
+
+    def create_proof(self, a_eval, b_eval, c_eval, x, w, r, s):
+        """Proof {a, b, c} for the synthesised constraint system: (A, B, C) = cs.evaluate(), x = cs.x(), w = cs.w();
+        (r, s) are the blinding scalars the reference draws from its rng (prover.rs:71-72).
+        Raises ProverSubVersionCrsAttack like prover.rs:67-69."""
+        up = lambda v: self.ctx.upload(np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4))
+        da, db, dc, dx, dw = up(a_eval), up(b_eval), up(c_eval), up(x), up(w)
+        return self.ctx.groth16_prove(self.crs, da.ptr, db.ptr, dc.ptr, dx.ptr, dw.ptr, r, s)

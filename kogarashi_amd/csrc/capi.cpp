@@ -21,6 +21,14 @@ int ensure_ws2(kg_ctx* c, size_t bytes) {
   c->ws2_bytes = bytes;
   return KG_OK;
 }
+int ensure_ws3(kg_ctx* c, size_t bytes) {
+  if (bytes <= c->ws3_bytes) return KG_OK;
+  if (c->ws3) { hipStreamSynchronize(c->stream); hipFree(c->ws3); c->ws3 = nullptr; c->ws3_bytes = 0; }
+  hipError_t e = hipMalloc(&c->ws3, bytes);
+  if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "prover buffer allocation", e);
+  c->ws3_bytes = bytes;
+  return KG_OK;
+}
 int ensure_pinned(kg_ctx* c, size_t bytes) {
   if (bytes <= c->h_pinned_bytes) return KG_OK;
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -72,6 +80,7 @@ const char* kg_strerror(int s) {
     case KG_ERR_OOM: return "out of device memory";
     case KG_ERR_HIP: return "HIP runtime error";
     case KG_ERR_UNSUPPORTED: return "unsupported";
+    case KG_ERR_CRS: return "CRS delta is the identity (ProverSubVersionCrsAttack)";
     default: return "unknown status";
   }
 }
@@ -98,6 +107,7 @@ void kg_ctx_destroy(kg_ctx* c) {
   tw_cache_free(c);
   if (c->ws) hipFree(c->ws);
   if (c->ws2) hipFree(c->ws2);
+  if (c->ws3) hipFree(c->ws3);
   if (c->h_pinned) hipHostFree(c->h_pinned);
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->own_stream);

@@ -21,6 +21,8 @@ struct kg_ctx {
   size_t ws_bytes = 0;
   void* ws2 = nullptr;                   // NTT ping-pong buffer
   size_t ws2_bytes = 0;
+  void* ws3 = nullptr;                   // prover polynomial buffers
+  size_t ws3_bytes = 0;
   void* h_pinned = nullptr;              // small pinned staging buffer for results
   size_t h_pinned_bytes = 0;
   std::vector<kg_tw_cache*> tw;          // per-(log_n, inverse) twiddle tables
@@ -54,6 +56,7 @@ inline int set_err(kg_ctx* c, int code, const char* what, hipError_t e = hipSucc
 
 int ensure_ws(kg_ctx* c, size_t bytes);
 int ensure_ws2(kg_ctx* c, size_t bytes);
+int ensure_ws3(kg_ctx* c, size_t bytes);
 int ensure_pinned(kg_ctx* c, size_t bytes);
 
 // RAII-free phase timer: PhaseScope p(ctx, "name"); ... p.end();

@@ -1,0 +1,224 @@
+// groth16.hip -- fixed-base multiples and the Groth16 prover orchestration on the device.
+//
+// kg_groth16_prove_bn254 replaces groth16/src/prover.rs:20-99 (after synthesis): 6 NTTs (idft + coset_dft of the
+// A, B, C evaluation vectors, :36-41), the point-wise h = a*b - c and the division by Z on the coset (:43-46,
+// fused into one kernel here), one coset iNTT (:47), eight MSMs against the resident CRS (:51-65) and the proof
+// assembly (:71-98).  The polynomial vectors never leave HBM between steps; only the eight MSM results and the
+// three proof points touch the host, which also runs the six short scalar multiplications of the assembly
+// (sequential double-and-add, as in the reference).
+#include "common.h"
+#include "host_fp.h"
+
+using namespace kg;
+
+namespace {
+
+// ---- generator multiples --------------------------------------------------------------------------
+template <class F> struct Gen;
+template <> struct Gen<Fq> {                    // bn254/src/params.rs:8-9: (1, 2)
+  static __device__ Affine<Fq> g() {
+    uint32_t two[8] = {2, 0, 0, 0, 0, 0, 0, 0};
+    return {Fq::one(), from_int<FqParams>(two)};
+  }
+};
+template <> struct Gen<Fr> {                    // grumpkin/src/params.rs:4-10: (1, sqrt(-16))
+  static __device__ Affine<Fr> g() {
+    // GENERATOR_Y in the reference's Montgomery form, converted on the fly
+    const uint32_t y[8] = {0x448c41d8u, 0x11b2dff1u, 0x21c77dc3u, 0x23d3446fu, 0x35dfafbbu, 0xaa7b8cf4u, 0x9dc25d68u, 0x14b34cf6u};
+    return {Fr::one(), from_ref<FrParams>(y)};
+  }
+};
+template <> struct Gen<Fq2> {                   // bn254/src/params.rs:15-42 (canonical integers)
+  static __device__ Affine<Fq2> g() {
+    const uint32_t x0[8] = {0xd992f6edu, 0x46debd5cu, 0xf75edaddu, 0x674322d4u, 0x5e5c4479u, 0x426a0066u, 0x121f1e76u, 0x1800deefu};
+    const uint32_t x1[8] = {0xaef312c2u, 0x97e485b7u, 0x35a9e712u, 0xf1aa4933u, 0x31fb5d25u, 0x7260bfb7u, 0x920d483au, 0x198e9393u};
+    const uint32_t y0[8] = {0x66fa7daau, 0x4ce6cc01u, 0x0c43d37bu, 0xe3d1e769u, 0x8dcb408fu, 0x4aab7180u, 0xdb8c6debu, 0x12c85ea5u};
+    const uint32_t y1[8] = {0xd122975bu, 0x55acdadcu, 0x70b38ef3u, 0xbc4b3133u, 0x690c3395u, 0xec9e99adu, 0x585ff075u, 0x090689d0u};
+    return {{from_int<FqParams>(x0), from_int<FqParams>(x1)}, {from_int<FqParams>(y0), from_int<FqParams>(y1)}};
+  }
+};
+
+template <class P>
+__device__ __forceinline__ void put_ref(const Fp<P>& a, uint64_t* dst) {
+  uint32_t w[8];
+  to_ref(a, w);
+  store_words(dst, 0, w);
+}
+template <class F>
+__device__ __forceinline__ void put_ref(const Fp2<F>& a, uint64_t* dst) { put_ref(a.c0, dst); put_ref(a.c1, dst + 4); }
+
+// one lane per scalar: MSB-first double-and-add on the generator, then one Fermat inversion to affine
+template <class F, class SP, int E64>
+__global__ void __launch_bounds__(64) k_fixed_base_mul(const uint64_t* __restrict__ k, size_t n, uint64_t* __restrict__ out_xy, uint8_t* __restrict__ out_inf) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8], e[8];
+  load_words(k, i, w);
+  ref_to_int<SP>(w, e);
+  const Affine<F> g = Gen<F>::g();
+  XYZZ<F> acc = XYZZ<F>::identity();
+  for (int b = 253; b >= 0; --b) {
+    acc = double_xyzz(acc);
+    if ((e[b >> 5] >> (b & 31)) & 1) acc = add_mixed(acc, g);
+  }
+  Affine<F> a;
+  uint64_t* dst = out_xy + i * 2 * E64;
+  if (to_affine(acc, a)) {
+    put_ref(a.x, dst);
+    put_ref(a.y, dst + E64);
+    out_inf[i] = 0;
+  } else {                                   // (0, 1, inf): macros/curve/weierstrass/group.rs:22-26
+    put_ref(F::zero(), dst);
+    put_ref(F::one(), dst + E64);
+    out_inf[i] = 1;
+  }
+}
+
+// h[i] = (a[i] * b[i] - c[i]) * zinv   (poly.rs:168-195 + fft.rs:150-154 in one pass; data stays in ABI form)
+__global__ void __launch_bounds__(256) k_qap_combine(uint64_t* __restrict__ a, const uint64_t* __restrict__ b, const uint64_t* __restrict__ c,
+                                                     size_t n, Words8 zinv) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t wa[8], wb[8], wc[8], wo[8];
+  load_words(a, i, wa); load_words(b, i, wb); load_words(c, i, wc);
+  Fr x = from_ref<FrParams>(wa), y = from_ref<FrParams>(wb), z = from_ref<FrParams>(wc);
+  Fr t = norm(sub<4, 1>(mul(x, y), z));
+  to_ref(mul(t, from_ref<FrParams>(zinv.w)), wo);
+  store_words(a, i, wo);
+}
+
+// ---- host curve helpers (assembly of the proof, prover.rs:71-98) ---------------------------------------
+template <class HF, int E>
+Affine<HF> h_load_aff(const uint64_t* p);
+template <>
+Affine<HostFq> h_load_aff<HostFq, 4>(const uint64_t* p) { return {HostFq::from_words(p), HostFq::from_words(p + 4)}; }
+template <>
+Affine<HostFq2> h_load_aff<HostFq2, 8>(const uint64_t* p) {
+  return {{HostFq::from_words(p), HostFq::from_words(p + 4)}, {HostFq::from_words(p + 8), HostFq::from_words(p + 12)}};
+}
+// ABI projective (x, y, z in {0, 1}) -> XYZZ
+template <class HF>
+XYZZ<HF> h_from_abi(const Affine<HF>& a, bool inf) { return inf ? XYZZ<HF>::identity() : from_affine(a); }
+
+template <class HF>
+XYZZ<HF> h_scalar_mul(const XYZZ<HF>& p, const uint64_t k[4]) {
+  XYZZ<HF> acc = XYZZ<HF>::identity();
+  for (int b = 255; b >= 0; --b) {
+    acc = double_xyzz(acc);
+    if ((k[b >> 6] >> (b & 63)) & 1) acc = add_xyzz(acc, p);
+  }
+  return acc;
+}
+void h_store(const HostFq& a, uint64_t* w) { a.to_words(w); }
+void h_store(const HostFq2& a, uint64_t* w) { a.c0.to_words(w); a.c1.to_words(w + 4); }
+template <class HF, int E>
+void h_store_affine(const XYZZ<HF>& p, uint64_t* xy, uint8_t* inf) {
+  Affine<HF> a;
+  if (to_affine(p, a)) { h_store(a.x, xy); h_store(a.y, xy + E); *inf = 0; }
+  else { h_store(HF::zero(), xy); h_store(HF::one(), xy + E); *inf = 1; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int kg_fixed_base_mul(kg_ctx* ctx, int curve, const uint64_t* d_k, size_t n, uint64_t* d_out_xy, uint8_t* d_out_inf) {
+  if (!ctx || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
+  if (n == 0) return KG_OK;
+  if (!d_k || !d_out_xy || !d_out_inf) return KG_ERR_BAD_ARG;
+  KG_HIP(ctx, hipSetDevice(ctx->device));
+  dim3 grid((unsigned)((n + 63) / 64));
+  if (curve == KG_G1) hipLaunchKernelGGL((k_fixed_base_mul<Fq, FrParams, 4>), grid, dim3(64), 0, ctx->stream, d_k, n, d_out_xy, d_out_inf);
+  else if (curve == KG_GRUMPKIN) hipLaunchKernelGGL((k_fixed_base_mul<Fr, FqParams, 4>), grid, dim3(64), 0, ctx->stream, d_k, n, d_out_xy, d_out_inf);
+  else hipLaunchKernelGGL((k_fixed_base_mul<Fq2, FrParams, 8>), grid, dim3(64), 0, ctx->stream, d_k, n, d_out_xy, d_out_inf);
+  KG_HIP(ctx, hipGetLastError());
+  return KG_OK;
+}
+
+int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
+                           const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
+                           const uint64_t* s, uint64_t* proof_out, uint8_t* proof_inf) {
+  if (!ctx || !crs || !d_a_eval || !d_b_eval || !d_c_eval || !d_x || !r || !s || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
+  const size_t m = crs->m, l = crs->l, m_l_1 = crs->m_l_1;
+  if (m < 1 || l < 1 || (m_l_1 && !d_w)) return KG_ERR_BAD_ARG;
+  KG_HIP(ctx, hipSetDevice(ctx->device));
+  uint32_t k = 0;
+  size_t n = 1;
+  while (n < m) { n <<= 1; ++k; }                       // cs.m().next_power_of_two() (prover.rs:28-29)
+  if (k < 1) { k = 1; n = 2; }
+  if (k > 28) return KG_ERR_BAD_ARG;
+  hipStream_t st = ctx->stream;
+  KG_TRY(ensure_ws3(ctx, 3 * n * 32));
+  uint64_t* A = (uint64_t*)ctx->ws3;
+  uint64_t* B = A + 4 * n;
+  uint64_t* C = B + 4 * n;
+  const uint64_t* src[3] = {d_a_eval, d_b_eval, d_c_eval};
+  uint64_t* dst[3] = {A, B, C};
+  for (int v = 0; v < 3; ++v) {                         // prepare_fft zero padding, then idft + coset_dft (prover.rs:36-41)
+    KG_HIP(ctx, hipMemcpyAsync(dst[v], src[v], m * 32, hipMemcpyDeviceToDevice, st));
+    if (n > m) KG_HIP(ctx, hipMemsetAsync(dst[v] + 4 * m, 0, (n - m) * 32, st));
+    KG_TRY(kg_ntt_bn254_fr(ctx, dst[v], k, 1, 0));
+    KG_TRY(kg_ntt_bn254_fr(ctx, dst[v], k, 0, 1));
+  }
+  // (7^n - 1)^-1 on the host: n = 2^k squarings of 7
+  HostFr seven = HostFr::one();
+  {
+    HostFr one = HostFr::one(), acc = HostFr::zero();
+    for (int i = 0; i < 7; ++i) acc = add(acc, one);
+    seven = acc;
+  }
+  HostFr z = seven;
+  for (uint32_t i = 0; i < k; ++i) z = sqr(z);
+  z = inv(sub<4, 1>(z, HostFr::one()));                 // z_on_coset().invert() (fft.rs:141-151)
+  Words8 zw;
+  for (int i = 0; i < 4; ++i) { zw.w[2 * i] = (uint32_t)z.v[i]; zw.w[2 * i + 1] = (uint32_t)(z.v[i] >> 32); }
+  hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, C, n, zw);
+  KG_HIP(ctx, hipGetLastError());
+  KG_TRY(kg_ntt_bn254_fr(ctx, A, k, 1, 1));             // coset_idft (prover.rs:47)
+
+  // the eight MSMs (prover.rs:51-65).  q keeps its trailing zeros: zero scalars are skipped by the MSM, which is
+  // what Coefficients::new's trimming plus zip achieves in the reference (poly.rs:61-63, msm.rs:25).
+  const size_t hn = (m - 1) < n ? (m - 1) : n;
+  uint64_t q_p[12], l_p[12], ai[12], aa[12], b1i[12], b1a[12], b2i[24], b2a[24];
+  KG_TRY(kg_msm(ctx, KG_G1, crs->d_h, crs->d_h_inf, A, hn, q_p));
+  KG_TRY(kg_msm(ctx, KG_G1, crs->d_l, crs->d_l_inf, d_w, m_l_1, l_p));
+  KG_TRY(kg_msm(ctx, KG_G1, crs->d_a, crs->d_a_inf, d_x, l, ai));
+  KG_TRY(kg_msm(ctx, KG_G1, crs->d_a + 8 * l, crs->d_a_inf ? crs->d_a_inf + l : nullptr, d_w, m_l_1, aa));
+  KG_TRY(kg_msm(ctx, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, d_x, l, b1i));
+  KG_TRY(kg_msm(ctx, KG_G1, crs->d_b_g1 + 8 * l, crs->d_b_g1_inf ? crs->d_b_g1_inf + l : nullptr, d_w, m_l_1, b1a));
+  KG_TRY(kg_msm(ctx, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, d_x, l, b2i));
+  KG_TRY(kg_msm(ctx, KG_G2, crs->d_b_g2 + 16 * l, crs->d_b_g2_inf ? crs->d_b_g2_inf + l : nullptr, d_w, m_l_1, b2a));
+  if (crs->delta_g1_inf || crs->delta_g2_inf) return set_err(ctx, KG_ERR_CRS, "delta is the identity");   // prover.rs:67-69
+
+  // assembly (prover.rs:71-98) on the host
+  auto g1pt = [](const uint64_t* xyz) {
+    bool inf = !(xyz[8] | xyz[9] | xyz[10] | xyz[11]);
+    return h_from_abi<HostFq>(h_load_aff<HostFq, 4>(xyz), inf);
+  };
+  auto g2pt = [](const uint64_t* xyz) {
+    bool inf = true;
+    for (int i = 16; i < 24; ++i) inf = inf && xyz[i] == 0;
+    return h_from_abi<HostFq2>(h_load_aff<HostFq2, 8>(xyz), inf);
+  };
+  HostFr rm = HostFr::from_words(r), sm = HostFr::from_words(s);
+  HostFr raw_one{{1, 0, 0, 0}};
+  HostFr rk = mul(rm, raw_one), sk = mul(sm, raw_one), rsk = mul(mul(rm, sm), raw_one);   // out of Montgomery form
+  XYZZ<HostFq> alpha = from_affine(h_load_aff<HostFq, 4>(crs->alpha_g1)), beta1 = from_affine(h_load_aff<HostFq, 4>(crs->beta_g1)),
+               delta1 = from_affine(h_load_aff<HostFq, 4>(crs->delta_g1));
+  XYZZ<HostFq2> beta2 = from_affine(h_load_aff<HostFq2, 8>(crs->beta_g2)), delta2 = from_affine(h_load_aff<HostFq2, 8>(crs->delta_g2));
+  XYZZ<HostFq> a_ans = add_xyzz(g1pt(ai), g1pt(aa));
+  XYZZ<HostFq> b1_ans = add_xyzz(g1pt(b1i), g1pt(b1a));
+  XYZZ<HostFq2> b2_ans = add_xyzz(g2pt(b2i), g2pt(b2a));
+  XYZZ<HostFq> g_a = add_xyzz(add_xyzz(h_scalar_mul(delta1, rk.v), alpha), a_ans);                         // :75,81
+  XYZZ<HostFq2> g_b = add_xyzz(add_xyzz(h_scalar_mul(delta2, sk.v), beta2), b2_ans);                       // :76,88
+  XYZZ<HostFq> g_c = add_xyzz(add_xyzz(h_scalar_mul(delta1, rsk.v), h_scalar_mul(alpha, sk.v)), h_scalar_mul(beta1, rk.v));   // :77
+  g_c = add_xyzz(g_c, h_scalar_mul(a_ans, sk.v));                                                          // :83
+  g_c = add_xyzz(g_c, h_scalar_mul(b1_ans, rk.v));                                                         // :90
+  g_c = add_xyzz(g_c, add_xyzz(g1pt(q_p), g1pt(l_p)));                                                     // :92
+  h_store_affine<HostFq, 4>(g_a, proof_out, proof_inf);
+  h_store_affine<HostFq2, 8>(g_b, proof_out + 8, proof_inf + 1);
+  h_store_affine<HostFq, 4>(g_c, proof_out + 24, proof_inf + 2);
+  return KG_OK;
+}
+
+}  // extern "C"

@@ -21,11 +21,27 @@ EXPORTS = [
     "kg_ctx_sync", "kg_malloc", "kg_free", "kg_memcpy_h2d", "kg_memcpy_d2h", "kg_memcpy_d2d", "kg_field_vec_op",
     "kg_field_vec_scale", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_msm", "kg_msm_host", "kg_commit",
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
+    "kg_fixed_base_mul", "kg_groth16_prove_bn254",
 ]
+
+
+class Groth16Crs(C.Structure):
+    """kg_groth16_crs of include/kogarashi_amd.h"""
+    _fields_ = [("m", C.c_size_t), ("l", C.c_size_t), ("m_l_1", C.c_size_t),
+                ("d_h", C.c_void_p), ("d_h_inf", C.c_void_p), ("d_l", C.c_void_p), ("d_l_inf", C.c_void_p),
+                ("d_a", C.c_void_p), ("d_a_inf", C.c_void_p), ("d_b_g1", C.c_void_p), ("d_b_g1_inf", C.c_void_p),
+                ("d_b_g2", C.c_void_p), ("d_b_g2_inf", C.c_void_p),
+                ("alpha_g1", C.c_uint64 * 8), ("beta_g1", C.c_uint64 * 8), ("delta_g1", C.c_uint64 * 8),
+                ("beta_g2", C.c_uint64 * 16), ("delta_g2", C.c_uint64 * 16),
+                ("delta_g1_inf", C.c_uint8), ("delta_g2_inf", C.c_uint8)]
 
 
 class KogarashiError(RuntimeError):
     pass
+
+
+class ProverSubVersionCrsAttack(KogarashiError):
+    """groth16::Error::ProverSubVersionCrsAttack (groth16/src/error.rs:2-8, prover.rs:67-69)"""
 
 
 _lib = None
@@ -162,6 +178,22 @@ class Context:
 
     def gen_bases(self, curve: int, seed: int, start: int, n: int, out: int):
         self._chk(self._lib.kg_gen_bases(self._h, curve, C.c_uint64(seed), C.c_size_t(start), C.c_size_t(n), _vp(out)), "kg_gen_bases")
+
+    def fixed_base_mul(self, curve: int, k: int, n: int, out_xy: int, out_inf: int):
+        self._chk(self._lib.kg_fixed_base_mul(self._h, curve, _vp(k), C.c_size_t(n), _vp(out_xy), _vp(out_inf)), "kg_fixed_base_mul")
+
+    def groth16_prove(self, crs: "Groth16Crs", a_eval: int, b_eval: int, c_eval: int, x: int, w: int, r: np.ndarray, s: np.ndarray):
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        s = np.ascontiguousarray(s, dtype=np.uint64)
+        out = np.zeros(32, dtype=np.uint64)
+        inf = np.zeros(3, dtype=np.uint8)
+        rc = self._lib.kg_groth16_prove_bn254(self._h, C.byref(crs), _vp(a_eval), _vp(b_eval), _vp(c_eval), _vp(x), _vp(w),
+                                              r.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p),
+                                              out.ctypes.data_as(C.c_void_p), inf.ctypes.data_as(C.c_void_p))
+        if rc == -6:
+            raise ProverSubVersionCrsAttack("delta is the identity")
+        self._chk(rc, "kg_groth16_prove_bn254")
+        return out[:8].copy(), out[8:24].copy(), out[24:].copy(), inf
 
     def profile_enable(self, on: bool = True):
         self._chk(self._lib.kg_profile_enable(self._h, int(on)), "kg_profile_enable")

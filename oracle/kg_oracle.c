@@ -585,4 +585,6 @@ void kgo_gen_bases_mt(int curve, u64 seed, size_t start, size_t n, u64 *out, int
     }
     for (int t = 0; t < used; t++) pthread_join(th[t], NULL);
 }
+#include "kg_oracle_groth16.inc"
+
 int kgo_version(void) { return 1; }

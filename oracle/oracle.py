@@ -295,3 +295,110 @@ def gen_bases(curve, seed, start, n, threads=8):
     o = np.empty((n, 8), dtype=np.uint64)
     lib().kgo_gen_bases_mt(curve, C.c_uint64(seed), C.c_size_t(start), C.c_size_t(n), _p(o), int(threads))
     return o
+
+
+# ---- Groth16 (oracle/kg_oracle_groth16.inc) -------------------------------------------------------
+class R1cs:
+    """Minimal R1CS container: CSR matrices over z = x || w (instance wires first), zkstd/src/r1cs.rs:11-27."""
+
+    def __init__(self, a, b, c, x, w):
+        self.a, self.b, self.c = a, b, c            # each: (row_ptr uint64[m+1], col uint64[nnz], val uint64[nnz,4])
+        self.x, self.w = _arr(x).reshape(-1, 4), _arr(w).reshape(-1, 4)
+        self.m, self.l, self.m_l_1 = len(a[0]) - 1, len(self.x), len(self.w)
+
+    def evaluate(self):
+        """cs.evaluate() (r1cs.rs:137-142): (A z, B z, C z)."""
+        z = np.ascontiguousarray(np.concatenate([self.x, self.w]))
+        outs = []
+        for rp, col, val in (self.a, self.b, self.c):
+            o = np.empty((self.m, 4), dtype=np.uint64)
+            lib().kgo_r1cs_evaluate(_p(rp), _p(col), _p(val), C.c_size_t(self.m), _p(z), _p(o))
+            outs.append(o)
+        return outs
+
+
+def chain_r1cs(m: int, t0_mont):
+    """Synthetic circuit of SURVEY.md 8d(4): t_{i+1} = t_i * (t_i + 1), i < m; x = [1, t_0], w = [t_1 .. t_m].
+    Constraint i: A = t_i, B = t_i + ONE, C = t_{i+1} (a FieldAssignment::mul gate on linear combinations)."""
+    one = f_consts(FR)["r"]
+    t = [_arr(t0_mont)]
+    for _ in range(m):
+        t.append(f_mul(FR, t[-1], f_add(FR, t[-1], one)))
+    x = np.stack([one, t[0]])
+    w = np.stack(t[1:])
+    wire = lambda i: np.uint64(1) if i == 0 else np.uint64(2 + i - 1)        # t_0 is instance wire 1; t_i (i>0) is witness i-1 -> column l + (i-1), l = 2
+    a_rp = np.arange(m + 1, dtype=np.uint64)
+    a_col = np.array([wire(i) for i in range(m)], dtype=np.uint64)
+    a_val = np.tile(one, (m, 1))
+    b_rp = np.arange(0, 2 * m + 1, 2, dtype=np.uint64)
+    b_col = np.empty(2 * m, dtype=np.uint64)
+    b_col[0::2] = a_col
+    b_col[1::2] = 0
+    b_val = np.tile(one, (2 * m, 1))
+    c_rp = np.arange(m + 1, dtype=np.uint64)
+    c_col = np.array([wire(i + 1) for i in range(m)], dtype=np.uint64)
+    c_val = np.tile(one, (m, 1))
+    return R1cs((a_rp, a_col, np.ascontiguousarray(a_val)), (b_rp, b_col, np.ascontiguousarray(b_val)),
+                (c_rp, c_col, np.ascontiguousarray(c_val)), x, w)
+
+
+def groth16_setup_scalars(cs: R1cs, toxic):
+    """zksnark.rs:17-127, scalar half.  toxic = (alpha, beta, gamma, delta, tau) Montgomery Fr, shape (5, 4)."""
+    toxic = _arr(toxic).reshape(5, 4)
+    nv = cs.l + cs.m_l_1
+    h = np.zeros((max(cs.m - 1, 0), 4), dtype=np.uint64)
+    lq = np.zeros((cs.m_l_1, 4), dtype=np.uint64)
+    a = np.zeros((nv, 4), dtype=np.uint64)
+    b = np.zeros((nv, 4), dtype=np.uint64)
+    ic = np.zeros((cs.l, 4), dtype=np.uint64)
+    rc = lib().kgo_groth16_setup_scalars(_p(cs.a[0]), _p(cs.a[1]), _p(cs.a[2]), _p(cs.b[0]), _p(cs.b[1]), _p(cs.b[2]),
+                                         _p(cs.c[0]), _p(cs.c[1]), _p(cs.c[2]), C.c_size_t(cs.m), C.c_size_t(cs.l), C.c_size_t(cs.m_l_1),
+                                         _p(toxic), _p(h), _p(lq), _p(a), _p(b), _p(ic))
+    if rc:
+        raise ValueError("ProverInversionFailed")
+    return {"h": h, "l": lq, "a": a, "b": b, "ic": ic}
+
+
+def fixed_base_mul(curve: int, k, threads=8):
+    """generator * k -> (affine x|y, inf flags); curve 0 G1, 1 Grumpkin, 2 G2."""
+    k = _arr(k).reshape(-1, 4)
+    w = 16 if curve == 2 else 8
+    xy = np.zeros((len(k), w), dtype=np.uint64)
+    inf = np.zeros(len(k), dtype=np.uint8)
+    if len(k):
+        lib().kgo_fixed_base_mul(curve, _p(k), C.c_size_t(len(k)), _p(xy), _u8(inf), int(threads))
+    return xy, inf
+
+
+def groth16_params(cs: R1cs, toxic, threads=8):
+    """Full Parameters (groth16/src/params.rs:6-28) by the oracle: scalars, then generator multiples."""
+    sc = groth16_setup_scalars(cs, toxic)
+    toxic = _arr(toxic).reshape(5, 4)
+    P = {}
+    P["h"], P["h_inf"] = fixed_base_mul(0, sc["h"], threads)
+    P["l"], P["l_inf"] = fixed_base_mul(0, sc["l"], threads)
+    P["a"], P["a_inf"] = fixed_base_mul(0, sc["a"], threads)
+    P["b_g1"], P["b_g1_inf"] = fixed_base_mul(0, sc["b"], threads)
+    P["b_g2"], P["b_g2_inf"] = fixed_base_mul(2, sc["b"], threads)
+    P["ic"], P["ic_inf"] = fixed_base_mul(0, sc["ic"], threads)
+    g1, _ = fixed_base_mul(0, np.stack([toxic[0], toxic[1], toxic[3]]), 1)        # alpha_g1, beta_g1, delta_g1
+    g2, _ = fixed_base_mul(2, np.stack([toxic[1], toxic[3], toxic[2]]), 1)        # beta_g2, delta_g2, gamma_g2
+    P["vk_g1"], P["vk_g2"] = g1, g2
+    P["scalars"] = sc
+    return P
+
+
+def groth16_prove(cs: R1cs, P, r, s, threads=8, evals=None):
+    """Prover::create_proof (prover.rs:20-99) with injected (r, s).  Returns (A xy[8], B xy[16], C xy[8], inf[3])."""
+    a_ev, b_ev, c_ev = evals if evals is not None else cs.evaluate()
+    out = np.zeros(32, dtype=np.uint64)
+    inf = np.zeros(3, dtype=np.uint8)
+    r, s = _arr(r), _arr(s)
+    rc = lib().kgo_groth16_prove(_p(a_ev), _p(b_ev), _p(c_ev), C.c_size_t(cs.m), _p(cs.x), C.c_size_t(cs.l), _p(cs.w), C.c_size_t(cs.m_l_1),
+                                 _p(P["h"]), _u8(P["h_inf"]), _p(P["l"]), _u8(P["l_inf"]), _p(P["a"]), _u8(P["a_inf"]),
+                                 _p(P["b_g1"]), _u8(P["b_g1_inf"]), _p(P["b_g2"]), _u8(P["b_g2_inf"]),
+                                 _p(np.ascontiguousarray(P["vk_g1"])), _p(np.ascontiguousarray(P["vk_g2"][:2])), 0,
+                                 _p(r), _p(s), _p(out), _u8(inf), int(threads))
+    if rc:
+        raise ValueError("ProverSubVersionCrsAttack")
+    return out[:8].copy(), out[8:24].copy(), out[24:].copy(), inf

@@ -1,0 +1,64 @@
+"""Groth16 prover and fixed-base multiples on the GPU vs the oracle's restatement of groth16/src/{zksnark,prover}.rs.
+The proof is unique given (CRS, witness, r, s); parity is bit equality of the three affine points."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = 0x4B6F676172617368
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import kogarashi_amd as K
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("curve,sfd,w", [(0, 0, 8), (1, 1, 8), (2, 0, 16)])
+def test_fixed_base_mul(ctx, oracle, curve, sfd, w):
+    O = oracle
+    n = 70 if curve != 2 else 24
+    k = O.gen_scalars(sfd, SEED + 300 + curve, 0, n)
+    k[0] = 0
+    k[1] = O.f_consts(sfd)["r"]                   # 1 * G
+    k[2] = O.f_neg(sfd, O.f_consts(sfd)["r"])     # -1 * G
+    dk = ctx.upload(k)
+    dxy, dinf = ctx.empty((n, w)), ctx.empty((n,), dtype=np.uint8)
+    ctx.fixed_base_mul(curve, dk.ptr, n, dxy.ptr, dinf.ptr)
+    want_xy, want_inf = O.fixed_base_mul(curve, k)
+    assert (dinf.numpy() == want_inf).all() and want_inf[0] == 1
+    assert (dxy.numpy() == want_xy).all()
+
+
+@pytest.mark.parametrize("m", [1, 2, 5, 16, 100, 1024])
+def test_groth16_proof_matches_oracle(ctx, oracle, m):
+    import kogarashi_amd as K
+    O = oracle
+    t0 = O.gen_scalars(0, SEED + 400 + m, 0, 1)[0]
+    cs = O.chain_r1cs(m, t0)
+    toxic = O.gen_scalars(0, SEED + 401, 0, 5)
+    params = O.groth16_params(cs, toxic, threads=8)
+    r, s = O.gen_scalars(0, SEED + 402, 0, 2)
+    a, b, c = cs.evaluate()
+    want = O.groth16_prove(cs, params, r, s, evals=(a, b, c))
+    params["vk_g2"] = params["vk_g2"][:2]
+    prover = K.Prover(params, cs.m, cs.l, cs.m_l_1, ctx=ctx)
+    got = prover.create_proof(a, b, c, cs.x, cs.w, r, s)
+    for g, w_, name in zip(got[:3], want[:3], "ABC"):
+        assert (g == w_).all(), name
+    assert (got[3] == want[3]).all()
+
+
+def test_groth16_rejects_identity_delta(ctx, oracle):
+    import kogarashi_amd as K
+    from kogarashi_amd.lib import ProverSubVersionCrsAttack
+    O = oracle
+    cs = O.chain_r1cs(4, O.gen_scalars(0, SEED + 410, 0, 1)[0])
+    params = O.groth16_params(cs, O.gen_scalars(0, SEED + 411, 0, 5))
+    params["vk_g2"] = params["vk_g2"][:2]
+    params["delta_g1_inf"] = 1
+    a, b, c = cs.evaluate()
+    r, s = O.gen_scalars(0, SEED + 412, 0, 2)
+    with pytest.raises(ProverSubVersionCrsAttack):
+        K.Prover(params, cs.m, cs.l, cs.m_l_1, ctx=ctx).create_proof(a, b, c, cs.x, cs.w, r, s)
