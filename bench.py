@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-groth16", action="store_true")
+    ap.add_argument("--groth16-log-m", type=int, default=18)
     ap.add_argument("--window", type=int, default=0)
     args = ap.parse_args()
 
@@ -124,6 +126,8 @@ def main():
             line["ntt"] = bench_ntt(ctx, torch, dev, K)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ctx, K, bases, scalars, n, res)
+        if not args.no_groth16:
+            line["groth16"] = bench_groth16(ctx, torch, dev, K, args.groth16_log_m, cpu=not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
@@ -149,6 +153,83 @@ def bench_ntt(ctx, torch, dev, K, log_n=22, steps=10):
     return {"metric": "bn254_fr_ntt_elements_per_sec", "log_n": log_n, "value": n / (ms * 1e-3), "ms": ms,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes": 64 * n}}
+
+
+def bench_groth16(ctx, torch, dev, K, log_m=18, steps=3, cpu=True):
+    """secondary line: Groth16 prove at m = 2^log_m constraints (BASELINE.json configs[3]).  Circuit: the chain
+    t_{i+1} = t_i * (t_i + 1) (x = [1, t_0], w = t_1..t_m); CRS: uniform valid curve points of the right shapes
+    (throughput does not depend on the CRS being a trapdoor image; tests/test_gpu_groth16.py proves parity on real
+    CRSs); fixed (r, s).  The CPU leg runs the oracle's create_proof on the same inputs and compares the proof."""
+    import numpy as np
+    from kogarashi_amd.lib import Groth16Crs
+    R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    m = 1 << log_m
+    l, m_l_1 = 2, m
+    t = [0x123456789ABCDEF0123456789ABCDEF % R_MOD]
+    for _ in range(m):
+        t.append(t[-1] * (t[-1] + 1) % R_MOD)
+    mont = lambda v: [((v << 256) % R_MOD >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
+    tm = np.array([mont(v) for v in t], dtype=np.uint64)
+    one = np.array(mont(1), dtype=np.uint64)
+    a_ev = tm[:m].copy()
+    b_ev = np.array([mont((v + 1) % R_MOD) for v in t[:m]], dtype=np.uint64)
+    c_ev = tm[1:].copy()
+    x = np.stack([one, tm[0]])
+    w = tm[1:].copy()
+    up = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(dev)
+    d_a, d_b, d_c, d_x, d_w = up(a_ev), up(b_ev), up(c_ev), up(x), up(w)
+    nv = l + m_l_1
+    # CRS-shaped inputs generated on the device
+    g1 = {name: torch.empty(cnt * 8, dtype=torch.int64, device=dev) for name, cnt in (("h", m - 1), ("l", m_l_1), ("a", nv), ("b_g1", nv))}
+    for i, (name, cnt) in enumerate((("h", m - 1), ("l", m_l_1), ("a", nv), ("b_g1", nv))):
+        ctx.gen_bases(K.KG_G1, SEED + 20 + i, 0, cnt, g1[name].data_ptr())
+    k2 = torch.empty(nv * 4, dtype=torch.int64, device=dev)
+    ctx.gen_scalars(K.KG_FR, SEED + 30, 0, nv, k2.data_ptr())
+    b_g2 = torch.empty(nv * 16, dtype=torch.int64, device=dev)
+    b_g2_inf = torch.empty(nv, dtype=torch.uint8, device=dev)
+    ctx.fixed_base_mul(K.KG_G2, k2.data_ptr(), nv, b_g2.data_ptr(), b_g2_inf.data_ptr())
+    vk1 = torch.empty(3 * 8, dtype=torch.int64, device=dev)
+    ctx.gen_bases(K.KG_G1, SEED + 40, 0, 3, vk1.data_ptr())
+    torch.cuda.synchronize()
+    vk_g1 = vk1.cpu().numpy().view(np.uint64).reshape(3, 8)
+    vk_g2 = b_g2[: 2 * 16].cpu().numpy().view(np.uint64).reshape(2, 16)       # any two valid G2 points
+    crs = Groth16Crs()
+    crs.m, crs.l, crs.m_l_1 = m, l, m_l_1
+    crs.d_h, crs.d_l, crs.d_a, crs.d_b_g1, crs.d_b_g2 = (g1["h"].data_ptr(), g1["l"].data_ptr(), g1["a"].data_ptr(),
+                                                          g1["b_g1"].data_ptr(), b_g2.data_ptr())
+    for i in range(8):
+        crs.alpha_g1[i], crs.beta_g1[i], crs.delta_g1[i] = int(vk_g1[0, i]), int(vk_g1[1, i]), int(vk_g1[2, i])
+    for i in range(16):
+        crs.beta_g2[i], crs.delta_g2[i] = int(vk_g2[0, i]), int(vk_g2[1, i])
+    r = np.array(mont(0x1111111111111111222222222222222233333333333333334444444444444 % R_MOD), dtype=np.uint64)
+    s_ = np.array(mont(0x5555555555555555666666666666666677777777777777778888888888888 % R_MOD), dtype=np.uint64)
+    prove = lambda: ctx.groth16_prove(crs, d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), d_x.data_ptr(), d_w.data_ptr(), r, s_)
+    proof = prove()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = prove()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"metric": "groth16_proofs_per_sec", "log_m": log_m, "value": 1.0 / dt, "ms_per_proof": dt * 1e3,
+           "algorithmic_bytes_per_proof": (7 * 64 + 4 * 32 + 4 * 96 + 160) * m}      # SURVEY.md 8d: 1120 B per constraint
+    out["roofline"] = {"bound": "hbm", "achieved": out["algorithmic_bytes_per_proof"] / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": out["algorithmic_bytes_per_proof"] / dt / 1e9 / HBM_PEAK_GBS}
+    if cpu:
+        from oracle import oracle as O
+        host = lambda tns, wd: tns.cpu().numpy().view(np.uint64).reshape(-1, wd)
+        P = {"h": host(g1["h"], 8), "l": host(g1["l"], 8), "a": host(g1["a"], 8), "b_g1": host(g1["b_g1"], 8), "b_g2": host(b_g2, 16),
+             "h_inf": None, "l_inf": None, "a_inf": None, "b_g1_inf": None, "b_g2_inf": b_g2_inf.cpu().numpy(),
+             "vk_g1": vk_g1, "vk_g2": np.concatenate([vk_g2, vk_g2[:1]])}
+        cs = O.R1cs((np.zeros(m + 1, dtype=np.uint64),) * 3, (np.zeros(m + 1, dtype=np.uint64),) * 3, (np.zeros(m + 1, dtype=np.uint64),) * 3, x, w)
+        threads = min(32, os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        want = O.groth16_prove(cs, P, r, s_, threads=threads, evals=(a_ev, b_ev, c_ev))
+        cdt = time.perf_counter() - t0
+        same = all((g == w_).all() for g, w_ in zip(proof[:3], want[:3])) and (proof[3] == want[3]).all()
+        out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "proofs/s", "cores": threads, "kind": "port",
+                               "sample": f"one full proof at m = 2^{log_m}, {cdt:.2f} s", "gpu_matches_cpu_at_full_size": bool(same)}
+    return out
 
 
 def cpu_baseline(ctx, K, bases, scalars, n, gpu_result):
