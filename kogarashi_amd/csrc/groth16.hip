@@ -148,7 +148,7 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   if (k < 1) { k = 1; n = 2; }
   if (k > 28) return KG_ERR_BAD_ARG;
   hipStream_t st = ctx->stream;
-  KG_TRY(ensure_ws3(ctx, 3 * n * 32));
+  KG_TRY(ensure_ws3(ctx, (3 * n + l + m_l_1) * 32));
   uint64_t* A = (uint64_t*)ctx->ws3;
   uint64_t* B = A + 4 * n;
   uint64_t* C = B + 4 * n;
@@ -176,18 +176,23 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   KG_HIP(ctx, hipGetLastError());
   KG_TRY(kg_ntt_bn254_fr(ctx, A, k, 1, 1));             // coset_idft (prover.rs:47)
 
-  // the eight MSMs (prover.rs:51-65).  q keeps its trailing zeros: zero scalars are skipped by the MSM, which is
-  // what Coefficients::new's trimming plus zip achieves in the reference (poly.rs:61-63, msm.rs:25).
+  // The eight MSMs of prover.rs:51-65 as five: a_inputs + a_aux (:58-59,80) is one MSM of a[..] against
+  // z = x || w, likewise b_g1 (:61-62,85) and b_g2 (:64-65,86) -- the sums are what the proof uses.
+  // q keeps its trailing zeros: zero scalars are skipped by the MSM, which is what Coefficients::new's
+  // trimming plus zip achieves in the reference (poly.rs:61-63, msm.rs:25).
   const size_t hn = (m - 1) < n ? (m - 1) : n;
+  const size_t nz = l + m_l_1;
+  uint64_t* Z = C + 4 * n;                                // z = x || w
+  KG_HIP(ctx, hipMemcpyAsync(Z, d_x, l * 32, hipMemcpyDeviceToDevice, st));
+  if (m_l_1) KG_HIP(ctx, hipMemcpyAsync(Z + 4 * l, d_w, m_l_1 * 32, hipMemcpyDeviceToDevice, st));
   uint64_t q_p[12], l_p[12], ai[12], aa[12], b1i[12], b1a[12], b2i[24], b2a[24];
   KG_TRY(kg_msm(ctx, KG_G1, crs->d_h, crs->d_h_inf, A, hn, q_p));
   KG_TRY(kg_msm(ctx, KG_G1, crs->d_l, crs->d_l_inf, d_w, m_l_1, l_p));
-  KG_TRY(kg_msm(ctx, KG_G1, crs->d_a, crs->d_a_inf, d_x, l, ai));
-  KG_TRY(kg_msm(ctx, KG_G1, crs->d_a + 8 * l, crs->d_a_inf ? crs->d_a_inf + l : nullptr, d_w, m_l_1, aa));
-  KG_TRY(kg_msm(ctx, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, d_x, l, b1i));
-  KG_TRY(kg_msm(ctx, KG_G1, crs->d_b_g1 + 8 * l, crs->d_b_g1_inf ? crs->d_b_g1_inf + l : nullptr, d_w, m_l_1, b1a));
-  KG_TRY(kg_msm(ctx, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, d_x, l, b2i));
-  KG_TRY(kg_msm(ctx, KG_G2, crs->d_b_g2 + 16 * l, crs->d_b_g2_inf ? crs->d_b_g2_inf + l : nullptr, d_w, m_l_1, b2a));
+  KG_TRY(kg_msm(ctx, KG_G1, crs->d_a, crs->d_a_inf, Z, nz, ai));
+  KG_TRY(kg_msm(ctx, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, Z, nz, b1i));
+  KG_TRY(kg_msm(ctx, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, Z, nz, b2i));
+  for (int i = 0; i < 12; ++i) aa[i] = b1a[i] = 0;       // identity (0, *, 0): the partner sums are folded in
+  for (int i = 0; i < 24; ++i) b2a[i] = 0;
   if (crs->delta_g1_inf || crs->delta_g2_inf) return set_err(ctx, KG_ERR_CRS, "delta is the identity");   // prover.rs:67-69
 
   // assembly (prover.rs:71-98) on the host

@@ -265,6 +265,48 @@ __global__ void k_row_bases(const uint32_t* __restrict__ row_total, int W, uint3
   info[1] = maxv ? *maxv : 0;
 }
 
+// Partial sums are written by lanes in length order but indexed by task id, so they use an array-of-structures
+// layout (NW contiguous words per point, 16-byte vector accesses): a scattered point costs whole cache lines,
+// not one sector per limb.
+template <class F>
+struct PointAoS {
+  static constexpr int NW = PointIO<F>::NW;
+  static __device__ __forceinline__ void store(uint32_t* base, size_t i, const XYZZ<F>& p) {
+    uint32_t w[NW];
+    pack(p, w);
+    uint4* dst = reinterpret_cast<uint4*>(base + i * NW);
+#pragma unroll
+    for (int j = 0; j < NW / 4; ++j) dst[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+  }
+  static __device__ __forceinline__ XYZZ<F> load(const uint32_t* base, size_t i) {
+    uint32_t w[NW];
+    const uint4* src = reinterpret_cast<const uint4*>(base + i * NW);
+#pragma unroll
+    for (int j = 0; j < NW / 4; ++j) { uint4 v = src[j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
+    return unpack(w);
+  }
+  template <class P> static __device__ __forceinline__ void put(const Fp<P>& a, uint32_t* w) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = a.l[k];
+  }
+  template <class G> static __device__ __forceinline__ void put(const Fp2<G>& a, uint32_t* w) { put(a.c0, w); put(a.c1, w + 9); }
+  template <class P> static __device__ __forceinline__ void get(Fp<P>& a, const uint32_t* w) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a.l[k] = w[k];
+  }
+  template <class G> static __device__ __forceinline__ void get(Fp2<G>& a, const uint32_t* w) { get(a.c0, w); get(a.c1, w + 9); }
+  static __device__ __forceinline__ void pack(const XYZZ<F>& p, uint32_t* w) {
+    constexpr int E = RawIO<F>::NW;
+    put(p.x, w); put(p.y, w + E); put(p.zz, w + 2 * E); put(p.zzz, w + 3 * E);
+  }
+  static __device__ __forceinline__ XYZZ<F> unpack(const uint32_t* w) {
+    constexpr int E = RawIO<F>::NW;
+    XYZZ<F> p;
+    get(p.x, w); get(p.y, w + E); get(p.zz, w + 2 * E); get(p.zzz, w + 3 * E);
+    return p;
+  }
+};
+
 // ---- order tasks by length (longest first) so the 64 lanes of a wave run equally long loops ---------------
 // key = min(length, 255); bins are laid out in DESCENDING key order.  One lane per bucket: a bucket contributes
 // ntask-1 full tasks (length T) and one remainder.
@@ -367,7 +409,7 @@ __global__ void __launch_bounds__(64) k_acc_tasks(const uint32_t* __restrict__ p
     if (e & 0x80000000u) a = neg_affine(a);
     acc = add_mixed(acc, a);
   }
-  PointIO<F>::store(partial, pstride, t, acc);
+  PointAoS<F>::store(partial, t, acc);
 }
 
 // round r > 1: partial sums of the previous round (grouped by bucket through Lin) -> fewer partial sums
@@ -383,9 +425,9 @@ __global__ void __launch_bounds__(64) k_sum_tasks(const uint32_t* __restrict__ p
   const uint32_t len_all = Lin.cnt[bi];
   const uint32_t lo = seg * T2, hi = lo + T2 < len_all ? lo + T2 : len_all;
   const size_t first = (size_t)Lin.base[w] + Lin.rel[bi];
-  XYZZ<F> acc = PointIO<F>::load(pin, in_stride, first + lo);
-  for (uint32_t j = lo + 1; j < hi; ++j) acc = add_xyzz(acc, PointIO<F>::load(pin, in_stride, first + j));
-  PointIO<F>::store(pout, out_stride, t, acc);
+  XYZZ<F> acc = PointAoS<F>::load(pin, first + lo);
+  for (uint32_t j = lo + 1; j < hi; ++j) acc = add_xyzz(acc, PointAoS<F>::load(pin, first + j));
+  PointAoS<F>::store(pout, t, acc);
 }
 
 // final: dense bucket array for the halving reduction
@@ -397,7 +439,7 @@ __global__ void __launch_bounds__(256) k_gather_buckets(const uint32_t* __restri
   if (t >= total) return;
   const int w = (int)(t / B);
   XYZZ<F> p = XYZZ<F>::identity();
-  if (L.cnt[t]) p = PointIO<F>::load(pin, in_stride, (size_t)L.base[w] + L.rel[t]);
+  if (L.cnt[t]) p = PointAoS<F>::load(pin, (size_t)L.base[w] + L.rel[t]);
   PointIO<F>::store(buckets, total, t, p);
 }
 
@@ -454,9 +496,13 @@ int pick_window(size_t n, int forced) {
   if (forced) return forced;
   int lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) ++lg;      // floor(log2 n)
-  int c = lg - 4;
+  // The top window holds the 254 - (W-1)c leftover bits; c = 15 / 16 leave it 14 bits (as many buckets as the
+  // signed windows use), while c = 12..14 would leave 2..7 bits, i.e. a handful of buckets holding ~n points each.
+  if (lg >= 19) return 16;
+  if (lg >= 14) return 15;
+  int c = lg - 3;
   if (c < 2) c = 2;
-  if (c > 16) c = 16;
+  if (c > 10) c = 10;
   return c;
 }
 
