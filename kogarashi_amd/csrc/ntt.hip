@@ -173,14 +173,20 @@ __global__ void __launch_bounds__(NT, 2) k_ntt_step(StepArgs A) {
       const uint32_t r0 = ((pidx >> (s - 1)) << s) + j, r1 = r0 + half;
       const uint32_t e0 = tile_index<ROW>(r0, col, A.log_m, A.log_tc), e1 = tile_index<ROW>(r1, col, A.log_m, A.log_tc);
       Fr a = lds_load(lds, e0), b = lds_load(lds, e1);
-      Fr t = mul(b, ld_tw(A.tw_small, (size_t)j << (SMALL_LOG - s)));     // w_{2^s}^j = w_1024^(j * 2^(10-s))
-      lds_store(lds, e0, norm(add(a, t)));
-      lds_store(lds, e1, norm(sub<4, 1>(a, t)));
+      if (s == 1) {                                   // w_2^0 = 1: the first stage needs no product
+        lds_store(lds, e0, norm(add(a, b)));
+        lds_store(lds, e1, norm(sub<8, 1>(a, b)));
+      } else {
+        Fr t = mul(b, ld_tw(A.tw_small, (size_t)j << (SMALL_LOG - s)));     // w_{2^s}^j = w_1024^(j * 2^(10-s))
+        lds_store(lds, e0, norm(add(a, t)));
+        lds_store(lds, e1, norm(sub<4, 1>(a, t)));
+      }
     }
     __syncthreads();
   }
 
   // ---- store: inter-step twiddle (or a plain value reduction), canonicalise, re-pack ------------------
+  Fr tw_cur = Fr::one(), tw_step = Fr::one();
   for (uint32_t idx = threadIdx.x; idx < tile_elems; idx += NT) {
     uint32_t r, col;
     uint64_t addr;
@@ -196,8 +202,18 @@ __global__ void __launch_bounds__(NT, 2) k_ntt_step(StepArgs A) {
       const uint64_t g = g0 + col;
       addr = (g / A.inner) * ((uint64_t)m * A.inner) + (uint64_t)r * A.inner + (g % A.inner);
       v = lds_load(lds, tile_index<ROW>(r, col, A.log_m, A.log_tc));
-      if (A.mult) v = mul(v, two_level(A.tw_lo, A.tw_hi, A.lo_bits, (uint64_t)r * (g % A.inner) * A.mult));
-      else v = vred(v);
+      if (A.mult) {
+        // w_n^(r * cexp): this lane keeps its column and walks r in steps of NT / tc, so the twiddle advances by a
+        // fixed ratio -- one product per element instead of the two of a table lookup
+        if (idx == threadIdx.x) {
+          const uint64_t cexp = (g % A.inner) * A.mult;
+          tw_cur = two_level(A.tw_lo, A.tw_hi, A.lo_bits, (uint64_t)r * cexp);
+          tw_step = two_level(A.tw_lo, A.tw_hi, A.lo_bits, (uint64_t)(NT >> A.log_tc) * cexp);
+        } else {
+          tw_cur = mul(tw_cur, tw_step);
+        }
+        v = mul(v, tw_cur);
+      } else v = vred(v);
     }
     uint32_t w[8];
     words_from_limbs(reduce_2p(v), w);

@@ -1,0 +1,12 @@
+"""Runs only the Groth16 2^18 leg of bench.py (for rocprofv3 --kernel-trace)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import kogarashi_amd as K
+import bench
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+ctx = K.Context(0)
+st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st); ctx.set_stream(st.cuda_stream)
+out = bench.bench_groth16(ctx, torch, dev, K, int(sys.argv[1]) if len(sys.argv) > 1 else 18, steps=5, cpu=False)
+print(out)
