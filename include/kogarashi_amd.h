@@ -134,6 +134,13 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
                            const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
                            const uint64_t* s, uint64_t* proof_out, uint8_t* proof_inf);
 
+/* ---- R1CS evaluation -------------------------------------------------------------------------------
+ * zkstd/src/matrix.rs:31-33 SparseMatrix::evaluate_with_z (row.rs:43-51): out[i] = sum_e val[e] * z[col[e]] over the
+ * entries row_ptr[i] <= e < row_ptr[i+1] of a CSR matrix with m rows; z = x || w (instance wires first).  The step
+ * right before the prover's NTTs (cs.evaluate(), zkstd/src/r1cs.rs:137-142).  All pointers are device pointers. */
+int kg_r1cs_evaluate(kg_ctx* ctx, const uint64_t* d_row_ptr, const uint64_t* d_col, const uint64_t* d_val, size_t m,
+                     const uint64_t* d_z, uint64_t* d_out);
+
 /* ---- deterministic synthetic inputs (identical streams in oracle/) -------------------- */
 int kg_gen_scalars(kg_ctx* ctx, int field, uint64_t seed, size_t start, size_t n, uint64_t* d_out);
 int kg_gen_bases(kg_ctx* ctx, int curve, uint64_t seed, size_t start, size_t n, uint64_t* d_out); /* G1, Grumpkin */

@@ -46,6 +46,27 @@ __global__ void __launch_bounds__(256) k_vec_scale(const uint64_t* __restrict__ 
   store_words(out, i, wo);
 }
 
+// CSR sparse matrix-vector product over Fr, one lane per row (zkstd/src/matrix/row.rs:43-51).  Rows of R1CS
+// matrices are short (a few entries), so the products are accumulated lazily and reduced once per row.
+__global__ void __launch_bounds__(256) k_r1cs_evaluate(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
+                                                       const uint64_t* __restrict__ val, size_t m, const uint64_t* __restrict__ z,
+                                                       uint64_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  Fr sum = Fr::zero();
+  for (uint64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+    uint32_t wv[8], wz[8];
+    load_words(val, e, wv);
+    load_words(z, col[e], wz);
+    // raw(z) * internal(val) keeps the product in the ABI's Montgomery domain
+    Fr t = mul(limbs_from_words<FrParams>(wz), from_ref<FrParams>(wv));
+    sum = vred(norm(add(sum, t)));
+  }
+  uint32_t wo[8];
+  words_from_limbs(reduce_2p(sum), wo);
+  store_words(out, i, wo);
+}
+
 // ---- splitmix64 streams (oracle/pyoracle.py stream_at, oracle/kg_oracle.c stream_words) ---------------
 __device__ __forceinline__ uint64_t splitmix_next(uint64_t& s) {
   s += 0x9E3779B97F4A7C15ULL;
@@ -170,6 +191,15 @@ int kg_field_vec_scale(kg_ctx* c, int field, const uint64_t* a, const uint64_t* 
   dim3 grid((unsigned)((n + 255) / 256));
   if (field == KG_FR) hipLaunchKernelGGL(k_vec_scale<FrParams>, grid, dim3(256), 0, c->stream, a, s, out, n);
   else hipLaunchKernelGGL(k_vec_scale<FqParams>, grid, dim3(256), 0, c->stream, a, s, out, n);
+  KG_HIP(c, hipGetLastError());
+  return KG_OK;
+}
+
+int kg_r1cs_evaluate(kg_ctx* c, const uint64_t* row_ptr, const uint64_t* col, const uint64_t* val, size_t m, const uint64_t* z, uint64_t* out) {
+  if (!c) return KG_ERR_BAD_ARG;
+  if (m == 0) return KG_OK;
+  if (!row_ptr || !col || !val || !z || !out) return KG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_r1cs_evaluate, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, row_ptr, col, val, m, z, out);
   KG_HIP(c, hipGetLastError());
   return KG_OK;
 }

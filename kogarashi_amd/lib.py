@@ -21,7 +21,7 @@ EXPORTS = [
     "kg_ctx_sync", "kg_malloc", "kg_free", "kg_memcpy_h2d", "kg_memcpy_d2h", "kg_memcpy_d2d", "kg_field_vec_op",
     "kg_field_vec_scale", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_msm", "kg_msm_host", "kg_commit",
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
-    "kg_fixed_base_mul", "kg_groth16_prove_bn254",
+    "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate",
 ]
 
 
@@ -178,6 +178,9 @@ class Context:
 
     def gen_bases(self, curve: int, seed: int, start: int, n: int, out: int):
         self._chk(self._lib.kg_gen_bases(self._h, curve, C.c_uint64(seed), C.c_size_t(start), C.c_size_t(n), _vp(out)), "kg_gen_bases")
+
+    def r1cs_evaluate(self, row_ptr: int, col: int, val: int, m: int, z: int, out: int):
+        self._chk(self._lib.kg_r1cs_evaluate(self._h, _vp(row_ptr), _vp(col), _vp(val), C.c_size_t(m), _vp(z), _vp(out)), "kg_r1cs_evaluate")
 
     def fixed_base_mul(self, curve: int, k: int, n: int, out_xy: int, out_inf: int):
         self._chk(self._lib.kg_fixed_base_mul(self._h, curve, _vp(k), C.c_size_t(n), _vp(out_xy), _vp(out_inf)), "kg_fixed_base_mul")

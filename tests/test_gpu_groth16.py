@@ -62,3 +62,30 @@ def test_groth16_rejects_identity_delta(ctx, oracle):
     r, s = O.gen_scalars(0, SEED + 412, 0, 2)
     with pytest.raises(ProverSubVersionCrsAttack):
         K.Prover(params, cs.m, cs.l, cs.m_l_1, ctx=ctx).create_proof(a, b, c, cs.x, cs.w, r, s)
+
+
+def test_r1cs_evaluate_matches_oracle(ctx, oracle):
+    """cs.evaluate() (zkstd/src/r1cs.rs:137-142) as a CSR SpMV on the device, on a random sparse system plus the chain."""
+    O = oracle
+    rng = np.random.default_rng(3)
+    m, nv = 3000, 500
+    counts = rng.integers(0, 6, m)
+    counts[7] = 0                                   # empty row -> 0
+    rp = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    col = rng.integers(0, nv, int(rp[-1])).astype(np.uint64)
+    val = O.gen_scalars(0, SEED + 500, 0, int(rp[-1]))
+    z = O.gen_scalars(0, SEED + 501, 0, nv)
+    want = np.empty((m, 4), dtype=np.uint64)
+    import ctypes as C
+    O.lib().kgo_r1cs_evaluate(O._p(rp), O._p(col), O._p(val), C.c_size_t(m), O._p(z), O._p(want))
+    drp, dcol, dval, dz, dout = ctx.upload(rp), ctx.upload(col), ctx.upload(val), ctx.upload(z), ctx.empty((m, 4))
+    ctx.r1cs_evaluate(drp.ptr, dcol.ptr, dval.ptr, m, dz.ptr, dout.ptr)
+    assert (dout.numpy() == want).all()
+    cs = O.chain_r1cs(64, O.gen_scalars(0, SEED + 502, 0, 1)[0])
+    zz = np.concatenate([cs.x, cs.w])
+    dz = ctx.upload(zz)
+    for (rp, col, val), want in zip((cs.a, cs.b, cs.c), cs.evaluate()):
+        d = [ctx.upload(np.ascontiguousarray(t)) for t in (rp, col, val)]
+        out = ctx.empty((cs.m, 4))
+        ctx.r1cs_evaluate(d[0].ptr, d[1].ptr, d[2].ptr, cs.m, dz.ptr, out.ptr)
+        assert (out.numpy() == want).all()
