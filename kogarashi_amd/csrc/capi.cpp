@@ -29,6 +29,27 @@ int ensure_ws3(kg_ctx* c, size_t bytes) {
   c->ws3_bytes = bytes;
   return KG_OK;
 }
+int ensure_ws_run(kg_ctx* c, size_t bytes) {
+  if (bytes <= c->ws_run_bytes) return KG_OK;
+  if (c->ws_run) { hipStreamSynchronize(c->stream); hipFree(c->ws_run); c->ws_run = nullptr; c->ws_run_bytes = 0; }
+  size_t want = bytes + bytes / 8;
+  hipError_t e = hipMalloc(&c->ws_run, want);
+  if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "msm run-space allocation", e);
+  c->ws_run_bytes = want;
+  return KG_OK;
+}
+int ensure_slot(kg_ctx* c, int slot, size_t bytes) {
+  if (slot < 0 || slot >= 8) return set_err(c, KG_ERR_BAD_ARG, "bad result slot");
+  kg_ctx::Slot& s = c->slots[slot];
+  if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation");
+  if (bytes <= s.bytes) return KG_OK;
+  if (s.host) hipHostFree(s.host);
+  s.host = nullptr; s.bytes = 0;
+  hipError_t e = hipHostMalloc(&s.host, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "pinned slot allocation", e);
+  s.bytes = bytes;
+  return KG_OK;
+}
 int ensure_pinned(kg_ctx* c, size_t bytes) {
   if (bytes <= c->h_pinned_bytes) return KG_OK;
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -108,6 +129,9 @@ void kg_ctx_destroy(kg_ctx* c) {
   if (c->ws) hipFree(c->ws);
   if (c->ws2) hipFree(c->ws2);
   if (c->ws3) hipFree(c->ws3);
+  if (c->ws_run) hipFree(c->ws_run);
+  if (c->ev_info) hipEventDestroy(c->ev_info);
+  for (auto& sl : c->slots) { if (sl.host) hipHostFree(sl.host); if (sl.done) hipEventDestroy(sl.done); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->own_stream);

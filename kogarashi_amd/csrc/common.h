@@ -23,6 +23,11 @@ struct kg_ctx {
   size_t ws2_bytes = 0;
   void* ws3 = nullptr;                   // prover polynomial buffers
   size_t ws3_bytes = 0;
+  void* ws_run = nullptr;                // MSM base-side scratch (packed bases, partial sums, halving buffers)
+  size_t ws_run_bytes = 0;
+  hipEvent_t ev_info = nullptr;          // marks the task-count read-back of msm_sort
+  struct Slot { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0; };
+  Slot slots[8];                         // pinned result slots: MSMs in flight whose host finish is pending
   void* h_pinned = nullptr;              // small pinned staging buffer for results
   size_t h_pinned_bytes = 0;
   std::vector<kg_tw_cache*> tw;          // per-(log_n, inverse) twiddle tables
@@ -57,6 +62,8 @@ inline int set_err(kg_ctx* c, int code, const char* what, hipError_t e = hipSucc
 int ensure_ws(kg_ctx* c, size_t bytes);
 int ensure_ws2(kg_ctx* c, size_t bytes);
 int ensure_ws3(kg_ctx* c, size_t bytes);
+int ensure_ws_run(kg_ctx* c, size_t bytes);
+int ensure_slot(kg_ctx* c, int slot, size_t bytes);
 int ensure_pinned(kg_ctx* c, size_t bytes);
 
 // RAII-free phase timer: PhaseScope p(ctx, "name"); ... p.end();
@@ -139,5 +146,24 @@ template <class F> struct RefIO<Fp2<F>> {
   static constexpr int W64 = 8;
   static __device__ __forceinline__ Fp2<F> load(const uint64_t* p) { return {RefIO<F>::load(p), RefIO<F>::load(p + 4)}; }
 };
+
+
+// msm.hip: scalar-side / base-side / host halves of an MSM (used by kg_msm and by the Groth16 prover).
+// MsmSorted is the scalar-side state: digits sorted into per-bucket lists plus the task decomposition.  It depends
+// only on the scalars, so several base arrays (the CRS vectors a, b_g1, b_g2, l of a Groth16 proof all meet the same
+// witness) share one.  It lives in ctx->ws until the next msm_sort.
+struct MsmSorted {
+  size_t n = 0;
+  int c = 0, W = 0, B = 0;
+  uint32_t T = 0, T2 = 16;
+  size_t npts = 0, part_cap = 0;
+  uint32_t ntasks = 0, max_cnt = 0;
+  uint32_t *sorted = nullptr, *bsize = nullptr, *bstart = nullptr, *lcnt = nullptr, *lrel = nullptr, *lbase = nullptr;
+  uint32_t *task_bkt = nullptr, *task_id = nullptr;
+};
+int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S);
+int msm_run(kg_ctx* ctx, const MsmSorted& S, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, uint32_t idx_off, int slot);
+int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz);
+void msm_identity(int curve, uint64_t* out_xyz);
 
 }  // namespace kg

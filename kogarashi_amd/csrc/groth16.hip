@@ -8,6 +8,8 @@
 // (sequential double-and-add, as in the reference).
 #include "common.h"
 #include "host_fp.h"
+#include <future>
+#include <vector>
 
 using namespace kg;
 
@@ -177,22 +179,47 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   KG_TRY(kg_ntt_bn254_fr(ctx, A, k, 1, 1));             // coset_idft (prover.rs:47)
 
   // The eight MSMs of prover.rs:51-65 as five: a_inputs + a_aux (:58-59,80) is one MSM of a[..] against
-  // z = x || w, likewise b_g1 (:61-62,85) and b_g2 (:64-65,86) -- the sums are what the proof uses.
-  // q keeps its trailing zeros: zero scalars are skipped by the MSM, which is what Coefficients::new's
-  // trimming plus zip achieves in the reference (poly.rs:61-63, msm.rs:25).
+  // z = x || w, likewise b_g1 (:61-62,85) and b_g2 (:64-65,86) -- the sums are what the proof uses.  The four MSMs
+  // that meet the witness share ONE scalar-side sort (l's bases start l entries into z).  q keeps its trailing
+  // zeros: zero scalars are skipped by the MSM, which is what Coefficients::new's trimming plus zip achieves in
+  // the reference (poly.rs:61-63, msm.rs:25).  Each MSM's 255-step host finish runs on a worker thread while the
+  // device continues with the next one.
   const size_t hn = (m - 1) < n ? (m - 1) : n;
   const size_t nz = l + m_l_1;
   uint64_t* Z = C + 4 * n;                                // z = x || w
   KG_HIP(ctx, hipMemcpyAsync(Z, d_x, l * 32, hipMemcpyDeviceToDevice, st));
   if (m_l_1) KG_HIP(ctx, hipMemcpyAsync(Z + 4 * l, d_w, m_l_1 * 32, hipMemcpyDeviceToDevice, st));
   uint64_t q_p[12], l_p[12], ai[12], aa[12], b1i[12], b1a[12], b2i[24], b2a[24];
-  KG_TRY(kg_msm(ctx, KG_G1, crs->d_h, crs->d_h_inf, A, hn, q_p));
-  KG_TRY(kg_msm(ctx, KG_G1, crs->d_l, crs->d_l_inf, d_w, m_l_1, l_p));
-  KG_TRY(kg_msm(ctx, KG_G1, crs->d_a, crs->d_a_inf, Z, nz, ai));
-  KG_TRY(kg_msm(ctx, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, Z, nz, b1i));
-  KG_TRY(kg_msm(ctx, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, Z, nz, b2i));
   for (int i = 0; i < 12; ++i) aa[i] = b1a[i] = 0;       // identity (0, *, 0): the partner sums are folded in
   for (int i = 0; i < 24; ++i) b2a[i] = 0;
+  prof_reset(ctx);
+  std::vector<std::future<int>> pending;
+  auto finish_async = [&](int curve, int slot, uint64_t* out) {
+    pending.emplace_back(std::async(std::launch::async, [ctx, curve, slot, out] { return msm_finish(ctx, curve, slot, out); }));
+  };
+  int rc = KG_OK;
+  if (hn) {
+    MsmSorted Sq;
+    rc = msm_sort(ctx, KG_FR, A, hn, &Sq);
+    if (rc == KG_OK) rc = msm_run(ctx, Sq, KG_G1, crs->d_h, crs->d_h_inf, hn, 0, 0);
+    if (rc == KG_OK) finish_async(KG_G1, 0, q_p);
+  } else msm_identity(KG_G1, q_p);
+  if (rc == KG_OK) {
+    MsmSorted Sz;
+    rc = msm_sort(ctx, KG_FR, Z, nz, &Sz);
+    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G1, crs->d_a, crs->d_a_inf, nz, 0, 1);
+    if (rc == KG_OK) finish_async(KG_G1, 1, ai);
+    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, nz, 0, 2);
+    if (rc == KG_OK) finish_async(KG_G1, 2, b1i);
+    if (rc == KG_OK && m_l_1) {
+      rc = msm_run(ctx, Sz, KG_G1, crs->d_l, crs->d_l_inf, m_l_1, (uint32_t)l, 3);
+      if (rc == KG_OK) finish_async(KG_G1, 3, l_p);
+    } else msm_identity(KG_G1, l_p);
+    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, 0, 4);
+    if (rc == KG_OK) finish_async(KG_G2, 4, b2i);
+  }
+  for (auto& f : pending) { int r2 = f.get(); if (rc == KG_OK) rc = r2; }
+  if (rc != KG_OK) return rc;
   if (crs->delta_g1_inf || crs->delta_g2_inf) return set_err(ctx, KG_ERR_CRS, "delta is the identity");   // prover.rs:67-69
 
   // assembly (prover.rs:71-98) on the host

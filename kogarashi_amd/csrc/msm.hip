@@ -389,7 +389,7 @@ template <class F>
 __global__ void __launch_bounds__(64) k_acc_tasks(const uint32_t* __restrict__ pbases, const uint32_t* __restrict__ sorted,
                                                   const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bsize, Level L,
                                                   const uint32_t* __restrict__ task_bkt, const uint32_t* __restrict__ task_id,
-                                                  size_t n, int W, int B, uint32_t T, uint32_t* __restrict__ partial, size_t pstride) {
+                                                  size_t n, int W, int B, uint32_t T, uint32_t idx_off, uint32_t* __restrict__ partial, size_t pstride) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= L.base[W]) return;
   const size_t bi = task_bkt[p];
@@ -403,7 +403,9 @@ __global__ void __launch_bounds__(64) k_acc_tasks(const uint32_t* __restrict__ p
   XYZZ<F> acc = XYZZ<F>::identity();
   for (uint32_t j = lo; j < hi; ++j) {
     const uint32_t e = list[j];
-    const uint32_t* src = pbases + (size_t)(e & 0x7fffffffu) * PW;
+    const uint32_t idx = e & 0x7fffffffu;
+    if (idx < idx_off) continue;                         // scalars in front of this base array (shared sort, z = x || w)
+    const uint32_t* src = pbases + (size_t)(idx - idx_off) * PW;
     if (src[7] & INF_BIT) continue;                      // identity base (msm.rs:58-64 adds it as a no-op)
     Affine<F> a{BaseIO<F>::load(src), BaseIO<F>::load(src + BaseIO<F>::W)};
     if (e & 0x80000000u) a = neg_affine(a);
@@ -524,20 +526,33 @@ XYZZ<typename Cfg::HF> host_load_point(const uint64_t* p) {
 }
 
 template <class Cfg>
-size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
-
-// Device pipeline; leaves W*c exported XYZZ points in ctx->h_pinned and returns the host-side partial sum.
-template <class Cfg>
-int msm_device(kg_ctx* ctx, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,
-               XYZZ<typename Cfg::HF>& result) {
-  using F = typename Cfg::F;
+void store_projective(const XYZZ<typename Cfg::HF>& p, uint64_t* out_xyz) {
   using HF = typename Cfg::HF;
-  result = XYZZ<HF>::identity();
-  if (n == 0) return KG_OK;
-  if (n >= ((size_t)1 << 31)) return set_err(ctx, KG_ERR_BAD_ARG, "msm length above 2^31 - 1");
-  KG_HIP(ctx, hipSetDevice(ctx->device));
-  prof_reset(ctx);
+  constexpr int E = Cfg::E64;
+  Affine<HF> a;
+  if (!to_affine(p, a)) {                        // (0, 1, 0): macros/curve/weierstrass/group.rs:106-110
+    HostIO<HF>::store(HF::zero(), out_xyz);
+    HostIO<HF>::store(HF::one(), out_xyz + E);
+    HostIO<HF>::store(HF::zero(), out_xyz + 2 * E);
+    return;
+  }
+  HostIO<HF>::store(a.x, out_xyz);
+  HostIO<HF>::store(a.y, out_xyz + E);
+  HostIO<HF>::store(HF::one(), out_xyz + 2 * E);
+}
 
+struct Carver {
+  size_t off = 0;
+  size_t take(size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; }
+};
+
+}  // namespace
+
+namespace kg {
+
+int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S) {
+  if (n == 0 || n >= ((size_t)1 << 31)) return set_err(ctx, KG_ERR_BAD_ARG, "msm length must be in [1, 2^31)");
+  KG_HIP(ctx, hipSetDevice(ctx->device));
   const int c = pick_window(n, ctx->msm_window);
   const int W = (255 + c - 1) / c;
   const int B = 1 << (c - 1);
@@ -545,66 +560,41 @@ int msm_device(kg_ctx* ctx, const uint64_t* d_bases, const uint8_t* d_inf, const
   if (nch > 16) nch = 16;
   if (nch < 1) nch = 1;
   const size_t chunk_len = (n + nch - 1) / nch;
-  constexpr int PW = 2 * BaseIO<F>::W;              // packed words per base
-  constexpr int NW = PointIO<F>::NW;                // raw words per XYZZ point
-
-  // work space carve-up
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
-  const size_t o_kt = carve(n * 32);
-  const size_t o_pb = carve(n * PW * 4);
-  const size_t o_cnt = carve((size_t)W * nch * B * 4);
-  const size_t o_bsize = carve((size_t)W * B * 4);
-  const size_t o_bstart = carve((size_t)W * B * 4);
-  const size_t o_sorted = carve((size_t)W * n * 4);
   const size_t npts = (size_t)W * B;
-  const size_t o_p0 = carve(npts * NW * 4);
-  const size_t o_p1 = carve(npts * NW * 4);
-  const size_t nexp = (size_t)W * c;
-  const size_t o_exp = carve(nexp * 4 * Cfg::E64 * 8);
-  // task bookkeeping: two levels (ping-pong) of cnt / rel / base, row totals, max word, info words
   uint32_t T = (uint32_t)(2 * (n / B) + 32);
   if (T < 64) T = 64;
   if (T > 4096) T = 4096;
-  const uint32_t T2 = 16;
   const size_t part_cap = (size_t)W * ((n + T - 1) / T) + npts;     // upper bound on round-1 tasks
-  size_t o_lcnt[2], o_lrel[2], o_lbase[2], o_part[2];
-  for (int i = 0; i < 2; ++i) {
-    o_lcnt[i] = carve(npts * 4);
-    o_lrel[i] = carve(npts * 4);
-    o_lbase[i] = carve((size_t)(W + 1) * 4);
-    o_part[i] = carve(part_cap * NW * 4);
-  }
-  const size_t o_rowtot = carve((size_t)W * 4);
-  const size_t o_misc = carve(64);
-  const size_t o_lenh = carve(2 * LEN_BINS * 4);
-  const size_t o_tbkt = carve(part_cap * 4);
-  const size_t o_tid = carve(part_cap * 4);
-  KG_TRY(ensure_ws(ctx, off));
-  KG_TRY(ensure_pinned(ctx, nexp * 4 * Cfg::E64 * 8 + 64));
+
+  Carver cv;
+  const size_t o_kt = cv.take(n * 32), o_cnt = cv.take((size_t)W * nch * B * 4), o_bsize = cv.take(npts * 4), o_bstart = cv.take(npts * 4);
+  const size_t o_sorted = cv.take((size_t)W * n * 4), o_lcnt = cv.take(npts * 4), o_lrel = cv.take(npts * 4), o_lbase = cv.take((size_t)(W + 1) * 4);
+  const size_t o_rowtot = cv.take((size_t)W * 4), o_misc = cv.take(64), o_lenh = cv.take(2 * LEN_BINS * 4);
+  const size_t o_tbkt = cv.take(part_cap * 4), o_tid = cv.take(part_cap * 4);
+  KG_TRY(ensure_ws(ctx, cv.off));
+  KG_TRY(ensure_pinned(ctx, 4096));
   char* ws = (char*)ctx->ws;
   uint32_t* kt = (uint32_t*)(ws + o_kt);
-  uint32_t* pb = (uint32_t*)(ws + o_pb);
   uint32_t* cnt = (uint32_t*)(ws + o_cnt);
-  uint32_t* bsize = (uint32_t*)(ws + o_bsize);
-  uint32_t* bstart = (uint32_t*)(ws + o_bstart);
-  uint32_t* sorted = (uint32_t*)(ws + o_sorted);
-  uint32_t* pbuf[2] = {(uint32_t*)(ws + o_p0), (uint32_t*)(ws + o_p1)};
-  uint64_t* d_exp = (uint64_t*)(ws + o_exp);
+  uint32_t* rowtot = (uint32_t*)(ws + o_rowtot);
+  uint32_t* misc = (uint32_t*)(ws + o_misc);
+  uint32_t* lenh = (uint32_t*)(ws + o_lenh);
+  S->n = n; S->c = c; S->W = W; S->B = B; S->T = T; S->npts = npts; S->part_cap = part_cap;
+  S->sorted = (uint32_t*)(ws + o_sorted); S->bsize = (uint32_t*)(ws + o_bsize); S->bstart = (uint32_t*)(ws + o_bstart);
+  S->lcnt = (uint32_t*)(ws + o_lcnt); S->lrel = (uint32_t*)(ws + o_lrel); S->lbase = (uint32_t*)(ws + o_lbase);
+  S->task_bkt = (uint32_t*)(ws + o_tbkt); S->task_id = (uint32_t*)(ws + o_tid);
   hipStream_t st = ctx->stream;
 
-  // bias H = sum_{w < W-1} 2^(w*c + c - 1)
-  Words8 H;
+  Words8 H;                                          // bias H = sum_{w < W-1} 2^(w*c + c - 1)
   for (int j = 0; j < 8; ++j) H.w[j] = 0;
   for (int w = 0; w < W - 1; ++w) {
     int bit = w * c + c - 1;
     H.w[bit >> 5] |= 1u << (bit & 31);
   }
-
   {
-    PhaseScope ph(ctx, "prep");
-    hipLaunchKernelGGL(k_prep_scalars<typename Cfg::SP>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
-    hipLaunchKernelGGL(k_prep_bases<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_bases, d_inf, n, pb);
+    PhaseScope ph(ctx, "prep_scalars");
+    if (scalar_field == KG_FR) hipLaunchKernelGGL(k_prep_scalars<FrParams>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
+    else hipLaunchKernelGGL(k_prep_scalars<FqParams>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
     ph.end();
   }
   {
@@ -615,58 +605,97 @@ int msm_device(kg_ctx* ctx, const uint64_t* d_bases, const uint8_t* d_inf, const
       KG_HIP(ctx, hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     hipLaunchKernelGGL(k_count, dim3(nch, W), dim3(1024), lds, st, kt, n, c, W, chunk_len, cnt);
-    hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, cnt, W, nch, B, bsize);
-    hipLaunchKernelGGL(k_scan_buckets, dim3(W), dim3(1024), 0, st, bsize, B, bstart);
-    hipLaunchKernelGGL(k_scatter, dim3(nch, W), dim3(1024), lds, st, kt, n, c, W, chunk_len, cnt, bstart, sorted);
-    ph.end();
-  }
-  {
-    PhaseScope ph(ctx, "accumulate");
-    uint32_t* lcnt[2] = {(uint32_t*)(ws + o_lcnt[0]), (uint32_t*)(ws + o_lcnt[1])};
-    uint32_t* lrel[2] = {(uint32_t*)(ws + o_lrel[0]), (uint32_t*)(ws + o_lrel[1])};
-    uint32_t* lbase[2] = {(uint32_t*)(ws + o_lbase[0]), (uint32_t*)(ws + o_lbase[1])};
-    uint32_t* part[2] = {(uint32_t*)(ws + o_part[0]), (uint32_t*)(ws + o_part[1])};
-    uint32_t* rowtot = (uint32_t*)(ws + o_rowtot);
-    uint32_t* misc = (uint32_t*)(ws + o_misc);          // [0] max bucket size, [4..5] info
-    uint32_t* h_info = (uint32_t*)((char*)ctx->h_pinned + nexp * 4 * Cfg::E64 * 8);
-    uint32_t* lenh = (uint32_t*)(ws + o_lenh);          // [0..255] histogram, [256..511] cursors
-    uint32_t* task_bkt = (uint32_t*)(ws + o_tbkt);
-    uint32_t* task_id = (uint32_t*)(ws + o_tid);
+    hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, cnt, W, nch, B, S->bsize);
+    // task decomposition (needs only the bucket sizes); its two result words travel to the host while the
+    // scatter below still runs, so the read-back does not stall the queue
     KG_HIP(ctx, hipMemsetAsync(misc, 0, 64, st));
     KG_HIP(ctx, hipMemsetAsync(lenh, 0, 2 * LEN_BINS * 4, st));
     const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
-    hipLaunchKernelGGL(k_task_count, dim3(g1024), dim3(1024), 0, st, bsize, npts, T, lcnt[0], misc);
-    hipLaunchKernelGGL(k_scan_rows, dim3(W), dim3(1024), 0, st, lcnt[0], B, lrel[0], rowtot);
-    hipLaunchKernelGGL(k_row_bases, dim3(1), dim3(64), 0, st, rowtot, W, lbase[0], misc, misc + 4);
-    hipLaunchKernelGGL(k_len_hist, dim3(g1024), dim3(1024), 0, st, bsize, lcnt[0], npts, T, lenh);
-    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(64), 0, st, lenh, lenh + LEN_BINS);
-    hipLaunchKernelGGL(k_len_scatter, dim3(g1024), dim3(1024), 0, st, bsize, lcnt[0], lrel[0], lbase[0], npts, B, T, lenh + LEN_BINS, task_bkt, task_id);
+    hipLaunchKernelGGL(k_task_count, dim3(g1024), dim3(1024), 0, st, S->bsize, npts, T, S->lcnt, misc);
+    hipLaunchKernelGGL(k_scan_rows, dim3(W), dim3(1024), 0, st, S->lcnt, B, S->lrel, rowtot);
+    hipLaunchKernelGGL(k_row_bases, dim3(1), dim3(64), 0, st, rowtot, W, S->lbase, misc, misc + 4);
+    uint32_t* h_info = (uint32_t*)ctx->h_pinned;
     KG_HIP(ctx, hipMemcpyAsync(h_info, misc + 4, 8, hipMemcpyDeviceToHost, st));
-    KG_HIP(ctx, hipStreamSynchronize(st));
-    uint32_t ntasks = h_info[0];
-    uint32_t max_cnt = (h_info[1] + T - 1) / T;          // most tasks any bucket has
-    if (ntasks > part_cap) return set_err(ctx, KG_ERR_HIP, "task count exceeds its bound");
-    int lv = 0;
-    Level L{lcnt[0], lrel[0], lbase[0]};
-    if (ntasks)
-      hipLaunchKernelGGL(k_acc_tasks<F>, dim3((ntasks + 63) / 64), dim3(64), 0, st, pb, sorted, bstart, bsize, L, task_bkt, task_id, n, W, B, T, part[0], part_cap);
-    int pcur = 0;
+    if (!ctx->ev_info) KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_info, hipEventDisableTiming));
+    KG_HIP(ctx, hipEventRecord(ctx->ev_info, st));
+    hipLaunchKernelGGL(k_len_hist, dim3(g1024), dim3(1024), 0, st, S->bsize, S->lcnt, npts, T, lenh);
+    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(64), 0, st, lenh, lenh + LEN_BINS);
+    hipLaunchKernelGGL(k_len_scatter, dim3(g1024), dim3(1024), 0, st, S->bsize, S->lcnt, S->lrel, S->lbase, npts, B, T, lenh + LEN_BINS, S->task_bkt, S->task_id);
+    hipLaunchKernelGGL(k_scan_buckets, dim3(W), dim3(1024), 0, st, S->bsize, B, S->bstart);
+    hipLaunchKernelGGL(k_scatter, dim3(nch, W), dim3(1024), lds, st, kt, n, c, W, chunk_len, cnt, S->bstart, S->sorted);
+    ph.end();
+    KG_HIP(ctx, hipGetLastError());
+    KG_HIP(ctx, hipEventSynchronize(ctx->ev_info));
+    S->ntasks = h_info[0];
+    S->max_cnt = (h_info[1] + T - 1) / T;              // most tasks any bucket has
+    if (S->ntasks > part_cap) return set_err(ctx, KG_ERR_HIP, "task count exceeds its bound");
+  }
+  return KG_OK;
+}
+
+// Base-side half: accumulate + reduce against one base array, export, and start the copy into host slot `slot`.
+template <class Cfg>
+int msm_run_t(kg_ctx* ctx, const MsmSorted& S, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, uint32_t idx_off, int slot) {
+  using F = typename Cfg::F;
+  constexpr int PW = 2 * BaseIO<F>::W;              // packed words per base
+  constexpr int NW = PointIO<F>::NW;                // raw words per XYZZ point
+  const int W = S.W, B = S.B, c = S.c;
+  const size_t npts = S.npts, part_cap = S.part_cap, nexp = (size_t)W * c;
+  Carver cv;
+  const size_t o_pb = cv.take(nbases * PW * 4);
+  size_t o_lc[2], o_lr[2], o_lb[2], o_part[2], o_pbuf[2];
+  for (int i = 0; i < 2; ++i) {
+    o_lc[i] = cv.take(npts * 4); o_lr[i] = cv.take(npts * 4); o_lb[i] = cv.take((size_t)(W + 1) * 4);
+    o_part[i] = cv.take(part_cap * NW * 4); o_pbuf[i] = cv.take(npts * NW * 4);
+  }
+  const size_t o_rowtot = cv.take((size_t)W * 4), o_misc = cv.take(64);
+  const size_t exp_bytes = nexp * 4 * Cfg::E64 * 8;
+  const size_t o_exp = cv.take(exp_bytes);
+  KG_TRY(ensure_ws_run(ctx, cv.off));
+  KG_TRY(ensure_slot(ctx, slot, exp_bytes));
+  char* ws = (char*)ctx->ws_run;
+  uint32_t* pb = (uint32_t*)(ws + o_pb);
+  uint32_t* part[2] = {(uint32_t*)(ws + o_part[0]), (uint32_t*)(ws + o_part[1])};
+  uint32_t* pbuf[2] = {(uint32_t*)(ws + o_pbuf[0]), (uint32_t*)(ws + o_pbuf[1])};
+  uint32_t* rowtot = (uint32_t*)(ws + o_rowtot);
+  uint32_t* misc = (uint32_t*)(ws + o_misc);
+  uint64_t* d_exp = (uint64_t*)(ws + o_exp);
+  hipStream_t st = ctx->stream;
+  {
+    PhaseScope ph(ctx, "prep_bases");
+    hipLaunchKernelGGL(k_prep_bases<F>, dim3((unsigned)((nbases + 255) / 256)), dim3(256), 0, st, d_bases, d_inf, nbases, pb);
+    ph.end();
+  }
+  Level L{S.lcnt, S.lrel, S.lbase};
+  int pcur = 0;
+  {
+    PhaseScope ph(ctx, "accumulate");
+    if (S.ntasks)
+      hipLaunchKernelGGL(k_acc_tasks<F>, dim3((S.ntasks + 63) / 64), dim3(64), 0, st, pb, S.sorted, S.bstart, S.bsize, L, S.task_bkt, S.task_id,
+                         S.n, W, B, S.T, idx_off, part[0], part_cap);
+    // skewed inputs: re-sum a bucket's partial sums until it owns one point
+    uint32_t max_cnt = S.max_cnt;
+    int lv = -1;                                     // -1: level arrays of S; 0/1: local ping-pong
+    const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
     while (max_cnt > 1) {
-      const int nx = lv ^ 1;
-      hipLaunchKernelGGL(k_task_count, dim3(g1024), dim3(1024), 0, st, lcnt[lv], npts, T2, lcnt[nx], misc + 8);
-      hipLaunchKernelGGL(k_scan_rows, dim3(W), dim3(1024), 0, st, lcnt[nx], B, lrel[nx], rowtot);
-      hipLaunchKernelGGL(k_row_bases, dim3(1), dim3(64), 0, st, rowtot, W, lbase[nx], (const uint32_t*)nullptr, misc + 4);
-      KG_HIP(ctx, hipMemcpyAsync(h_info, misc + 4, 8, hipMemcpyDeviceToHost, st));
-      KG_HIP(ctx, hipStreamSynchronize(st));
-      const uint32_t nt2 = h_info[0];
-      Level Lin{lcnt[lv], lrel[lv], lbase[lv]}, Lout{lcnt[nx], lrel[nx], lbase[nx]};
-      hipLaunchKernelGGL(k_sum_tasks<F>, dim3((nt2 + 63) / 64), dim3(64), 0, st, part[pcur], part_cap, Lin, Lout, W, B, T2, part[pcur ^ 1], part_cap);
+      const int nx = lv < 0 ? 0 : (lv ^ 1);
+      uint32_t* ncnt = (uint32_t*)(ws + o_lc[nx]);
+      uint32_t* nrel = (uint32_t*)(ws + o_lr[nx]);
+      uint32_t* nbase = (uint32_t*)(ws + o_lb[nx]);
+      KG_HIP(ctx, hipMemsetAsync(misc, 0, 64, st));
+      hipLaunchKernelGGL(k_task_count, dim3(g1024), dim3(1024), 0, st, L.cnt, npts, S.T2, ncnt, misc + 8);
+      hipLaunchKernelGGL(k_scan_rows, dim3(W), dim3(1024), 0, st, ncnt, B, nrel, rowtot);
+      hipLaunchKernelGGL(k_row_bases, dim3(1), dim3(64), 0, st, rowtot, W, nbase, (const uint32_t*)nullptr, misc + 4);
+      Level Lout{ncnt, nrel, nbase};
+      // the task count of this round is bounded by the previous one; threads beyond base[W] exit
+      const uint32_t bound = lv < 0 ? S.ntasks : (uint32_t)part_cap;
+      hipLaunchKernelGGL(k_sum_tasks<F>, dim3((bound + 63) / 64), dim3(64), 0, st, part[pcur], part_cap, L, Lout, W, B, S.T2, part[pcur ^ 1], part_cap);
       pcur ^= 1;
+      L = Lout;
       lv = nx;
-      max_cnt = (max_cnt + T2 - 1) / T2;
+      max_cnt = (max_cnt + S.T2 - 1) / S.T2;
     }
-    Level Lf{lcnt[lv], lrel[lv], lbase[lv]};
-    hipLaunchKernelGGL(k_gather_buckets<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, part[pcur], part_cap, Lf, W, B, pbuf[0]);
+    hipLaunchKernelGGL(k_gather_buckets<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, part[pcur], part_cap, L, W, B, pbuf[0]);
     ph.end();
   }
   int cur = 0;
@@ -689,51 +718,60 @@ int msm_device(kg_ctx* ctx, const uint64_t* d_bases, const uint8_t* d_inf, const
     ph.end();
   }
   KG_HIP(ctx, hipGetLastError());
-  KG_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, d_exp, nexp * 4 * Cfg::E64 * 8, hipMemcpyDeviceToHost, st));
-  KG_HIP(ctx, hipStreamSynchronize(st));
+  kg_ctx::Slot& sl = ctx->slots[slot];
+  KG_HIP(ctx, hipMemcpyAsync(sl.host, d_exp, exp_bytes, hipMemcpyDeviceToHost, st));
+  KG_HIP(ctx, hipEventRecord(sl.done, st));
+  sl.W = W; sl.c = c;
+  return KG_OK;
+}
 
-  // host finish: window w contributes 2^(w*c) * (A_w + sum_l 2^l T_{w,l}); array 0 = A, array 1 + l = T_l.
-  // (B == 1, c == 1: no halving ran; the single "array" is the bucket itself.)
-  const uint64_t* hp = (const uint64_t*)ctx->h_pinned;
+// Host half: wait for the slot's copy, then the 255-step double-and-add over the c*W bit-plane sums.
+// Window w contributes 2^(w*c) * (A_w + sum_l 2^l T_{w,l}); array 0 = A, array 1 + l = T_l.
+template <class Cfg>
+int msm_finish_t(kg_ctx* ctx, int slot, uint64_t* out_xyz) {
+  using HF = typename Cfg::HF;
+  kg_ctx::Slot& sl = ctx->slots[slot];
+  hipSetDevice(ctx->device);
+  if (hipEventSynchronize(sl.done) != hipSuccess) return KG_ERR_HIP;
+  const uint64_t* hp = (const uint64_t*)sl.host;
   constexpr int PE = 4 * Cfg::E64;
+  const int W = sl.W, c = sl.c;
   XYZZ<HF> acc = XYZZ<HF>::identity();
-  const int nbits = (W - 1) * c + c;             // highest bit position + 1
-  for (int bit = nbits - 1; bit >= 0; --bit) {
+  for (int bit = W * c - 1; bit >= 0; --bit) {
     acc = double_xyzz(acc);
     const int w = bit / c, l = bit % c;
-    if (l < c - 1 || c == 1) {
-      // T_l exists for l = 0..c-2 (array 1 + l); for c == 1 there are no T arrays
-      if (c > 1) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c + 1 + l) * PE));
-    }
+    if (c > 1 && l < c - 1) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c + 1 + l) * PE));
     if (l == 0) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c) * PE));
   }
-  result = acc;
+  store_projective<Cfg>(acc, out_xyz);
   return KG_OK;
 }
 
-template <class Cfg>
-void store_projective(const XYZZ<typename Cfg::HF>& p, uint64_t* out_xyz) {
-  using HF = typename Cfg::HF;
-  constexpr int E = Cfg::E64;
-  Affine<HF> a;
-  if (!to_affine(p, a)) {                        // (0, 1, 0): macros/curve/weierstrass/group.rs:106-110
-    HostIO<HF>::store(HF::zero(), out_xyz);
-    HostIO<HF>::store(HF::one(), out_xyz + E);
-    HostIO<HF>::store(HF::zero(), out_xyz + 2 * E);
-    return;
+int msm_run(kg_ctx* ctx, const MsmSorted& S, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, uint32_t idx_off, int slot) {
+  switch (curve) {
+    case KG_G1: return msm_run_t<G1Cfg>(ctx, S, d_bases, d_inf, nbases, idx_off, slot);
+    case KG_GRUMPKIN: return msm_run_t<GkCfg>(ctx, S, d_bases, d_inf, nbases, idx_off, slot);
+    case KG_G2: return msm_run_t<G2Cfg>(ctx, S, d_bases, d_inf, nbases, idx_off, slot);
+    default: return KG_ERR_BAD_ARG;
   }
-  HostIO<HF>::store(a.x, out_xyz);
-  HostIO<HF>::store(a.y, out_xyz + E);
-  HostIO<HF>::store(HF::one(), out_xyz + 2 * E);
+}
+int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz) {
+  switch (curve) {
+    case KG_G1: return msm_finish_t<G1Cfg>(ctx, slot, out_xyz);
+    case KG_GRUMPKIN: return msm_finish_t<GkCfg>(ctx, slot, out_xyz);
+    case KG_G2: return msm_finish_t<G2Cfg>(ctx, slot, out_xyz);
+    default: return KG_ERR_BAD_ARG;
+  }
+}
+void msm_identity(int curve, uint64_t* out_xyz) {
+  if (curve == KG_G2) store_projective<G2Cfg>(XYZZ<HostFq2>::identity(), out_xyz);
+  else if (curve == KG_GRUMPKIN) store_projective<GkCfg>(XYZZ<HostFr>::identity(), out_xyz);
+  else store_projective<G1Cfg>(XYZZ<HostFq>::identity(), out_xyz);
 }
 
-template <class Cfg>
-int msm_impl(kg_ctx* ctx, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
-  XYZZ<typename Cfg::HF> r;
-  KG_TRY(msm_device<Cfg>(ctx, d_bases, d_inf, d_scalars, n, r));
-  store_projective<Cfg>(r, out_xyz);
-  return KG_OK;
-}
+}  // namespace kg
+
+namespace {
 
 template <class Cfg>
 int sum_affine_impl(const uint64_t* pts, const uint8_t* inf, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
@@ -757,13 +795,13 @@ int sum_affine_impl(const uint64_t* pts, const uint8_t* inf, size_t count, uint6
 extern "C" {
 
 int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
-  if (!ctx || !out_xyz || (n && (!d_bases || !d_scalars))) return KG_ERR_BAD_ARG;
-  switch (curve) {
-    case KG_G1: return msm_impl<G1Cfg>(ctx, d_bases, d_inf, d_scalars, n, out_xyz);
-    case KG_GRUMPKIN: return msm_impl<GkCfg>(ctx, d_bases, d_inf, d_scalars, n, out_xyz);
-    case KG_G2: return msm_impl<G2Cfg>(ctx, d_bases, d_inf, d_scalars, n, out_xyz);
-    default: return KG_ERR_BAD_ARG;
-  }
+  if (!ctx || !out_xyz || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
+  if (n == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
+  prof_reset(ctx);
+  kg::MsmSorted S;
+  KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S));
+  KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 0));
+  return kg::msm_finish(ctx, curve, 0, out_xyz);
 }
 
 int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars, size_t n, uint64_t* out_xyz) {
