@@ -29,13 +29,18 @@ int ensure_ws3(kg_ctx* c, size_t bytes) {
   c->ws3_bytes = bytes;
   return KG_OK;
 }
-int ensure_ws_run(kg_ctx* c, size_t bytes) {
-  if (bytes <= c->ws_run_bytes) return KG_OK;
-  if (c->ws_run) { hipStreamSynchronize(c->stream); hipFree(c->ws_run); c->ws_run = nullptr; c->ws_run_bytes = 0; }
+int ensure_ws_run(kg_ctx* c, int which, size_t bytes) {
+  if (bytes <= c->ws_run_bytes[which]) return KG_OK;
+  if (c->ws_run[which]) {
+    hipStreamSynchronize(c->stream);
+    if (c->side_stream) hipStreamSynchronize(c->side_stream);
+    hipFree(c->ws_run[which]);
+    c->ws_run[which] = nullptr; c->ws_run_bytes[which] = 0;
+  }
   size_t want = bytes + bytes / 8;
-  hipError_t e = hipMalloc(&c->ws_run, want);
+  hipError_t e = hipMalloc(&c->ws_run[which], want);
   if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "msm run-space allocation", e);
-  c->ws_run_bytes = want;
+  c->ws_run_bytes[which] = want;
   return KG_OK;
 }
 int ensure_slot(kg_ctx* c, int slot, size_t bytes) {
@@ -69,15 +74,15 @@ static hipEvent_t next_event(kg_ctx* c) {
   return c->event_pool[c->event_next++];
 }
 void prof_reset(kg_ctx* c) { c->phases.clear(); c->event_next = 0; }
-PhaseScope::PhaseScope(kg_ctx* ctx, const char* name) : c(ctx) {
+PhaseScope::PhaseScope(kg_ctx* ctx, const char* name, hipStream_t stream) : c(ctx), s(stream ? stream : ctx->stream) {
   if (!c->prof) return;
   kg_ctx::Phase p{name, next_event(c), next_event(c)};
-  hipEventRecord(p.e0, c->stream);
+  hipEventRecord(p.e0, s);
   idx = (int)c->phases.size();
   c->phases.push_back(p);
 }
 void PhaseScope::end() {
-  if (idx >= 0) hipEventRecord(c->phases[idx].e1, c->stream);
+  if (idx >= 0) hipEventRecord(c->phases[idx].e1, s);
   idx = -1;
 }
 void tw_cache_free(kg_ctx* c);   // ntt.hip
@@ -129,7 +134,9 @@ void kg_ctx_destroy(kg_ctx* c) {
   if (c->ws) hipFree(c->ws);
   if (c->ws2) hipFree(c->ws2);
   if (c->ws3) hipFree(c->ws3);
-  if (c->ws_run) hipFree(c->ws_run);
+  if (c->side_stream) hipStreamSynchronize(c->side_stream);
+  for (int i = 0; i < 2; ++i) { if (c->ws_run[i]) hipFree(c->ws_run[i]); if (c->ev_acc[i]) hipEventDestroy(c->ev_acc[i]); }
+  if (c->side_stream) hipStreamDestroy(c->side_stream);
   if (c->ev_info) hipEventDestroy(c->ev_info);
   for (auto& sl : c->slots) { if (sl.host) hipHostFree(sl.host); if (sl.done) hipEventDestroy(sl.done); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -148,6 +155,7 @@ int kg_ctx_set_stream(kg_ctx* c, void* s) {
 int kg_ctx_sync(kg_ctx* c) {
   if (!c) return KG_ERR_BAD_ARG;
   KG_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->side_stream) KG_HIP(c, hipStreamSynchronize(c->side_stream));
   return KG_OK;
 }
 int kg_malloc(kg_ctx* c, size_t bytes, void** p) {
@@ -191,6 +199,7 @@ int kg_profile_enable(kg_ctx* c, int on) {
 int kg_profile_last(kg_ctx* c, const char** names, float* ms, int cap) {
   if (!c) return KG_ERR_BAD_ARG;
   hipStreamSynchronize(c->stream);
+  if (c->side_stream) hipStreamSynchronize(c->side_stream);
   int n = 0;
   for (auto& p : c->phases) {
     if (n >= cap) break;

@@ -23,10 +23,12 @@ struct kg_ctx {
   size_t ws2_bytes = 0;
   void* ws3 = nullptr;                   // prover polynomial buffers
   size_t ws3_bytes = 0;
-  void* ws_run = nullptr;                // MSM base-side scratch (packed bases, partial sums, halving buffers)
-  size_t ws_run_bytes = 0;
+  void* ws_run[2] = {nullptr, nullptr};  // MSM base-side scratch (packed bases, partial sums, halving buffers), double buffered
+  size_t ws_run_bytes[2] = {0, 0};
+  hipStream_t side_stream = nullptr;     // bucket reduction of MSM i overlaps the accumulation of MSM i+1
+  hipEvent_t ev_acc[2] = {nullptr, nullptr};
   hipEvent_t ev_info = nullptr;          // marks the task-count read-back of msm_sort
-  struct Slot { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0; };
+  struct Slot { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0; bool busy = false; };
   Slot slots[8];                         // pinned result slots: MSMs in flight whose host finish is pending
   void* h_pinned = nullptr;              // small pinned staging buffer for results
   size_t h_pinned_bytes = 0;
@@ -62,14 +64,14 @@ inline int set_err(kg_ctx* c, int code, const char* what, hipError_t e = hipSucc
 int ensure_ws(kg_ctx* c, size_t bytes);
 int ensure_ws2(kg_ctx* c, size_t bytes);
 int ensure_ws3(kg_ctx* c, size_t bytes);
-int ensure_ws_run(kg_ctx* c, size_t bytes);
+int ensure_ws_run(kg_ctx* c, int which, size_t bytes);
 int ensure_slot(kg_ctx* c, int slot, size_t bytes);
 int ensure_pinned(kg_ctx* c, size_t bytes);
 
 // RAII-free phase timer: PhaseScope p(ctx, "name"); ... p.end();
 struct PhaseScope {
-  kg_ctx* c; int idx = -1;
-  PhaseScope(kg_ctx* ctx, const char* name);
+  kg_ctx* c; int idx = -1; hipStream_t s;
+  PhaseScope(kg_ctx* ctx, const char* name, hipStream_t stream = nullptr);
   void end();
 };
 void prof_reset(kg_ctx* c);

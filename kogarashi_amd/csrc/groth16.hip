@@ -111,6 +111,20 @@ XYZZ<HF> h_scalar_mul(const XYZZ<HF>& p, const uint64_t k[4]) {
   }
   return acc;
 }
+// k1 * p + k2 * q in one double-and-add pass (Straus)
+template <class HF>
+XYZZ<HF> h_scalar_mul2(const XYZZ<HF>& p, const uint64_t k1[4], const XYZZ<HF>& q, const uint64_t k2[4]) {
+  const XYZZ<HF> pq = add_xyzz(p, q);
+  XYZZ<HF> acc = XYZZ<HF>::identity();
+  for (int b = 255; b >= 0; --b) {
+    acc = double_xyzz(acc);
+    const int b1 = (int)((k1[b >> 6] >> (b & 63)) & 1), b2 = (int)((k2[b >> 6] >> (b & 63)) & 1);
+    if (b1 && b2) acc = add_xyzz(acc, pq);
+    else if (b1) acc = add_xyzz(acc, p);
+    else if (b2) acc = add_xyzz(acc, q);
+  }
+  return acc;
+}
 void h_store(const HostFq& a, uint64_t* w) { a.to_words(w); }
 void h_store(const HostFq2& a, uint64_t* w) { a.c0.to_words(w); a.c1.to_words(w + 4); }
 template <class HF, int E>
@@ -218,11 +232,25 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
     if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, 0, 4);
     if (rc == KG_OK) finish_async(KG_G2, 4, b2i);
   }
+  // While the device works: the parts of the assembly (prover.rs:75-77) that do not depend on any MSM result
+  HostFr rm = HostFr::from_words(r), sm = HostFr::from_words(s);
+  HostFr raw_one{{1, 0, 0, 0}};
+  HostFr rk = mul(rm, raw_one), sk = mul(sm, raw_one), rsk = mul(mul(rm, sm), raw_one);   // out of Montgomery form
+  XYZZ<HostFq> alpha = from_affine(h_load_aff<HostFq, 4>(crs->alpha_g1)), beta1 = from_affine(h_load_aff<HostFq, 4>(crs->beta_g1)),
+               delta1 = from_affine(h_load_aff<HostFq, 4>(crs->delta_g1));
+  XYZZ<HostFq2> beta2 = from_affine(h_load_aff<HostFq2, 8>(crs->beta_g2)), delta2 = from_affine(h_load_aff<HostFq2, 8>(crs->delta_g2));
+  const bool bad_delta = crs->delta_g1_inf || crs->delta_g2_inf;
+  XYZZ<HostFq> g_a = XYZZ<HostFq>::identity(), g_c = g_a;
+  XYZZ<HostFq2> g_b = XYZZ<HostFq2>::identity();
+  if (rc == KG_OK && !bad_delta) {
+    g_a = add_xyzz(h_scalar_mul(delta1, rk.v), alpha);                                                      // :75
+    g_b = add_xyzz(h_scalar_mul(delta2, sk.v), beta2);                                                      // :76
+    g_c = add_xyzz(add_xyzz(h_scalar_mul(delta1, rsk.v), h_scalar_mul(alpha, sk.v)), h_scalar_mul(beta1, rk.v));   // :77
+  }
   for (auto& f : pending) { int r2 = f.get(); if (rc == KG_OK) rc = r2; }
   if (rc != KG_OK) return rc;
-  if (crs->delta_g1_inf || crs->delta_g2_inf) return set_err(ctx, KG_ERR_CRS, "delta is the identity");   // prover.rs:67-69
+  if (bad_delta) return set_err(ctx, KG_ERR_CRS, "delta is the identity");   // prover.rs:67-69
 
-  // assembly (prover.rs:71-98) on the host
   auto g1pt = [](const uint64_t* xyz) {
     bool inf = !(xyz[8] | xyz[9] | xyz[10] | xyz[11]);
     return h_from_abi<HostFq>(h_load_aff<HostFq, 4>(xyz), inf);
@@ -232,20 +260,12 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
     for (int i = 16; i < 24; ++i) inf = inf && xyz[i] == 0;
     return h_from_abi<HostFq2>(h_load_aff<HostFq2, 8>(xyz), inf);
   };
-  HostFr rm = HostFr::from_words(r), sm = HostFr::from_words(s);
-  HostFr raw_one{{1, 0, 0, 0}};
-  HostFr rk = mul(rm, raw_one), sk = mul(sm, raw_one), rsk = mul(mul(rm, sm), raw_one);   // out of Montgomery form
-  XYZZ<HostFq> alpha = from_affine(h_load_aff<HostFq, 4>(crs->alpha_g1)), beta1 = from_affine(h_load_aff<HostFq, 4>(crs->beta_g1)),
-               delta1 = from_affine(h_load_aff<HostFq, 4>(crs->delta_g1));
-  XYZZ<HostFq2> beta2 = from_affine(h_load_aff<HostFq2, 8>(crs->beta_g2)), delta2 = from_affine(h_load_aff<HostFq2, 8>(crs->delta_g2));
   XYZZ<HostFq> a_ans = add_xyzz(g1pt(ai), g1pt(aa));
   XYZZ<HostFq> b1_ans = add_xyzz(g1pt(b1i), g1pt(b1a));
   XYZZ<HostFq2> b2_ans = add_xyzz(g2pt(b2i), g2pt(b2a));
-  XYZZ<HostFq> g_a = add_xyzz(add_xyzz(h_scalar_mul(delta1, rk.v), alpha), a_ans);                         // :75,81
-  XYZZ<HostFq2> g_b = add_xyzz(add_xyzz(h_scalar_mul(delta2, sk.v), beta2), b2_ans);                       // :76,88
-  XYZZ<HostFq> g_c = add_xyzz(add_xyzz(h_scalar_mul(delta1, rsk.v), h_scalar_mul(alpha, sk.v)), h_scalar_mul(beta1, rk.v));   // :77
-  g_c = add_xyzz(g_c, h_scalar_mul(a_ans, sk.v));                                                          // :83
-  g_c = add_xyzz(g_c, h_scalar_mul(b1_ans, rk.v));                                                         // :90
+  g_a = add_xyzz(g_a, a_ans);                                                                              // :81
+  g_b = add_xyzz(g_b, b2_ans);                                                                             // :88
+  g_c = add_xyzz(g_c, h_scalar_mul2(a_ans, sk.v, b1_ans, rk.v));                                           // :83,90
   g_c = add_xyzz(g_c, add_xyzz(g1pt(q_p), g1pt(l_p)));                                                     // :92
   h_store_affine<HostFq, 4>(g_a, proof_out, proof_inf);
   h_store_affine<HostFq2, 8>(g_b, proof_out + 8, proof_inf + 1);

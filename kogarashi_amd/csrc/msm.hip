@@ -651,16 +651,22 @@ int msm_run_t(kg_ctx* ctx, const MsmSorted& S, const uint64_t* d_bases, const ui
   const size_t o_rowtot = cv.take((size_t)W * 4), o_misc = cv.take(64);
   const size_t exp_bytes = nexp * 4 * Cfg::E64 * 8;
   const size_t o_exp = cv.take(exp_bytes);
-  KG_TRY(ensure_ws_run(ctx, cv.off));
+  const int set = slot & 1;                         // double-buffered run space: the reduction of the previous MSM may still read the other set
+  KG_TRY(ensure_ws_run(ctx, set, cv.off));
   KG_TRY(ensure_slot(ctx, slot, exp_bytes));
-  char* ws = (char*)ctx->ws_run;
+  if (!ctx->side_stream) KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+  if (!ctx->ev_acc[set]) KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_acc[set], hipEventDisableTiming));
+  char* ws = (char*)ctx->ws_run[set];
   uint32_t* pb = (uint32_t*)(ws + o_pb);
   uint32_t* part[2] = {(uint32_t*)(ws + o_part[0]), (uint32_t*)(ws + o_part[1])};
   uint32_t* pbuf[2] = {(uint32_t*)(ws + o_pbuf[0]), (uint32_t*)(ws + o_pbuf[1])};
   uint32_t* rowtot = (uint32_t*)(ws + o_rowtot);
   uint32_t* misc = (uint32_t*)(ws + o_misc);
   uint64_t* d_exp = (uint64_t*)(ws + o_exp);
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ctx->stream, side = ctx->side_stream;
+  // this buffer set was last used by slot (slot - 2): its side-stream work must be over before we overwrite it
+  for (int s2 = 0; s2 < 8; ++s2)
+    if ((s2 & 1) == set && ctx->slots[s2].done && ctx->slots[s2].busy) { KG_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[s2].done, 0)); ctx->slots[s2].busy = false; }
   {
     PhaseScope ph(ctx, "prep_bases");
     hipLaunchKernelGGL(k_prep_bases<F>, dim3((unsigned)((nbases + 255) / 256)), dim3(256), 0, st, d_bases, d_inf, nbases, pb);
@@ -698,15 +704,19 @@ int msm_run_t(kg_ctx* ctx, const MsmSorted& S, const uint64_t* d_bases, const ui
     hipLaunchKernelGGL(k_gather_buckets<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, part[pcur], part_cap, L, W, B, pbuf[0]);
     ph.end();
   }
+  // the bucket reduction is a chain of c-1 latency-bound launches: it runs on the side stream so that the next MSM's
+  // accumulation (main stream, other buffer set) fills the chip meanwhile
+  KG_HIP(ctx, hipEventRecord(ctx->ev_acc[set], st));
+  KG_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_acc[set], 0));
   int cur = 0;
   {
-    PhaseScope ph(ctx, "reduce");
+    PhaseScope ph(ctx, "reduce", side);
     size_t in_stride = npts;                     // level 0 reads the bucket array: stride = W*B items
     int narr = 1;
     for (uint32_t n_out = (uint32_t)B / 2; n_out >= 1; n_out /= 2) {
       const size_t tasks = (size_t)W * narr * n_out;
       const size_t out_stride = (size_t)W * (narr + 1) * n_out;
-      hipLaunchKernelGGL(k_halve<F>, dim3((unsigned)((tasks + 63) / 64)), dim3(64), 0, st, pbuf[cur], in_stride, pbuf[cur ^ 1], out_stride,
+      hipLaunchKernelGGL(k_halve<F>, dim3((unsigned)((tasks + 63) / 64)), dim3(64), 0, side, pbuf[cur], in_stride, pbuf[cur ^ 1], out_stride,
                          W, narr, n_out);
       cur ^= 1;
       in_stride = out_stride;
@@ -714,14 +724,14 @@ int msm_run_t(kg_ctx* ctx, const MsmSorted& S, const uint64_t* d_bases, const ui
       if (n_out == 1) break;
     }
     // now: W windows x narr (= c) single points, stride W*c
-    hipLaunchKernelGGL((k_export<F, Cfg::E64>), dim3((unsigned)((nexp + 63) / 64)), dim3(64), 0, st, pbuf[cur], nexp, nexp, d_exp);
+    hipLaunchKernelGGL((k_export<F, Cfg::E64>), dim3((unsigned)((nexp + 63) / 64)), dim3(64), 0, side, pbuf[cur], nexp, nexp, d_exp);
     ph.end();
   }
   KG_HIP(ctx, hipGetLastError());
   kg_ctx::Slot& sl = ctx->slots[slot];
-  KG_HIP(ctx, hipMemcpyAsync(sl.host, d_exp, exp_bytes, hipMemcpyDeviceToHost, st));
-  KG_HIP(ctx, hipEventRecord(sl.done, st));
-  sl.W = W; sl.c = c;
+  KG_HIP(ctx, hipMemcpyAsync(sl.host, d_exp, exp_bytes, hipMemcpyDeviceToHost, side));
+  KG_HIP(ctx, hipEventRecord(sl.done, side));
+  sl.W = W; sl.c = c; sl.busy = true;
   return KG_OK;
 }
 
