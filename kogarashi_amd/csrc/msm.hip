@@ -124,7 +124,9 @@ __global__ void __launch_bounds__(1024) k_count(const uint32_t* __restrict__ kt,
                                                 uint32_t* __restrict__ cnt) {
   extern __shared__ uint32_t hist[];
   const int B = 1 << (c - 1);
-  const int ch = blockIdx.x, w = blockIdx.y, nch = gridDim.x;
+  // workgroups are dealt round-robin over the 8 XCDs by linear id: with the window in blockIdx.x (W = 16 or 17) all
+  // chunks of a window land on the same XCD, so its L2 sees every write to that window's region of the sorted lists
+  const int w = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;
   for (int b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
   __syncthreads();
   const size_t lo = (size_t)ch * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
@@ -153,27 +155,56 @@ __global__ void __launch_bounds__(256) k_scan_chunks(uint32_t* __restrict__ cnt,
   bsize[t] = run;
 }
 
-// per window: exclusive prefix of bucket sizes -> bucket start inside the window's sorted list
-__global__ void __launch_bounds__(1024) k_scan_buckets(const uint32_t* __restrict__ bsize, int B, uint32_t* __restrict__ bstart) {
-  __shared__ uint32_t part[1024];
-  const int w = blockIdx.x, T = blockDim.x;
+// exclusive scan of one row of B counters by one 1024-thread workgroup: every lane owns a contiguous run (read as
+// 16-byte vectors when the run allows), runs are combined with wave shuffles and one LDS hop
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* sh, uint32_t& total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  if (lane == 63) sh[wv] = inc;
+  __syncthreads();
+  if (wv == 0) {
+    uint32_t x = lane < 16 ? sh[lane] : 0, xi = x;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) { uint32_t o = __shfl_up(xi, d); if (lane >= d) xi += o; }
+    if (lane < 16) sh[16 + lane] = xi - x;
+    if (lane == 15) sh[32] = xi;
+  }
+  __syncthreads();
+  total = sh[32];
+  return inc - v + sh[16 + wv];
+}
+__device__ __forceinline__ void scan_row(const uint32_t* __restrict__ in, int B, uint32_t* __restrict__ out, uint32_t* __restrict__ row_total, int w) {
+  __shared__ uint32_t sh[40];
+  const int T = 1024;
   const int per = (B + T - 1) / T;
   const int lo = threadIdx.x * per, hi = lo + per < B ? lo + per : B;
+  const uint32_t* src = in + (size_t)w * B;
+  uint32_t* dst = out + (size_t)w * B;
   uint32_t s = 0;
-  for (int b = lo; b < hi; ++b) s += bsize[(size_t)w * B + b];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (int d = 1; d < T; d <<= 1) {           // Hillis-Steele inclusive scan
-    uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
+  if ((per & 3) == 0 && hi - lo == per) {
+    for (int b = lo; b < hi; b += 4) { uint4 q = *reinterpret_cast<const uint4*>(src + b); s += q.x + q.y + q.z + q.w; }
+  } else {
+    for (int b = lo; b < hi; ++b) s += src[b];
   }
-  uint32_t run = part[threadIdx.x] - s;
-  for (int b = lo; b < hi; ++b) {
-    bstart[(size_t)w * B + b] = run;
-    run += bsize[(size_t)w * B + b];
+  uint32_t total;
+  uint32_t run = block_exclusive_scan_1024(s, sh, total);
+  if ((per & 3) == 0 && hi - lo == per) {
+    for (int b = lo; b < hi; b += 4) {
+      uint4 q = *reinterpret_cast<const uint4*>(src + b), o;
+      o.x = run; o.y = run + q.x; o.z = o.y + q.y; o.w = o.z + q.z;
+      run = o.w + q.w;
+      *reinterpret_cast<uint4*>(dst + b) = o;
+    }
+  } else {
+    for (int b = lo; b < hi; ++b) { uint32_t v = src[b]; dst[b] = run; run += v; }
   }
+  if (threadIdx.x == 0 && row_total) row_total[w] = total;
+}
+// per window: exclusive prefix of bucket sizes -> bucket start inside the window's sorted list
+__global__ void __launch_bounds__(1024) k_scan_buckets(const uint32_t* __restrict__ bsize, int B, uint32_t* __restrict__ bstart) {
+  scan_row(bsize, B, bstart, nullptr, blockIdx.x);
 }
 
 __global__ void __launch_bounds__(1024) k_scatter(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len,
@@ -181,7 +212,7 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint32_t* __restrict__ k
                                                   uint32_t* __restrict__ sorted) {
   extern __shared__ uint32_t off[];
   const int B = 1 << (c - 1);
-  const int ch = blockIdx.x, w = blockIdx.y, nch = gridDim.x;
+  const int w = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;
   const uint32_t* src = cnt + ((size_t)w * nch + ch) * B;
   for (int b = threadIdx.x; b < B; b += blockDim.x) off[b] = src[b] + bstart[(size_t)w * B + b];
   __syncthreads();
@@ -233,26 +264,7 @@ __global__ void __launch_bounds__(1024) k_task_count(const uint32_t* __restrict_
 // per window: exclusive prefix of `in` -> rel, window total -> row_total[w]
 __global__ void __launch_bounds__(1024) k_scan_rows(const uint32_t* __restrict__ in, int B, uint32_t* __restrict__ rel,
                                                     uint32_t* __restrict__ row_total) {
-  __shared__ uint32_t part[1024];
-  const int w = blockIdx.x, T = blockDim.x;
-  const int per = (B + T - 1) / T;
-  const int lo = threadIdx.x * per, hi = lo + per < B ? lo + per : B;
-  uint32_t s = 0;
-  for (int b = lo; b < hi; ++b) s += in[(size_t)w * B + b];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (int d = 1; d < T; d <<= 1) {
-    uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[threadIdx.x] - s;
-  for (int b = lo; b < hi; ++b) {
-    rel[(size_t)w * B + b] = run;
-    run += in[(size_t)w * B + b];
-  }
-  if (threadIdx.x == T - 1 && row_total) row_total[w] = part[T - 1];
+  scan_row(in, B, rel, row_total, blockIdx.x);
 }
 // base[w] = sum_{w' < w} row_total[w'], base[W] = grand total; info[0] = grand total, info[1] = *maxv
 __global__ void k_row_bases(const uint32_t* __restrict__ row_total, int W, uint32_t* __restrict__ base, const uint32_t* __restrict__ maxv,
@@ -604,7 +616,7 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
       KG_HIP(ctx, hipFuncSetAttribute((const void*)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       KG_HIP(ctx, hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(k_count, dim3(nch, W), dim3(1024), lds, st, kt, n, c, W, chunk_len, cnt);
+    hipLaunchKernelGGL(k_count, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, cnt);
     hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, cnt, W, nch, B, S->bsize);
     // task decomposition (needs only the bucket sizes); its two result words travel to the host while the
     // scatter below still runs, so the read-back does not stall the queue
@@ -622,7 +634,7 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
     hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(64), 0, st, lenh, lenh + LEN_BINS);
     hipLaunchKernelGGL(k_len_scatter, dim3(g1024), dim3(1024), 0, st, S->bsize, S->lcnt, S->lrel, S->lbase, npts, B, T, lenh + LEN_BINS, S->task_bkt, S->task_id);
     hipLaunchKernelGGL(k_scan_buckets, dim3(W), dim3(1024), 0, st, S->bsize, B, S->bstart);
-    hipLaunchKernelGGL(k_scatter, dim3(nch, W), dim3(1024), lds, st, kt, n, c, W, chunk_len, cnt, S->bstart, S->sorted);
+    hipLaunchKernelGGL(k_scatter, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, cnt, S->bstart, S->sorted);
     ph.end();
     KG_HIP(ctx, hipGetLastError());
     KG_HIP(ctx, hipEventSynchronize(ctx->ev_info));
