@@ -15,6 +15,8 @@
 // domain conversion, only a limb re-packing at load/store.
 // Algorithmic HBM bytes: 64 B/element; this design moves 64 B/element per step.
 #include "common.h"
+#include "ntt_core.h"
+#include <type_traits>
 
 using namespace kg;
 
@@ -116,11 +118,15 @@ __device__ __forceinline__ Fr two_level(const uint32_t* __restrict__ lo, const u
 // LDS tile, structure-of-arrays: limb k of tile element e at lds[k * TILE + e]
 template <bool ROW>
 __device__ __forceinline__ uint32_t tile_index(uint32_t r, uint32_t col, uint32_t log_m, uint32_t log_tc) {
-  // col flavour: columns fastest (global loads run along columns); row flavour: rows fastest, odd pitch
+  // col flavour: columns fastest (global loads run along columns); row flavour: rows fastest, odd pitch.
+  // The row index is XOR-swizzled (bits 0-4 ^= bits 3-7): whichever 5 index bits vary across a 32-lane group in the
+  // three register passes (bits 3-7, then 0-2 and 6-7, then 0-4), the 32 lanes land on 32 different banks.
+  r ^= (r >> 3) & 31u;
   if (ROW) return col * ((1u << log_m) + 1u) + r;
   return (r << log_tc) + col;
 }
-constexpr int LDS_WORDS = 9 * (TILE + 8);
+constexpr int LDS_TILE_WORDS = 9 * (TILE + 8);
+constexpr int LDS_WORDS = LDS_TILE_WORDS + 9 * 128;      // tile + twiddle table w_m^e, e < 128
 
 __device__ __forceinline__ Fr lds_load(const uint32_t* lds, uint32_t e) {
   Fr r;
@@ -131,6 +137,50 @@ __device__ __forceinline__ Fr lds_load(const uint32_t* lds, uint32_t e) {
 __device__ __forceinline__ void lds_store(uint32_t* lds, uint32_t e, const Fr& a) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) lds[k * (TILE + 8) + e] = a.l[k];
+}
+
+// twiddle source of one register pass: w_{2^s}^j = w_m^(j * m / 2^s), from the LDS copy (m <= 256) or the global table
+struct TwSrc {
+  const uint32_t* twl;
+  const uint32_t* tw_small;
+  bool in_lds;
+  uint32_t log_m, s0, r_low;
+  __device__ __forceinline__ Fr operator()(int t, int k0) const {
+    const uint32_t s = s0 + (uint32_t)t;
+    const uint32_t j = (((uint32_t)k0 & ((1u << (t - 1)) - 1)) << s0) | r_low;     // r mod 2^(s-1)
+    if (in_lds) {
+      Fr r;
+      uint32_t e = j << (log_m - s);
+      e ^= e >> 4;                                            // same swizzle as the fill: strided exponents spread over banks
+#pragma unroll
+      for (int k = 0; k < 9; ++k) r.l[k] = twl[k * 128 + e];
+      return r;
+    }
+    return ld_tw(tw_small, (size_t)j << (SMALL_LOG - s));
+  }
+};
+
+// G consecutive radix-2 DIT stages (butterfly_arithmetic, fft.rs:195-218) with the 2^G elements of a lane in
+// registers: the lane owns the elements that differ in index bits [s0, s0+G), so a 2^8-point tile makes 3 LDS round
+// trips and 3 barriers instead of 8.
+template <bool ROW, int G>
+__device__ __forceinline__ void radix_pass(uint32_t* lds, const uint32_t* twl, bool tw_in_lds, const StepArgs& A, uint32_t s0) {
+  const uint32_t m = 1u << A.log_m, tc = 1u << A.log_tc;
+  const uint32_t groups = (m << A.log_tc) >> G;
+  for (uint32_t q = threadIdx.x; q < groups; q += NT) {
+    uint32_t col, rest;
+    if (ROW) { rest = q & ((m >> G) - 1); col = q >> (A.log_m - G); }
+    else { col = q & (tc - 1); rest = q >> A.log_tc; }
+    const uint32_t r_low = rest & ((1u << s0) - 1), r_high = rest >> s0;
+    const uint32_t base_r = (r_high << (s0 + G)) | r_low;
+    Fr x[1 << G];
+#pragma unroll
+    for (int k = 0; k < (1 << G); ++k) x[k] = lds_load(lds, tile_index<ROW>(base_r | ((uint32_t)k << s0), col, A.log_m, A.log_tc));
+    TwSrc tw{twl, A.tw_small, tw_in_lds, A.log_m, s0, r_low};
+    dit_network<G>(x, s0 == 0, tw);
+#pragma unroll
+    for (int k = 0; k < (1 << G); ++k) lds_store(lds, tile_index<ROW>(base_r | ((uint32_t)k << s0), col, A.log_m, A.log_tc), norm(x[k]));
+  }
 }
 
 template <bool ROW>
@@ -161,28 +211,28 @@ __global__ void __launch_bounds__(NT, 2) k_ntt_step(StepArgs A) {
   }
   __syncthreads();
 
-  // ---- log2(m) radix-2 DIT stages in LDS (butterfly_arithmetic, fft.rs:195-218) -----------------------
-  const uint32_t nbf = tile_elems >> 1;
-  for (uint32_t s = 1; s <= A.log_m; ++s) {
-    const uint32_t half = 1u << (s - 1);
-    for (uint32_t bt = threadIdx.x; bt < nbf; bt += NT) {
-      uint32_t col, pidx;
-      if (ROW) { pidx = bt & ((m >> 1) - 1); col = bt >> (A.log_m - 1); }
-      else { col = bt & (tc - 1); pidx = bt >> A.log_tc; }
-      const uint32_t j = pidx & (half - 1);
-      const uint32_t r0 = ((pidx >> (s - 1)) << s) + j, r1 = r0 + half;
-      const uint32_t e0 = tile_index<ROW>(r0, col, A.log_m, A.log_tc), e1 = tile_index<ROW>(r1, col, A.log_m, A.log_tc);
-      Fr a = lds_load(lds, e0), b = lds_load(lds, e1);
-      if (s == 1) {                                   // w_2^0 = 1: the first stage needs no product
-        lds_store(lds, e0, norm(add(a, b)));
-        lds_store(lds, e1, norm(sub<8, 1>(a, b)));
-      } else {
-        Fr t = mul(b, ld_tw(A.tw_small, (size_t)j << (SMALL_LOG - s)));     // w_{2^s}^j = w_1024^(j * 2^(10-s))
-        lds_store(lds, e0, norm(add(a, t)));
-        lds_store(lds, e1, norm(sub<4, 1>(a, t)));
-      }
+  // ---- log2(m) radix-2 DIT stages (butterfly_arithmetic, fft.rs:195-218), three at a time in registers: one lane
+  // owns the 8 elements that differ in index bits [s0, s0+3), so a tile makes 3 LDS round trips and 3 barriers instead
+  // of 8; twiddles w_m^e (e < m/2) sit in LDS behind the tile when m <= 256
+  uint32_t* twl = lds + LDS_TILE_WORDS;
+  const bool tw_in_lds = A.log_m <= 8;
+  if (tw_in_lds) {
+    const uint32_t cnt = m >> 1;
+    for (uint32_t e = threadIdx.x; e < cnt; e += NT) {
+      Fr w = ld_tw(A.tw_small, (size_t)e << (SMALL_LOG - A.log_m));
+#pragma unroll
+      for (int k = 0; k < 9; ++k) twl[k * 128 + (e ^ (e >> 4))] = w.l[k];
     }
     __syncthreads();
+  }
+  for (uint32_t s0 = 0; s0 < A.log_m;) {
+    const uint32_t left = A.log_m - s0;
+    const uint32_t g = left >= 3 ? (left == 4 ? 2 : 3) : left;       // 8 -> 3,3,2; 7 -> 3,2,2; 4 -> 2,2
+    if (g == 3) radix_pass<ROW, 3>(lds, twl, tw_in_lds, A, s0);
+    else if (g == 2) radix_pass<ROW, 2>(lds, twl, tw_in_lds, A, s0);
+    else radix_pass<ROW, 1>(lds, twl, tw_in_lds, A, s0);
+    __syncthreads();
+    s0 += g;
   }
 
   // ---- store: inter-step twiddle (or a plain value reduction), canonicalise, re-pack ------------------

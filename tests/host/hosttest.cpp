@@ -6,6 +6,7 @@
 #include "../../kogarashi_amd/csrc/fp29.h"
 #include "../../kogarashi_amd/csrc/fp29_checked.h"
 #include "../../kogarashi_amd/csrc/curve.h"
+#include "../../kogarashi_amd/csrc/ntt_core.h"
 
 using namespace kg;
 
@@ -113,4 +114,29 @@ extern "C" int ht_curve_sum(int curve, int checked, int mode, const uint32_t* pt
   if (curve == 0) return checked ? curve_sum<FqC>(mode, pts, inf, n, out_xy) : curve_sum<Fq>(mode, pts, inf, n, out_xy);
   if (curve == 1) return checked ? curve_sum<FrC>(mode, pts, inf, n, out_xy) : curve_sum<Fr>(mode, pts, inf, n, out_xy);
   return checked ? curve_sum<Fq2C>(mode, pts, inf, n, out_xy) : curve_sum<Fq2>(mode, pts, inf, n, out_xy);
+}
+
+// ---- NTT butterfly network (ntt_core.h) ---------------------------------------------------------------
+// data: 8 raw elements (any 256-bit value, as loaded by the kernel without a domain change), tw: 7 twiddles in the
+// ABI's Montgomery form (stage 1: tw[0]; stage 2: tw[1..2]; stage 3: tw[3..6]); `rounds` networks are chained with a
+// norm in between, like the kernel's passes.  Output: elements reduced to canonical form.
+template <class F> struct RawIn;
+template <class P> struct RawIn<Fp<P>> { static Fp<P> in(const uint32_t* w) { return limbs_from_words<P>(w); } };
+template <class P> struct RawIn<FpChecked<P>> { static FpChecked<P> in(const uint32_t* w) { return FpChecked<P>::wrap(limbs_from_words<P>(w), 5.4); } };
+template <class P> static void raw_out(const Fp<P>& a, uint32_t* w) { words_from_limbs(reduce_2p(vred(a)), w); }
+template <class P> static void raw_out(const FpChecked<P>& a, uint32_t* w) { words_from_limbs(reduce_2p(vred(a)).v, w); }
+
+template <class F>
+static void ntt_network(const uint32_t* data, const uint32_t* tw, int rounds, int trivial_first, uint32_t* out) {
+  F x[8], w[7];
+  for (int k = 0; k < 8; ++k) x[k] = RawIn<F>::in(data + 8 * k);
+  for (int k = 0; k < 7; ++k) w[k] = Conv<F>::in(tw + 8 * k);
+  for (int r = 0; r < rounds; ++r) {
+    dit_network<3>(x, trivial_first && r == 0, [&](int t, int k0) { return t == 1 ? w[0] : (t == 2 ? w[1 + (k0 & 1)] : w[3 + (k0 & 3)]); });
+    for (int k = 0; k < 8; ++k) x[k] = norm(x[k]);
+  }
+  for (int k = 0; k < 8; ++k) raw_out(x[k], out + 8 * k);
+}
+extern "C" void ht_ntt_network(int checked, const uint32_t* data, const uint32_t* tw, int rounds, int trivial_first, uint32_t* out) {
+  if (checked) ntt_network<FrC>(data, tw, rounds, trivial_first, out); else ntt_network<Fr>(data, tw, rounds, trivial_first, out);
 }

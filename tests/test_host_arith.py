@@ -107,3 +107,37 @@ def test_xyzz_point_formulas_match_bigint_oracle(hostlib, pyoracle, name):
                 assert curve_sum(hostlib, cid, cur, chk, 3, pts, inf) == cur.add(exp, exp), (name, ci, "dbl")
     for chk in (0, 1):
         assert curve_sum(hostlib, cid, cur, chk, 4, [A] * 5, [0] * 5) == cur.mul(A, 32)
+
+
+def test_ntt_butterfly_network_bounds_and_values(hostlib, oracle):
+    """The register-resident 3-stage DIT network of the NTT kernel (ntt_core.h): values vs the oracle's field ops, and
+    worst-case bounds via FpChecked over 3 chained passes (K grows by up to 4 per stage, limbs stay lazy inside a pass)."""
+    O = oracle
+    rng = np.random.default_rng(11)
+    for trial in range(20):
+        data = O.gen_scalars(0, SEED + 700 + trial, 0, 8)
+        if trial == 0:
+            data[:] = 0xFFFFFFFFFFFFFFFF                      # non-canonical all-ones input (value < 2^256)
+        tw = O.gen_scalars(0, SEED + 800 + trial, 0, 7)
+        rounds, trivial = 3, trial % 2
+        # reference: same network with fully reduced oracle arithmetic, on values taken mod p
+        # raw 256-bit loads stand for their residue mod p: from_mont(to_mont(v)) = v mod p
+        x = [data[k].copy() for k in range(8)]
+        x = [O.f_from_mont(0, O.f_to_mont(0, v)) for v in x]
+        for r in range(rounds):
+            for t in (1, 2, 3):
+                half = 1 << (t - 1)
+                for pi in range(4):
+                    k0 = ((pi >> (t - 1)) << t) | (pi & (half - 1)); k1 = k0 + half
+                    if t == 1 and trivial and r == 0:
+                        tt = x[k1]
+                    else:
+                        w = tw[0] if t == 1 else (tw[1 + (k0 & 1)] if t == 2 else tw[3 + (k0 & 3)])
+                        tt = O.f_mul(0, x[k1], w)
+                    a = x[k0]
+                    x[k0], x[k1] = O.f_add(0, a, tt), O.f_sub(0, a, tt)
+        want = np.stack(x)
+        for chk in (0, 1):
+            out = np.zeros((8, 4), dtype=np.uint64)
+            hostlib.ht_ntt_network(chk, p32(data.view(np.uint32)), p32(tw.view(np.uint32)), rounds, trivial, p32(out.view(np.uint32)))
+            assert (out == want).all(), (trial, chk)
