@@ -409,6 +409,12 @@ KG_HD Fp2<F> sqr(const Fp2<F>& a) {
 }
 template <class F>
 KG_HD Fp2<F> vred(const Fp2<F>& a) { return {vred(a.c0), vred(a.c1)}; }
+// a*b - c*d in Fq2 (the point formulas' Y3): component-wise from base-field products
+template <class F>
+KG_HD Fp2<F> mul2sub(const Fp2<F>& a, const Fp2<F>& b, const Fp2<F>& c, const Fp2<F>& d) {
+  Fp2<F> x = mul(a, b), y = mul(c, d);
+  return {vred(norm(sub<4, 1>(x.c0, y.c0))), vred(norm(sub<4, 1>(x.c1, y.c1)))};
+}
 template <class F>
 KG_HD bool is_zero_2p(const Fp2<F>& a) { return is_zero_2p(a.c0) && is_zero_2p(a.c1); }
 template <class F>
