@@ -115,9 +115,10 @@ def main():
         "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 64-bit accumulate)", "data": "synthetic",
         "config": {"workload": f"bn254 G1 MSM, 2^{args.log_n} uniform Fr scalars x uniform G1 bases per GPU, inputs resident in HBM",
                    "pairs_per_gpu": n, "sharding": "index range" if world > 1 else "none"},
-        "roofline": {"bound": "hbm", "kernel": "k_accumulate (bucket accumulation, one launch per MSM)",
+        "roofline": {"bound": "hbm", "kernel": "k_acc_tasks (bucket accumulation, one launch per MSM)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel_ms": acc_avg_ms, "algorithmic_bytes_per_launch": G1_BYTES_PER_PAIR * n},
+                     "traffic": pmc_traffic(args.log_n), "kernel_ms": acc_avg_ms, "algorithmic_bytes_per_launch": G1_BYTES_PER_PAIR * n,
+                     "note": "VALU-bound kernel (16 n point additions): see DESIGN.md section 3 for the instruction-rate bound"},
         "phases_ms_per_step": {k_: v_ / args.steps for k_, v_ in phase_sum.items()},
     }
 
@@ -132,6 +133,17 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(log_n):
+    """Memory-side bytes per k_acc_tasks launch from the committed rocprofv3 --pmc passes (profiles/): FETCH_SIZE and
+    WRITE_SIZE are collected in separate runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950.  Only valid for the configuration it was measured on (2^20 pairs); null otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01_e_pmc_hbm.json")
+    if log_n != LOG_N or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["k_acc_tasks_traffic_bytes_per_launch"]["total_corrected"]
 
 
 def bench_ntt(ctx, torch, dev, K, log_n=22, steps=10):

@@ -573,7 +573,8 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   if (nch < 1) nch = 1;
   const size_t chunk_len = (n + nch - 1) / nch;
   const size_t npts = (size_t)W * B;
-  uint32_t T = (uint32_t)(2 * (n / B) + 32);
+  // one task per bucket for uniform scalars: the unsigned top window of c = 15/16 holds twice the average load
+  uint32_t T = (uint32_t)(4 * (n / B) + 32);
   if (T < 64) T = 64;
   if (T > 4096) T = 4096;
   const size_t part_cap = (size_t)W * ((n + T - 1) / T) + npts;     // upper bound on round-1 tasks
