@@ -48,3 +48,50 @@ def test_product_does_not_import_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not bad.search(txt), f
                 assert "liboracle" not in txt, f
+
+
+def test_host_point_sums_without_a_device(lib):
+    """kg_points_sum_affine is the host half of the sharded commit (kogarashi_amd/dist.py): it needs no GPU, so its
+    group-law edge cases are checked here against the oracle for all three curves."""
+    import ctypes as C
+    import numpy as np
+    from oracle import oracle as O
+    so = lib.load()
+    seed = 0x4B6F676172617368
+
+    def host_sum(curve, pts, inf):
+        pts = np.ascontiguousarray(pts, dtype=np.uint64)
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+        xy = np.zeros(pts.shape[1], dtype=np.uint64)
+        oi = C.c_uint8(0)
+        assert so.kg_points_sum_affine(None, curve, pts.ctypes.data_as(C.c_void_p), inf.ctypes.data_as(C.c_void_p), C.c_size_t(len(inf)),
+                                       xy.ctypes.data_as(C.c_void_p), C.byref(oi)) == 0
+        return xy, int(oi.value)
+
+    for cv, curve, sfd in (("g1", 0, 0), ("gk", 1, 1), ("g2", 2, 0)):
+        k = O.gen_scalars(sfd, seed + 900 + curve, 0, 6)
+        pts, _ = O.fixed_base_mul(curve, k)
+        nb = pts.shape[1] // 2
+        base_fd = 0 if cv == "gk" else 1
+        neg0 = pts[0].copy()
+        for j in range(nb // 4):
+            neg0[nb + 4 * j: nb + 4 * j + 4] = O.f_neg(base_fd, pts[0, nb + 4 * j: nb + 4 * j + 4])
+        cases = [(pts, np.zeros(6, dtype=np.uint8)), (np.stack([pts[0], pts[0], pts[0]]), np.zeros(3, dtype=np.uint8)),
+                 (np.stack([pts[0], neg0]), np.zeros(2, dtype=np.uint8)), (pts, np.array([0, 1, 0, 1, 1, 0], dtype=np.uint8)),
+                 (pts[:2], np.ones(2, dtype=np.uint8))]
+        for arr, inf in cases:
+            want = None
+            for p, f in zip(arr, inf):
+                if f:
+                    continue
+                if want is None:
+                    one = np.concatenate([O.f_consts(base_fd)["r"], np.zeros(nb - 4, dtype=np.uint64)])
+                    want = np.concatenate([p, one])
+                else:
+                    want = O.add_mixed(cv, p, 0, want)
+            got_xy, got_inf = host_sum(curve, arr, inf)
+            if want is None:
+                assert got_inf == 1
+            else:
+                wxy, winf = O.to_affine(cv, want)
+                assert got_inf == winf and (winf or (got_xy == wxy).all()), (cv, len(arr))
