@@ -74,6 +74,10 @@ int kg_memcpy_d2d(kg_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 typedef enum { KG_OP_ADD = 0, KG_OP_SUB = 1, KG_OP_MUL = 2, KG_OP_SQUARE = 3, KG_OP_NEG = 4, KG_OP_DOUBLE = 5,
                KG_OP_INVERT = 6, KG_OP_FROM_MONT = 7, KG_OP_TO_MONT = 8 } kg_field_op;
 int kg_field_vec_op(kg_ctx* ctx, int field, int op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n);
+/* out[i] = a[i] + s * b[i]  (s: one element, HOST pointer): the vector folds of Nova's NIFS,
+ * nova/src/relaxed_r1cs/witness.rs:56-70 (W = W1 + r W2, E = E1 + r T + r^2 E2) and instance.rs:81-101 (x = x1 + r x2);
+ * Fr for the bn254 driver, Fq for the Grumpkin driver (nova/src/driver.rs:9-42). */
+int kg_field_vec_axpy(kg_ctx* ctx, int field, const uint64_t* d_a, const uint64_t* h_s, const uint64_t* d_b, uint64_t* d_out, size_t n);
 /* out[i] = a[i] * s  (s: one element, HOST pointer); fft.rs:104,150-154 */
 int kg_field_vec_scale(kg_ctx* ctx, int field, const uint64_t* d_a, const uint64_t* h_s, uint64_t* d_out, size_t n);
 

@@ -46,6 +46,21 @@ __global__ void __launch_bounds__(256) k_vec_scale(const uint64_t* __restrict__ 
   store_words(out, i, wo);
 }
 
+// out = a + s * b  (Nova fold, witness.rs:56-70): one product, lazy sum, one canonicalisation per element
+template <class P>
+__global__ void __launch_bounds__(256) k_vec_axpy(const uint64_t* __restrict__ a, Words8 s, const uint64_t* __restrict__ b,
+                                                  uint64_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t wa[8], wb[8], wo[8];
+  load_words(a, i, wa);
+  load_words(b, i, wb);
+  // raw(b) * internal(s) stays in the ABI's Montgomery domain, like raw(a)
+  Fp<P> t = mul(limbs_from_words<P>(wb), from_ref<P>(s.w));
+  words_from_limbs(reduce_2p(vred(norm(add(limbs_from_words<P>(wa), t)))), wo);
+  store_words(out, i, wo);
+}
+
 // CSR sparse matrix-vector product over Fr, one lane per row (zkstd/src/matrix/row.rs:43-51).  Rows of R1CS
 // matrices are short (a few entries), so the products are accumulated lazily and reduced once per row.
 __global__ void __launch_bounds__(256) k_r1cs_evaluate(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
@@ -191,6 +206,19 @@ int kg_field_vec_scale(kg_ctx* c, int field, const uint64_t* a, const uint64_t* 
   dim3 grid((unsigned)((n + 255) / 256));
   if (field == KG_FR) hipLaunchKernelGGL(k_vec_scale<FrParams>, grid, dim3(256), 0, c->stream, a, s, out, n);
   else hipLaunchKernelGGL(k_vec_scale<FqParams>, grid, dim3(256), 0, c->stream, a, s, out, n);
+  KG_HIP(c, hipGetLastError());
+  return KG_OK;
+}
+
+int kg_field_vec_axpy(kg_ctx* c, int field, const uint64_t* a, const uint64_t* h_s, const uint64_t* b, uint64_t* out, size_t n) {
+  if (!c || !h_s || (field != KG_FR && field != KG_FQ)) return KG_ERR_BAD_ARG;
+  if (n == 0) return KG_OK;
+  if (!a || !b || !out) return KG_ERR_BAD_ARG;
+  Words8 s;
+  for (int i = 0; i < 4; ++i) { s.w[2 * i] = (uint32_t)h_s[i]; s.w[2 * i + 1] = (uint32_t)(h_s[i] >> 32); }
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (field == KG_FR) hipLaunchKernelGGL(k_vec_axpy<FrParams>, grid, dim3(256), 0, c->stream, a, s, b, out, n);
+  else hipLaunchKernelGGL(k_vec_axpy<FqParams>, grid, dim3(256), 0, c->stream, a, s, b, out, n);
   KG_HIP(c, hipGetLastError());
   return KG_OK;
 }

@@ -21,7 +21,7 @@ EXPORTS = [
     "kg_ctx_sync", "kg_malloc", "kg_free", "kg_memcpy_h2d", "kg_memcpy_d2h", "kg_memcpy_d2d", "kg_field_vec_op",
     "kg_field_vec_scale", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_msm", "kg_msm_host", "kg_commit",
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
-    "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate",
+    "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy",
 ]
 
 
@@ -131,6 +131,10 @@ class Context:
     def field_vec_scale(self, field: int, a: int, s: np.ndarray, out: int, n: int):
         s = np.ascontiguousarray(s, dtype=np.uint64)
         self._chk(self._lib.kg_field_vec_scale(self._h, field, _vp(a), s.ctypes.data_as(C.c_void_p), _vp(out), C.c_size_t(n)), "kg_field_vec_scale")
+
+    def field_vec_axpy(self, field: int, a: int, s: np.ndarray, b: int, out: int, n: int):
+        s = np.ascontiguousarray(s, dtype=np.uint64)
+        self._chk(self._lib.kg_field_vec_axpy(self._h, field, _vp(a), s.ctypes.data_as(C.c_void_p), _vp(b), _vp(out), C.c_size_t(n)), "kg_field_vec_axpy")
 
     def ntt(self, data: int, log_n: int, inverse: bool, coset: bool):
         self._chk(self._lib.kg_ntt_bn254_fr(self._h, _vp(data), C.c_uint32(log_n), int(bool(inverse)), int(bool(coset))), "kg_ntt_bn254_fr")

@@ -59,6 +59,9 @@ def test_field_vector_ops(ctx, oracle, fd):
     s = O.gen_scalars(fd, SEED + 3, 0, 1)[0]
     ctx.field_vec_scale(fd, da.ptr, s, do.ptr, n)
     assert (do.numpy() == np.stack([O.f_mul(fd, a[i], s) for i in range(n)])).all()
+    # Nova fold W1 + r * W2 (nova/src/relaxed_r1cs/witness.rs:56-70)
+    ctx.field_vec_axpy(fd, da.ptr, s, db.ptr, do.ptr, n)
+    assert (do.numpy() == np.stack([O.f_add(fd, a[i], O.f_mul(fd, s, b[i])) for i in range(n)])).all()
 
 
 def test_generators_match_oracle(ctx, oracle):
