@@ -18,7 +18,7 @@ OUT = os.path.join(HERE, "libkogarashi_amd.so")
 SOURCES = ["capi.cpp", "vec.hip", "msm.hip", "ntt.hip", "groth16.hip"]
 HEADERS = ["common.h", "fp29.h", "fp_consts.h", "curve.h", "host_fp.h", "../../include/kogarashi_amd.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
-         "-ffp-contract=off"]
+         "-ffp-contract=off", "-Xarch_host", "-march=x86-64-v3"]
 
 
 def _stale(target: str, deps: list[str]) -> bool:

@@ -209,6 +209,11 @@ int kg_profile_last(kg_ctx* c, const char** names, float* ms, int cap) {
     if (ms) ms[n] = t;
     ++n;
   }
+  if (n < cap && c->host_finish_ms > 0.f) {
+    if (names) names[n] = "host_finish";
+    if (ms) ms[n] = c->host_finish_ms;
+    ++n;
+  }
   return n;
 }
 

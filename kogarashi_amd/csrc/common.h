@@ -39,6 +39,7 @@ struct kg_ctx {
   std::vector<Phase> phases;
   std::vector<hipEvent_t> event_pool;
   size_t event_next = 0;
+  float host_finish_ms = 0.f;            // wall time of the last host finish (double-and-add + inversion)
 };
 
 namespace kg {

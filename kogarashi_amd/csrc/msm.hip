@@ -19,6 +19,7 @@
 // Algorithmic HBM bytes: 96 B/pair (G1, Grumpkin), 160 B/pair (G2): SURVEY.md 8d.
 #include "common.h"
 #include "host_fp.h"
+#include <chrono>
 
 using namespace kg;
 
@@ -756,6 +757,7 @@ int msm_finish_t(kg_ctx* ctx, int slot, uint64_t* out_xyz) {
   kg_ctx::Slot& sl = ctx->slots[slot];
   hipSetDevice(ctx->device);
   if (hipEventSynchronize(sl.done) != hipSuccess) return KG_ERR_HIP;
+  const auto t0 = std::chrono::steady_clock::now();
   const uint64_t* hp = (const uint64_t*)sl.host;
   constexpr int PE = 4 * Cfg::E64;
   const int W = sl.W, c = sl.c;
@@ -767,6 +769,7 @@ int msm_finish_t(kg_ctx* ctx, int slot, uint64_t* out_xyz) {
     if (l == 0) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c) * PE));
   }
   store_projective<Cfg>(acc, out_xyz);
+  ctx->host_finish_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return KG_OK;
 }
 
