@@ -137,6 +137,9 @@ void kg_ctx_destroy(kg_ctx* c) {
   if (c->side_stream) hipStreamSynchronize(c->side_stream);
   for (int i = 0; i < 2; ++i) { if (c->ws_run[i]) hipFree(c->ws_run[i]); if (c->ev_acc[i]) hipEventDestroy(c->ev_acc[i]); }
   if (c->side_stream) hipStreamDestroy(c->side_stream);
+  if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); }
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  for (int i = 0; i < 2; ++i) if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
   if (c->ev_info) hipEventDestroy(c->ev_info);
   for (auto& sl : c->slots) { if (sl.host) hipHostFree(sl.host); if (sl.done) hipEventDestroy(sl.done); }
   if (c->h_pinned) hipHostFree(c->h_pinned);

@@ -26,6 +26,8 @@ struct kg_ctx {
   void* ws_run[2] = {nullptr, nullptr};  // MSM base-side scratch (packed bases, partial sums, halving buffers), double buffered
   size_t ws_run_bytes[2] = {0, 0};
   hipStream_t side_stream = nullptr;     // bucket reduction of MSM i overlaps the accumulation of MSM i+1
+  hipStream_t aux_stream = nullptr;      // third queue for the prover's independent transform chains
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   hipEvent_t ev_acc[2] = {nullptr, nullptr};
   hipEvent_t ev_info = nullptr;          // marks the task-count read-back of msm_sort
   struct Slot { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0; bool busy = false; };
@@ -164,6 +166,9 @@ struct MsmSorted {
   uint32_t *sorted = nullptr, *bsize = nullptr, *bstart = nullptr, *lcnt = nullptr, *lrel = nullptr, *lbase = nullptr;
   uint32_t *task_bkt = nullptr, *task_id = nullptr;
 };
+// ntt.hip
+int ntt_prepare(kg_ctx* ctx, uint32_t log_n, int inverse);
+int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, uint32_t log_n, int inverse, int coset);
 int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S);
 int msm_run(kg_ctx* ctx, const MsmSorted& S, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, uint32_t idx_off, int slot);
 int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz);

@@ -168,13 +168,34 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   uint64_t* A = (uint64_t*)ctx->ws3;
   uint64_t* B = A + 4 * n;
   uint64_t* C = B + 4 * n;
+  // The three idft -> coset_dft chains (prover.rs:36-41) are independent: each runs on its own stream with its own
+  // transform scratch, so a 2^18-point chain (128 workgroups per launch) does not leave half the chip idle.
+  if (!ctx->side_stream) KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+  if (!ctx->aux_stream) KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+  if (!ctx->ev_fork) {
+    KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[0], hipEventDisableTiming));
+    KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[1], hipEventDisableTiming));
+  }
+  KG_TRY(ntt_prepare(ctx, k, 0));
+  KG_TRY(ntt_prepare(ctx, k, 1));
+  KG_TRY(ensure_ws2(ctx, 3 * n * 32));
   const uint64_t* src[3] = {d_a_eval, d_b_eval, d_c_eval};
   uint64_t* dst[3] = {A, B, C};
-  for (int v = 0; v < 3; ++v) {                         // prepare_fft zero padding, then idft + coset_dft (prover.rs:36-41)
-    KG_HIP(ctx, hipMemcpyAsync(dst[v], src[v], m * 32, hipMemcpyDeviceToDevice, st));
-    if (n > m) KG_HIP(ctx, hipMemsetAsync(dst[v] + 4 * m, 0, (n - m) * 32, st));
-    KG_TRY(kg_ntt_bn254_fr(ctx, dst[v], k, 1, 0));
-    KG_TRY(kg_ntt_bn254_fr(ctx, dst[v], k, 0, 1));
+  hipStream_t lanes[3] = {st, ctx->side_stream, ctx->aux_stream};
+  KG_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+  for (int v = 0; v < 3; ++v) {                         // prepare_fft zero padding, then idft + coset_dft
+    hipStream_t sv = lanes[v];
+    uint64_t* tmp = (uint64_t*)ctx->ws2 + (size_t)v * 4 * n;
+    if (v) KG_HIP(ctx, hipStreamWaitEvent(sv, ctx->ev_fork, 0));
+    KG_HIP(ctx, hipMemcpyAsync(dst[v], src[v], m * 32, hipMemcpyDeviceToDevice, sv));
+    if (n > m) KG_HIP(ctx, hipMemsetAsync(dst[v] + 4 * m, 0, (n - m) * 32, sv));
+    KG_TRY(ntt_enqueue(ctx, sv, tmp, dst[v], k, 1, 0));
+    KG_TRY(ntt_enqueue(ctx, sv, tmp, dst[v], k, 0, 1));
+    if (v) {
+      KG_HIP(ctx, hipEventRecord(ctx->ev_join[v - 1], sv));
+      KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[v - 1], 0));
+    }
   }
   // (7^n - 1)^-1 on the host: n = 2^k squarings of 7
   HostFr seven = HostFr::one();
@@ -190,7 +211,7 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   for (int i = 0; i < 4; ++i) { zw.w[2 * i] = (uint32_t)z.v[i]; zw.w[2 * i + 1] = (uint32_t)(z.v[i] >> 32); }
   hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, C, n, zw);
   KG_HIP(ctx, hipGetLastError());
-  KG_TRY(kg_ntt_bn254_fr(ctx, A, k, 1, 1));             // coset_idft (prover.rs:47)
+  KG_TRY(ntt_enqueue(ctx, st, (uint64_t*)ctx->ws2, A, k, 1, 1));   // coset_idft (prover.rs:47)
 
   // The eight MSMs of prover.rs:51-65 as five: a_inputs + a_aux (:58-59,80) is one MSM of a[..] against
   // z = x || w, likewise b_g1 (:61-62,85) and b_g2 (:64-65,86) -- the sums are what the proof uses.  The four MSMs
@@ -221,16 +242,17 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   if (rc == KG_OK) {
     MsmSorted Sz;
     rc = msm_sort(ctx, KG_FR, Z, nz, &Sz);
-    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G1, crs->d_a, crs->d_a_inf, nz, 0, 1);
-    if (rc == KG_OK) finish_async(KG_G1, 1, ai);
-    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, nz, 0, 2);
-    if (rc == KG_OK) finish_async(KG_G1, 2, b1i);
+    // G2 first: its host finish (Fq2 arithmetic, ~3x a G1 finish) then overlaps the three G1 accumulations
+    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, 0, 1);
+    if (rc == KG_OK) finish_async(KG_G2, 1, b2i);
+    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G1, crs->d_a, crs->d_a_inf, nz, 0, 2);
+    if (rc == KG_OK) finish_async(KG_G1, 2, ai);
+    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, nz, 0, 3);
+    if (rc == KG_OK) finish_async(KG_G1, 3, b1i);
     if (rc == KG_OK && m_l_1) {
-      rc = msm_run(ctx, Sz, KG_G1, crs->d_l, crs->d_l_inf, m_l_1, (uint32_t)l, 3);
-      if (rc == KG_OK) finish_async(KG_G1, 3, l_p);
+      rc = msm_run(ctx, Sz, KG_G1, crs->d_l, crs->d_l_inf, m_l_1, (uint32_t)l, 4);
+      if (rc == KG_OK) finish_async(KG_G1, 4, l_p);
     } else msm_identity(KG_G1, l_p);
-    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, 0, 4);
-    if (rc == KG_OK) finish_async(KG_G2, 4, b2i);
   }
   // While the device works: the parts of the assembly (prover.rs:75-77) that do not depend on any MSM result
   HostFr rm = HostFr::from_words(r), sm = HostFr::from_words(s);

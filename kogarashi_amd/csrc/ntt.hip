@@ -329,15 +329,21 @@ void tw_cache_free(kg_ctx* c) {
 
 extern "C" {
 
-int kg_ntt_bn254_fr(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n, int inverse, int coset) {
-  if (!ctx || !d_data || log_n < 1 || log_n > 28) return KG_ERR_BAD_ARG;
-  KG_HIP(ctx, hipSetDevice(ctx->device));
-  prof_reset(ctx);
+}  // extern "C"
+
+namespace kg {
+// Build (or find) the twiddle tables of a transform size on the context's main stream.
+int ntt_prepare(kg_ctx* ctx, uint32_t log_n, int inverse) {
+  kg_tw_cache* T;
+  return get_tables(ctx, log_n, inverse ? 1 : 0, &T);
+}
+
+// Enqueue one transform on `st`; tmp: scratch of n elements private to this call (unused when log_n <= 8).
+int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, uint32_t log_n, int inverse, int coset) {
   inverse = inverse ? 1 : 0;
   kg_tw_cache* T;
   KG_TRY(get_tables(ctx, log_n, inverse, &T));
   const uint64_t n = 1ull << log_n;
-  hipStream_t st = ctx->stream;
   const size_t lds_bytes = (size_t)LDS_WORDS * 4;
   KG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   KG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -363,12 +369,8 @@ int kg_ntt_bn254_fr(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n, int inverse, 
   const bool post_scale = inverse != 0;              // idft: * n^-1 ; coset_idft: * n^-1 * 7^-i
   // plain idft (no coset) scales by the constant n^-1 in a separate pass below.
 
-  uint64_t* tmp = nullptr;
-  if (k1) {
-    KG_TRY(ensure_ws2(ctx, n * 32));
-    tmp = (uint64_t*)ctx->ws2;
-  }
-  PhaseScope ph(ctx, "ntt");
+  if (k1 && !tmp) return set_err(ctx, KG_ERR_BAD_ARG, "ntt scratch missing");
+  PhaseScope ph(ctx, "ntt", st);
   if (k1) {
     // step A: data -> tmp
     StepArgs a = base;
@@ -403,6 +405,21 @@ int kg_ntt_bn254_fr(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n, int inverse, 
     KG_HIP(ctx, hipGetLastError());
   }
   return KG_OK;
+}
+}  // namespace kg
+
+extern "C" {
+
+int kg_ntt_bn254_fr(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n, int inverse, int coset) {
+  if (!ctx || !d_data || log_n < 1 || log_n > 28) return KG_ERR_BAD_ARG;
+  KG_HIP(ctx, hipSetDevice(ctx->device));
+  prof_reset(ctx);
+  uint64_t* tmp = nullptr;
+  if (log_n > 8) {
+    KG_TRY(ensure_ws2(ctx, ((size_t)1 << log_n) * 32));
+    tmp = (uint64_t*)ctx->ws2;
+  }
+  return kg::ntt_enqueue(ctx, ctx->stream, tmp, d_data, log_n, inverse, coset);
 }
 
 int kg_fr_divide_by_z_on_coset(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n) {
