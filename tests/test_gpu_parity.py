@@ -208,3 +208,28 @@ def test_msm_skewed_scalars(ctx, oracle, c):
         assert gpu_aff(ctx.msm_host(0, bases, None, scal, n), 4) == want
     finally:
         ctx.set_msm_window(0)
+
+
+def test_msm_degenerate_inputs_hit_the_exceptional_branches(ctx, oracle):
+    """One base repeated with one scalar: every addition after the first meets an equal point (doubling branch of
+    add_mixed / add_xyzz, weierstrass.rs:75-81,114-120) and every bucket list is maximally skewed; alternating P, -P
+    cancels to the identity through the inverse-point branch."""
+    O = oracle
+    n = 6000
+    P = O.gen_bases(0, SEED + 95, 0, 1)[0]
+    bases = np.tile(P, (n, 1))
+    k = O.gen_scalars(0, SEED + 96, 0, 1)[0]
+    scal = np.tile(k, (n, 1))
+    want = aff(O, "g1", O.msm("g1", bases, scal, None, threads=8))
+    assert gpu_aff(ctx.msm_host(0, bases, None, scal, n), 4) == want
+    one = O.f_consts(0)["r"]
+    scal1 = np.tile(one, (n, 1))
+    want = aff(O, "g1", O.msm("g1", bases, scal1, None, threads=8))          # n * P
+    assert gpu_aff(ctx.msm_host(0, bases, None, scal1, n), 4) == want
+    negP = P.copy(); negP[4:] = O.f_neg(1, P[4:])
+    bases[1::2] = negP
+    assert gpu_aff(ctx.msm_host(0, bases, None, scal, n), 4) is None        # k*P - k*P + ... = identity
+    bases[-1] = P                                                            # odd one out
+    scal[-1] = one
+    want = aff(O, "g1", O.msm("g1", bases, scal, None, threads=8))
+    assert gpu_aff(ctx.msm_host(0, bases, None, scal, n), 4) == want
