@@ -78,6 +78,9 @@ int kg_field_vec_op(kg_ctx* ctx, int field, int op, const uint64_t* d_a, const u
  * nova/src/relaxed_r1cs/witness.rs:56-70 (W = W1 + r W2, E = E1 + r T + r^2 E2) and instance.rs:81-101 (x = x1 + r x2);
  * Fr for the bn254 driver, Fq for the Grumpkin driver (nova/src/driver.rs:9-42). */
 int kg_field_vec_axpy(kg_ctx* ctx, int field, const uint64_t* d_a, const uint64_t* h_s, const uint64_t* d_b, uint64_t* d_out, size_t n);
+/* out[i] = start * base^i, i < n  (start, base: one element each, HOST pointers): the `scan(one, *= g)` tables of
+ * fft.rs:35-41,56-70 and the powers of tau of the trusted setup, groth16/src/zksnark.rs:44-49. */
+int kg_field_powers(kg_ctx* ctx, int field, const uint64_t* h_start, const uint64_t* h_base, uint64_t* d_out, size_t n);
 /* out[i] = a[i] * s  (s: one element, HOST pointer); fft.rs:104,150-154 */
 int kg_field_vec_scale(kg_ctx* ctx, int field, const uint64_t* d_a, const uint64_t* h_s, uint64_t* d_out, size_t n);
 

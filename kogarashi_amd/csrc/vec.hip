@@ -46,6 +46,21 @@ __global__ void __launch_bounds__(256) k_vec_scale(const uint64_t* __restrict__ 
   store_words(out, i, wo);
 }
 
+// out[i] = start * base^i: each lane raises base to its own index (<= 64 squarings), no serial scan
+template <class P>
+__global__ void __launch_bounds__(256) k_powers(Words8 start, Words8 base, uint64_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fp<P> b = from_ref<P>(base.w), r = from_ref<P>(start.w);
+  for (size_t e = i; e; e >>= 1) {
+    if (e & 1) r = mul(r, b);
+    b = sqr(b);
+  }
+  uint32_t wo[8];
+  to_ref(r, wo);
+  store_words(out, i, wo);
+}
+
 // out = a + s * b  (Nova fold, witness.rs:56-70): one product, lazy sum, one canonicalisation per element
 template <class P>
 __global__ void __launch_bounds__(256) k_vec_axpy(const uint64_t* __restrict__ a, Words8 s, const uint64_t* __restrict__ b,
@@ -206,6 +221,22 @@ int kg_field_vec_scale(kg_ctx* c, int field, const uint64_t* a, const uint64_t* 
   dim3 grid((unsigned)((n + 255) / 256));
   if (field == KG_FR) hipLaunchKernelGGL(k_vec_scale<FrParams>, grid, dim3(256), 0, c->stream, a, s, out, n);
   else hipLaunchKernelGGL(k_vec_scale<FqParams>, grid, dim3(256), 0, c->stream, a, s, out, n);
+  KG_HIP(c, hipGetLastError());
+  return KG_OK;
+}
+
+int kg_field_powers(kg_ctx* c, int field, const uint64_t* h_start, const uint64_t* h_base, uint64_t* out, size_t n) {
+  if (!c || !h_start || !h_base || (field != KG_FR && field != KG_FQ)) return KG_ERR_BAD_ARG;
+  if (n == 0) return KG_OK;
+  if (!out) return KG_ERR_BAD_ARG;
+  Words8 s, b;
+  for (int i = 0; i < 4; ++i) {
+    s.w[2 * i] = (uint32_t)h_start[i]; s.w[2 * i + 1] = (uint32_t)(h_start[i] >> 32);
+    b.w[2 * i] = (uint32_t)h_base[i]; b.w[2 * i + 1] = (uint32_t)(h_base[i] >> 32);
+  }
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (field == KG_FR) hipLaunchKernelGGL(k_powers<FrParams>, grid, dim3(256), 0, c->stream, s, b, out, n);
+  else hipLaunchKernelGGL(k_powers<FqParams>, grid, dim3(256), 0, c->stream, s, b, out, n);
   KG_HIP(c, hipGetLastError());
   return KG_OK;
 }

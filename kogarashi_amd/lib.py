@@ -21,7 +21,7 @@ EXPORTS = [
     "kg_ctx_sync", "kg_malloc", "kg_free", "kg_memcpy_h2d", "kg_memcpy_d2h", "kg_memcpy_d2d", "kg_field_vec_op",
     "kg_field_vec_scale", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_msm", "kg_msm_host", "kg_commit",
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
-    "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy",
+    "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers",
 ]
 
 
@@ -114,6 +114,12 @@ class Context:
             self._chk(self._lib.kg_memcpy_h2d(self._h, _vp(d.ptr), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)), "kg_memcpy_h2d")
         return d
 
+    def write(self, dptr: int, arr: np.ndarray):
+        """host array -> device memory at dptr"""
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes:
+            self._chk(self._lib.kg_memcpy_h2d(self._h, _vp(dptr), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)), "kg_memcpy_h2d")
+
     def empty(self, shape, dtype=np.uint64) -> "DeviceArray":
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         return DeviceArray(self, nbytes, tuple(shape), np.dtype(dtype))
@@ -131,6 +137,11 @@ class Context:
     def field_vec_scale(self, field: int, a: int, s: np.ndarray, out: int, n: int):
         s = np.ascontiguousarray(s, dtype=np.uint64)
         self._chk(self._lib.kg_field_vec_scale(self._h, field, _vp(a), s.ctypes.data_as(C.c_void_p), _vp(out), C.c_size_t(n)), "kg_field_vec_scale")
+
+    def field_powers(self, field: int, start: np.ndarray, base: np.ndarray, out: int, n: int):
+        start = np.ascontiguousarray(start, dtype=np.uint64)
+        base = np.ascontiguousarray(base, dtype=np.uint64)
+        self._chk(self._lib.kg_field_powers(self._h, field, start.ctypes.data_as(C.c_void_p), base.ctypes.data_as(C.c_void_p), _vp(out), C.c_size_t(n)), "kg_field_powers")
 
     def field_vec_axpy(self, field: int, a: int, s: np.ndarray, b: int, out: int, n: int):
         s = np.ascontiguousarray(s, dtype=np.uint64)

@@ -173,3 +173,38 @@ def test_ntt_golden_and_fft_properties(oracle, pyoracle):
         for j, y in enumerate(bi):
             want[i + j] = (want[i + j] + x * y) % P.R_MOD
     assert [P.from_mont(I(x), P.R_MOD) for x in prod] == want
+
+
+def test_groth16_oracle_proof_verifies_in_the_exponent(oracle, pyoracle):
+    """Pins the oracle's restatement of ZkSnark::setup + Prover::create_proof without a pairing: with the toxic waste
+    known, the discrete logs of A, B, C follow from the witness by big-integer arithmetic alone; the proof points must be
+    those multiples of the generators, and a*b = alpha*beta + (sum_i ic_i x_i)*gamma + c*delta must hold (the Groth16
+    verification equation, groth16/src/proof.rs, read in the exponent)."""
+    O, P = oracle, pyoracle
+    p = P.R_MOD
+    fm = lambda x: P.from_mont(I(x), p)
+    for m in (4, 16):
+        cs = O.chain_r1cs(m, O.gen_scalars(0, SEED + 30 + m, 0, 1)[0])
+        a, b, c = cs.evaluate()
+        assert (O.fr_vec("mul", a, b) == c).all()                                  # is_sat (r1cs.rs:60-76)
+        toxic = O.gen_scalars(0, SEED + 31, 0, 5)
+        prm = O.groth16_params(cs, toxic, threads=4)
+        r, s = O.gen_scalars(0, SEED + 32, 0, 2)
+        A, B, C, inf = O.groth16_prove(cs, prm, r, s)
+        assert not inf.any()
+        alpha, beta, gamma, delta, tau = [fm(x) for x in toxic]
+        sc = prm["scalars"]
+        z = [fm(v) for v in np.concatenate([cs.x, cs.w])]
+        a_s, b_s, l_s, ic_s, h_s = ([fm(v) for v in sc[k]] for k in ("a", "b", "l", "ic", "h"))
+        k = max(1, (m - 1).bit_length())
+        av, bv, cv = ([fm(v) for v in t] for t in (a, b, c))
+        ac, bc, cc = (P.coset_dft(P.idft(t, k), k) for t in (av, bv, cv))
+        q = P.coset_idft(P.divide_by_z_on_coset([(x * y - w) % p for x, y, w in zip(ac, bc, cc)], k), k)
+        rr, ss = fm(r), fm(s)
+        a_dl = (alpha + sum(zi * ai for zi, ai in zip(z, a_s)) + rr * delta) % p
+        b_dl = (beta + sum(zi * bi for zi, bi in zip(z, b_s)) + ss * delta) % p
+        c_dl = (sum(zi * li for zi, li in zip(z[cs.l:], l_s)) + sum(qi * hi for qi, hi in zip(q, h_s)) + ss * a_dl + rr * b_dl - rr * ss * delta) % p
+        assert np_to_pt(P.G1, A, 0) == P.G1.mul(P.G1.gen, a_dl)
+        assert np_to_pt(P.G2, B, 0) == P.G2.mul(P.G2.gen, b_dl)
+        assert np_to_pt(P.G1, C, 0) == P.G1.mul(P.G1.gen, c_dl)
+        assert a_dl * b_dl % p == (alpha * beta + sum(zi * ici for zi, ici in zip(z[:cs.l], ic_s)) * gamma + c_dl * delta) % p
