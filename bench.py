@@ -169,9 +169,8 @@ def bench_ntt(ctx, torch, dev, K, log_n=22, steps=10):
 
 def bench_groth16(ctx, torch, dev, K, log_m=18, steps=3, cpu=True):
     """secondary line: Groth16 prove at m = 2^log_m constraints (BASELINE.json configs[3]).  Circuit: the chain
-    t_{i+1} = t_i * (t_i + 1) (x = [1, t_0], w = t_1..t_m); CRS: uniform valid curve points of the right shapes
-    (throughput does not depend on the CRS being a trapdoor image; tests/test_gpu_groth16.py proves parity on real
-    CRSs); fixed (r, s).  The CPU leg runs the oracle's create_proof on the same inputs and compares the proof."""
+    t_{i+1} = t_i * (t_i + 1) (x = [1, t_0], w = t_1..t_m); CRS:
+    a real CRS from a fixed toxic waste, generated on the device; fixed (r, s).  The CPU leg runs the oracle's create_proof on the same inputs and compares the proof."""
     import numpy as np
     from kogarashi_amd.lib import Groth16Crs
     R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
@@ -191,24 +190,38 @@ def bench_groth16(ctx, torch, dev, K, log_m=18, steps=3, cpu=True):
     up = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(dev)
     d_a, d_b, d_c, d_x, d_w = up(a_ev), up(b_ev), up(c_ev), up(x), up(w)
     nv = l + m_l_1
-    # CRS-shaped inputs generated on the device
-    g1 = {name: torch.empty(cnt * 8, dtype=torch.int64, device=dev) for name, cnt in (("h", m - 1), ("l", m_l_1), ("a", nv), ("b_g1", nv))}
-    for i, (name, cnt) in enumerate((("h", m - 1), ("l", m_l_1), ("a", nv), ("b_g1", nv))):
-        ctx.gen_bases(K.KG_G1, SEED + 20 + i, 0, cnt, g1[name].data_ptr())
-    k2 = torch.empty(nv * 4, dtype=torch.int64, device=dev)
-    ctx.gen_scalars(K.KG_FR, SEED + 30, 0, nv, k2.data_ptr())
-    b_g2 = torch.empty(nv * 16, dtype=torch.int64, device=dev)
-    b_g2_inf = torch.empty(nv, dtype=torch.uint8, device=dev)
-    ctx.fixed_base_mul(K.KG_G2, k2.data_ptr(), nv, b_g2.data_ptr(), b_g2_inf.data_ptr())
-    vk1 = torch.empty(3 * 8, dtype=torch.int64, device=dev)
-    ctx.gen_bases(K.KG_G1, SEED + 40, 0, 3, vk1.data_ptr())
-    torch.cuda.synchronize()
-    vk_g1 = vk1.cpu().numpy().view(np.uint64).reshape(3, 8)
-    vk_g2 = b_g2[: 2 * 16].cpu().numpy().view(np.uint64).reshape(2, 16)       # any two valid G2 points
+    # a REAL CRS for this circuit: ZkSnark::setup composed from the device primitives (kogarashi_amd.api.groth16_setup,
+    # parity-tested against the oracle in tests/test_gpu_groth16.py), toxic waste fixed
+    from kogarashi_amd.api import groth16_setup
+    wire = np.concatenate([[1], 2 + np.arange(m, dtype=np.uint64)]).astype(np.uint64)     # t_0 is instance wire 1, t_i (i > 0) witness i-1
+    ones = np.tile(one, (m, 1))
+    a_csr = (np.arange(m + 1, dtype=np.uint64), wire[:m].copy(), ones)
+    b_col = np.empty(2 * m, dtype=np.uint64)
+    b_col[0::2] = wire[:m]
+    b_col[1::2] = 0
+    b_csr = (np.arange(0, 2 * m + 1, 2, dtype=np.uint64), b_col, np.tile(one, (2 * m, 1)))
+    c_csr = (np.arange(m + 1, dtype=np.uint64), wire[1:].copy(), ones)
+
+    class FrOps:       # the five host-side scalars of the setup, in plain Python integers
+        to_i = staticmethod(lambda v: (sum(int(x) << (64 * j) for j, x in enumerate(v)) * pow(1 << 256, -1, R_MOD)) % R_MOD)
+        to_m = staticmethod(lambda i: np.array(mont(i), dtype=np.uint64))
+        one = staticmethod(lambda: one)
+        inv = classmethod(lambda cls, x: cls.to_m(pow(cls.to_i(x), -1, R_MOD)))
+        mul = classmethod(lambda cls, x, y: cls.to_m(cls.to_i(x) * cls.to_i(y) % R_MOD))
+        sub = classmethod(lambda cls, x, y: cls.to_m((cls.to_i(x) - cls.to_i(y)) % R_MOD))
+        pow2k = classmethod(lambda cls, x, k: cls.to_m(pow(cls.to_i(x), 1 << k, R_MOD)))
+
+    toxic = np.array([mont((0xA11CE + 0x9E3779B97F4A7C15 * (j + 1)) ** 3 % R_MOD) for j in range(5)], dtype=np.uint64)
+    P = groth16_setup(a_csr, b_csr, c_csr, m, l, m_l_1, toxic, FrOps, ctx=ctx)
+    dev_arr = {name: up(P[name]) for name in ("h", "l", "a", "b_g1", "b_g2")}
+    dev_inf = {name: (torch.from_numpy(P[name + "_inf"]).to(dev) if P[name + "_inf"].any() else None) for name in ("h", "l", "a", "b_g1", "b_g2")}
+    vk_g1, vk_g2 = P["vk_g1"], P["vk_g2"]
     crs = Groth16Crs()
     crs.m, crs.l, crs.m_l_1 = m, l, m_l_1
-    crs.d_h, crs.d_l, crs.d_a, crs.d_b_g1, crs.d_b_g2 = (g1["h"].data_ptr(), g1["l"].data_ptr(), g1["a"].data_ptr(),
-                                                          g1["b_g1"].data_ptr(), b_g2.data_ptr())
+    for name in ("h", "l", "a", "b_g1", "b_g2"):
+        setattr(crs, "d_" + name, dev_arr[name].data_ptr())
+        if dev_inf[name] is not None:
+            setattr(crs, "d_" + name + "_inf", dev_inf[name].data_ptr())
     for i in range(8):
         crs.alpha_g1[i], crs.beta_g1[i], crs.delta_g1[i] = int(vk_g1[0, i]), int(vk_g1[1, i]), int(vk_g1[2, i])
     for i in range(16):
@@ -229,14 +242,13 @@ def bench_groth16(ctx, torch, dev, K, log_m=18, steps=3, cpu=True):
                        "frac": out["algorithmic_bytes_per_proof"] / dt / 1e9 / HBM_PEAK_GBS}
     if cpu:
         from oracle import oracle as O
-        host = lambda tns, wd: tns.cpu().numpy().view(np.uint64).reshape(-1, wd)
-        P = {"h": host(g1["h"], 8), "l": host(g1["l"], 8), "a": host(g1["a"], 8), "b_g1": host(g1["b_g1"], 8), "b_g2": host(b_g2, 16),
-             "h_inf": None, "l_inf": None, "a_inf": None, "b_g1_inf": None, "b_g2_inf": b_g2_inf.cpu().numpy(),
-             "vk_g1": vk_g1, "vk_g2": np.concatenate([vk_g2, vk_g2[:1]])}
+        Pc = {name: P[name] for name in ("h", "l", "a", "b_g1", "b_g2")}
+        Pc.update({name + "_inf": (P[name + "_inf"] if P[name + "_inf"].any() else None) for name in ("h", "l", "a", "b_g1", "b_g2")})
+        Pc["vk_g1"], Pc["vk_g2"] = vk_g1, np.concatenate([vk_g2, vk_g2[:1]])
         cs = O.R1cs((np.zeros(m + 1, dtype=np.uint64),) * 3, (np.zeros(m + 1, dtype=np.uint64),) * 3, (np.zeros(m + 1, dtype=np.uint64),) * 3, x, w)
         threads = min(32, os.cpu_count() or 1)
         t0 = time.perf_counter()
-        want = O.groth16_prove(cs, P, r, s_, threads=threads, evals=(a_ev, b_ev, c_ev))
+        want = O.groth16_prove(cs, Pc, r, s_, threads=threads, evals=(a_ev, b_ev, c_ev))
         cdt = time.perf_counter() - t0
         same = all((g == w_).all() for g, w_ in zip(proof[:3], want[:3])) and (proof[3] == want[3]).all()
         out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "proofs/s", "cores": threads, "kind": "port",
