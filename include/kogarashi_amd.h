@@ -98,6 +98,13 @@ int kg_fr_divide_by_z_on_coset(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n);
  * out_xyz: HOST, 12 (G1, Grumpkin) or 24 (G2) uint64.  n == 0 yields the identity. */
 int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars,
            size_t n, uint64_t* out_xyz);
+/* Split form for callers with several MSMs to run (a prover issues five per proof): kg_msm_begin enqueues the whole
+ * device pipeline of one MSM and returns; kg_msm_end waits for it and runs the short host finish.  Up to 4 MSMs may be
+ * in flight (ticket = 0..3, reusable after its kg_msm_end); results are identical to kg_msm.  While MSM i+1 sorts and
+ * accumulates, MSM i's bucket reduction (side stream) and host finish overlap it. */
+int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars,
+                 size_t n, int ticket);
+int kg_msm_end(kg_ctx* ctx, int curve, int ticket, uint64_t* out_xyz);
 /* Same with HOST inputs (uploads, runs, frees): the call shape of the Rust slices. */
 int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars,
                 size_t n, uint64_t* out_xyz);
@@ -153,9 +160,11 @@ int kg_gen_scalars(kg_ctx* ctx, int field, uint64_t seed, size_t start, size_t n
 int kg_gen_bases(kg_ctx* ctx, int curve, uint64_t seed, size_t start, size_t n, uint64_t* d_out); /* G1, Grumpkin */
 
 /* ---- timing: when enabled, the library brackets its device phases with HIP events on its stream ------ */
-int kg_profile_enable(kg_ctx* ctx, int on);
-/* phases of the most recent call; returns the count written (<= cap); names are static strings */
-int kg_profile_last(kg_ctx* ctx, const char** names, float* ms, int cap);
+int kg_profile_enable(kg_ctx* ctx, int on);       /* (re)starts the accumulation */
+/* per phase name: summed milliseconds and number of occurrences since kg_profile_enable; returns the number of
+ * distinct names written (<= cap); names are static strings.  Synchronises the context's streams. */
+int kg_profile_summary(kg_ctx* ctx, const char** names, float* total_ms, int* counts, int cap);
+int kg_profile_last(kg_ctx* ctx, const char** names, float* ms, int cap);   /* = summary without the counts */
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,13 @@ int ensure_slot(kg_ctx* c, int slot, size_t bytes) {
   s.bytes = bytes;
   return KG_OK;
 }
+// The side stream carries the latency-bound bucket reductions of MSM i under the sort / accumulation of MSM i+1.
+// (A lowest-priority stream was measured and made no difference: the two queues do not compete for issue slots.)
+int make_side_stream(kg_ctx* c) {
+  hipError_t e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) return set_err(c, KG_ERR_HIP, "side stream creation", e);
+  return KG_OK;
+}
 int ensure_pinned(kg_ctx* c, size_t bytes) {
   if (bytes <= c->h_pinned_bytes) return KG_OK;
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -73,7 +80,7 @@ static hipEvent_t next_event(kg_ctx* c) {
   }
   return c->event_pool[c->event_next++];
 }
-void prof_reset(kg_ctx* c) { c->phases.clear(); c->event_next = 0; }
+void prof_reset(kg_ctx* c) { c->phases.clear(); c->event_next = 0; c->host_finish_ms = 0.f; c->host_finish_calls = 0; }
 PhaseScope::PhaseScope(kg_ctx* ctx, const char* name, hipStream_t stream) : c(ctx), s(stream ? stream : ctx->stream) {
   if (!c->prof) return;
   kg_ctx::Phase p{name, next_event(c), next_event(c)};
@@ -196,26 +203,38 @@ int kg_msm_set_window(kg_ctx* c, int w) {
 }
 int kg_profile_enable(kg_ctx* c, int on) {
   if (!c) return KG_ERR_BAD_ARG;
+  hipStreamSynchronize(c->stream);
+  if (c->side_stream) hipStreamSynchronize(c->side_stream);
   c->prof = on != 0;
+  prof_reset(c);                 // phases accumulate from here until the next enable / disable
   return KG_OK;
 }
 int kg_profile_last(kg_ctx* c, const char** names, float* ms, int cap) {
+  return kg_profile_summary(c, names, ms, nullptr, cap);
+}
+int kg_profile_summary(kg_ctx* c, const char** names, float* total_ms, int* counts, int cap) {
   if (!c) return KG_ERR_BAD_ARG;
   hipStreamSynchronize(c->stream);
   if (c->side_stream) hipStreamSynchronize(c->side_stream);
+  if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
   int n = 0;
+  std::vector<const char*> nm;
+  std::vector<float> tot;
+  std::vector<int> cnt;
   for (auto& p : c->phases) {
-    if (n >= cap) break;
     float t = 0;
-    if (hipEventElapsedTime(&t, p.e0, p.e1) != hipSuccess) t = -1.f;
-    if (names) names[n] = p.name;
-    if (ms) ms[n] = t;
-    ++n;
+    if (hipEventElapsedTime(&t, p.e0, p.e1) != hipSuccess) continue;
+    size_t k = 0;
+    while (k < nm.size() && nm[k] != p.name) ++k;
+    if (k == nm.size()) { nm.push_back(p.name); tot.push_back(0.f); cnt.push_back(0); }
+    tot[k] += t;
+    cnt[k] += 1;
   }
-  if (n < cap && c->host_finish_ms > 0.f) {
-    if (names) names[n] = "host_finish";
-    if (ms) ms[n] = c->host_finish_ms;
-    ++n;
+  if (c->host_finish_calls) { nm.push_back("host_finish"); tot.push_back(c->host_finish_ms); cnt.push_back(c->host_finish_calls); }
+  for (size_t k = 0; k < nm.size() && n < cap; ++k, ++n) {
+    if (names) names[n] = nm[k];
+    if (total_ms) total_ms[n] = tot[k];
+    if (counts) counts[n] = cnt[k];
   }
   return n;
 }

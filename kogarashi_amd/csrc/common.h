@@ -31,7 +31,8 @@ struct kg_ctx {
   hipEvent_t ev_acc[2] = {nullptr, nullptr};
   hipEvent_t ev_info = nullptr;          // marks the task-count read-back of msm_sort
   struct Slot { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0; bool busy = false; };
-  Slot slots[8];                         // pinned result slots: MSMs in flight whose host finish is pending
+  Slot slots[8];
+  size_t ticket_n[4] = {0, 0, 0, 0};     // lengths of the MSMs begun with kg_msm_begin                         // pinned result slots: MSMs in flight whose host finish is pending
   void* h_pinned = nullptr;              // small pinned staging buffer for results
   size_t h_pinned_bytes = 0;
   std::vector<kg_tw_cache*> tw;          // per-(log_n, inverse) twiddle tables
@@ -41,7 +42,8 @@ struct kg_ctx {
   std::vector<Phase> phases;
   std::vector<hipEvent_t> event_pool;
   size_t event_next = 0;
-  float host_finish_ms = 0.f;            // wall time of the last host finish (double-and-add + inversion)
+  float host_finish_ms = 0.f;            // summed wall time of the host finishes (double-and-add + inversion) since the last reset
+  int host_finish_calls = 0;
 };
 
 namespace kg {
@@ -70,6 +72,7 @@ int ensure_ws3(kg_ctx* c, size_t bytes);
 int ensure_ws_run(kg_ctx* c, int which, size_t bytes);
 int ensure_slot(kg_ctx* c, int slot, size_t bytes);
 int ensure_pinned(kg_ctx* c, size_t bytes);
+int make_side_stream(kg_ctx* c);
 
 // RAII-free phase timer: PhaseScope p(ctx, "name"); ... p.end();
 struct PhaseScope {

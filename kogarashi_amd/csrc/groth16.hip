@@ -170,7 +170,7 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   uint64_t* C = B + 4 * n;
   // The three idft -> coset_dft chains (prover.rs:36-41) are independent: each runs on its own stream with its own
   // transform scratch, so a 2^18-point chain (128 workgroups per launch) does not leave half the chip idle.
-  if (!ctx->side_stream) KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+  if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
   if (!ctx->aux_stream) KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
   if (!ctx->ev_fork) {
     KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -227,7 +227,6 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   uint64_t q_p[12], l_p[12], ai[12], aa[12], b1i[12], b1a[12], b2i[24], b2a[24];
   for (int i = 0; i < 12; ++i) aa[i] = b1a[i] = 0;       // identity (0, *, 0): the partner sums are folded in
   for (int i = 0; i < 24; ++i) b2a[i] = 0;
-  prof_reset(ctx);
   std::vector<std::future<int>> pending;
   auto finish_async = [&](int curve, int slot, uint64_t* out) {
     pending.emplace_back(std::async(std::launch::async, [ctx, curve, slot, out] { return msm_finish(ctx, curve, slot, out); }));

@@ -668,7 +668,7 @@ int msm_run_t(kg_ctx* ctx, const MsmSorted& S, const uint64_t* d_bases, const ui
   const int set = slot & 1;                         // double-buffered run space: the reduction of the previous MSM may still read the other set
   KG_TRY(ensure_ws_run(ctx, set, cv.off));
   KG_TRY(ensure_slot(ctx, slot, exp_bytes));
-  if (!ctx->side_stream) KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+  if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
   if (!ctx->ev_acc[set]) KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_acc[set], hipEventDisableTiming));
   char* ws = (char*)ctx->ws_run[set];
   uint32_t* pb = (uint32_t*)(ws + o_pb);
@@ -769,7 +769,10 @@ int msm_finish_t(kg_ctx* ctx, int slot, uint64_t* out_xyz) {
     if (l == 0) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c) * PE));
   }
   store_projective<Cfg>(acc, out_xyz);
-  ctx->host_finish_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (ctx->prof) {                                 // (worker threads of the prover may race here: statistics only)
+    ctx->host_finish_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->host_finish_calls += 1;
+  }
   return KG_OK;
 }
 
@@ -823,11 +826,25 @@ extern "C" {
 int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
   if (!ctx || !out_xyz || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
-  prof_reset(ctx);
   kg::MsmSorted S;
   KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S));
   KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 0));
   return kg::msm_finish(ctx, curve, 0, out_xyz);
+}
+
+int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, int ticket) {
+  if (!ctx || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2 || ticket < 0 || ticket > 3) return KG_ERR_BAD_ARG;
+  ctx->ticket_n[ticket] = n;
+  if (n == 0) return KG_OK;
+  kg::MsmSorted S;
+  KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S));
+  return kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 4 + ticket);       // slots 4..7: 0..3 belong to kg_msm / the prover
+}
+
+int kg_msm_end(kg_ctx* ctx, int curve, int ticket, uint64_t* out_xyz) {
+  if (!ctx || !out_xyz || curve < 0 || curve > KG_G2 || ticket < 0 || ticket > 3) return KG_ERR_BAD_ARG;
+  if (ctx->ticket_n[ticket] == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
+  return kg::msm_finish(ctx, curve, 4 + ticket, out_xyz);
 }
 
 int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars, size_t n, uint64_t* out_xyz) {

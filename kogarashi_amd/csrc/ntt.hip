@@ -413,7 +413,6 @@ extern "C" {
 int kg_ntt_bn254_fr(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n, int inverse, int coset) {
   if (!ctx || !d_data || log_n < 1 || log_n > 28) return KG_ERR_BAD_ARG;
   KG_HIP(ctx, hipSetDevice(ctx->device));
-  prof_reset(ctx);
   uint64_t* tmp = nullptr;
   if (log_n > 8) {
     KG_TRY(ensure_ws2(ctx, ((size_t)1 << log_n) * 32));

@@ -21,7 +21,7 @@ EXPORTS = [
     "kg_ctx_sync", "kg_malloc", "kg_free", "kg_memcpy_h2d", "kg_memcpy_d2h", "kg_memcpy_d2d", "kg_field_vec_op",
     "kg_field_vec_scale", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_msm", "kg_msm_host", "kg_commit",
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
-    "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers",
+    "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary",
 ]
 
 
@@ -158,6 +158,14 @@ class Context:
         self._chk(self._lib.kg_msm(self._h, curve, _vp(bases), _vp(inf), _vp(scalars), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)), "kg_msm")
         return out
 
+    def msm_begin(self, curve: int, bases: int, inf: int, scalars: int, n: int, ticket: int):
+        self._chk(self._lib.kg_msm_begin(self._h, curve, _vp(bases), _vp(inf), _vp(scalars), C.c_size_t(n), int(ticket)), "kg_msm_begin")
+
+    def msm_end(self, curve: int, ticket: int) -> np.ndarray:
+        out = np.zeros(24 if curve == KG_G2 else 12, dtype=np.uint64)
+        self._chk(self._lib.kg_msm_end(self._h, curve, int(ticket), out.ctypes.data_as(C.c_void_p)), "kg_msm_end")
+        return out
+
     def msm_host(self, curve: int, bases: np.ndarray, inf, scalars: np.ndarray, n: int) -> np.ndarray:
         out = np.zeros(24 if curve == KG_G2 else 12, dtype=np.uint64)
         bases = np.ascontiguousarray(bases, dtype=np.uint64)
@@ -217,10 +225,16 @@ class Context:
         self._chk(self._lib.kg_profile_enable(self._h, int(on)), "kg_profile_enable")
 
     def profile_last(self) -> dict:
-        names = (C.c_char_p * 16)()
-        ms = (C.c_float * 16)()
-        n = self._lib.kg_profile_last(self._h, names, ms, 16)
-        return {names[i].decode(): float(ms[i]) for i in range(max(n, 0))}
+        """{phase: summed ms} since profile_enable"""
+        return {k: v[0] for k, v in self.profile_summary().items()}
+
+    def profile_summary(self) -> dict:
+        """{phase: (summed ms, occurrences)} since profile_enable"""
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        cnt = (C.c_int * 32)()
+        n = self._lib.kg_profile_summary(self._h, names, ms, cnt, 32)
+        return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(max(n, 0))}
 
 
 class DeviceArray:

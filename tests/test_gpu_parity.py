@@ -233,3 +233,26 @@ def test_msm_degenerate_inputs_hit_the_exceptional_branches(ctx, oracle):
     scal[-1] = one
     want = aff(O, "g1", O.msm("g1", bases, scal, None, threads=8))
     assert gpu_aff(ctx.msm_host(0, bases, None, scal, n), 4) == want
+
+
+def test_msm_begin_end_pipeline_matches_blocking_calls(ctx, oracle):
+    """kg_msm_begin / kg_msm_end with several MSMs in flight (different sizes, curves and tickets) give exactly the
+    results of the blocking kg_msm."""
+    import kogarashi_amd as K
+    O = oracle
+    jobs = []
+    for i, (curve, sfd, n) in enumerate([(0, 0, 3000), (1, 1, 700), (0, 0, 20000), (0, 0, 1), (1, 1, 5000), (0, 0, 0)]):
+        b = O.gen_bases(curve, SEED + 200 + i, 0, max(n, 1))[:n]
+        s = O.gen_scalars(sfd, SEED + 210 + i, 0, max(n, 1))[:n]
+        jobs.append((curve, n, ctx.upload(b) if n else None, ctx.upload(s) if n else None))
+    want = [ctx.msm(c, b.ptr if b else 0, 0, s.ptr if s else 0, n) for c, n, b, s in jobs]
+    got = [None] * len(jobs)
+    depth = 3
+    for i, (c, n, b, s) in enumerate(jobs):
+        if i >= depth:
+            got[i - depth] = ctx.msm_end(jobs[i - depth][0], (i - depth) % 4)
+        ctx.msm_begin(c, b.ptr if b else 0, 0, s.ptr if s else 0, n, i % 4)
+    for i in range(max(0, len(jobs) - depth), len(jobs)):
+        got[i] = ctx.msm_end(jobs[i][0], i % 4)
+    for g, w in zip(got, want):
+        assert (g == w).all()
