@@ -76,15 +76,23 @@ __global__ void __launch_bounds__(256) k_vec_axpy(const uint64_t* __restrict__ a
   store_words(out, i, wo);
 }
 
-// CSR sparse matrix-vector product over Fr, one lane per row (zkstd/src/matrix/row.rs:43-51).  Rows of R1CS
-// matrices are short (a few entries), so the products are accumulated lazily and reduced once per row.
+// CSR sparse matrix-vector product over Fr (zkstd/src/matrix/row.rs:43-51), one WAVE per row: lanes stride over the
+// row's entries, partial sums meet through 6 shuffle steps.  R1CS rows are short, but the transposed system used by the
+// setup has a column (the constant-one wire) touching every constraint, so a row may hold millions of entries.
+__device__ __forceinline__ Fr shfl_xor_fr(const Fr& a, int mask) {
+  Fr r;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r.l[k] = __shfl_xor(a.l[k], mask);
+  return r;
+}
 __global__ void __launch_bounds__(256) k_r1cs_evaluate(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
                                                        const uint64_t* __restrict__ val, size_t m, const uint64_t* __restrict__ z,
                                                        uint64_t* __restrict__ out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
+  const size_t row = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= m) return;
   Fr sum = Fr::zero();
-  for (uint64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+  for (uint64_t e = row_ptr[row] + lane; e < row_ptr[row + 1]; e += 64) {
     uint32_t wv[8], wz[8];
     load_words(val, e, wv);
     load_words(z, col[e], wz);
@@ -92,9 +100,13 @@ __global__ void __launch_bounds__(256) k_r1cs_evaluate(const uint64_t* __restric
     Fr t = mul(limbs_from_words<FrParams>(wz), from_ref<FrParams>(wv));
     sum = vred(norm(add(sum, t)));
   }
-  uint32_t wo[8];
-  words_from_limbs(reduce_2p(sum), wo);
-  store_words(out, i, wo);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum = vred(norm(add(sum, shfl_xor_fr(sum, d))));
+  if (lane == 0) {
+    uint32_t wo[8];
+    words_from_limbs(reduce_2p(sum), wo);
+    store_words(out, row, wo);
+  }
 }
 
 // ---- splitmix64 streams (oracle/pyoracle.py stream_at, oracle/kg_oracle.c stream_words) ---------------
@@ -258,7 +270,7 @@ int kg_r1cs_evaluate(kg_ctx* c, const uint64_t* row_ptr, const uint64_t* col, co
   if (!c) return KG_ERR_BAD_ARG;
   if (m == 0) return KG_OK;
   if (!row_ptr || !col || !val || !z || !out) return KG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_r1cs_evaluate, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, row_ptr, col, val, m, z, out);
+  hipLaunchKernelGGL(k_r1cs_evaluate, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, c->stream, row_ptr, col, val, m, z, out);
   KG_HIP(c, hipGetLastError());
   return KG_OK;
 }
