@@ -20,6 +20,14 @@ SEED = 0x4B6F676172617368
 LOG_N = 20
 G1_BYTES_PER_PAIR = 96          # 32 B scalar + 64 B affine base
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+MADD_PEAK_G = 14.8              # measured: mixed XYZZ additions/s per chip, operands in registers (profiles/r01_mul_rate.txt)
+
+
+def window_adds(n):
+    """bucket additions of one MSM: one per (window, scalar) pair with a non-zero digit ~ W * n"""
+    lg = n.bit_length() - 1
+    c = 16 if lg >= 19 else (15 if lg >= 14 else min(max(lg - 3, 2), 10))
+    return ((255 + c - 1) // c) * n
 
 
 def main():
@@ -124,6 +132,10 @@ def main():
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(args.log_n), "kernel_ms": acc_avg_ms, "algorithmic_bytes_per_launch": G1_BYTES_PER_PAIR * n,
                      "note": "VALU-bound kernel (16 n point additions): see DESIGN.md section 3 for the instruction-rate bound"},
+        # the bound that actually limits the kernel: point additions per second against the chip's measured rate for the
+        # same madd routine with operands in registers (tools/ubench/mul_rate.hip, profiles/r01_mul_rate.txt)
+        "valu_roofline": {"bound": "valu", "unit": "G point additions/s", "achieved": window_adds(n) / (acc_avg_ms * 1e-3) / 1e9,
+                          "peak": MADD_PEAK_G, "frac": window_adds(n) / (acc_avg_ms * 1e-3) / 1e9 / MADD_PEAK_G},
         "phases_ms_per_step": phase_avg, "pipelining": "two MSM steps in flight (kg_msm_begin / kg_msm_end)",
     }
 
