@@ -140,6 +140,17 @@ def main():
     }
 
     if rank == 0 and world == 1:
+        # informational: the same steps with the bases registered (kg_bases_register: converted to the internal
+        # form once, as a resident CRS / commitment key would be); never the headline value
+        ctx.bases_register(K.KG_G1, bases.data_ptr(), 0, n)
+        run(2)
+        barrier()
+        t0 = time.perf_counter()
+        res_reg = run(args.steps)
+        barrier()
+        line["registered_bases"] = {"ms_per_step": (time.perf_counter() - t0) / args.steps * 1e3,
+                                    "matches_unregistered": bool((res_reg[0] == res[0]).all() and res_reg[1] == res[1])}
+        ctx.bases_unregister(bases.data_ptr())
         if not args.no_ntt:
             line["ntt"] = bench_ntt(ctx, torch, dev, K)
         if not args.no_cpu_baseline:

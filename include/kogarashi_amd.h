@@ -117,6 +117,13 @@ int kg_commit(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_
  * kg_points_sum_affine.  See DESIGN.md "Multi-GPU". */
 int kg_points_sum_affine(kg_ctx* ctx, int curve, const uint64_t* h_points_xy, const uint8_t* h_inf, size_t count,
                          uint64_t* out_xy, uint8_t* out_inf);
+/* Resident bases (CRS vectors, commitment keys): registering an array converts it ONCE to the device's internal form
+ * (the reference re-reads and re-converts its bases on every call).  Afterwards every entry point that is handed a
+ * pointer inside a registered array (kg_msm, kg_msm_begin, kg_commit, kg_groth16_prove_bn254; any whole-point offset,
+ * e.g. params.a[cs.l()..]) skips the per-call conversion.  The caller must not modify a registered array;
+ * d_inf (may be NULL) is captured at registration.  kg_bases_unregister(d_bases) releases it. */
+int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t n);
+int kg_bases_unregister(kg_ctx* ctx, const uint64_t* d_bases);
 /* Tuning knob: window width c (0 = automatic). */
 int kg_msm_set_window(kg_ctx* ctx, int c);
 

@@ -95,6 +95,13 @@ class PedersenCommitment:
         self._inf = None
         if is_infinity is not None:
             self._inf = self.ctx.upload(np.ascontiguousarray(is_infinity, dtype=np.uint8))
+        self.ctx.bases_register(self.cid, self._g.ptr, self._inf.ptr if self._inf else 0, self.len)
+
+    def __del__(self):
+        try:
+            self.ctx.bases_unregister(self._g.ptr)
+        except Exception:
+            pass
 
     def commit(self, m):
         m = np.ascontiguousarray(m, dtype=np.uint64).reshape(-1, 4)
@@ -114,6 +121,7 @@ class Prover:
         self.ctx = ctx or default_context()
         self.m, self.l, self.m_l_1 = m, l, m_l_1
         self._keep = []
+        self._registered = []
         crs = Groth16Crs()
         crs.m, crs.l, crs.m_l_1 = m, l, m_l_1
         for name, w in (("h", 8), ("l", 8), ("a", 8), ("b_g1", 8), ("b_g2", 16)):
@@ -122,10 +130,14 @@ class Prover:
             self._keep.append(d)
             setattr(crs, "d_" + name, d.ptr)
             inf = params.get(name + "_inf")
+            di = None
             if inf is not None and np.any(inf):
                 di = self.ctx.upload(np.ascontiguousarray(inf, dtype=np.uint8))
                 self._keep.append(di)
                 setattr(crs, "d_" + name + "_inf", di.ptr)
+            # Parameters is immutable: convert each CRS vector to the device's internal form once
+            self.ctx.bases_register(KG_G2 if w == 16 else KG_G1, d.ptr, di.ptr if di else 0, len(arr))
+            self._registered.append(d.ptr)
         g1 = np.ascontiguousarray(params["vk_g1"], dtype=np.uint64).reshape(-1, 8)
         g2 = np.ascontiguousarray(params["vk_g2"], dtype=np.uint64).reshape(-1, 16)
         for i in range(8):
@@ -135,6 +147,13 @@ class Prover:
         crs.delta_g1_inf = int(bool(params.get("delta_g1_inf", 0)))
         crs.delta_g2_inf = int(bool(params.get("delta_g2_inf", 0)))
         self.crs = crs
+
+    def __del__(self):
+        for p_ in getattr(self, "_registered", []):
+            try:
+                self.ctx.bases_unregister(p_)
+            except Exception:
+                pass
 
     def create_proof(self, a_eval, b_eval, c_eval, x, w, r, s):
         """Proof {a, b, c} for the synthesised constraint system: (A, B, C) = cs.evaluate(), x = cs.x(), w = cs.w();

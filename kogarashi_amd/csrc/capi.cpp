@@ -150,6 +150,7 @@ void kg_ctx_destroy(kg_ctx* c) {
   if (c->ev_info) hipEventDestroy(c->ev_info);
   for (auto& sl : c->slots) { if (sl.host) hipHostFree(sl.host); if (sl.done) hipEventDestroy(sl.done); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
+  for (auto& r : c->registered) hipFree(r.packed);
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -176,7 +177,10 @@ int kg_malloc(kg_ctx* c, size_t bytes, void** p) {
 }
 int kg_free(kg_ctx* c, void* p) {
   if (!c) return KG_ERR_BAD_ARG;
-  if (p) KG_HIP(c, hipFree(p));
+  if (p) {
+    kg_bases_unregister(c, (const uint64_t*)p);     // a freed array must never be served from its registration
+    KG_HIP(c, hipFree(p));
+  }
   return KG_OK;
 }
 int kg_memcpy_h2d(kg_ctx* c, void* d, const void* h, size_t bytes) {

@@ -32,7 +32,9 @@ struct kg_ctx {
   hipEvent_t ev_info = nullptr;          // marks the task-count read-back of msm_sort
   struct Slot { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0; bool busy = false; };
   Slot slots[8];
-  size_t ticket_n[4] = {0, 0, 0, 0};     // lengths of the MSMs begun with kg_msm_begin                         // pinned result slots: MSMs in flight whose host finish is pending
+  size_t ticket_n[4] = {0, 0, 0, 0};
+  struct Registered { const uint64_t* base; size_t n; int curve; uint32_t* packed; };
+  std::vector<Registered> registered;    // bases converted once by kg_bases_register     // lengths of the MSMs begun with kg_msm_begin                         // pinned result slots: MSMs in flight whose host finish is pending
   void* h_pinned = nullptr;              // small pinned staging buffer for results
   size_t h_pinned_bytes = 0;
   std::vector<kg_tw_cache*> tw;          // per-(log_n, inverse) twiddle tables

@@ -25,9 +25,9 @@ using namespace kg;
 
 namespace {
 
-struct G1Cfg { using F = Fq; using SP = FrParams; using HF = HostFq; static constexpr int E64 = 4; };
-struct GkCfg { using F = Fr; using SP = FqParams; using HF = HostFr; static constexpr int E64 = 4; };
-struct G2Cfg { using F = Fq2; using SP = FrParams; using HF = HostFq2; static constexpr int E64 = 8; };
+struct G1Cfg { using F = Fq; using SP = FrParams; using HF = HostFq; static constexpr int E64 = 4; static constexpr int ID = KG_G1; };
+struct GkCfg { using F = Fr; using SP = FqParams; using HF = HostFr; static constexpr int E64 = 4; static constexpr int ID = KG_GRUMPKIN; };
+struct G2Cfg { using F = Fq2; using SP = FrParams; using HF = HostFq2; static constexpr int E64 = 8; static constexpr int ID = KG_G2; };
 
 constexpr uint32_t INF_BIT = 0x80000000u;   // bit 255 of the packed x coordinate marks an identity base
 
@@ -656,7 +656,14 @@ int msm_run_t(kg_ctx* ctx, const MsmSorted& S, const uint64_t* d_bases, const ui
   const int W = S.W, B = S.B, c = S.c;
   const size_t npts = S.npts, part_cap = S.part_cap, nexp = (size_t)W * c;
   Carver cv;
-  const size_t o_pb = cv.take(nbases * PW * 4);
+  // bases inside a registered array are already in packed internal form
+  const uint32_t* reg_pb = nullptr;
+  for (const auto& r : ctx->registered) {
+    if (r.curve != Cfg::ID || d_bases < r.base) continue;
+    const size_t off64 = (size_t)(d_bases - r.base);
+    if (off64 % (size_t)BaseIO<F>::W == 0 && off64 / BaseIO<F>::W + nbases <= r.n) { reg_pb = r.packed + (off64 / BaseIO<F>::W) * PW; break; }
+  }
+  const size_t o_pb = cv.take(reg_pb ? 256 : nbases * PW * 4);
   size_t o_lc[2], o_lr[2], o_lb[2], o_part[2], o_pbuf[2];
   for (int i = 0; i < 2; ++i) {
     o_lc[i] = cv.take(npts * 4); o_lr[i] = cv.take(npts * 4); o_lb[i] = cv.take((size_t)(W + 1) * 4);
@@ -671,7 +678,7 @@ int msm_run_t(kg_ctx* ctx, const MsmSorted& S, const uint64_t* d_bases, const ui
   if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
   if (!ctx->ev_acc[set]) KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_acc[set], hipEventDisableTiming));
   char* ws = (char*)ctx->ws_run[set];
-  uint32_t* pb = (uint32_t*)(ws + o_pb);
+  const uint32_t* pb = reg_pb ? reg_pb : (uint32_t*)(ws + o_pb);
   uint32_t* part[2] = {(uint32_t*)(ws + o_part[0]), (uint32_t*)(ws + o_part[1])};
   uint32_t* pbuf[2] = {(uint32_t*)(ws + o_pbuf[0]), (uint32_t*)(ws + o_pbuf[1])};
   uint32_t* rowtot = (uint32_t*)(ws + o_rowtot);
@@ -681,9 +688,9 @@ int msm_run_t(kg_ctx* ctx, const MsmSorted& S, const uint64_t* d_bases, const ui
   // this buffer set was last used by slot (slot - 2): its side-stream work must be over before we overwrite it
   for (int s2 = 0; s2 < 8; ++s2)
     if ((s2 & 1) == set && ctx->slots[s2].done && ctx->slots[s2].busy) { KG_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[s2].done, 0)); ctx->slots[s2].busy = false; }
-  {
+  if (!reg_pb) {
     PhaseScope ph(ctx, "prep_bases");
-    hipLaunchKernelGGL(k_prep_bases<F>, dim3((unsigned)((nbases + 255) / 256)), dim3(256), 0, st, d_bases, d_inf, nbases, pb);
+    hipLaunchKernelGGL(k_prep_bases<F>, dim3((unsigned)((nbases + 255) / 256)), dim3(256), 0, st, d_bases, d_inf, nbases, (uint32_t*)(ws + o_pb));
     ph.end();
   }
   Level L{S.lcnt, S.lrel, S.lbase};
@@ -830,6 +837,37 @@ int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf
   KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S));
   KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 0));
   return kg::msm_finish(ctx, curve, 0, out_xyz);
+}
+
+int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t n) {
+  if (!ctx || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
+  if (n == 0) return KG_OK;                         // nothing to convert (e.g. an empty CRS vector)
+  if (!d_bases) return KG_ERR_BAD_ARG;
+  KG_HIP(ctx, hipSetDevice(ctx->device));
+  kg_bases_unregister(ctx, d_bases);
+  const size_t pw = curve == KG_G2 ? 32 : 16;
+  uint32_t* packed = nullptr;
+  KG_HIP(ctx, hipMalloc((void**)&packed, n * pw * 4));
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (curve == KG_G1) hipLaunchKernelGGL(k_prep_bases<Fq>, grid, dim3(256), 0, ctx->stream, d_bases, d_inf, n, packed);
+  else if (curve == KG_GRUMPKIN) hipLaunchKernelGGL(k_prep_bases<Fr>, grid, dim3(256), 0, ctx->stream, d_bases, d_inf, n, packed);
+  else hipLaunchKernelGGL(k_prep_bases<Fq2>, grid, dim3(256), 0, ctx->stream, d_bases, d_inf, n, packed);
+  KG_HIP(ctx, hipGetLastError());
+  ctx->registered.push_back({d_bases, n, curve, packed});
+  return KG_OK;
+}
+
+int kg_bases_unregister(kg_ctx* ctx, const uint64_t* d_bases) {
+  if (!ctx) return KG_ERR_BAD_ARG;
+  for (size_t i = 0; i < ctx->registered.size(); ++i) {
+    if (ctx->registered[i].base == d_bases) {
+      kg_ctx_sync(ctx);
+      hipFree(ctx->registered[i].packed);
+      ctx->registered.erase(ctx->registered.begin() + i);
+      return KG_OK;
+    }
+  }
+  return KG_OK;
 }
 
 int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, int ticket) {

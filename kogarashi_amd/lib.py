@@ -21,7 +21,7 @@ EXPORTS = [
     "kg_ctx_sync", "kg_malloc", "kg_free", "kg_memcpy_h2d", "kg_memcpy_d2h", "kg_memcpy_d2d", "kg_field_vec_op",
     "kg_field_vec_scale", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_msm", "kg_msm_host", "kg_commit",
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
-    "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary",
+    "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister",
 ]
 
 
@@ -157,6 +157,12 @@ class Context:
         out = np.zeros(24 if curve == KG_G2 else 12, dtype=np.uint64)
         self._chk(self._lib.kg_msm(self._h, curve, _vp(bases), _vp(inf), _vp(scalars), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)), "kg_msm")
         return out
+
+    def bases_register(self, curve: int, bases: int, inf: int, n: int):
+        self._chk(self._lib.kg_bases_register(self._h, curve, _vp(bases), _vp(inf), C.c_size_t(n)), "kg_bases_register")
+
+    def bases_unregister(self, bases: int):
+        self._chk(self._lib.kg_bases_unregister(self._h, _vp(bases)), "kg_bases_unregister")
 
     def msm_begin(self, curve: int, bases: int, inf: int, scalars: int, n: int, ticket: int):
         self._chk(self._lib.kg_msm_begin(self._h, curve, _vp(bases), _vp(inf), _vp(scalars), C.c_size_t(n), int(ticket)), "kg_msm_begin")

@@ -256,3 +256,38 @@ def test_msm_begin_end_pipeline_matches_blocking_calls(ctx, oracle):
         got[i] = ctx.msm_end(jobs[i][0], i % 4)
     for g, w in zip(got, want):
         assert (g == w).all()
+
+
+@pytest.mark.parametrize("cv,curve,sfd", [("g1", 0, 0), ("gk", 1, 1), ("g2", 2, 0)])
+def test_registered_bases_give_identical_results(ctx, oracle, cv, curve, sfd):
+    """kg_bases_register converts a resident base array once; every MSM over it or over a whole-point offset into it
+    (params.a[cs.l()..] style) must equal the unregistered call and the oracle.  A pointer that does not fall on a
+    point boundary of a registered array, or a range that runs past its end, is not served from it."""
+    O = oracle
+    if curve == 2:                                  # G2 bases: k_i * G2 from the device (checked against the oracle elsewhere)
+        n = 1500
+        dk = ctx.upload(O.gen_scalars(0, SEED + 299, 0, n))
+        dxy, dinf = ctx.empty((n, 16)), ctx.empty((n,), dtype=np.uint8)
+        ctx.fixed_base_mul(2, dk.ptr, n, dxy.ptr, dinf.ptr)
+        b = dxy.numpy()
+    else:
+        n = 6000
+        b = O.gen_bases(curve, SEED + 300, 0, n)
+    inf = np.zeros(n, dtype=np.uint8); inf[[5, 77]] = 1
+    s = O.gen_scalars(sfd, SEED + 301, 0, n)
+    db, di, ds = ctx.upload(b), ctx.upload(inf), ctx.upload(s)
+    stride = b.shape[1] * 8
+    nb = 8 if curve == 2 else 4
+    cases = [(0, n), (1234, n - 1234), (17, 1000), (n - 1, 1)]
+    assert b.shape[1] * 8 == stride and stride == (128 if curve == 2 else 64)
+    plain = [ctx.msm(curve, db.ptr + o * stride, di.ptr + o, ds.ptr, m) for o, m in cases]
+    ctx.bases_register(curve, db.ptr, di.ptr, n)
+    try:
+        for (o, m), want in zip(cases, plain):
+            got = ctx.msm(curve, db.ptr + o * stride, di.ptr + o, ds.ptr, m)
+            assert (got == want).all()
+        o, m = cases[1]
+        assert gpu_aff(plain[1], nb) == aff(O, cv, O.msm(cv, b[o:], s[:m], inf=inf[o:], threads=8))
+    finally:
+        ctx.bases_unregister(db.ptr)
+    assert (ctx.msm(curve, db.ptr, di.ptr, ds.ptr, n) == plain[0]).all()
