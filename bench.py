@@ -33,8 +33,8 @@ def window_adds(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")

@@ -106,7 +106,8 @@ __device__ __forceinline__ uint32_t window_digit(const uint32_t* __restrict__ kt
   const int o = w * c;
   const int j = o >> 5, sh = o & 31;
   uint64_t v = kt[(size_t)j * n + i];
-  if (j + 1 < 8) v |= (uint64_t)kt[(size_t)(j + 1) * n + i] << 32;
+  // second plane only when the digit straddles a word (never for c = 16: half of the loads of the sort)
+  if (j + 1 < 8 && sh + (w == W - 1 ? 17 : c) > 32) v |= (uint64_t)kt[(size_t)(j + 1) * n + i] << 32;
   uint32_t e = (uint32_t)(v >> sh);
   if (w == W - 1) {            // top window: unsigned remainder (no bias term was added for it)
     negative = false;
@@ -121,10 +122,11 @@ __device__ __forceinline__ uint32_t window_digit(const uint32_t* __restrict__ kt
 // ---------------------------------------------------------------------------------------------------
 // counting sort by (window, bucket): histogram of one (chunk, window) in LDS
 // ---------------------------------------------------------------------------------------------------
+//   shift = 0: one bin per bucket (single-pass sort);  shift = FINE_BITS: one bin per group of 2^shift buckets
 __global__ void __launch_bounds__(1024) k_count(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len,
-                                                uint32_t* __restrict__ cnt) {
+                                                int shift, uint32_t* __restrict__ cnt) {
   extern __shared__ uint32_t hist[];
-  const int B = 1 << (c - 1);
+  const int B = (1 << (c - 1)) >> shift;
   // workgroups are dealt round-robin over the 8 XCDs by linear id: with the window in blockIdx.x (W = 16 or 17) all
   // chunks of a window land on the same XCD, so its L2 sees every write to that window's region of the sorted lists
   const int w = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;
@@ -134,7 +136,7 @@ __global__ void __launch_bounds__(1024) k_count(const uint32_t* __restrict__ kt,
   for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     bool neg;
     uint32_t m = window_digit(kt, n, i, w, c, W, neg);
-    if (m) atomicAdd(&hist[m - 1], 1u);
+    if (m) atomicAdd(&hist[(m - 1) >> shift], 1u);
   }
   __syncthreads();
   uint32_t* dst = cnt + ((size_t)w * nch + ch) * B;
@@ -208,11 +210,16 @@ __global__ void __launch_bounds__(1024) k_scan_buckets(const uint32_t* __restric
   scan_row(bsize, B, bstart, nullptr, blockIdx.x);
 }
 
+// shift = 0: final entries (index | sign << 31) in bucket order.  shift = FINE_BITS: first pass of the two-pass sort --
+// entries land in their bucket GROUP and carry the bucket's low bits (index | fine << 24 | sign << 31).  A workgroup then
+// has only B >> shift open output runs, so the L2 sees every line completed before it is evicted (the one-pass
+// scatter pays a read-modify-write per 4-byte store once W * n * 4 B outgrows the L2: tools/ubench/scatter_rate.hip).
 __global__ void __launch_bounds__(1024) k_scatter(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len,
-                                                  const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bstart,
+                                                  int shift, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bstart,
                                                   uint32_t* __restrict__ sorted) {
   extern __shared__ uint32_t off[];
-  const int B = 1 << (c - 1);
+  const int B = (1 << (c - 1)) >> shift;
+  const uint32_t fine_mask = (1u << shift) - 1u;
   const int w = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;
   const uint32_t* src = cnt + ((size_t)w * nch + ch) * B;
   for (int b = threadIdx.x; b < B; b += blockDim.x) off[b] = src[b] + bstart[(size_t)w * B + b];
@@ -223,9 +230,140 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint32_t* __restrict__ k
     bool neg;
     uint32_t m = window_digit(kt, n, i, w, c, W, neg);
     if (m) {
-      uint32_t pos = atomicAdd(&off[m - 1], 1u);
-      dst[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
+      uint32_t pos = atomicAdd(&off[(m - 1) >> shift], 1u);
+      dst[pos] = (uint32_t)i | (((m - 1) & fine_mask) << 24) | (neg ? 0x80000000u : 0u);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// second pass of the two-pass sort.  A bucket group's entries are contiguous after the first pass; they are cut into
+// segments of at most SEG entries, one workgroup per segment (so a 0/1-heavy witness, whose entries pile into one
+// group, still spreads over the chip).  k_fine_count histograms a segment by the bucket's low bits and reserves the
+// segment's place inside each bucket (atomicAdd on the bucket size returns it); k_fine_scatter sorts the segment in
+// LDS and copies it out run by run, so consecutive lanes write consecutive addresses.
+// ---------------------------------------------------------------------------------------------------
+constexpr int FINE_BITS = 7, FINE = 1 << FINE_BITS, SEG = 8192;
+
+// segbase[w][g] = first segment of group g (exclusive prefix of ceil(size / SEG)); segbase[w][G] = segments of window w
+__global__ void __launch_bounds__(1024) k_seg_table(const uint32_t* __restrict__ gsize, int G, uint32_t* __restrict__ segbase) {
+  __shared__ uint32_t sh[40];
+  const int w = blockIdx.x, g = threadIdx.x;
+  const uint32_t ns = g < G ? (gsize[(size_t)w * G + g] + SEG - 1) / SEG : 0;
+  uint32_t total;
+  const uint32_t ex = block_exclusive_scan_1024(ns, sh, total);
+  if (g < G) segbase[(size_t)w * (G + 1) + g] = ex;
+  if (g == 0) segbase[(size_t)w * (G + 1) + G] = total;
+}
+
+// One workgroup per window, one lane per bucket group: exclusive prefix of the group's counters over the chunks (in
+// place), group sizes and starts, the segment table, and the window's bucket sizes zeroed for k_fine_count.
+__global__ void __launch_bounds__(1024) k_group_scan(uint32_t* __restrict__ cnt, int nch, int G, int B, uint32_t* __restrict__ gsize,
+                                                     uint32_t* __restrict__ gstart, uint32_t* __restrict__ segbase, uint32_t* __restrict__ bsize) {
+  __shared__ uint32_t sh[40];
+  const int w = blockIdx.x, g = threadIdx.x;
+  uint32_t run = 0;
+  if (g < G) {
+    for (int ch = 0; ch < nch; ++ch) {
+      uint32_t* p = cnt + ((size_t)w * nch + ch) * G + g;
+      const uint32_t v = *p;
+      *p = run;
+      run += v;
+    }
+    gsize[(size_t)w * G + g] = run;
+  }
+  uint32_t total;
+  const uint32_t st = block_exclusive_scan_1024(run, sh, total);
+  if (g < G) gstart[(size_t)w * G + g] = st;
+  const uint32_t ns = (run + SEG - 1) / SEG;
+  const uint32_t ex = block_exclusive_scan_1024(ns, sh, total);
+  if (g < G) segbase[(size_t)w * (G + 1) + g] = ex;
+  if (g == 0) segbase[(size_t)w * (G + 1) + G] = total;
+  uint4* z = reinterpret_cast<uint4*>(bsize + (size_t)w * B);            // B is a multiple of 4 here (c >= 12)
+  for (int b = threadIdx.x; b < B / 4; b += blockDim.x) z[b] = make_uint4(0, 0, 0, 0);
+}
+
+struct SegRange { int g; uint32_t lo, hi; };
+// which group / entry range does segment s of window w cover?  (sb: the window's segbase row in LDS)
+__device__ __forceinline__ bool seg_locate(const uint32_t* sb, int G, uint32_t s, const uint32_t* __restrict__ gstart,
+                                           const uint32_t* __restrict__ gsize, int w, SegRange& r) {
+  if (s >= sb[G]) return false;
+  int lo = 0, hi = G;                                // largest g with sb[g] <= s (empty groups repeat the value: take the last)
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sb[mid] <= s) lo = mid; else hi = mid; }
+  r.g = lo;
+  const uint32_t st = gstart[(size_t)w * G + lo], sz = gsize[(size_t)w * G + lo];
+  r.lo = st + (s - sb[lo]) * SEG;
+  r.hi = r.lo + SEG < st + sz ? r.lo + SEG : st + sz;
+  return true;
+}
+
+__global__ void __launch_bounds__(512) k_fine_count(const uint32_t* __restrict__ tmp, size_t n, int G, int B, int maxseg,
+                                                    const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gsize,
+                                                    const uint32_t* __restrict__ segbase, uint32_t* __restrict__ bsize,
+                                                    uint32_t* __restrict__ segcnt, uint32_t* __restrict__ segoff) {
+  __shared__ uint32_t sb[1025];
+  __shared__ uint32_t hist[FINE];
+  const int w = blockIdx.x;
+  const uint32_t s = blockIdx.y;
+  for (int g = threadIdx.x; g <= G; g += blockDim.x) sb[g] = segbase[(size_t)w * (G + 1) + g];
+  if (threadIdx.x < FINE) hist[threadIdx.x] = 0;
+  __syncthreads();
+  SegRange r;
+  if (!seg_locate(sb, G, s, gstart, gsize, w, r)) return;
+  const uint32_t* src = tmp + (size_t)w * n;
+  for (uint32_t i = r.lo + threadIdx.x; i < r.hi; i += blockDim.x) atomicAdd(&hist[(src[i] >> 24) & (FINE - 1)], 1u);
+  __syncthreads();
+  if (threadIdx.x < FINE) {
+    const uint32_t cnt = hist[threadIdx.x];
+    const size_t o = ((size_t)w * maxseg + s) * FINE + threadIdx.x;
+    segcnt[o] = cnt;
+    segoff[o] = cnt ? atomicAdd(&bsize[(size_t)w * B + (size_t)r.g * FINE + threadIdx.x], cnt) : 0u;
+  }
+}
+
+__global__ void __launch_bounds__(512) k_fine_scatter(const uint32_t* __restrict__ tmp, size_t n, int G, int B, int maxseg,
+                                                      const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gsize,
+                                                      const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ bstart,
+                                                      const uint32_t* __restrict__ segcnt, const uint32_t* __restrict__ segoff,
+                                                      uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t sb[1025];
+  __shared__ uint32_t lstart[FINE], cursor[FINE], gbase[FINE], wsum;
+  __shared__ uint32_t stage[SEG];
+  const int w = blockIdx.x;
+  const uint32_t s = blockIdx.y;
+  for (int g = threadIdx.x; g <= G; g += blockDim.x) sb[g] = segbase[(size_t)w * (G + 1) + g];
+  __syncthreads();
+  SegRange r;
+  if (!seg_locate(sb, G, s, gstart, gsize, w, r)) return;
+  uint32_t cnt = 0, inc = 0;
+  if (threadIdx.x < FINE) {                          // exclusive prefix of the segment's FINE counters (two waves)
+    const size_t o = ((size_t)w * maxseg + s) * FINE + threadIdx.x;
+    cnt = segcnt[o];
+    gbase[threadIdx.x] = bstart[(size_t)w * B + (size_t)r.g * FINE + threadIdx.x] + segoff[o];
+    inc = cnt;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o2 = __shfl_up(inc, d); if (lane >= d) inc += o2; }
+    if (threadIdx.x == 63) wsum = inc;
+  }
+  __syncthreads();
+  if (threadIdx.x < FINE) {
+    const uint32_t ex = inc - cnt + (threadIdx.x >= 64 ? wsum : 0u);
+    lstart[threadIdx.x] = ex;
+    cursor[threadIdx.x] = ex;
+  }
+  __syncthreads();
+  const uint32_t* src = tmp + (size_t)w * n;
+  for (uint32_t i = r.lo + threadIdx.x; i < r.hi; i += blockDim.x) {
+    const uint32_t rec = src[i];
+    stage[atomicAdd(&cursor[(rec >> 24) & (FINE - 1)], 1u)] = rec;
+  }
+  __syncthreads();
+  uint32_t* dst = sorted + (size_t)w * n;
+  const uint32_t len = r.hi - r.lo;
+  for (uint32_t p = threadIdx.x; p < len; p += blockDim.x) {
+    const uint32_t rec = stage[p], f = (rec >> 24) & (FINE - 1);
+    dst[gbase[f] + (p - lstart[f])] = rec & 0x80ffffffu;
   }
 }
 
@@ -382,6 +520,94 @@ __global__ void __launch_bounds__(1024) k_len_scatter(const uint32_t* __restrict
     task_bkt[pos] = (uint32_t)t;
     task_id[pos] = first + nt - 1;
   }
+}
+
+// One workgroup per window over the bucket sizes: bucket starts (exclusive prefix), tasks per bucket and their prefix,
+// the window's task total, the largest bucket, and the histogram of task lengths -- everything the task decomposition
+// needs from one read of the sizes (k_task_count + k_scan_rows + k_scan_buckets + k_len_hist of the multi-round path).
+__global__ void __launch_bounds__(1024) k_bucket_rows(const uint32_t* __restrict__ bsize, int B, uint32_t T, uint32_t* __restrict__ bstart,
+                                                      uint32_t* __restrict__ ntask, uint32_t* __restrict__ rel, uint32_t* __restrict__ row_total,
+                                                      uint32_t* __restrict__ maxv, uint32_t* __restrict__ ghist) {
+  __shared__ uint32_t sh[40], h[LEN_BINS], red[16];
+  const int w = blockIdx.x;
+  if (threadIdx.x < LEN_BINS) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int per = (B + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = lo + per < B ? lo + per : B;
+  const uint32_t* src = bsize + (size_t)w * B;
+  const bool vec = (per & 3) == 0 && hi - lo == per;       // every lane owns whole 16-byte groups
+  uint32_t ssum = 0, tsum = 0, mx = 0;
+  auto tally = [&](uint32_t v) {
+    if (v) {
+      const uint32_t nt = (v + T - 1) / T;
+      ssum += v; tsum += nt; mx = v > mx ? v : mx;
+      atomicAdd(&h[len_key(v - (nt - 1) * T)], 1u);
+      if (nt > 1) atomicAdd(&h[len_key(T)], nt - 1);
+    }
+  };
+  if (vec) {
+    for (int b = lo; b < hi; b += 4) { const uint4 q = *reinterpret_cast<const uint4*>(src + b); tally(q.x); tally(q.y); tally(q.z); tally(q.w); }
+  } else {
+    for (int b = lo; b < hi; ++b) tally(src[b]);
+  }
+  uint32_t total_s, total_t;
+  uint32_t run_s = block_exclusive_scan_1024(ssum, sh, total_s);
+  uint32_t run_t = block_exclusive_scan_1024(tsum, sh, total_t);
+  uint32_t* o_start = bstart + (size_t)w * B;
+  uint32_t* o_nt = ntask + (size_t)w * B;
+  uint32_t* o_rel = rel + (size_t)w * B;
+  if (vec) {
+    for (int b = lo; b < hi; b += 4) {
+      const uint4 q = *reinterpret_cast<const uint4*>(src + b);
+      uint4 st, nt, rl;
+      nt.x = (q.x + T - 1) / T; nt.y = (q.y + T - 1) / T; nt.z = (q.z + T - 1) / T; nt.w = (q.w + T - 1) / T;
+      st.x = run_s; st.y = st.x + q.x; st.z = st.y + q.y; st.w = st.z + q.z; run_s = st.w + q.w;
+      rl.x = run_t; rl.y = rl.x + nt.x; rl.z = rl.y + nt.y; rl.w = rl.z + nt.z; run_t = rl.w + nt.w;
+      *reinterpret_cast<uint4*>(o_start + b) = st;
+      *reinterpret_cast<uint4*>(o_nt + b) = nt;
+      *reinterpret_cast<uint4*>(o_rel + b) = rl;
+    }
+  } else {
+    for (int b = lo; b < hi; ++b) {
+      const uint32_t v = src[b], nt = (v + T - 1) / T;
+      o_start[b] = run_s; o_nt[b] = nt; o_rel[b] = run_t;
+      run_s += v; run_t += nt;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t m = 0;
+    for (int i = 0; i < 16; ++i) m = red[i] > m ? red[i] : m;
+    if (m) atomicMax(maxv, m);
+    row_total[w] = total_t;
+  }
+  if (threadIdx.x < LEN_BINS && h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
+}
+// k_row_bases + k_len_scan in one launch (one wave): window task bases and the descending-length cursors
+__global__ void __launch_bounds__(64) k_task_bases(const uint32_t* __restrict__ row_total, int W, uint32_t* __restrict__ base,
+                                                   const uint32_t* __restrict__ maxv, uint32_t* __restrict__ info,
+                                                   const uint32_t* __restrict__ ghist, uint32_t* __restrict__ cursor) {
+  const int lane = threadIdx.x;
+  if (lane == 0) {
+    uint32_t run = 0;
+    for (int w = 0; w < W; ++w) { base[w] = run; run += row_total[w]; }
+    base[W] = run;
+    info[0] = run;
+    info[1] = *maxv;
+  }
+  static_assert(LEN_BINS == 256, "four bins per lane");
+  const uint32_t h0 = ghist[4 * lane], h1 = ghist[4 * lane + 1], h2 = ghist[4 * lane + 2], h3 = ghist[4 * lane + 3];
+  uint32_t inc = h0 + h1 + h2 + h3;                 // inclusive suffix sum over lanes
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_down(inc, d); if (lane + d < 64) inc += o; }
+  const uint32_t above = inc - (h0 + h1 + h2 + h3); // tasks with a key in a higher lane's bins
+  cursor[4 * lane + 3] = above;
+  cursor[4 * lane + 2] = above + h3;
+  cursor[4 * lane + 1] = above + h3 + h2;
+  cursor[4 * lane] = above + h3 + h2 + h1;
 }
 
 // task id -> (window, bucket, segment index)
@@ -566,7 +792,8 @@ namespace kg {
 int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S) {
   if (n == 0 || n >= ((size_t)1 << 31)) return set_err(ctx, KG_ERR_BAD_ARG, "msm length must be in [1, 2^31)");
   KG_HIP(ctx, hipSetDevice(ctx->device));
-  const int c = pick_window(n, ctx->msm_window);
+  int c = pick_window(n, ctx->msm_window);
+  if (c > 16 && !(n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24))) c = 16;   // one-pass histogram: 2^(c-1) LDS counters
   const int W = (255 + c - 1) / c;
   const int B = 1 << (c - 1);
   int nch = (int)((n + 16383) / 16384);
@@ -580,8 +807,15 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   if (T > 4096) T = 4096;
   const size_t part_cap = (size_t)W * ((n + T - 1) / T) + npts;     // upper bound on round-1 tasks
 
+  // two passes (bucket group, then bucket inside the group) once the sorted lists outgrow the L2; entries carry the
+  // bucket's low FINE_BITS between the passes, which leaves 24 bits for the index
+  const bool two_pass = c - 1 >= FINE_BITS + 4 && n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24);
+  const int G = two_pass ? B >> FINE_BITS : 0;      // bucket groups per window (<= 1024)
+  const int maxseg = two_pass ? G + (int)((n + SEG - 1) / SEG) : 0;
   Carver cv;
-  const size_t o_kt = cv.take(n * 32), o_cnt = cv.take((size_t)W * nch * B * 4), o_bsize = cv.take(npts * 4), o_bstart = cv.take(npts * 4);
+  const size_t o_kt = cv.take(n * 32), o_cnt = cv.take((size_t)W * nch * (two_pass ? G : B) * 4), o_bsize = cv.take(npts * 4), o_bstart = cv.take(npts * 4);
+  const size_t o_tmp = cv.take(two_pass ? (size_t)W * n * 4 : 0), o_gsize = cv.take((size_t)W * G * 4), o_gstart = cv.take((size_t)W * G * 4);
+  const size_t o_segbase = cv.take((size_t)W * (G + 1) * 4), o_segcnt = cv.take((size_t)W * maxseg * FINE * 4), o_segoff = cv.take((size_t)W * maxseg * FINE * 4);
   const size_t o_sorted = cv.take((size_t)W * n * 4), o_lcnt = cv.take(npts * 4), o_lrel = cv.take(npts * 4), o_lbase = cv.take((size_t)(W + 1) * 4);
   const size_t o_rowtot = cv.take((size_t)W * 4), o_misc = cv.take(64), o_lenh = cv.take(2 * LEN_BINS * 4);
   const size_t o_tbkt = cv.take(part_cap * 4), o_tid = cv.take(part_cap * 4);
@@ -613,30 +847,41 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   }
   {
     PhaseScope ph(ctx, "sort");
-    const size_t lds = (size_t)B * 4;
+    const size_t lds = (size_t)(two_pass ? G : B) * 4;
     if (lds > 48 * 1024) {      // the whole-window histogram needs more than the default dynamic LDS limit
       KG_HIP(ctx, hipFuncSetAttribute((const void*)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       KG_HIP(ctx, hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(k_count, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, cnt);
-    hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, cnt, W, nch, B, S->bsize);
+    uint32_t* tmp = (uint32_t*)(ws + o_tmp);
+    uint32_t* gsize = (uint32_t*)(ws + o_gsize);
+    uint32_t* gstart = (uint32_t*)(ws + o_gstart);
+    uint32_t* segbase = (uint32_t*)(ws + o_segbase);
+    uint32_t* segcnt = (uint32_t*)(ws + o_segcnt);
+    uint32_t* segoff = (uint32_t*)(ws + o_segoff);
+    KG_HIP(ctx, hipMemsetAsync(misc, 0, (o_lenh - o_misc) + 2 * LEN_BINS * 4, st));      // misc and the length histogram
+    if (two_pass) {
+      hipLaunchKernelGGL(k_count, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, FINE_BITS, cnt);
+      hipLaunchKernelGGL(k_group_scan, dim3(W), dim3(1024), 0, st, cnt, nch, G, B, gsize, gstart, segbase, S->bsize);
+      hipLaunchKernelGGL(k_scatter, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, FINE_BITS, cnt, gstart, tmp);
+      hipLaunchKernelGGL(k_fine_count, dim3(W, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, gstart, gsize, segbase, S->bsize, segcnt, segoff);
+    } else {
+      hipLaunchKernelGGL(k_count, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, 0, cnt);
+      hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, cnt, W, nch, B, S->bsize);
+    }
     // task decomposition (needs only the bucket sizes); its two result words travel to the host while the
     // scatter below still runs, so the read-back does not stall the queue
-    KG_HIP(ctx, hipMemsetAsync(misc, 0, 64, st));
-    KG_HIP(ctx, hipMemsetAsync(lenh, 0, 2 * LEN_BINS * 4, st));
     const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
-    hipLaunchKernelGGL(k_task_count, dim3(g1024), dim3(1024), 0, st, S->bsize, npts, T, S->lcnt, misc);
-    hipLaunchKernelGGL(k_scan_rows, dim3(W), dim3(1024), 0, st, S->lcnt, B, S->lrel, rowtot);
-    hipLaunchKernelGGL(k_row_bases, dim3(1), dim3(64), 0, st, rowtot, W, S->lbase, misc, misc + 4);
+    hipLaunchKernelGGL(k_bucket_rows, dim3(W), dim3(1024), 0, st, S->bsize, B, T, S->bstart, S->lcnt, S->lrel, rowtot, misc, lenh);
+    hipLaunchKernelGGL(k_task_bases, dim3(1), dim3(64), 0, st, rowtot, W, S->lbase, misc, misc + 4, lenh, lenh + LEN_BINS);
     uint32_t* h_info = (uint32_t*)ctx->h_pinned;
     KG_HIP(ctx, hipMemcpyAsync(h_info, misc + 4, 8, hipMemcpyDeviceToHost, st));
     if (!ctx->ev_info) KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_info, hipEventDisableTiming));
     KG_HIP(ctx, hipEventRecord(ctx->ev_info, st));
-    hipLaunchKernelGGL(k_len_hist, dim3(g1024), dim3(1024), 0, st, S->bsize, S->lcnt, npts, T, lenh);
-    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(64), 0, st, lenh, lenh + LEN_BINS);
     hipLaunchKernelGGL(k_len_scatter, dim3(g1024), dim3(1024), 0, st, S->bsize, S->lcnt, S->lrel, S->lbase, npts, B, T, lenh + LEN_BINS, S->task_bkt, S->task_id);
-    hipLaunchKernelGGL(k_scan_buckets, dim3(W), dim3(1024), 0, st, S->bsize, B, S->bstart);
-    hipLaunchKernelGGL(k_scatter, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, cnt, S->bstart, S->sorted);
+    if (two_pass)
+      hipLaunchKernelGGL(k_fine_scatter, dim3(W, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, gstart, gsize, segbase, S->bstart, segcnt, segoff, S->sorted);
+    else
+      hipLaunchKernelGGL(k_scatter, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, 0, cnt, S->bstart, S->sorted);
     ph.end();
     KG_HIP(ctx, hipGetLastError());
     KG_HIP(ctx, hipEventSynchronize(ctx->ev_info));

@@ -291,3 +291,33 @@ def test_registered_bases_give_identical_results(ctx, oracle, cv, curve, sfd):
     finally:
         ctx.bases_unregister(db.ptr)
     assert (ctx.msm(curve, db.ptr, di.ptr, ds.ptr, n) == plain[0]).all()
+
+
+@pytest.mark.parametrize("cv,curve,sfd,n,c,skew", [
+    ("g1", 0, 0, 1 << 16, 0, False), ("g1", 0, 0, 70001, 12, False), ("gk", 1, 1, 100000, 16, False),
+    ("g1", 0, 0, 1 << 17, 0, True), ("g1", 0, 0, 150000, 13, True), ("gk", 1, 1, 90000, 16, True),
+])
+def test_msm_two_pass_sort_sizes(ctx, oracle, cv, curve, sfd, n, c, skew):
+    """n >= 2^16 with c >= 12 takes the two-pass bucket sort (bucket group, then bucket inside the group; groups cut
+    into 8192-entry segments).  Uniform scalars fill every group evenly; the witness-like mix piles half of the entries
+    into one group of window 0 (many segments of one group) and leaves most other groups empty."""
+    O = oracle
+    bases = O.gen_bases(curve, SEED + 500 + n, 0, n)
+    scal = O.gen_scalars(sfd, SEED + 501 + n, 0, n)
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[[3, n - 1]] = 1
+    if skew:
+        rng = np.random.default_rng(n)
+        kind = rng.integers(0, 10, n)
+        one = O.f_consts(sfd)["r"]
+        scal[kind < 5] = one
+        scal[(kind >= 5) & (kind < 7)] = 0
+        scal[kind == 7] = O.f_neg(sfd, one)
+        scal[kind == 8] = O.f_to_mont(sfd, np.array([5, 0, 0, 0], dtype=np.uint64))
+        bases[1000:1500] = bases[1000]
+    want = aff(O, cv, O.msm(cv, bases, scal, inf, threads=8))
+    ctx.set_msm_window(c)
+    try:
+        assert gpu_aff(ctx.msm_host(curve, bases, inf, scal, n), 4) == want
+    finally:
+        ctx.set_msm_window(0)
