@@ -739,6 +739,9 @@ int pick_window(size_t n, int forced) {
   while (((size_t)1 << (lg + 1)) <= n) ++lg;      // floor(log2 n)
   // The top window holds the 254 - (W-1)c leftover bits; c = 15 / 16 leave it 14 bits (as many buckets as the
   // signed windows use), while c = 12..14 would leave 2..7 bits, i.e. a handful of buckets holding ~n points each.
+  // c = 17 (W = 15, a 16-bit top window) needs the two-pass sort, i.e. n <= 2^24; measured faster from 2^21 up
+  // (2^22: 6.6 vs 7.0 ms, 2^24: 25.8 vs 35.2 ms), slower at 2^20 where its bucket reduction doubles
+  if (lg >= 21 && n <= ((size_t)1 << 24)) return 17;
   if (lg >= 19) return 16;
   if (lg >= 14) return 15;
   int c = lg - 3;

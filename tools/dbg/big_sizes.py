@@ -9,7 +9,7 @@ SEED = 0x4B6F676172617368
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 ctx = K.Context(0)
 for curve, fld, name in ((K.KG_G1, K.KG_FR, "g1"), (K.KG_GRUMPKIN, K.KG_FQ, "grumpkin")):
-    for lg in (22, 24) if curve == K.KG_G1 else (22,):
+    for lg in (22, 24, 25) if curve == K.KG_G1 else (22,):
         n = 1 << lg
         bases = torch.empty(n * 8, dtype=torch.int64, device=dev)
         scal = torch.empty(n * 4, dtype=torch.int64, device=dev)
