@@ -52,6 +52,54 @@ __global__ void __launch_bounds__(256) k_prep_scalars(const uint64_t* __restrict
   }
 }
 
+// The same conversion for the two-pass sort, which also wants the first pass's histogram: a workgroup converts PREP_CH
+// consecutive scalars, peels all W digits off each k + H while the words are still in registers (a 256-bit funnel
+// shift by c per window), counts bucket groups in LDS ([W][G] counters) and adds its counters to the (window, chunk,
+// group) table that k_group_scan turns into offsets -- no second read of kt for counting.
+constexpr int PREP_CH = 4096;
+template <class SP>
+__global__ void __launch_bounds__(1024) k_prep_scalars_count(const uint64_t* __restrict__ scalars, size_t n, Words8 H, uint32_t* __restrict__ kt,
+                                                             int c, int W, int shift, int G, int nch, size_t chunk_len, uint32_t* __restrict__ cnt) {
+  extern __shared__ uint32_t hist[];                 // [W][G]
+  for (int t = threadIdx.x; t < W * G; t += blockDim.x) hist[t] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * PREP_CH;
+  const uint32_t cmask = (1u << c) - 1u, half = 1u << (c - 1);
+  for (int r = 0; r < PREP_CH / 1024; ++r) {
+    const size_t i = lo + (size_t)r * 1024 + threadIdx.x;
+    if (i >= n) break;
+    uint32_t w[8], k[8];
+    load_words(scalars, i, w);
+    ref_to_int<SP>(w, k);
+    uint64_t cy = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint64_t s = (uint64_t)k[j] + H.w[j] + cy;
+      k[j] = (uint32_t)s;
+      kt[(size_t)j * n + i] = k[j];
+      cy = s >> 32;
+    }
+    for (int wd = 0; wd < W; ++wd) {
+      uint32_t m;
+      if (wd == W - 1) m = k[0] & 0x1ffffu;           // unsigned top window (window_digit)
+      else {
+        const int32_t d = (int32_t)(k[0] & cmask) - (int32_t)half;
+        m = (uint32_t)(d < 0 ? -d : d);
+      }
+      if (m) atomicAdd(&hist[wd * G + ((m - 1) >> shift)], 1u);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) k[j] = (k[j] >> c) | (k[j + 1] << (32 - c));
+      k[7] >>= c;
+    }
+  }
+  __syncthreads();
+  const int ch = (int)(lo / chunk_len);               // chunk_len is a multiple of PREP_CH: one chunk per workgroup
+  for (int t = threadIdx.x; t < W * G; t += blockDim.x) {
+    const uint32_t v = hist[t];
+    if (v) atomicAdd(&cnt[((size_t)(t / G) * nch + ch) * G + (t % G)], v);
+  }
+}
+
 template <class P>
 __device__ __forceinline__ void pack_internal(const Fp<P>& a, uint32_t w[8]) { words_from_limbs(reduce_2p(a), w); }
 template <class P>
@@ -802,7 +850,7 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   int nch = (int)((n + 16383) / 16384);
   if (nch > 16) nch = 16;
   if (nch < 1) nch = 1;
-  const size_t chunk_len = (n + nch - 1) / nch;
+  size_t chunk_len = (n + nch - 1) / nch;
   const size_t npts = (size_t)W * B;
   // one task per bucket for uniform scalars: the unsigned top window of c = 15/16 holds twice the average load
   uint32_t T = (uint32_t)(4 * (n / B) + 32);
@@ -815,6 +863,7 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   const bool two_pass = c - 1 >= FINE_BITS + 4 && n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24);
   const int G = two_pass ? B >> FINE_BITS : 0;      // bucket groups per window (<= 1024)
   const int maxseg = two_pass ? G + (int)((n + SEG - 1) / SEG) : 0;
+  if (two_pass) chunk_len = (chunk_len + PREP_CH - 1) / PREP_CH * PREP_CH;   // k_prep_scalars_count: one chunk per workgroup
   Carver cv;
   const size_t o_kt = cv.take(n * 32), o_cnt = cv.take((size_t)W * nch * (two_pass ? G : B) * 4), o_bsize = cv.take(npts * 4), o_bstart = cv.take(npts * 4);
   const size_t o_tmp = cv.take(two_pass ? (size_t)W * n * 4 : 0), o_gsize = cv.take((size_t)W * G * 4), o_gstart = cv.take((size_t)W * G * 4);
@@ -844,7 +893,18 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   }
   {
     PhaseScope ph(ctx, "prep_scalars");
-    if (scalar_field == KG_FR) hipLaunchKernelGGL(k_prep_scalars<FrParams>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
+    if (two_pass) {
+      const size_t hl = (size_t)W * G * 4;
+      KG_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)W * nch * G * 4, st));
+      const dim3 grid((unsigned)((n + PREP_CH - 1) / PREP_CH));
+      if (scalar_field == KG_FR) {
+        if (hl > 48 * 1024) KG_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_scalars_count<FrParams>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
+        hipLaunchKernelGGL(k_prep_scalars_count<FrParams>, grid, dim3(1024), hl, st, d_scalars, n, H, kt, c, W, FINE_BITS, G, nch, chunk_len, cnt);
+      } else {
+        if (hl > 48 * 1024) KG_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_scalars_count<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
+        hipLaunchKernelGGL(k_prep_scalars_count<FqParams>, grid, dim3(1024), hl, st, d_scalars, n, H, kt, c, W, FINE_BITS, G, nch, chunk_len, cnt);
+      }
+    } else if (scalar_field == KG_FR) hipLaunchKernelGGL(k_prep_scalars<FrParams>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
     else hipLaunchKernelGGL(k_prep_scalars<FqParams>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
     ph.end();
   }
@@ -863,7 +923,6 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
     uint32_t* segoff = (uint32_t*)(ws + o_segoff);
     KG_HIP(ctx, hipMemsetAsync(misc, 0, (o_lenh - o_misc) + 2 * LEN_BINS * 4, st));      // misc and the length histogram
     if (two_pass) {
-      hipLaunchKernelGGL(k_count, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, FINE_BITS, cnt);
       hipLaunchKernelGGL(k_group_scan, dim3(W), dim3(1024), 0, st, cnt, nch, G, B, gsize, gstart, segbase, S->bsize);
       hipLaunchKernelGGL(k_scatter, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, FINE_BITS, cnt, gstart, tmp);
       hipLaunchKernelGGL(k_fine_count, dim3(W, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, gstart, gsize, segbase, S->bsize, segcnt, segoff);
