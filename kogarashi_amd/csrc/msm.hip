@@ -304,6 +304,63 @@ __global__ void __launch_bounds__(1024) k_seg_table(const uint32_t* __restrict__
   if (g == 0) segbase[(size_t)w * (G + 1) + G] = total;
 }
 
+// First pass of the two-pass sort, staged through LDS: a workgroup walks its (scalar chunk, window) pair in tiles of
+// GS_TILE entries, ranks a tile's entries inside their bucket group with LDS atomics, lays the tile out group by group
+// in LDS and copies it out, so that consecutive lanes write consecutive addresses of a group's run (a 4-byte store per
+// lane to a random line is what bounds the unstaged k_scatter: tools/ubench/scatter_rate.hip).
+constexpr int GS_TILE = 8192;
+__global__ void __launch_bounds__(1024) k_group_scatter(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len, int G,
+                                                        const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ gstart,
+                                                        uint32_t* __restrict__ tmp) {
+  __shared__ uint32_t cursor[1024], hist[1024], lstart[1024], sh[40];    // G <= 1024; hist doubles as the tile's address delta
+  __shared__ uint32_t stage[GS_TILE];
+  __shared__ uint16_t sg[GS_TILE];
+  const int w = blockIdx.x, ch = blockIdx.y, nch = gridDim.y, tid = threadIdx.x;
+  if (tid < G) cursor[tid] = cnt[((size_t)w * nch + ch) * G + tid] + gstart[(size_t)w * G + tid];
+  const size_t lo = (size_t)ch * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
+  uint32_t* dst = tmp + (size_t)w * n;
+  for (size_t tile = lo; tile < hi; tile += GS_TILE) {
+    if (tid < G) hist[tid] = 0;
+    __syncthreads();
+    uint32_t rec[GS_TILE / 1024], rk[GS_TILE / 1024], gg[GS_TILE / 1024];
+#pragma unroll
+    for (int r = 0; r < GS_TILE / 1024; ++r) {
+      const size_t i = tile + (size_t)r * 1024 + tid;
+      gg[r] = 0xffffffffu;
+      if (i < hi) {
+        bool neg;
+        const uint32_t m = window_digit(kt, n, i, w, c, W, neg);
+        if (m) {
+          gg[r] = (m - 1) >> FINE_BITS;
+          rec[r] = (uint32_t)i | (((m - 1) & (FINE - 1)) << 24) | (neg ? 0x80000000u : 0u);
+          rk[r] = atomicAdd(&hist[gg[r]], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t v = tid < G ? hist[tid] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan_1024(v, sh, total);
+    if (tid < G) {
+      lstart[tid] = ex;
+      hist[tid] = cursor[tid] - ex;                   // destination = position in the tile + this
+      cursor[tid] += v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < GS_TILE / 1024; ++r) {
+      if (gg[r] != 0xffffffffu) {
+        const uint32_t p = lstart[gg[r]] + rk[r];
+        stage[p] = rec[r];
+        sg[p] = (uint16_t)gg[r];
+      }
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < total; p += 1024) dst[p + hist[sg[p]]] = stage[p];
+    __syncthreads();
+  }
+}
+
 // One workgroup per window, one lane per bucket group: exclusive prefix of the group's counters over the chunks (in
 // place), group sizes and starts, the segment table, and the window's bucket sizes zeroed for k_fine_count.
 __global__ void __launch_bounds__(1024) k_group_scan(uint32_t* __restrict__ cnt, int nch, int G, int B, uint32_t* __restrict__ gsize,
@@ -924,7 +981,7 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
     KG_HIP(ctx, hipMemsetAsync(misc, 0, (o_lenh - o_misc) + 2 * LEN_BINS * 4, st));      // misc and the length histogram
     if (two_pass) {
       hipLaunchKernelGGL(k_group_scan, dim3(W), dim3(1024), 0, st, cnt, nch, G, B, gsize, gstart, segbase, S->bsize);
-      hipLaunchKernelGGL(k_scatter, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, FINE_BITS, cnt, gstart, tmp);
+      hipLaunchKernelGGL(k_group_scatter, dim3(W, nch), dim3(1024), 0, st, kt, n, c, W, chunk_len, G, cnt, gstart, tmp);
       hipLaunchKernelGGL(k_fine_count, dim3(W, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, gstart, gsize, segbase, S->bsize, segcnt, segoff);
     } else {
       hipLaunchKernelGGL(k_count, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, 0, cnt);
