@@ -1,0 +1,25 @@
+"""Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, as MI355X_MICROARCH.md prescribes) into one
+JSON: per kernel the mean KB per dispatch, plus VGPR / LDS use.  python tools/dbg/pmc_summary.py gpurun_out/pmc_ out.json"""
+import csv, glob, json, re, sys, collections
+out = {}
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"{sys.argv[1]}{counter}/*/*counter_collection.csv")[0]
+    acc = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+        name = re.sub(r"^void ", "", name)
+        m = re.match(r"([A-Za-z_0-9]+)(<[^(]*>)?\(", name)
+        key = m.group(1) + (m.group(2) if m and m.group(2) and ("Fp2" in m.group(2)) else "") if m else name[:40]
+        if m and m.group(2) and "Fp2" in m.group(2):
+            key = m.group(1) + "<Fq2>"
+        a = acc.setdefault(key, {"dispatches": 0, "sum": 0.0, "vgpr": int(r["VGPR_Count"]), "lds": int(r["LDS_Block_Size"]), "wg": int(r["Workgroup_Size"])})
+        a["dispatches"] += 1
+        a["sum"] += float(r["Counter_Value"])
+    out[counter] = {k: {"dispatches": v["dispatches"], "mean_KB": round(v["sum"] / v["dispatches"], 1), "vgpr": v["vgpr"], "lds_bytes": v["lds"], "workgroup": v["wg"]} for k, v in acc.items()}
+out["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ntt --no-groth16`; "
+               "values are KB per dispatch as reported; gfx950 correction: FETCH_SIZE x2 for wide coalesced reads (MI355X_MICROARCH.md, HBM section)")
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+for k in out["FETCH_SIZE"]:
+    print(f"{k:32s} fetch {out['FETCH_SIZE'][k]['mean_KB']/1024:9.2f} MB  write {out['WRITE_SIZE'].get(k, {}).get('mean_KB', 0)/1024:9.2f} MB  vgpr {out['FETCH_SIZE'][k]['vgpr']} lds {out['FETCH_SIZE'][k]['lds_bytes']}")
