@@ -321,3 +321,16 @@ def test_msm_two_pass_sort_sizes(ctx, oracle, cv, curve, sfd, n, c, skew):
         assert gpu_aff(ctx.msm_host(curve, bases, inf, scal, n), 4) == want
     finally:
         ctx.set_msm_window(0)
+
+
+def test_msm_two_pass_sort_degenerate_scalars(ctx, oracle):
+    """All-zero scalars leave every bucket group empty (no segments, no tasks): the identity.  One scalar value
+    everywhere piles each window's entries into a single bucket (one group, many segments, multi-round partial sums)."""
+    O, n = oracle, (1 << 16) + 5
+    bases = O.gen_bases(0, SEED + 600, 0, n)
+    zeros = np.zeros((n, 4), dtype=np.uint64)
+    assert gpu_aff(ctx.msm_host(0, bases, None, zeros, n), 4) is None
+    k = O.gen_scalars(0, SEED + 601, 0, 1)[0]
+    scal = np.tile(k, (n, 1))
+    want = aff(O, "g1", O.msm("g1", bases, scal, None, threads=8))
+    assert gpu_aff(ctx.msm_host(0, bases, None, scal, n), 4) == want
