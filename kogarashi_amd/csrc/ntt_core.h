@@ -11,8 +11,7 @@
 namespace kg {
 
 // x[k], k in [0, 2^G): element whose G "middle" index bits equal k.  Stage t (1..G) pairs k0 / k0 + 2^(t-1).
-// tw(t, k0) returns the twiddle of that butterfly; trivial_first: stage 1 has w = 1 (global stage 1), and then its
-// operands may be raw loads (value < 2^256), hence the wider fat constant.
+// tw(t, k0) returns the twiddle of that butterfly; trivial_first: this pass runs global stages 1..G.
 // (compile-time recursion instead of loops: every x[] index is a constant expression, so the array stays in registers)
 template <int G, int T, int PI, class F, class TwFn>
 KG_HD void dit_step(F (&x)[1 << G], bool trivial_first, const TwFn& tw) {
@@ -20,10 +19,19 @@ KG_HD void dit_step(F (&x)[1 << G], bool trivial_first, const TwFn& tw) {
     constexpr int half = 1 << (T - 1);
     constexpr int k0 = ((PI >> (T - 1)) << T) | (PI & (half - 1));
     constexpr int k1 = k0 + half;
-    if (T == 1 && trivial_first) {
-      F a = x[k0], b = norm(x[k1]);
-      x[k0] = add(a, b);
-      x[k1] = sub<8, 1>(a, b);
+    // first pass of a tile (global stages 1..G): the twiddle of stage T is w^(k0 mod 2^(T-1)), i.e. 1 for 1, 2, 4 of the
+    // butterflies of stages 1, 2, 3 -- 7 of the 12 products of a radix-8 pass are skipped.  The operands of a skipped
+    // product are lazy sums: stage 1 sees raw loads (value < 2^256: fat constant 8p), later stages reduce the value first.
+    if (trivial_first && (k0 & (half - 1)) == 0) {
+      if constexpr (T == 1) {
+        F a = x[k0], b = norm(x[k1]);
+        x[k0] = add(a, b);
+        x[k1] = sub<8, 1>(a, b);
+      } else {                                       // value reduction (a tenth of a product) keeps the growth of a product's path
+        F a = x[k0], b = vred(norm(x[k1]));
+        x[k0] = add(a, b);
+        x[k1] = sub<4, 1>(a, b);
+      }
     } else {
       F tt = mul(x[k1], tw(T, k0));
       F a = x[k0];

@@ -129,7 +129,7 @@ def test_ntt_butterfly_network_bounds_and_values(hostlib, oracle):
                 half = 1 << (t - 1)
                 for pi in range(4):
                     k0 = ((pi >> (t - 1)) << t) | (pi & (half - 1)); k1 = k0 + half
-                    if t == 1 and trivial and r == 0:
+                    if trivial and r == 0 and (k0 & (half - 1)) == 0:        # w = 1: product skipped
                         tt = x[k1]
                     else:
                         w = tw[0] if t == 1 else (tw[1 + (k0 & 1)] if t == 2 else tw[3 + (k0 & 3)])
