@@ -34,6 +34,7 @@ int ensure_ws_run(kg_ctx* c, int which, size_t bytes) {
   if (c->ws_run[which]) {
     hipStreamSynchronize(c->stream);
     if (c->side_stream) hipStreamSynchronize(c->side_stream);
+    if (c->side2_stream) hipStreamSynchronize(c->side2_stream);
     hipFree(c->ws_run[which]);
     c->ws_run[which] = nullptr; c->ws_run_bytes[which] = 0;
   }
@@ -58,7 +59,10 @@ int ensure_slot(kg_ctx* c, int slot, size_t bytes) {
 // The side stream carries the latency-bound bucket reductions of MSM i under the sort / accumulation of MSM i+1.
 // (A lowest-priority stream was measured and made no difference: the two queues do not compete for issue slots.)
 int make_side_stream(kg_ctx* c) {
+  // (stream priorities were measured, high and low, for the prover and the MSM pipeline: no gain either way)
   hipError_t e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) return set_err(c, KG_ERR_HIP, "side stream creation", e);
+  e = hipStreamCreateWithFlags(&c->side2_stream, hipStreamNonBlocking);
   if (e != hipSuccess) return set_err(c, KG_ERR_HIP, "side stream creation", e);
   return KG_OK;
 }
@@ -142,11 +146,13 @@ void kg_ctx_destroy(kg_ctx* c) {
   if (c->ws2) hipFree(c->ws2);
   if (c->ws3) hipFree(c->ws3);
   if (c->side_stream) hipStreamSynchronize(c->side_stream);
-  for (int i = 0; i < 2; ++i) { if (c->ws_run[i]) hipFree(c->ws_run[i]); if (c->ev_acc[i]) hipEventDestroy(c->ev_acc[i]); }
+  for (int i = 0; i < kg_ctx::RUN_SETS; ++i) { if (c->ws_run[i]) hipFree(c->ws_run[i]); if (c->ev_acc[i]) hipEventDestroy(c->ev_acc[i]); }
   if (c->side_stream) hipStreamDestroy(c->side_stream);
+  if (c->side2_stream) { hipStreamSynchronize(c->side2_stream); hipStreamDestroy(c->side2_stream); }
   if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); }
+  if (c->aux2_stream) { hipStreamSynchronize(c->aux2_stream); hipStreamDestroy(c->aux2_stream); }
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
-  for (int i = 0; i < 2; ++i) if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
+  for (int i = 0; i < 3; ++i) if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
   if (c->ev_info) hipEventDestroy(c->ev_info);
   for (auto& sl : c->slots) { if (sl.host) hipHostFree(sl.host); if (sl.done) hipEventDestroy(sl.done); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -167,6 +173,7 @@ int kg_ctx_sync(kg_ctx* c) {
   if (!c) return KG_ERR_BAD_ARG;
   KG_HIP(c, hipStreamSynchronize(c->stream));
   if (c->side_stream) KG_HIP(c, hipStreamSynchronize(c->side_stream));
+  if (c->side2_stream) KG_HIP(c, hipStreamSynchronize(c->side2_stream));
   return KG_OK;
 }
 int kg_malloc(kg_ctx* c, size_t bytes, void** p) {
@@ -221,6 +228,15 @@ int kg_profile_summary(kg_ctx* c, const char** names, float* total_ms, int* coun
   hipStreamSynchronize(c->stream);
   if (c->side_stream) hipStreamSynchronize(c->side_stream);
   if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
+  if (c->aux2_stream) hipStreamSynchronize(c->aux2_stream);
+  if (c->side2_stream) hipStreamSynchronize(c->side2_stream);
+  if (getenv("KG_PROFILE_TIMELINE") && !c->phases.empty()) {     // debugging aid: phase start / end relative to the first phase
+    for (auto& p : c->phases) {
+      float a = 0, b = 0;
+      if (hipEventElapsedTime(&a, c->phases[0].e0, p.e0) == hipSuccess && hipEventElapsedTime(&b, c->phases[0].e0, p.e1) == hipSuccess)
+        fprintf(stderr, "[timeline] %-14s %9.1f -> %9.1f us\n", p.name, a * 1e3f, b * 1e3f);
+    }
+  }
   int n = 0;
   std::vector<const char*> nm;
   std::vector<float> tot;

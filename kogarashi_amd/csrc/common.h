@@ -23,12 +23,14 @@ struct kg_ctx {
   size_t ws2_bytes = 0;
   void* ws3 = nullptr;                   // prover polynomial buffers
   size_t ws3_bytes = 0;
-  void* ws_run[2] = {nullptr, nullptr};  // MSM base-side scratch (packed bases, partial sums, halving buffers), double buffered
-  size_t ws_run_bytes[2] = {0, 0};
+  static constexpr int RUN_SETS = 4;     // a slow reduction (G2) may overlap the next TWO accumulations
+  void* ws_run[RUN_SETS] = {};           // MSM base-side scratch (packed bases, partial sums, halving buffers), one set per slot mod RUN_SETS
+  size_t ws_run_bytes[RUN_SETS] = {};
   hipStream_t side_stream = nullptr;     // bucket reduction of MSM i overlaps the accumulation of MSM i+1
-  hipStream_t aux_stream = nullptr;      // third queue for the prover's independent transform chains
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-  hipEvent_t ev_acc[2] = {nullptr, nullptr};
+  hipStream_t side2_stream = nullptr;    // second reduction queue (odd slots): a slow G2 reduction does not hold up the next MSM's
+  hipStream_t aux_stream = nullptr, aux2_stream = nullptr;   // queues for the prover's independent transform chains
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_acc[RUN_SETS] = {};
   hipEvent_t ev_info = nullptr;          // marks the task-count read-back of msm_sort
   struct Slot { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0; bool busy = false; };
   Slot slots[8];

@@ -7,6 +7,7 @@
 // three proof points touch the host, which also runs the six short scalar multiplications of the assembly
 // (sequential double-and-add, as in the reference).
 #include "common.h"
+#include <chrono>
 #include "host_fp.h"
 #include <future>
 #include <vector>
@@ -168,50 +169,34 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   uint64_t* A = (uint64_t*)ctx->ws3;
   uint64_t* B = A + 4 * n;
   uint64_t* C = B + 4 * n;
-  // The three idft -> coset_dft chains (prover.rs:36-41) are independent: each runs on its own stream with its own
-  // transform scratch, so a 2^18-point chain (128 workgroups per launch) does not leave half the chip idle.
+  // Queue layout.  The four MSMs against z = x || w need nothing from the transforms, and the transforms are short,
+  // latency-bound launches (2^18 points = 128..512 workgroups): the three idft -> coset_dft chains (prover.rs:36-41)
+  // run on three side queues UNDER the witness MSMs of the main queue, and h's MSM -- the only consumer of the
+  // transforms -- goes last.
   if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
   if (!ctx->aux_stream) KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+  if (!ctx->aux2_stream) KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux2_stream, hipStreamNonBlocking));
   if (!ctx->ev_fork) {
     KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[0], hipEventDisableTiming));
-    KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[1], hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
   }
   KG_TRY(ntt_prepare(ctx, k, 0));
   KG_TRY(ntt_prepare(ctx, k, 1));
   KG_TRY(ensure_ws2(ctx, 3 * n * 32));
   const uint64_t* src[3] = {d_a_eval, d_b_eval, d_c_eval};
   uint64_t* dst[3] = {A, B, C};
-  hipStream_t lanes[3] = {st, ctx->side_stream, ctx->aux_stream};
+  hipStream_t lanes[3] = {ctx->aux_stream, ctx->aux2_stream, ctx->side_stream};
   KG_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
   for (int v = 0; v < 3; ++v) {                         // prepare_fft zero padding, then idft + coset_dft
     hipStream_t sv = lanes[v];
     uint64_t* tmp = (uint64_t*)ctx->ws2 + (size_t)v * 4 * n;
-    if (v) KG_HIP(ctx, hipStreamWaitEvent(sv, ctx->ev_fork, 0));
+    KG_HIP(ctx, hipStreamWaitEvent(sv, ctx->ev_fork, 0));
     KG_HIP(ctx, hipMemcpyAsync(dst[v], src[v], m * 32, hipMemcpyDeviceToDevice, sv));
     if (n > m) KG_HIP(ctx, hipMemsetAsync(dst[v] + 4 * m, 0, (n - m) * 32, sv));
     KG_TRY(ntt_enqueue(ctx, sv, tmp, dst[v], k, 1, 0));
     KG_TRY(ntt_enqueue(ctx, sv, tmp, dst[v], k, 0, 1));
-    if (v) {
-      KG_HIP(ctx, hipEventRecord(ctx->ev_join[v - 1], sv));
-      KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[v - 1], 0));
-    }
+    KG_HIP(ctx, hipEventRecord(ctx->ev_join[v], sv));
   }
-  // (7^n - 1)^-1 on the host: n = 2^k squarings of 7
-  HostFr seven = HostFr::one();
-  {
-    HostFr one = HostFr::one(), acc = HostFr::zero();
-    for (int i = 0; i < 7; ++i) acc = add(acc, one);
-    seven = acc;
-  }
-  HostFr z = seven;
-  for (uint32_t i = 0; i < k; ++i) z = sqr(z);
-  z = inv(sub<4, 1>(z, HostFr::one()));                 // z_on_coset().invert() (fft.rs:141-151)
-  Words8 zw;
-  for (int i = 0; i < 4; ++i) { zw.w[2 * i] = (uint32_t)z.v[i]; zw.w[2 * i + 1] = (uint32_t)(z.v[i] >> 32); }
-  hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, C, n, zw);
-  KG_HIP(ctx, hipGetLastError());
-  KG_TRY(ntt_enqueue(ctx, st, (uint64_t*)ctx->ws2, A, k, 1, 1));   // coset_idft (prover.rs:47)
 
   // The eight MSMs of prover.rs:51-65 as five: a_inputs + a_aux (:58-59,80) is one MSM of a[..] against
   // z = x || w, likewise b_g1 (:61-62,85) and b_g2 (:64-65,86) -- the sums are what the proof uses.  The four MSMs
@@ -227,32 +212,52 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   uint64_t q_p[12], l_p[12], ai[12], aa[12], b1i[12], b1a[12], b2i[24], b2a[24];
   for (int i = 0; i < 12; ++i) aa[i] = b1a[i] = 0;       // identity (0, *, 0): the partner sums are folded in
   for (int i = 0; i < 24; ++i) b2a[i] = 0;
-  std::vector<std::future<int>> pending;
+  std::future<int> f_q, f_l, f_a, f_b1, f_b2;
   auto finish_async = [&](int curve, int slot, uint64_t* out) {
-    pending.emplace_back(std::async(std::launch::async, [ctx, curve, slot, out] { return msm_finish(ctx, curve, slot, out); }));
+    return std::async(std::launch::async, [ctx, curve, slot, out] { return msm_finish(ctx, curve, slot, out); });
   };
   int rc = KG_OK;
-  if (hn) {
-    MsmSorted Sq;
-    rc = msm_sort(ctx, KG_FR, A, hn, &Sq);
-    if (rc == KG_OK) rc = msm_run(ctx, Sq, KG_G1, crs->d_h, crs->d_h_inf, hn, 0, 0);
-    if (rc == KG_OK) finish_async(KG_G1, 0, q_p);
-  } else msm_identity(KG_G1, q_p);
-  if (rc == KG_OK) {
+  // result slots: consecutive MSMs alternate between the two reduction queues (slot parity) and rotate through the
+  // four run-space sets (slot mod 4); measured against giving G2's long reduction a queue of its own: 4.33 vs 4.45 ms
+  static constexpr int SL[5] = {1, 2, 3, 4, 5};
+  {
     MsmSorted Sz;
     rc = msm_sort(ctx, KG_FR, Z, nz, &Sz);
-    // G2 first: its host finish (Fq2 arithmetic, ~3x a G1 finish) then overlaps the three G1 accumulations
-    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, 0, 1);
-    if (rc == KG_OK) finish_async(KG_G2, 1, b2i);
-    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G1, crs->d_a, crs->d_a_inf, nz, 0, 2);
-    if (rc == KG_OK) finish_async(KG_G1, 2, ai);
-    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, nz, 0, 3);
-    if (rc == KG_OK) finish_async(KG_G1, 3, b1i);
+    // G2 first: its host finish (Fq2 arithmetic, ~3x a G1 finish) and its slow reduction then overlap the G1 accumulations
+    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, 0, SL[0]);
+    if (rc == KG_OK) f_b2 = finish_async(KG_G2, SL[0], b2i);
+    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G1, crs->d_a, crs->d_a_inf, nz, 0, SL[1]);
+    if (rc == KG_OK) f_a = finish_async(KG_G1, SL[1], ai);
+    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, nz, 0, SL[2]);
+    if (rc == KG_OK) f_b1 = finish_async(KG_G1, SL[2], b1i);
     if (rc == KG_OK && m_l_1) {
-      rc = msm_run(ctx, Sz, KG_G1, crs->d_l, crs->d_l_inf, m_l_1, (uint32_t)l, 4);
-      if (rc == KG_OK) finish_async(KG_G1, 4, l_p);
+      rc = msm_run(ctx, Sz, KG_G1, crs->d_l, crs->d_l_inf, m_l_1, (uint32_t)l, SL[3]);
+      if (rc == KG_OK) f_l = finish_async(KG_G1, SL[3], l_p);
     } else msm_identity(KG_G1, l_p);
   }
+  // h = (a o b - c) / Z on the coset, back to coefficients (prover.rs:43-47), then its MSM
+  for (int v = 0; v < 3; ++v) KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[v], 0));
+  // (7^n - 1)^-1 on the host: n = 2^k squarings of 7
+  HostFr seven = HostFr::one();
+  {
+    HostFr one = HostFr::one(), acc = HostFr::zero();
+    for (int i = 0; i < 7; ++i) acc = add(acc, one);
+    seven = acc;
+  }
+  HostFr z = seven;
+  for (uint32_t i = 0; i < k; ++i) z = sqr(z);
+  z = inv(sub<4, 1>(z, HostFr::one()));                 // z_on_coset().invert() (fft.rs:141-151)
+  Words8 zw;
+  for (int i = 0; i < 4; ++i) { zw.w[2 * i] = (uint32_t)z.v[i]; zw.w[2 * i + 1] = (uint32_t)(z.v[i] >> 32); }
+  hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, C, n, zw);
+  KG_HIP(ctx, hipGetLastError());
+  if (rc == KG_OK) rc = ntt_enqueue(ctx, st, (uint64_t*)ctx->ws2, A, k, 1, 1);   // coset_idft (prover.rs:47)
+  if (rc == KG_OK && hn) {
+    MsmSorted Sq;
+    rc = msm_sort(ctx, KG_FR, A, hn, &Sq);
+    if (rc == KG_OK) rc = msm_run(ctx, Sq, KG_G1, crs->d_h, crs->d_h_inf, hn, 0, SL[4]);
+    if (rc == KG_OK) f_q = finish_async(KG_G1, SL[4], q_p);
+  } else msm_identity(KG_G1, q_p);
   // While the device works: the parts of the assembly (prover.rs:75-77) that do not depend on any MSM result
   HostFr rm = HostFr::from_words(r), sm = HostFr::from_words(s);
   HostFr raw_one{{1, 0, 0, 0}};
@@ -268,10 +273,7 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
     g_b = add_xyzz(h_scalar_mul(delta2, sk.v), beta2);                                                      // :76
     g_c = add_xyzz(add_xyzz(h_scalar_mul(delta1, rsk.v), h_scalar_mul(alpha, sk.v)), h_scalar_mul(beta1, rk.v));   // :77
   }
-  for (auto& f : pending) { int r2 = f.get(); if (rc == KG_OK) rc = r2; }
-  if (rc != KG_OK) return rc;
-  if (bad_delta) return set_err(ctx, KG_ERR_CRS, "delta is the identity");   // prover.rs:67-69
-
+  auto join = [&](std::future<int>& f) { if (f.valid()) { int r2 = f.get(); if (rc == KG_OK) rc = r2; } };
   auto g1pt = [](const uint64_t* xyz) {
     bool inf = !(xyz[8] | xyz[9] | xyz[10] | xyz[11]);
     return h_from_abi<HostFq>(h_load_aff<HostFq, 4>(xyz), inf);
@@ -281,15 +283,23 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
     for (int i = 16; i < 24; ++i) inf = inf && xyz[i] == 0;
     return h_from_abi<HostFq2>(h_load_aff<HostFq2, 8>(xyz), inf);
   };
-  XYZZ<HostFq> a_ans = add_xyzz(g1pt(ai), g1pt(aa));
-  XYZZ<HostFq> b1_ans = add_xyzz(g1pt(b1i), g1pt(b1a));
-  XYZZ<HostFq2> b2_ans = add_xyzz(g2pt(b2i), g2pt(b2a));
-  g_a = add_xyzz(g_a, a_ans);                                                                              // :81
-  g_b = add_xyzz(g_b, b2_ans);                                                                             // :88
-  g_c = add_xyzz(g_c, h_scalar_mul2(a_ans, sk.v, b1_ans, rk.v));                                           // :83,90
-  g_c = add_xyzz(g_c, add_xyzz(g1pt(q_p), g1pt(l_p)));                                                     // :92
-  h_store_affine<HostFq, 4>(g_a, proof_out, proof_inf);
-  h_store_affine<HostFq2, 8>(g_b, proof_out + 8, proof_inf + 1);
+  // everything that does not need h's MSM is assembled while the device is still working on it
+  join(f_b2); join(f_a); join(f_b1); join(f_l);
+  if (rc == KG_OK && !bad_delta) {
+    XYZZ<HostFq> a_ans = add_xyzz(g1pt(ai), g1pt(aa));
+    XYZZ<HostFq> b1_ans = add_xyzz(g1pt(b1i), g1pt(b1a));
+    XYZZ<HostFq2> b2_ans = add_xyzz(g2pt(b2i), g2pt(b2a));
+    g_a = add_xyzz(g_a, a_ans);                                                                            // :81
+    g_b = add_xyzz(g_b, b2_ans);                                                                           // :88
+    g_c = add_xyzz(g_c, h_scalar_mul2(a_ans, sk.v, b1_ans, rk.v));                                         // :83,90
+    g_c = add_xyzz(g_c, g1pt(l_p));                                                                        // :92 (l part)
+    h_store_affine<HostFq, 4>(g_a, proof_out, proof_inf);
+    h_store_affine<HostFq2, 8>(g_b, proof_out + 8, proof_inf + 1);
+  }
+  join(f_q);
+  if (rc != KG_OK) return rc;
+  if (bad_delta) return set_err(ctx, KG_ERR_CRS, "delta is the identity");   // prover.rs:67-69
+  g_c = add_xyzz(g_c, g1pt(q_p));                                                                          // :92 (h part)
   h_store_affine<HostFq, 4>(g_c, proof_out + 24, proof_inf + 2);
   return KG_OK;
 }

@@ -1036,7 +1036,7 @@ int msm_run_t(kg_ctx* ctx, const MsmSorted& S, const uint64_t* d_bases, const ui
   const size_t o_rowtot = cv.take((size_t)W * 4), o_misc = cv.take(64);
   const size_t exp_bytes = nexp * 4 * Cfg::E64 * 8;
   const size_t o_exp = cv.take(exp_bytes);
-  const int set = slot & 1;                         // double-buffered run space: the reduction of the previous MSM may still read the other set
+  const int set = slot % kg_ctx::RUN_SETS;          // run space per set: the reductions of the previous MSMs may still read the other sets
   KG_TRY(ensure_ws_run(ctx, set, cv.off));
   KG_TRY(ensure_slot(ctx, slot, exp_bytes));
   if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
@@ -1048,10 +1048,11 @@ int msm_run_t(kg_ctx* ctx, const MsmSorted& S, const uint64_t* d_bases, const ui
   uint32_t* rowtot = (uint32_t*)(ws + o_rowtot);
   uint32_t* misc = (uint32_t*)(ws + o_misc);
   uint64_t* d_exp = (uint64_t*)(ws + o_exp);
-  hipStream_t st = ctx->stream, side = ctx->side_stream;
+  // two reduction queues, by slot parity: a long reduction (G2: ~4x a G1 one) does not hold up the next MSM's
+  hipStream_t st = ctx->stream, side = (slot & 1) ? ctx->side2_stream : ctx->side_stream;
   // this buffer set was last used by slot (slot - 2): its side-stream work must be over before we overwrite it
   for (int s2 = 0; s2 < 8; ++s2)
-    if ((s2 & 1) == set && ctx->slots[s2].done && ctx->slots[s2].busy) { KG_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[s2].done, 0)); ctx->slots[s2].busy = false; }
+    if (s2 % kg_ctx::RUN_SETS == set && ctx->slots[s2].done && ctx->slots[s2].busy) { KG_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[s2].done, 0)); ctx->slots[s2].busy = false; }
   if (!reg_pb) {
     PhaseScope ph(ctx, "prep_bases");
     hipLaunchKernelGGL(k_prep_bases<F>, dim3((unsigned)((nbases + 255) / 256)), dim3(256), 0, st, d_bases, d_inf, nbases, (uint32_t*)(ws + o_pb));
