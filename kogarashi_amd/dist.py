@@ -17,9 +17,22 @@ def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+_comm_streams = {}
+
+
+def _comm_stream(torch, device):
+    """One exchange queue per device: the 9-word all_gather must not queue behind the next MSM's accumulation on the
+    compute stream (a collective issued on the compute stream would wait 1 ms for it and leave a bubble after it)."""
+    key = (device.type, device.index)
+    if key not in _comm_streams:
+        _comm_streams[key] = torch.cuda.Stream(device=device)
+    return _comm_streams[key]
+
+
 def combine_partials(ctx, curve: int, partial_xy: np.ndarray, partial_inf: int, group=None, device=None):
     """all_gather the ranks' affine partial sums and add them (every rank gets the total).
     partial_xy: 2*E uint64 words (E = 4, or 8 for G2); returns (xy, inf)."""
+    import contextlib
     import torch
     import torch.distributed as dist
     e2 = 16 if curve == KG_G2 else 8
@@ -28,11 +41,13 @@ def combine_partials(ctx, curve: int, partial_xy: np.ndarray, partial_inf: int, 
     mine[:e2] = np.ascontiguousarray(partial_xy, dtype=np.uint64).view(np.int64)[:e2]
     mine[e2] = int(partial_inf)
     t = torch.from_numpy(mine)
-    if device is not None:
-        t = t.to(device)
-    out = torch.empty(world * (e2 + 1), dtype=torch.int64, device=t.device)
-    dist.all_gather_into_tensor(out, t, group=group)
-    h = out.cpu().numpy().view(np.uint64).reshape(world, e2 + 1)
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+    with (torch.cuda.stream(_comm_stream(torch, torch.device(device))) if on_gpu else contextlib.nullcontext()):
+        if device is not None:
+            t = t.to(device)
+        out = torch.empty(world * (e2 + 1), dtype=torch.int64, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=group)
+        h = out.cpu().numpy().view(np.uint64).reshape(world, e2 + 1)
     return ctx.points_sum_affine(curve, np.ascontiguousarray(h[:, :e2]), (h[:, e2] != 0).astype(np.uint8))
 
 

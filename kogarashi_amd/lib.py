@@ -53,6 +53,14 @@ def load():
     if _lib is None:
         if not os.path.exists(SO_PATH):
             raise KogarashiError(f"{SO_PATH} is missing: build it with `python -m kogarashi_amd.build` (hipcc, gfx950)")
+        # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64.so.7 / libhsa-runtime64 and
+        # loads them by path.  If this library came first it would bind /opt/rocm's copies, torch would then load a
+        # second runtime and report "No HIP GPUs are available".  With torch imported first the soname is already
+        # resolved and both share the runtime (torch tensors and kg_malloc memory live in one address space).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(SO_PATH)
         _lib.kg_strerror.restype = C.c_char_p
         _lib.kg_last_error.restype = C.c_char_p

@@ -334,3 +334,30 @@ def test_msm_two_pass_sort_degenerate_scalars(ctx, oracle):
     scal = np.tile(k, (n, 1))
     want = aff(O, "g1", O.msm("g1", bases, scal, None, threads=8))
     assert gpu_aff(ctx.msm_host(0, bases, None, scal, n), 4) == want
+
+
+def test_combine_partials_over_rccl_single_rank(ctx, oracle):
+    """The exchange step of the sharded MSM on the device path: a one-rank RCCL group (backend "nccl") all_gathers the
+    partial sum on the dedicated exchange stream and returns it unchanged; an identity partial stays the identity."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from kogarashi_amd import dist as kdist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        P = oracle.gen_bases(0, SEED + 700, 0, 1)[0]
+        xy, inf = kdist.combine_partials(ctx, 0, P, 0, device=dev)
+        assert not inf and (xy == P).all()
+        xy, inf = kdist.combine_partials(ctx, 0, np.zeros(8, dtype=np.uint64), 1, device=dev)
+        assert inf
+    finally:
+        dist.destroy_process_group()
