@@ -154,6 +154,15 @@ typedef struct {
 int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
                            const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
                            const uint64_t* s, uint64_t* proof_out, uint8_t* proof_inf);
+/* Two proofs in flight (tickets 0 and 1), for provers that make proofs back to back: _begin enqueues the whole proof and
+ * starts its host-side assembly on worker threads; _end waits for it and writes the proof (same layout and status codes
+ * as kg_groth16_prove_bn254).  _begin(i + 1) before _end(i) lets the next proof's transforms and sorts run while the
+ * previous proof's last reduction, host finish and assembly complete.  crs and the device inputs must stay valid
+ * until the matching _end. */
+int kg_groth16_prove_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
+                           const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
+                           const uint64_t* s, int ticket);
+int kg_groth16_prove_end(kg_ctx* ctx, int ticket, uint64_t* proof_out, uint8_t* proof_inf);
 
 /* ---- R1CS evaluation -------------------------------------------------------------------------------
  * zkstd/src/matrix.rs:31-33 SparseMatrix::evaluate_with_z (row.rs:43-51): out[i] = sum_e val[e] * z[col[e]] over the

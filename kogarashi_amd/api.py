@@ -163,6 +163,24 @@ class Prover:
         da, db, dc, dx, dw = up(a_eval), up(b_eval), up(c_eval), up(x), up(w)
         return self.ctx.groth16_prove(self.crs, da.ptr, db.ptr, dc.ptr, dx.ptr, dw.ptr, r, s)
 
+    def create_proofs(self, jobs):
+        """Proofs for an iterable of (a_eval, b_eval, c_eval, x, w, r, s), two in flight (kg_groth16_prove_begin / _end):
+        proof i+1 is enqueued before proof i is collected, so its transforms and sorts overlap proof i's last reduction
+        and host assembly.  Yields the proofs in order."""
+        up = lambda v: self.ctx.upload(np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4))
+        held = [None, None]
+        pending = None
+        for i, (a_eval, b_eval, c_eval, x, w, r, s) in enumerate(jobs):
+            t = i & 1
+            held[t] = [up(a_eval), up(b_eval), up(c_eval), up(x), up(w)]       # alive until the matching end
+            da, db, dc, dx, dw = held[t]
+            self.ctx.groth16_prove_begin(self.crs, da.ptr, db.ptr, dc.ptr, dx.ptr, dw.ptr, r, s, t)
+            if pending is not None:
+                yield self.ctx.groth16_prove_end(pending)
+            pending = t
+        if pending is not None:
+            yield self.ctx.groth16_prove_end(pending)
+
 
 def _csr_transpose(row_ptr, col, val, m, nvars):
     """index-only transposition of a CSR matrix (m rows) -> CSR of its transpose (nvars rows, column = constraint);

@@ -45,7 +45,7 @@ int ensure_ws_run(kg_ctx* c, int which, size_t bytes) {
   return KG_OK;
 }
 int ensure_slot(kg_ctx* c, int slot, size_t bytes) {
-  if (slot < 0 || slot >= 8) return set_err(c, KG_ERR_BAD_ARG, "bad result slot");
+  if (slot < 0 || slot >= kg_ctx::NSLOTS) return set_err(c, KG_ERR_BAD_ARG, "bad result slot");
   kg_ctx::Slot& s = c->slots[slot];
   if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation");
   if (bytes <= s.bytes) return KG_OK;
@@ -140,6 +140,7 @@ int kg_ctx_create(int device, kg_ctx** out) {
 void kg_ctx_destroy(kg_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
+  c->prover_jobs.reset();                             // joins the worker threads of proofs still in flight
   hipStreamSynchronize(c->stream);
   tw_cache_free(c);
   if (c->ws) hipFree(c->ws);

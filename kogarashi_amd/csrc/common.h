@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <memory>
 #include <vector>
 #include "../../include/kogarashi_amd.h"
 #include "curve.h"
@@ -33,7 +34,9 @@ struct kg_ctx {
   hipEvent_t ev_acc[RUN_SETS] = {};
   hipEvent_t ev_info = nullptr;          // marks the task-count read-back of msm_sort
   struct Slot { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0; bool busy = false; };
-  Slot slots[8];
+  static constexpr int NSLOTS = 16;      // 0..3 kg_msm / prover job 0 (1..5), 4..7 kg_msm_begin tickets, 8..15 prover job 1 (9..13)
+  Slot slots[NSLOTS];
+  std::shared_ptr<void> prover_jobs;     // groth16.hip: proofs in flight (kg_groth16_prove_begin / _end)
   size_t ticket_n[4] = {0, 0, 0, 0};
   struct Registered { const uint64_t* base; size_t n; int curve; uint32_t* packed; };
   std::vector<Registered> registered;    // bases converted once by kg_bases_register     // lengths of the MSMs begun with kg_msm_begin                         // pinned result slots: MSMs in flight whose host finish is pending

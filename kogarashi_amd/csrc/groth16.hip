@@ -152,10 +152,29 @@ int kg_fixed_base_mul(kg_ctx* ctx, int curve, const uint64_t* d_k, size_t n, uin
   return KG_OK;
 }
 
-int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
-                           const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
-                           const uint64_t* s, uint64_t* proof_out, uint8_t* proof_inf) {
-  if (!ctx || !crs || !d_a_eval || !d_b_eval || !d_c_eval || !d_x || !r || !s || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
+}  // extern "C"
+
+namespace {
+// One proof in flight: everything the host side needs between "all device work enqueued" and "proof read".
+struct ProofJob {
+  uint64_t q_p[12], l_p[12], ai[12], b1i[12], b2i[24];
+  std::future<int> f_q, f_l, f_a, f_b1, f_b2, assembly;
+  uint64_t proof[32];
+  uint8_t inf[3];
+  bool active = false;
+};
+struct ProofJobs { ProofJob j[2]; };   // job 0: kg_groth16_prove_bn254 and ticket 0; job 1: ticket 1 (result slots 8..15)
+ProofJob* job_of(kg_ctx* ctx, int i) {
+  if (!ctx->prover_jobs) ctx->prover_jobs = std::make_shared<ProofJobs>();
+  return &static_cast<ProofJobs*>(ctx->prover_jobs.get())->j[i];
+}
+
+// Enqueues the whole proof on the device and starts the host-side assembly on a worker thread; returns once h's MSM is
+// on the queue (the scalar sorts read two words back, so this call spans most of the proof's device time).
+int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
+                  const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
+                  const uint64_t* s, ProofJob* job, int slot_base) {
+  if (!ctx || !crs || !d_a_eval || !d_b_eval || !d_c_eval || !d_x || !r || !s) return KG_ERR_BAD_ARG;
   const size_t m = crs->m, l = crs->l, m_l_1 = crs->m_l_1;
   if (m < 1 || l < 1 || (m_l_1 && !d_w)) return KG_ERR_BAD_ARG;
   KG_HIP(ctx, hipSetDevice(ctx->device));
@@ -209,17 +228,15 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   uint64_t* Z = C + 4 * n;                                // z = x || w
   KG_HIP(ctx, hipMemcpyAsync(Z, d_x, l * 32, hipMemcpyDeviceToDevice, st));
   if (m_l_1) KG_HIP(ctx, hipMemcpyAsync(Z + 4 * l, d_w, m_l_1 * 32, hipMemcpyDeviceToDevice, st));
-  uint64_t q_p[12], l_p[12], ai[12], aa[12], b1i[12], b1a[12], b2i[24], b2a[24];
-  for (int i = 0; i < 12; ++i) aa[i] = b1a[i] = 0;       // identity (0, *, 0): the partner sums are folded in
-  for (int i = 0; i < 24; ++i) b2a[i] = 0;
-  std::future<int> f_q, f_l, f_a, f_b1, f_b2;
+  uint64_t *q_p = job->q_p, *l_p = job->l_p, *ai = job->ai, *b1i = job->b1i, *b2i = job->b2i;
+  std::future<int>&f_q = job->f_q, &f_l = job->f_l, &f_a = job->f_a, &f_b1 = job->f_b1, &f_b2 = job->f_b2;
   auto finish_async = [&](int curve, int slot, uint64_t* out) {
     return std::async(std::launch::async, [ctx, curve, slot, out] { return msm_finish(ctx, curve, slot, out); });
   };
   int rc = KG_OK;
   // result slots: consecutive MSMs alternate between the two reduction queues (slot parity) and rotate through the
   // four run-space sets (slot mod 4); measured against giving G2's long reduction a queue of its own: 4.33 vs 4.45 ms
-  static constexpr int SL[5] = {1, 2, 3, 4, 5};
+  const int SL[5] = {slot_base + 1, slot_base + 2, slot_base + 3, slot_base + 4, slot_base + 5};
   {
     MsmSorted Sz;
     rc = msm_sort(ctx, KG_FR, Z, nz, &Sz);
@@ -258,50 +275,96 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
     if (rc == KG_OK) rc = msm_run(ctx, Sq, KG_G1, crs->d_h, crs->d_h_inf, hn, 0, SL[4]);
     if (rc == KG_OK) f_q = finish_async(KG_G1, SL[4], q_p);
   } else msm_identity(KG_G1, q_p);
-  // While the device works: the parts of the assembly (prover.rs:75-77) that do not depend on any MSM result
-  HostFr rm = HostFr::from_words(r), sm = HostFr::from_words(s);
-  HostFr raw_one{{1, 0, 0, 0}};
-  HostFr rk = mul(rm, raw_one), sk = mul(sm, raw_one), rsk = mul(mul(rm, sm), raw_one);   // out of Montgomery form
-  XYZZ<HostFq> alpha = from_affine(h_load_aff<HostFq, 4>(crs->alpha_g1)), beta1 = from_affine(h_load_aff<HostFq, 4>(crs->beta_g1)),
-               delta1 = from_affine(h_load_aff<HostFq, 4>(crs->delta_g1));
-  XYZZ<HostFq2> beta2 = from_affine(h_load_aff<HostFq2, 8>(crs->beta_g2)), delta2 = from_affine(h_load_aff<HostFq2, 8>(crs->delta_g2));
-  const bool bad_delta = crs->delta_g1_inf || crs->delta_g2_inf;
-  XYZZ<HostFq> g_a = XYZZ<HostFq>::identity(), g_c = g_a;
-  XYZZ<HostFq2> g_b = XYZZ<HostFq2>::identity();
-  if (rc == KG_OK && !bad_delta) {
-    g_a = add_xyzz(h_scalar_mul(delta1, rk.v), alpha);                                                      // :75
-    g_b = add_xyzz(h_scalar_mul(delta2, sk.v), beta2);                                                      // :76
-    g_c = add_xyzz(add_xyzz(h_scalar_mul(delta1, rsk.v), h_scalar_mul(alpha, sk.v)), h_scalar_mul(beta1, rk.v));   // :77
-  }
-  auto join = [&](std::future<int>& f) { if (f.valid()) { int r2 = f.get(); if (rc == KG_OK) rc = r2; } };
-  auto g1pt = [](const uint64_t* xyz) {
-    bool inf = !(xyz[8] | xyz[9] | xyz[10] | xyz[11]);
-    return h_from_abi<HostFq>(h_load_aff<HostFq, 4>(xyz), inf);
-  };
-  auto g2pt = [](const uint64_t* xyz) {
-    bool inf = true;
-    for (int i = 16; i < 24; ++i) inf = inf && xyz[i] == 0;
-    return h_from_abi<HostFq2>(h_load_aff<HostFq2, 8>(xyz), inf);
-  };
-  // everything that does not need h's MSM is assembled while the device is still working on it
-  join(f_b2); join(f_a); join(f_b1); join(f_l);
-  if (rc == KG_OK && !bad_delta) {
-    XYZZ<HostFq> a_ans = add_xyzz(g1pt(ai), g1pt(aa));
-    XYZZ<HostFq> b1_ans = add_xyzz(g1pt(b1i), g1pt(b1a));
-    XYZZ<HostFq2> b2_ans = add_xyzz(g2pt(b2i), g2pt(b2a));
-    g_a = add_xyzz(g_a, a_ans);                                                                            // :81
-    g_b = add_xyzz(g_b, b2_ans);                                                                           // :88
-    g_c = add_xyzz(g_c, h_scalar_mul2(a_ans, sk.v, b1_ans, rk.v));                                         // :83,90
-    g_c = add_xyzz(g_c, g1pt(l_p));                                                                        // :92 (l part)
-    h_store_affine<HostFq, 4>(g_a, proof_out, proof_inf);
-    h_store_affine<HostFq2, 8>(g_b, proof_out + 8, proof_inf + 1);
-  }
-  join(f_q);
-  if (rc != KG_OK) return rc;
-  if (bad_delta) return set_err(ctx, KG_ERR_CRS, "delta is the identity");   // prover.rs:67-69
-  g_c = add_xyzz(g_c, g1pt(q_p));                                                                          // :92 (h part)
-  h_store_affine<HostFq, 4>(g_c, proof_out + 24, proof_inf + 2);
+  // Host side of the proof on a worker thread: first the parts of the assembly (prover.rs:75-77) that depend on no MSM
+  // result, then A, B and C up to h's term as the witness MSMs' host finishes arrive, then h's term.
+  uint64_t rr[4], ss[4];
+  for (int i = 0; i < 4; ++i) { rr[i] = r[i]; ss[i] = s[i]; }
+  const kg_groth16_crs vk = *crs;                       // the host-resident part (alpha, beta, delta) is read by value
+  job->active = true;
+  job->assembly = std::async(std::launch::async, [ctx, job, vk, rr, ss, rc0 = rc]() -> int {
+    int rc = rc0;
+    uint64_t *q_p = job->q_p, *l_p = job->l_p, *ai = job->ai, *b1i = job->b1i, *b2i = job->b2i;
+    HostFr rm = HostFr::from_words(rr), sm = HostFr::from_words(ss);
+    HostFr raw_one{{1, 0, 0, 0}};
+    HostFr rk = mul(rm, raw_one), sk = mul(sm, raw_one), rsk = mul(mul(rm, sm), raw_one);   // out of Montgomery form
+    XYZZ<HostFq> alpha = from_affine(h_load_aff<HostFq, 4>(vk.alpha_g1)), beta1 = from_affine(h_load_aff<HostFq, 4>(vk.beta_g1)),
+                 delta1 = from_affine(h_load_aff<HostFq, 4>(vk.delta_g1));
+    XYZZ<HostFq2> beta2 = from_affine(h_load_aff<HostFq2, 8>(vk.beta_g2)), delta2 = from_affine(h_load_aff<HostFq2, 8>(vk.delta_g2));
+    const bool bad_delta = vk.delta_g1_inf || vk.delta_g2_inf;
+    XYZZ<HostFq> g_a = XYZZ<HostFq>::identity(), g_c = g_a;
+    XYZZ<HostFq2> g_b = XYZZ<HostFq2>::identity();
+    if (rc == KG_OK && !bad_delta) {
+      g_a = add_xyzz(h_scalar_mul(delta1, rk.v), alpha);                                                    // :75
+      g_b = add_xyzz(h_scalar_mul(delta2, sk.v), beta2);                                                    // :76
+      g_c = add_xyzz(add_xyzz(h_scalar_mul(delta1, rsk.v), h_scalar_mul(alpha, sk.v)), h_scalar_mul(beta1, rk.v));   // :77
+    }
+    auto join = [&](std::future<int>& f) { if (f.valid()) { int r2 = f.get(); if (rc == KG_OK) rc = r2; } };
+    auto g1pt = [](const uint64_t* xyz) {
+      bool inf = !(xyz[8] | xyz[9] | xyz[10] | xyz[11]);
+      return h_from_abi<HostFq>(h_load_aff<HostFq, 4>(xyz), inf);
+    };
+    auto g2pt = [](const uint64_t* xyz) {
+      bool inf = true;
+      for (int i = 16; i < 24; ++i) inf = inf && xyz[i] == 0;
+      return h_from_abi<HostFq2>(h_load_aff<HostFq2, 8>(xyz), inf);
+    };
+    // everything that does not need h's MSM is assembled while the device is still working on it
+    join(job->f_b2); join(job->f_a); join(job->f_b1); join(job->f_l);
+    if (rc == KG_OK && !bad_delta) {
+      XYZZ<HostFq> a_ans = g1pt(ai), b1_ans = g1pt(b1i);
+      XYZZ<HostFq2> b2_ans = g2pt(b2i);
+      g_a = add_xyzz(g_a, a_ans);                                                                          // :81
+      g_b = add_xyzz(g_b, b2_ans);                                                                         // :88
+      g_c = add_xyzz(g_c, h_scalar_mul2(a_ans, sk.v, b1_ans, rk.v));                                       // :83,90
+      g_c = add_xyzz(g_c, g1pt(l_p));                                                                      // :92 (l part)
+      h_store_affine<HostFq, 4>(g_a, job->proof, job->inf);
+      h_store_affine<HostFq2, 8>(g_b, job->proof + 8, job->inf + 1);
+    }
+    join(job->f_q);
+    if (rc != KG_OK) return rc;
+    if (bad_delta) return set_err(ctx, KG_ERR_CRS, "delta is the identity");   // prover.rs:67-69
+    g_c = add_xyzz(g_c, g1pt(q_p));                                                                        // :92 (h part)
+    h_store_affine<HostFq, 4>(g_c, job->proof + 24, job->inf + 2);
+    return KG_OK;
+  });
   return KG_OK;
+}
+
+int prove_collect(ProofJob* job, uint64_t* proof_out, uint8_t* proof_inf) {
+  if (!job->active) return KG_ERR_BAD_ARG;
+  job->active = false;
+  const int rc = job->assembly.get();
+  if (rc != KG_OK) return rc;
+  for (int i = 0; i < 32; ++i) proof_out[i] = job->proof[i];
+  for (int i = 0; i < 3; ++i) proof_inf[i] = job->inf[i];
+  return KG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
+                           const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
+                           const uint64_t* s, uint64_t* proof_out, uint8_t* proof_inf) {
+  if (!ctx || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
+  ProofJob* job = job_of(ctx, 0);
+  if (job->active) return KG_ERR_BAD_ARG;                // a proof begun with ticket 0 has not been collected
+  KG_TRY(prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job, 0));
+  return prove_collect(job, proof_out, proof_inf);
+}
+
+// Two proofs in flight (tickets 0 and 1): begin(i + 1) may be called before end(i), so that the next proof's transforms
+// and sorts start while the previous proof's last reduction, host finish and assembly are still running.  crs and the
+// device inputs must stay valid until the matching end.
+int kg_groth16_prove_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
+                           const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
+                           const uint64_t* s, int ticket) {
+  if (!ctx || ticket < 0 || ticket > 1 || job_of(ctx, ticket)->active) return KG_ERR_BAD_ARG;
+  return prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job_of(ctx, ticket), 8 * ticket);
+}
+int kg_groth16_prove_end(kg_ctx* ctx, int ticket, uint64_t* proof_out, uint8_t* proof_inf) {
+  if (!ctx || ticket < 0 || ticket > 1 || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
+  return prove_collect(job_of(ctx, ticket), proof_out, proof_inf);
 }
 
 }  // extern "C"

@@ -1051,7 +1051,7 @@ int msm_run_t(kg_ctx* ctx, const MsmSorted& S, const uint64_t* d_bases, const ui
   // two reduction queues, by slot parity: a long reduction (G2: ~4x a G1 one) does not hold up the next MSM's
   hipStream_t st = ctx->stream, side = (slot & 1) ? ctx->side2_stream : ctx->side_stream;
   // this buffer set was last used by slot (slot - 2): its side-stream work must be over before we overwrite it
-  for (int s2 = 0; s2 < 8; ++s2)
+  for (int s2 = 0; s2 < kg_ctx::NSLOTS; ++s2)
     if (s2 % kg_ctx::RUN_SETS == set && ctx->slots[s2].done && ctx->slots[s2].busy) { KG_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[s2].done, 0)); ctx->slots[s2].busy = false; }
   if (!reg_pb) {
     PhaseScope ph(ctx, "prep_bases");

@@ -21,7 +21,7 @@ EXPORTS = [
     "kg_ctx_sync", "kg_malloc", "kg_free", "kg_memcpy_h2d", "kg_memcpy_d2h", "kg_memcpy_d2d", "kg_field_vec_op",
     "kg_field_vec_scale", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_msm", "kg_msm_host", "kg_commit",
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
-    "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister",
+    "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
 ]
 
 
@@ -233,6 +233,23 @@ class Context:
         if rc == -6:
             raise ProverSubVersionCrsAttack("delta is the identity")
         self._chk(rc, "kg_groth16_prove_bn254")
+        return out[:8].copy(), out[8:24].copy(), out[24:].copy(), inf
+
+    def groth16_prove_begin(self, crs: "Groth16Crs", a_eval: int, b_eval: int, c_eval: int, x: int, w: int, r: np.ndarray, s: np.ndarray, ticket: int):
+        """kg_groth16_prove_begin: enqueue a proof (ticket 0 or 1); crs and the device inputs stay alive until the end."""
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        s = np.ascontiguousarray(s, dtype=np.uint64)
+        rc = self._lib.kg_groth16_prove_begin(self._h, C.byref(crs), _vp(a_eval), _vp(b_eval), _vp(c_eval), _vp(x), _vp(w),
+                                              r.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), int(ticket))
+        self._chk(rc, "kg_groth16_prove_begin")
+
+    def groth16_prove_end(self, ticket: int):
+        out = np.zeros(32, dtype=np.uint64)
+        inf = np.zeros(3, dtype=np.uint8)
+        rc = self._lib.kg_groth16_prove_end(self._h, int(ticket), out.ctypes.data_as(C.c_void_p), inf.ctypes.data_as(C.c_void_p))
+        if rc == -6:
+            raise ProverSubVersionCrsAttack("delta is the identity")
+        self._chk(rc, "kg_groth16_prove_end")
         return out[:8].copy(), out[8:24].copy(), out[24:].copy(), inf
 
     def profile_enable(self, on: bool = True):

@@ -135,3 +135,34 @@ def test_device_setup_matches_oracle_and_proves(ctx, oracle, m):
     proof = K.Prover(got, cs.m, cs.l, cs.m_l_1, ctx=ctx).create_proof(a, b, c, cs.x, cs.w, r, s)
     ref = O.groth16_prove(cs, want, r, s, evals=(a, b, c))
     assert all((g == w_).all() for g, w_ in zip(proof[:3], ref[:3]))
+
+
+def test_groth16_two_proofs_in_flight_match_blocking_calls(ctx, oracle):
+    """kg_groth16_prove_begin / _end with two proofs in flight (different witnesses and blinding scalars, alternating
+    tickets) return exactly the proofs of the blocking call; an identity delta surfaces at the matching _end."""
+    import kogarashi_amd as K
+    from kogarashi_amd.lib import ProverSubVersionCrsAttack
+    O = oracle
+    m = 300
+    css = [O.chain_r1cs(m, O.gen_scalars(0, SEED + 450 + j, 0, 1)[0]) for j in range(5)]
+    full = O.groth16_params(css[0], O.gen_scalars(0, SEED + 451, 0, 5), threads=8)
+    params = dict(full)
+    params["vk_g2"] = full["vk_g2"][:2]
+    prover = K.Prover(params, css[0].m, css[0].l, css[0].m_l_1, ctx=ctx)
+    jobs = []
+    for j, cs in enumerate(css):
+        a, b, c = cs.evaluate()
+        r, s = O.gen_scalars(0, SEED + 460 + j, 0, 2)
+        jobs.append((a, b, c, cs.x, cs.w, r, s))
+    want = [prover.create_proof(*job) for job in jobs]
+    got = list(prover.create_proofs(jobs))
+    assert len(got) == len(want)
+    for g, w_ in zip(got, want):
+        for k in range(4):
+            assert (g[k] == w_[k]).all()
+    # the oracle agrees with the first one (the blocking path is compared in test_groth16_proof_matches_oracle)
+    ref = O.groth16_prove(css[0], full, jobs[0][5], jobs[0][6], evals=jobs[0][:3])
+    assert all((got[0][k] == ref[k]).all() for k in range(3))
+    bad = dict(params); bad["delta_g1_inf"] = 1
+    with pytest.raises(ProverSubVersionCrsAttack):
+        list(K.Prover(bad, css[0].m, css[0].l, css[0].m_l_1, ctx=ctx).create_proofs(jobs[:2]))

@@ -10,4 +10,4 @@ st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st); ctx.set_stream(st
 for c in [int(a) for a in sys.argv[2:]]:
     ctx.set_msm_window(c)
     out = bench.bench_groth16(ctx, torch, dev, K, int(sys.argv[1]), steps=10, cpu=False)
-    print(c, round(out["ms_per_proof"], 3), flush=True)
+    print(c, "pipelined", round(out["ms_per_proof"], 3), "blocking", round(out.get("ms_per_proof_blocking", 0), 3), flush=True)
