@@ -24,7 +24,7 @@ struct kg_ctx {
   size_t ws2_bytes = 0;
   void* ws3 = nullptr;                   // prover polynomial buffers
   size_t ws3_bytes = 0;
-  static constexpr int RUN_SETS = 4;     // a slow reduction (G2) may overlap the next TWO accumulations
+  static constexpr int RUN_SETS = 8;     // a slow reduction (G2) may overlap all the later accumulations of a proof
   void* ws_run[RUN_SETS] = {};           // MSM base-side scratch (packed bases, partial sums, halving buffers), one set per slot mod RUN_SETS
   size_t ws_run_bytes[RUN_SETS] = {};
   hipStream_t side_stream = nullptr;     // bucket reduction of MSM i overlaps the accumulation of MSM i+1
@@ -180,6 +180,9 @@ struct MsmSorted {
 int ntt_prepare(kg_ctx* ctx, uint32_t log_n, int inverse);
 int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, uint32_t log_n, int inverse, int coset);
 int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S);
+// several base arrays against one scalar sort, accumulated by one launch (at most 3; result slots in distinct run-space sets)
+struct MsmRunJob { const uint64_t* d_bases; const uint8_t* d_inf; size_t nbases; uint32_t idx_off; int slot; };
+int msm_run_multi(kg_ctx* ctx, const MsmSorted& S, int curve, const MsmRunJob* jobs, int njobs);
 int msm_run(kg_ctx* ctx, const MsmSorted& S, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, uint32_t idx_off, int slot);
 int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz);
 void msm_identity(int curve, uint64_t* out_xyz);

@@ -728,14 +728,32 @@ __device__ __forceinline__ void locate_task(const Level& L, int W, int B, uint32
   seg = x - rel[b];
 }
 
-// round 1: lists of (base index | sign) -> partial XYZZ per task; lane p runs the p-th longest task
+// round 1: lists of (base index | sign) -> partial XYZZ per task; lane p runs the p-th longest task.
+// Up to MAX_FUSED base arrays that share one scalar sort (the prover's a, b_g1 and l queries against z) are accumulated
+// by ONE launch, waves dealt to the arrays in turn: with a single array a 2^18-pair MSM has 4352 waves for 4096 resident
+// wave slots -- one round, no refill, and a tail at one wave per SIMD (69 % of the four-wave issue rate); three arrays
+// make 3.2 rounds (measured: 10.2 -> 13 G additions/s).
+constexpr int MAX_FUSED = 3;
+struct AccSets {
+  int nsets;
+  const uint32_t* pb[MAX_FUSED];      // packed bases of each array
+  uint32_t idx_off[MAX_FUSED];        // scalars in front of the array (shared sort, z = x || w)
+  uint32_t* partial[MAX_FUSED];       // partial sums, one per task
+};
 template <class F>
-__global__ void __launch_bounds__(64) k_acc_tasks(const uint32_t* __restrict__ pbases, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(64) k_acc_tasks(AccSets A, const uint32_t* __restrict__ sorted,
                                                   const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bsize, Level L,
                                                   const uint32_t* __restrict__ task_bkt, const uint32_t* __restrict__ task_id,
-                                                  size_t n, int W, int B, uint32_t T, uint32_t idx_off, uint32_t* __restrict__ partial, size_t pstride) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+                                                  size_t n, int W, int B, uint32_t T, size_t pstride) {
+  const int set = A.nsets > 1 ? (int)(blockIdx.x % (unsigned)A.nsets) : 0;
+  const uint32_t p = (A.nsets > 1 ? blockIdx.x / (unsigned)A.nsets : blockIdx.x) * blockDim.x + threadIdx.x;
   if (p >= L.base[W]) return;
+  const uint32_t* __restrict__ pbases = A.pb[0];
+  uint32_t idx_off = A.idx_off[0];
+  uint32_t* __restrict__ partial = A.partial[0];
+#pragma unroll
+  for (int k = 1; k < MAX_FUSED; ++k)
+    if (set == k) { pbases = A.pb[k]; idx_off = A.idx_off[k]; partial = A.partial[k]; }
   const size_t bi = task_bkt[p];
   const uint32_t t = task_id[p];
   const int w = (int)(bi / B);
@@ -1011,113 +1029,140 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   return KG_OK;
 }
 
-// Base-side half: accumulate + reduce against one base array, export, and start the copy into host slot `slot`.
+// Base-side half: accumulate + reduce against up to MAX_FUSED base arrays that share the scalar sort S, export, and start
+// the copy of each result into its host slot.  One accumulation launch serves all arrays (see k_acc_tasks); everything
+// after it runs per array, its reduction on one of the two side queues.
+struct RunJob { const uint64_t* d_bases; const uint8_t* d_inf; size_t nbases; uint32_t idx_off; int slot; };
+
 template <class Cfg>
-int msm_run_t(kg_ctx* ctx, const MsmSorted& S, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, uint32_t idx_off, int slot) {
+int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njobs) {
   using F = typename Cfg::F;
   constexpr int PW = 2 * BaseIO<F>::W;              // packed words per base
   constexpr int NW = PointIO<F>::NW;                // raw words per XYZZ point
+  if (njobs < 1 || njobs > MAX_FUSED) return set_err(ctx, KG_ERR_BAD_ARG, "bad number of fused base arrays");
   const int W = S.W, B = S.B, c = S.c;
   const size_t npts = S.npts, part_cap = S.part_cap, nexp = (size_t)W * c;
-  Carver cv;
-  // bases inside a registered array are already in packed internal form
-  const uint32_t* reg_pb = nullptr;
-  for (const auto& r : ctx->registered) {
-    if (r.curve != Cfg::ID || d_bases < r.base) continue;
-    const size_t off64 = (size_t)(d_bases - r.base);
-    if (off64 % (size_t)BaseIO<F>::W == 0 && off64 / BaseIO<F>::W + nbases <= r.n) { reg_pb = r.packed + (off64 / BaseIO<F>::W) * PW; break; }
-  }
-  const size_t o_pb = cv.take(reg_pb ? 256 : nbases * PW * 4);
-  size_t o_lc[2], o_lr[2], o_lb[2], o_part[2], o_pbuf[2];
-  for (int i = 0; i < 2; ++i) {
-    o_lc[i] = cv.take(npts * 4); o_lr[i] = cv.take(npts * 4); o_lb[i] = cv.take((size_t)(W + 1) * 4);
-    o_part[i] = cv.take(part_cap * NW * 4); o_pbuf[i] = cv.take(npts * NW * 4);
-  }
-  const size_t o_rowtot = cv.take((size_t)W * 4), o_misc = cv.take(64);
   const size_t exp_bytes = nexp * 4 * Cfg::E64 * 8;
-  const size_t o_exp = cv.take(exp_bytes);
-  const int set = slot % kg_ctx::RUN_SETS;          // run space per set: the reductions of the previous MSMs may still read the other sets
-  KG_TRY(ensure_ws_run(ctx, set, cv.off));
-  KG_TRY(ensure_slot(ctx, slot, exp_bytes));
+  hipStream_t st = ctx->stream;
   if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
-  if (!ctx->ev_acc[set]) KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_acc[set], hipEventDisableTiming));
-  char* ws = (char*)ctx->ws_run[set];
-  const uint32_t* pb = reg_pb ? reg_pb : (uint32_t*)(ws + o_pb);
-  uint32_t* part[2] = {(uint32_t*)(ws + o_part[0]), (uint32_t*)(ws + o_part[1])};
-  uint32_t* pbuf[2] = {(uint32_t*)(ws + o_pbuf[0]), (uint32_t*)(ws + o_pbuf[1])};
-  uint32_t* rowtot = (uint32_t*)(ws + o_rowtot);
-  uint32_t* misc = (uint32_t*)(ws + o_misc);
-  uint64_t* d_exp = (uint64_t*)(ws + o_exp);
-  // two reduction queues, by slot parity: a long reduction (G2: ~4x a G1 one) does not hold up the next MSM's
-  hipStream_t st = ctx->stream, side = (slot & 1) ? ctx->side2_stream : ctx->side_stream;
-  // this buffer set was last used by slot (slot - 2): its side-stream work must be over before we overwrite it
-  for (int s2 = 0; s2 < kg_ctx::NSLOTS; ++s2)
-    if (s2 % kg_ctx::RUN_SETS == set && ctx->slots[s2].done && ctx->slots[s2].busy) { KG_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[s2].done, 0)); ctx->slots[s2].busy = false; }
-  if (!reg_pb) {
-    PhaseScope ph(ctx, "prep_bases");
-    hipLaunchKernelGGL(k_prep_bases<F>, dim3((unsigned)((nbases + 255) / 256)), dim3(256), 0, st, d_bases, d_inf, nbases, (uint32_t*)(ws + o_pb));
-    ph.end();
+  struct Lay { size_t o_pb, o_lc[2], o_lr[2], o_lb[2], o_part[2], o_pbuf[2], o_rowtot, o_misc, o_exp; char* ws; const uint32_t* pb; int set; };
+  Lay lay[MAX_FUSED];
+  AccSets A;
+  A.nsets = njobs;
+  for (int k = 0; k < MAX_FUSED; ++k) { A.pb[k] = nullptr; A.idx_off[k] = 0; A.partial[k] = nullptr; }
+  for (int k = 0; k < njobs; ++k) {
+    const RunJob& J = jobs[k];
+    Lay& Y = lay[k];
+    Carver cv;
+    const uint32_t* reg_pb = nullptr;               // bases inside a registered array are already in packed internal form
+    for (const auto& r : ctx->registered) {
+      if (r.curve != Cfg::ID || J.d_bases < r.base) continue;
+      const size_t off64 = (size_t)(J.d_bases - r.base);
+      if (off64 % (size_t)BaseIO<F>::W == 0 && off64 / BaseIO<F>::W + J.nbases <= r.n) { reg_pb = r.packed + (off64 / BaseIO<F>::W) * PW; break; }
+    }
+    Y.o_pb = cv.take(reg_pb ? 256 : J.nbases * PW * 4);
+    for (int i = 0; i < 2; ++i) {
+      Y.o_lc[i] = cv.take(npts * 4); Y.o_lr[i] = cv.take(npts * 4); Y.o_lb[i] = cv.take((size_t)(W + 1) * 4);
+      Y.o_part[i] = cv.take(part_cap * NW * 4); Y.o_pbuf[i] = cv.take(npts * NW * 4);
+    }
+    Y.o_rowtot = cv.take((size_t)W * 4); Y.o_misc = cv.take(64);
+    Y.o_exp = cv.take(exp_bytes);
+    Y.set = J.slot % kg_ctx::RUN_SETS;              // run space per set: the reductions of the previous MSMs may still read the other sets
+    for (int k2 = 0; k2 < k; ++k2)
+      if (lay[k2].set == Y.set) return set_err(ctx, KG_ERR_BAD_ARG, "fused MSMs need result slots in different run-space sets");
+    KG_TRY(ensure_ws_run(ctx, Y.set, cv.off));
+    KG_TRY(ensure_slot(ctx, J.slot, exp_bytes));
+    if (!ctx->ev_acc[Y.set]) KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_acc[Y.set], hipEventDisableTiming));
+    Y.ws = (char*)ctx->ws_run[Y.set];
+    Y.pb = reg_pb ? reg_pb : (uint32_t*)(Y.ws + Y.o_pb);
+    // this buffer set was last used by an earlier slot: its side-stream work must be over before we overwrite it
+    for (int s2 = 0; s2 < kg_ctx::NSLOTS; ++s2)
+      if (s2 % kg_ctx::RUN_SETS == Y.set && ctx->slots[s2].done && ctx->slots[s2].busy) { KG_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[s2].done, 0)); ctx->slots[s2].busy = false; }
+    if (!reg_pb) {
+      PhaseScope ph(ctx, "prep_bases");
+      hipLaunchKernelGGL(k_prep_bases<F>, dim3((unsigned)((J.nbases + 255) / 256)), dim3(256), 0, st, J.d_bases, J.d_inf, J.nbases, (uint32_t*)(Y.ws + Y.o_pb));
+      ph.end();
+    }
+    A.pb[k] = Y.pb; A.idx_off[k] = J.idx_off; A.partial[k] = (uint32_t*)(Y.ws + Y.o_part[0]);
   }
-  Level L{S.lcnt, S.lrel, S.lbase};
-  int pcur = 0;
-  {
+  const Level L0{S.lcnt, S.lrel, S.lbase};
+  if (S.ntasks) {
     PhaseScope ph(ctx, "accumulate");
-    if (S.ntasks)
-      hipLaunchKernelGGL(k_acc_tasks<F>, dim3((S.ntasks + 63) / 64), dim3(64), 0, st, pb, S.sorted, S.bstart, S.bsize, L, S.task_bkt, S.task_id,
-                         S.n, W, B, S.T, idx_off, part[0], part_cap);
-    // skewed inputs: re-sum a bucket's partial sums until it owns one point
-    uint32_t max_cnt = S.max_cnt;
-    int lv = -1;                                     // -1: level arrays of S; 0/1: local ping-pong
-    const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
-    while (max_cnt > 1) {
-      const int nx = lv < 0 ? 0 : (lv ^ 1);
-      uint32_t* ncnt = (uint32_t*)(ws + o_lc[nx]);
-      uint32_t* nrel = (uint32_t*)(ws + o_lr[nx]);
-      uint32_t* nbase = (uint32_t*)(ws + o_lb[nx]);
-      KG_HIP(ctx, hipMemsetAsync(misc, 0, 64, st));
-      hipLaunchKernelGGL(k_task_count, dim3(g1024), dim3(1024), 0, st, L.cnt, npts, S.T2, ncnt, misc + 8);
-      hipLaunchKernelGGL(k_scan_rows, dim3(W), dim3(1024), 0, st, ncnt, B, nrel, rowtot);
-      hipLaunchKernelGGL(k_row_bases, dim3(1), dim3(64), 0, st, rowtot, W, nbase, (const uint32_t*)nullptr, misc + 4);
-      Level Lout{ncnt, nrel, nbase};
-      // the task count of this round is bounded by the previous one; threads beyond base[W] exit
-      const uint32_t bound = lv < 0 ? S.ntasks : (uint32_t)part_cap;
-      hipLaunchKernelGGL(k_sum_tasks<F>, dim3((bound + 63) / 64), dim3(64), 0, st, part[pcur], part_cap, L, Lout, W, B, S.T2, part[pcur ^ 1], part_cap);
-      pcur ^= 1;
-      L = Lout;
-      lv = nx;
-      max_cnt = (max_cnt + S.T2 - 1) / S.T2;
-    }
-    hipLaunchKernelGGL(k_gather_buckets<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, part[pcur], part_cap, L, W, B, pbuf[0]);
+    hipLaunchKernelGGL(k_acc_tasks<F>, dim3(((S.ntasks + 63) / 64) * (unsigned)njobs), dim3(64), 0, st, A, S.sorted, S.bstart, S.bsize, L0, S.task_bkt, S.task_id,
+                       S.n, W, B, S.T, part_cap);
     ph.end();
   }
-  // the bucket reduction is a chain of c-1 latency-bound launches: it runs on the side stream so that the next MSM's
-  // accumulation (main stream, other buffer set) fills the chip meanwhile
-  KG_HIP(ctx, hipEventRecord(ctx->ev_acc[set], st));
-  KG_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_acc[set], 0));
-  int cur = 0;
-  {
-    PhaseScope ph(ctx, "reduce", side);
-    size_t in_stride = npts;                     // level 0 reads the bucket array: stride = W*B items
-    int narr = 1;
-    for (uint32_t n_out = (uint32_t)B / 2; n_out >= 1; n_out /= 2) {
-      const size_t tasks = (size_t)W * narr * n_out;
-      const size_t out_stride = (size_t)W * (narr + 1) * n_out;
-      hipLaunchKernelGGL(k_halve<F>, dim3((unsigned)((tasks + 63) / 64)), dim3(64), 0, side, pbuf[cur], in_stride, pbuf[cur ^ 1], out_stride,
-                         W, narr, n_out);
-      cur ^= 1;
-      in_stride = out_stride;
-      ++narr;
-      if (n_out == 1) break;
+  for (int k = 0; k < njobs; ++k) {
+    const RunJob& J = jobs[k];
+    const Lay& Y = lay[k];
+    const int slot = J.slot, set = Y.set;
+    char* ws = Y.ws;
+    const size_t* o_lc = Y.o_lc; const size_t* o_lr = Y.o_lr; const size_t* o_lb = Y.o_lb;
+    uint32_t* part[2] = {(uint32_t*)(ws + Y.o_part[0]), (uint32_t*)(ws + Y.o_part[1])};
+    uint32_t* pbuf[2] = {(uint32_t*)(ws + Y.o_pbuf[0]), (uint32_t*)(ws + Y.o_pbuf[1])};
+    uint32_t* rowtot = (uint32_t*)(ws + Y.o_rowtot);
+    uint32_t* misc = (uint32_t*)(ws + Y.o_misc);
+    uint64_t* d_exp = (uint64_t*)(ws + Y.o_exp);
+    // two reduction queues, by slot parity: a long reduction (G2: ~4x a G1 one) does not hold up the next MSM's
+    hipStream_t side = (slot & 1) ? ctx->side2_stream : ctx->side_stream;
+    Level L = L0;
+    int pcur = 0;
+    {
+      PhaseScope ph(ctx, "gather");
+      // skewed inputs: re-sum a bucket's partial sums until it owns one point
+      uint32_t max_cnt = S.max_cnt;
+      int lv = -1;                                     // -1: level arrays of S; 0/1: local ping-pong
+      const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
+      while (max_cnt > 1) {
+        const int nx = lv < 0 ? 0 : (lv ^ 1);
+        uint32_t* ncnt = (uint32_t*)(ws + o_lc[nx]);
+        uint32_t* nrel = (uint32_t*)(ws + o_lr[nx]);
+        uint32_t* nbase = (uint32_t*)(ws + o_lb[nx]);
+        KG_HIP(ctx, hipMemsetAsync(misc, 0, 64, st));
+        hipLaunchKernelGGL(k_task_count, dim3(g1024), dim3(1024), 0, st, L.cnt, npts, S.T2, ncnt, misc + 8);
+        hipLaunchKernelGGL(k_scan_rows, dim3(W), dim3(1024), 0, st, ncnt, B, nrel, rowtot);
+        hipLaunchKernelGGL(k_row_bases, dim3(1), dim3(64), 0, st, rowtot, W, nbase, (const uint32_t*)nullptr, misc + 4);
+        Level Lout{ncnt, nrel, nbase};
+        // the task count of this round is bounded by the previous one; threads beyond base[W] exit
+        const uint32_t bound = lv < 0 ? S.ntasks : (uint32_t)part_cap;
+        hipLaunchKernelGGL(k_sum_tasks<F>, dim3((bound + 63) / 64), dim3(64), 0, st, part[pcur], part_cap, L, Lout, W, B, S.T2, part[pcur ^ 1], part_cap);
+        pcur ^= 1;
+        L = Lout;
+        lv = nx;
+        max_cnt = (max_cnt + S.T2 - 1) / S.T2;
+      }
+      hipLaunchKernelGGL(k_gather_buckets<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, part[pcur], part_cap, L, W, B, pbuf[0]);
+      ph.end();
     }
-    // now: W windows x narr (= c) single points, stride W*c
-    hipLaunchKernelGGL((k_export<F, Cfg::E64>), dim3((unsigned)((nexp + 63) / 64)), dim3(64), 0, side, pbuf[cur], nexp, nexp, d_exp);
-    ph.end();
+    // the bucket reduction is a chain of c-1 latency-bound launches: it runs on the side stream so that the next MSM's
+    // accumulation (main stream, other buffer set) fills the chip meanwhile
+    KG_HIP(ctx, hipEventRecord(ctx->ev_acc[set], st));
+    KG_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_acc[set], 0));
+    int cur = 0;
+    {
+      PhaseScope ph(ctx, "reduce", side);
+      size_t in_stride = npts;                     // level 0 reads the bucket array: stride = W*B items
+      int narr = 1;
+      for (uint32_t n_out = (uint32_t)B / 2; n_out >= 1; n_out /= 2) {
+        const size_t tasks = (size_t)W * narr * n_out;
+        const size_t out_stride = (size_t)W * (narr + 1) * n_out;
+        hipLaunchKernelGGL(k_halve<F>, dim3((unsigned)((tasks + 63) / 64)), dim3(64), 0, side, pbuf[cur], in_stride, pbuf[cur ^ 1], out_stride,
+                           W, narr, n_out);
+        cur ^= 1;
+        in_stride = out_stride;
+        ++narr;
+        if (n_out == 1) break;
+      }
+      // now: W windows x narr (= c) single points, stride W*c
+      hipLaunchKernelGGL((k_export<F, Cfg::E64>), dim3((unsigned)((nexp + 63) / 64)), dim3(64), 0, side, pbuf[cur], nexp, nexp, d_exp);
+      ph.end();
+    }
+    KG_HIP(ctx, hipGetLastError());
+    kg_ctx::Slot& sl = ctx->slots[slot];
+    KG_HIP(ctx, hipMemcpyAsync(sl.host, d_exp, exp_bytes, hipMemcpyDeviceToHost, side));
+    KG_HIP(ctx, hipEventRecord(sl.done, side));
+    sl.W = W; sl.c = c; sl.busy = true;
   }
-  KG_HIP(ctx, hipGetLastError());
-  kg_ctx::Slot& sl = ctx->slots[slot];
-  KG_HIP(ctx, hipMemcpyAsync(sl.host, d_exp, exp_bytes, hipMemcpyDeviceToHost, side));
-  KG_HIP(ctx, hipEventRecord(sl.done, side));
-  sl.W = W; sl.c = c; sl.busy = true;
   return KG_OK;
 }
 
@@ -1148,13 +1193,20 @@ int msm_finish_t(kg_ctx* ctx, int slot, uint64_t* out_xyz) {
   return KG_OK;
 }
 
-int msm_run(kg_ctx* ctx, const MsmSorted& S, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, uint32_t idx_off, int slot) {
+int msm_run_multi(kg_ctx* ctx, const MsmSorted& S, int curve, const MsmRunJob* jobs, int njobs) {
+  RunJob rj[MAX_FUSED];
+  if (njobs < 1 || njobs > MAX_FUSED) return KG_ERR_BAD_ARG;
+  for (int k = 0; k < njobs; ++k) rj[k] = RunJob{jobs[k].d_bases, jobs[k].d_inf, jobs[k].nbases, jobs[k].idx_off, jobs[k].slot};
   switch (curve) {
-    case KG_G1: return msm_run_t<G1Cfg>(ctx, S, d_bases, d_inf, nbases, idx_off, slot);
-    case KG_GRUMPKIN: return msm_run_t<GkCfg>(ctx, S, d_bases, d_inf, nbases, idx_off, slot);
-    case KG_G2: return msm_run_t<G2Cfg>(ctx, S, d_bases, d_inf, nbases, idx_off, slot);
+    case KG_G1: return msm_run_multi_t<G1Cfg>(ctx, S, rj, njobs);
+    case KG_GRUMPKIN: return msm_run_multi_t<GkCfg>(ctx, S, rj, njobs);
+    case KG_G2: return msm_run_multi_t<G2Cfg>(ctx, S, rj, njobs);
     default: return KG_ERR_BAD_ARG;
   }
+}
+int msm_run(kg_ctx* ctx, const MsmSorted& S, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, uint32_t idx_off, int slot) {
+  const MsmRunJob j{d_bases, d_inf, nbases, idx_off, slot};
+  return msm_run_multi(ctx, S, curve, &j, 1);
 }
 int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz) {
   switch (curve) {
