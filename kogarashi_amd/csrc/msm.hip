@@ -740,8 +740,12 @@ struct AccSets {
   uint32_t idx_off[MAX_FUSED];        // scalars in front of the array (shared sort, z = x || w)
   uint32_t* partial[MAX_FUSED];       // partial sums, one per task
 };
+// G2: the compiler lands on 256 VGPRs + 1 AGPR = one wave per SIMD; asking for two waves costs a few spilled registers
+// and buys the second wave (the issue rate of this code at one wave per SIMD is ~69 % of its rate at four)
+template <class F> struct AccWaves { static constexpr int MIN = 1; };
+template <class G> struct AccWaves<Fp2<G>> { static constexpr int MIN = 2; };
 template <class F>
-__global__ void __launch_bounds__(64) k_acc_tasks(AccSets A, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::MIN))) k_acc_tasks(AccSets A, const uint32_t* __restrict__ sorted,
                                                   const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bsize, Level L,
                                                   const uint32_t* __restrict__ task_bkt, const uint32_t* __restrict__ task_id,
                                                   size_t n, int W, int B, uint32_t T, size_t pstride) {

@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libkogarashi_amd.so")
+SO_PATH = os.environ.get("KG_LIB_PATH", SO_PATH)     # A/B experiments: an alternative build of the same ABI
 
 KG_FR, KG_FQ = 0, 1
 KG_G1, KG_GRUMPKIN, KG_G2 = 0, 1, 2
