@@ -54,12 +54,21 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # KG_BENCH_SELFTEST=1: control-flow check of this N > 1 path on a ONE-GPU box -- every rank uses cuda:0 and the
+        # exchange goes over gloo with host tensors (RCCL refuses two ranks on one device).  Never a measurement.
+        selftest = os.environ.get("KG_BENCH_SELFTEST") == "1"
+        if selftest:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if selftest:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
         local_rank = 0
     dev = torch.device("cuda", local_rank)
+    xdev = None if (world > 1 and os.environ.get("KG_BENCH_SELFTEST") == "1") else dev     # where exchanged tensors live
     n = 1 << args.log_n
 
     ctx = K.Context(local_rank)
@@ -85,7 +94,7 @@ def main():
         xy, inf = out[:8], int(not out[8:].any())
         if world > 1:
             # exchange step: one all_gather of 9 words per rank over RCCL, every rank adds the partial sums
-            xy, inf = kdist.combine_partials(ctx, K.KG_G1, xy, inf, device=dev)
+            xy, inf = kdist.combine_partials(ctx, K.KG_G1, xy, inf, device=xdev)
         return xy, inf
 
     def run(k):
@@ -116,7 +125,7 @@ def main():
     acc_avg_ms = summary["accumulate"][0] / summary["accumulate"][1]
     phase_avg = {k_: v_[0] / v_[1] for k_, v_ in summary.items()}
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev if xdev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
