@@ -35,7 +35,7 @@ struct kg_tw_cache {
 namespace {
 
 constexpr int TILE = 2048;            // elements per workgroup tile
-constexpr int NT = 256;               // threads per workgroup
+constexpr int NT = 512;               // threads per workgroup: one radix-4 group per lane on a 2048-element tile (92-96 VGPRs)
 constexpr int SMALL_LOG = 10;         // largest in-LDS DFT: 2^10
 
 __device__ __forceinline__ Fr ld_tw(const uint32_t* __restrict__ tab, size_t e) {
@@ -211,8 +211,8 @@ __global__ void __launch_bounds__(NT, 2) k_ntt_step(StepArgs A) {
   }
   __syncthreads();
 
-  // ---- log2(m) radix-2 DIT stages (butterfly_arithmetic, fft.rs:195-218), three at a time in registers: one lane
-  // owns the 8 elements that differ in index bits [s0, s0+3), so a tile makes 3 LDS round trips and 3 barriers instead
+  // ---- log2(m) radix-2 DIT stages (butterfly_arithmetic, fft.rs:195-218), two at a time in registers: one lane
+  // owns the 4 elements that differ in index bits [s0, s0+2), so a tile makes 4 LDS round trips and 4 barriers instead
   // of 8; twiddles w_m^e (e < m/2) sit in LDS behind the tile when m <= 256
   uint32_t* twl = lds + LDS_TILE_WORDS;
   const bool tw_in_lds = A.log_m <= 8;
@@ -227,9 +227,10 @@ __global__ void __launch_bounds__(NT, 2) k_ntt_step(StepArgs A) {
   }
   for (uint32_t s0 = 0; s0 < A.log_m;) {
     const uint32_t left = A.log_m - s0;
-    const uint32_t g = left >= 3 ? (left == 4 ? 2 : 3) : left;       // 8 -> 3,3,2; 7 -> 3,2,2; 4 -> 2,2
-    if (g == 3) radix_pass<ROW, 3>(lds, twl, tw_in_lds, A, s0);
-    else if (g == 2) radix_pass<ROW, 2>(lds, twl, tw_in_lds, A, s0);
+    // radix-4 register passes (8 -> 2,2,2,2; 7 -> 2,2,2,1): with radix-8 passes only 256 lanes of a 2048-element tile have
+    // work and the kernel needs 210 VGPRs (two waves per SIMD); radix-4 keeps 512 lanes busy at four waves per SIMD
+    const uint32_t g = left >= 2 ? 2 : left;
+    if (g == 2) radix_pass<ROW, 2>(lds, twl, tw_in_lds, A, s0);
     else radix_pass<ROW, 1>(lds, twl, tw_in_lds, A, s0);
     __syncthreads();
     s0 += g;
