@@ -1,0 +1,21 @@
+"""Forward NTT time against log n:  python tools/dbg/ntt_sizes.py 14 16 18 20 22"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import kogarashi_amd as K
+SEED = 0x4B6F676172617368
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+ctx = K.Context(0)
+st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st); ctx.set_stream(st.cuda_stream)
+for lg in [int(a) for a in sys.argv[1:]]:
+    n = 1 << lg
+    v = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    ctx.gen_scalars(K.KG_FR, SEED + lg, 0, n, v.data_ptr())
+    for _ in range(3): ctx.ntt(v.data_ptr(), lg, False, False)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): ctx.ntt(v.data_ptr(), lg, False, False)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print(f"ntt 2^{lg}: {ms*1e3:.1f} us  {n/ms/1e6:.2f} G elements/s", flush=True)
