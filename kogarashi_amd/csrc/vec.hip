@@ -19,13 +19,17 @@ __global__ void __launch_bounds__(256) k_vec_op(int op, const uint64_t* __restri
   const bool binary = (op == KG_OP_ADD || op == KG_OP_SUB || op == KG_OP_MUL);
   if (binary) load_words(b, i, wb);
   using F = Fp<P>;
+  // The linear ops never leave the caller's Montgomery domain (a*R + b*R = (a+b)*R): re-pack, lazy add / fat subtract,
+  // one value reduction, canonicalise.  A product needs one extra constant product: mont'(aR, bR) = ab*R^2/2^261, and
+  // mont'(., 2^522/R) brings it back to ab*R.
+  const F A = limbs_from_words<P>(wa);
   switch (op) {
-    case KG_OP_ADD: to_ref(norm(add(from_ref<P>(wa), from_ref<P>(wb))), wo); break;
-    case KG_OP_SUB: to_ref(norm(sub<4, 1>(from_ref<P>(wa), from_ref<P>(wb))), wo); break;
-    case KG_OP_MUL: to_ref(mul(from_ref<P>(wa), from_ref<P>(wb)), wo); break;
-    case KG_OP_SQUARE: to_ref(sqr(from_ref<P>(wa)), wo); break;
-    case KG_OP_NEG: to_ref(norm(sub<4, 1>(F::zero(), from_ref<P>(wa))), wo); break;
-    case KG_OP_DOUBLE: to_ref(norm(dbl(from_ref<P>(wa))), wo); break;
+    case KG_OP_ADD: words_from_limbs(reduce_2p(vred(norm(add(A, limbs_from_words<P>(wb))))), wo); break;
+    case KG_OP_SUB: words_from_limbs(reduce_2p(vred(norm(sub<8, 1>(A, limbs_from_words<P>(wb))))), wo); break;
+    case KG_OP_MUL: words_from_limbs(reduce_2p(mul(mul(A, limbs_from_words<P>(wb)), F::from_const(P::C_FROM_REF))), wo); break;
+    case KG_OP_SQUARE: words_from_limbs(reduce_2p(mul(sqr(A), F::from_const(P::C_FROM_REF))), wo); break;
+    case KG_OP_NEG: words_from_limbs(reduce_2p(vred(norm(sub<8, 1>(F::zero(), A)))), wo); break;
+    case KG_OP_DOUBLE: words_from_limbs(reduce_2p(vred(norm(dbl(A)))), wo); break;
     case KG_OP_INVERT: to_ref(inv(from_ref<P>(wa)), wo); break;
     case KG_OP_FROM_MONT: ref_to_int<P>(wa, wo); break;
     case KG_OP_TO_MONT: int_to_ref<P>(wa, wo); break;
