@@ -361,3 +361,43 @@ def test_combine_partials_over_rccl_single_rank(ctx, oracle):
         assert inf
     finally:
         dist.destroy_process_group()
+
+
+def test_msm_randomised_configurations(ctx, oracle):
+    """Seeded sweep over (curve, n, forced window, scalar mix, identity density, duplicate density): 60 small MSMs against
+    the oracle.  Scalar mixes: uniform, small (< 2^20), near the group order (p - small), powers of two, 0/1-heavy --
+    they move the load between windows and hit the signed-digit borrow at every window boundary."""
+    O = oracle
+    rng = np.random.default_rng(20260101)
+    for case in range(60):
+        cv, curve, sfd = [("g1", 0, 0), ("gk", 1, 1)][int(rng.integers(0, 2))]
+        n = int(rng.choice([1, 2, 5, 17, 64, 100, 333, 1000, 2500, 4097]))
+        c = int(rng.choice([0, 0, 2, 3, 5, 8, 11, 13]))
+        bases = O.gen_bases(curve, SEED + 900 + case, 0, n)
+        scal = O.gen_scalars(sfd, SEED + 901 + case, 0, n)
+        mix = int(rng.integers(0, 5))
+        pm = O.f_consts(sfd)["p"]
+        for i in range(n):
+            if mix == 1:
+                v = int(rng.integers(0, 1 << 20))
+                scal[i] = O.f_to_mont(sfd, np.array([v, 0, 0, 0], dtype=np.uint64))
+            elif mix == 2:
+                v = pm.copy(); v[0] -= np.uint64(int(rng.integers(1, 1 << 16)))            # p - small
+                scal[i] = O.f_to_mont(sfd, v)
+            elif mix == 3:
+                e = int(rng.integers(0, 253))
+                v = np.zeros(4, dtype=np.uint64); v[e // 64] = np.uint64(1) << np.uint64(e % 64)
+                scal[i] = O.f_to_mont(sfd, v)
+            elif mix == 4 and rng.random() < 0.8:
+                scal[i] = O.f_to_mont(sfd, np.array([int(rng.integers(0, 2)), 0, 0, 0], dtype=np.uint64))
+        inf = (rng.random(n) < [0.0, 0.02, 0.3][int(rng.integers(0, 3))]).astype(np.uint8)
+        if n > 4 and rng.random() < 0.5:                   # duplicate points
+            dup = rng.integers(0, n, size=max(1, n // 10))
+            bases[dup] = bases[0]
+        want = aff(O, cv, O.msm(cv, bases, scal, inf, threads=8))
+        ctx.set_msm_window(c)
+        try:
+            got = gpu_aff(ctx.msm_host(curve, bases, inf, scal, n), 4)
+        finally:
+            ctx.set_msm_window(0)
+        assert got == want, (case, cv, n, c, mix)
