@@ -96,6 +96,8 @@ struct StepArgs {
   uint64_t mult;         // col flavour: twiddle exponent multiplier; 0 = no twiddle
   uint64_t n1;           // row flavour: i1 extent;  n2 = G / n1
   uint64_t G;            // number of independent DFTs (= n / m)
+  uint32_t log_inner, log_n1, log_G;   // inner, n1 and G are powers of two: index arithmetic is shifts and masks (a 64-bit
+                                       // division costs ~100 instructions, and there were five per element and step)
   uint32_t lo_bits;
   const uint32_t* tw_small;
   const uint32_t* tw_lo;
@@ -196,12 +198,12 @@ __global__ void __launch_bounds__(NT, 2) k_ntt_step(StepArgs A) {
     uint64_t addr;
     if (ROW) {
       r = idx & (m - 1); col = idx >> A.log_m;
-      const uint64_t g = g0 + col, i1 = g % A.n1, i2 = g / A.n1, n2 = A.G / A.n1;
-      addr = ((i1 * n2 + i2) << A.log_m) + r;
+      const uint64_t g = g0 + col, i1 = g & (A.n1 - 1), i2 = g >> A.log_n1;
+      addr = (((i1 << (A.log_G - A.log_n1)) + i2) << A.log_m) + r;
     } else {
       col = idx & (tc - 1); r = idx >> A.log_tc;
       const uint64_t g = g0 + col;
-      addr = (g / A.inner) * ((uint64_t)m * A.inner) + (uint64_t)r * A.inner + (g % A.inner);
+      addr = ((g >> A.log_inner) << (A.log_m + A.log_inner)) + ((uint64_t)r << A.log_inner) + (g & (A.inner - 1));
     }
     uint32_t w[8];
     load_words(A.in, addr, w);
@@ -244,20 +246,20 @@ __global__ void __launch_bounds__(NT, 2) k_ntt_step(StepArgs A) {
     Fr v;
     if (ROW) {
       col = idx & (tc - 1); r = idx >> A.log_tc;           // adjacent lanes -> adjacent i1 -> contiguous output
-      addr = (g0 + col) + A.G * (uint64_t)r;
+      addr = (g0 + col) + ((uint64_t)r << A.log_G);
       v = lds_load(lds, tile_index<ROW>(r, col, A.log_m, A.log_tc));
       if (A.scale_mode == 2) v = mul(v, two_level(A.cos_lo, A.cos_hi, A.lo_bits, addr));
       else v = vred(v);
     } else {
       col = idx & (tc - 1); r = idx >> A.log_tc;
       const uint64_t g = g0 + col;
-      addr = (g / A.inner) * ((uint64_t)m * A.inner) + (uint64_t)r * A.inner + (g % A.inner);
+      addr = ((g >> A.log_inner) << (A.log_m + A.log_inner)) + ((uint64_t)r << A.log_inner) + (g & (A.inner - 1));
       v = lds_load(lds, tile_index<ROW>(r, col, A.log_m, A.log_tc));
       if (A.mult) {
         // w_n^(r * cexp): this lane keeps its column and walks r in steps of NT / tc, so the twiddle advances by a
         // fixed ratio -- one product per element instead of the two of a table lookup
         if (idx == threadIdx.x) {
-          const uint64_t cexp = (g % A.inner) * A.mult;
+          const uint64_t cexp = (g & (A.inner - 1)) * A.mult;
           tw_cur = two_level(A.tw_lo, A.tw_hi, A.lo_bits, (uint64_t)r * cexp);
           tw_step = two_level(A.tw_lo, A.tw_hi, A.lo_bits, (uint64_t)(NT >> A.log_tc) * cexp);
         } else {
@@ -376,26 +378,26 @@ int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, ui
   if (k1) {
     // step A: data -> tmp
     StepArgs a = base;
-    a.in = d_data; a.out = tmp; a.log_m = k1; a.inner = n >> k1; a.mult = 1; a.G = n >> k1; a.n1 = 1;
+    a.in = d_data; a.out = tmp; a.log_m = k1; a.inner = n >> k1; a.mult = 1; a.G = n >> k1; a.n1 = 1; a.log_inner = log_n - k1; a.log_G = log_n - k1; a.log_n1 = 0;
     a.log_tc = tile_cols(k1, a.inner);
     a.scale_mode = pre_scale ? 1 : 0;
     hipLaunchKernelGGL(k_ntt_step<false>, dim3((unsigned)(a.G >> a.log_tc)), dim3(NT), lds_bytes, st, a);
     if (k2) {
       // step B: tmp in place
       StepArgs b = base;
-      b.in = tmp; b.out = tmp; b.log_m = k2; b.inner = n3; b.mult = n1; b.G = n >> k2; b.n1 = 1;
+      b.in = tmp; b.out = tmp; b.log_m = k2; b.inner = n3; b.mult = n1; b.G = n >> k2; b.n1 = 1; b.log_inner = k3; b.log_G = log_n - k2; b.log_n1 = 0;
       b.log_tc = tile_cols(k2, b.inner);
       hipLaunchKernelGGL(k_ntt_step<false>, dim3((unsigned)(b.G >> b.log_tc)), dim3(NT), lds_bytes, st, b);
     }
     // step C: tmp -> data (transposed write)
     StepArgs c = base;
-    c.in = tmp; c.out = d_data; c.log_m = k3; c.G = n >> k3; c.n1 = n1;
+    c.in = tmp; c.out = d_data; c.log_m = k3; c.G = n >> k3; c.n1 = n1; c.log_G = log_n - k3; c.log_n1 = k1; c.log_inner = 0;
     c.log_tc = tile_cols(k3, n1);
     c.scale_mode = (post_scale && coset) ? 2 : 0;
     hipLaunchKernelGGL(k_ntt_step<true>, dim3((unsigned)(c.G >> c.log_tc)), dim3(NT), lds_bytes, st, c);
   } else {
     StepArgs c = base;
-    c.in = d_data; c.out = d_data; c.log_m = k3; c.G = 1; c.n1 = 1; c.log_tc = 0;
+    c.in = d_data; c.out = d_data; c.log_m = k3; c.G = 1; c.n1 = 1; c.log_tc = 0; c.log_G = 0; c.log_n1 = 0; c.log_inner = 0;
     c.scale_mode = pre_scale ? 1 : ((post_scale && coset) ? 2 : 0);
     hipLaunchKernelGGL(k_ntt_step<true>, dim3(1), dim3(NT), lds_bytes, st, c);
   }
