@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkogarashi_amd.so")
 SOURCES = ["capi.cpp", "vec.hip", "msm.hip", "ntt.hip", "groth16.hip"]
-HEADERS = ["common.h", "fp29.h", "fp_consts.h", "curve.h", "host_fp.h", "../../include/kogarashi_amd.h"]
+EXTRA_DEPS = ["../../include/kogarashi_amd.h"]     # plus every header under csrc/ (see _compile)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
          "-ffp-contract=off", "-Xarch_host", "-march=x86-64-v3"]
 
@@ -30,7 +30,8 @@ def _stale(target: str, deps: list[str]) -> bool:
 
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
-    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
+    headers = [h for h in os.listdir(CSRC) if h.endswith((".h", ".inc"))]
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in headers + EXTRA_DEPS]
     if force or _stale(obj, deps):
         cmd = ["hipcc", "-x", "hip"] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -382,6 +382,53 @@ KG_HD Fp<P> inv(const Fp<P>& a) {
 // ---------------------------------------------------------------------------------------------
 // Fq2 = Fq[u]/(u^2+1) over any Fp-like type F (bn254/src/fqn.rs:12-13, 359-369)
 // ---------------------------------------------------------------------------------------------
+// Montgomery (a*b + sigma*c*d)/2^261 with one reduction over SIGNED 64-bit columns, sigma = -1 if `negate` else +1;
+// result in [0, 2p).  The sign is data (a lane's half of an Fq2 product: see Fp2S), the instruction stream is the same
+// for both.  Needs limbs < 2^31 and 9*(max_a*max_b + max_c*max_d) + 9*2^58 + 2^36 < 2^63 (both products may add up).
+template <class P>
+KG_HD Fp<P> mul2pm(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d, bool negate) {
+  uint32_t m[9];
+  int32_t sc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) sc[i] = negate ? -(int32_t)c.l[i] : (int32_t)c.l[i];
+  Fp<P> r;
+  int64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (int64_t)((uint64_t)a.l[i] * b.l[k - i]);
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (int64_t)sc[i] * (int64_t)(int32_t)d.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc += (int64_t)((uint64_t)m[i] * P::P[k - i]);
+    m[k] = ((uint32_t)acc * P::INV) & M29;
+    acc += (int64_t)((uint64_t)m[k] * P::P[0]);
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) acc += (int64_t)((uint64_t)a.l[i] * b.l[k - i]);
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) acc += (int64_t)sc[i] * (int64_t)(int32_t)d.l[k - i];
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) acc += (int64_t)((uint64_t)m[i] * P::P[k - i]);
+    r.l[k - 9] = (uint32_t)acc & M29;
+    acc >>= 29;
+  }
+  // value in (-p, 2p): add p when negative, then propagate carries
+  const uint32_t neg_mask = (uint32_t)((int32_t)(acc >> 32) >> 31);
+  uint32_t cy = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t v = r.l[i] + (P::P[i] & neg_mask) + cy;
+    r.l[i] = v & M29;
+    cy = v >> 29;
+  }
+  r.l[8] = (uint32_t)acc + (P::P[8] & neg_mask) + cy;
+  return r;
+}
+
 template <class F>
 struct Fp2 {
   F c0, c1;
@@ -400,7 +447,11 @@ KG_HD Fp2<F> norm(const Fp2<F>& a) { return {norm(a.c0), norm(a.c1)}; }
 // multiply count of Karatsuba without its additions) and lands in [0, 2p) like a base-field product.
 template <class F>
 KG_HD Fp2<F> mul(const Fp2<F>& a, const Fp2<F>& b) {
+#ifdef KG_FP2_MUL_VIA_PM   // host bound checker: drive the lane-pair routine (fp2s.h) through every G2 formula, both signs
+  return {mul2pm(a.c0, b.c0, a.c1, b.c1, true), mul2pm(a.c0, b.c1, a.c1, b.c0, false)};
+#else
   return {mul2sub(a.c0, b.c0, a.c1, b.c1), mul2add(a.c0, b.c1, a.c1, b.c0)};
+#endif
 }
 // (a0 + a1 u)^2 = (a0 + a1)(a0 - a1) + 2 a0 a1 u     (inputs: normalised limbs, K <= 6)
 template <class F>

@@ -105,6 +105,23 @@ inline FpChecked<P> mul2sub(const FpChecked<P>& a, const FpChecked<P>& b, const 
   return r;
 }
 template <class P>
+inline FpChecked<P> mul2pm(const FpChecked<P>& a, const FpChecked<P>& b, const FpChecked<P>& c, const FpChecked<P>& d, bool negate) {
+  a.check_actual(); b.check_actual(); c.check_actual(); d.check_actual();
+  double A = a.lb > a.tb ? a.lb : a.tb, B = b.lb > b.tb ? b.lb : b.tb;
+  double C = c.lb > c.tb ? c.lb : c.tb, D = d.lb > d.tb ? d.lb : d.tb;
+  const double TWO63 = 9223372036854775808.0, TWO31 = 2147483648.0;
+  if (!(A < TWO31 && B < TWO31 && C < TWO31 && D < TWO31)) BoundFail::fail("mul2pm limb above 2^31", A, TWO31);
+  // either sign must be safe: the sign is data on the device (both products may add up in a column)
+  double pos = 9.0 * (A * B + C * D) + 9.0 * (double)M29 * (double)M29 + 68719476736.0;
+  if (!(pos < TWO63)) BoundFail::fail("mul2pm signed column", pos, TWO63);
+  double kk = a.kb * b.kb + c.kb * d.kb;
+  if (!(kk < FpChecked<P>::RHO())) BoundFail::fail("mul2pm value bound", kk, FpChecked<P>::RHO());
+  double ko = kk / FpChecked<P>::RHO() + 1.0;
+  FpChecked<P> r{mul2pm(a.v, b.v, c.v, d.v, negate), (double)M29, ko * FpChecked<P>::ptop1(), ko};
+  r.check_actual();
+  return r;
+}
+template <class P>
 inline FpChecked<P> vred(const FpChecked<P>& a) {
   a.check_actual();
   if (!(a.lb <= (double)M29)) BoundFail::fail("vred input limbs not normalised", a.lb, (double)M29);

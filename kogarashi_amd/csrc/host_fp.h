@@ -140,6 +140,10 @@ template <class P>
 inline HostFp<P> mul2sub(const HostFp<P>& a, const HostFp<P>& b, const HostFp<P>& c, const HostFp<P>& d) {
   return sub<4, 1>(mul(a, b), mul(c, d));
 }
+template <class P>
+inline HostFp<P> mul2pm(const HostFp<P>& a, const HostFp<P>& b, const HostFp<P>& c, const HostFp<P>& d, bool negate) {
+  return negate ? mul2sub(a, b, c, d) : mul2add(a, b, c, d);
+}
 // a^(p-2) (zkstd normal.rs:256-270); 0 for a == 0
 template <class P>
 inline HostFp<P> inv(const HostFp<P>& a) {

@@ -19,15 +19,16 @@
 // Algorithmic HBM bytes: 96 B/pair (G1, Grumpkin), 160 B/pair (G2): SURVEY.md 8d.
 #include "common.h"
 #include "host_fp.h"
+#include "fp2s.h"
 #include <chrono>
 
 using namespace kg;
 
 namespace {
 
-struct G1Cfg { using F = Fq; using SP = FrParams; using HF = HostFq; static constexpr int E64 = 4; static constexpr int ID = KG_G1; };
-struct GkCfg { using F = Fr; using SP = FqParams; using HF = HostFr; static constexpr int E64 = 4; static constexpr int ID = KG_GRUMPKIN; };
-struct G2Cfg { using F = Fq2; using SP = FrParams; using HF = HostFq2; static constexpr int E64 = 8; static constexpr int ID = KG_G2; };
+struct G1Cfg { using F = Fq; using KF = Fq; using SP = FrParams; using HF = HostFq; static constexpr int E64 = 4; static constexpr int ID = KG_G1; };
+struct GkCfg { using F = Fr; using KF = Fr; using SP = FqParams; using HF = HostFr; static constexpr int E64 = 4; static constexpr int ID = KG_GRUMPKIN; };
+struct G2Cfg { using F = Fq2; using KF = Fp2S<Fq>; using SP = FrParams; using HF = HostFq2; static constexpr int E64 = 8; static constexpr int ID = KG_G2; };
 
 constexpr uint32_t INF_BIT = 0x80000000u;   // bit 255 of the packed x coordinate marks an identity base
 
@@ -130,6 +131,25 @@ template <class F> struct BaseIO<Fp2<F>> {
   }
   static __device__ __forceinline__ Fp2<F> load(const uint32_t* src) { return {BaseIO<F>::load(src), BaseIO<F>::load(src + 8)}; }
 };
+
+// lane-pair Fq2 (fp2s.h): a lane moves its own coordinate only
+template <class F> struct BaseIO<Fp2S<F>> {
+  static constexpr int W = 16;
+  static __device__ __forceinline__ Fp2S<F> load(const uint32_t* src) { return {BaseIO<F>::load(src + 8 * Fp2S<F>::half())}; }
+};
+}  // namespace
+namespace kg {
+template <class F> struct RawIO<Fp2S<F>> {
+  static constexpr int NW = 18;
+  static __device__ __forceinline__ Fp2S<F> load(const uint32_t* base, size_t stride, size_t i) {
+    return {RawIO<F>::load(base + (size_t)(9 * Fp2S<F>::half()) * stride, stride, i)};
+  }
+  static __device__ __forceinline__ void store(uint32_t* base, size_t stride, size_t i, const Fp2S<F>& a) {
+    RawIO<F>::store(base + (size_t)(9 * Fp2S<F>::half()) * stride, stride, i, a.v);
+  }
+};
+}  // namespace kg
+namespace {
 
 // bases: ABI affine (x | y) -> packed internal (x | y), 2*W words per point; identity flag -> INF_BIT of x
 template <class F>
@@ -563,6 +583,31 @@ struct PointAoS {
   }
 };
 
+// lane-pair Fq2: a lane's four coordinates are contiguous (36 words, nine 16-byte vectors) at half() * 36 inside the point
+template <class G>
+struct PointAoS<Fp2S<G>> {
+  using F = Fp2S<G>;
+  static constexpr int NW = PointIO<F>::NW;          // 72
+  static __device__ __forceinline__ void store(uint32_t* base, size_t i, const XYZZ<F>& p) {
+    uint32_t w[36];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { w[k] = p.x.v.l[k]; w[9 + k] = p.y.v.l[k]; w[18 + k] = p.zz.v.l[k]; w[27 + k] = p.zzz.v.l[k]; }
+    uint4* dst = reinterpret_cast<uint4*>(base + i * NW + 36 * F::half());
+#pragma unroll
+    for (int j = 0; j < 9; ++j) dst[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+  }
+  static __device__ __forceinline__ XYZZ<F> load(const uint32_t* base, size_t i) {
+    uint32_t w[36];
+    const uint4* src = reinterpret_cast<const uint4*>(base + i * NW + 36 * F::half());
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { uint4 v = src[j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
+    XYZZ<F> p;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { p.x.v.l[k] = w[k]; p.y.v.l[k] = w[9 + k]; p.zz.v.l[k] = w[18 + k]; p.zzz.v.l[k] = w[27 + k]; }
+    return p;
+  }
+};
+
 // ---- order tasks by length (longest first) so the 64 lanes of a wave run equally long loops ---------------
 // key = min(length, 255); bins are laid out in DESCENDING key order.  One lane per bucket: a bucket contributes
 // ntask-1 full tasks (length T) and one remainder.
@@ -750,7 +795,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
                                                   const uint32_t* __restrict__ task_bkt, const uint32_t* __restrict__ task_id,
                                                   size_t n, int W, int B, uint32_t T, size_t pstride) {
   const int set = A.nsets > 1 ? (int)(blockIdx.x % (unsigned)A.nsets) : 0;
-  const uint32_t p = (A.nsets > 1 ? blockIdx.x / (unsigned)A.nsets : blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint32_t p = ((A.nsets > 1 ? blockIdx.x / (unsigned)A.nsets : blockIdx.x) * blockDim.x + threadIdx.x) / Lanes<F>::N;   // Fq2: a lane pair per task
   if (p >= L.base[W]) return;
   const uint32_t* __restrict__ pbases = A.pb[0];
   uint32_t idx_off = A.idx_off[0];
@@ -784,7 +829,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
 template <class F>
 __global__ void __launch_bounds__(64) k_sum_tasks(const uint32_t* __restrict__ pin, size_t in_stride, Level Lin, Level L, int W, int B, uint32_t T2,
                                                   uint32_t* __restrict__ pout, size_t out_stride) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
   if (t >= L.base[W]) return;
   int w, b;
   uint32_t seg;
@@ -802,7 +847,7 @@ __global__ void __launch_bounds__(64) k_sum_tasks(const uint32_t* __restrict__ p
 template <class F>
 __global__ void __launch_bounds__(256) k_gather_buckets(const uint32_t* __restrict__ pin, size_t in_stride, Level L, int W, int B,
                                                         uint32_t* __restrict__ buckets) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
   const size_t total = (size_t)W * B;
   if (t >= total) return;
   const int w = (int)(t / B);
@@ -821,7 +866,7 @@ __global__ void __launch_bounds__(256) k_gather_buckets(const uint32_t* __restri
 template <class F>
 __global__ void __launch_bounds__(64) k_halve(const uint32_t* __restrict__ in, size_t in_stride, uint32_t* __restrict__ out, size_t out_stride,
                                               int W, int narr_in, uint32_t n_out) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
   const size_t per_w = (size_t)narr_in * n_out;
   if (t >= per_w * W) return;
   const int w = (int)(t / per_w);
@@ -845,9 +890,11 @@ __device__ __forceinline__ void export_el(const Fp<P>& a, uint64_t* dst) {
 }
 template <class F>
 __device__ __forceinline__ void export_el(const Fp2<F>& a, uint64_t* dst) { export_el(a.c0, dst); export_el(a.c1, dst + 4); }
+template <class F>
+__device__ __forceinline__ void export_el(const Fp2S<F>& a, uint64_t* dst) { export_el(a.v, dst + 4 * Fp2S<F>::half()); }
 template <class F, int E64>
 __global__ void __launch_bounds__(64) k_export(const uint32_t* __restrict__ in, size_t stride, size_t count, uint64_t* __restrict__ out) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
   if (t >= count) return;
   XYZZ<F> p = PointIO<F>::load(in, stride, t);
   uint64_t* dst = out + t * 4 * E64;
@@ -1041,6 +1088,8 @@ struct RunJob { const uint64_t* d_bases; const uint8_t* d_inf; size_t nbases; ui
 template <class Cfg>
 int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njobs) {
   using F = typename Cfg::F;
+  using KF = typename Cfg::KF;                      // field type of the reduction kernels (Fq2: a lane pair per task, fp2s.h)
+  constexpr unsigned LPT = Lanes<KF>::N;            // lanes per task
   constexpr int PW = 2 * BaseIO<F>::W;              // packed words per base
   constexpr int NW = PointIO<F>::NW;                // raw words per XYZZ point
   if (njobs < 1 || njobs > MAX_FUSED) return set_err(ctx, KG_ERR_BAD_ARG, "bad number of fused base arrays");
@@ -1150,7 +1199,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       for (uint32_t n_out = (uint32_t)B / 2; n_out >= 1; n_out /= 2) {
         const size_t tasks = (size_t)W * narr * n_out;
         const size_t out_stride = (size_t)W * (narr + 1) * n_out;
-        hipLaunchKernelGGL(k_halve<F>, dim3((unsigned)((tasks + 63) / 64)), dim3(64), 0, side, pbuf[cur], in_stride, pbuf[cur ^ 1], out_stride,
+        hipLaunchKernelGGL(k_halve<KF>, dim3((unsigned)((tasks * LPT + 63) / 64)), dim3(64), 0, side, pbuf[cur], in_stride, pbuf[cur ^ 1], out_stride,
                            W, narr, n_out);
         cur ^= 1;
         in_stride = out_stride;
@@ -1158,7 +1207,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
         if (n_out == 1) break;
       }
       // now: W windows x narr (= c) single points, stride W*c
-      hipLaunchKernelGGL((k_export<F, Cfg::E64>), dim3((unsigned)((nexp + 63) / 64)), dim3(64), 0, side, pbuf[cur], nexp, nexp, d_exp);
+      hipLaunchKernelGGL((k_export<KF, Cfg::E64>), dim3((unsigned)((nexp * LPT + 63) / 64)), dim3(64), 0, side, pbuf[cur], nexp, nexp, d_exp);
       ph.end();
     }
     KG_HIP(ctx, hipGetLastError());

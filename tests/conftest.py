@@ -38,3 +38,17 @@ def hostlib():
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]])
     return ctypes.CDLL(so)
+
+
+@pytest.fixture(scope="session")
+def hostlib_pm():
+    """Same templates with Fq2 products routed through mul2pm, the signed double product a lane pair shares on the
+    device (csrc/fp2s.h): the bound checker then sees it with the operands of every G2 formula, in both sign modes."""
+    import ctypes
+    d = os.path.join(ROOT, "tests", "host")
+    so = os.path.join(d, "libhosttest_pm.so")
+    srcs = [os.path.join(d, "hosttest.cpp")] + [
+        os.path.join(ROOT, "kogarashi_amd", "csrc", f) for f in ("fp29.h", "fp29_checked.h", "curve.h", "fp_consts.h", "ntt_core.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DKG_FP2_MUL_VIA_PM", "-o", so, srcs[0]])
+    return ctypes.CDLL(so)

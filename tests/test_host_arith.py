@@ -80,6 +80,16 @@ def curve_sum(H, cid, cur, chk, mode, pts, inf):
 def test_xyzz_point_formulas_match_bigint_oracle(hostlib, pyoracle, name):
     """Group-law cases of the reference's curve_test! (zkstd/src/macros/curve/weierstrass/test.rs:2-224) plus the
     exceptional branches of weierstrass.rs (equal points, inverse points, identities in the input)."""
+    _check_point_formulas(hostlib, pyoracle, name)
+
+
+def test_g2_formulas_with_the_lane_pair_product(hostlib_pm, pyoracle):
+    """The same G2 cases with every Fq2 product computed by mul2pm (a*b + sigma*c*d over signed columns, the routine the
+    lane-pair type of csrc/fp2s.h runs on the device): values against the oracle, worst-case bounds by FpChecked."""
+    _check_point_formulas(hostlib_pm, pyoracle, "g2")
+
+
+def _check_point_formulas(hostlib, pyoracle, name):
     P = pyoracle
     cid, cur, _ = CURVES[name]
     rnd = random.Random(5)
