@@ -176,7 +176,7 @@ def pmc_traffic(log_n):
     """Memory-side bytes per k_acc_tasks launch from the committed rocprofv3 --pmc passes (profiles/): FETCH_SIZE and
     WRITE_SIZE are collected in separate runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     for gfx950.  Only valid for the configuration it was measured on (2^20 pairs); null otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_k_pmc_hbm.json")
+    path = os.path.join(ROOT, "profiles", "r01_l_pmc_hbm.json")
     if log_n != LOG_N or not os.path.exists(path):
         return None
     with open(path) as f:
