@@ -158,7 +158,9 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
  * starts its host-side assembly on worker threads; _end waits for it and writes the proof (same layout and status codes
  * as kg_groth16_prove_bn254).  _begin(i + 1) before _end(i) lets the next proof's transforms and sorts run while the
  * previous proof's last reduction, host finish and assembly complete.  crs and the device inputs must stay valid
- * until the matching _end. */
+ * until the matching _end.  Every _begin must be followed by its _end (also after an error: _end returns the status).
+ * Result slots of kg_msm, of the kg_msm_begin tickets and of the two proof tickets are disjoint, so these calls may be
+ * interleaved on one context. */
 int kg_groth16_prove_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
                            const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
                            const uint64_t* s, int ticket);

@@ -169,17 +169,24 @@ class Prover:
         and host assembly.  Yields the proofs in order."""
         up = lambda v: self.ctx.upload(np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4))
         held = [None, None]
-        pending = None
-        for i, (a_eval, b_eval, c_eval, x, w, r, s) in enumerate(jobs):
-            t = i & 1
-            held[t] = [up(a_eval), up(b_eval), up(c_eval), up(x), up(w)]       # alive until the matching end
-            da, db, dc, dx, dw = held[t]
-            self.ctx.groth16_prove_begin(self.crs, da.ptr, db.ptr, dc.ptr, dx.ptr, dw.ptr, r, s, t)
-            if pending is not None:
-                yield self.ctx.groth16_prove_end(pending)
-            pending = t
-        if pending is not None:
-            yield self.ctx.groth16_prove_end(pending)
+        in_flight = []                                  # tickets begun and not yet ended, oldest first
+        try:
+            for i, (a_eval, b_eval, c_eval, x, w, r, s) in enumerate(jobs):
+                t = i & 1
+                held[t] = [up(a_eval), up(b_eval), up(c_eval), up(x), up(w)]       # alive until the matching end
+                da, db, dc, dx, dw = held[t]
+                self.ctx.groth16_prove_begin(self.crs, da.ptr, db.ptr, dc.ptr, dx.ptr, dw.ptr, r, s, t)
+                in_flight.append(t)
+                if len(in_flight) == 2:
+                    yield self.ctx.groth16_prove_end(in_flight.pop(0))
+            while in_flight:
+                yield self.ctx.groth16_prove_end(in_flight.pop(0))
+        finally:
+            for t in in_flight:                         # an error or an abandoned generator: every begin gets its end
+                try:
+                    self.ctx.groth16_prove_end(t)
+                except Exception:
+                    pass
 
 
 def _csr_transpose(row_ptr, col, val, m, nvars):

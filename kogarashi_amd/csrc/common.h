@@ -34,7 +34,7 @@ struct kg_ctx {
   hipEvent_t ev_acc[RUN_SETS] = {};
   hipEvent_t ev_info = nullptr;          // marks the task-count read-back of msm_sort
   struct Slot { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0; bool busy = false; };
-  static constexpr int NSLOTS = 16;      // 0..3 kg_msm / prover job 0 (1..5), 4..7 kg_msm_begin tickets, 8..15 prover job 1 (9..13)
+  static constexpr int NSLOTS = 16;      // 0 kg_msm, 1..4 kg_msm_begin tickets, 6..10 prover job 0, 11..15 prover job 1 (disjoint: calls may interleave)
   Slot slots[NSLOTS];
   std::shared_ptr<void> prover_jobs;     // groth16.hip: proofs in flight (kg_groth16_prove_begin / _end)
   size_t ticket_n[4] = {0, 0, 0, 0};

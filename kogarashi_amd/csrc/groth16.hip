@@ -163,7 +163,7 @@ struct ProofJob {
   uint8_t inf[3];
   bool active = false;
 };
-struct ProofJobs { ProofJob j[2]; };   // job 0: kg_groth16_prove_bn254 and ticket 0; job 1: ticket 1 (result slots 8..15)
+struct ProofJobs { ProofJob j[2]; };   // job 0: kg_groth16_prove_bn254 and ticket 0 (result slots 6..10); job 1: ticket 1 (slots 11..15)
 ProofJob* job_of(kg_ctx* ctx, int i) {
   if (!ctx->prover_jobs) ctx->prover_jobs = std::make_shared<ProofJobs>();
   return &static_cast<ProofJobs*>(ctx->prover_jobs.get())->j[i];
@@ -352,7 +352,7 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   if (!ctx || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
   ProofJob* job = job_of(ctx, 0);
   if (job->active) return KG_ERR_BAD_ARG;                // a proof begun with ticket 0 has not been collected
-  KG_TRY(prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job, 0));
+  KG_TRY(prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job, 5));
   return prove_collect(job, proof_out, proof_inf);
 }
 
@@ -363,7 +363,7 @@ int kg_groth16_prove_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
                            const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
                            const uint64_t* s, int ticket) {
   if (!ctx || ticket < 0 || ticket > 1 || job_of(ctx, ticket)->active) return KG_ERR_BAD_ARG;
-  return prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job_of(ctx, ticket), 8 * ticket);
+  return prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job_of(ctx, ticket), 5 + 5 * ticket);
 }
 int kg_groth16_prove_end(kg_ctx* ctx, int ticket, uint64_t* proof_out, uint8_t* proof_inf) {
   if (!ctx || ticket < 0 || ticket > 1 || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;

@@ -1346,13 +1346,13 @@ int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t*
   if (n == 0) return KG_OK;
   kg::MsmSorted S;
   KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S));
-  return kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 4 + ticket);       // slots 4..7: 0..3 belong to kg_msm / the prover
+  return kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 1 + ticket);       // slots 1..4 (slot 0: kg_msm; 6..15: the prover's two jobs)
 }
 
 int kg_msm_end(kg_ctx* ctx, int curve, int ticket, uint64_t* out_xyz) {
   if (!ctx || !out_xyz || curve < 0 || curve > KG_G2 || ticket < 0 || ticket > 3) return KG_ERR_BAD_ARG;
   if (ctx->ticket_n[ticket] == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
-  return kg::msm_finish(ctx, curve, 4 + ticket, out_xyz);
+  return kg::msm_finish(ctx, curve, 1 + ticket, out_xyz);
 }
 
 int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars, size_t n, uint64_t* out_xyz) {

@@ -166,3 +166,77 @@ def test_groth16_two_proofs_in_flight_match_blocking_calls(ctx, oracle):
     bad = dict(params); bad["delta_g1_inf"] = 1
     with pytest.raises(ProverSubVersionCrsAttack):
         list(K.Prover(bad, css[0].m, css[0].l, css[0].m_l_1, ctx=ctx).create_proofs(jobs[:2]))
+
+
+def test_interleaved_calls_share_one_context(ctx, oracle):
+    """Soak: blocking MSMs on three curves, MSMs in flight, NTTs, blocking proofs and proofs in flight, registered and
+    plain base arrays, issued in a seeded random order on ONE context -- the calls share result slots, run-space sets,
+    reduction queues and the sort work space, so every result is compared with the value the same call gave alone."""
+    import kogarashi_amd as K
+    O = oracle
+    rng = np.random.default_rng(99)
+    # fixtures
+    msm_in = {}
+    for name, curve, sfd, n in (("g1a", 0, 0, 70000), ("g1b", 0, 0, 3000), ("gk", 1, 1, 20000)):
+        b = O.gen_bases(curve, SEED + 800 + n, 0, n); s = O.gen_scalars(sfd, SEED + 801 + n, 0, n)
+        msm_in[name] = (curve, n, ctx.upload(b), ctx.upload(s))
+    n2 = 900
+    dk = ctx.upload(O.gen_scalars(0, SEED + 810, 0, n2)); dxy = ctx.empty((n2, 16)); dinf = ctx.empty((n2,), dtype=np.uint8)
+    ctx.fixed_base_mul(2, dk.ptr, n2, dxy.ptr, dinf.ptr)
+    msm_in["g2"] = (2, n2, dxy, ctx.upload(O.gen_scalars(0, SEED + 811, 0, n2)))
+    ctx.bases_register(0, msm_in["g1a"][2].ptr, 0, msm_in["g1a"][1])
+    cs = O.chain_r1cs(700, O.gen_scalars(0, SEED + 820, 0, 1)[0])
+    params = O.groth16_params(cs, O.gen_scalars(0, SEED + 821, 0, 5), threads=8)
+    params["vk_g2"] = params["vk_g2"][:2]
+    prover = K.Prover(params, cs.m, cs.l, cs.m_l_1, ctx=ctx)
+    a, b_, c = cs.evaluate()
+    r, s_ = O.gen_scalars(0, SEED + 822, 0, 2)
+    proof_args = (a, b_, c, cs.x, cs.w, r, s_)
+    up = lambda v: ctx.upload(np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4))
+    dproof = [up(v) for v in proof_args[:5]]
+    ntt_v = O.gen_scalars(0, SEED + 830, 0, 1 << 14)
+    fft = K.Fft(14, ctx=ctx)
+    # reference values, each call alone
+    want_msm = {k: ctx.msm(c_, b.ptr, 0, s.ptr, n) for k, (c_, n, b, s) in msm_in.items()}
+    want_proof = prover.create_proof(*proof_args)
+    want_ntt = fft.coset_dft(ntt_v)
+    try:
+        pending_msm, pending_proof = {}, {}
+        for step in range(60):
+            op = int(rng.integers(0, 6))
+            if op == 0:
+                k = list(msm_in)[int(rng.integers(0, 4))]
+                c_, n, b, s = msm_in[k]
+                assert (ctx.msm(c_, b.ptr, 0, s.ptr, n) == want_msm[k]).all(), (step, k)
+            elif op == 1:
+                t = int(rng.integers(0, 4))
+                if t in pending_msm:
+                    k = pending_msm.pop(t)
+                    assert (ctx.msm_end(msm_in[k][0], t) == want_msm[k]).all(), (step, "end", k)
+                else:
+                    k = list(msm_in)[int(rng.integers(0, 4))]
+                    c_, n, b, s = msm_in[k]
+                    ctx.msm_begin(c_, b.ptr, 0, s.ptr, n, t)
+                    pending_msm[t] = k
+            elif op == 2:
+                assert (fft.coset_dft(ntt_v) == want_ntt).all(), step
+            elif op == 3:
+                got = prover.create_proof(*proof_args) if 0 not in pending_proof else None
+                if got is not None:
+                    assert all((got[i] == want_proof[i]).all() for i in range(4)), step
+            else:
+                t = int(rng.integers(0, 2))
+                if t in pending_proof:
+                    pending_proof.pop(t)
+                    got = ctx.groth16_prove_end(t)
+                    assert all((got[i] == want_proof[i]).all() for i in range(4)), (step, "proof end")
+                else:
+                    ctx.groth16_prove_begin(prover.crs, *[d.ptr for d in dproof], r, s_, t)
+                    pending_proof[t] = True
+        for t, k in pending_msm.items():
+            assert (ctx.msm_end(msm_in[k][0], t) == want_msm[k]).all()
+        for t in pending_proof:
+            got = ctx.groth16_prove_end(t)
+            assert all((got[i] == want_proof[i]).all() for i in range(4))
+    finally:
+        ctx.bases_unregister(msm_in["g1a"][2].ptr)
