@@ -241,3 +241,29 @@ def test_interleaved_calls_share_one_context(ctx, oracle, seed):
             assert all((got[i] == want_proof[i]).all() for i in range(4))
     finally:
         ctx.bases_unregister(msm_in["g1a"][2].ptr)
+
+
+def test_context_closes_with_a_proof_in_flight(oracle):
+    """kg_ctx_destroy with a proof begun and never collected: the worker threads are joined, nothing hangs or crashes,
+    and a new context afterwards proves correctly."""
+    import kogarashi_amd as K
+    O = oracle
+    cs = O.chain_r1cs(200, O.gen_scalars(0, SEED + 470, 0, 1)[0])
+    full = O.groth16_params(cs, O.gen_scalars(0, SEED + 471, 0, 5), threads=8)
+    params = dict(full); params["vk_g2"] = full["vk_g2"][:2]
+    a, b, c = cs.evaluate()
+    r, s = O.gen_scalars(0, SEED + 472, 0, 2)
+    want = O.groth16_prove(cs, full, r, s, evals=(a, b, c))
+    c1 = K.Context(0)
+    p1 = K.Prover(params, cs.m, cs.l, cs.m_l_1, ctx=c1)
+    up = lambda v: c1.upload(np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4))
+    d = [up(v) for v in (a, b, c, cs.x, cs.w)]
+    c1.groth16_prove_begin(p1.crs, *[x.ptr for x in d], r, s, 1)
+    del p1
+    c1.close()
+    c2 = K.Context(0)
+    try:
+        got = K.Prover(params, cs.m, cs.l, cs.m_l_1, ctx=c2).create_proof(a, b, c, cs.x, cs.w, r, s)
+        assert all((got[k] == want[k]).all() for k in range(3))
+    finally:
+        c2.close()

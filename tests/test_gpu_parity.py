@@ -401,3 +401,30 @@ def test_msm_randomised_configurations(ctx, oracle):
         finally:
             ctx.set_msm_window(0)
         assert got == want, (case, cv, n, c, mix)
+
+
+def test_work_space_growth_with_msms_in_flight(oracle):
+    """A fresh context whose MSM sizes grow while earlier MSMs are still in flight: every growth re-allocates sort or
+    run space that a pending ticket may still be using (the library must wait for it), and destroying the context with
+    a ticket never collected must not hang or crash."""
+    import kogarashi_amd as K
+    O = oracle
+    c = K.Context(0)
+    try:
+        sizes = [100, 70000, 5, 200000, 3000, 66000]
+        data = []
+        for i, n in enumerate(sizes):
+            b = O.gen_bases(0, SEED + 950 + i, 0, n); s = O.gen_scalars(0, SEED + 960 + i, 0, n)
+            data.append((n, c.upload(b), c.upload(s), aff(O, "g1", O.msm("g1", b, s, None, threads=8))))
+        # begin i, begin i+1 (bigger: re-allocates), end i, ...
+        c.msm_begin(0, data[0][1].ptr, 0, data[0][2].ptr, data[0][0], 0)
+        for i in range(1, len(sizes)):
+            n, b, s, _ = data[i]
+            c.msm_begin(0, b.ptr, 0, s.ptr, n, i & 3)
+            got = c.msm_end(0, (i - 1) & 3)
+            assert gpu_aff(got, 4) == data[i - 1][3], i - 1
+            assert gpu_aff(c.msm(0, b.ptr, 0, s.ptr, n), 4) == data[i][3], ("blocking", i)
+        assert gpu_aff(c.msm_end(0, (len(sizes) - 1) & 3), 4) == data[-1][3]
+        c.msm_begin(0, data[3][1].ptr, 0, data[3][2].ptr, data[3][0], 2)      # never collected
+    finally:
+        c.close()
