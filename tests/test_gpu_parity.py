@@ -428,3 +428,35 @@ def test_work_space_growth_with_msms_in_flight(oracle):
         c.msm_begin(0, data[3][1].ptr, 0, data[3][2].ptr, data[3][0], 2)      # never collected
     finally:
         c.close()
+
+
+def test_bad_arguments_are_status_codes_not_crashes(ctx):
+    """The ABI never aborts: null pointers, unknown curves / fields / ops, out-of-range tickets, sizes and
+    window widths come back as KG_ERR_BAD_ARG (-2) -- called through the raw ctypes handle, past the Python checks."""
+    import ctypes as C
+    L, h = ctx._lib, ctx._h
+    n = 64
+    d = ctx.empty((n, 8))
+    s = ctx.empty((n, 4))
+    out = (C.c_uint64 * 24)()
+    vp = lambda x: C.c_void_p(x)
+    BAD = -2
+    assert L.kg_msm(h, 7, vp(d.ptr), None, vp(s.ptr), C.c_size_t(n), out) == BAD              # unknown curve
+    assert L.kg_msm(h, 0, None, None, vp(s.ptr), C.c_size_t(n), out) == BAD                   # null bases
+    assert L.kg_msm(h, 0, vp(d.ptr), None, vp(s.ptr), C.c_size_t(n), None) == BAD             # null output
+    assert L.kg_msm(None, 0, vp(d.ptr), None, vp(s.ptr), C.c_size_t(n), out) == BAD           # null context
+    assert L.kg_msm_begin(h, 0, vp(d.ptr), None, vp(s.ptr), C.c_size_t(n), 4) == BAD          # ticket out of range
+    assert L.kg_msm_end(h, 0, -1, out) == BAD
+    assert L.kg_ntt_bn254_fr(h, vp(s.ptr), 0, 0, 0) == BAD                                    # log_n out of range
+    assert L.kg_ntt_bn254_fr(h, vp(s.ptr), 29, 0, 0) == BAD
+    assert L.kg_ntt_bn254_fr(h, None, 4, 0, 0) == BAD
+    assert L.kg_field_vec_op(h, 9, 0, vp(s.ptr), vp(s.ptr), vp(s.ptr), C.c_size_t(n)) == BAD  # unknown field
+    assert L.kg_field_vec_op(h, 0, 0, vp(s.ptr), None, vp(s.ptr), C.c_size_t(n)) == BAD       # binary op without b
+    assert L.kg_msm_set_window(h, 19) == BAD
+    assert L.kg_bases_register(h, 5, vp(d.ptr), None, C.c_size_t(n)) == BAD
+    assert L.kg_groth16_prove_end(h, 0, out, None) == BAD                                     # null flags
+    assert L.kg_groth16_prove_end(h, 1, out, (C.c_uint8 * 3)()) == BAD                        # nothing begun on ticket 1
+    assert L.kg_groth16_prove_begin(h, None, None, None, None, None, None, None, None, 0) == BAD
+    # zero-length inputs are valid: the identity
+    assert L.kg_msm(h, 0, None, None, None, C.c_size_t(0), out) == 0 and not any(out[8:12])
+    assert ctx.msm(0, d.ptr, 0, s.ptr, 0) is not None
