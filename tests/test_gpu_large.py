@@ -58,3 +58,31 @@ def test_ntt_round_trips_and_linearity(ctx, k):
     ctx.ntt(s.ptr, k, False, False)
     ctx.field_vec_op(K.KG_FR, "add", a.ptr, b.ptr, a.ptr, n)
     assert (a.numpy() == s.numpy()).all()               # dft(a + b) = dft(a) + dft(b)
+
+
+@pytest.mark.parametrize("curve,sfd", [(0, 0), (1, 1)])
+def test_commit_2_24_properties(ctx, curve, sfd):
+    """BASELINE.json configs[4] (Nova's commitment key: 2^24 bases) on one GPU, both curves: no oracle at this size, so
+    size-independent properties of commit(m) = affine(sum g_i * m_i): the split sum over a ragged cut, and linearity in
+    the scalars, commit(a + b) = commit(a) + commit(b) (the vector sum through kg_field_vec_op)."""
+    import kogarashi_amd as K
+    n = 1 << 24
+    fld = K.KG_FR if sfd == 0 else K.KG_FQ
+    g, a, b, s = ctx.empty((n, 8)), ctx.empty((n, 4)), ctx.empty((n, 4)), ctx.empty((n, 4))
+    ctx.gen_bases(curve, SEED + 40 + curve, 0, n, g.ptr)
+    ctx.gen_scalars(fld, SEED + 41, 0, n, a.ptr)
+    ctx.gen_scalars(fld, SEED + 42, 0, n, b.ptr)
+    ca, ia = ctx.commit(curve, g.ptr, 0, a.ptr, n)
+    cb, ib = ctx.commit(curve, g.ptr, 0, b.ptr, n)
+    assert not ia and not ib
+    # split sum
+    h = 5000001
+    c1, i1 = ctx.commit(curve, g.ptr, 0, a.ptr, h)
+    c2, i2 = ctx.commit(curve, g.ptr + 64 * h, 0, a.ptr + 32 * h, n - h)
+    xy, inf = ctx.points_sum_affine(curve, np.stack([c1, c2]), np.array([i1, i2], dtype=np.uint8))
+    assert inf == 0 and (xy == ca).all()
+    # linearity
+    ctx.field_vec_op(fld, "add", a.ptr, b.ptr, s.ptr, n)
+    cs, is_ = ctx.commit(curve, g.ptr, 0, s.ptr, n)
+    xy, inf = ctx.points_sum_affine(curve, np.stack([ca, cb]), np.array([ia, ib], dtype=np.uint8))
+    assert not is_ and inf == 0 and (xy == cs).all()
