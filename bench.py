@@ -112,6 +112,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run(40)                                   # untimed: first-touch allocations and the clock ramp of a cold GPU (~70 ms)
     if args.warmup:
         run(args.warmup)
     ctx.profile_enable(True)
