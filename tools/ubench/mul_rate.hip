@@ -61,7 +61,7 @@ template <class K> float time_it(K launch) {
 int main() {
   uint32_t* d; CHECK(hipMalloc(&d, 1 << 24));
   const char* fn[] = {"mul (dependent chain)", "sqr (dependent chain)", "mul x2 interleaved", "add_mixed", "sub+norm+vred"};
-  for (int wps : {1, 2, 4}) {
+  for (int wps : {1, 2, 3, 4, 5, 6, 8}) {
     int blocks = 256 * wps, iters = 2000;
     float ms;
     ms = time_it([&] { k_field<0><<<blocks, 256>>>(d, iters); }); printf("%-24s w/SIMD=%d %8.3f ms  %8.2f Gop/s\n", fn[0], wps, ms, (double)blocks * 256 * iters / ms * 1e-6);
