@@ -85,6 +85,36 @@ KG_HD XYZZ<F> add_mixed(const XYZZ<F>& p, const Affine<F>& a) {
   return {x3, y3, mul(p.zz, pp), mul(p.zzz, ppp)};
 }
 
+// P + (+-a): the bucket kernel's form.  The sign of a signed digit is folded into R = +-S2 - Y1 (a fat subtraction
+// from zero: 8p - S2) instead of negating the point's y first (subtract, normalise, value-reduce: ~80 instructions that
+// every lane of a wave pays as soon as one lane's digit is negative).
+// (Base fields only: R reaches K = 12 in the negated case, which an Fq2 square's inner subtraction does not admit --
+// the Fq2 overload below negates the point as before.)
+template <class F>
+KG_HD XYZZ<F> add_mixed_signed(const XYZZ<F>& p, const Affine<F>& a, bool negate) {
+  if (is_identity(p)) return from_affine(negate ? neg_affine(a) : a);
+  F u2 = mul(a.x, p.zz);
+  F s2 = mul(a.y, p.zzz);
+  F pp_ = norm(sub<4, 1>(u2, p.x));     // P = U2 - X1
+  F t = negate ? sub<8, 1>(F::zero(), s2) : s2;   // S2 < 2.1p: the 4p constant does not dominate its top limb
+  F r = norm(sub<4, 1>(t, p.y));        // R = +-S2 - Y1
+  F pp = sqr(pp_);
+  if (is_zero_2p(pp)) {                 // same x: doubling or inverse (weierstrass.rs:75-81)
+    if (is_zero(r)) return double_affine(negate ? neg_affine(a) : a);
+    return XYZZ<F>::identity();
+  }
+  F ppp = mul(pp_, pp);
+  F q = mul(p.x, pp);
+  F x3 = vred(norm(sub<4, 1>(sqr(r), norm(add(ppp, dbl(q))))));
+  F y3 = mul2sub(r, norm(sub<4, 1>(q, x3)), p.y, ppp);          // R*(Q - X3) - Y1*PPP with ONE reduction
+  return {x3, y3, mul(p.zz, pp), mul(p.zzz, ppp)};
+}
+
+template <class G>
+KG_HD XYZZ<Fp2<G>> add_mixed_signed(const XYZZ<Fp2<G>>& p, const Affine<Fp2<G>>& a, bool negate) {
+  return add_mixed(p, negate ? neg_affine(a) : a);
+}
+
 // P + Q  (add-2008-s)
 template <class F>
 KG_HD XYZZ<F> add_xyzz(const XYZZ<F>& p, const XYZZ<F>& q_) {

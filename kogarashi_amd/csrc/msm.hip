@@ -818,9 +818,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
     if (idx < idx_off) continue;                         // scalars in front of this base array (shared sort, z = x || w)
     const uint32_t* src = pbases + (size_t)(idx - idx_off) * PW;
     if (src[7] & INF_BIT) continue;                      // identity base (msm.rs:58-64 adds it as a no-op)
-    Affine<F> a{BaseIO<F>::load(src), BaseIO<F>::load(src + BaseIO<F>::W)};
-    if (e & 0x80000000u) a = neg_affine(a);
-    acc = add_mixed(acc, a);
+    const Affine<F> a{BaseIO<F>::load(src), BaseIO<F>::load(src + BaseIO<F>::W)};
+    acc = add_mixed_signed(acc, a, (e & 0x80000000u) != 0);
   }
   PointAoS<F>::store(partial, t, acc);
 }

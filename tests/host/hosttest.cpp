@@ -81,7 +81,8 @@ static int st_aff(const XYZZ<F>& p, uint32_t* xy) {
   return 0;
 }
 // mode 0: left fold with add_mixed; 1: pairwise tree with add_xyzz; 2: fold of add_xyzz(from_affine);
-// 3: sum_i 2*P_i via double_affine + add_xyzz; 4: double_xyzz applied `n` times to point 0; 5: fold, negated
+// 3: sum_i 2*P_i via double_affine + add_xyzz; 4: double_xyzz applied `n` times to point 0; 5: fold, negated;
+// 7: fold of add_mixed_signed(acc, -P_i, negate = true), i.e. the sign folded back: equals mode 0
 template <class F>
 static int curve_sum(int mode, const uint32_t* pts, const uint8_t* inf, size_t n, uint32_t* out_xy) {
   const int W2 = 2 * Conv<F>::W;
@@ -89,6 +90,11 @@ static int curve_sum(int mode, const uint32_t* pts, const uint8_t* inf, size_t n
   if (mode == 0 || mode == 5) {
     for (size_t i = 0; i < n; ++i) if (!inf || !inf[i]) acc = add_mixed(acc, ld_aff<F>(pts + W2 * i));
     if (mode == 5) acc = neg_xyzz(acc);
+  } else if (mode == 7) {
+    for (size_t i = 0; i < n; ++i) if (!inf || !inf[i]) {
+      Affine<F> a = ld_aff<F>(pts + W2 * i);
+      acc = (i & 1) ? add_mixed_signed(acc, neg_affine(a), true) : add_mixed_signed(acc, a, false);
+    }
   } else if (mode == 1) {
     std::vector<XYZZ<F>> v;
     for (size_t i = 0; i < n; ++i) v.push_back((inf && inf[i]) ? XYZZ<F>::identity() : from_affine(ld_aff<F>(pts + W2 * i)));
