@@ -80,7 +80,7 @@ KG_HD XYZZ<F> add_mixed(const XYZZ<F>& p, const Affine<F>& a) {
   }
   F ppp = mul(pp_, pp);
   F q = mul(p.x, pp);
-  F x3 = vred(norm(sub<4, 1>(sqr(r), norm(add(ppp, dbl(q))))));
+  F x3 = vred(norm(sub<8, 3>(sqr(r), add(ppp, dbl(q)))));   // PPP + 2Q stays lazy: the 8p constant with 3 x 2^29 limbs dominates it
   F y3 = mul2sub(r, norm(sub<4, 1>(q, x3)), p.y, ppp);          // R*(Q - X3) - Y1*PPP with ONE reduction
   return {x3, y3, mul(p.zz, pp), mul(p.zzz, ppp)};
 }
@@ -105,7 +105,7 @@ KG_HD XYZZ<F> add_mixed_signed(const XYZZ<F>& p, const Affine<F>& a, bool negate
   }
   F ppp = mul(pp_, pp);
   F q = mul(p.x, pp);
-  F x3 = vred(norm(sub<4, 1>(sqr(r), norm(add(ppp, dbl(q))))));
+  F x3 = vred(norm(sub<8, 3>(sqr(r), add(ppp, dbl(q)))));   // PPP + 2Q stays lazy: the 8p constant with 3 x 2^29 limbs dominates it
   F y3 = mul2sub(r, norm(sub<4, 1>(q, x3)), p.y, ppp);          // R*(Q - X3) - Y1*PPP with ONE reduction
   return {x3, y3, mul(p.zz, pp), mul(p.zzz, ppp)};
 }
@@ -133,7 +133,7 @@ KG_HD XYZZ<F> add_xyzz(const XYZZ<F>& p, const XYZZ<F>& q_) {
   }
   F ppp = mul(pp_, pp);
   F q = mul(u1, pp);
-  F x3 = vred(norm(sub<4, 1>(sqr(r), norm(add(ppp, dbl(q))))));
+  F x3 = vred(norm(sub<8, 3>(sqr(r), add(ppp, dbl(q)))));   // PPP + 2Q stays lazy: the 8p constant with 3 x 2^29 limbs dominates it
   F y3 = mul2sub(r, norm(sub<4, 1>(q, x3)), s1, ppp);
   return {x3, y3, mul(mul(p.zz, q_.zz), pp), mul(mul(p.zzz, q_.zzz), ppp)};
 }
