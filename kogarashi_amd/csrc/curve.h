@@ -95,7 +95,7 @@ KG_HD XYZZ<F> add_mixed_signed(const XYZZ<F>& p, const Affine<F>& a, bool negate
   if (is_identity(p)) return from_affine(negate ? neg_affine(a) : a);
   F u2 = mul(a.x, p.zz);
   F s2 = mul(a.y, p.zzz);
-  F pp_ = norm(sub<4, 1>(u2, p.x));     // P = U2 - X1
+  F pp_ = norm(sub<8, 1>(u2, p.x));     // P = U2 - X1   (X1 < 6p: see X3 below)
   F t = negate ? sub<8, 1>(F::zero(), s2) : s2;   // S2 < 2.1p: the 4p constant does not dominate its top limb
   F r = norm(sub<4, 1>(t, p.y));        // R = +-S2 - Y1
   F pp = sqr(pp_);
@@ -105,8 +105,10 @@ KG_HD XYZZ<F> add_mixed_signed(const XYZZ<F>& p, const Affine<F>& a, bool negate
   }
   F ppp = mul(pp_, pp);
   F q = mul(p.x, pp);
-  F x3 = vred(norm(sub<8, 3>(sqr(r), add(ppp, dbl(q)))));   // PPP + 2Q stays lazy: the 8p constant with 3 x 2^29 limbs dominates it
-  F y3 = mul2sub(r, norm(sub<4, 1>(q, x3)), p.y, ppp);          // R*(Q - X3) - Y1*PPP with ONE reduction
+  // X3 = R^2 + 4p - (PPP + 2Q) < 6p is kept WITHOUT a value reduction: the accumulator's X only ever enters products and
+  // the two fat subtractions of the next addition (8p constants), and the bucket array is value-reduced on export
+  F x3 = norm(sub<4, 3>(sqr(r), add(ppp, dbl(q))));
+  F y3 = mul2sub(r, norm(sub<8, 1>(q, x3)), p.y, ppp);          // R*(Q - X3) - Y1*PPP with ONE reduction
   return {x3, y3, mul(p.zz, pp), mul(p.zzz, ppp)};
 }
 

@@ -82,7 +82,9 @@ static int st_aff(const XYZZ<F>& p, uint32_t* xy) {
 }
 // mode 0: left fold with add_mixed; 1: pairwise tree with add_xyzz; 2: fold of add_xyzz(from_affine);
 // 3: sum_i 2*P_i via double_affine + add_xyzz; 4: double_xyzz applied `n` times to point 0; 5: fold, negated;
-// 7: fold of add_mixed_signed(acc, -P_i, negate = true), i.e. the sign folded back: equals mode 0
+// 7: fold of add_mixed_signed(acc, -P_i, negate = true), i.e. the sign folded back: equals mode 0;
+// 8: the device pipeline's shape -- chunks of three folded with add_mixed_signed (their X is not value-reduced), the
+//    partial sums combined by an add_xyzz tree
 template <class F>
 static int curve_sum(int mode, const uint32_t* pts, const uint8_t* inf, size_t n, uint32_t* out_xy) {
   const int W2 = 2 * Conv<F>::W;
@@ -95,6 +97,24 @@ static int curve_sum(int mode, const uint32_t* pts, const uint8_t* inf, size_t n
       Affine<F> a = ld_aff<F>(pts + W2 * i);
       acc = (i & 1) ? add_mixed_signed(acc, neg_affine(a), true) : add_mixed_signed(acc, a, false);
     }
+  } else if (mode == 8) {
+    std::vector<XYZZ<F>> v;
+    XYZZ<F> part = XYZZ<F>::identity();
+    size_t cnt = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (!(inf && inf[i])) {
+        Affine<F> a = ld_aff<F>(pts + W2 * i);
+        part = (i & 1) ? add_mixed_signed(part, neg_affine(a), true) : add_mixed_signed(part, a, false);
+      }
+      if (++cnt == 3 || i + 1 == n) { v.push_back(part); part = XYZZ<F>::identity(); cnt = 0; }
+    }
+    while (v.size() > 1) {
+      std::vector<XYZZ<F>> w;
+      for (size_t i = 0; i + 1 < v.size(); i += 2) w.push_back(add_xyzz(v[i], v[i + 1]));
+      if (v.size() & 1) w.push_back(v.back());
+      v.swap(w);
+    }
+    if (!v.empty()) acc = v[0];
   } else if (mode == 1) {
     std::vector<XYZZ<F>> v;
     for (size_t i = 0; i < n; ++i) v.push_back((inf && inf[i]) ? XYZZ<F>::identity() : from_affine(ld_aff<F>(pts + W2 * i)));

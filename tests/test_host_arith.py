@@ -111,7 +111,7 @@ def _check_point_formulas(hostlib, pyoracle, name):
                 if not f:
                     exp = cur.add(exp, pt)
             for chk in (0, 1):
-                for mode in (0, 1, 2, 7):
+                for mode in (0, 1, 2, 7, 8):
                     assert curve_sum(hostlib, cid, cur, chk, mode, pts, inf) == exp, (name, ci, some_inf, chk, mode)
                 assert curve_sum(hostlib, cid, cur, chk, 5, pts, inf) == cur.neg(exp)
                 assert curve_sum(hostlib, cid, cur, chk, 3, pts, inf) == cur.add(exp, exp), (name, ci, "dbl")
