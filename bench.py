@@ -20,7 +20,7 @@ SEED = 0x4B6F676172617368
 LOG_N = 20
 G1_BYTES_PER_PAIR = 96          # 32 B scalar + 64 B affine base
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
-MADD_PEAK_G = 14.8              # measured: mixed XYZZ additions/s per chip, operands in registers (profiles/r01_mul_rate.txt)
+MADD_PEAK_G = 16.5              # measured: the bucket kernel's addition routine, operands in registers, 4 waves/SIMD (profiles/r01_mul_rate.txt)
 
 
 def window_adds(n):
@@ -177,7 +177,7 @@ def pmc_traffic(log_n):
     """Memory-side bytes per k_acc_tasks launch from the committed rocprofv3 --pmc passes (profiles/): FETCH_SIZE and
     WRITE_SIZE are collected in separate runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     for gfx950.  Only valid for the configuration it was measured on (2^20 pairs); null otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_l_pmc_hbm.json")
+    path = os.path.join(ROOT, "profiles", "r01_m_pmc_hbm.json")
     if log_n != LOG_N or not os.path.exists(path):
         return None
     with open(path) as f:

@@ -7,7 +7,7 @@ using namespace kg;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 template <int KIND>
-__global__ void __launch_bounds__(256) k_field(uint32_t* out, int iters) {
+__global__ void __launch_bounds__(64) k_field(uint32_t* out, int iters) {
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   Fq a = Fq::one(), b = Fq::from_const(FqParams::G1_B3);
   a.l[0] += tid & 0xffff; b.l[1] ^= tid & 0xfff;
@@ -17,8 +17,9 @@ __global__ void __launch_bounds__(256) k_field(uint32_t* out, int iters) {
   else if constexpr (KIND == 3) {
     XYZZ<Fq> p = from_affine(Affine<Fq>{a, b});
     Affine<Fq> q{b, a};
-    for (int i = 0; i < iters; ++i) { p = add_mixed(p, q); q.x.l[0] ^= 1; }
-    a = p.x;
+    // the bucket kernel's routine (sign folded, X not value-reduced), operands in registers
+    for (int i = 0; i < iters; ++i) { p = add_mixed_signed(p, q, (i & 1) != 0); q.x.l[0] ^= 1; }
+    a = norm(add(p.x, p.zzz));
   } else if constexpr (KIND == 4) { for (int i = 0; i < iters; ++i) a = vred(norm(sub<4, 1>(a, b))); }
   uint32_t s = 0;
   for (int k = 0; k < 9; ++k) s += a.l[k];
@@ -64,11 +65,11 @@ int main() {
   for (int wps : {1, 2, 3, 4, 5, 6, 8}) {
     int blocks = 256 * wps, iters = 2000;
     float ms;
-    ms = time_it([&] { k_field<0><<<blocks, 256>>>(d, iters); }); printf("%-24s w/SIMD=%d %8.3f ms  %8.2f Gop/s\n", fn[0], wps, ms, (double)blocks * 256 * iters / ms * 1e-6);
-    ms = time_it([&] { k_field<1><<<blocks, 256>>>(d, iters); }); printf("%-24s w/SIMD=%d %8.3f ms  %8.2f Gop/s\n", fn[1], wps, ms, (double)blocks * 256 * iters / ms * 1e-6);
-    ms = time_it([&] { k_field<2><<<blocks, 256>>>(d, iters); }); printf("%-24s w/SIMD=%d %8.3f ms  %8.2f Gop/s\n", fn[2], wps, ms, (double)blocks * 256 * iters * 2 / ms * 1e-6);
-    ms = time_it([&] { k_field<3><<<blocks, 256>>>(d, 200); }); printf("%-24s w/SIMD=%d %8.3f ms  %8.2f Gop/s\n", fn[3], wps, ms, (double)blocks * 256 * 200 / ms * 1e-6);
-    ms = time_it([&] { k_field<4><<<blocks, 256>>>(d, iters); }); printf("%-24s w/SIMD=%d %8.3f ms  %8.2f Gop/s\n", fn[4], wps, ms, (double)blocks * 256 * iters / ms * 1e-6);
+    ms = time_it([&] { k_field<0><<<blocks * 4, 64>>>(d, iters); }); printf("%-24s w/SIMD=%d %8.3f ms  %8.2f Gop/s\n", fn[0], wps, ms, (double)blocks * 256 * iters / ms * 1e-6);
+    ms = time_it([&] { k_field<1><<<blocks * 4, 64>>>(d, iters); }); printf("%-24s w/SIMD=%d %8.3f ms  %8.2f Gop/s\n", fn[1], wps, ms, (double)blocks * 256 * iters / ms * 1e-6);
+    ms = time_it([&] { k_field<2><<<blocks * 4, 64>>>(d, iters); }); printf("%-24s w/SIMD=%d %8.3f ms  %8.2f Gop/s\n", fn[2], wps, ms, (double)blocks * 256 * iters * 2 / ms * 1e-6);
+    ms = time_it([&] { k_field<3><<<blocks * 4, 64>>>(d, 200); }); printf("%-24s w/SIMD=%d %8.3f ms  %8.2f Gop/s\n", fn[3], wps, ms, (double)blocks * 256 * 200 / ms * 1e-6);
+    ms = time_it([&] { k_field<4><<<blocks * 4, 64>>>(d, iters); }); printf("%-24s w/SIMD=%d %8.3f ms  %8.2f Gop/s\n", fn[4], wps, ms, (double)blocks * 256 * iters / ms * 1e-6);
   }
   const char* on[] = {"v_lshrrev_b64", "v_ashrrev_i64", "v_and_b32", "v_alignbit_b32", "v_add3_u32", "v_mov_b32", "v_mad_i64_i32", "v_lshl_add_u64", "v_add_u32", "v_lshrrev_b32", "v_and_or_b32"};
   int blocks = 1024, iters = 4096;
