@@ -7,7 +7,7 @@
 //
 //   prep      scalars -> canonical integers k (one Montgomery product) biased by H = sum_w 2^(wc+c-1), so
 //             every window's SIGNED digit is a plain bit-field of k+H (halves the bucket count);
-//             bases -> internal Montgomery form, packed 64 B/point, identity flag folded into a spare bit
+//             bases -> internal Montgomery form as 9-limb coordinates (72 B per G1 point), identity flag in a spare bit
 //   count     one workgroup per (scalar chunk, window): the window's whole histogram (2^(c-1) counters,
 //   scan      up to 128 KiB) lives in LDS -- a single-pass counting sort with a 15-bit digit
 //   scatter   -> per-bucket lists of (point index | sign)
@@ -101,42 +101,60 @@ __global__ void __launch_bounds__(1024) k_prep_scalars_count(const uint64_t* __r
   }
 }
 
-template <class P>
-__device__ __forceinline__ void pack_internal(const Fp<P>& a, uint32_t w[8]) { words_from_limbs(reduce_2p(a), w); }
-template <class P>
-__device__ __forceinline__ Fp<P> unpack_internal(const uint32_t w[8]) { return limbs_from_words<P>(w); }
-
+// Resident form of a base: the 9 x 29-bit limbs of each coordinate as they are (internal Montgomery form, < 2p), i.e. 72
+// bytes per G1 / Grumpkin point and 144 per G2 point instead of the ABI's 64 / 128.  The gather pays 12.5 % more bytes
+// -- it is not what bounds the accumulation -- and the ~50 shift / mask instructions per addition that re-spread 8
+// words over 9 limbs disappear.  The identity flag rides in bit 31 of the first coordinate's top limb (< 2^23).
 template <class F> struct BaseIO;
 template <class P> struct BaseIO<Fp<P>> {
-  static constexpr int W = 8;   // u32 words per packed base-field element
-  static __device__ __forceinline__ void convert(const uint64_t* src, uint32_t* dst) {   // ABI -> packed internal
-    uint32_t w[8], o[8];
+  static constexpr int W = 8;    // u32 words of an element in the ABI (= u64 words of a point)
+  static constexpr int PE = 9;   // u32 words of a resident element
+  static __device__ __forceinline__ void convert(const uint64_t* src, uint32_t* dst) {   // ABI -> resident
+    uint32_t w[8];
     load_words(src, 0, w);
-    pack_internal(from_ref<P>(w), o);
+    const Fp<P> v = from_ref<P>(w);                  // normalised limbs, < 2p
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dst[j] = o[j];
+    for (int j = 0; j < 9; ++j) dst[j] = v.l[j];
   }
-  static __device__ __forceinline__ Fp<P> load(const uint32_t* src) {
-    const uint4* p = reinterpret_cast<const uint4*>(src);
-    uint4 a = p[0], b = p[1];
-    uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w & ~INF_BIT};
-    return unpack_internal<P>(w);
+  static __device__ __forceinline__ Fp<P> from_words(const uint32_t* w) {
+    Fp<P> r;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) r.l[j] = w[j];
+    return r;
+  }
+  // whole point (x | y, 18 words at an 8-byte aligned address); returns the identity flag
+  static __device__ __forceinline__ bool load_point(const uint32_t* src, Fp<P>& x, Fp<P>& y) {
+    uint32_t w[18];
+    const uint2* p = reinterpret_cast<const uint2*>(src);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { const uint2 v = p[j]; w[2 * j] = v.x; w[2 * j + 1] = v.y; }
+    const bool inf = (w[8] & INF_BIT) != 0;
+    w[8] &= ~INF_BIT;
+    x = from_words(w); y = from_words(w + 9);
+    return inf;
   }
 };
 template <class F> struct BaseIO<Fp2<F>> {
   static constexpr int W = 16;
+  static constexpr int PE = 18;
   static __device__ __forceinline__ void convert(const uint64_t* src, uint32_t* dst) {
     BaseIO<F>::convert(src, dst);
-    BaseIO<F>::convert(src + 4, dst + 8);
+    BaseIO<F>::convert(src + 4, dst + 9);
   }
-  static __device__ __forceinline__ Fp2<F> load(const uint32_t* src) { return {BaseIO<F>::load(src), BaseIO<F>::load(src + 8)}; }
+  // whole point (x.c0 | x.c1 | y.c0 | y.c1, 36 words at a 16-byte aligned address)
+  static __device__ __forceinline__ bool load_point(const uint32_t* src, Fp2<F>& x, Fp2<F>& y) {
+    uint32_t w[36];
+    const uint4* p = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { const uint4 v = p[j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
+    const bool inf = (w[8] & INF_BIT) != 0;
+    w[8] &= ~INF_BIT;
+    x = {BaseIO<F>::from_words(w), BaseIO<F>::from_words(w + 9)};
+    y = {BaseIO<F>::from_words(w + 18), BaseIO<F>::from_words(w + 27)};
+    return inf;
+  }
 };
 
-// lane-pair Fq2 (fp2s.h): a lane moves its own coordinate only
-template <class F> struct BaseIO<Fp2S<F>> {
-  static constexpr int W = 16;
-  static __device__ __forceinline__ Fp2S<F> load(const uint32_t* src) { return {BaseIO<F>::load(src + 8 * Fp2S<F>::half())}; }
-};
 }  // namespace
 namespace kg {
 template <class F> struct RawIO<Fp2S<F>> {
@@ -151,20 +169,20 @@ template <class F> struct RawIO<Fp2S<F>> {
 }  // namespace kg
 namespace {
 
-// bases: ABI affine (x | y) -> packed internal (x | y), 2*W words per point; identity flag -> INF_BIT of x
+// bases: ABI affine (x | y) -> resident form (limbs of x | limbs of y), 2*PE words per point; identity flag -> INF_BIT
 template <class F>
 __global__ void __launch_bounds__(256) k_prep_bases(const uint64_t* __restrict__ bases, const uint8_t* __restrict__ inf, size_t n,
                                                     uint32_t* __restrict__ out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  constexpr int W = BaseIO<F>::W;
-  uint32_t buf[2 * W];
+  constexpr int W = BaseIO<F>::W, PE = BaseIO<F>::PE;
+  uint32_t buf[2 * PE];
   BaseIO<F>::convert(bases + (size_t)i * W, buf);            // W u32 words == W/2 u64 words per element
-  BaseIO<F>::convert(bases + (size_t)i * W + W / 2, buf + W);
-  if (inf && inf[i]) buf[7] |= INF_BIT;
-  uint4* dst = reinterpret_cast<uint4*>(out + (size_t)i * 2 * W);
+  BaseIO<F>::convert(bases + (size_t)i * W + W / 2, buf + PE);
+  if (inf && inf[i]) buf[8] |= INF_BIT;
+  uint2* dst = reinterpret_cast<uint2*>(out + (size_t)i * 2 * PE);
 #pragma unroll
-  for (int j = 0; j < 2 * W / 4; ++j) dst[j] = make_uint4(buf[4 * j], buf[4 * j + 1], buf[4 * j + 2], buf[4 * j + 3]);
+  for (int j = 0; j < PE; ++j) dst[j] = make_uint2(buf[2 * j], buf[2 * j + 1]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -810,15 +828,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
   const uint32_t len_all = bsize[bi];
   const uint32_t lo = seg * T, hi = lo + T < len_all ? lo + T : len_all;
   const uint32_t* list = sorted + (size_t)w * n + bstart[bi];
-  constexpr int PW = 2 * BaseIO<F>::W;
+  constexpr int PW = 2 * BaseIO<F>::PE;
   XYZZ<F> acc = XYZZ<F>::identity();
   for (uint32_t j = lo; j < hi; ++j) {
     const uint32_t e = list[j];
     const uint32_t idx = e & 0x7fffffffu;
     if (idx < idx_off) continue;                         // scalars in front of this base array (shared sort, z = x || w)
-    const uint32_t* src = pbases + (size_t)(idx - idx_off) * PW;
-    if (src[7] & INF_BIT) continue;                      // identity base (msm.rs:58-64 adds it as a no-op)
-    const Affine<F> a{BaseIO<F>::load(src), BaseIO<F>::load(src + BaseIO<F>::W)};
+    Affine<F> a;
+    if (BaseIO<F>::load_point(pbases + (size_t)(idx - idx_off) * PW, a.x, a.y)) continue;   // identity base (msm.rs:58-64 adds it as a no-op)
     acc = add_mixed_signed(acc, a, (e & 0x80000000u) != 0);
   }
   PointAoS<F>::store(partial, t, acc);
@@ -1089,7 +1106,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
   using F = typename Cfg::F;
   using KF = typename Cfg::KF;                      // field type of the reduction kernels (Fq2: a lane pair per task, fp2s.h)
   constexpr unsigned LPT = Lanes<KF>::N;            // lanes per task
-  constexpr int PW = 2 * BaseIO<F>::W;              // packed words per base
+  constexpr int PW = 2 * BaseIO<F>::PE;             // resident words per base
   constexpr int NW = PointIO<F>::NW;                // raw words per XYZZ point
   if (njobs < 1 || njobs > MAX_FUSED) return set_err(ctx, KG_ERR_BAD_ARG, "bad number of fused base arrays");
   const int W = S.W, B = S.B, c = S.c;
@@ -1314,7 +1331,7 @@ int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uin
   if (!d_bases) return KG_ERR_BAD_ARG;
   KG_HIP(ctx, hipSetDevice(ctx->device));
   kg_bases_unregister(ctx, d_bases);
-  const size_t pw = curve == KG_G2 ? 32 : 16;
+  const size_t pw = curve == KG_G2 ? 36 : 18;
   uint32_t* packed = nullptr;
   KG_HIP(ctx, hipMalloc((void**)&packed, n * pw * 4));
   dim3 grid((unsigned)((n + 255) / 256));
