@@ -211,45 +211,18 @@ def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True):
     a real CRS from a fixed toxic waste, generated on the device; fixed (r, s).  The CPU leg runs the oracle's create_proof on the same inputs and compares the proof."""
     import numpy as np
     from kogarashi_amd.lib import Groth16Crs
-    R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    from kogarashi_amd import synthetic as syn
     m = 1 << log_m
-    l, m_l_1 = 2, m
-    t = [0x123456789ABCDEF0123456789ABCDEF % R_MOD]
-    for _ in range(m):
-        t.append(t[-1] * (t[-1] + 1) % R_MOD)
-    mont = lambda v: [((v << 256) % R_MOD >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
-    tm = np.array([mont(v) for v in t], dtype=np.uint64)
-    one = np.array(mont(1), dtype=np.uint64)
-    a_ev = tm[:m].copy()
-    b_ev = np.array([mont((v + 1) % R_MOD) for v in t[:m]], dtype=np.uint64)
-    c_ev = tm[1:].copy()
-    x = np.stack([one, tm[0]])
-    w = tm[1:].copy()
+    cc = syn.ChainCircuit(m)
+    l, m_l_1 = cc.l, cc.m_l_1
+    a_ev, b_ev, c_ev, x, w = cc.a_eval, cc.b_eval, cc.c_eval, cc.x, cc.w
     up = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(dev)
     d_a, d_b, d_c, d_x, d_w = up(a_ev), up(b_ev), up(c_ev), up(x), up(w)
-    nv = l + m_l_1
     # a REAL CRS for this circuit: ZkSnark::setup composed from the device primitives (kogarashi_amd.api.groth16_setup,
     # parity-tested against the oracle in tests/test_gpu_groth16.py), toxic waste fixed
     from kogarashi_amd.api import groth16_setup
-    wire = np.concatenate([[1], 2 + np.arange(m, dtype=np.uint64)]).astype(np.uint64)     # t_0 is instance wire 1, t_i (i > 0) witness i-1
-    ones = np.tile(one, (m, 1))
-    a_csr = (np.arange(m + 1, dtype=np.uint64), wire[:m].copy(), ones)
-    b_col = np.empty(2 * m, dtype=np.uint64)
-    b_col[0::2] = wire[:m]
-    b_col[1::2] = 0
-    b_csr = (np.arange(0, 2 * m + 1, 2, dtype=np.uint64), b_col, np.tile(one, (2 * m, 1)))
-    c_csr = (np.arange(m + 1, dtype=np.uint64), wire[1:].copy(), ones)
-
-    class FrOps:       # the five host-side scalars of the setup, in plain Python integers
-        to_i = staticmethod(lambda v: (sum(int(x) << (64 * j) for j, x in enumerate(v)) * pow(1 << 256, -1, R_MOD)) % R_MOD)
-        to_m = staticmethod(lambda i: np.array(mont(i), dtype=np.uint64))
-        one = staticmethod(lambda: one)
-        inv = classmethod(lambda cls, x: cls.to_m(pow(cls.to_i(x), -1, R_MOD)))
-        mul = classmethod(lambda cls, x, y: cls.to_m(cls.to_i(x) * cls.to_i(y) % R_MOD))
-        sub = classmethod(lambda cls, x, y: cls.to_m((cls.to_i(x) - cls.to_i(y)) % R_MOD))
-        pow2k = classmethod(lambda cls, x, k: cls.to_m(pow(cls.to_i(x), 1 << k, R_MOD)))
-
-    toxic = np.array([mont((0xA11CE + 0x9E3779B97F4A7C15 * (j + 1)) ** 3 % R_MOD) for j in range(5)], dtype=np.uint64)
+    a_csr, b_csr, c_csr, FrOps = cc.a, cc.b, cc.c, syn.FrOps
+    toxic = syn.fixed_toxic()
     P = groth16_setup(a_csr, b_csr, c_csr, m, l, m_l_1, toxic, FrOps, ctx=ctx)
     dev_arr = {name: up(P[name]) for name in ("h", "l", "a", "b_g1", "b_g2")}
     dev_inf = {name: (torch.from_numpy(P[name + "_inf"]).to(dev) if P[name + "_inf"].any() else None) for name in ("h", "l", "a", "b_g1", "b_g2")}
@@ -267,8 +240,7 @@ def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True):
         crs.alpha_g1[i], crs.beta_g1[i], crs.delta_g1[i] = int(vk_g1[0, i]), int(vk_g1[1, i]), int(vk_g1[2, i])
     for i in range(16):
         crs.beta_g2[i], crs.delta_g2[i] = int(vk_g2[0, i]), int(vk_g2[1, i])
-    r = np.array(mont(0x1111111111111111222222222222222233333333333333334444444444444 % R_MOD), dtype=np.uint64)
-    s_ = np.array(mont(0x5555555555555555666666666666666677777777777777778888888888888 % R_MOD), dtype=np.uint64)
+    r, s_ = syn.fixed_rs()
     args_ = (crs, d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), d_x.data_ptr(), d_w.data_ptr(), r, s_)
     prove = lambda: ctx.groth16_prove(*args_)
     proof = prove()

@@ -120,12 +120,17 @@ int kg_points_sum_affine(kg_ctx* ctx, int curve, const uint64_t* h_points_xy, co
 /* Resident bases (CRS vectors, commitment keys): registering an array converts it ONCE to the device's internal form
  * (the reference re-reads and re-converts its bases on every call).  Afterwards every entry point that is handed a
  * pointer inside a registered array (kg_msm, kg_msm_begin, kg_commit, kg_groth16_prove_bn254; any whole-point offset,
- * e.g. params.a[cs.l()..]) skips the per-call conversion.  The caller must not modify a registered array;
- * d_inf (may be NULL) is captured at registration.  kg_bases_unregister(d_bases) releases it. */
+ * e.g. params.a[cs.l()..]) skips the per-call conversion.  The caller must not modify a registered array or its
+ * flag array; the resident copy is used when a call passes the registered flag array at the same offset (or NULL
+ * where NULL was registered) -- any other d_inf is honoured by converting per call.  kg_bases_unregister(d_bases)
+ * releases it. */
 int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t n);
 int kg_bases_unregister(kg_ctx* ctx, const uint64_t* d_bases);
 /* Tuning knob: window width c (0 = automatic). */
 int kg_msm_set_window(kg_ctx* ctx, int c);
+/* The automatic rule: window width c for n pairs (W = ceil(255 / c) signed windows of 2^(c-1) buckets; the reference's
+ * rule is groth16/src/msm.rs:7-14).  Pure function: needs no device and no context. */
+int kg_msm_pick_window(size_t n);
 
 /* ---- fixed-base multiples ------------------------------------------------------------------------
  * out[i] = affine(generator * k[i]): the `(g * scalar).into()` of the CRS construction (groth16/src/zksnark.rs:57,

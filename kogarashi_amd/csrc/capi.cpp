@@ -4,9 +4,17 @@
 using namespace kg;
 
 namespace kg {
+// Every queue of the context drained: before a work space is released, and around profiling resets.  (The sort space is
+// read on the main queue only today; draining all of them keeps a future side-queue reader safe.)
+void sync_all(kg_ctx* c) {
+  hipStreamSynchronize(c->stream);
+  if (c->own_stream && c->own_stream != c->stream) hipStreamSynchronize(c->own_stream);
+  for (hipStream_t s : {c->side_stream, c->side2_stream, c->aux_stream, c->aux2_stream})
+    if (s) hipStreamSynchronize(s);
+}
 int ensure_ws(kg_ctx* c, size_t bytes) {
   if (bytes <= c->ws_bytes) return KG_OK;
-  if (c->ws) { hipStreamSynchronize(c->stream); hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
+  if (c->ws) { sync_all(c); hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
   size_t want = bytes + bytes / 8;
   hipError_t e = hipMalloc(&c->ws, want);
   if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "workspace allocation", e);
@@ -15,7 +23,7 @@ int ensure_ws(kg_ctx* c, size_t bytes) {
 }
 int ensure_ws2(kg_ctx* c, size_t bytes) {
   if (bytes <= c->ws2_bytes) return KG_OK;
-  if (c->ws2) { hipStreamSynchronize(c->stream); hipFree(c->ws2); c->ws2 = nullptr; c->ws2_bytes = 0; }
+  if (c->ws2) { sync_all(c); hipFree(c->ws2); c->ws2 = nullptr; c->ws2_bytes = 0; }
   hipError_t e = hipMalloc(&c->ws2, bytes);
   if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "ntt buffer allocation", e);
   c->ws2_bytes = bytes;
@@ -23,7 +31,7 @@ int ensure_ws2(kg_ctx* c, size_t bytes) {
 }
 int ensure_ws3(kg_ctx* c, size_t bytes) {
   if (bytes <= c->ws3_bytes) return KG_OK;
-  if (c->ws3) { hipStreamSynchronize(c->stream); hipFree(c->ws3); c->ws3 = nullptr; c->ws3_bytes = 0; }
+  if (c->ws3) { sync_all(c); hipFree(c->ws3); c->ws3 = nullptr; c->ws3_bytes = 0; }
   hipError_t e = hipMalloc(&c->ws3, bytes);
   if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "prover buffer allocation", e);
   c->ws3_bytes = bytes;
@@ -32,9 +40,7 @@ int ensure_ws3(kg_ctx* c, size_t bytes) {
 int ensure_ws_run(kg_ctx* c, int which, size_t bytes) {
   if (bytes <= c->ws_run_bytes[which]) return KG_OK;
   if (c->ws_run[which]) {
-    hipStreamSynchronize(c->stream);
-    if (c->side_stream) hipStreamSynchronize(c->side_stream);
-    if (c->side2_stream) hipStreamSynchronize(c->side2_stream);
+    sync_all(c);
     hipFree(c->ws_run[which]);
     c->ws_run[which] = nullptr; c->ws_run_bytes[which] = 0;
   }
@@ -84,7 +90,7 @@ static hipEvent_t next_event(kg_ctx* c) {
   }
   return c->event_pool[c->event_next++];
 }
-void prof_reset(kg_ctx* c) { c->phases.clear(); c->event_next = 0; c->host_finish_ms = 0.f; c->host_finish_calls = 0; }
+void prof_reset(kg_ctx* c) { c->phases.clear(); c->event_next = 0; c->host_finish_us = 0; c->host_finish_calls = 0; }
 PhaseScope::PhaseScope(kg_ctx* ctx, const char* name, hipStream_t stream) : c(ctx), s(stream ? stream : ctx->stream) {
   if (!c->prof) return;
   kg_ctx::Phase p{name, next_event(c), next_event(c)};
@@ -167,14 +173,22 @@ const char* kg_last_error(kg_ctx* c) { return c ? c->last_error.c_str() : "null 
 
 int kg_ctx_set_stream(kg_ctx* c, void* s) {
   if (!c) return KG_ERR_BAD_ARG;
-  c->stream = s ? (hipStream_t)s : c->own_stream;
+  hipStream_t next = s ? (hipStream_t)s : c->own_stream;
+  if (next != c->stream) {
+    // work queued on the outgoing stream may still use the context's work spaces: the new stream has no ordering
+    // against it, so drain it (a stream switch is a set-up step, not a hot-path call)
+    KG_HIP(c, hipSetDevice(c->device));
+    KG_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = next;
+  }
   return KG_OK;
 }
 int kg_ctx_sync(kg_ctx* c) {
   if (!c) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipSetDevice(c->device));
   KG_HIP(c, hipStreamSynchronize(c->stream));
-  if (c->side_stream) KG_HIP(c, hipStreamSynchronize(c->side_stream));
-  if (c->side2_stream) KG_HIP(c, hipStreamSynchronize(c->side2_stream));
+  for (hipStream_t s : {c->side_stream, c->side2_stream, c->aux_stream, c->aux2_stream})
+    if (s) KG_HIP(c, hipStreamSynchronize(s));
   return KG_OK;
 }
 int kg_malloc(kg_ctx* c, size_t bytes, void** p) {
@@ -186,6 +200,7 @@ int kg_malloc(kg_ctx* c, size_t bytes, void** p) {
 int kg_free(kg_ctx* c, void* p) {
   if (!c) return KG_ERR_BAD_ARG;
   if (p) {
+    KG_HIP(c, hipSetDevice(c->device));
     kg_bases_unregister(c, (const uint64_t*)p);     // a freed array must never be served from its registration
     KG_HIP(c, hipFree(p));
   }
@@ -193,18 +208,21 @@ int kg_free(kg_ctx* c, void* p) {
 }
 int kg_memcpy_h2d(kg_ctx* c, void* d, const void* h, size_t bytes) {
   if (!c || (bytes && (!d || !h))) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipSetDevice(c->device));
   KG_HIP(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
   KG_HIP(c, hipStreamSynchronize(c->stream));
   return KG_OK;
 }
 int kg_memcpy_d2h(kg_ctx* c, void* h, const void* d, size_t bytes) {
   if (!c || (bytes && (!d || !h))) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipSetDevice(c->device));
   KG_HIP(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
   KG_HIP(c, hipStreamSynchronize(c->stream));
   return KG_OK;
 }
 int kg_memcpy_d2d(kg_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c || (bytes && (!dst || !src))) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipSetDevice(c->device));
   KG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
   return KG_OK;
 }
@@ -215,8 +233,8 @@ int kg_msm_set_window(kg_ctx* c, int w) {
 }
 int kg_profile_enable(kg_ctx* c, int on) {
   if (!c) return KG_ERR_BAD_ARG;
-  hipStreamSynchronize(c->stream);
-  if (c->side_stream) hipStreamSynchronize(c->side_stream);
+  hipSetDevice(c->device);
+  sync_all(c);                   // events still pending on any queue must not be re-recorded by the reset below
   c->prof = on != 0;
   prof_reset(c);                 // phases accumulate from here until the next enable / disable
   return KG_OK;
@@ -226,11 +244,8 @@ int kg_profile_last(kg_ctx* c, const char** names, float* ms, int cap) {
 }
 int kg_profile_summary(kg_ctx* c, const char** names, float* total_ms, int* counts, int cap) {
   if (!c) return KG_ERR_BAD_ARG;
-  hipStreamSynchronize(c->stream);
-  if (c->side_stream) hipStreamSynchronize(c->side_stream);
-  if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
-  if (c->aux2_stream) hipStreamSynchronize(c->aux2_stream);
-  if (c->side2_stream) hipStreamSynchronize(c->side2_stream);
+  hipSetDevice(c->device);
+  sync_all(c);
   if (getenv("KG_PROFILE_TIMELINE") && !c->phases.empty()) {     // debugging aid: phase start / end relative to the first phase
     for (auto& p : c->phases) {
       float a = 0, b = 0;
@@ -251,7 +266,7 @@ int kg_profile_summary(kg_ctx* c, const char** names, float* total_ms, int* coun
     tot[k] += t;
     cnt[k] += 1;
   }
-  if (c->host_finish_calls) { nm.push_back("host_finish"); tot.push_back(c->host_finish_ms); cnt.push_back(c->host_finish_calls); }
+  if (c->host_finish_calls) { nm.push_back("host_finish"); tot.push_back((float)c->host_finish_us.load() * 1e-3f); cnt.push_back(c->host_finish_calls.load()); }
   for (size_t k = 0; k < nm.size() && n < cap; ++k, ++n) {
     if (names) names[n] = nm[k];
     if (total_ms) total_ms[n] = tot[k];

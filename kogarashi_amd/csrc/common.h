@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <atomic>
 #include <cstdio>
 #include <string>
 #include <memory>
@@ -38,7 +39,7 @@ struct kg_ctx {
   Slot slots[NSLOTS];
   std::shared_ptr<void> prover_jobs;     // groth16.hip: proofs in flight (kg_groth16_prove_begin / _end)
   size_t ticket_n[4] = {0, 0, 0, 0};
-  struct Registered { const uint64_t* base; size_t n; int curve; uint32_t* packed; };
+  struct Registered { const uint64_t* base; const uint8_t* inf; size_t n; int curve; uint32_t* packed; };
   std::vector<Registered> registered;    // bases converted once by kg_bases_register     // lengths of the MSMs begun with kg_msm_begin                         // pinned result slots: MSMs in flight whose host finish is pending
   void* h_pinned = nullptr;              // small pinned staging buffer for results
   size_t h_pinned_bytes = 0;
@@ -49,8 +50,8 @@ struct kg_ctx {
   std::vector<Phase> phases;
   std::vector<hipEvent_t> event_pool;
   size_t event_next = 0;
-  float host_finish_ms = 0.f;            // summed wall time of the host finishes (double-and-add + inversion) since the last reset
-  int host_finish_calls = 0;
+  std::atomic<long long> host_finish_us{0};   // summed wall time of the host finishes (double-and-add + inversion) since the last
+  std::atomic<int> host_finish_calls{0};      // reset; atomics: a prover's finishes run on up to five worker threads at once
 };
 
 namespace kg {
@@ -80,6 +81,7 @@ int ensure_ws_run(kg_ctx* c, int which, size_t bytes);
 int ensure_slot(kg_ctx* c, int slot, size_t bytes);
 int ensure_pinned(kg_ctx* c, size_t bytes);
 int make_side_stream(kg_ctx* c);
+void sync_all(kg_ctx* c);
 
 // RAII-free phase timer: PhaseScope p(ctx, "name"); ... p.end();
 struct PhaseScope {

@@ -255,8 +255,13 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
     if (rc == KG_OK && m_l_1) f_l = finish_async(KG_G1, SL[3], l_p);
     else msm_identity(KG_G1, l_p);
   }
+  // From here on host finishes may already be running on worker threads: no early return -- every failure travels
+  // through rc into the assembly task below, which joins all of them before it reports.
+  auto hip_rc = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == KG_OK) rc = set_err(ctx, e == hipErrorOutOfMemory ? KG_ERR_OOM : KG_ERR_HIP, what, e);
+  };
   // h = (a o b - c) / Z on the coset, back to coefficients (prover.rs:43-47), then its MSM
-  for (int v = 0; v < 3; ++v) KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join[v], 0));
+  for (int v = 0; v < 3; ++v) hip_rc(hipStreamWaitEvent(st, ctx->ev_join[v], 0), "hipStreamWaitEvent(join)");
   // (7^n - 1)^-1 on the host: n = 2^k squarings of 7
   HostFr seven = HostFr::one();
   {
@@ -270,7 +275,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   Words8 zw;
   for (int i = 0; i < 4; ++i) { zw.w[2 * i] = (uint32_t)z.v[i]; zw.w[2 * i + 1] = (uint32_t)(z.v[i] >> 32); }
   hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, C, n, zw);
-  KG_HIP(ctx, hipGetLastError());
+  hip_rc(hipGetLastError(), "k_qap_combine launch");
   if (rc == KG_OK) rc = ntt_enqueue(ctx, st, (uint64_t*)ctx->ws2, A, k, 1, 1);   // coset_idft (prover.rs:47)
   if (rc == KG_OK && hn) {
     MsmSorted Sq;
@@ -284,7 +289,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   for (int i = 0; i < 4; ++i) { rr[i] = r[i]; ss[i] = s[i]; }
   const kg_groth16_crs vk = *crs;                       // the host-resident part (alpha, beta, delta) is read by value
   job->active = true;
-  job->assembly = std::async(std::launch::async, [ctx, job, vk, rr, ss, rc0 = rc]() -> int {
+  job->assembly = std::async(std::launch::async, [job, vk, rr, ss, rc0 = rc]() -> int {
     int rc = rc0;
     uint64_t *q_p = job->q_p, *l_p = job->l_p, *ai = job->ai, *b1i = job->b1i, *b2i = job->b2i;
     HostFr rm = HostFr::from_words(rr), sm = HostFr::from_words(ss);
@@ -325,7 +330,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
     }
     join(job->f_q);
     if (rc != KG_OK) return rc;
-    if (bad_delta) return set_err(ctx, KG_ERR_CRS, "delta is the identity");   // prover.rs:67-69
+    if (bad_delta) return KG_ERR_CRS;                     // prover.rs:67-69 (the message is set by prove_collect, on the caller's thread)
     g_c = add_xyzz(g_c, g1pt(q_p));                                                                        // :92 (h part)
     h_store_affine<HostFq, 4>(g_c, job->proof + 24, job->inf + 2);
     return KG_OK;
@@ -333,10 +338,11 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   return KG_OK;
 }
 
-int prove_collect(ProofJob* job, uint64_t* proof_out, uint8_t* proof_inf) {
+int prove_collect(kg_ctx* ctx, ProofJob* job, uint64_t* proof_out, uint8_t* proof_inf) {
   if (!job->active) return KG_ERR_BAD_ARG;
   job->active = false;
   const int rc = job->assembly.get();
+  if (rc == KG_ERR_CRS) return set_err(ctx, KG_ERR_CRS, "delta is the identity");
   if (rc != KG_OK) return rc;
   for (int i = 0; i < 32; ++i) proof_out[i] = job->proof[i];
   for (int i = 0; i < 3; ++i) proof_inf[i] = job->inf[i];
@@ -353,7 +359,7 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   ProofJob* job = job_of(ctx, 0);
   if (job->active) return KG_ERR_BAD_ARG;                // a proof begun with ticket 0 has not been collected
   KG_TRY(prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job, 5));
-  return prove_collect(job, proof_out, proof_inf);
+  return prove_collect(ctx, job, proof_out, proof_inf);
 }
 
 // Two proofs in flight (tickets 0 and 1): begin(i + 1) may be called before end(i), so that the next proof's transforms
@@ -367,7 +373,7 @@ int kg_groth16_prove_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
 }
 int kg_groth16_prove_end(kg_ctx* ctx, int ticket, uint64_t* proof_out, uint8_t* proof_inf) {
   if (!ctx || ticket < 0 || ticket > 1 || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
-  return prove_collect(job_of(ctx, ticket), proof_out, proof_inf);
+  return prove_collect(ctx, job_of(ctx, ticket), proof_out, proof_inf);
 }
 
 }  // extern "C"

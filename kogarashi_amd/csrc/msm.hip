@@ -1127,7 +1127,13 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
     for (const auto& r : ctx->registered) {
       if (r.curve != Cfg::ID || J.d_bases < r.base) continue;
       const size_t off64 = (size_t)(J.d_bases - r.base);
-      if (off64 % (size_t)BaseIO<F>::W == 0 && off64 / BaseIO<F>::W + J.nbases <= r.n) { reg_pb = r.packed + (off64 / BaseIO<F>::W) * PW; break; }
+      if (off64 % (size_t)BaseIO<F>::W != 0 || off64 / BaseIO<F>::W + J.nbases > r.n) continue;
+      // the identity flags were baked in at registration: the resident copy serves the call only when the call's flag
+      // array is the registered one (same offset), or both are absent; any other combination converts per call
+      const size_t off = off64 / BaseIO<F>::W;
+      if (J.d_inf != (r.inf ? r.inf + off : nullptr)) continue;
+      reg_pb = r.packed + off * PW;
+      break;
     }
     Y.o_pb = cv.take(reg_pb ? 256 : J.nbases * PW * 4);
     for (int i = 0; i < 2; ++i) {
@@ -1255,8 +1261,8 @@ int msm_finish_t(kg_ctx* ctx, int slot, uint64_t* out_xyz) {
     if (l == 0) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c) * PE));
   }
   store_projective<Cfg>(acc, out_xyz);
-  if (ctx->prof) {                                 // (worker threads of the prover may race here: statistics only)
-    ctx->host_finish_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (ctx->prof) {
+    ctx->host_finish_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     ctx->host_finish_calls += 1;
   }
   return KG_OK;
@@ -1325,6 +1331,8 @@ int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf
   return kg::msm_finish(ctx, curve, 0, out_xyz);
 }
 
+int kg_msm_pick_window(size_t n) { return pick_window(n ? n : 1, 0); }
+
 int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t n) {
   if (!ctx || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) return KG_OK;                         // nothing to convert (e.g. an empty CRS vector)
@@ -1338,8 +1346,11 @@ int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uin
   if (curve == KG_G1) hipLaunchKernelGGL(k_prep_bases<Fq>, grid, dim3(256), 0, ctx->stream, d_bases, d_inf, n, packed);
   else if (curve == KG_GRUMPKIN) hipLaunchKernelGGL(k_prep_bases<Fr>, grid, dim3(256), 0, ctx->stream, d_bases, d_inf, n, packed);
   else hipLaunchKernelGGL(k_prep_bases<Fq2>, grid, dim3(256), 0, ctx->stream, d_bases, d_inf, n, packed);
-  KG_HIP(ctx, hipGetLastError());
-  ctx->registered.push_back({d_bases, n, curve, packed});
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+    hipFree(packed);
+    return set_err(ctx, KG_ERR_HIP, "k_prep_bases launch", e);
+  }
+  ctx->registered.push_back({d_bases, d_inf, n, curve, packed});
   return KG_OK;
 }
 

@@ -10,8 +10,8 @@ using namespace kg;
 namespace {
 
 template <class P>
-__global__ void __launch_bounds__(256) k_vec_op(int op, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
-                                                uint64_t* __restrict__ out, size_t n) {
+__global__ void __launch_bounds__(256) k_vec_op(int op, const uint64_t* a, const uint64_t* b,
+                                                uint64_t* out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t wa[8], wb[8], wo[8];
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) k_vec_op(int op, const uint64_t* __restri
 }
 
 template <class P>
-__global__ void __launch_bounds__(256) k_vec_scale(const uint64_t* __restrict__ a, Words8 s, uint64_t* __restrict__ out, size_t n) {
+__global__ void __launch_bounds__(256) k_vec_scale(const uint64_t* a, Words8 s, uint64_t* out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t wa[8], wo[8];
@@ -67,8 +67,8 @@ __global__ void __launch_bounds__(256) k_powers(Words8 start, Words8 base, uint6
 
 // out = a + s * b  (Nova fold, witness.rs:56-70): one product, lazy sum, one canonicalisation per element
 template <class P>
-__global__ void __launch_bounds__(256) k_vec_axpy(const uint64_t* __restrict__ a, Words8 s, const uint64_t* __restrict__ b,
-                                                  uint64_t* __restrict__ out, size_t n) {
+__global__ void __launch_bounds__(256) k_vec_axpy(const uint64_t* a, Words8 s, const uint64_t* b,
+                                                  uint64_t* out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t wa[8], wb[8], wo[8];
@@ -219,6 +219,7 @@ extern "C" {
 int kg_field_vec_op(kg_ctx* c, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
   if (!c || op < 0 || op > KG_OP_TO_MONT || (field != KG_FR && field != KG_FQ)) return KG_ERR_BAD_ARG;
   if (n == 0) return KG_OK;
+  KG_HIP(c, hipSetDevice(c->device));
   const bool binary = (op == KG_OP_ADD || op == KG_OP_SUB || op == KG_OP_MUL);
   if (!a || !out || (binary && !b)) return KG_ERR_BAD_ARG;
   dim3 grid((unsigned)((n + 255) / 256));
@@ -231,6 +232,7 @@ int kg_field_vec_op(kg_ctx* c, int field, int op, const uint64_t* a, const uint6
 int kg_field_vec_scale(kg_ctx* c, int field, const uint64_t* a, const uint64_t* h_s, uint64_t* out, size_t n) {
   if (!c || !h_s || (field != KG_FR && field != KG_FQ)) return KG_ERR_BAD_ARG;
   if (n == 0) return KG_OK;
+  KG_HIP(c, hipSetDevice(c->device));
   if (!a || !out) return KG_ERR_BAD_ARG;
   Words8 s;
   for (int i = 0; i < 4; ++i) { s.w[2 * i] = (uint32_t)h_s[i]; s.w[2 * i + 1] = (uint32_t)(h_s[i] >> 32); }
@@ -244,6 +246,7 @@ int kg_field_vec_scale(kg_ctx* c, int field, const uint64_t* a, const uint64_t* 
 int kg_field_powers(kg_ctx* c, int field, const uint64_t* h_start, const uint64_t* h_base, uint64_t* out, size_t n) {
   if (!c || !h_start || !h_base || (field != KG_FR && field != KG_FQ)) return KG_ERR_BAD_ARG;
   if (n == 0) return KG_OK;
+  KG_HIP(c, hipSetDevice(c->device));
   if (!out) return KG_ERR_BAD_ARG;
   Words8 s, b;
   for (int i = 0; i < 4; ++i) {
@@ -260,6 +263,7 @@ int kg_field_powers(kg_ctx* c, int field, const uint64_t* h_start, const uint64_
 int kg_field_vec_axpy(kg_ctx* c, int field, const uint64_t* a, const uint64_t* h_s, const uint64_t* b, uint64_t* out, size_t n) {
   if (!c || !h_s || (field != KG_FR && field != KG_FQ)) return KG_ERR_BAD_ARG;
   if (n == 0) return KG_OK;
+  KG_HIP(c, hipSetDevice(c->device));
   if (!a || !b || !out) return KG_ERR_BAD_ARG;
   Words8 s;
   for (int i = 0; i < 4; ++i) { s.w[2 * i] = (uint32_t)h_s[i]; s.w[2 * i + 1] = (uint32_t)(h_s[i] >> 32); }
@@ -273,6 +277,7 @@ int kg_field_vec_axpy(kg_ctx* c, int field, const uint64_t* a, const uint64_t* h
 int kg_r1cs_evaluate(kg_ctx* c, const uint64_t* row_ptr, const uint64_t* col, const uint64_t* val, size_t m, const uint64_t* z, uint64_t* out) {
   if (!c) return KG_ERR_BAD_ARG;
   if (m == 0) return KG_OK;
+  KG_HIP(c, hipSetDevice(c->device));
   if (!row_ptr || !col || !val || !z || !out) return KG_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_r1cs_evaluate, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, c->stream, row_ptr, col, val, m, z, out);
   KG_HIP(c, hipGetLastError());
@@ -282,6 +287,7 @@ int kg_r1cs_evaluate(kg_ctx* c, const uint64_t* row_ptr, const uint64_t* col, co
 int kg_gen_scalars(kg_ctx* c, int field, uint64_t seed, size_t start, size_t n, uint64_t* out) {
   if (!c || (field != KG_FR && field != KG_FQ)) return KG_ERR_BAD_ARG;
   if (n == 0) return KG_OK;
+  KG_HIP(c, hipSetDevice(c->device));
   if (!out) return KG_ERR_BAD_ARG;
   dim3 grid((unsigned)((n + 255) / 256));
   if (field == KG_FR) hipLaunchKernelGGL(k_gen_scalars<FrParams>, grid, dim3(256), 0, c->stream, seed, start, n, out);
@@ -293,6 +299,7 @@ int kg_gen_scalars(kg_ctx* c, int field, uint64_t seed, size_t start, size_t n, 
 int kg_gen_bases(kg_ctx* c, int curve, uint64_t seed, size_t start, size_t n, uint64_t* out) {
   if (!c || (curve != KG_G1 && curve != KG_GRUMPKIN)) return KG_ERR_BAD_ARG;
   if (n == 0) return KG_OK;
+  KG_HIP(c, hipSetDevice(c->device));
   if (!out) return KG_ERR_BAD_ARG;
   dim3 grid((unsigned)((n + 63) / 64));
   if (curve == KG_G1) hipLaunchKernelGGL(k_gen_bases<Fq>, grid, dim3(64), 0, c->stream, seed, start, n, out);

@@ -23,6 +23,7 @@ EXPORTS = [
     "kg_field_vec_scale", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_msm", "kg_msm_host", "kg_commit",
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
     "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
+    "kg_msm_pick_window",
 ]
 
 
@@ -67,6 +68,11 @@ def load():
         _lib.kg_last_error.restype = C.c_char_p
         _lib.kg_last_error.argtypes = [C.c_void_p]
     return _lib
+
+
+def msm_pick_window(n: int) -> int:
+    """kg_msm_pick_window: the automatic window width for n pairs (no device needed)"""
+    return int(load().kg_msm_pick_window(C.c_size_t(n)))
 
 
 def _vp(x):

@@ -106,8 +106,91 @@ def ntt_vectors():
     return out
 
 
+def digest(ints):
+    """sha256 over the canonical integers as 32-byte little-endian strings (what the tests recompute from limbs)"""
+    import hashlib
+    h = hashlib.sha256()
+    for v in ints:
+        h.update(int(v).to_bytes(32, "little"))
+    return h.hexdigest()
+
+
+def big_vectors():
+    """MSM n = 2^10 (BASELINE.json configs[0]), NTT k = 10 and one tiny Groth16 proof with
+    fixed (r, s).  Inputs of the two large cases are the seeded streams every implementation regenerates (base_at /
+    scalar_at == kg_gen_bases / kg_gen_scalars == the oracle's generators); the fixture pins them with digests and holds
+    the outputs (the MSM sum; digests plus sampled entries of the transforms)."""
+    out = {}
+    n = 1 << 10
+    seed_b, seed_s = SEED + 0x1000, SEED + 0x1001
+    pts = [P.base_at(P.G1, seed_b, i) for i in range(n)]
+    ks = [P.scalar_at(seed_s, i, P.R_MOD) for i in range(n)]
+    res = P.G1.msm(pts, ks)
+    assert res == P.G1.msm_naive(pts, ks)                      # bucketed == sum of independent double-and-adds
+    out["msm_2_10"] = {"curve": "g1", "n": n, "seed_bases": hx(seed_b), "seed_scalars": hx(seed_s),
+                       "bases_digest": digest([c for q in pts for c in q]), "scalars_digest": digest(ks), "sum": pt(P.G1, res)}
+    k = 10
+    seed_v = SEED + 0x1002
+    v = [P.scalar_at(seed_v, i, P.R_MOD) for i in range(1 << k)]
+    ntt = {"k": k, "seed": hx(seed_v), "input_digest": digest(v)}
+    sample = [0, 1, 2, 511, 512, 1022, 1023]
+    for name, fn in (("dft", P.dft), ("idft", P.idft), ("coset_dft", P.coset_dft), ("coset_idft", P.coset_idft)):
+        o = fn(v, k)
+        ntt[name] = {"digest": digest(o), "sample_index": sample, "sample": [hx(o[i]) for i in sample]}
+    assert P.idft(P.dft(v, k), k) == v
+    out["ntt_2_10"] = ntt
+    out["groth16_tiny"] = groth16_vector()
+    return out
+
+
+def groth16_vector():
+    """One Groth16 proof with everything fixed, computed with integers only: with the toxic waste known the discrete
+    logs of the CRS elements and of the proof follow from the witness, and every point is that multiple of its
+    generator (groth16/src/zksnark.rs:17-127 setup, prover.rs:20-99 create_proof, read in the exponent).  Circuit: the
+    4-constraint chain t_{i+1} = t_i (t_i + 1) (the size of the reference's own end-to-end test, groth16/src/lib.rs:29-77)."""
+    p = P.R_MOD
+    m, l = 4, 2
+    t = [0x1234567 % p]
+    for _ in range(m):
+        t.append(t[-1] * (t[-1] + 1) % p)
+    z = [1, t[0]] + t[1:]                                   # x = [1, t_0], w = t_1..t_m
+    wire = lambda i: 1 if i == 0 else 2 + i - 1
+    A = [{wire(i): 1} for i in range(m)]
+    B = [{wire(i): 1, 0: 1} for i in range(m)]
+    C = [{wire(i + 1): 1} for i in range(m)]
+    ev = lambda M: [sum(c * z[v] for v, c in row.items()) % p for row in M]
+    av, bv, cv = ev(A), ev(B), ev(C)
+    assert all(x * y % p == w for x, y, w in zip(av, bv, cv))
+    alpha, beta, gamma, delta, tau = [pow(0xA11CE + 977 * j, 5, p) for j in range(1, 6)]
+    r, s = 0x1111111122222222333333334444444455555555 % p, 0x66666666777777778888888899999999AAAAAAAA % p
+    k, n = 2, 4
+    lag = P.idft([pow(tau, i, p) for i in range(m)] + [0] * (n - m), k)      # zksnark.rs:44-49,61
+    nv = len(z)
+    at_tau = lambda M: [sum(row.get(v, 0) * lag[i] for i, row in enumerate(M)) % p for v in range(nv)]
+    a_s, b_s, c_s = at_tau(A), at_tau(B), at_tau(C)
+    ext = [(beta * a + alpha * b + c) % p for a, b, c in zip(a_s, b_s, c_s)]
+    ic_s = [e * pow(gamma, -1, p) % p for e in ext[:l]]
+    l_s = [e * pow(delta, -1, p) % p for e in ext[l:]]
+    coeff = (pow(tau, n, p) - 1) * pow(delta, -1, p) % p
+    h_s = [pow(tau, i, p) * coeff % p for i in range(m - 1)]
+    ac, bc, cc = (P.coset_dft(P.idft(v, k), k) for v in (av, bv, cv))
+    q = P.coset_idft(P.divide_by_z_on_coset([(x * y - w) % p for x, y, w in zip(ac, bc, cc)], k), k)
+    a_dl = (alpha + sum(zi * ai for zi, ai in zip(z, a_s)) + r * delta) % p
+    b_dl = (beta + sum(zi * bi for zi, bi in zip(z, b_s)) + s * delta) % p
+    c_dl = (sum(zi * li for zi, li in zip(z[l:], l_s)) + sum(qi * hi for qi, hi in zip(q, h_s)) + s * a_dl + r * b_dl - r * s * delta) % p
+    # the Groth16 verification equation in the exponent (groth16/src/verifier.rs): e(A, B) = e(alpha, beta) e(ic . x, gamma) e(C, delta)
+    assert a_dl * b_dl % p == (alpha * beta + sum(zi * ici for zi, ici in zip(z[:l], ic_s)) * gamma + c_dl * delta) % p
+    g1m = lambda e: pt(P.G1, P.G1.mul(P.G1.gen, e))
+    g2m = lambda e: pt(P.G2, P.G2.mul(P.G2.gen, e))
+    return {"m": m, "l": l, "t0": hx(t[0]), "toxic": [hx(v) for v in (alpha, beta, gamma, delta, tau)], "r": hx(r), "s": hx(s),
+            "crs_scalars": {"h": [hx(v) for v in h_s], "l": [hx(v) for v in l_s], "a": [hx(v) for v in a_s], "b": [hx(v) for v in b_s],
+                            "ic": [hx(v) for v in ic_s]},
+            "h_coefficients": [hx(v) for v in q],
+            "proof": {"a": g1m(a_dl), "b": g2m(b_dl), "c": g1m(c_dl)}}
+
+
 def main():
-    data = {"field": field_vectors(), "points": point_vectors(), "msm": msm_vectors(), "ntt": ntt_vectors()}
+    data = {"field": field_vectors(), "points": point_vectors(), "msm": msm_vectors(), "ntt": ntt_vectors(), "big": big_vectors()}
     for k, v in data.items():
         with open(os.path.join(HERE, f"{k}.json"), "w") as f:
             json.dump(v, f, indent=0, separators=(",", ":"))

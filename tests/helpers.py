@@ -44,3 +44,47 @@ def np_to_pt(cur, xy, inf):
 
 
 CURVES = {"g1": (0, P.G1, 0), "gk": (1, P.GRUMPKIN, 1), "g2": (2, P.G2, 0)}  # name -> (id, pycurve, scalar field id)
+
+
+def digest_limbs(arr, p):
+    """sha256 over the canonical integers (32-byte little endian each) of an (n, 4) array of Montgomery limbs -- the
+    digest format of tests/golden/big.json (make_golden.py: digest)."""
+    import hashlib
+    h = hashlib.sha256()
+    rinv = pow(1 << 256, -1, p)
+    for row in np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, 4):
+        h.update((I(row) * rinv % p).to_bytes(32, "little"))
+    return h.hexdigest()
+
+
+class PyFrOps:
+    """the five host-side Fr scalar operations kogarashi_amd.api.groth16_setup asks for, in plain Python integers"""
+    p = P.R_MOD
+
+    @classmethod
+    def _i(cls, v):
+        return P.from_mont(I(v), cls.p)
+
+    @classmethod
+    def _m(cls, i):
+        return L(P.to_mont(i % cls.p, cls.p))
+
+    @classmethod
+    def one(cls):
+        return cls._m(1)
+
+    @classmethod
+    def inv(cls, x):
+        return cls._m(pow(cls._i(x), -1, cls.p))
+
+    @classmethod
+    def mul(cls, x, y):
+        return cls._m(cls._i(x) * cls._i(y))
+
+    @classmethod
+    def sub(cls, x, y):
+        return cls._m(cls._i(x) - cls._i(y))
+
+    @classmethod
+    def pow2k(cls, x, k):
+        return cls._m(pow(cls._i(x), 1 << k, cls.p))

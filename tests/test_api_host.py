@@ -11,17 +11,22 @@ def test_fft_argument_checks():
 
 
 def test_window_rule_is_total():
-    """every n gets a window whose top digit fits the bucket range (W*c >= 255) -- mirrors pick_window in msm.hip"""
-    def pick(n):
-        lg = n.bit_length() - 1
-        if lg >= 19:
-            return 16
-        if lg >= 14:
-            return 15
-        return min(max(lg - 3, 2), 10)
+    """every n gets a window whose top digit fits the bucket range (W*c >= 255) -- asks the library's own rule
+    (kg_msm_pick_window, the function msm_sort calls), not a copy of it"""
+    from kogarashi_amd import build, lib
+    build.build()
+    pick = lib.msm_pick_window
     for n in list(range(1, 70)) + [2 ** k + d for k in range(6, 31) for d in (-1, 0, 1)]:
         c = pick(n)
         w = (255 + c - 1) // c
-        assert w * c >= 255 and 2 <= c <= 16
+        assert w * c >= 255 and 2 <= c <= 17
         top_bits = 254 - (w - 1) * c
-        assert top_bits <= c - 1            # top digit (+1 carry) stays within 2^(c-1) buckets
+        assert top_bits <= c - 1, (n, c)    # top digit (+1 carry of the bias) stays within the 2^(c-1) buckets
+        if c == 17:
+            assert (1 << 16) <= n <= (1 << 24)        # needs the two-pass sort (msm_sort)
+    assert pick(1 << 20) == 16 and pick(1 << 18) == 15 and pick(1 << 22) == 17 and pick(1 << 24) == 17 and pick(1 << 10) == 7
+    # bench.py's addition count uses the same rule
+    import bench
+    for lg in (10, 18, 20, 22, 24):
+        c = pick(1 << lg)
+        assert bench.window_adds(1 << lg) == ((255 + c - 1) // c) << lg

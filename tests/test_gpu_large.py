@@ -1,5 +1,6 @@
-"""BASELINE.json's full sizes: oracle equality where the oracle finishes in seconds (MSM 2^20, NTT 2^20) and
-size-independent properties beyond that (split-sum of an MSM, transform round trips, linearity)."""
+"""BASELINE.json's full sizes: oracle equality where the oracle finishes in seconds (G1 MSM 2^20, G2 MSM 2^16 / 2^18,
+NTT 2^20 / 2^22, the Groth16 proof at 2^18 constraints) and size-independent properties beyond that (split-sum of an
+MSM, transform round trips, linearity)."""
 import numpy as np
 import pytest
 
@@ -86,3 +87,96 @@ def test_commit_2_24_properties(ctx, curve, sfd):
     cs, is_ = ctx.commit(curve, g.ptr, 0, s.ptr, n)
     xy, inf = ctx.points_sum_affine(curve, np.stack([ca, cb]), np.array([ia, ib], dtype=np.uint8))
     assert not is_ and inf == 0 and (xy == cs).all()
+
+
+def test_ntt_2_22_all_variants_match_oracle(ctx, oracle):
+    """BASELINE.json configs[2] against the oracle's restatement of Fft<Fr> (fft.rs:92-127), all four transforms."""
+    import kogarashi_amd as K
+    O, k = oracle, 22
+    n = 1 << k
+    d = ctx.empty((n, 4))
+    ctx.gen_scalars(K.KG_FR, SEED + 60, 0, n, d.ptr)
+    v = d.numpy()
+    fo = O.Fft(k)
+    work = ctx.empty((n, 4))
+    for name, inv, coset in (("dft", False, False), ("idft", True, False), ("coset_dft", False, True), ("coset_idft", True, True)):
+        ctx._chk(ctx._lib.kg_memcpy_d2d(ctx._h, work.ptr, d.ptr, n * 32), "kg_memcpy_d2d")
+        ctx.ntt(work.ptr, k, inv, coset)
+        want = getattr(fo, name)(v, threads=16)
+        assert (work.numpy() == want).all(), name
+
+
+def _g2_bases(ctx, oracle, n, seed):
+    """n G2 points k_i * G2 (cofactor != 1: SURVEY.md 8d draws G2 bases as generator multiples), made on the device
+    (kg_fixed_base_mul == the oracle's scalar_point: tests/test_gpu_groth16.py) with two identities mixed in."""
+    import kogarashi_amd as K
+    dk = ctx.empty((n, 4))
+    ctx.gen_scalars(K.KG_FR, seed, 0, n, dk.ptr)
+    ctx.write(dk.ptr + 32 * 11, np.zeros((1, 4), dtype=np.uint64))          # k = 0: an identity base with its flag set
+    dxy, dinf = ctx.empty((n, 16)), ctx.empty((n,), dtype=np.uint8)
+    ctx.fixed_base_mul(K.KG_G2, dk.ptr, n, dxy.ptr, dinf.ptr)
+    return dxy, dinf
+
+
+def _witness_like(O, scal, seed):
+    """Groth16 witnesses are 0/1-heavy: half ones, a fifth zeros, some -1 and small values"""
+    n = len(scal)
+    rng = np.random.default_rng(seed)
+    kind = rng.integers(0, 10, n)
+    one = O.f_consts(0)["r"]
+    scal[kind < 5] = one
+    scal[(kind >= 5) & (kind < 7)] = 0
+    scal[kind == 7] = O.f_neg(0, one)
+    scal[kind == 8] = O.f_to_mont(0, np.array([5, 0, 0, 0], dtype=np.uint64))
+    return scal
+
+
+@pytest.mark.parametrize("log_n,skew", [(16, False), (16, True), (18, False), (18, True)])
+def test_msm_g2_at_scale_matches_oracle(ctx, oracle, log_n, skew):
+    """G2 through the two-pass sort (n >= 2^16), the two-wave k_acc_tasks<Fq2> and the lane-pair halving reduction
+    (k_halve<Fp2S>), against the oracle's msm_curve_addition on the same bases -- plain and registered."""
+    import kogarashi_amd as K
+    O, n = oracle, 1 << log_n
+    dxy, dinf = _g2_bases(ctx, O, n, SEED + 70 + log_n)
+    scal = O.gen_scalars(0, SEED + 71 + log_n, 0, n)
+    if skew:
+        scal = _witness_like(O, scal, log_n)
+    ds = ctx.upload(scal)
+    bases, inf = dxy.numpy(), dinf.numpy()
+    assert inf[11] == 1 and inf.sum() == 1
+    wxy, winf = O.to_affine("g2", O.msm("g2", bases, scal, inf, threads=18))
+    got = ctx.msm(K.KG_G2, dxy.ptr, dinf.ptr, ds.ptr, n)
+    assert not winf and got[16:].any() and (got[:16] == wxy).all()
+    ctx.bases_register(K.KG_G2, dxy.ptr, dinf.ptr, n)
+    try:
+        assert (ctx.msm(K.KG_G2, dxy.ptr, dinf.ptr, ds.ptr, n) == got).all()
+    finally:
+        ctx.bases_unregister(dxy.ptr)
+
+
+def test_groth16_2_18_matches_oracle(ctx, oracle):
+    """BASELINE.json configs[3]: Groth16 prove at 2^18 constraints.  CRS from the device setup (api.groth16_setup), proof
+    from Prover.create_proof (blocking) and from two proofs in flight, against the oracle's create_proof (prover.rs:20-99)
+    run on the host with the same CRS, witness and (r, s): the three affine points must be bit-identical."""
+    import kogarashi_amd as K
+    from kogarashi_amd import synthetic as syn
+    from kogarashi_amd.api import groth16_setup
+    O = oracle
+    m = 1 << 18
+    cc = syn.ChainCircuit(m)
+    P = groth16_setup(cc.a, cc.b, cc.c, m, cc.l, cc.m_l_1, syn.fixed_toxic(), syn.FrOps, ctx=ctx)
+    r, s = syn.fixed_rs()
+    prover = K.Prover(P, m, cc.l, cc.m_l_1, ctx=ctx)
+    got = prover.create_proof(cc.a_eval, cc.b_eval, cc.c_eval, cc.x, cc.w, r, s)
+    Pc = {name: P[name] for name in ("h", "l", "a", "b_g1", "b_g2")}
+    Pc.update({name + "_inf": (P[name + "_inf"] if P[name + "_inf"].any() else None) for name in ("h", "l", "a", "b_g1", "b_g2")})
+    Pc["vk_g1"], Pc["vk_g2"] = P["vk_g1"], P["vk_g2"]
+    empty = (np.zeros(m + 1, dtype=np.uint64),) * 3
+    cs = O.R1cs(empty, empty, empty, cc.x, cc.w)
+    want = O.groth16_prove(cs, Pc, r, s, threads=32, evals=(cc.a_eval, cc.b_eval, cc.c_eval))
+    for g, w_, name in zip(got[:3], want[:3], "ABC"):
+        assert (g == w_).all(), name
+    assert (got[3] == want[3]).all() and not got[3].any()
+    jobs = [(cc.a_eval, cc.b_eval, cc.c_eval, cc.x, cc.w, r, s)] * 3
+    for pr in prover.create_proofs(jobs):
+        assert all((pr[i] == got[i]).all() for i in range(4))

@@ -59,6 +59,24 @@ def test_field_vector_ops(ctx, oracle, fd):
     s = O.gen_scalars(fd, SEED + 3, 0, 1)[0]
     ctx.field_vec_scale(fd, da.ptr, s, do.ptr, n)
     assert (do.numpy() == np.stack([O.f_mul(fd, a[i], s) for i in range(n)])).all()
+    # to_mont_form (represent.rs:30-32) of canonical integers, and its round trip with montgomery_reduce
+    ints = np.stack([O.f_from_mont(fd, a[i]) for i in range(n)])
+    di = ctx.upload(ints)
+    ctx.field_vec_op(fd, "to_mont", di.ptr, 0, do.ptr, n)
+    assert (do.numpy() == np.stack([O.f_to_mont(fd, ints[i]) for i in range(n)])).all() and (do.numpy() == a).all()
+    ctx.field_vec_op(fd, "from_mont", do.ptr, 0, do.ptr, n)
+    assert (do.numpy() == ints).all()
+    # start * base^i (the scan tables of fft.rs:35-41, the powers of tau of zksnark.rs:44-49)
+    npow = 3000
+    dp = ctx.empty((npow, 4))
+    ctx.field_powers(fd, a[5], b[5], dp.ptr, npow)
+    want, cur = [], a[5]
+    for _ in range(npow):
+        want.append(cur)
+        cur = O.f_mul(fd, cur, b[5])
+    assert (dp.numpy() == np.stack(want)).all()
+    ctx.field_powers(fd, c["r"], np.zeros(4, dtype=np.uint64), dp.ptr, 4)            # 0^0 = 1, then zeros
+    assert (dp.numpy()[0] == c["r"]).all() and not dp.numpy()[1:4].any()
     # Nova fold W1 + r * W2 (nova/src/relaxed_r1cs/witness.rs:56-70)
     ctx.field_vec_axpy(fd, da.ptr, s, db.ptr, do.ptr, n)
     assert (do.numpy() == np.stack([O.f_add(fd, a[i], O.f_mul(fd, s, b[i])) for i in range(n)])).all()
@@ -296,13 +314,20 @@ def test_registered_bases_give_identical_results(ctx, oracle, cv, curve, sfd):
 @pytest.mark.parametrize("cv,curve,sfd,n,c,skew", [
     ("g1", 0, 0, 1 << 16, 0, False), ("g1", 0, 0, 70001, 12, False), ("gk", 1, 1, 100000, 16, False),
     ("g1", 0, 0, 1 << 17, 0, True), ("g1", 0, 0, 150000, 13, True), ("gk", 1, 1, 90000, 16, True),
+    ("g2", 2, 0, 66000, 0, False), ("g2", 2, 0, 70001, 13, True),
 ])
 def test_msm_two_pass_sort_sizes(ctx, oracle, cv, curve, sfd, n, c, skew):
     """n >= 2^16 with c >= 12 takes the two-pass bucket sort (bucket group, then bucket inside the group; groups cut
     into 8192-entry segments).  Uniform scalars fill every group evenly; the witness-like mix piles half of the entries
     into one group of window 0 (many segments of one group) and leaves most other groups empty."""
     O = oracle
-    bases = O.gen_bases(curve, SEED + 500 + n, 0, n)
+    if curve == 2:                                  # G2 bases: k_i * G2 made on the device (== the oracle's: test_fixed_base_mul)
+        dk = ctx.upload(O.gen_scalars(0, SEED + 499 + n, 0, n))
+        dxy, dinf = ctx.empty((n, 16)), ctx.empty((n,), dtype=np.uint8)
+        ctx.fixed_base_mul(2, dk.ptr, n, dxy.ptr, dinf.ptr)
+        bases = dxy.numpy()
+    else:
+        bases = O.gen_bases(curve, SEED + 500 + n, 0, n)
     scal = O.gen_scalars(sfd, SEED + 501 + n, 0, n)
     inf = np.zeros(n, dtype=np.uint8)
     inf[[3, n - 1]] = 1
@@ -318,7 +343,7 @@ def test_msm_two_pass_sort_sizes(ctx, oracle, cv, curve, sfd, n, c, skew):
     want = aff(O, cv, O.msm(cv, bases, scal, inf, threads=8))
     ctx.set_msm_window(c)
     try:
-        assert gpu_aff(ctx.msm_host(curve, bases, inf, scal, n), 4) == want
+        assert gpu_aff(ctx.msm_host(curve, bases, inf, scal, n), 8 if curve == 2 else 4) == want
     finally:
         ctx.set_msm_window(0)
 

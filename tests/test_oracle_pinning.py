@@ -208,3 +208,50 @@ def test_groth16_oracle_proof_verifies_in_the_exponent(oracle, pyoracle):
         assert np_to_pt(P.G2, B, 0) == P.G2.mul(P.G2.gen, b_dl)
         assert np_to_pt(P.G1, C, 0) == P.G1.mul(P.G1.gen, c_dl)
         assert a_dl * b_dl % p == (alpha * beta + sum(zi * ici for zi, ici in zip(z[:cs.l], ic_s)) * gamma + c_dl * delta) % p
+
+
+def test_big_golden_msm_2_10_and_ntt_2_10(oracle, pyoracle):
+    """tests/golden/big.json: BASELINE.json configs[0] (G1 MSM, 2^10 pairs) and the k = 10 transforms, inputs from the
+    seeded streams (pinned by digest), outputs from the big-integer oracle."""
+    from helpers import digest_limbs
+    O, P = oracle, pyoracle
+    g = gold("big")
+    c = g["msm_2_10"]
+    bases = O.gen_bases(0, int(c["seed_bases"], 16), 0, c["n"])
+    scal = O.gen_scalars(0, int(c["seed_scalars"], 16), 0, c["n"])
+    assert digest_limbs(bases, P.Q_MOD) == c["bases_digest"] and digest_limbs(scal, P.R_MOD) == c["scalars_digest"]
+    for threads in (1, 8):
+        assert np_to_pt(P.G1, *O.to_affine("g1", O.msm("g1", bases, scal, None, threads=threads))) == gpt(P.G1, c["sum"])
+    c = g["ntt_2_10"]
+    v = O.gen_scalars(0, int(c["seed"], 16), 0, 1 << c["k"])
+    assert digest_limbs(v, P.R_MOD) == c["input_digest"]
+    f = O.Fft(c["k"])
+    for name in ("dft", "idft", "coset_dft", "coset_idft"):
+        out = getattr(f, name)(v, threads=4)
+        assert digest_limbs(out, P.R_MOD) == c[name]["digest"], name
+        for i, h in zip(c[name]["sample_index"], c[name]["sample"]):
+            assert P.from_mont(I(out[i]), P.R_MOD) == int(h, 16)
+
+
+def groth16_tiny_case(P):
+    """inputs of the fixed-(r, s) proof in tests/golden/big.json as Montgomery limbs"""
+    c = gold("big")["groth16_tiny"]
+    m = lambda h: L(P.to_mont(int(h, 16), P.R_MOD))
+    return c, m(c["t0"]), np.stack([m(h) for h in c["toxic"]]), m(c["r"]), m(c["s"])
+
+
+def test_big_golden_groth16_tiny(oracle, pyoracle):
+    """One Groth16 proof with fixed toxic waste and (r, s) (shape of groth16/src/lib.rs:29-77): the C restatement's setup
+    scalars, h coefficients' MSM inputs and proof must equal the integer-only fixture."""
+    O, P = oracle, pyoracle
+    c, t0, toxic, r, s = groth16_tiny_case(P)
+    cs = O.chain_r1cs(c["m"], t0)
+    prm = O.groth16_params(cs, toxic, threads=2)
+    for name in ("h", "l", "a", "b", "ic"):
+        want = [int(h, 16) for h in c["crs_scalars"][name]]
+        assert [P.from_mont(I(v), P.R_MOD) for v in prm["scalars"][name]] == want, name
+    A, B, C, inf = O.groth16_prove(cs, prm, r, s)
+    assert not inf.any()
+    assert np_to_pt(P.G1, A, 0) == gpt(P.G1, c["proof"]["a"])
+    assert np_to_pt(P.G2, B, 0) == gpt(P.G2, c["proof"]["b"])
+    assert np_to_pt(P.G1, C, 0) == gpt(P.G1, c["proof"]["c"])
