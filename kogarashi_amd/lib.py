@@ -135,6 +135,10 @@ class Context:
         if arr.nbytes:
             self._chk(self._lib.kg_memcpy_h2d(self._h, _vp(dptr), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)), "kg_memcpy_h2d")
 
+    def copy_d2d(self, dst: int, src: int, nbytes: int):
+        """device -> device on the context's stream (asynchronous, ordered with the kernels)"""
+        self._chk(self._lib.kg_memcpy_d2d(self._h, _vp(dst), _vp(src), C.c_size_t(nbytes)), "kg_memcpy_d2d")
+
     def empty(self, shape, dtype=np.uint64) -> "DeviceArray":
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         return DeviceArray(self, nbytes, tuple(shape), np.dtype(dtype))

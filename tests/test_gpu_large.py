@@ -100,7 +100,7 @@ def test_ntt_2_22_all_variants_match_oracle(ctx, oracle):
     fo = O.Fft(k)
     work = ctx.empty((n, 4))
     for name, inv, coset in (("dft", False, False), ("idft", True, False), ("coset_dft", False, True), ("coset_idft", True, True)):
-        ctx._chk(ctx._lib.kg_memcpy_d2d(ctx._h, work.ptr, d.ptr, n * 32), "kg_memcpy_d2d")
+        ctx.copy_d2d(work.ptr, d.ptr, n * 32)
         ctx.ntt(work.ptr, k, inv, coset)
         want = getattr(fo, name)(v, threads=16)
         assert (work.numpy() == want).all(), name
