@@ -132,6 +132,30 @@ int kg_msm_set_window(kg_ctx* ctx, int c);
  * rule is groth16/src/msm.rs:7-14).  Pure function: needs no device and no context. */
 int kg_msm_pick_window(size_t n);
 
+/* ---- several devices, one process ------------------------------------------------------------------
+ * MSM / commitment over n_ctx contexts (normally one per GPU of the node; several contexts on one GPU also work): the
+ * index range is cut into contiguous slices, context i holds slice i (kg_shard_range gives the cut), one host thread per
+ * context runs the single-device pipeline on its slice and the n_ctx affine partial sums are added on the host -- the
+ * exchange is 72 B (G1) per device, so no collective library is involved.  d_bases[i] / d_inf[i] / d_scalars[i] are
+ * DEVICE pointers of context i's device, n_local[i] pairs each (d_inf or d_inf[i] may be NULL).  Results are identical
+ * to kg_commit / kg_msm over the concatenated arrays.  The multi-process form of the same sharding (one rank per GPU,
+ * RCCL all_gather of the partials) is kogarashi_amd/dist.py. */
+int kg_shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi);
+int kg_commit_sharded(kg_ctx* const* ctxs, int n_ctx, int curve, const uint64_t* const* d_bases, const uint8_t* const* d_inf,
+                      const uint64_t* const* d_scalars, const size_t* n_local, uint64_t* out_xy, uint8_t* out_inf);
+int kg_msm_sharded(kg_ctx* const* ctxs, int n_ctx, int curve, const uint64_t* const* d_bases, const uint8_t* const* d_inf,
+                   const uint64_t* const* d_scalars, const size_t* n_local, uint64_t* out_xyz);
+/* nova/src/pedersen.rs:6-20 PedersenCommitment<C> { g } spread over the devices: _create (= new, given the generators)
+ * uploads slice i of the HOST arrays h_bases / h_inf (may be NULL) to context i and registers it (kg_bases_register);
+ * _commit takes the HOST scalar vector m (n elements; zip semantics: min(n, key length) pairs), uploads each device's
+ * slice and returns affine(sum_i m[i] * g[i]) like kg_commit.  The contexts must outlive the key. */
+typedef struct kg_sharded_key kg_sharded_key;
+int kg_sharded_key_create(kg_ctx* const* ctxs, int n_ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, size_t n,
+                          kg_sharded_key** out);
+void kg_sharded_key_destroy(kg_sharded_key* key);
+size_t kg_sharded_key_len(const kg_sharded_key* key);
+int kg_sharded_key_commit(kg_sharded_key* key, const uint64_t* h_scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf);
+
 /* ---- fixed-base multiples ------------------------------------------------------------------------
  * out[i] = affine(generator * k[i]): the `(g * scalar).into()` of the CRS construction (groth16/src/zksnark.rs:57,
  * 168-187), of VerifyingKey (zksnark.rs:104-112) and of Group::random (macros/curve/weierstrass/group.rs:39-41,

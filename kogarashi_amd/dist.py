@@ -11,7 +11,8 @@ from .lib import KG_G2
 
 
 def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
-    """Contiguous slice [lo, hi) of rank `rank`; slices differ by at most one element."""
+    """Contiguous slice [lo, hi) of rank `rank`; slices differ by at most one element (== kg_shard_range, the cut the
+    single-process multi-device entries kg_commit_sharded / kg_sharded_key_* use)."""
     base, extra = divmod(n, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)

@@ -23,7 +23,8 @@ EXPORTS = [
     "kg_field_vec_scale", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_msm", "kg_msm_host", "kg_commit",
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
     "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
-    "kg_msm_pick_window",
+    "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
+    "kg_sharded_key_len", "kg_sharded_key_commit",
 ]
 
 
@@ -67,6 +68,10 @@ def load():
         _lib.kg_strerror.restype = C.c_char_p
         _lib.kg_last_error.restype = C.c_char_p
         _lib.kg_last_error.argtypes = [C.c_void_p]
+        _lib.kg_sharded_key_len.restype = C.c_size_t
+        _lib.kg_sharded_key_len.argtypes = [C.c_void_p]
+        _lib.kg_sharded_key_destroy.argtypes = [C.c_void_p]
+        _lib.kg_sharded_key_destroy.restype = None
     return _lib
 
 
@@ -296,3 +301,81 @@ class DeviceArray:
 
     def numpy(self) -> np.ndarray:
         return self.ctx.download(self)
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """kg_shard_range: contiguous slice [lo, hi) of `rank` (no device needed)"""
+    lo, hi = C.c_size_t(0), C.c_size_t(0)
+    rc = load().kg_shard_range(C.c_size_t(n), int(rank), int(world), C.byref(lo), C.byref(hi))
+    if rc != 0:
+        raise KogarashiError(f"kg_shard_range: {load().kg_strerror(rc).decode()}")
+    return int(lo.value), int(hi.value)
+
+
+def _ptr_array(ctype, values):
+    return (ctype * len(values))(*[ctype(int(v) if v else 0) for v in values])
+
+
+def commit_sharded(ctxs, curve: int, bases, infs, scalars, n_local):
+    """kg_commit_sharded over `ctxs`: per-context device pointers (ints) and pair counts; returns (xy, inf)."""
+    k = len(ctxs)
+    h = (C.c_void_p * k)(*[c._h for c in ctxs])
+    pb, ps = _ptr_array(C.c_void_p, bases), _ptr_array(C.c_void_p, scalars)
+    pi = _ptr_array(C.c_void_p, infs) if infs is not None else None
+    nl = (C.c_size_t * k)(*[int(v) for v in n_local])
+    xy = np.zeros(16 if curve == KG_G2 else 8, dtype=np.uint64)
+    oi = C.c_uint8(0)
+    ctxs[0]._chk(load().kg_commit_sharded(h, k, curve, pb, pi, ps, nl, xy.ctypes.data_as(C.c_void_p), C.byref(oi)), "kg_commit_sharded")
+    return xy, int(oi.value)
+
+
+def msm_sharded(ctxs, curve: int, bases, infs, scalars, n_local) -> np.ndarray:
+    k = len(ctxs)
+    h = (C.c_void_p * k)(*[c._h for c in ctxs])
+    pb, ps = _ptr_array(C.c_void_p, bases), _ptr_array(C.c_void_p, scalars)
+    pi = _ptr_array(C.c_void_p, infs) if infs is not None else None
+    nl = (C.c_size_t * k)(*[int(v) for v in n_local])
+    out = np.zeros(24 if curve == KG_G2 else 12, dtype=np.uint64)
+    ctxs[0]._chk(load().kg_msm_sharded(h, k, curve, pb, pi, ps, nl, out.ctypes.data_as(C.c_void_p)), "kg_msm_sharded")
+    return out
+
+
+class ShardedKey:
+    """kg_sharded_key: a commitment key (nova/src/pedersen.rs:6-13) resident across several contexts"""
+
+    def __init__(self, ctxs, curve: int, bases: np.ndarray, inf=None):
+        self.ctxs, self.curve = list(ctxs), curve
+        w = 16 if curve == KG_G2 else 8
+        bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, w)
+        ip = None
+        if inf is not None:
+            inf = np.ascontiguousarray(inf, dtype=np.uint8)
+            ip = inf.ctypes.data_as(C.c_void_p)
+        k = len(self.ctxs)
+        h = (C.c_void_p * k)(*[c._h for c in self.ctxs])
+        key = C.c_void_p()
+        self.ctxs[0]._chk(load().kg_sharded_key_create(h, k, curve, bases.ctypes.data_as(C.c_void_p), ip, C.c_size_t(len(bases)), C.byref(key)),
+                          "kg_sharded_key_create")
+        self._k = key
+
+    def __len__(self):
+        return int(load().kg_sharded_key_len(self._k))
+
+    def commit(self, m: np.ndarray):
+        m = np.ascontiguousarray(m, dtype=np.uint64).reshape(-1, 4)
+        xy = np.zeros(16 if self.curve == KG_G2 else 8, dtype=np.uint64)
+        oi = C.c_uint8(0)
+        self.ctxs[0]._chk(load().kg_sharded_key_commit(self._k, m.ctypes.data_as(C.c_void_p), C.c_size_t(len(m)), xy.ctypes.data_as(C.c_void_p), C.byref(oi)),
+                          "kg_sharded_key_commit")
+        return xy, int(oi.value)
+
+    def close(self):
+        if getattr(self, "_k", None):
+            load().kg_sharded_key_destroy(self._k)
+            self._k = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -30,3 +30,19 @@ def test_window_rule_is_total():
     for lg in (10, 18, 20, 22, 24):
         c = pick(1 << lg)
         assert bench.window_adds(1 << lg) == ((255 + c - 1) // c) << lg
+
+
+def test_shard_range_matches_dist_and_covers():
+    """kg_shard_range (the cut of kg_commit_sharded / kg_sharded_key_*) == dist.shard_range (the multi-process cut)"""
+    from kogarashi_amd import build, dist, lib
+    build.build()
+    for n in (0, 1, 7, 8, 9, 1000, (1 << 24) + 1):
+        for world in (1, 2, 3, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = lib.shard_range(n, r, world)
+                assert (lo, hi) == dist.shard_range(n, r, world) and lo == prev and hi - lo in (n // world, n // world + 1)
+                prev = hi
+            assert prev == n
+    with pytest.raises(lib.KogarashiError):
+        lib.shard_range(10, 3, 3)

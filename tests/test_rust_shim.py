@@ -1,0 +1,97 @@
+"""The Rust shim (rust/) cannot be compiled in this image (no rustc / cargo): these checks keep it mechanically in step
+with the C ABI and with the reference tree it patches."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_rust_ffi as G  # noqa: E402
+
+RUST = os.path.join(ROOT, "rust")
+HEADER = open(os.path.join(ROOT, "include", "kogarashi_amd.h")).read()
+
+
+def test_ffi_block_is_generated_from_the_header():
+    fns = G.parse(HEADER)
+    declared = sorted(set(re.findall(r"\b(kg_[a-z0-9_]+)\s*\(", G.strip_comments(HEADER))))
+    assert sorted(f[0] for f in fns) == declared                      # the parser sees every function of the header
+    assert open(G.OUT).read() == G.render(fns), "run python tools/gen_rust_ffi.py"
+    by_name = {f[0]: f for f in fns}
+    # spot checks of the type mapping
+    assert by_name["kg_commit_sharded"][1][0] == ("ctxs", "*const *mut KgCtx")
+    assert by_name["kg_commit_sharded"][1][3] == ("d_bases", "*const *const u64")
+    assert by_name["kg_strerror"][2] == "*const c_char" and by_name["kg_ctx_destroy"][2] is None
+    assert by_name["kg_malloc"][1][2] == ("d_ptr", "*mut *mut c_void")
+
+
+def test_glue_calls_match_the_header():
+    """every sys::kg_* call in rust/kogarashi-amd names a header function and passes its number of arguments"""
+    arity = {f[0]: len(f[1]) for f in G.parse(HEADER)}
+    seen = set()
+    for dirpath, _, files in os.walk(os.path.join(RUST, "kogarashi-amd", "src")):
+        for f in files:
+            src = open(os.path.join(dirpath, f)).read()
+            for m in re.finditer(r"sys::(kg_[a-z0-9_]+)\s*\(", src):
+                name, i, depth, args, cur = m.group(1), m.end(), 1, 0, ""
+                while depth:
+                    ch = src[i]
+                    depth += ch in "([{"
+                    depth -= ch in ")]}"
+                    if ch == "," and depth == 1:
+                        args += 1
+                        cur = ""
+                    elif depth:
+                        cur += ch
+                    i += 1
+                n_args = args + (1 if cur.strip() else 0)
+                assert name in arity, (f, name)
+                assert n_args == arity[name], (f, name, n_args, arity[name])
+                seen.add(name)
+    for needed in ("kg_msm_host", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_sharded_key_create", "kg_sharded_key_commit",
+                   "kg_groth16_prove_bn254", "kg_bases_register"):
+        assert needed in seen, needed
+
+
+def test_crs_struct_mirrors_the_header():
+    c = re.search(r"typedef struct \{(.*?)\} kg_groth16_crs;", G.strip_comments(HEADER), re.S).group(1)
+    c_fields = []
+    for decl in c.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            c_fields.append(re.search(r"([A-Za-z_0-9]+)\s*(\[\d+\])?$", part.strip()).group(1))
+    r = re.search(r"pub struct KgGroth16Crs \{(.*?)\n\}", open(os.path.join(RUST, "kogarashi-amd-sys", "src", "lib.rs")).read(), re.S).group(1)
+    r_fields = re.findall(r"pub ([a-z0-9_]+):", r)
+    assert r_fields == c_fields
+    # and the ctypes mirror the tests run through
+    from kogarashi_amd.lib import Groth16Crs
+    assert [f[0] for f in Groth16Crs._fields_] == c_fields
+
+
+def test_constants_match_the_header():
+    lib_rs = open(os.path.join(RUST, "kogarashi-amd-sys", "src", "lib.rs")).read()
+    consts = {k: int(v) for k, v in re.findall(r"pub const (KG_[A-Z0-9_]+): i32 = (-?\d+);", lib_rs)}
+    hdr = G.strip_comments(HEADER)
+    for name, val in re.findall(r"\b(KG_[A-Z0-9_]+)\s*=\s*(-?\d+)", hdr):
+        assert consts.get(name) == int(val), name
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/groth16"), reason="the reference tree is only present in the build container")
+def test_patches_apply_to_the_reference(tmp_path):
+    for d in ("groth16", "nova", "zkstd", "bn254"):
+        subprocess.check_call(["cp", "-r", os.path.join("/root/reference", d), str(tmp_path / d)])
+    patches = sorted(p for p in os.listdir(os.path.join(RUST, "patches")) if p.endswith(".diff"))
+    assert len(patches) >= 7
+    for p in patches:
+        with open(os.path.join(RUST, "patches", p)) as f:
+            subprocess.run(["patch", "-p1", "-s"], stdin=f, cwd=str(tmp_path), check=True)
+    # the call sites the patches name exist afterwards
+    assert "kogarashi_amd::msm(bases, coeffs)" in (tmp_path / "groth16/src/msm.rs").read_text()
+    assert "kogarashi_amd::pedersen::commit" in (tmp_path / "nova/src/pedersen.rs").read_text()
+    assert "kogarashi_amd::groth16::resident" in (tmp_path / "groth16/src/prover.rs").read_text()
+    assert (tmp_path / "groth16/src/fft.rs").read_text().count("gpu::transform") == 5
