@@ -201,6 +201,21 @@ int kg_groth16_prove_end(kg_ctx* ctx, int ticket, uint64_t* proof_out, uint8_t* 
  * right before the prover's NTTs (cs.evaluate(), zkstd/src/r1cs.rs:137-142).  All pointers are device pointers. */
 int kg_r1cs_evaluate(kg_ctx* ctx, const uint64_t* d_row_ptr, const uint64_t* d_col, const uint64_t* d_val, size_t m,
                      const uint64_t* d_z, uint64_t* d_out);
+/* zkstd/src/matrix.rs:36-48 SparseMatrix::prod over either scalar field (Fr: Bn254Driver, Fq: GrumpkinDriver,
+ * nova/src/driver.rs:9-42): the same CSR product with z = (u | x | w) -- prod's wire arithmetic (Instance(i) -> z[i],
+ * Witness(i) -> z[i + l]) is resolved when the CSR columns are written.  kg_r1cs_evaluate is the Fr case. */
+int kg_r1cs_prod(kg_ctx* ctx, int field, const uint64_t* d_row_ptr, const uint64_t* d_col, const uint64_t* d_val, size_t m,
+                 const uint64_t* d_z, uint64_t* d_out);
+
+/* ---- Nova cross term -------------------------------------------------------------------------------
+ * nova/src/prover.rs:53-90 Prover::compute_cross_term: T = AZ1 o BZ2 + AZ2 o BZ1 - u1 * CZ2 - u2 * CZ1 (m elements), the
+ * vector Prover::prove commits to next (commit_t = ck.commit(&t), prover.rs:35: kg_commit on d_out).  a, b, c: the shape's
+ * matrices as CSR over z = (u | x | w); d_z1 / d_z2: the two z vectors (relaxed instance-witness pair and the fresh one);
+ * h_u1, h_u2: HOST, one element each (the reference passes instance1.u and one).  One fused kernel: each matrix row is
+ * read once, the six products stay in registers. */
+typedef struct { const uint64_t* d_row_ptr; const uint64_t* d_col; const uint64_t* d_val; } kg_csr;
+int kg_nova_cross_term(kg_ctx* ctx, int field, const kg_csr* a, const kg_csr* b, const kg_csr* c, size_t m, const uint64_t* d_z1,
+                       const uint64_t* d_z2, const uint64_t* h_u1, const uint64_t* h_u2, uint64_t* d_out);
 
 /* ---- deterministic synthetic inputs (identical streams in oracle/) -------------------- */
 int kg_gen_scalars(kg_ctx* ctx, int field, uint64_t seed, size_t start, size_t n, uint64_t* d_out);

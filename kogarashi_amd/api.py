@@ -6,6 +6,7 @@ Montgomery limbs (the reference's `Fr([u64; 4])` / `Fq`), points are (x | y) row
   Fft(k).dft / idft / coset_dft / coset_idft / divide_by_z_on_coset      groth16/src/fft.rs:27-154
   PedersenCommitment(g).commit(m)              nova/src/pedersen.rs:10-20
   Prover(params).create_proof(...)             groth16/src/prover.rs:14-99
+  NovaProver(shape, ck).compute_cross_term / commit_t      nova/src/prover.rs:24-90
 """
 from __future__ import annotations
 
@@ -187,6 +188,50 @@ class Prover:
                     self.ctx.groth16_prove_end(t)
                 except Exception:
                     pass
+
+
+class NovaProver:
+    """nova::Prover { ck, shape } as far as the hot path goes: the cross term T of a folding step and its commitment
+    (nova/src/prover.rs:31-35, 53-90).  shape: the R1CS matrices (a, b, c) as CSR triples (row_ptr, col, val) over
+    z = (u | x | w) -- column 0 is the relaxed one-wire, instance wire i is column i, witness wire k is column l + k with
+    l = len(x) + 1 (SparseMatrix::prod's index rule, zkstd/src/matrix.rs:36-48).  Scalars are Fr for the bn254 driver and
+    Fq for the Grumpkin driver (nova/src/driver.rs:9-42).  The matrices are uploaded once and stay resident."""
+
+    def __init__(self, shape, ck: "PedersenCommitment", ctx: Context | None = None):
+        self.ctx = ctx or ck.ctx
+        self.ck = ck
+        self.field = KG_FQ if ck.cid == KG_GRUMPKIN else KG_FR
+        self.m = len(shape[0][0]) - 1
+        self._dev = []
+        for rp, col, val in shape:
+            val = np.ascontiguousarray(val, dtype=np.uint64).reshape(-1, 4)
+            col = np.ascontiguousarray(col, dtype=np.uint64)
+            self._dev.append((self.ctx.upload(np.ascontiguousarray(rp, dtype=np.uint64)),
+                              self.ctx.upload(col if len(col) else np.zeros(1, dtype=np.uint64)),
+                              self.ctx.upload(val if len(val) else np.zeros((1, 4), dtype=np.uint64))))
+
+    def _z(self, u, x, w):
+        parts = [np.ascontiguousarray(u, dtype=np.uint64).reshape(1, 4), np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4),
+                 np.ascontiguousarray(w, dtype=np.uint64).reshape(-1, 4)]
+        return self.ctx.upload(np.concatenate(parts))
+
+    def compute_cross_term_device(self, u1, x1, w1, u2, x2, w2):
+        """T = AZ1 o BZ2 + AZ2 o BZ1 - u1 CZ2 - u2 CZ1 as a device array of m elements (prover.rs:53-90)"""
+        z1, z2 = self._z(u1, x1, w1), self._z(u2, x2, w2)
+        t = self.ctx.empty((self.m, 4))
+        ptrs = [tuple(d.ptr for d in trip) for trip in self._dev]
+        self.ctx.nova_cross_term(self.field, ptrs[0], ptrs[1], ptrs[2], self.m, z1.ptr, z2.ptr, u1, u2, t.ptr)
+        return t
+
+    def compute_cross_term(self, u1, x1, w1, u2, x2, w2) -> np.ndarray:
+        return self.compute_cross_term_device(u1, x1, w1, u2, x2, w2).numpy()
+
+    def commit_t(self, u1, x1, w1, u2, x2, w2):
+        """(T, commit_T): the cross term and ck.commit(&t) (prover.rs:33-35); T never leaves the device in between"""
+        t = self.compute_cross_term_device(u1, x1, w1, u2, x2, w2)
+        n = min(self.m, self.ck.len)
+        xy, inf = self.ctx.commit(self.ck.cid, self.ck._g.ptr, self.ck._inf.ptr if self.ck._inf else 0, t.ptr, n)
+        return t.numpy(), (xy, inf)
 
 
 def _csr_transpose(row_ptr, col, val, m, nvars):

@@ -4,6 +4,7 @@
 // zkstd/src/arithmetic/limbs/bits_256/normal.rs:4-31,34-53,56-80,83-121,124-166,170-184,256-270 and the
 // point-wise polynomial ops groth16/src/poly.rs:168-195.  HBM-bound for add/sub/mul (96 B/element).
 #include "common.h"
+#include "vecops.h"
 
 using namespace kg;
 
@@ -80,37 +81,78 @@ __global__ void __launch_bounds__(256) k_vec_axpy(const uint64_t* a, Words8 s, c
   store_words(out, i, wo);
 }
 
-// CSR sparse matrix-vector product over Fr (zkstd/src/matrix/row.rs:43-51), one WAVE per row: lanes stride over the
-// row's entries, partial sums meet through 6 shuffle steps.  R1CS rows are short, but the transposed system used by the
-// setup has a column (the constant-one wire) touching every constraint, so a row may hold millions of entries.
-__device__ __forceinline__ Fr shfl_xor_fr(const Fr& a, int mask) {
-  Fr r;
+// CSR sparse matrix-vector product (zkstd/src/matrix/row.rs:43-51, matrix.rs:36-48), G lanes per row: lanes stride over the
+// row's entries, partial sums meet through log2(G) shuffle steps.  G = 64 (one wave per row) for kg_r1cs_evaluate, whose
+// callers include the transposed system of the setup -- there one column (the constant-one wire) touches every
+// constraint, so a row may hold millions of entries; G = 8 for Nova's cross term, whose rows are constraint rows.
+template <class P>
+__device__ __forceinline__ Fp<P> shfl_xor_f(const Fp<P>& a, int mask) {
+  Fp<P> r;
 #pragma unroll
   for (int k = 0; k < 9; ++k) r.l[k] = __shfl_xor(a.l[k], mask);
   return r;
 }
+// sum_e val[e] * z[col[e]] over the row, for one or two z vectors; the result (every lane of the group holds it) stays in the
+// ABI's Montgomery domain: raw(z) * internal(val) = z * val * 2^256
+template <class P, int G, int NZ>
+__device__ __forceinline__ void row_dot(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col, const uint64_t* __restrict__ val,
+                                        size_t row, int lane, const uint64_t* __restrict__ z1, const uint64_t* __restrict__ z2, Fp<P> (&sum)[NZ]) {
+#pragma unroll
+  for (int q = 0; q < NZ; ++q) sum[q] = Fp<P>::zero();
+  for (uint64_t e = row_ptr[row] + lane; e < row_ptr[row + 1]; e += G) {
+    uint32_t wv[8], wz[8];
+    load_words(val, e, wv);
+    const Fp<P> v = from_ref<P>(wv);
+    const uint64_t c = col[e];
+    load_words(z1, c, wz);
+    sum[0] = dot_step(sum[0], limbs_from_words<P>(wz), v);
+    if (NZ > 1) {
+      load_words(z2, c, wz);
+      sum[NZ - 1] = dot_step(sum[NZ - 1], limbs_from_words<P>(wz), v);
+    }
+  }
+#pragma unroll
+  for (int d = G / 2; d >= 1; d >>= 1)
+#pragma unroll
+    for (int q = 0; q < NZ; ++q) sum[q] = dot_merge(sum[q], shfl_xor_f(sum[q], d));
+}
+
+template <class P>
 __global__ void __launch_bounds__(256) k_r1cs_evaluate(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
                                                        const uint64_t* __restrict__ val, size_t m, const uint64_t* __restrict__ z,
                                                        uint64_t* __restrict__ out) {
   const size_t row = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (row >= m) return;
-  Fr sum = Fr::zero();
-  for (uint64_t e = row_ptr[row] + lane; e < row_ptr[row + 1]; e += 64) {
-    uint32_t wv[8], wz[8];
-    load_words(val, e, wv);
-    load_words(z, col[e], wz);
-    // raw(z) * internal(val) keeps the product in the ABI's Montgomery domain
-    Fr t = mul(limbs_from_words<FrParams>(wz), from_ref<FrParams>(wv));
-    sum = vred(norm(add(sum, t)));
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) sum = vred(norm(add(sum, shfl_xor_fr(sum, d))));
+  Fp<P> sum[1];
+  row_dot<P, 64, 1>(row_ptr, col, val, row, lane, z, z, sum);
   if (lane == 0) {
     uint32_t wo[8];
-    words_from_limbs(reduce_2p(sum), wo);
+    words_from_limbs(reduce_2p(sum[0]), wo);
     store_words(out, row, wo);
   }
+}
+
+// Nova's cross term (nova/src/prover.rs:53-90): T = AZ1 o BZ2 + AZ2 o BZ1 - u1 * CZ2 - u2 * CZ1, one kernel: every matrix row
+// is read once for both z vectors, the six matrix-vector products never touch memory.  8 lanes per constraint row.
+struct CsrView { const uint64_t* row_ptr; const uint64_t* col; const uint64_t* val; };
+constexpr int XT_G = 8;
+template <class P>
+__global__ void __launch_bounds__(256) k_nova_cross_term(CsrView A, CsrView B, CsrView C, size_t m, const uint64_t* __restrict__ z1,
+                                                         const uint64_t* __restrict__ z2, Words8 u1, Words8 u2, uint64_t* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t row = t / XT_G;
+  const int lane = (int)(t % XT_G);
+  if (row >= m) return;                                  // whole groups leave together: XT_G divides the wave and the block
+  Fp<P> az[2], bz[2], cz[2];
+  row_dot<P, XT_G, 2>(A.row_ptr, A.col, A.val, row, lane, z1, z2, az);
+  row_dot<P, XT_G, 2>(B.row_ptr, B.col, B.val, row, lane, z1, z2, bz);
+  row_dot<P, XT_G, 2>(C.row_ptr, C.col, C.val, row, lane, z1, z2, cz);
+  if (lane != 0) return;
+  const Fp<P> r = cross_term_row(az[0], az[1], bz[0], bz[1], cz[0], cz[1], from_ref<P>(u1.w), from_ref<P>(u2.w), Fp<P>::from_const(P::C_FROM_REF));
+  uint32_t wo[8];
+  words_from_limbs(reduce_2p(r), wo);
+  store_words(out, row, wo);
 }
 
 // ---- splitmix64 streams (oracle/pyoracle.py stream_at, oracle/kg_oracle.c stream_words) ---------------
@@ -274,12 +316,39 @@ int kg_field_vec_axpy(kg_ctx* c, int field, const uint64_t* a, const uint64_t* h
   return KG_OK;
 }
 
-int kg_r1cs_evaluate(kg_ctx* c, const uint64_t* row_ptr, const uint64_t* col, const uint64_t* val, size_t m, const uint64_t* z, uint64_t* out) {
-  if (!c) return KG_ERR_BAD_ARG;
+int kg_r1cs_prod(kg_ctx* c, int field, const uint64_t* row_ptr, const uint64_t* col, const uint64_t* val, size_t m, const uint64_t* z, uint64_t* out) {
+  if (!c || (field != KG_FR && field != KG_FQ)) return KG_ERR_BAD_ARG;
   if (m == 0) return KG_OK;
-  KG_HIP(c, hipSetDevice(c->device));
   if (!row_ptr || !col || !val || !z || !out) return KG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_r1cs_evaluate, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, c->stream, row_ptr, col, val, m, z, out);
+  KG_HIP(c, hipSetDevice(c->device));
+  const dim3 grid((unsigned)((m + 3) / 4));
+  if (field == KG_FR) hipLaunchKernelGGL(k_r1cs_evaluate<FrParams>, grid, dim3(256), 0, c->stream, row_ptr, col, val, m, z, out);
+  else hipLaunchKernelGGL(k_r1cs_evaluate<FqParams>, grid, dim3(256), 0, c->stream, row_ptr, col, val, m, z, out);
+  KG_HIP(c, hipGetLastError());
+  return KG_OK;
+}
+
+int kg_r1cs_evaluate(kg_ctx* c, const uint64_t* row_ptr, const uint64_t* col, const uint64_t* val, size_t m, const uint64_t* z, uint64_t* out) {
+  return kg_r1cs_prod(c, KG_FR, row_ptr, col, val, m, z, out);
+}
+
+int kg_nova_cross_term(kg_ctx* c, int field, const kg_csr* a, const kg_csr* b, const kg_csr* cm, size_t m, const uint64_t* d_z1,
+                       const uint64_t* d_z2, const uint64_t* h_u1, const uint64_t* h_u2, uint64_t* d_out) {
+  if (!c || (field != KG_FR && field != KG_FQ) || !a || !b || !cm || !h_u1 || !h_u2) return KG_ERR_BAD_ARG;
+  if (m == 0) return KG_OK;
+  if (!d_z1 || !d_z2 || !d_out) return KG_ERR_BAD_ARG;
+  for (const kg_csr* x : {a, b, cm})
+    if (!x->d_row_ptr || !x->d_col || !x->d_val) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipSetDevice(c->device));
+  Words8 u1, u2;
+  for (int i = 0; i < 4; ++i) {
+    u1.w[2 * i] = (uint32_t)h_u1[i]; u1.w[2 * i + 1] = (uint32_t)(h_u1[i] >> 32);
+    u2.w[2 * i] = (uint32_t)h_u2[i]; u2.w[2 * i + 1] = (uint32_t)(h_u2[i] >> 32);
+  }
+  const CsrView A{a->d_row_ptr, a->d_col, a->d_val}, B{b->d_row_ptr, b->d_col, b->d_val}, C{cm->d_row_ptr, cm->d_col, cm->d_val};
+  const dim3 grid((unsigned)((m * XT_G + 255) / 256));
+  if (field == KG_FR) hipLaunchKernelGGL(k_nova_cross_term<FrParams>, grid, dim3(256), 0, c->stream, A, B, C, m, d_z1, d_z2, u1, u2, d_out);
+  else hipLaunchKernelGGL(k_nova_cross_term<FqParams>, grid, dim3(256), 0, c->stream, A, B, C, m, d_z1, d_z2, u1, u2, d_out);
   KG_HIP(c, hipGetLastError());
   return KG_OK;
 }

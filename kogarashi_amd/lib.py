@@ -24,7 +24,7 @@ EXPORTS = [
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
     "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
-    "kg_sharded_key_len", "kg_sharded_key_commit",
+    "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term",
 ]
 
 
@@ -37,6 +37,11 @@ class Groth16Crs(C.Structure):
                 ("alpha_g1", C.c_uint64 * 8), ("beta_g1", C.c_uint64 * 8), ("delta_g1", C.c_uint64 * 8),
                 ("beta_g2", C.c_uint64 * 16), ("delta_g2", C.c_uint64 * 16),
                 ("delta_g1_inf", C.c_uint8), ("delta_g2_inf", C.c_uint8)]
+
+
+class Csr(C.Structure):
+    """kg_csr of include/kogarashi_amd.h"""
+    _fields_ = [("d_row_ptr", C.c_void_p), ("d_col", C.c_void_p), ("d_val", C.c_void_p)]
 
 
 class KogarashiError(RuntimeError):
@@ -234,6 +239,18 @@ class Context:
 
     def r1cs_evaluate(self, row_ptr: int, col: int, val: int, m: int, z: int, out: int):
         self._chk(self._lib.kg_r1cs_evaluate(self._h, _vp(row_ptr), _vp(col), _vp(val), C.c_size_t(m), _vp(z), _vp(out)), "kg_r1cs_evaluate")
+
+    def r1cs_prod(self, field: int, row_ptr: int, col: int, val: int, m: int, z: int, out: int):
+        self._chk(self._lib.kg_r1cs_prod(self._h, field, _vp(row_ptr), _vp(col), _vp(val), C.c_size_t(m), _vp(z), _vp(out)), "kg_r1cs_prod")
+
+    def nova_cross_term(self, field: int, a, b, c, m: int, z1: int, z2: int, u1: np.ndarray, u2: np.ndarray, out: int):
+        """kg_nova_cross_term; a, b, c: (row_ptr, col, val) device pointers"""
+        mk = lambda t: Csr(_vp(t[0]), _vp(t[1]), _vp(t[2]))
+        ca, cb, cc = mk(a), mk(b), mk(c)
+        u1 = np.ascontiguousarray(u1, dtype=np.uint64)
+        u2 = np.ascontiguousarray(u2, dtype=np.uint64)
+        self._chk(self._lib.kg_nova_cross_term(self._h, field, C.byref(ca), C.byref(cb), C.byref(cc), C.c_size_t(m), _vp(z1), _vp(z2),
+                                               u1.ctypes.data_as(C.c_void_p), u2.ctypes.data_as(C.c_void_p), _vp(out)), "kg_nova_cross_term")
 
     def fixed_base_mul(self, curve: int, k: int, n: int, out_xy: int, out_inf: int):
         self._chk(self._lib.kg_fixed_base_mul(self._h, curve, _vp(k), C.c_size_t(n), _vp(out_xy), _vp(out_inf)), "kg_fixed_base_mul")

@@ -587,4 +587,6 @@ void kgo_gen_bases_mt(int curve, u64 seed, size_t start, size_t n, u64 *out, int
 }
 #include "kg_oracle_groth16.inc"
 
+#include "kg_oracle_nova.inc"
+
 int kgo_version(void) { return 1; }

@@ -22,7 +22,7 @@ U8P = C.POINTER(C.c_uint8)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("kg_oracle.c", "kg_oracle_curve.inc", "kg_oracle_groth16.inc")]
+    srcs = [os.path.join(_HERE, f) for f in ("kg_oracle.c", "kg_oracle_curve.inc", "kg_oracle_groth16.inc", "kg_oracle_nova.inc")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -402,3 +402,25 @@ def groth16_prove(cs: R1cs, P, r, s, threads=8, evals=None):
     if rc:
         raise ValueError("ProverSubVersionCrsAttack")
     return out[:8].copy(), out[8:24].copy(), out[24:].copy(), inf
+
+
+# ---- Nova (oracle/kg_oracle_nova.inc) ----------------------------------------------------------------
+def matrix_prod(fd, csr, z):
+    """SparseMatrix::prod (zkstd/src/matrix.rs:36-48) over z = (u | x | w)"""
+    rp, col, val = (_arr(t) for t in csr)
+    z = _arr(z)
+    m = len(rp) - 1
+    o = np.empty((m, 4), dtype=np.uint64)
+    lib().kgo_matrix_prod(int(fd), _p(rp), _p(col), _p(val), C.c_size_t(m), _p(z), _p(o))
+    return o
+
+
+def nova_cross_term(fd, a, b, c, z1, z2, u1, u2):
+    """Prover::compute_cross_term (nova/src/prover.rs:53-90): T = AZ1 o BZ2 + AZ2 o BZ1 - u1 CZ2 - u2 CZ1"""
+    a, b, c = ([_arr(t) for t in csr] for csr in (a, b, c))
+    z1, z2, u1, u2 = _arr(z1), _arr(z2), _arr(u1), _arr(u2)
+    m = len(a[0]) - 1
+    o = np.empty((m, 4), dtype=np.uint64)
+    lib().kgo_nova_cross_term(int(fd), _p(a[0]), _p(a[1]), _p(a[2]), _p(b[0]), _p(b[1]), _p(b[2]), _p(c[0]), _p(c[1]), _p(c[2]),
+                              C.c_size_t(m), _p(z1), _p(z2), _p(u1), _p(u2), _p(o))
+    return o

@@ -48,6 +48,15 @@ pub struct KgGroth16Crs {
     pub delta_g2_inf: u8,
 }
 
+/// `kg_csr`: one sparse matrix of an R1CS shape as CSR over z = (u | x | w), device pointers (`kg_nova_cross_term`).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct KgCsr {
+    pub d_row_ptr: *const u64,
+    pub d_col: *const u64,
+    pub d_val: *const u64,
+}
+
 // kg_status
 pub const KG_OK: i32 = 0;
 pub const KG_ERR_NO_DEVICE: i32 = -1;

@@ -7,6 +7,7 @@
 #include "../../kogarashi_amd/csrc/fp29_checked.h"
 #include "../../kogarashi_amd/csrc/curve.h"
 #include "../../kogarashi_amd/csrc/ntt_core.h"
+#include "../../kogarashi_amd/csrc/vecops.h"
 
 using namespace kg;
 
@@ -165,4 +166,27 @@ static void ntt_network(const uint32_t* data, const uint32_t* tw, int rounds, in
 }
 extern "C" void ht_ntt_network(int checked, const uint32_t* data, const uint32_t* tw, int rounds, int trivial_first, uint32_t* out) {
   if (checked) ntt_network<FrC>(data, tw, rounds, trivial_first, out); else ntt_network<Fr>(data, tw, rounds, trivial_first, out);
+}
+
+// ---- vector kernels (vecops.h) ------------------------------------------------------------------------
+// Nova cross term of one row from dense "rows": az1 = sum_k va[k] * z1[k] etc. over cnt terms (the kernel's row_dot with
+// every lane's terms folded in sequence, then merged pairwise like the shuffle tree), then cross_term_row.
+// va, vb, vc, z1, z2: cnt elements each in the ABI form; u1, u2: one element each.  out: canonical ABI form.
+template <class F>
+static void cross_term(const uint32_t* va, const uint32_t* vb, const uint32_t* vc, const uint32_t* z1, const uint32_t* z2, size_t cnt,
+                       const uint32_t* u1, const uint32_t* u2, uint32_t* out) {
+  using P = typename F::Params;
+  auto dot = [&](const uint32_t* v, const uint32_t* z) {
+    F lane[4] = {F::zero(), F::zero(), F::zero(), F::zero()};
+    for (size_t k = 0; k < cnt; ++k) lane[k & 3] = dot_step(lane[k & 3], RawIn<F>::in(z + 8 * k), Conv<F>::in(v + 8 * k));
+    return dot_merge(dot_merge(lane[0], lane[1]), dot_merge(lane[2], lane[3]));
+  };
+  const F r = cross_term_row(dot(va, z1), dot(va, z2), dot(vb, z1), dot(vb, z2), dot(vc, z1), dot(vc, z2), Conv<F>::in(u1), Conv<F>::in(u2),
+                             F::from_const(P::C_FROM_REF));
+  raw_out(r, out);
+}
+extern "C" void ht_cross_term(int field, int checked, const uint32_t* va, const uint32_t* vb, const uint32_t* vc, const uint32_t* z1,
+                              const uint32_t* z2, size_t cnt, const uint32_t* u1, const uint32_t* u2, uint32_t* out) {
+  if (field == 0) { if (checked) cross_term<FrC>(va, vb, vc, z1, z2, cnt, u1, u2, out); else cross_term<Fr>(va, vb, vc, z1, z2, cnt, u1, u2, out); }
+  else { if (checked) cross_term<FqC>(va, vb, vc, z1, z2, cnt, u1, u2, out); else cross_term<Fq>(va, vb, vc, z1, z2, cnt, u1, u2, out); }
 }

@@ -151,3 +151,27 @@ def test_ntt_butterfly_network_bounds_and_values(hostlib, oracle):
             out = np.zeros((8, 4), dtype=np.uint64)
             hostlib.ht_ntt_network(chk, p32(data.view(np.uint32)), p32(tw.view(np.uint32)), rounds, trivial, p32(out.view(np.uint32)))
             assert (out == want).all(), (trial, chk)
+
+
+@pytest.mark.parametrize("fd", [0, 1])
+def test_cross_term_row_bounds_and_values(hostlib, oracle, fd):
+    """vecops.h: the lazy row products and the cross-term combination of kg_nova_cross_term (nova/src/prover.rs:53-90) with
+    the bound-tracking type (no column / limb / value overflow for ANY operands) and against the oracle's restatement."""
+    O = oracle
+    c = O.f_consts(fd)
+    pm1 = O.f_to_mont(fd, (lambda v: (v.__setitem__(0, v[0] - 1), v)[1])(c["p"].copy()))
+    for cnt, seed in ((1, 1), (3, 2), (9, 3), (40, 4)):
+        va, vb, vc = (O.gen_scalars(fd, SEED + 700 + 10 * seed + j, 0, cnt) for j in range(3))
+        z1, z2 = O.gen_scalars(fd, SEED + 710 + seed, 0, cnt), O.gen_scalars(fd, SEED + 720 + seed, 0, cnt)
+        u1, u2 = O.gen_scalars(fd, SEED + 730 + seed, 0, 1)[0], c["r"]
+        if seed == 4:                                   # worst-case magnitudes: everything p - 1
+            va[:], vb[:], vc[:], z1[:], z2[:] = pm1, pm1, pm1, pm1, pm1
+            u1 = pm1
+        rp = np.array([0, cnt], dtype=np.uint64)
+        col = np.arange(cnt, dtype=np.uint64)
+        want = O.nova_cross_term(fd, (rp, col, va), (rp, col, vb), (rp, col, vc), z1, z2, u1, u2)[0]
+        for chk in (0, 1):
+            out = np.empty(4, dtype=np.uint64)
+            a32 = lambda x: p32(np.ascontiguousarray(x).view(np.uint32))
+            hostlib.ht_cross_term(fd, chk, a32(va), a32(vb), a32(vc), a32(z1), a32(z2), C.c_size_t(cnt), a32(u1), a32(u2), p32(out.view(np.uint32)))
+            assert (out == want).all(), (fd, cnt, chk)
