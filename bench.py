@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--no-groth16", action="store_true")
     ap.add_argument("--groth16-log-m", type=int, default=18)
     ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--depth", type=int, default=4, help="MSM steps in flight (1..4)")
+    ap.add_argument("--stream-ordered-inputs", action="store_true", help="do not declare the (static, synchronised) inputs complete")
     args = ap.parse_args()
 
     import numpy as np
@@ -72,11 +74,11 @@ def main():
     n = 1 << args.log_n
 
     ctx = K.Context(local_rank)
-    # every kernel of the library goes to ONE explicit (non-default) torch stream, so torch.cuda.Event and the
-    # library's own HIP events bracket the same queue
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
+    # The library launches on its own queues (main queue: accumulations; scalar-side queue: digit extraction, sort, base
+    # conversion; two reduction queues) and brackets its phases with HIP events recorded on those queues; the timed region
+    # is bracketed by device-wide synchronisation.
+    if not args.stream_ordered_inputs:
+        ctx.set_inputs_complete(True)          # inputs are generated once and synchronised before the timed region
     if args.window:
         ctx.set_msm_window(args.window)
 
@@ -85,6 +87,7 @@ def main():
     scalars = torch.empty(n * 4, dtype=torch.int64, device=dev)
     ctx.gen_bases(K.KG_G1, SEED + 1, rank * n, n, bases.data_ptr())
     ctx.gen_scalars(K.KG_FR, SEED + 2, rank * n, n, scalars.data_ptr())
+    ctx.sync()
     torch.cuda.synchronize()
 
     from kogarashi_amd import dist as kdist
@@ -97,15 +100,20 @@ def main():
             xy, inf = kdist.combine_partials(ctx, K.KG_G1, xy, inf, device=xdev)
         return xy, inf
 
+    depth = max(1, min(args.depth, 4))
+
     def run(k):
-        """k MSM steps, software-pipelined two deep through kg_msm_begin / kg_msm_end: while step i+1 sorts and
-        accumulates, step i's bucket reduction (side stream) and host finish complete.  Every step's result is produced."""
+        """k MSM steps, software-pipelined `depth` deep through kg_msm_begin / kg_msm_end (tickets 0..3): while step i
+        accumulates, step i+1 is sorted on the scalar queue and steps i-1, i-2 finish their bucket reductions (reduction
+        queues) and host tails.  Every step's result is produced inside the loop."""
         res = None
-        ctx.msm_begin(K.KG_G1, bases.data_ptr(), 0, scalars.data_ptr(), n, 0)
-        for i in range(1, k):
-            ctx.msm_begin(K.KG_G1, bases.data_ptr(), 0, scalars.data_ptr(), n, i & 1)
-            res = finish((i - 1) & 1)
-        return finish((k - 1) & 1)
+        for i in range(k):
+            ctx.msm_begin(K.KG_G1, bases.data_ptr(), 0, scalars.data_ptr(), n, i % 4)
+            if i >= depth - 1:
+                res = finish((i - depth + 1) % 4)
+        for i in range(max(k - depth + 1, 0), k):
+            res = finish(i % 4)
+        return res
 
     def barrier():
         if world > 1:
@@ -146,7 +154,7 @@ def main():
         # same madd routine with operands in registers (tools/ubench/mul_rate.hip, profiles/r01_mul_rate.txt)
         "valu_roofline": {"bound": "valu", "unit": "G point additions/s", "achieved": window_adds(n) / (acc_avg_ms * 1e-3) / 1e9,
                           "peak": MADD_PEAK_G, "frac": window_adds(n) / (acc_avg_ms * 1e-3) / 1e9 / MADD_PEAK_G},
-        "phases_ms_per_step": phase_avg, "pipelining": "two MSM steps in flight (kg_msm_begin / kg_msm_end)",
+        "phases_ms_per_step": phase_avg, "pipelining": f"{depth} MSM steps in flight (kg_msm_begin / kg_msm_end)",
     }
 
     if rank == 0 and world == 1:
@@ -191,14 +199,14 @@ def bench_ntt(ctx, torch, dev, K, log_n=22, steps=10):
     ctx.gen_scalars(K.KG_FR, SEED + 3, 0, n, data.data_ptr())
     for _ in range(2):
         ctx.ntt(data.data_ptr(), log_n, False, False)
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
+    ctx.sync()
+    # the library brackets every transform with HIP events on the queue it launches on ("ntt" phase)
+    ctx.profile_enable(True)
     for _ in range(steps):
         ctx.ntt(data.data_ptr(), log_n, False, False)
-    ev1.record()
-    torch.cuda.synchronize()
-    ms = ev0.elapsed_time(ev1) / steps
+    tot, cnt = ctx.profile_summary()["ntt"]
+    ctx.profile_enable(False)
+    ms = tot / cnt
     gbs = 64.0 * n / (ms * 1e-3) / 1e9
     return {"metric": "bn254_fr_ntt_elements_per_sec", "log_n": log_n, "value": n / (ms * 1e-3), "ms": ms,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,

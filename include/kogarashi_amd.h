@@ -58,6 +58,12 @@ const char* kg_last_error(kg_ctx* ctx);
 /* Launch on a caller-owned HIP stream (e.g. torch's current stream) instead of the context's own. */
 int kg_ctx_set_stream(kg_ctx* ctx, void* hip_stream);
 int kg_ctx_sync(kg_ctx* ctx);
+/* Stream semantics of the MSM entry points: by default an MSM's inputs may still be in flight on the context's stream
+ * (e.g. produced by kg_field_vec_op just before); its scalar-side pipeline (digit extraction, bucket sort) then starts
+ * behind everything enqueued so far.  on = 1 declares that device inputs handed to kg_msm / kg_msm_begin / kg_commit are
+ * COMPLETE when the call is made (uploaded with kg_memcpy_h2d, or the caller synchronised): the scalar side of MSM i+1 then
+ * runs on its own queue UNDER the accumulation of MSM i instead of behind it. */
+int kg_ctx_set_inputs_complete(kg_ctx* ctx, int on);
 
 /* device memory plumbing so that non-HIP hosts (Rust shim, ctypes) never link the HIP runtime */
 int kg_malloc(kg_ctx* ctx, size_t bytes, void** d_ptr);

@@ -9,16 +9,36 @@ namespace kg {
 void sync_all(kg_ctx* c) {
   hipStreamSynchronize(c->stream);
   if (c->own_stream && c->own_stream != c->stream) hipStreamSynchronize(c->own_stream);
-  for (hipStream_t s : {c->side_stream, c->side2_stream, c->aux_stream, c->aux2_stream})
+  for (hipStream_t s : {c->sort_stream, c->side_stream, c->side2_stream, c->aux_stream, c->aux2_stream})
     if (s) hipStreamSynchronize(s);
 }
-int ensure_ws(kg_ctx* c, size_t bytes) {
-  if (bytes <= c->ws_bytes) return KG_OK;
-  if (c->ws) { sync_all(c); hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
+int ensure_ws_sort(kg_ctx* c, int set, size_t bytes) {
+  if (bytes <= c->ws_sort_bytes[set]) return KG_OK;
+  if (c->ws_sort[set]) { sync_all(c); hipFree(c->ws_sort[set]); c->ws_sort[set] = nullptr; c->ws_sort_bytes[set] = 0; }
   size_t want = bytes + bytes / 8;
-  hipError_t e = hipMalloc(&c->ws, want);
+  hipError_t e = hipMalloc(&c->ws_sort[set], want);
   if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "workspace allocation", e);
-  c->ws_bytes = want;
+  c->ws_sort_bytes[set] = want;
+  return KG_OK;
+}
+// Queues of the context.  (CU-masked queues -- hipExtStreamCreateWithCUMask, a compute / service partition -- and queue
+// priorities were measured and dropped: tools/ubench/cumask_probe.hip; what makes concurrent queues
+// work is the wave priority of the service kernels, KG_SERVICE_PRIO.)
+hipError_t create_stream(kg_ctx* c, hipStream_t* out, bool service) {
+  (void)c; (void)service;
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+int make_sort_stream(kg_ctx* c) {
+  if (c->sort_stream) return KG_OK;
+  hipError_t e = create_stream(c, &c->sort_stream, true);
+  if (e != hipSuccess) return set_err(c, KG_ERR_HIP, "scalar-queue creation", e);
+  for (int i = 0; i < 2; ++i) {
+    if ((e = hipEventCreateWithFlags(&c->ev_sorted[i], hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
+    for (int j = 0; j < kg_ctx::IDLE_EVS; ++j)
+      if ((e = hipEventCreateWithFlags(&c->ev_ws_idle[i][j], hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
+  }
+  if ((e = hipEventCreateWithFlags(&c->ev_bases, hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
+  if ((e = hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
   return KG_OK;
 }
 int ensure_ws2(kg_ctx* c, size_t bytes) {
@@ -66,9 +86,9 @@ int ensure_slot(kg_ctx* c, int slot, size_t bytes) {
 // (A lowest-priority stream was measured and made no difference: the two queues do not compete for issue slots.)
 int make_side_stream(kg_ctx* c) {
   // (stream priorities were measured, high and low, for the prover and the MSM pipeline: no gain either way)
-  hipError_t e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
+  hipError_t e = create_stream(c, &c->side_stream, true);
   if (e != hipSuccess) return set_err(c, KG_ERR_HIP, "side stream creation", e);
-  e = hipStreamCreateWithFlags(&c->side2_stream, hipStreamNonBlocking);
+  e = create_stream(c, &c->side2_stream, true);
   if (e != hipSuccess) return set_err(c, KG_ERR_HIP, "side stream creation", e);
   return KG_OK;
 }
@@ -137,7 +157,7 @@ int kg_ctx_create(int device, kg_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return KG_ERR_NO_DEVICE;
   kg_ctx* c = new kg_ctx();
   c->device = device;
-  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KG_ERR_HIP; }
+  if (create_stream(c, &c->own_stream, false) != hipSuccess) { delete c; return KG_ERR_HIP; }
   c->stream = c->own_stream;
   *out = c;
   return KG_OK;
@@ -147,9 +167,17 @@ void kg_ctx_destroy(kg_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   c->prover_jobs.reset();                             // joins the worker threads of proofs still in flight
+  for (auto& f : c->ticket_fut) if (f.valid()) f.wait();      // and of MSM tickets begun and never ended
   hipStreamSynchronize(c->stream);
   tw_cache_free(c);
-  if (c->ws) hipFree(c->ws);
+  for (int i = 0; i < 2; ++i) {
+    if (c->ws_sort[i]) hipFree(c->ws_sort[i]);
+    if (c->ev_sorted[i]) hipEventDestroy(c->ev_sorted[i]);
+    for (int j = 0; j < kg_ctx::IDLE_EVS; ++j) if (c->ev_ws_idle[i][j]) hipEventDestroy(c->ev_ws_idle[i][j]);
+  }
+  if (c->ev_bases) hipEventDestroy(c->ev_bases);
+  if (c->ev_order) hipEventDestroy(c->ev_order);
+  if (c->sort_stream) { hipStreamSynchronize(c->sort_stream); hipStreamDestroy(c->sort_stream); }
   if (c->ws2) hipFree(c->ws2);
   if (c->ws3) hipFree(c->ws3);
   if (c->side_stream) hipStreamSynchronize(c->side_stream);
@@ -187,8 +215,13 @@ int kg_ctx_sync(kg_ctx* c) {
   if (!c) return KG_ERR_BAD_ARG;
   KG_HIP(c, hipSetDevice(c->device));
   KG_HIP(c, hipStreamSynchronize(c->stream));
-  for (hipStream_t s : {c->side_stream, c->side2_stream, c->aux_stream, c->aux2_stream})
+  for (hipStream_t s : {c->sort_stream, c->side_stream, c->side2_stream, c->aux_stream, c->aux2_stream})
     if (s) KG_HIP(c, hipStreamSynchronize(s));
+  return KG_OK;
+}
+int kg_ctx_set_inputs_complete(kg_ctx* c, int on) {
+  if (!c) return KG_ERR_BAD_ARG;
+  c->inputs_complete = on != 0;
   return KG_OK;
 }
 int kg_malloc(kg_ctx* c, size_t bytes, void** p) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <atomic>
+#include <future>
 #include <cstdio>
 #include <string>
 #include <memory>
@@ -19,8 +20,20 @@ struct kg_ctx {
   std::string last_error;
   int msm_window = 0;                    // 0 = auto
   // grow-only scratch
-  void* ws = nullptr;
-  size_t ws_bytes = 0;
+  // MSM scalar-side space (sorted digit lists, task tables), two sets used in turn: the sort of MSM i+1 runs on the scalar
+  // queue while the accumulation of MSM i still reads the other set
+  void* ws_sort[2] = {nullptr, nullptr};
+  size_t ws_sort_bytes[2] = {0, 0};
+  unsigned sort_seq = 0;
+  hipStream_t sort_stream = nullptr;     // scalar-side queue (prep_scalars, sort, task bookkeeping); == stream when no overlap is possible
+  hipEvent_t ev_sorted[2] = {nullptr, nullptr};     // sort of the set complete (recorded on the scalar queue)
+  static constexpr int IDLE_EVS = 8;                // readers of one set whose completion the next sort into it waits for
+  hipEvent_t ev_ws_idle[2][IDLE_EVS] = {};          // a bucket gather that read the set's level tables is complete (reduction queues)
+  int ws_idle_n[2] = {0, 0};
+  hipEvent_t ev_bases = nullptr;                    // per-call base conversion on the scalar queue complete
+  hipEvent_t ev_order = nullptr;         // stream-order hand-over main -> scalar queue
+  bool inputs_complete = false;          // kg_ctx_set_inputs_complete: MSM inputs are complete when the call is made
+
   void* ws2 = nullptr;                   // NTT ping-pong buffer
   size_t ws2_bytes = 0;
   void* ws3 = nullptr;                   // prover polynomial buffers
@@ -39,6 +52,10 @@ struct kg_ctx {
   Slot slots[NSLOTS];
   std::shared_ptr<void> prover_jobs;     // groth16.hip: proofs in flight (kg_groth16_prove_begin / _end)
   size_t ticket_n[4] = {0, 0, 0, 0};
+  // kg_msm_begin starts the ticket's host finish (wait for the reduction, 255-step double-and-add, inversion) on a worker
+  // thread, so the calling thread goes straight on to enqueue the next MSM; kg_msm_end joins it
+  std::future<int> ticket_fut[4];
+  uint64_t ticket_out[4][24] = {};
   struct Registered { const uint64_t* base; const uint8_t* inf; size_t n; int curve; uint32_t* packed; };
   std::vector<Registered> registered;    // bases converted once by kg_bases_register     // lengths of the MSMs begun with kg_msm_begin                         // pinned result slots: MSMs in flight whose host finish is pending
   void* h_pinned = nullptr;              // small pinned staging buffer for results
@@ -74,7 +91,9 @@ inline int set_err(kg_ctx* c, int code, const char* what, hipError_t e = hipSucc
     if (s__ != KG_OK) return s__; \
   } while (0)
 
-int ensure_ws(kg_ctx* c, size_t bytes);
+int ensure_ws_sort(kg_ctx* c, int set, size_t bytes);
+int make_sort_stream(kg_ctx* c);
+hipError_t create_stream(kg_ctx* c, hipStream_t* out, bool service);
 int ensure_ws2(kg_ctx* c, size_t bytes);
 int ensure_ws3(kg_ctx* c, size_t bytes);
 int ensure_ws_run(kg_ctx* c, int which, size_t bytes);
@@ -90,6 +109,19 @@ struct PhaseScope {
   void end();
 };
 void prof_reset(kg_ctx* c);
+
+// Wave priority of the "service" kernels (sorts, bookkeeping, reductions, transforms, vector ops).  VALU issue on a SIMD is
+// arbitrated by priority, then age: next to a resident, VALU-saturating accumulation (whose waves are older) a young wave at
+// the default priority gets only the leftover issue slots and runs ~10x slower (tools/ubench/coexec.hip).  With priority 3
+// the service waves -- mostly waiting on memory or LDS -- issue when they are ready and cost the accumulation ~2 %.
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifndef KG_PRIO_LEVEL
+#define KG_PRIO_LEVEL 3
+#endif
+#define KG_SERVICE_PRIO() __builtin_amdgcn_s_setprio(KG_PRIO_LEVEL)
+#else
+#define KG_SERVICE_PRIO() ((void)0)
+#endif
 
 // ---- device-side layouts ------------------------------------------------------------------------
 // A field element in the ABI: 8 x u32 words (4 x u64 LE).  Loaded/stored as two 16-byte vectors.
@@ -168,7 +200,7 @@ template <class F> struct RefIO<Fp2<F>> {
 // msm.hip: scalar-side / base-side / host halves of an MSM (used by kg_msm and by the Groth16 prover).
 // MsmSorted is the scalar-side state: digits sorted into per-bucket lists plus the task decomposition.  It depends
 // only on the scalars, so several base arrays (the CRS vectors a, b_g1, b_g2, l of a Groth16 proof all meet the same
-// witness) share one.  It lives in ctx->ws until the next msm_sort.
+// witness) share one.  It lives in one of the two scalar-side spaces of the context until the sort after next.
 struct MsmSorted {
   size_t n = 0;
   int c = 0, W = 0, B = 0;
@@ -177,11 +209,17 @@ struct MsmSorted {
   uint32_t ntasks = 0, max_cnt = 0;
   uint32_t *sorted = nullptr, *bsize = nullptr, *bstart = nullptr, *lcnt = nullptr, *lrel = nullptr, *lbase = nullptr;
   uint32_t *task_bkt = nullptr, *task_id = nullptr;
+  int set = 0;                // which scalar-side space it lives in
+  hipEvent_t ready = nullptr; // recorded on the scalar queue after the last sort kernel
 };
 // ntt.hip
 int ntt_prepare(kg_ctx* ctx, uint32_t log_n, int inverse);
 int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, uint32_t log_n, int inverse, int coset);
-int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S);
+// ordered: the caller has already put the scalar queue (ctx->sort_stream, see scalar_queue()) behind the producer of
+// d_scalars; otherwise msm_sort orders it after everything enqueued on the main queue so far (stream semantics), or not
+// at all when the context's inputs are declared complete (kg_ctx_set_inputs_complete)
+int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered = false);
+int scalar_queue(kg_ctx* ctx, hipStream_t* out);     // the scalar-side queue, created on first use
 // several base arrays against one scalar sort, accumulated by one launch (at most 3; result slots in distinct run-space sets)
 struct MsmRunJob { const uint64_t* d_bases; const uint8_t* d_inf; size_t nbases; uint32_t idx_off; int slot; };
 int msm_run_multi(kg_ctx* ctx, const MsmSorted& S, int curve, const MsmRunJob* jobs, int njobs);

@@ -80,6 +80,7 @@ __global__ void __launch_bounds__(64) k_fixed_base_mul(const uint64_t* __restric
 // h[i] = (a[i] * b[i] - c[i]) * zinv   (poly.rs:168-195 + fft.rs:150-154 in one pass; data stays in ABI form)
 __global__ void __launch_bounds__(256) k_qap_combine(uint64_t* __restrict__ a, const uint64_t* __restrict__ b, const uint64_t* __restrict__ c,
                                                      size_t n, Words8 zinv) {
+  KG_SERVICE_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t wa[8], wb[8], wc[8], wo[8];
@@ -193,8 +194,8 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // run on three side queues UNDER the witness MSMs of the main queue, and h's MSM -- the only consumer of the
   // transforms -- goes last.
   if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
-  if (!ctx->aux_stream) KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-  if (!ctx->aux2_stream) KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux2_stream, hipStreamNonBlocking));
+  if (!ctx->aux_stream) KG_HIP(ctx, create_stream(ctx, &ctx->aux_stream, true));
+  if (!ctx->aux2_stream) KG_HIP(ctx, create_stream(ctx, &ctx->aux2_stream, true));
   if (!ctx->ev_fork) {
     KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
@@ -225,9 +226,15 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // device continues with the next one.
   const size_t hn = (m - 1) < n ? (m - 1) : n;
   const size_t nz = l + m_l_1;
-  uint64_t* Z = C + 4 * n;                                // z = x || w
-  KG_HIP(ctx, hipMemcpyAsync(Z, d_x, l * 32, hipMemcpyDeviceToDevice, st));
-  if (m_l_1) KG_HIP(ctx, hipMemcpyAsync(Z + 4 * l, d_w, m_l_1 * 32, hipMemcpyDeviceToDevice, st));
+  uint64_t* Z = C + 4 * n;                                // z = x || w, assembled on the scalar queue (its only reader is the sort)
+  hipStream_t sq;
+  KG_TRY(scalar_queue(ctx, &sq));
+  if (!ctx->inputs_complete) {                            // stream semantics: d_x / d_w may still be in flight on the main queue
+    KG_HIP(ctx, hipEventRecord(ctx->ev_order, st));
+    KG_HIP(ctx, hipStreamWaitEvent(sq, ctx->ev_order, 0));
+  }
+  KG_HIP(ctx, hipMemcpyAsync(Z, d_x, l * 32, hipMemcpyDeviceToDevice, sq));
+  if (m_l_1) KG_HIP(ctx, hipMemcpyAsync(Z + 4 * l, d_w, m_l_1 * 32, hipMemcpyDeviceToDevice, sq));
   uint64_t *q_p = job->q_p, *l_p = job->l_p, *ai = job->ai, *b1i = job->b1i, *b2i = job->b2i;
   std::future<int>&f_q = job->f_q, &f_l = job->f_l, &f_a = job->f_a, &f_b1 = job->f_b1, &f_b2 = job->f_b2;
   auto finish_async = [&](int curve, int slot, uint64_t* out) {
@@ -239,7 +246,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   const int SL[5] = {slot_base + 1, slot_base + 2, slot_base + 3, slot_base + 4, slot_base + 5};
   {
     MsmSorted Sz;
-    rc = msm_sort(ctx, KG_FR, Z, nz, &Sz);
+    rc = msm_sort(ctx, KG_FR, Z, nz, &Sz, true);
     // G2 first: its host finish (Fq2 arithmetic, ~3x a G1 finish) and its slow reduction then overlap the G1 accumulations
     if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, 0, SL[0]);
     if (rc == KG_OK) f_b2 = finish_async(KG_G2, SL[0], b2i);
@@ -279,7 +286,9 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   if (rc == KG_OK) rc = ntt_enqueue(ctx, st, (uint64_t*)ctx->ws2, A, k, 1, 1);   // coset_idft (prover.rs:47)
   if (rc == KG_OK && hn) {
     MsmSorted Sq;
-    rc = msm_sort(ctx, KG_FR, A, hn, &Sq);
+    hip_rc(hipEventRecord(ctx->ev_order, st), "hipEventRecord(order)");             // h's coefficients come off the main queue
+    hip_rc(hipStreamWaitEvent(sq, ctx->ev_order, 0), "hipStreamWaitEvent(order)");
+    if (rc == KG_OK) rc = msm_sort(ctx, KG_FR, A, hn, &Sq, true);
     if (rc == KG_OK) rc = msm_run(ctx, Sq, KG_G1, crs->d_h, crs->d_h_inf, hn, 0, SL[4]);
     if (rc == KG_OK) f_q = finish_async(KG_G1, SL[4], q_p);
   } else msm_identity(KG_G1, q_p);

@@ -39,6 +39,7 @@ constexpr uint32_t INF_BIT = 0x80000000u;   // bit 255 of the packed x coordinat
 template <class SP>
 __global__ void __launch_bounds__(256) k_prep_scalars(const uint64_t* __restrict__ scalars, size_t n, Words8 H,
                                                       uint32_t* __restrict__ kt) {
+  KG_SERVICE_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t w[8], k[8];
@@ -58,16 +59,18 @@ __global__ void __launch_bounds__(256) k_prep_scalars(const uint64_t* __restrict
 // shift by c per window), counts bucket groups in LDS ([W][G] counters) and adds its counters to the (window, chunk,
 // group) table that k_group_scan turns into offsets -- no second read of kt for counting.
 constexpr int PREP_CH = 4096;
+constexpr int PREP_NT = 256;      // one wave per SIMD at <= 64 VGPRs: fits beside a resident accumulation (4 x 112 VGPRs per SIMD)
 template <class SP>
-__global__ void __launch_bounds__(1024) k_prep_scalars_count(const uint64_t* __restrict__ scalars, size_t n, Words8 H, uint32_t* __restrict__ kt,
+__global__ void __launch_bounds__(PREP_NT) k_prep_scalars_count(const uint64_t* __restrict__ scalars, size_t n, Words8 H, uint32_t* __restrict__ kt,
                                                              int c, int W, int shift, int G, int nch, size_t chunk_len, uint32_t* __restrict__ cnt) {
+  KG_SERVICE_PRIO();
   extern __shared__ uint32_t hist[];                 // [W][G]
   for (int t = threadIdx.x; t < W * G; t += blockDim.x) hist[t] = 0;
   __syncthreads();
   const size_t lo = (size_t)blockIdx.x * PREP_CH;
   const uint32_t cmask = (1u << c) - 1u, half = 1u << (c - 1);
-  for (int r = 0; r < PREP_CH / 1024; ++r) {
-    const size_t i = lo + (size_t)r * 1024 + threadIdx.x;
+  for (int r = 0; r < PREP_CH / PREP_NT; ++r) {
+    const size_t i = lo + (size_t)r * PREP_NT + threadIdx.x;
     if (i >= n) break;
     uint32_t w[8], k[8];
     load_words(scalars, i, w);
@@ -173,6 +176,7 @@ namespace {
 template <class F>
 __global__ void __launch_bounds__(256) k_prep_bases(const uint64_t* __restrict__ bases, const uint8_t* __restrict__ inf, size_t n,
                                                     uint32_t* __restrict__ out) {
+  KG_SERVICE_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   constexpr int W = BaseIO<F>::W, PE = BaseIO<F>::PE;
@@ -211,6 +215,7 @@ __device__ __forceinline__ uint32_t window_digit(const uint32_t* __restrict__ kt
 //   shift = 0: one bin per bucket (single-pass sort);  shift = FINE_BITS: one bin per group of 2^shift buckets
 __global__ void __launch_bounds__(1024) k_count(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len,
                                                 int shift, uint32_t* __restrict__ cnt) {
+  KG_SERVICE_PRIO();
   extern __shared__ uint32_t hist[];
   const int B = (1 << (c - 1)) >> shift;
   // workgroups are dealt round-robin over the 8 XCDs by linear id: with the window in blockIdx.x (W = 16 or 17) all
@@ -229,8 +234,22 @@ __global__ void __launch_bounds__(1024) k_count(const uint32_t* __restrict__ kt,
   for (int b = threadIdx.x; b < B; b += blockDim.x) dst[b] = hist[b];
 }
 
+// zero fill with the service priority (the runtime's own fill kernel runs at the default priority and crawls beside an
+// accumulation); words: number of 32-bit words, a multiple of 4, 16-byte aligned
+__global__ void __launch_bounds__(256) k_zero(uint4* __restrict__ p, size_t quads) {
+  KG_SERVICE_PRIO();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0, 0, 0, 0);
+}
+static inline void zero_fill(hipStream_t st, void* p, size_t bytes) {
+  const size_t quads = (bytes + 15) / 16;              // carved regions are padded to 256 bytes
+  unsigned blocks = (unsigned)((quads + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks) hipLaunchKernelGGL(k_zero, dim3(blocks), dim3(256), 0, st, reinterpret_cast<uint4*>(p), quads);
+}
+
 // per (window, bucket): exclusive prefix over chunks (in place) and the bucket's total
 __global__ void __launch_bounds__(256) k_scan_chunks(uint32_t* __restrict__ cnt, int W, int nch, int B, uint32_t* __restrict__ bsize) {
+  KG_SERVICE_PRIO();
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)W * B) return;
   const int w = (int)(t / B), b = (int)(t % B);
@@ -246,15 +265,16 @@ __global__ void __launch_bounds__(256) k_scan_chunks(uint32_t* __restrict__ cnt,
 
 // exclusive scan of one row of B counters by one 1024-thread workgroup: every lane owns a contiguous run (read as
 // 16-byte vectors when the run allows), runs are combined with wave shuffles and one LDS hop
+// (any block size that is a multiple of 64, up to 1024)
 __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* sh, uint32_t& total) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
   uint32_t inc = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
   if (lane == 63) sh[wv] = inc;
   __syncthreads();
   if (wv == 0) {
-    uint32_t x = lane < 16 ? sh[lane] : 0, xi = x;
+    uint32_t x = lane < nw ? sh[lane] : 0, xi = x;
 #pragma unroll
     for (int d = 1; d < 16; d <<= 1) { uint32_t o = __shfl_up(xi, d); if (lane >= d) xi += o; }
     if (lane < 16) sh[16 + lane] = xi - x;
@@ -266,7 +286,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 }
 __device__ __forceinline__ void scan_row(const uint32_t* __restrict__ in, int B, uint32_t* __restrict__ out, uint32_t* __restrict__ row_total, int w) {
   __shared__ uint32_t sh[40];
-  const int T = 1024;
+  const int T = (int)blockDim.x;
   const int per = (B + T - 1) / T;
   const int lo = threadIdx.x * per, hi = lo + per < B ? lo + per : B;
   const uint32_t* src = in + (size_t)w * B;
@@ -293,6 +313,7 @@ __device__ __forceinline__ void scan_row(const uint32_t* __restrict__ in, int B,
 }
 // per window: exclusive prefix of bucket sizes -> bucket start inside the window's sorted list
 __global__ void __launch_bounds__(1024) k_scan_buckets(const uint32_t* __restrict__ bsize, int B, uint32_t* __restrict__ bstart) {
+  KG_SERVICE_PRIO();
   scan_row(bsize, B, bstart, nullptr, blockIdx.x);
 }
 
@@ -303,6 +324,7 @@ __global__ void __launch_bounds__(1024) k_scan_buckets(const uint32_t* __restric
 __global__ void __launch_bounds__(1024) k_scatter(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len,
                                                   int shift, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bstart,
                                                   uint32_t* __restrict__ sorted) {
+  KG_SERVICE_PRIO();
   extern __shared__ uint32_t off[];
   const int B = (1 << (c - 1)) >> shift;
   const uint32_t fine_mask = (1u << shift) - 1u;
@@ -333,6 +355,7 @@ constexpr int FINE_BITS = 7, FINE = 1 << FINE_BITS, SEG = 8192;
 
 // segbase[w][g] = first segment of group g (exclusive prefix of ceil(size / SEG)); segbase[w][G] = segments of window w
 __global__ void __launch_bounds__(1024) k_seg_table(const uint32_t* __restrict__ gsize, int G, uint32_t* __restrict__ segbase) {
+  KG_SERVICE_PRIO();
   __shared__ uint32_t sh[40];
   const int w = blockIdx.x, g = threadIdx.x;
   const uint32_t ns = g < G ? (gsize[(size_t)w * G + g] + SEG - 1) / SEG : 0;
@@ -346,82 +369,108 @@ __global__ void __launch_bounds__(1024) k_seg_table(const uint32_t* __restrict__
 // GS_TILE entries, ranks a tile's entries inside their bucket group with LDS atomics, lays the tile out group by group
 // in LDS and copies it out, so that consecutive lanes write consecutive addresses of a group's run (a 4-byte store per
 // lane to a random line is what bounds the unstaged k_scatter: tools/ubench/scatter_rate.hip).
-constexpr int GS_TILE = 8192;
-__global__ void __launch_bounds__(1024) k_group_scatter(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len, int G,
-                                                        const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ gstart,
-                                                        uint32_t* __restrict__ tmp) {
-  __shared__ uint32_t cursor[1024], hist[1024], lstart[1024], sh[40];    // G <= 1024; hist doubles as the tile's address delta
+// 256 threads and at most 64 VGPRs: one wave per SIMD that fits in the registers a resident accumulation leaves free, so the
+// sort of the next MSM runs beside it (see KG_SERVICE_PRIO).
+constexpr int GS_NT = 256, GS_TILE = 1024, GS_MAXG = 1024;
+__global__ void __launch_bounds__(GS_NT) k_group_scatter(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len, int G,
+                                                         const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ gstart,
+                                                         uint32_t* __restrict__ tmp) {
+  KG_SERVICE_PRIO();
+  __shared__ uint32_t cursor[GS_MAXG], hist[GS_MAXG], lstart[GS_MAXG], sh[40];    // hist doubles as the tile's address delta
   __shared__ uint32_t stage[GS_TILE];
   __shared__ uint16_t sg[GS_TILE];
   const int w = blockIdx.x, ch = blockIdx.y, nch = gridDim.y, tid = threadIdx.x;
-  if (tid < G) cursor[tid] = cnt[((size_t)w * nch + ch) * G + tid] + gstart[(size_t)w * G + tid];
+  const int per = (G + GS_NT - 1) / GS_NT;            // groups a lane owns in the scans (consecutive; <= 4)
+  for (int g = tid; g < G; g += GS_NT) cursor[g] = cnt[((size_t)w * nch + ch) * G + g] + gstart[(size_t)w * G + g];
   const size_t lo = (size_t)ch * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
   uint32_t* dst = tmp + (size_t)w * n;
   for (size_t tile = lo; tile < hi; tile += GS_TILE) {
-    if (tid < G) hist[tid] = 0;
+    for (int g = tid; g < G; g += GS_NT) hist[g] = 0;
     __syncthreads();
-    uint32_t rec[GS_TILE / 1024], rk[GS_TILE / 1024], gg[GS_TILE / 1024];
+    uint32_t rec[GS_TILE / GS_NT], key[GS_TILE / GS_NT];        // key = group << 16 | rank inside the group (tile-local; < 2048)
 #pragma unroll
-    for (int r = 0; r < GS_TILE / 1024; ++r) {
-      const size_t i = tile + (size_t)r * 1024 + tid;
-      gg[r] = 0xffffffffu;
+    for (int r = 0; r < GS_TILE / GS_NT; ++r) {
+      const size_t i = tile + (size_t)r * GS_NT + tid;
+      key[r] = 0xffffffffu;
       if (i < hi) {
         bool neg;
         const uint32_t m = window_digit(kt, n, i, w, c, W, neg);
         if (m) {
-          gg[r] = (m - 1) >> FINE_BITS;
+          const uint32_t g = (m - 1) >> FINE_BITS;
           rec[r] = (uint32_t)i | (((m - 1) & (FINE - 1)) << 24) | (neg ? 0x80000000u : 0u);
-          rk[r] = atomicAdd(&hist[gg[r]], 1u);
+          key[r] = (g << 16) | atomicAdd(&hist[g], 1u);
         }
       }
     }
     __syncthreads();
-    const uint32_t v = tid < G ? hist[tid] : 0u;
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan_1024(v, sh, total);
-    if (tid < G) {
-      lstart[tid] = ex;
-      hist[tid] = cursor[tid] - ex;                   // destination = position in the tile + this
-      cursor[tid] += v;
-    }
-    __syncthreads();
+    uint32_t v[4], vsum = 0;
 #pragma unroll
-    for (int r = 0; r < GS_TILE / 1024; ++r) {
-      if (gg[r] != 0xffffffffu) {
-        const uint32_t p = lstart[gg[r]] + rk[r];
-        stage[p] = rec[r];
-        sg[p] = (uint16_t)gg[r];
+    for (int j = 0; j < 4; ++j) { const int g = tid * per + j; v[j] = (j < per && g < G) ? hist[g] : 0u; vsum += v[j]; }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan_1024(vsum, sh, total);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = tid * per + j;
+      if (j < per && g < G) {
+        lstart[g] = ex;
+        hist[g] = cursor[g] - ex;                     // destination = position in the tile + this
+        cursor[g] += v[j];
+        ex += v[j];
       }
     }
     __syncthreads();
-    for (uint32_t p = tid; p < total; p += 1024) dst[p + hist[sg[p]]] = stage[p];
+#pragma unroll
+    for (int r = 0; r < GS_TILE / GS_NT; ++r) {
+      if (key[r] != 0xffffffffu) {
+        const uint32_t g = key[r] >> 16, p = lstart[g] + (key[r] & 0xffffu);
+        stage[p] = rec[r];
+        sg[p] = (uint16_t)g;
+      }
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < total; p += GS_NT) dst[p + hist[sg[p]]] = stage[p];
     __syncthreads();
   }
 }
 
 // One workgroup per window, one lane per bucket group: exclusive prefix of the group's counters over the chunks (in
 // place), group sizes and starts, the segment table, and the window's bucket sizes zeroed for k_fine_count.
-__global__ void __launch_bounds__(1024) k_group_scan(uint32_t* __restrict__ cnt, int nch, int G, int B, uint32_t* __restrict__ gsize,
-                                                     uint32_t* __restrict__ gstart, uint32_t* __restrict__ segbase, uint32_t* __restrict__ bsize) {
+__global__ void __launch_bounds__(GS_NT) k_group_scan(uint32_t* __restrict__ cnt, int nch, int G, int B, uint32_t* __restrict__ gsize,
+                                                       uint32_t* __restrict__ gstart, uint32_t* __restrict__ segbase, uint32_t* __restrict__ bsize) {
+  KG_SERVICE_PRIO();
   __shared__ uint32_t sh[40];
-  const int w = blockIdx.x, g = threadIdx.x;
-  uint32_t run = 0;
-  if (g < G) {
-    for (int ch = 0; ch < nch; ++ch) {
-      uint32_t* p = cnt + ((size_t)w * nch + ch) * G + g;
-      const uint32_t v = *p;
-      *p = run;
-      run += v;
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const int per = (G + GS_NT - 1) / GS_NT;            // consecutive groups per lane (<= 4)
+  uint32_t run[4], ns[4], rsum = 0, nsum = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = tid * per + j;
+    run[j] = 0;
+    if (j < per && g < G) {
+      for (int ch = 0; ch < nch; ++ch) {
+        uint32_t* p = cnt + ((size_t)w * nch + ch) * G + g;
+        const uint32_t v = *p;
+        *p = run[j];
+        run[j] += v;
+      }
+      gsize[(size_t)w * G + g] = run[j];
     }
-    gsize[(size_t)w * G + g] = run;
+    ns[j] = (run[j] + SEG - 1) / SEG;
+    rsum += run[j]; nsum += ns[j];
   }
   uint32_t total;
-  const uint32_t st = block_exclusive_scan_1024(run, sh, total);
-  if (g < G) gstart[(size_t)w * G + g] = st;
-  const uint32_t ns = (run + SEG - 1) / SEG;
-  const uint32_t ex = block_exclusive_scan_1024(ns, sh, total);
-  if (g < G) segbase[(size_t)w * (G + 1) + g] = ex;
-  if (g == 0) segbase[(size_t)w * (G + 1) + G] = total;
+  uint32_t st = block_exclusive_scan_1024(rsum, sh, total);
+  uint32_t ex = block_exclusive_scan_1024(nsum, sh, total);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = tid * per + j;
+    if (j < per && g < G) {
+      gstart[(size_t)w * G + g] = st;
+      segbase[(size_t)w * (G + 1) + g] = ex;
+      st += run[j]; ex += ns[j];
+    }
+  }
+  if (tid == 0) segbase[(size_t)w * (G + 1) + G] = total;
   uint4* z = reinterpret_cast<uint4*>(bsize + (size_t)w * B);            // B is a multiple of 4 here (c >= 12)
   for (int b = threadIdx.x; b < B / 4; b += blockDim.x) z[b] = make_uint4(0, 0, 0, 0);
 }
@@ -444,6 +493,7 @@ __global__ void __launch_bounds__(512) k_fine_count(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gsize,
                                                     const uint32_t* __restrict__ segbase, uint32_t* __restrict__ bsize,
                                                     uint32_t* __restrict__ segcnt, uint32_t* __restrict__ segoff) {
+  KG_SERVICE_PRIO();
   __shared__ uint32_t sb[1025];
   __shared__ uint32_t hist[FINE];
   const int w = blockIdx.x;
@@ -469,6 +519,7 @@ __global__ void __launch_bounds__(512) k_fine_scatter(const uint32_t* __restrict
                                                       const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ bstart,
                                                       const uint32_t* __restrict__ segcnt, const uint32_t* __restrict__ segoff,
                                                       uint32_t* __restrict__ sorted) {
+  KG_SERVICE_PRIO();
   __shared__ uint32_t sb[1025];
   __shared__ uint32_t lstart[FINE], cursor[FINE], gbase[FINE], wsum;
   __shared__ uint32_t stage[SEG];
@@ -525,6 +576,7 @@ struct Level {            // one round's task bookkeeping, all device pointers
 // tasks per bucket for item counts `in` and a segment length T; block-reduced maximum of `in`
 __global__ void __launch_bounds__(1024) k_task_count(const uint32_t* __restrict__ in, size_t total, uint32_t T,
                                                      uint32_t* __restrict__ ntask, uint32_t* __restrict__ maxv) {
+  KG_SERVICE_PRIO();
   __shared__ uint32_t red[16];
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t v = 0;
@@ -546,11 +598,13 @@ __global__ void __launch_bounds__(1024) k_task_count(const uint32_t* __restrict_
 // per window: exclusive prefix of `in` -> rel, window total -> row_total[w]
 __global__ void __launch_bounds__(1024) k_scan_rows(const uint32_t* __restrict__ in, int B, uint32_t* __restrict__ rel,
                                                     uint32_t* __restrict__ row_total) {
+  KG_SERVICE_PRIO();
   scan_row(in, B, rel, row_total, blockIdx.x);
 }
 // base[w] = sum_{w' < w} row_total[w'], base[W] = grand total; info[0] = grand total, info[1] = *maxv
 __global__ void k_row_bases(const uint32_t* __restrict__ row_total, int W, uint32_t* __restrict__ base, const uint32_t* __restrict__ maxv,
                             uint32_t* __restrict__ info) {
+  KG_SERVICE_PRIO();
   if (threadIdx.x || blockIdx.x) return;
   uint32_t run = 0;
   for (int w = 0; w < W; ++w) { base[w] = run; run += row_total[w]; }
@@ -634,6 +688,7 @@ __device__ __forceinline__ uint32_t len_key(uint32_t len) { return len > 255u ? 
 
 __global__ void __launch_bounds__(1024) k_len_hist(const uint32_t* __restrict__ bsize, const uint32_t* __restrict__ ntask, size_t total, uint32_t T,
                                                    uint32_t* __restrict__ ghist) {
+  KG_SERVICE_PRIO();
   __shared__ uint32_t h[LEN_BINS];
   if (threadIdx.x < LEN_BINS) h[threadIdx.x] = 0;
   __syncthreads();
@@ -651,6 +706,7 @@ __global__ void __launch_bounds__(1024) k_len_hist(const uint32_t* __restrict__ 
 }
 // cursor[k] = number of tasks with a larger key (descending layout)
 __global__ void k_len_scan(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ cursor) {
+  KG_SERVICE_PRIO();
   if (threadIdx.x || blockIdx.x) return;
   uint32_t run = 0;
   for (int k = LEN_BINS - 1; k >= 0; --k) { cursor[k] = run; run += ghist[k]; }
@@ -659,6 +715,7 @@ __global__ void __launch_bounds__(1024) k_len_scatter(const uint32_t* __restrict
                                                       const uint32_t* __restrict__ rel, const uint32_t* __restrict__ base, size_t total, int B,
                                                       uint32_t T, uint32_t* __restrict__ cursor, uint32_t* __restrict__ task_bkt,
                                                       uint32_t* __restrict__ task_id) {
+  KG_SERVICE_PRIO();
   __shared__ uint32_t h[LEN_BINS], start[LEN_BINS], fill[LEN_BINS];
   if (threadIdx.x < LEN_BINS) { h[threadIdx.x] = 0; fill[threadIdx.x] = 0; }
   __syncthreads();
@@ -693,14 +750,16 @@ __global__ void __launch_bounds__(1024) k_len_scatter(const uint32_t* __restrict
 // One workgroup per window over the bucket sizes: bucket starts (exclusive prefix), tasks per bucket and their prefix,
 // the window's task total, the largest bucket, and the histogram of task lengths -- everything the task decomposition
 // needs from one read of the sizes (k_task_count + k_scan_rows + k_scan_buckets + k_len_hist of the multi-round path).
-__global__ void __launch_bounds__(1024) k_bucket_rows(const uint32_t* __restrict__ bsize, int B, uint32_t T, uint32_t* __restrict__ bstart,
+constexpr int BR_NT = 256;
+__global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restrict__ bsize, int B, uint32_t T, uint32_t* __restrict__ bstart,
                                                       uint32_t* __restrict__ ntask, uint32_t* __restrict__ rel, uint32_t* __restrict__ row_total,
                                                       uint32_t* __restrict__ maxv, uint32_t* __restrict__ ghist) {
+  KG_SERVICE_PRIO();
   __shared__ uint32_t sh[40], h[LEN_BINS], red[16];
   const int w = blockIdx.x;
   if (threadIdx.x < LEN_BINS) h[threadIdx.x] = 0;
   __syncthreads();
-  const int per = (B + 1023) / 1024;
+  const int per = (B + BR_NT - 1) / BR_NT;
   const int lo = threadIdx.x * per, hi = lo + per < B ? lo + per : B;
   const uint32_t* src = bsize + (size_t)w * B;
   const bool vec = (per & 3) == 0 && hi - lo == per;       // every lane owns whole 16-byte groups
@@ -748,7 +807,7 @@ __global__ void __launch_bounds__(1024) k_bucket_rows(const uint32_t* __restrict
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t m = 0;
-    for (int i = 0; i < 16; ++i) m = red[i] > m ? red[i] : m;
+    for (int i = 0; i < BR_NT / 64; ++i) m = red[i] > m ? red[i] : m;
     if (m) atomicMax(maxv, m);
     row_total[w] = total_t;
   }
@@ -758,6 +817,7 @@ __global__ void __launch_bounds__(1024) k_bucket_rows(const uint32_t* __restrict
 __global__ void __launch_bounds__(64) k_task_bases(const uint32_t* __restrict__ row_total, int W, uint32_t* __restrict__ base,
                                                    const uint32_t* __restrict__ maxv, uint32_t* __restrict__ info,
                                                    const uint32_t* __restrict__ ghist, uint32_t* __restrict__ cursor) {
+  KG_SERVICE_PRIO();
   const int lane = threadIdx.x;
   if (lane == 0) {
     uint32_t run = 0;
@@ -863,6 +923,7 @@ __global__ void __launch_bounds__(64) k_sum_tasks(const uint32_t* __restrict__ p
 template <class F>
 __global__ void __launch_bounds__(256) k_gather_buckets(const uint32_t* __restrict__ pin, size_t in_stride, Level L, int W, int B,
                                                         uint32_t* __restrict__ buckets) {
+  KG_SERVICE_PRIO();
   const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
   const size_t total = (size_t)W * B;
   if (t >= total) return;
@@ -882,6 +943,7 @@ __global__ void __launch_bounds__(256) k_gather_buckets(const uint32_t* __restri
 template <class F>
 __global__ void __launch_bounds__(64) k_halve(const uint32_t* __restrict__ in, size_t in_stride, uint32_t* __restrict__ out, size_t out_stride,
                                               int W, int narr_in, uint32_t n_out) {
+  KG_SERVICE_PRIO();
   const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
   const size_t per_w = (size_t)narr_in * n_out;
   if (t >= per_w * W) return;
@@ -910,6 +972,7 @@ template <class F>
 __device__ __forceinline__ void export_el(const Fp2S<F>& a, uint64_t* dst) { export_el(a.v, dst + 4 * Fp2S<F>::half()); }
 template <class F, int E64>
 __global__ void __launch_bounds__(64) k_export(const uint32_t* __restrict__ in, size_t stride, size_t count, uint64_t* __restrict__ out) {
+  KG_SERVICE_PRIO();
   size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
   if (t >= count) return;
   XYZZ<F> p = PointIO<F>::load(in, stride, t);
@@ -923,6 +986,14 @@ __global__ void __launch_bounds__(64) k_export(const uint32_t* __restrict__ in, 
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+// debugging aid (KG_TRACE_HOST=1): host-side timestamps of the pipeline's calls
+static void host_trace(const char* what) {
+  static const bool on = getenv("KG_TRACE_HOST") != nullptr;
+  if (!on) return;
+  static const auto t0 = std::chrono::steady_clock::now();
+  fprintf(stderr, "[host] %-18s %10.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+}
+
 int pick_window(size_t n, int forced) {
   if (forced) return forced;
   int lg = 0;
@@ -982,8 +1053,9 @@ struct Carver {
 
 namespace kg {
 
-int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S) {
+int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered) {
   if (n == 0 || n >= ((size_t)1 << 31)) return set_err(ctx, KG_ERR_BAD_ARG, "msm length must be in [1, 2^31)");
+  host_trace("sort: enter");
   KG_HIP(ctx, hipSetDevice(ctx->device));
   int c = pick_window(n, ctx->msm_window);
   if (c > 16 && !(n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24))) c = 16;   // one-pass histogram: 2^(c-1) LDS counters
@@ -1013,9 +1085,23 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   const size_t o_sorted = cv.take((size_t)W * n * 4), o_lcnt = cv.take(npts * 4), o_lrel = cv.take(npts * 4), o_lbase = cv.take((size_t)(W + 1) * 4);
   const size_t o_rowtot = cv.take((size_t)W * 4), o_misc = cv.take(64), o_lenh = cv.take(2 * LEN_BINS * 4);
   const size_t o_tbkt = cv.take(part_cap * 4), o_tid = cv.take(part_cap * 4);
-  KG_TRY(ensure_ws(ctx, cv.off));
+  // The scalar side runs on a queue of its own and alternates between two spaces: while MSM i accumulates (main queue,
+  // reading set i & 1), MSM i+1 is sorted into the other set.  Ordering: the scalar queue waits for `after` (the producer
+  // of d_scalars), or -- stream semantics -- for everything enqueued on the main queue so far, unless the context's inputs
+  // are declared complete (kg_ctx_set_inputs_complete); and for the last reader of the set it is about to overwrite.
+  const int set = (int)(ctx->sort_seq++ & 1u);
+  KG_TRY(ensure_ws_sort(ctx, set, cv.off));
   KG_TRY(ensure_pinned(ctx, 4096));
-  char* ws = (char*)ctx->ws;
+  KG_TRY(make_sort_stream(ctx));
+  char* ws = (char*)ctx->ws_sort[set];
+  hipStream_t st = ctx->sort_stream;
+  if (!ordered && !ctx->inputs_complete) {
+    KG_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
+    KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_order, 0));
+  }
+  for (int j = 0; j < ctx->ws_idle_n[set]; ++j) KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_ws_idle[set][j], 0));
+  ctx->ws_idle_n[set] = 0;
+  S->set = set; S->ready = ctx->ev_sorted[set];
   uint32_t* kt = (uint32_t*)(ws + o_kt);
   uint32_t* cnt = (uint32_t*)(ws + o_cnt);
   uint32_t* rowtot = (uint32_t*)(ws + o_rowtot);
@@ -1025,7 +1111,6 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   S->sorted = (uint32_t*)(ws + o_sorted); S->bsize = (uint32_t*)(ws + o_bsize); S->bstart = (uint32_t*)(ws + o_bstart);
   S->lcnt = (uint32_t*)(ws + o_lcnt); S->lrel = (uint32_t*)(ws + o_lrel); S->lbase = (uint32_t*)(ws + o_lbase);
   S->task_bkt = (uint32_t*)(ws + o_tbkt); S->task_id = (uint32_t*)(ws + o_tid);
-  hipStream_t st = ctx->stream;
 
   Words8 H;                                          // bias H = sum_{w < W-1} 2^(w*c + c - 1)
   for (int j = 0; j < 8; ++j) H.w[j] = 0;
@@ -1034,24 +1119,24 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
     H.w[bit >> 5] |= 1u << (bit & 31);
   }
   {
-    PhaseScope ph(ctx, "prep_scalars");
+    PhaseScope ph(ctx, "prep_scalars", st);
     if (two_pass) {
       const size_t hl = (size_t)W * G * 4;
-      KG_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)W * nch * G * 4, st));
+      zero_fill(st, cnt, (size_t)W * nch * G * 4);
       const dim3 grid((unsigned)((n + PREP_CH - 1) / PREP_CH));
       if (scalar_field == KG_FR) {
         if (hl > 48 * 1024) KG_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_scalars_count<FrParams>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
-        hipLaunchKernelGGL(k_prep_scalars_count<FrParams>, grid, dim3(1024), hl, st, d_scalars, n, H, kt, c, W, FINE_BITS, G, nch, chunk_len, cnt);
+        hipLaunchKernelGGL(k_prep_scalars_count<FrParams>, grid, dim3(PREP_NT), hl, st, d_scalars, n, H, kt, c, W, FINE_BITS, G, nch, chunk_len, cnt);
       } else {
         if (hl > 48 * 1024) KG_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_scalars_count<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
-        hipLaunchKernelGGL(k_prep_scalars_count<FqParams>, grid, dim3(1024), hl, st, d_scalars, n, H, kt, c, W, FINE_BITS, G, nch, chunk_len, cnt);
+        hipLaunchKernelGGL(k_prep_scalars_count<FqParams>, grid, dim3(PREP_NT), hl, st, d_scalars, n, H, kt, c, W, FINE_BITS, G, nch, chunk_len, cnt);
       }
     } else if (scalar_field == KG_FR) hipLaunchKernelGGL(k_prep_scalars<FrParams>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
     else hipLaunchKernelGGL(k_prep_scalars<FqParams>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
     ph.end();
   }
   {
-    PhaseScope ph(ctx, "sort");
+    PhaseScope ph(ctx, "sort", st);
     const size_t lds = (size_t)(two_pass ? G : B) * 4;
     if (lds > 48 * 1024) {      // the whole-window histogram needs more than the default dynamic LDS limit
       KG_HIP(ctx, hipFuncSetAttribute((const void*)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1063,10 +1148,10 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
     uint32_t* segbase = (uint32_t*)(ws + o_segbase);
     uint32_t* segcnt = (uint32_t*)(ws + o_segcnt);
     uint32_t* segoff = (uint32_t*)(ws + o_segoff);
-    KG_HIP(ctx, hipMemsetAsync(misc, 0, (o_lenh - o_misc) + 2 * LEN_BINS * 4, st));      // misc and the length histogram
+    zero_fill(st, misc, (o_lenh - o_misc) + 2 * LEN_BINS * 4);      // misc and the length histogram
     if (two_pass) {
-      hipLaunchKernelGGL(k_group_scan, dim3(W), dim3(1024), 0, st, cnt, nch, G, B, gsize, gstart, segbase, S->bsize);
-      hipLaunchKernelGGL(k_group_scatter, dim3(W, nch), dim3(1024), 0, st, kt, n, c, W, chunk_len, G, cnt, gstart, tmp);
+      hipLaunchKernelGGL(k_group_scan, dim3(W), dim3(GS_NT), 0, st, cnt, nch, G, B, gsize, gstart, segbase, S->bsize);
+      hipLaunchKernelGGL(k_group_scatter, dim3(W, nch), dim3(GS_NT), 0, st, kt, n, c, W, chunk_len, G, cnt, gstart, tmp);
       hipLaunchKernelGGL(k_fine_count, dim3(W, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, gstart, gsize, segbase, S->bsize, segcnt, segoff);
     } else {
       hipLaunchKernelGGL(k_count, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, 0, cnt);
@@ -1075,7 +1160,7 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
     // task decomposition (needs only the bucket sizes); its two result words travel to the host while the
     // scatter below still runs, so the read-back does not stall the queue
     const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
-    hipLaunchKernelGGL(k_bucket_rows, dim3(W), dim3(1024), 0, st, S->bsize, B, T, S->bstart, S->lcnt, S->lrel, rowtot, misc, lenh);
+    hipLaunchKernelGGL(k_bucket_rows, dim3(W), dim3(BR_NT), 0, st, S->bsize, B, T, S->bstart, S->lcnt, S->lrel, rowtot, misc, lenh);
     hipLaunchKernelGGL(k_task_bases, dim3(1), dim3(64), 0, st, rowtot, W, S->lbase, misc, misc + 4, lenh, lenh + LEN_BINS);
     uint32_t* h_info = (uint32_t*)ctx->h_pinned;
     KG_HIP(ctx, hipMemcpyAsync(h_info, misc + 4, 8, hipMemcpyDeviceToHost, st));
@@ -1088,7 +1173,10 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
       hipLaunchKernelGGL(k_scatter, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, 0, cnt, S->bstart, S->sorted);
     ph.end();
     KG_HIP(ctx, hipGetLastError());
+    KG_HIP(ctx, hipEventRecord(S->ready, st));
+    host_trace("sort: enqueued");
     KG_HIP(ctx, hipEventSynchronize(ctx->ev_info));
+    host_trace("sort: info back");
     S->ntasks = h_info[0];
     S->max_cnt = (h_info[1] + T - 1) / T;              // most tasks any bucket has
     if (S->ntasks > part_cap) return set_err(ctx, KG_ERR_HIP, "task count exceeds its bound");
@@ -1112,7 +1200,9 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
   const int W = S.W, B = S.B, c = S.c;
   const size_t npts = S.npts, part_cap = S.part_cap, nexp = (size_t)W * c;
   const size_t exp_bytes = nexp * 4 * Cfg::E64 * 8;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ctx->stream, sq;
+  KG_TRY(scalar_queue(ctx, &sq));
+  bool ordered_bases = false, converted = false;
   if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
   struct Lay { size_t o_pb, o_lc[2], o_lr[2], o_lb[2], o_part[2], o_pbuf[2], o_rowtot, o_misc, o_exp; char* ws; const uint32_t* pb; int set; };
   Lay lay[MAX_FUSED];
@@ -1152,15 +1242,31 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
     Y.pb = reg_pb ? reg_pb : (uint32_t*)(Y.ws + Y.o_pb);
     // this buffer set was last used by an earlier slot: its side-stream work must be over before we overwrite it
     for (int s2 = 0; s2 < kg_ctx::NSLOTS; ++s2)
-      if (s2 % kg_ctx::RUN_SETS == Y.set && ctx->slots[s2].done && ctx->slots[s2].busy) { KG_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[s2].done, 0)); ctx->slots[s2].busy = false; }
+      if (s2 % kg_ctx::RUN_SETS == Y.set && ctx->slots[s2].done && ctx->slots[s2].busy) {
+        KG_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[s2].done, 0));
+        if (!reg_pb) KG_HIP(ctx, hipStreamWaitEvent(sq, ctx->slots[s2].done, 0));
+        ctx->slots[s2].busy = false;
+      }
     if (!reg_pb) {
-      PhaseScope ph(ctx, "prep_bases");
-      hipLaunchKernelGGL(k_prep_bases<F>, dim3((unsigned)((J.nbases + 255) / 256)), dim3(256), 0, st, J.d_bases, J.d_inf, J.nbases, (uint32_t*)(Y.ws + Y.o_pb));
+      // per-call conversion of the bases, on the scalar queue: it runs beside the previous MSM's accumulation instead
+      // of between two accumulations on the main queue
+      if (!ctx->inputs_complete && !ordered_bases) {       // stream semantics: the bases may still be in flight on the main queue
+        KG_HIP(ctx, hipEventRecord(ctx->ev_order, st));
+        KG_HIP(ctx, hipStreamWaitEvent(sq, ctx->ev_order, 0));
+        ordered_bases = true;
+      }
+      PhaseScope ph(ctx, "prep_bases", sq);
+      hipLaunchKernelGGL(k_prep_bases<F>, dim3((unsigned)((J.nbases + 255) / 256)), dim3(256), 0, sq, J.d_bases, J.d_inf, J.nbases, (uint32_t*)(Y.ws + Y.o_pb));
       ph.end();
+      converted = true;
     }
     A.pb[k] = Y.pb; A.idx_off[k] = J.idx_off; A.partial[k] = (uint32_t*)(Y.ws + Y.o_part[0]);
   }
   const Level L0{S.lcnt, S.lrel, S.lbase};
+  if (converted) {                                                       // later on the scalar queue than the sort: covers both
+    KG_HIP(ctx, hipEventRecord(ctx->ev_bases, sq));
+    KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_bases, 0));
+  } else if (S.ready) KG_HIP(ctx, hipStreamWaitEvent(st, S.ready, 0));   // the scalar queue's sort of this set
   if (S.ntasks) {
     PhaseScope ph(ctx, "accumulate");
     hipLaunchKernelGGL(k_acc_tasks<F>, dim3(((S.ntasks + 63) / 64) * (unsigned)njobs), dim3(64), 0, st, A, S.sorted, S.bstart, S.bsize, L0, S.task_bkt, S.task_id,
@@ -1183,7 +1289,6 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
     Level L = L0;
     int pcur = 0;
     {
-      PhaseScope ph(ctx, "gather");
       // skewed inputs: re-sum a bucket's partial sums until it owns one point
       uint32_t max_cnt = S.max_cnt;
       int lv = -1;                                     // -1: level arrays of S; 0/1: local ping-pong
@@ -1206,13 +1311,20 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
         lv = nx;
         max_cnt = (max_cnt + S.T2 - 1) / S.T2;
       }
-      hipLaunchKernelGGL(k_gather_buckets<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, part[pcur], part_cap, L, W, B, pbuf[0]);
-      ph.end();
     }
-    // the bucket reduction is a chain of c-1 latency-bound launches: it runs on the side stream so that the next MSM's
-    // accumulation (main stream, other buffer set) fills the chip meanwhile
+    // Everything after the accumulation runs on a reduction queue, so that the main queue goes from one accumulation straight
+    // to the next: the dense bucket array (gather) and the c-1 latency-bound halving levels.
     KG_HIP(ctx, hipEventRecord(ctx->ev_acc[set], st));
     KG_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_acc[set], 0));
+    {
+      PhaseScope ph(ctx, "gather", side);
+      hipLaunchKernelGGL(k_gather_buckets<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, side, part[pcur], part_cap, L, W, B, pbuf[0]);
+      ph.end();
+    }
+    if (ctx->ws_idle_n[S.set] < kg_ctx::IDLE_EVS) {      // the gather is the last reader of the scalar-side set (level tables of S)
+      KG_HIP(ctx, hipEventRecord(ctx->ev_ws_idle[S.set][ctx->ws_idle_n[S.set]], side));
+      ctx->ws_idle_n[S.set] += 1;
+    } else KG_HIP(ctx, hipStreamSynchronize(side));       // more readers than events: wait here instead (never in practice)
     int cur = 0;
     {
       PhaseScope ph(ctx, "reduce", side);
@@ -1238,6 +1350,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
     KG_HIP(ctx, hipEventRecord(sl.done, side));
     sl.W = W; sl.c = c; sl.busy = true;
   }
+  host_trace("run: enqueued");
   return KG_OK;
 }
 
@@ -1248,7 +1361,9 @@ int msm_finish_t(kg_ctx* ctx, int slot, uint64_t* out_xyz) {
   using HF = typename Cfg::HF;
   kg_ctx::Slot& sl = ctx->slots[slot];
   hipSetDevice(ctx->device);
+  host_trace("finish: enter");
   if (hipEventSynchronize(sl.done) != hipSuccess) return KG_ERR_HIP;
+  host_trace("finish: slot ready");
   const auto t0 = std::chrono::steady_clock::now();
   const uint64_t* hp = (const uint64_t*)sl.host;
   constexpr int PE = 4 * Cfg::E64;
@@ -1261,10 +1376,17 @@ int msm_finish_t(kg_ctx* ctx, int slot, uint64_t* out_xyz) {
     if (l == 0) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c) * PE));
   }
   store_projective<Cfg>(acc, out_xyz);
+  host_trace("finish: done");
   if (ctx->prof) {
     ctx->host_finish_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     ctx->host_finish_calls += 1;
   }
+  return KG_OK;
+}
+
+int scalar_queue(kg_ctx* ctx, hipStream_t* out) {
+  KG_TRY(make_sort_stream(ctx));
+  *out = ctx->sort_stream;
   return KG_OK;
 }
 
@@ -1373,13 +1495,21 @@ int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t*
   if (n == 0) return KG_OK;
   kg::MsmSorted S;
   KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S));
-  return kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 1 + ticket);       // slots 1..4 (slot 0: kg_msm; 6..15: the prover's two jobs)
+  if (ctx->ticket_fut[ticket].valid()) ctx->ticket_fut[ticket].wait();      // a ticket begun twice without its end: drop the older result
+  KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 1 + ticket));      // slots 1..4 (slot 0: kg_msm; 6..15: the prover's two jobs)
+  uint64_t* out = ctx->ticket_out[ticket];
+  ctx->ticket_fut[ticket] = std::async(std::launch::async, [ctx, curve, ticket, out] { return kg::msm_finish(ctx, curve, 1 + ticket, out); });
+  return KG_OK;
 }
 
 int kg_msm_end(kg_ctx* ctx, int curve, int ticket, uint64_t* out_xyz) {
   if (!ctx || !out_xyz || curve < 0 || curve > KG_G2 || ticket < 0 || ticket > 3) return KG_ERR_BAD_ARG;
   if (ctx->ticket_n[ticket] == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
-  return kg::msm_finish(ctx, curve, 1 + ticket, out_xyz);
+  if (!ctx->ticket_fut[ticket].valid()) return kg::set_err(ctx, KG_ERR_BAD_ARG, "kg_msm_end without a matching kg_msm_begin");
+  const int rc = ctx->ticket_fut[ticket].get();
+  if (rc != KG_OK) return rc;
+  std::memcpy(out_xyz, ctx->ticket_out[ticket], (curve == KG_G2 ? 24 : 12) * 8);
+  return KG_OK;
 }
 
 int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars, size_t n, uint64_t* out_xyz) {

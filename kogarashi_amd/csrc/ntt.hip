@@ -187,6 +187,7 @@ __device__ __forceinline__ void radix_pass(uint32_t* lds, const uint32_t* twl, b
 
 template <bool ROW>
 __global__ void __launch_bounds__(NT, 2) k_ntt_step(StepArgs A) {
+  KG_SERVICE_PRIO();
   extern __shared__ uint32_t lds[];
   const uint32_t m = 1u << A.log_m, tc = 1u << A.log_tc;
   const uint64_t g0 = (uint64_t)blockIdx.x << A.log_tc;
@@ -276,6 +277,7 @@ __global__ void __launch_bounds__(NT, 2) k_ntt_step(StepArgs A) {
 
 // data[i] *= c   (c: one internal-form constant in device memory)
 __global__ void __launch_bounds__(256) k_scale_const(uint64_t* __restrict__ data, size_t n, const uint32_t* __restrict__ c) {
+  KG_SERVICE_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t w[8];

@@ -13,6 +13,7 @@ namespace {
 template <class P>
 __global__ void __launch_bounds__(256) k_vec_op(int op, const uint64_t* a, const uint64_t* b,
                                                 uint64_t* out, size_t n) {
+  KG_SERVICE_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t wa[8], wb[8], wo[8];
@@ -41,6 +42,7 @@ __global__ void __launch_bounds__(256) k_vec_op(int op, const uint64_t* a, const
 
 template <class P>
 __global__ void __launch_bounds__(256) k_vec_scale(const uint64_t* a, Words8 s, uint64_t* out, size_t n) {
+  KG_SERVICE_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t wa[8], wo[8];
@@ -54,6 +56,7 @@ __global__ void __launch_bounds__(256) k_vec_scale(const uint64_t* a, Words8 s, 
 // out[i] = start * base^i: each lane raises base to its own index (<= 64 squarings), no serial scan
 template <class P>
 __global__ void __launch_bounds__(256) k_powers(Words8 start, Words8 base, uint64_t* __restrict__ out, size_t n) {
+  KG_SERVICE_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fp<P> b = from_ref<P>(base.w), r = from_ref<P>(start.w);
@@ -70,6 +73,7 @@ __global__ void __launch_bounds__(256) k_powers(Words8 start, Words8 base, uint6
 template <class P>
 __global__ void __launch_bounds__(256) k_vec_axpy(const uint64_t* a, Words8 s, const uint64_t* b,
                                                   uint64_t* out, size_t n) {
+  KG_SERVICE_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t wa[8], wb[8], wo[8];
@@ -121,6 +125,7 @@ template <class P>
 __global__ void __launch_bounds__(256) k_r1cs_evaluate(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
                                                        const uint64_t* __restrict__ val, size_t m, const uint64_t* __restrict__ z,
                                                        uint64_t* __restrict__ out) {
+  KG_SERVICE_PRIO();
   const size_t row = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (row >= m) return;
@@ -140,6 +145,7 @@ constexpr int XT_G = 8;
 template <class P>
 __global__ void __launch_bounds__(256) k_nova_cross_term(CsrView A, CsrView B, CsrView C, size_t m, const uint64_t* __restrict__ z1,
                                                          const uint64_t* __restrict__ z2, Words8 u1, Words8 u2, uint64_t* __restrict__ out) {
+  KG_SERVICE_PRIO();
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t row = t / XT_G;
   const int lane = (int)(t % XT_G);
@@ -174,6 +180,7 @@ __device__ __forceinline__ void stream_words(uint64_t seed, uint64_t index, uint
 // uniform scalar by the reference's wide reduction (represent.rs:18-28,80-103): (lo + hi*2^256) mod p
 template <class P>
 __global__ void __launch_bounds__(256) k_gen_scalars(uint64_t seed, size_t start, size_t n, uint64_t* __restrict__ out) {
+  KG_SERVICE_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t lo[8], hi[8], wo[8];

@@ -24,7 +24,7 @@ EXPORTS = [
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
     "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
-    "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term",
+    "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete",
 ]
 
 
@@ -120,6 +120,9 @@ class Context:
     # ---- plumbing ------------------------------------------------------------------------------
     def set_stream(self, hip_stream_ptr: int):
         self._chk(self._lib.kg_ctx_set_stream(self._h, _vp(hip_stream_ptr)), "kg_ctx_set_stream")
+
+    def set_inputs_complete(self, on: bool = True):
+        self._chk(self._lib.kg_ctx_set_inputs_complete(self._h, int(bool(on))), "kg_ctx_set_inputs_complete")
 
     def sync(self):
         self._chk(self._lib.kg_ctx_sync(self._h), "kg_ctx_sync")
