@@ -49,12 +49,12 @@ int ensure_ws2(kg_ctx* c, size_t bytes) {
   c->ws2_bytes = bytes;
   return KG_OK;
 }
-int ensure_ws3(kg_ctx* c, size_t bytes) {
-  if (bytes <= c->ws3_bytes) return KG_OK;
-  if (c->ws3) { sync_all(c); hipFree(c->ws3); c->ws3 = nullptr; c->ws3_bytes = 0; }
-  hipError_t e = hipMalloc(&c->ws3, bytes);
+int ensure_ws3(kg_ctx* c, int which, size_t bytes) {
+  if (bytes <= c->ws3_bytes[which]) return KG_OK;
+  if (c->ws3[which]) { sync_all(c); hipFree(c->ws3[which]); c->ws3[which] = nullptr; c->ws3_bytes[which] = 0; }
+  hipError_t e = hipMalloc(&c->ws3[which], bytes);
   if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "prover buffer allocation", e);
-  c->ws3_bytes = bytes;
+  c->ws3_bytes[which] = bytes;
   return KG_OK;
 }
 int ensure_ws_run(kg_ctx* c, int which, size_t bytes) {
@@ -179,7 +179,7 @@ void kg_ctx_destroy(kg_ctx* c) {
   if (c->ev_order) hipEventDestroy(c->ev_order);
   if (c->sort_stream) { hipStreamSynchronize(c->sort_stream); hipStreamDestroy(c->sort_stream); }
   if (c->ws2) hipFree(c->ws2);
-  if (c->ws3) hipFree(c->ws3);
+  for (int i = 0; i < 2; ++i) if (c->ws3[i]) hipFree(c->ws3[i]);
   if (c->side_stream) hipStreamSynchronize(c->side_stream);
   for (int i = 0; i < kg_ctx::RUN_SETS; ++i) { if (c->ws_run[i]) hipFree(c->ws_run[i]); if (c->ev_acc[i]) hipEventDestroy(c->ev_acc[i]); }
   if (c->side_stream) hipStreamDestroy(c->side_stream);

@@ -36,8 +36,8 @@ struct kg_ctx {
 
   void* ws2 = nullptr;                   // NTT ping-pong buffer
   size_t ws2_bytes = 0;
-  void* ws3 = nullptr;                   // prover polynomial buffers
-  size_t ws3_bytes = 0;
+  void* ws3[2] = {nullptr, nullptr};     // prover polynomial buffers (a, b, c, z, transform scratch), one set per proof ticket
+  size_t ws3_bytes[2] = {0, 0};
   static constexpr int RUN_SETS = 8;     // a slow reduction (G2) may overlap all the later accumulations of a proof
   void* ws_run[RUN_SETS] = {};           // MSM base-side scratch (packed bases, partial sums, halving buffers), one set per slot mod RUN_SETS
   size_t ws_run_bytes[RUN_SETS] = {};
@@ -61,6 +61,7 @@ struct kg_ctx {
   void* h_pinned = nullptr;              // small pinned staging buffer for results
   size_t h_pinned_bytes = 0;
   std::vector<kg_tw_cache*> tw;          // per-(log_n, inverse) twiddle tables
+  bool tw_fresh = false;                 // tables were built on the main queue since the last fork (transform lanes must wait for them)
   // profiling
   bool prof = false;
   struct Phase { const char* name; hipEvent_t e0, e1; };
@@ -95,7 +96,7 @@ int ensure_ws_sort(kg_ctx* c, int set, size_t bytes);
 int make_sort_stream(kg_ctx* c);
 hipError_t create_stream(kg_ctx* c, hipStream_t* out, bool service);
 int ensure_ws2(kg_ctx* c, size_t bytes);
-int ensure_ws3(kg_ctx* c, size_t bytes);
+int ensure_ws3(kg_ctx* c, int which, size_t bytes);
 int ensure_ws_run(kg_ctx* c, int which, size_t bytes);
 int ensure_slot(kg_ctx* c, int slot, size_t bytes);
 int ensure_pinned(kg_ctx* c, size_t bytes);

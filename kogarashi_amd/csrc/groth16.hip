@@ -185,10 +185,15 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   if (k < 1) { k = 1; n = 2; }
   if (k > 28) return KG_ERR_BAD_ARG;
   hipStream_t st = ctx->stream;
-  KG_TRY(ensure_ws3(ctx, (3 * n + l + m_l_1) * 32));
-  uint64_t* A = (uint64_t*)ctx->ws3;
+  // polynomial buffers of this ticket: a, b, c (n each), z = x || w, three transform scratch vectors.  One set per ticket,
+  // so the next proof's transforms and witness sort start while this proof is still accumulating.
+  const int tk = slot_base >= 10 ? 1 : 0;
+  KG_TRY(ensure_ws3(ctx, tk, (6 * n + l + m_l_1) * 32));
+  uint64_t* A = (uint64_t*)ctx->ws3[tk];
   uint64_t* B = A + 4 * n;
   uint64_t* C = B + 4 * n;
+  uint64_t* Z = C + 4 * n;                                // z = x || w
+  uint64_t* TMP = Z + 4 * (l + m_l_1);                    // 3 n elements of transform scratch
   // Queue layout.  The four MSMs against z = x || w need nothing from the transforms, and the transforms are short,
   // latency-bound launches (2^18 points = 128..512 workgroups): the three idft -> coset_dft chains (prover.rs:36-41)
   // run on three side queues UNDER the witness MSMs of the main queue, and h's MSM -- the only consumer of the
@@ -202,15 +207,18 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   }
   KG_TRY(ntt_prepare(ctx, k, 0));
   KG_TRY(ntt_prepare(ctx, k, 1));
-  KG_TRY(ensure_ws2(ctx, 3 * n * 32));
   const uint64_t* src[3] = {d_a_eval, d_b_eval, d_c_eval};
   uint64_t* dst[3] = {A, B, C};
   hipStream_t lanes[3] = {ctx->aux_stream, ctx->aux2_stream, ctx->side_stream};
-  KG_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+  // stream semantics: the inputs may still be in flight on the main queue (and the twiddle tables are built there on first
+  // use); with complete inputs the chains start at once -- this ticket's buffers are free since its previous proof was collected
+  const bool fork = !ctx->inputs_complete || ctx->tw_fresh;
+  ctx->tw_fresh = false;
+  if (fork) KG_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
   for (int v = 0; v < 3; ++v) {                         // prepare_fft zero padding, then idft + coset_dft
     hipStream_t sv = lanes[v];
-    uint64_t* tmp = (uint64_t*)ctx->ws2 + (size_t)v * 4 * n;
-    KG_HIP(ctx, hipStreamWaitEvent(sv, ctx->ev_fork, 0));
+    uint64_t* tmp = TMP + (size_t)v * 4 * n;
+    if (fork) KG_HIP(ctx, hipStreamWaitEvent(sv, ctx->ev_fork, 0));
     KG_HIP(ctx, hipMemcpyAsync(dst[v], src[v], m * 32, hipMemcpyDeviceToDevice, sv));
     if (n > m) KG_HIP(ctx, hipMemsetAsync(dst[v] + 4 * m, 0, (n - m) * 32, sv));
     KG_TRY(ntt_enqueue(ctx, sv, tmp, dst[v], k, 1, 0));
@@ -226,8 +234,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // device continues with the next one.
   const size_t hn = (m - 1) < n ? (m - 1) : n;
   const size_t nz = l + m_l_1;
-  uint64_t* Z = C + 4 * n;                                // z = x || w, assembled on the scalar queue (its only reader is the sort)
-  hipStream_t sq;
+  hipStream_t sq;                                         // z is assembled on the scalar queue (its only reader is the sort)
   KG_TRY(scalar_queue(ctx, &sq));
   if (!ctx->inputs_complete) {                            // stream semantics: d_x / d_w may still be in flight on the main queue
     KG_HIP(ctx, hipEventRecord(ctx->ev_order, st));
@@ -267,7 +274,9 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   auto hip_rc = [&](hipError_t e, const char* what) {
     if (e != hipSuccess && rc == KG_OK) rc = set_err(ctx, e == hipErrorOutOfMemory ? KG_ERR_OOM : KG_ERR_HIP, what, e);
   };
-  // h = (a o b - c) / Z on the coset, back to coefficients (prover.rs:43-47), then its MSM
+  // h = (a o b - c) / Z on the coset, back to coefficients (prover.rs:43-47), then its MSM.  (Measured and dropped, again:
+  // this chain on a service queue under the witness accumulations -- the transform's 512-thread, 74 KiB workgroups only
+  // get onto a CU once an accumulation has drained, and then queue behind the reductions: 3.3 -> 3.85 ms per proof.)
   for (int v = 0; v < 3; ++v) hip_rc(hipStreamWaitEvent(st, ctx->ev_join[v], 0), "hipStreamWaitEvent(join)");
   // (7^n - 1)^-1 on the host: n = 2^k squarings of 7
   HostFr seven = HostFr::one();
@@ -283,7 +292,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   for (int i = 0; i < 4; ++i) { zw.w[2 * i] = (uint32_t)z.v[i]; zw.w[2 * i + 1] = (uint32_t)(z.v[i] >> 32); }
   hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, C, n, zw);
   hip_rc(hipGetLastError(), "k_qap_combine launch");
-  if (rc == KG_OK) rc = ntt_enqueue(ctx, st, (uint64_t*)ctx->ws2, A, k, 1, 1);   // coset_idft (prover.rs:47)
+  if (rc == KG_OK) rc = ntt_enqueue(ctx, st, TMP, A, k, 1, 1);                      // coset_idft (prover.rs:47)
   if (rc == KG_OK && hn) {
     MsmSorted Sq;
     hip_rc(hipEventRecord(ctx->ev_order, st), "hipEventRecord(order)");             // h's coefficients come off the main queue

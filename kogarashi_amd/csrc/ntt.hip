@@ -315,6 +315,7 @@ int get_tables(kg_ctx* ctx, uint32_t log_n, int inverse, kg_tw_cache** out) {
   hipLaunchKernelGGL(k_build_table, dim3((n_hi + 63) / 64), dim3(64), 0, st, 4, log_n, inverse, t->lo_bits, n_hi, t->cos_hi);
   hipLaunchKernelGGL(k_build_zinv, dim3(1), dim3(64), 0, st, log_n, t->zinv);
   KG_HIP(ctx, hipGetLastError());
+  ctx->tw_fresh = true;
   ctx->tw.push_back(t);
   *out = t;
   return KG_OK;

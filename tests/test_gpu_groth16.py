@@ -267,3 +267,32 @@ def test_context_closes_with_a_proof_in_flight(oracle):
         assert all((got[k] == want[k]).all() for k in range(3))
     finally:
         c2.close()
+
+
+def test_proofs_in_flight_with_complete_inputs(oracle):
+    """kg_ctx_set_inputs_complete(1) lets a proof's transform chains, witness sort and h chain start without waiting for the
+    main queue (per-ticket polynomial buffers): several proofs over two circuits sizes, two in flight, must equal the
+    blocking proofs and the oracle's."""
+    import kogarashi_amd as K
+    O = oracle
+    ctx = K.Context(0)
+    try:
+        provers = []
+        for m in (300, 5000):
+            cs = O.chain_r1cs(m, O.gen_scalars(0, SEED + 1300 + m, 0, 1)[0])
+            params = O.groth16_params(cs, O.gen_scalars(0, SEED + 1301, 0, 5), threads=8)
+            a, b, c = cs.evaluate()
+            rs = O.gen_scalars(0, SEED + 1302 + m, 0, 6)
+            want = [O.groth16_prove(cs, params, rs[2 * i], rs[2 * i + 1], evals=(a, b, c)) for i in range(3)]
+            params["vk_g2"] = params["vk_g2"][:2]
+            provers.append((K.Prover(params, cs.m, cs.l, cs.m_l_1, ctx=ctx), (a, b, c, cs.x, cs.w), rs, want))
+        ctx.set_inputs_complete(True)
+        for prover, (a, b, c, x, w), rs, want in provers:
+            jobs = [(a, b, c, x, w, rs[2 * (i % 3)], rs[2 * (i % 3) + 1]) for i in range(7)]
+            for i, got in enumerate(prover.create_proofs(jobs)):
+                for g, w_ in zip(got[:3], want[i % 3][:3]):
+                    assert (g == w_).all(), i
+            got = prover.create_proof(a, b, c, x, w, rs[0], rs[1])
+            assert all((g == w_).all() for g, w_ in zip(got[:3], want[0][:3]))
+    finally:
+        ctx.close()

@@ -1,5 +1,5 @@
 """GPU-side phase timeline of one Groth16 proof from the library's own HIP events (no profiler attached):
-KG_PROFILE_TIMELINE=1 python tools/dbg/g16_timeline.py [log_m]"""
+KG_PROFILE_TIMELINE=1 python tools/dbg/g16_timeline.py [log_m] [pipelined]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -7,16 +7,31 @@ import kogarashi_amd as K
 import bench
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 ctx = K.Context(0)
-st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st); ctx.set_stream(st.cuda_stream)
-orig = ctx.groth16_prove
+if os.environ.get("KG_ORDERED") != "1":
+    ctx.set_inputs_complete(True)
+pipelined = len(sys.argv) > 2
 calls = [0]
-def wrapped(*a, **k):
-    calls[0] += 1
-    if calls[0] == 3:
-        ctx.profile_enable(True)
-    out = orig(*a, **k)
-    if calls[0] == 3:
-        ctx.profile_summary(); ctx.profile_enable(False)
-    return out
-ctx.groth16_prove = wrapped
-print(bench.bench_groth16(ctx, torch, dev, K, int(sys.argv[1]) if len(sys.argv) > 1 else 18, steps=4, cpu=False)["ms_per_proof"])
+if pipelined:
+    orig = ctx.groth16_prove_begin
+    def wrapped(*a, **k):
+        calls[0] += 1
+        if calls[0] == 12:
+            ctx.sync(); ctx.profile_enable(True)
+        out = orig(*a, **k)
+        if calls[0] == 15:
+            ctx.profile_summary(); ctx.profile_enable(False)
+        return out
+    ctx.groth16_prove_begin = wrapped
+else:
+    orig = ctx.groth16_prove
+    def wrapped(*a, **k):
+        calls[0] += 1
+        if calls[0] == 3:
+            ctx.profile_enable(True)
+        out = orig(*a, **k)
+        if calls[0] == 3:
+            ctx.profile_summary(); ctx.profile_enable(False)
+        return out
+    ctx.groth16_prove = wrapped
+o = bench.bench_groth16(ctx, torch, dev, K, int(sys.argv[1]) if len(sys.argv) > 1 else 18, steps=4, cpu=False)
+print(o["ms_per_proof"], o["ms_per_proof_blocking"])
