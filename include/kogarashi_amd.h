@@ -111,7 +111,9 @@ int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf
 int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars,
                  size_t n, int ticket);
 int kg_msm_end(kg_ctx* ctx, int curve, int ticket, uint64_t* out_xyz);
-/* Same with HOST inputs (uploads, runs, frees): the call shape of the Rust slices. */
+/* Same with HOST inputs: the call shape of the Rust slices.  The arrays are cut into up to four index slices that are
+ * uploaded (into device buffers the context keeps), sorted and accumulated as a pipeline -- slice j accumulates while
+ * slice j + 1 is still on the bus -- and the slices' sums are added on the host. */
 int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars,
                 size_t n, uint64_t* out_xyz);
 /* nova/src/pedersen.rs:15-20 PedersenCommitment::commit: affine(sum_i m[i] * g[i]).

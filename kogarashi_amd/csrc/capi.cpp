@@ -9,7 +9,7 @@ namespace kg {
 void sync_all(kg_ctx* c) {
   hipStreamSynchronize(c->stream);
   if (c->own_stream && c->own_stream != c->stream) hipStreamSynchronize(c->own_stream);
-  for (hipStream_t s : {c->sort_stream, c->side_stream, c->side2_stream, c->aux_stream, c->aux2_stream})
+  for (hipStream_t s : {c->sort_stream, c->side_stream, c->side2_stream, c->aux_stream, c->aux2_stream, c->up_stream})
     if (s) hipStreamSynchronize(s);
 }
 int ensure_ws_sort(kg_ctx* c, int set, size_t bytes) {
@@ -191,6 +191,9 @@ void kg_ctx_destroy(kg_ctx* c) {
   if (c->ev_info) hipEventDestroy(c->ev_info);
   for (auto& sl : c->slots) { if (sl.host) hipHostFree(sl.host); if (sl.done) hipEventDestroy(sl.done); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
+  for (void* b : c->up_buf) if (b) hipFree(b);
+  if (c->up_stream) { hipStreamSynchronize(c->up_stream); hipStreamDestroy(c->up_stream); }
+  for (int i = 0; i < kg_ctx::UP_SLICES; ++i) { if (c->ev_up_s[i]) hipEventDestroy(c->ev_up_s[i]); if (c->ev_up_b[i]) hipEventDestroy(c->ev_up_b[i]); }
   for (auto& r : c->registered) hipFree(r.packed);
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->own_stream);

@@ -48,7 +48,7 @@ struct kg_ctx {
   hipEvent_t ev_acc[RUN_SETS] = {};
   hipEvent_t ev_info = nullptr;          // marks the task-count read-back of msm_sort
   struct Slot { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0; bool busy = false; };
-  static constexpr int NSLOTS = 16;      // 0 kg_msm, 1..4 kg_msm_begin tickets, 6..10 prover job 0, 11..15 prover job 1 (disjoint: calls may interleave)
+  static constexpr int NSLOTS = 20;      // 0 kg_msm, 1..4 kg_msm_begin tickets, 6..10 prover job 0, 11..15 prover job 1, 16..19 slices of kg_msm_host (disjoint: calls may interleave)
   Slot slots[NSLOTS];
   std::shared_ptr<void> prover_jobs;     // groth16.hip: proofs in flight (kg_groth16_prove_begin / _end)
   size_t ticket_n[4] = {0, 0, 0, 0};
@@ -58,6 +58,12 @@ struct kg_ctx {
   uint64_t ticket_out[4][24] = {};
   struct Registered { const uint64_t* base; const uint8_t* inf; size_t n; int curve; uint32_t* packed; };
   std::vector<Registered> registered;    // bases converted once by kg_bases_register     // lengths of the MSMs begun with kg_msm_begin                         // pinned result slots: MSMs in flight whose host finish is pending
+  // kg_msm_host: cached device copies of the caller's host arrays (grow-only) and the upload queue
+  void* up_buf[3] = {nullptr, nullptr, nullptr};     // bases, scalars, identity flags
+  size_t up_bytes[3] = {0, 0, 0};
+  hipStream_t up_stream = nullptr;
+  static constexpr int UP_SLICES = 4;
+  hipEvent_t ev_up_s[UP_SLICES] = {}, ev_up_b[UP_SLICES] = {};
   void* h_pinned = nullptr;              // small pinned staging buffer for results
   size_t h_pinned_bytes = 0;
   std::vector<kg_tw_cache*> tw;          // per-(log_n, inverse) twiddle tables
@@ -222,7 +228,8 @@ int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, ui
 int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered = false);
 int scalar_queue(kg_ctx* ctx, hipStream_t* out);     // the scalar-side queue, created on first use
 // several base arrays against one scalar sort, accumulated by one launch (at most 3; result slots in distinct run-space sets)
-struct MsmRunJob { const uint64_t* d_bases; const uint8_t* d_inf; size_t nbases; uint32_t idx_off; int slot; };
+// bases_complete: the base array is complete in device memory when the call is made (no ordering against the main queue)
+struct MsmRunJob { const uint64_t* d_bases; const uint8_t* d_inf; size_t nbases; uint32_t idx_off; int slot; bool bases_complete = false; };
 int msm_run_multi(kg_ctx* ctx, const MsmSorted& S, int curve, const MsmRunJob* jobs, int njobs);
 int msm_run(kg_ctx* ctx, const MsmSorted& S, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, uint32_t idx_off, int slot);
 int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz);

@@ -21,6 +21,7 @@
 #include "host_fp.h"
 #include "fp2s.h"
 #include <chrono>
+#include <thread>
 
 using namespace kg;
 
@@ -1187,7 +1188,7 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
 // Base-side half: accumulate + reduce against up to MAX_FUSED base arrays that share the scalar sort S, export, and start
 // the copy of each result into its host slot.  One accumulation launch serves all arrays (see k_acc_tasks); everything
 // after it runs per array, its reduction on one of the two side queues.
-struct RunJob { const uint64_t* d_bases; const uint8_t* d_inf; size_t nbases; uint32_t idx_off; int slot; };
+struct RunJob { const uint64_t* d_bases; const uint8_t* d_inf; size_t nbases; uint32_t idx_off; int slot; bool bases_complete; };
 
 template <class Cfg>
 int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njobs) {
@@ -1250,7 +1251,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
     if (!reg_pb) {
       // per-call conversion of the bases, on the scalar queue: it runs beside the previous MSM's accumulation instead
       // of between two accumulations on the main queue
-      if (!ctx->inputs_complete && !ordered_bases) {       // stream semantics: the bases may still be in flight on the main queue
+      if (!ctx->inputs_complete && !ordered_bases && !J.bases_complete) {   // stream semantics: the bases may still be in flight on the main queue
         KG_HIP(ctx, hipEventRecord(ctx->ev_order, st));
         KG_HIP(ctx, hipStreamWaitEvent(sq, ctx->ev_order, 0));
         ordered_bases = true;
@@ -1393,7 +1394,7 @@ int scalar_queue(kg_ctx* ctx, hipStream_t* out) {
 int msm_run_multi(kg_ctx* ctx, const MsmSorted& S, int curve, const MsmRunJob* jobs, int njobs) {
   RunJob rj[MAX_FUSED];
   if (njobs < 1 || njobs > MAX_FUSED) return KG_ERR_BAD_ARG;
-  for (int k = 0; k < njobs; ++k) rj[k] = RunJob{jobs[k].d_bases, jobs[k].d_inf, jobs[k].nbases, jobs[k].idx_off, jobs[k].slot};
+  for (int k = 0; k < njobs; ++k) rj[k] = RunJob{jobs[k].d_bases, jobs[k].d_inf, jobs[k].nbases, jobs[k].idx_off, jobs[k].slot, jobs[k].bases_complete};
   switch (curve) {
     case KG_G1: return msm_run_multi_t<G1Cfg>(ctx, S, rj, njobs);
     case KG_GRUMPKIN: return msm_run_multi_t<GkCfg>(ctx, S, rj, njobs);
@@ -1402,7 +1403,7 @@ int msm_run_multi(kg_ctx* ctx, const MsmSorted& S, int curve, const MsmRunJob* j
   }
 }
 int msm_run(kg_ctx* ctx, const MsmSorted& S, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, uint32_t idx_off, int slot) {
-  const MsmRunJob j{d_bases, d_inf, nbases, idx_off, slot};
+  const MsmRunJob j{d_bases, d_inf, nbases, idx_off, slot, false};
   return msm_run_multi(ctx, S, curve, &j, 1);
 }
 int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz) {
@@ -1512,22 +1513,113 @@ int kg_msm_end(kg_ctx* ctx, int curve, int ticket, uint64_t* out_xyz) {
   return KG_OK;
 }
 
+// Host arrays in, one point out: the call shape of the reference's slices (msm_curve_addition(&[C], &[C::Scalar])).
+// The index range is cut into up to four slices that travel through a pipeline: an uploader thread copies slice j's
+// scalars, then its bases, into cached device buffers (upload queue); the scalar queue sorts slice j as soon as its scalars
+// have landed, converts its bases when they have, and the main queue accumulates it while slice j+1 is still on the bus.
+// The slices' partial sums are added on the host.  PCIe (96 B per G1 pair) is the floor: 1.8 ms per 2^20 pairs.
+static int grow_device(kg_ctx* ctx, int which, size_t bytes) {
+  if (bytes <= ctx->up_bytes[which]) return KG_OK;
+  if (ctx->up_buf[which]) { sync_all(ctx); hipFree(ctx->up_buf[which]); ctx->up_buf[which] = nullptr; ctx->up_bytes[which] = 0; }
+  const hipError_t e = hipMalloc(&ctx->up_buf[which], bytes + bytes / 8);
+  if (e != hipSuccess) return set_err(ctx, KG_ERR_OOM, "upload buffer allocation", e);
+  ctx->up_bytes[which] = bytes + bytes / 8;
+  return KG_OK;
+}
+
 int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars, size_t n, uint64_t* out_xyz) {
   if (!ctx || !out_xyz || (n && (!h_bases || !h_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) return kg_msm(ctx, curve, nullptr, nullptr, nullptr, 0, out_xyz);
-  const size_t bb = n * (curve == KG_G2 ? 128 : 64);
-  void *db = nullptr, *ds = nullptr, *di = nullptr;
-  int rc = kg_malloc(ctx, bb, &db);
-  if (rc == KG_OK) rc = kg_malloc(ctx, n * 32, &ds);
-  if (rc == KG_OK && h_inf) rc = kg_malloc(ctx, n, &di);
-  if (rc == KG_OK) rc = kg_memcpy_h2d(ctx, db, h_bases, bb);
-  if (rc == KG_OK) rc = kg_memcpy_h2d(ctx, ds, h_scalars, n * 32);
-  if (rc == KG_OK && h_inf) rc = kg_memcpy_h2d(ctx, di, h_inf, n);
-  if (rc == KG_OK) rc = kg_msm(ctx, curve, (const uint64_t*)db, (const uint8_t*)di, (const uint64_t*)ds, n, out_xyz);
-  if (db) hipFree(db);
-  if (ds) hipFree(ds);
-  if (di) hipFree(di);
-  return rc;
+  KG_HIP(ctx, hipSetDevice(ctx->device));
+  host_trace("host: enter");
+  const size_t pb = curve == KG_G2 ? 128 : 64;             // bytes per base
+  const int E = curve == KG_G2 ? 8 : 4;
+  KG_TRY(grow_device(ctx, 0, n * pb));
+  KG_TRY(grow_device(ctx, 1, n * 32));
+  if (h_inf) KG_TRY(grow_device(ctx, 2, n));
+  if (!ctx->up_stream) {
+    KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+    for (int i = 0; i < kg_ctx::UP_SLICES; ++i) {
+      KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_up_s[i], hipEventDisableTiming));
+      KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_up_b[i], hipEventDisableTiming));
+    }
+  }
+  hipStream_t sq;
+  KG_TRY(kg::scalar_queue(ctx, &sq));
+  char* d_b = (char*)ctx->up_buf[0];
+  uint64_t* d_s = (uint64_t*)ctx->up_buf[1];
+  uint8_t* d_i = h_inf ? (uint8_t*)ctx->up_buf[2] : nullptr;
+  const int K = n >= ((size_t)1 << 19) ? 4 : (n >= ((size_t)1 << 16) ? 2 : 1);
+  size_t lo[kg_ctx::UP_SLICES + 1];
+  for (int j = 0; j <= K; ++j) lo[j] = n / K * j + (j == K ? n % K : 0);
+  // the previous call's readers of the cached buffers are done (every call joins its slices before it returns)
+  std::atomic<int> up_s{0}, up_b{0}, up_rc{(int)hipSuccess};
+  auto upload_all = [&] {
+    hipSetDevice(ctx->device);
+    for (int j = 0; j < K; ++j) {
+      const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
+      hipError_t e = hipMemcpyAsync(d_s + 4 * a, h_scalars + 4 * a, cnt * 32, hipMemcpyHostToDevice, ctx->up_stream);
+      if (e == hipSuccess) e = hipEventRecord(ctx->ev_up_s[j], ctx->up_stream);
+      if (e != hipSuccess) up_rc = (int)e;
+      up_s = j + 1;
+      host_trace("upload: scalars");
+      e = hipMemcpyAsync(d_b + a * pb, (const char*)h_bases + a * pb, cnt * pb, hipMemcpyHostToDevice, ctx->up_stream);
+      if (e == hipSuccess && h_inf) e = hipMemcpyAsync(d_i + a, h_inf + a, cnt, hipMemcpyHostToDevice, ctx->up_stream);
+      if (e == hipSuccess) e = hipEventRecord(ctx->ev_up_b[j], ctx->up_stream);
+      if (e != hipSuccess) up_rc = (int)e;
+      up_b = j + 1;
+      host_trace("upload: bases");
+    }
+  };
+  // one slice: nothing to overlap, the calling thread uploads; otherwise an uploader thread feeds the pipeline (a copy from
+  // pageable memory occupies its thread for the duration of the copy)
+  std::thread uploader;
+  if (K == 1) upload_all(); else uploader = std::thread(upload_all);
+  std::future<int> fin[kg_ctx::UP_SLICES];
+  uint64_t part[kg_ctx::UP_SLICES][24];
+  int rc = KG_OK;
+  const int sfield = curve == KG_GRUMPKIN ? KG_FQ : KG_FR;
+  for (int j = 0; j < K && rc == KG_OK; ++j) {
+    const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
+    while (up_s.load() <= j) std::this_thread::yield();
+    if (up_rc != (int)hipSuccess) { rc = set_err(ctx, KG_ERR_HIP, "host-to-device upload", (hipError_t)up_rc.load()); break; }
+    if (hipStreamWaitEvent(sq, ctx->ev_up_s[j], 0) != hipSuccess) { rc = KG_ERR_HIP; break; }
+    kg::MsmSorted S;
+    rc = kg::msm_sort(ctx, sfield, d_s + 4 * a, cnt, &S, true);
+    if (rc != KG_OK) break;
+    while (up_b.load() <= j) std::this_thread::yield();
+    if (up_rc != (int)hipSuccess) { rc = set_err(ctx, KG_ERR_HIP, "host-to-device upload", (hipError_t)up_rc.load()); break; }
+    const kg::MsmRunJob job{(const uint64_t*)(d_b + a * pb), d_i ? d_i + a : nullptr, cnt, 0u, 16 + j, true};
+    if (hipStreamWaitEvent(sq, ctx->ev_up_b[j], 0) != hipSuccess) { rc = KG_ERR_HIP; break; }
+    rc = kg::msm_run_multi(ctx, S, curve, &job, 1);
+    if (rc != KG_OK) break;
+    uint64_t* out = part[j];
+    fin[j] = std::async(std::launch::async, [ctx, curve, j, out] { return kg::msm_finish(ctx, curve, 16 + j, out); });
+  }
+  if (uploader.joinable()) uploader.join();
+  hipStreamSynchronize(ctx->up_stream);
+  host_trace("host: uploads synced");
+  for (int j = 0; j < K; ++j)
+    if (fin[j].valid()) { const int r2 = fin[j].get(); if (rc == KG_OK) rc = r2; }
+  if (rc != KG_OK) { kg_ctx_sync(ctx); return rc; }
+  if (K == 1) { std::memcpy(out_xyz, part[0], (size_t)3 * E * 8); return KG_OK; }
+  uint64_t pts[kg_ctx::UP_SLICES * 16];
+  uint8_t pinf[kg_ctx::UP_SLICES];
+  for (int j = 0; j < K; ++j) {
+    bool z0 = true;
+    for (int k = 0; k < E; ++k) z0 = z0 && part[j][2 * E + k] == 0;
+    pinf[j] = z0 ? 1 : 0;
+    std::memcpy(pts + (size_t)j * 2 * E, part[j], (size_t)2 * E * 8);
+  }
+  uint64_t xy[16];
+  uint8_t inf = 0;
+  KG_TRY(kg_points_sum_affine(ctx, curve, pts, pinf, (size_t)K, xy, &inf));
+  kg::msm_identity(curve, out_xyz);                        // (0, 1, 0); y doubles as the field's one
+  if (!inf) {
+    for (int k = 0; k < E; ++k) out_xyz[2 * E + k] = out_xyz[E + k];
+    std::memcpy(out_xyz, xy, (size_t)2 * E * 8);
+  }
+  return KG_OK;
 }
 
 int kg_commit(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,

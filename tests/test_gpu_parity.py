@@ -536,3 +536,31 @@ def test_pipeline_with_complete_inputs_matches_blocking_calls(oracle):
         assert (dbl[:8] == two[0]).all()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("cv,curve,sfd,n", [("g1", 0, 0, (1 << 19) + 77), ("gk", 1, 1, 70001), ("g2", 2, 0, 66000)])
+def test_msm_host_slices_match_device_call(ctx, oracle, cv, curve, sfd, n):
+    """kg_msm_host cuts large inputs into index slices that are uploaded, sorted and accumulated as a pipeline and adds the
+    slices' sums: identical to kg_msm over the same arrays resident on the device (and to the oracle), with identity
+    flags, zero scalars and a ragged length; repeated calls reuse the cached device buffers."""
+    O = oracle
+    if curve == 2:
+        dk = ctx.upload(O.gen_scalars(0, SEED + 1400, 0, n))
+        dxy, dinf = ctx.empty((n, 16)), ctx.empty((n,), dtype=np.uint8)
+        ctx.fixed_base_mul(2, dk.ptr, n, dxy.ptr, dinf.ptr)
+        bases = dxy.numpy()
+    else:
+        bases = O.gen_bases(curve, SEED + 1401, 0, n)
+    scal = O.gen_scalars(sfd, SEED + 1402, 0, n)
+    scal[::1000] = 0
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[[1, n // 4, n // 2 + 1, n - 1]] = 1
+    db, di, ds = ctx.upload(bases), ctx.upload(inf), ctx.upload(scal)
+    want = ctx.msm(curve, db.ptr, di.ptr, ds.ptr, n)
+    for _ in range(3):
+        assert (ctx.msm_host(curve, bases, inf, scal, n) == want).all()
+    assert (ctx.msm_host(curve, bases, None, scal, n) == ctx.msm(curve, db.ptr, 0, ds.ptr, n)).all()
+    m = n // 3                                          # a shorter call afterwards (fewer slices, same cached buffers)
+    assert (ctx.msm_host(curve, bases, inf, scal, m) == ctx.msm(curve, db.ptr, di.ptr, ds.ptr, m)).all()
+    nb = 8 if curve == 2 else 4
+    assert gpu_aff(want, nb) == aff(O, cv, O.msm(cv, bases, scal, inf, threads=8))
