@@ -971,17 +971,99 @@ template <class F>
 __device__ __forceinline__ void export_el(const Fp2<F>& a, uint64_t* dst) { export_el(a.c0, dst); export_el(a.c1, dst + 4); }
 template <class F>
 __device__ __forceinline__ void export_el(const Fp2S<F>& a, uint64_t* dst) { export_el(a.v, dst + 4 * Fp2S<F>::half()); }
+// ---- fused tail of the reduction --------------------------------------------------------------------------------
+// Once the arrays are short (L <= TAIL_L items) the remaining log2(L) levels run inside ONE launch: a workgroup per
+// (window, array) keeps its items in LDS and walks the levels with barriers instead of kernel launches, then converts its
+// results to the ABI form itself (the export).  Array 0 (the pair sums A) also spawns the new odd-index arrays T_s, T_s+1, ...
+// and sums them on the lanes the halving frees: at step t it holds t live arrays of L >> (t - 1) items (A at LDS item 0,
+// the array spawned at step j + 1 at item L >> (j + 1)), i.e. t * (L >> t) pairs <= L / 2 lanes.  Reads and writes of a
+// step are separated by a barrier, so every array shrinks in place.
+// LDS image: structure of arrays, word k of lane-item q at lds[k * cap + q] (consecutive lanes, consecutive banks); an Fq2
+// item is two lane-items (the pair's halves).
+template <class F> struct TailIO {                  // one lane's 36 words of a point
+  static __device__ __forceinline__ void get(const XYZZ<F>& p, uint32_t (&w)[36]) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { w[k] = p.x.l[k]; w[9 + k] = p.y.l[k]; w[18 + k] = p.zz.l[k]; w[27 + k] = p.zzz.l[k]; }
+  }
+  static __device__ __forceinline__ XYZZ<F> put(const uint32_t (&w)[36]) {
+    XYZZ<F> p;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { p.x.l[k] = w[k]; p.y.l[k] = w[9 + k]; p.zz.l[k] = w[18 + k]; p.zzz.l[k] = w[27 + k]; }
+    return p;
+  }
+};
+template <class G> struct TailIO<Fp2S<G>> {
+  using F = Fp2S<G>;
+  static __device__ __forceinline__ void get(const XYZZ<F>& p, uint32_t (&w)[36]) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { w[k] = p.x.v.l[k]; w[9 + k] = p.y.v.l[k]; w[18 + k] = p.zz.v.l[k]; w[27 + k] = p.zzz.v.l[k]; }
+  }
+  static __device__ __forceinline__ XYZZ<F> put(const uint32_t (&w)[36]) {
+    XYZZ<F> p;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { p.x.v.l[k] = w[k]; p.y.v.l[k] = w[9 + k]; p.zz.v.l[k] = w[18 + k]; p.zzz.v.l[k] = w[27 + k]; }
+    return p;
+  }
+};
+template <class F> struct TailCfg { static constexpr int L = 512; };          // items per array the fused tail takes over at
+template <class G> struct TailCfg<Fp2S<G>> { static constexpr int L = 256; }; // (72 KiB of LDS either way)
+
 template <class F, int E64>
-__global__ void __launch_bounds__(64) k_export(const uint32_t* __restrict__ in, size_t stride, size_t count, uint64_t* __restrict__ out) {
+__global__ void __launch_bounds__(512) k_reduce_tail(const uint32_t* __restrict__ in, size_t in_stride, int narr_in, uint32_t L, int c,
+                                                     uint64_t* __restrict__ out) {
   KG_SERVICE_PRIO();
-  size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
-  if (t >= count) return;
-  XYZZ<F> p = PointIO<F>::load(in, stride, t);
-  uint64_t* dst = out + t * 4 * E64;
-  export_el(p.x, dst);
-  export_el(p.y, dst + E64);
-  export_el(p.zz, dst + 2 * E64);
-  export_el(p.zzz, dst + 3 * E64);
+  extern __shared__ uint32_t lds[];
+  constexpr int LPT = Lanes<F>::N;
+  const uint32_t cap = L * LPT;                        // lane-items the image holds
+  const int w = (int)(blockIdx.x / (unsigned)narr_in), a = (int)(blockIdx.x % (unsigned)narr_in);
+  const uint32_t lane_item = threadIdx.x;              // LPT consecutive lanes form a task
+  const uint32_t task = lane_item / LPT, half = lane_item % LPT;
+  const bool spawns = a == 0;
+  int steps = 0;
+  while ((1u << steps) < L) ++steps;
+  auto lds_put = [&](uint32_t item, const XYZZ<F>& p) {
+    uint32_t wds[36];
+    TailIO<F>::get(p, wds);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) lds[k * cap + item * LPT + half] = wds[k];
+  };
+  auto lds_get = [&](uint32_t item) {
+    uint32_t wds[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) wds[k] = lds[k * cap + item * LPT + half];
+    return TailIO<F>::put(wds);
+  };
+  const size_t src0 = ((size_t)w * narr_in + a) * L;
+  for (int t = 1; t <= steps; ++t) {
+    const uint32_t per = L >> t;                       // pairs per live array in this step
+    const uint32_t live = spawns ? (uint32_t)t : 1u;
+    const bool active = task < live * per;
+    const uint32_t k = active ? task / per : 0u, q = active ? task % per : 0u;
+    const uint32_t base = k == 0 ? 0u : (L >> k);      // array k >= 1 was spawned at step k at item L >> k
+    XYZZ<F> p0, p1;
+    if (active) {
+      if (t == 1) { p0 = PointIO<F>::load(in, in_stride, src0 + 2 * q); p1 = PointIO<F>::load(in, in_stride, src0 + 2 * q + 1); }
+      else { p0 = lds_get(base + 2 * q); p1 = lds_get(base + 2 * q + 1); }
+    }
+    __syncthreads();                                   // every read of this step before any write
+    if (active) {
+      lds_put(base + q, add_xyzz(p0, p1));
+      if (spawns && k == 0) lds_put(per + q, p1);      // the odd items of A become the array spawned at this step
+    }
+    __syncthreads();
+  }
+  // results: A (or this workgroup's T array) at item 0; the array spawned at step j at item L >> j (one item each)
+  const uint32_t nres = spawns ? (uint32_t)steps + 1u : 1u;
+  if (task < nres) {
+    const uint32_t item = task == 0 ? 0u : (L >> task);
+    const int arr = task == 0 ? a : narr_in - 1 + (int)task;        // 0 = A, 1 + l = T_l
+    const XYZZ<F> p = lds_get(item);
+    uint64_t* dst = out + ((size_t)w * c + arr) * 4 * E64;
+    export_el(p.x, dst);
+    export_el(p.y, dst + E64);
+    export_el(p.zz, dst + 2 * E64);
+    export_el(p.zzz, dst + 3 * E64);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1331,7 +1413,10 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       PhaseScope ph(ctx, "reduce", side);
       size_t in_stride = npts;                     // level 0 reads the bucket array: stride = W*B items
       int narr = 1;
-      for (uint32_t n_out = (uint32_t)B / 2; n_out >= 1; n_out /= 2) {
+      uint32_t len = (uint32_t)B;                  // items per array
+      constexpr uint32_t TL = (uint32_t)TailCfg<KF>::L;
+      for (; len > TL; len /= 2) {                 // the wide levels: one launch each
+        const uint32_t n_out = len / 2;
         const size_t tasks = (size_t)W * narr * n_out;
         const size_t out_stride = (size_t)W * (narr + 1) * n_out;
         hipLaunchKernelGGL(k_halve<KF>, dim3((unsigned)((tasks * LPT + 63) / 64)), dim3(64), 0, side, pbuf[cur], in_stride, pbuf[cur ^ 1], out_stride,
@@ -1339,10 +1424,12 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
         cur ^= 1;
         in_stride = out_stride;
         ++narr;
-        if (n_out == 1) break;
       }
-      // now: W windows x narr (= c) single points, stride W*c
-      hipLaunchKernelGGL((k_export<KF, Cfg::E64>), dim3((unsigned)((nexp * LPT + 63) / 64)), dim3(64), 0, side, pbuf[cur], nexp, nexp, d_exp);
+      // the remaining log2(len) levels and the export in one launch (W * narr workgroups)
+      const size_t tail_lds = (size_t)36 * len * LPT * 4;
+      const unsigned tail_threads = (unsigned)(len / 2 * LPT) < 64u ? 64u : (unsigned)(len / 2 * LPT);
+      KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_reduce_tail<KF, Cfg::E64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
+      hipLaunchKernelGGL((k_reduce_tail<KF, Cfg::E64>), dim3((unsigned)(W * narr)), dim3(tail_threads), tail_lds, side, pbuf[cur], in_stride, narr, len, c, d_exp);
       ph.end();
     }
     KG_HIP(ctx, hipGetLastError());
