@@ -21,6 +21,10 @@ LOG_N = 20
 G1_BYTES_PER_PAIR = 96          # 32 B scalar + 64 B affine base
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 MADD_PEAK_G = 16.5              # measured: the bucket kernel's addition routine, operands in registers, 4 waves/SIMD (profiles/r01_mul_rate.txt)
+MAD_PEAK_T = 33.0               # measured chip-wide v_mad_u64_u32 issue rate, T instructions/s (profiles/r01_valu_rates.txt)
+MADS_PER_ADDITION = 1467        # add_mixed_signed (curve.h): 6 products x 162 + 2 squares x 126 + one double product x 243 multiply-accumulates (fp29.h)
+MUL_PEAK_G = 174.0              # measured Montgomery products/s (profiles/r01_mul_rate.txt)
+NTT_MULS_PER_ELEMENT_22 = 15    # 2^22 = 2^8 * 2^7 * 2^7: 11 butterfly products + 2 x 2 inter-step twiddle products per element
 
 
 def window_adds(n):
@@ -140,6 +144,19 @@ def main():
 
     value = world * n * args.steps / elapsed
     achieved = G1_BYTES_PER_PAIR * n / (acc_avg_ms * 1e-3) / 1e9
+    # The same kernel with nothing beside it (a few blocking MSMs after the timed region): in the timed region the
+    # accumulation shares the chip with the next step's sort and the previous steps' reductions, which is what makes the
+    # step shorter and the kernel's own launch longer.
+    barrier()
+    ctx.profile_enable(True)
+    for _ in range(5):
+        ctx.msm(K.KG_G1, bases.data_ptr(), 0, scalars.data_ptr(), n)
+    iso = ctx.profile_summary()
+    ctx.profile_enable(False)
+    iso_ms = iso["accumulate"][0] / iso["accumulate"][1]
+    iso_achieved = G1_BYTES_PER_PAIR * n / (iso_ms * 1e-3) / 1e9
+    adds = window_adds(n)
+    traffic = pmc_traffic(args.log_n)
     line = {
         "metric": "bn254_g1_msm_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -148,13 +165,23 @@ def main():
                    "pairs_per_gpu": n, "sharding": "index range" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "kernel": "k_acc_tasks (bucket accumulation, one launch per MSM)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(args.log_n), "kernel_ms": acc_avg_ms, "algorithmic_bytes_per_launch": G1_BYTES_PER_PAIR * n,
-                     "note": "VALU-bound kernel (16 n point additions): see DESIGN.md section 3 for the instruction-rate bound"},
-        # the bound that actually limits the kernel: point additions per second against the chip's measured rate for the
-        # same madd routine with operands in registers (tools/ubench/mul_rate.hip, profiles/r01_mul_rate.txt)
-        "valu_roofline": {"bound": "valu", "unit": "G point additions/s", "achieved": window_adds(n) / (acc_avg_ms * 1e-3) / 1e9,
-                          "peak": MADD_PEAK_G, "frac": window_adds(n) / (acc_avg_ms * 1e-3) / 1e9 / MADD_PEAK_G},
-        "phases_ms_per_step": phase_avg, "pipelining": f"{depth} MSM steps in flight (kg_msm_begin / kg_msm_end)",
+                     "traffic": traffic["corrected"] if traffic else None, "kernel_ms": acc_avg_ms, "algorithmic_bytes_per_launch": G1_BYTES_PER_PAIR * n,
+                     "traffic_detail": traffic,
+                     "isolated": {"kernel_ms": iso_ms, "achieved": iso_achieved, "frac": iso_achieved / HBM_PEAK_GBS,
+                                  "note": "same kernel, blocking kg_msm calls, nothing else on the chip"},
+                     "note": "VALU-bound kernel (16 n point additions, see valu_roofline); in the timed region its launches overlap the next step's sort "
+                             "and the previous steps' reductions (service kernels run at wave priority 3 beside it), so kernel_ms there is longer than "
+                             "isolated.kernel_ms while ms_per_step is shorter than their sum"},
+        # the bound that actually limits the kernel, against the MACHINE: multiply-accumulate instructions per second vs the
+        # chip's measured v_mad_u64_u32 issue rate; and against the same addition routine with operands in registers
+        "valu_roofline": {"bound": "valu", "unit": "T v_mad_u64_u32/s", "mads_per_addition": MADS_PER_ADDITION, "additions_per_launch": adds,
+                          "achieved": adds * MADS_PER_ADDITION / (iso_ms * 1e-3) / 1e12, "peak": MAD_PEAK_T,
+                          "frac": adds * MADS_PER_ADDITION / (iso_ms * 1e-3) / 1e12 / MAD_PEAK_T,
+                          "routine_relative": {"unit": "G point additions/s", "achieved": adds / (iso_ms * 1e-3) / 1e9, "peak": MADD_PEAK_G,
+                                               "frac": adds / (iso_ms * 1e-3) / 1e9 / MADD_PEAK_G},
+                          "note": "isolated launches; the remaining ~30 % of issue slots go to the shifts / masks / carries of the 29-bit limbs, "
+                                  "the lazy-reduction bookkeeping and the gathers"},
+        "phases_ms_per_step": phase_avg, "pipelining": f"{depth} MSM steps in flight (kg_msm_begin / kg_msm_end), inputs declared complete",
     }
 
     if rank == 0 and world == 1:
@@ -183,13 +210,18 @@ def main():
 
 def pmc_traffic(log_n):
     """Memory-side bytes per k_acc_tasks launch from the committed rocprofv3 --pmc passes (profiles/): FETCH_SIZE and
-    WRITE_SIZE are collected in separate runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    for gfx950.  Only valid for the configuration it was measured on (2^20 pairs); null otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_m_pmc_hbm.json")
-    if log_n != LOG_N or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f)["k_acc_tasks_traffic_bytes_per_launch"]["total_corrected"]
+    WRITE_SIZE are collected in separate runs of this same command.  MI355X_MICROARCH.md prescribes doubling FETCH_SIZE on
+    gfx950 for wide coalesced streams; this kernel's reads are scattered 8-byte-per-lane gathers, for which the correction is
+    uncalibrated -- both figures are reported.  Only valid for the configuration it was measured on (2^20 pairs); null otherwise."""
+    for name in ("r02_pmc_hbm.json", "r01_m_pmc_hbm.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if log_n == LOG_N and os.path.exists(path):
+            with open(path) as f:
+                t = json.load(f)["k_acc_tasks_traffic_bytes_per_launch"]
+            return {"uncorrected": t["fetch_reported"] + t["write"], "corrected": t["total_corrected"], "fetch_reported": t["fetch_reported"],
+                    "write": t["write"], "source": "profiles/" + name,
+                    "note": "FETCH_SIZE x2 is calibrated for 16-B-per-lane streams; 8-B gathers out of L2 / Infinity Cache make it an upper estimate"}
+    return None
 
 
 def bench_ntt(ctx, torch, dev, K, log_n=22, steps=10):
@@ -208,9 +240,14 @@ def bench_ntt(ctx, torch, dev, K, log_n=22, steps=10):
     ctx.profile_enable(False)
     ms = tot / cnt
     gbs = 64.0 * n / (ms * 1e-3) / 1e9
-    return {"metric": "bn254_fr_ntt_elements_per_sec", "log_n": log_n, "value": n / (ms * 1e-3), "ms": ms,
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "algorithmic_bytes": 64 * n}}
+    muls = NTT_MULS_PER_ELEMENT_22 if log_n == 22 else None
+    out = {"metric": "bn254_fr_ntt_elements_per_sec", "log_n": log_n, "value": n / (ms * 1e-3), "ms": ms,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "algorithmic_bytes": 64 * n, "kernel": "k_ntt_step x 3 (one HBM round trip each: 192 B moved per element)"}}
+    if muls:
+        out["valu_roofline"] = {"bound": "valu", "unit": "G Montgomery products/s", "products_per_element": muls,
+                                "achieved": muls * n / (ms * 1e-3) / 1e9, "peak": MUL_PEAK_G, "frac": muls * n / (ms * 1e-3) / 1e9 / MUL_PEAK_G}
+    return out
 
 
 def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True):
