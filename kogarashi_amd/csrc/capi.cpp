@@ -192,6 +192,8 @@ void kg_ctx_destroy(kg_ctx* c) {
   for (auto& sl : c->slots) { if (sl.host) hipHostFree(sl.host); if (sl.done) hipEventDestroy(sl.done); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
   for (void* b : c->up_buf) if (b) hipFree(b);
+  for (uint32_t* t : c->fb_table) if (t) hipFree(t);
+  if (c->fb_tmp) hipFree(c->fb_tmp);
   if (c->up_stream) { hipStreamSynchronize(c->up_stream); hipStreamDestroy(c->up_stream); }
   for (int i = 0; i < kg_ctx::UP_SLICES; ++i) { if (c->ev_up_s[i]) hipEventDestroy(c->ev_up_s[i]); if (c->ev_up_b[i]) hipEventDestroy(c->ev_up_b[i]); }
   for (auto& r : c->registered) hipFree(r.packed);

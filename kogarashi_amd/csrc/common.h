@@ -64,6 +64,9 @@ struct kg_ctx {
   hipStream_t up_stream = nullptr;
   static constexpr int UP_SLICES = 4;
   hipEvent_t ev_up_s[UP_SLICES] = {}, ev_up_b[UP_SLICES] = {};
+  void* fb_tmp = nullptr;                // XYZZ results between the two passes of kg_fixed_base_mul (grow-only)
+  size_t fb_tmp_bytes = 0;
+  uint32_t* fb_table[3] = {nullptr, nullptr, nullptr};   // kg_fixed_base_mul: 32 x 255 generator multiples d * 2^(8w) * G per curve, resident form
   void* h_pinned = nullptr;              // small pinned staging buffer for results
   size_t h_pinned_bytes = 0;
   std::vector<kg_tw_cache*> tw;          // per-(log_n, inverse) twiddle tables

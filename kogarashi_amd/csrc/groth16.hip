@@ -11,6 +11,7 @@
 #include "host_fp.h"
 #include <future>
 #include <vector>
+#include <type_traits>
 
 using namespace kg;
 
@@ -136,6 +137,155 @@ void h_store_affine(const XYZZ<HF>& p, uint64_t* xy, uint8_t* inf) {
   else { h_store(HF::zero(), xy); h_store(HF::one(), xy + E); *inf = 1; }
 }
 
+// ---- windowed fixed-base multiples (zksnark.rs:57,168-187: 5 m generator multiples per setup) -----------------------
+// table[w][d - 1] = (d * 2^(8w)) * G for w < 32, d = 1..255, affine in the MSM's resident form (18 / 36 words per point):
+// a multiple is then 32 mixed additions and no doubling.  The table is built once per (context, curve) with the
+// double-and-add kernel above; 8 160 points = 587 KB (G1) stay in L2.
+constexpr int FB_WIN = 32, FB_ENT = 255;
+
+template <class F> struct FbIO;                     // resident words of an affine point -> Affine<F>
+template <class P> struct FbIO<Fp<P>> {
+  static constexpr int PW = 18;
+  static __device__ __forceinline__ Affine<Fp<P>> load(const uint32_t* w) {
+    Affine<Fp<P>> a;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { a.x.l[k] = w[k]; a.y.l[k] = w[9 + k]; }
+    return a;
+  }
+};
+template <class G> struct FbIO<Fp2<G>> {
+  static constexpr int PW = 36;
+  static __device__ __forceinline__ Affine<Fp2<G>> load(const uint32_t* w) {
+    Affine<Fp2<G>> a;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { a.x.c0.l[k] = w[k]; a.x.c1.l[k] = w[9 + k]; a.y.c0.l[k] = w[18 + k]; a.y.c1.l[k] = w[27 + k]; }
+    return a;
+  }
+};
+// resident words <- ABI affine (x | y): the same conversion k_prep_bases does, one lane per point
+template <class F, int E64>
+__global__ void __launch_bounds__(64) k_fb_pack(const uint64_t* __restrict__ xy, size_t n, uint32_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int PW = FbIO<F>::PW;
+  for (int e = 0; e < 2 * E64 / 4; ++e) {            // field elements of the point: x, y (Fq2: x.c0, x.c1, y.c0, y.c1)
+    uint32_t w[8];
+    load_words(xy + i * 2 * E64 + 4 * e, 0, w);
+    const auto v = from_ref<typename std::conditional<std::is_same<F, Fr>::value, FrParams, FqParams>::type>(w);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[i * PW + 9 * e + k] = v.l[k];
+  }
+}
+
+// pass 1: one lane per scalar, 32 table additions -> XYZZ, raw internal form, array of structures (4 coordinates)
+template <class F, class SP>
+__global__ void __launch_bounds__(64) k_fb_window(const uint64_t* __restrict__ k, size_t n, const uint32_t* __restrict__ table,
+                                                  uint32_t* __restrict__ tmp) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8], e[8];
+  load_words(k, i, w);
+  ref_to_int<SP>(w, e);
+  constexpr int PW = FbIO<F>::PW;
+  XYZZ<F> acc = XYZZ<F>::identity();
+  for (int win = 0; win < FB_WIN; ++win) {
+    const uint32_t d = (e[win >> 2] >> (8 * (win & 3))) & 0xffu;
+    if (d) acc = add_mixed(acc, FbIO<F>::load(table + ((size_t)win * FB_ENT + (d - 1)) * PW));
+  }
+  PointIO<F>::store(tmp, n, i, acc);                  // structure of arrays over the n scalars
+}
+
+// pass 2: XYZZ -> affine ABI words with ONE inversion per lane for FB_BATCH consecutive points (Montgomery's trick)
+constexpr int FB_BATCH = 8;
+template <class F, int E64>
+__global__ void __launch_bounds__(64) k_fb_affine(const uint32_t* __restrict__ tmp, size_t n, uint64_t* __restrict__ out_xy,
+                                                  uint8_t* __restrict__ out_inf) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t first = t * FB_BATCH;
+  if (first >= n) return;
+  const int cnt = (int)(n - first < (size_t)FB_BATCH ? n - first : (size_t)FB_BATCH);
+  constexpr int E = RawIO<F>::NW;
+  F pre[FB_BATCH];                                    // prefix products of the non-zero ZZZ
+  F run = F::one();
+#pragma unroll
+  for (int j = 0; j < FB_BATCH; ++j) {
+    if (j < cnt) {
+      const F zzz = RawIO<F>::load(tmp + (size_t)3 * E * n, n, first + j);
+      if (!is_zero_2p(zzz)) run = mul(run, zzz);     // an identity (k = 0) contributes nothing
+    }
+    pre[j] = run;
+  }
+  F inv_run = inv(run);                               // (prod of the batch's ZZZ)^-1
+#pragma unroll
+  for (int j = FB_BATCH - 1; j >= 0; --j) {
+    if (j >= cnt) continue;
+    const size_t i = first + j;
+    const F zzz = RawIO<F>::load(tmp + (size_t)3 * E * n, n, i);
+    uint64_t* dst = out_xy + i * 2 * E64;
+    if (is_zero_2p(zzz)) {                            // (0, 1, inf): macros/curve/weierstrass/group.rs:22-26
+      put_ref(F::zero(), dst);
+      put_ref(F::one(), dst + E64);
+      out_inf[i] = 1;
+      continue;
+    }
+    const F zi = mul(inv_run, j ? pre[j - 1] : F::one());      // ZZZ_i^-1
+    inv_run = mul(inv_run, zzz);
+    const F x = RawIO<F>::load(tmp, n, i), y = RawIO<F>::load(tmp + (size_t)E * n, n, i), zz = RawIO<F>::load(tmp + (size_t)2 * E * n, n, i);
+    const F zzi = mul(mul(zi, zi), sqr(zz));          // ZZ^-1 = ZZZ^-2 * ZZ^2   (ZZ^3 = ZZZ^2)
+    put_ref(mul(x, zzi), dst);
+    put_ref(mul(y, zi), dst + E64);
+    out_inf[i] = 0;
+  }
+}
+
+template <class F, class SP, int E64>
+int fixed_base_t(kg_ctx* ctx, int curve, const uint64_t* d_k, size_t n, uint64_t* d_out_xy, uint8_t* d_out_inf) {
+  hipStream_t st = ctx->stream;
+  constexpr int PW = FbIO<F>::PW;
+  const size_t tn = (size_t)FB_WIN * FB_ENT;
+  if (n < 512) {                                      // few scalars (vk elements, tests): plain double-and-add; also builds the table
+    hipLaunchKernelGGL((k_fixed_base_mul<F, SP, E64>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_k, n, d_out_xy, d_out_inf);
+    KG_HIP(ctx, hipGetLastError());
+    return KG_OK;
+  }
+  if (!ctx->fb_table[curve]) {
+    // table scalars d * 2^(8w) as canonical integers -> the scalar field's Montgomery form -> generator multiples -> resident form
+    std::vector<uint64_t> hk(tn * 4, 0);
+    for (int w = 0; w < FB_WIN; ++w)
+      for (int d = 1; d <= FB_ENT; ++d) hk[((size_t)w * FB_ENT + (d - 1)) * 4 + (size_t)(w / 8)] = (uint64_t)d << (8 * (w % 8));
+    // (w = 31: d * 2^248 may exceed the group order; it is used as a plain integer multiple, which is what the table needs --
+    // the double-and-add below takes the canonical 254 bits of k mod p only, so reduce on the host instead)
+    uint64_t *d_tk = nullptr, *d_txy = nullptr; uint8_t* d_tinf = nullptr; uint32_t* table = nullptr;
+    KG_HIP(ctx, hipMalloc((void**)&d_tk, tn * 32));
+    KG_HIP(ctx, hipMalloc((void**)&d_txy, tn * 2 * E64 * 8));
+    KG_HIP(ctx, hipMalloc((void**)&d_tinf, tn));
+    KG_HIP(ctx, hipMalloc((void**)&table, tn * PW * 4));
+    KG_HIP(ctx, hipMemcpyAsync(d_tk, hk.data(), tn * 32, hipMemcpyHostToDevice, st));
+    KG_HIP(ctx, hipStreamSynchronize(st));
+    int rc = kg_field_vec_op(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, KG_OP_TO_MONT, d_tk, nullptr, d_tk, tn);
+    if (rc == KG_OK) {
+      hipLaunchKernelGGL((k_fixed_base_mul<F, SP, E64>), dim3((unsigned)((tn + 63) / 64)), dim3(64), 0, st, d_tk, tn, d_txy, d_tinf);
+      hipLaunchKernelGGL((k_fb_pack<F, E64>), dim3((unsigned)((tn + 63) / 64)), dim3(64), 0, st, d_txy, tn, table);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = set_err(ctx, KG_ERR_HIP, "fixed-base table construction");
+    }
+    hipFree(d_tk); hipFree(d_txy); hipFree(d_tinf);
+    if (rc != KG_OK) { hipFree(table); return rc; }
+    ctx->fb_table[curve] = table;
+  }
+  constexpr int NW = PointIO<F>::NW;
+  if (n * NW * 4 > ctx->fb_tmp_bytes) {
+    if (ctx->fb_tmp) { sync_all(ctx); hipFree(ctx->fb_tmp); ctx->fb_tmp = nullptr; ctx->fb_tmp_bytes = 0; }
+    KG_HIP(ctx, hipMalloc(&ctx->fb_tmp, n * NW * 4));
+    ctx->fb_tmp_bytes = n * NW * 4;
+  }
+  uint32_t* tmp = (uint32_t*)ctx->fb_tmp;
+  hipLaunchKernelGGL((k_fb_window<F, SP>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_k, n, ctx->fb_table[curve], tmp);
+  const size_t lanes = (n + FB_BATCH - 1) / FB_BATCH;
+  hipLaunchKernelGGL((k_fb_affine<F, E64>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, tmp, n, d_out_xy, d_out_inf);
+  KG_HIP(ctx, hipGetLastError());
+  return KG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -145,12 +295,9 @@ int kg_fixed_base_mul(kg_ctx* ctx, int curve, const uint64_t* d_k, size_t n, uin
   if (n == 0) return KG_OK;
   if (!d_k || !d_out_xy || !d_out_inf) return KG_ERR_BAD_ARG;
   KG_HIP(ctx, hipSetDevice(ctx->device));
-  dim3 grid((unsigned)((n + 63) / 64));
-  if (curve == KG_G1) hipLaunchKernelGGL((k_fixed_base_mul<Fq, FrParams, 4>), grid, dim3(64), 0, ctx->stream, d_k, n, d_out_xy, d_out_inf);
-  else if (curve == KG_GRUMPKIN) hipLaunchKernelGGL((k_fixed_base_mul<Fr, FqParams, 4>), grid, dim3(64), 0, ctx->stream, d_k, n, d_out_xy, d_out_inf);
-  else hipLaunchKernelGGL((k_fixed_base_mul<Fq2, FrParams, 8>), grid, dim3(64), 0, ctx->stream, d_k, n, d_out_xy, d_out_inf);
-  KG_HIP(ctx, hipGetLastError());
-  return KG_OK;
+  if (curve == KG_G1) return fixed_base_t<Fq, FrParams, 4>(ctx, curve, d_k, n, d_out_xy, d_out_inf);
+  if (curve == KG_GRUMPKIN) return fixed_base_t<Fr, FqParams, 4>(ctx, curve, d_k, n, d_out_xy, d_out_inf);
+  return fixed_base_t<Fq2, FrParams, 8>(ctx, curve, d_k, n, d_out_xy, d_out_inf);
 }
 
 }  // extern "C"

@@ -296,3 +296,26 @@ def test_proofs_in_flight_with_complete_inputs(oracle):
             assert all((g == w_).all() for g, w_ in zip(got[:3], want[0][:3]))
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("curve,sfd,w,n", [(0, 0, 8, 5000), (1, 1, 8, 3001), (2, 0, 16, 1200)])
+def test_fixed_base_mul_windowed(ctx, oracle, curve, sfd, w, n):
+    """n >= 512 takes the windowed path (32 x 255 generator multiples, 32 mixed additions per scalar, batched conversion to
+    affine with one inversion per 8 points): element for element the oracle's double-and-add, including k = 0 (identity flag),
+    +-1, bytes of zero, the largest scalar and identities at a batch's edges."""
+    O = oracle
+    k = O.gen_scalars(sfd, SEED + 1500 + curve, 0, n)
+    one = O.f_consts(sfd)["r"]
+    k[0] = 0; k[7] = 0; k[8] = 0; k[n - 1] = 0                       # identities inside and at the edges of inversion batches
+    k[1] = one
+    k[2] = O.f_neg(sfd, one)                                          # p - 1: the largest scalar
+    k[3] = O.f_to_mont(sfd, np.array([0, 0, 1, 0], dtype=np.uint64))  # 2^128: a single non-zero byte
+    k[4] = O.f_to_mont(sfd, np.array([0xFF00FF00FF00FF00, 0, 0xFF, 0], dtype=np.uint64))
+    dk = ctx.upload(k)
+    dxy, dinf = ctx.empty((n, w)), ctx.empty((n,), dtype=np.uint8)
+    ctx.fixed_base_mul(curve, dk.ptr, n, dxy.ptr, dinf.ptr)
+    want_xy, want_inf = O.fixed_base_mul(curve, k)
+    assert (dinf.numpy() == want_inf).all() and want_inf[[0, 7, 8, n - 1]].all() and want_inf.sum() == 4
+    assert (dxy.numpy() == want_xy).all()
+    ctx.fixed_base_mul(curve, dk.ptr, n, dxy.ptr, dinf.ptr)          # second call: cached table
+    assert (dxy.numpy() == want_xy).all()
