@@ -1145,7 +1145,7 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   const int W = (255 + c - 1) / c;
   const int B = 1 << (c - 1);
   int nch = (int)((n + 16383) / 16384);
-  if (nch > 16) nch = 16;
+  if (nch > 64) nch = 64;                         // (window, chunk) workgroups of the first sort pass: 1024 of them at 2^20
   if (nch < 1) nch = 1;
   size_t chunk_len = (n + nch - 1) / nch;
   const size_t npts = (size_t)W * B;
