@@ -30,6 +30,11 @@ struct kg_tw_cache {
   uint32_t* cos_lo = nullptr;  // g^(+-e) (g = 7), e < 2^lo_bits, for the coset shift [* n^-1 when inverse]
   uint32_t* cos_hi = nullptr;  // g^(+-(e << lo_bits))
   uint32_t* zinv = nullptr;    // (7^n - 1)^-1, one entry (fft.rs:141-154)
+  // inter-step twiddles read instead of generated: direct[s][r * inner + c] = w_n^(r * c * mult) for step s (0: A, 1: B).
+  // Step B's table is n2 * n3 <= 2^16 entries; step A's is n entries and is kept only while it stays cache-resident
+  // is worth its memory (log_n <= DIRECT_A_MAX_LOG = 22: 36 MB at 2^20, 151 MB at 2^22).  Saves the running-product update (one of the
+  // two products per element): 2^18 59 -> 52 us, 2^20 164 -> 145 us, 2^22 557 -> 548 us.
+  uint32_t* direct[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -37,6 +42,7 @@ namespace {
 constexpr int TILE = 2048;            // elements per workgroup tile
 constexpr int NT = 512;               // threads per workgroup: one radix-4 group per lane on a 2048-element tile (92-96 VGPRs)
 constexpr int SMALL_LOG = 10;         // largest in-LDS DFT: 2^10
+constexpr uint32_t DIRECT_A_MAX_LOG = 22;
 
 __device__ __forceinline__ Fr ld_tw(const uint32_t* __restrict__ tab, size_t e) {
   Fr r;
@@ -87,7 +93,16 @@ __global__ void __launch_bounds__(64) k_build_table(int kind, uint32_t log_n, in
   st_tw(tab, e, v);
 }
 
+// direct inter-step table: entry (r, c) = w_n^(r * c * mult), r < 2^log_m, c < 2^log_inner
+__global__ void __launch_bounds__(64) k_build_direct(uint32_t log_n, int inverse, uint32_t log_m, uint32_t log_inner, uint64_t mult, uint32_t* __restrict__ tab) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ((size_t)1 << (log_m + log_inner))) return;
+  const uint64_t r = e >> log_inner, c = e & (((uint64_t)1 << log_inner) - 1);
+  st_tw(tab, e, pow_u64(root_of(log_n, inverse), r * c * mult));
+}
+
 struct StepArgs {
+  const uint32_t* tw_direct;   // col flavour: inter-step twiddle table [r][c] (nullptr: generate w_n^(r * cexp) by a running product)
   const uint64_t* in;
   uint64_t* out;
   uint32_t log_m;        // DFT size of this step
@@ -256,7 +271,9 @@ __global__ void __launch_bounds__(NT, 2) k_ntt_step(StepArgs A) {
       const uint64_t g = g0 + col;
       addr = ((g >> A.log_inner) << (A.log_m + A.log_inner)) + ((uint64_t)r << A.log_inner) + (g & (A.inner - 1));
       v = lds_load(lds, tile_index<ROW>(r, col, A.log_m, A.log_tc));
-      if (A.mult) {
+      if (A.tw_direct) {
+        v = mul(v, ld_tw(A.tw_direct, ((size_t)r << A.log_inner) + (size_t)(g & (A.inner - 1))));
+      } else if (A.mult) {
         // w_n^(r * cexp): this lane keeps its column and walks r in steps of NT / tc, so the twiddle advances by a
         // fixed ratio -- one product per element instead of the two of a table lookup
         if (idx == threadIdx.x) {
@@ -294,6 +311,15 @@ __global__ void k_build_zinv(uint32_t log_n, uint32_t* __restrict__ out) {
   st_tw(out, 0, inv(norm(sub<4, 1>(g, Fr::one()))));
 }
 
+// log_n = k1 + k2 + k3: at most three steps of <= 8 bits (<= 10 for log_n > 24)
+void factor_steps(uint32_t log_n, uint32_t& k1, uint32_t& k2, uint32_t& k3) {
+  k1 = k2 = k3 = 0;
+  const uint32_t cap = log_n > 24 ? SMALL_LOG : 8;
+  if (log_n <= cap) k3 = log_n;
+  else if (log_n <= 2 * cap) { k1 = (log_n + 1) / 2; k3 = log_n - k1; }
+  else { k1 = (log_n + 2) / 3; k2 = (log_n - k1 + 1) / 2; k3 = log_n - k1 - k2; }
+}
+
 int get_tables(kg_ctx* ctx, uint32_t log_n, int inverse, kg_tw_cache** out) {
   for (kg_tw_cache* t : ctx->tw)
     if (t->log_n == log_n && t->inverse == inverse) { *out = t; return KG_OK; }
@@ -314,6 +340,20 @@ int get_tables(kg_ctx* ctx, uint32_t log_n, int inverse, kg_tw_cache** out) {
   hipLaunchKernelGGL(k_build_table, dim3((n_lo + 63) / 64), dim3(64), 0, st, 3, log_n, inverse, t->lo_bits, n_lo, t->cos_lo);
   hipLaunchKernelGGL(k_build_table, dim3((n_hi + 63) / 64), dim3(64), 0, st, 4, log_n, inverse, t->lo_bits, n_hi, t->cos_hi);
   hipLaunchKernelGGL(k_build_zinv, dim3(1), dim3(64), 0, st, log_n, t->zinv);
+  {
+    uint32_t k1, k2, k3;
+    factor_steps(log_n, k1, k2, k3);
+    if (k1 && log_n <= DIRECT_A_MAX_LOG) {                        // step A: w_n^(i1 * c), c < n / n1
+      const size_t cnt = (size_t)1 << log_n;
+      if (alloc(&t->direct[0], cnt) != hipSuccess) { delete t; return set_err(ctx, KG_ERR_OOM, "twiddle table allocation"); }
+      hipLaunchKernelGGL(k_build_direct, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, log_n, inverse, k1, log_n - k1, (uint64_t)1, t->direct[0]);
+    }
+    if (k2) {                                                     // step B: w_n^(n1 * i2 * j3)
+      const size_t cnt = (size_t)1 << (k2 + k3);
+      if (alloc(&t->direct[1], cnt) != hipSuccess) { delete t; return set_err(ctx, KG_ERR_OOM, "twiddle table allocation"); }
+      hipLaunchKernelGGL(k_build_direct, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, log_n, inverse, k2, k3, (uint64_t)1 << k1, t->direct[1]);
+    }
+  }
   KG_HIP(ctx, hipGetLastError());
   ctx->tw_fresh = true;
   ctx->tw.push_back(t);
@@ -327,6 +367,8 @@ namespace kg {
 void tw_cache_free(kg_ctx* c) {
   for (kg_tw_cache* t : c->tw) {
     hipFree(t->small); hipFree(t->lo); hipFree(t->hi); hipFree(t->cos_lo); hipFree(t->cos_hi); hipFree(t->zinv);
+    if (t->direct[0]) hipFree(t->direct[0]);
+    if (t->direct[1]) hipFree(t->direct[1]);
     delete t;
   }
   c->tw.clear();
@@ -354,12 +396,8 @@ int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, ui
   KG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   KG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 
-  // factor log_n into at most three steps of <= 8 bits (<= 10 for log_n > 24)
-  uint32_t k1 = 0, k2 = 0, k3 = 0;
-  const uint32_t cap = log_n > 24 ? SMALL_LOG : 8;
-  if (log_n <= cap) k3 = log_n;
-  else if (log_n <= 2 * cap) { k1 = (log_n + 1) / 2; k3 = log_n - k1; }
-  else { k1 = (log_n + 2) / 3; k2 = (log_n - k1 + 1) / 2; k3 = log_n - k1 - k2; }
+  uint32_t k1, k2, k3;
+  factor_steps(log_n, k1, k2, k3);
   const uint64_t n1 = 1ull << k1, n2 = 1ull << k2, n3 = 1ull << k3;
 
   StepArgs base{};
@@ -384,12 +422,14 @@ int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, ui
     a.in = d_data; a.out = tmp; a.log_m = k1; a.inner = n >> k1; a.mult = 1; a.G = n >> k1; a.n1 = 1; a.log_inner = log_n - k1; a.log_G = log_n - k1; a.log_n1 = 0;
     a.log_tc = tile_cols(k1, a.inner);
     a.scale_mode = pre_scale ? 1 : 0;
+    a.tw_direct = T->direct[0];
     hipLaunchKernelGGL(k_ntt_step<false>, dim3((unsigned)(a.G >> a.log_tc)), dim3(NT), lds_bytes, st, a);
     if (k2) {
       // step B: tmp in place
       StepArgs b = base;
       b.in = tmp; b.out = tmp; b.log_m = k2; b.inner = n3; b.mult = n1; b.G = n >> k2; b.n1 = 1; b.log_inner = k3; b.log_G = log_n - k2; b.log_n1 = 0;
       b.log_tc = tile_cols(k2, b.inner);
+      b.tw_direct = T->direct[1];
       hipLaunchKernelGGL(k_ntt_step<false>, dim3((unsigned)(b.G >> b.log_tc)), dim3(NT), lds_bytes, st, b);
     }
     // step C: tmp -> data (transposed write)
