@@ -24,7 +24,7 @@ MADD_PEAK_G = 16.5              # measured: the bucket kernel's addition routine
 MAD_PEAK_T = 33.0               # measured chip-wide v_mad_u64_u32 issue rate, T instructions/s (profiles/r01_valu_rates.txt)
 MADS_PER_ADDITION = 1467        # add_mixed_signed (curve.h): 6 products x 162 + 2 squares x 126 + one double product x 243 multiply-accumulates (fp29.h)
 MUL_PEAK_G = 174.0              # measured Montgomery products/s (profiles/r01_mul_rate.txt)
-NTT_MULS_PER_ELEMENT_22 = 15    # 2^22 = 2^8 * 2^7 * 2^7: 11 butterfly products + 2 x 2 inter-step twiddle products per element
+NTT_MULS_PER_ELEMENT_22 = 13    # 2^22 = 2^8 * 2^7 * 2^7: 11 butterfly products + one inter-step twiddle product per element at each of the two step boundaries (the twiddle itself is read from the direct table, ntt.hip)
 
 
 def window_adds(n):

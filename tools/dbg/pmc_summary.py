@@ -18,8 +18,10 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         a["dispatches"] += 1
         a["sum"] += float(r["Counter_Value"])
     out[counter] = {k: {"dispatches": v["dispatches"], "mean_KB": round(v["sum"] / v["dispatches"], 1), "vgpr": v["vgpr"], "lds_bytes": v["lds"], "workgroup": v["wg"]} for k, v in acc.items()}
-out["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ntt --no-groth16`; "
-               "values are KB per dispatch as reported; gfx950 correction: FETCH_SIZE x2 for wide coalesced reads (MI355X_MICROARCH.md, HBM section)")
+out["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-groth16` "
+               "(tools/collect_profiles.sh; counter passes serialise the dispatches, so k_acc_tasks does not share the caches with the next step's sort here); "
+               "KB per dispatch as reported; gfx950 correction: FETCH_SIZE x2 for wide coalesced reads (MI355X_MICROARCH.md, HBM section) -- "
+               "calibrated for 16-B-per-lane streams, an upper estimate for k_acc_tasks' 8-B gathers")
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 for k in out["FETCH_SIZE"]:
     print(f"{k:32s} fetch {out['FETCH_SIZE'][k]['mean_KB']/1024:9.2f} MB  write {out['WRITE_SIZE'].get(k, {}).get('mean_KB', 0)/1024:9.2f} MB  vgpr {out['FETCH_SIZE'][k]['vgpr']} lds {out['FETCH_SIZE'][k]['lds_bytes']}")
