@@ -250,7 +250,7 @@ def bench_ntt(ctx, torch, dev, K, log_n=22, steps=10):
     return out
 
 
-def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True):
+def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True, tables=True):
     """secondary line: Groth16 prove at m = 2^log_m constraints (BASELINE.json configs[3]).  Circuit: the chain
     t_{i+1} = t_i * (t_i + 1) (x = [1, t_0], w = t_1..t_m); CRS:
     a real CRS from a fixed toxic waste, generated on the device; fixed (r, s).  The CPU leg runs the oracle's create_proof on the same inputs and compares the proof."""
@@ -331,6 +331,34 @@ def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True):
         same = all((g == w_).all() for g, w_ in zip(proof[:3], want[:3])) and (proof[3] == want[3]).all()
         out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "proofs/s", "cores": threads, "kind": "port",
                                "sample": f"one full proof at m = 2^{log_m}, {cdt:.2f} s", "gpu_matches_cpu_at_full_size": bool(same)}
+    # the same proofs with window tables on the five CRS vectors (kg_bases_precompute: 2^(c w) * P for every window, built once
+    # per CRS): one bucket set for all windows of an MSM; proofs must be bit-identical
+    if tables:
+        nz = l + m_l_1
+        t0 = time.perf_counter()
+        for name in ("a", "b_g1", "b_g2", "l"):
+            ctx.bases_precompute(dev_arr[name].data_ptr(), nz)
+        ctx.bases_precompute(dev_arr["h"].data_ptr(), m - 1)
+        ctx.sync()
+        build_ms = (time.perf_counter() - t0) * 1e3
+        proof_t = prove()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            proof_t = prove()
+        torch.cuda.synchronize()
+        dt_tb = (time.perf_counter() - t0) / steps
+        run(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        proof_tp = run(k_pipe)
+        torch.cuda.synchronize()
+        dt_t = (time.perf_counter() - t0) / k_pipe
+        c_t = 17 if nz >= (1 << 17) else 16
+        w_t = (255 + c_t - 1) // c_t
+        out["window_tables"] = {"ms_per_proof": dt_t * 1e3, "ms_per_proof_blocking": dt_tb * 1e3, "value": 1.0 / dt_t, "build_ms": build_ms,
+                                "table_bytes": w_t * (72 * (3 * nz + (m - 1)) + 144 * nz),
+                                "proofs_match": bool(all((proof_t[i] == proof[i]).all() and (proof_tp[i] == proof[i]).all() for i in range(4)))}
     for name in ("h", "l", "a", "b_g1", "b_g2"):
         ctx.bases_unregister(dev_arr[name].data_ptr())
     return out

@@ -134,6 +134,15 @@ int kg_points_sum_affine(kg_ctx* ctx, int curve, const uint64_t* h_points_xy, co
  * releases it. */
 int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t n);
 int kg_bases_unregister(kg_ctx* ctx, const uint64_t* d_bases);
+/* Window tables for a registered array (fixed bases: a CRS vector, a commitment key): stores 2^(c*w) * base[i] for every
+ * window w next to the resident copy -- ceil(255 / c) x the array, 72 B per G1 / Grumpkin point and window, 144 B per G2
+ * point.  An MSM over the WHOLE array (kg_msm, kg_msm_begin, kg_commit, and kg_groth16_prove_bn254 when all five CRS
+ * vectors carry tables) then sorts the digits of all windows into ONE set of 2^(c-1) buckets: the bucket reduction and the
+ * host finish shrink by the window count, and the window can be one bit wider (c = 17: 15 additions per scalar instead
+ * of 16-17).  Results are bit-identical.  msm_len = the length of the MSMs the array will meet (0 = the array's own
+ * length; the Groth16 vector l meets the witness z = x || w, so its msm_len is |z|); offered for 2^16 <= msm_len <= 2^20,
+ * KG_ERR_BAD_ARG otherwise.  The reference has no counterpart (groth16/src/msm.rs re-reads affine bases per call). */
+int kg_bases_precompute(kg_ctx* ctx, const uint64_t* d_bases, size_t msm_len);
 /* Tuning knob: window width c (0 = automatic). */
 int kg_msm_set_window(kg_ctx* ctx, int c);
 /* The automatic rule: window width c for n pairs (W = ceil(255 / c) signed windows of 2^(c-1) buckets; the reference's

@@ -196,7 +196,7 @@ void kg_ctx_destroy(kg_ctx* c) {
   if (c->fb_tmp) hipFree(c->fb_tmp);
   if (c->up_stream) { hipStreamSynchronize(c->up_stream); hipStreamDestroy(c->up_stream); }
   for (int i = 0; i < kg_ctx::UP_SLICES; ++i) { if (c->ev_up_s[i]) hipEventDestroy(c->ev_up_s[i]); if (c->ev_up_b[i]) hipEventDestroy(c->ev_up_b[i]); }
-  for (auto& r : c->registered) hipFree(r.packed);
+  for (auto& r : c->registered) { hipFree(r.packed); if (r.table) hipFree(r.table); }
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;

@@ -56,7 +56,9 @@ struct kg_ctx {
   // thread, so the calling thread goes straight on to enqueue the next MSM; kg_msm_end joins it
   std::future<int> ticket_fut[4];
   uint64_t ticket_out[4][24] = {};
-  struct Registered { const uint64_t* base; const uint8_t* inf; size_t n; int curve; uint32_t* packed; };
+  // table: optional window multiples of the array (kg_bases_precompute): table[w][i] = 2^(table_c * w) * base[i] in resident
+  // form, w < table_W -- an MSM against them needs one set of buckets for all windows (merged sort, msm.hip)
+  struct Registered { const uint64_t* base; const uint8_t* inf; size_t n; int curve; uint32_t* packed; uint32_t* table = nullptr; int table_c = 0, table_W = 0; };
   std::vector<Registered> registered;    // bases converted once by kg_bases_register     // lengths of the MSMs begun with kg_msm_begin                         // pinned result slots: MSMs in flight whose host finish is pending
   // kg_msm_host: cached device copies of the caller's host arrays (grow-only) and the upload queue
   void* up_buf[3] = {nullptr, nullptr, nullptr};     // bases, scalars, identity flags
@@ -221,6 +223,9 @@ struct MsmSorted {
   uint32_t *task_bkt = nullptr, *task_id = nullptr;
   int set = 0;                // which scalar-side space it lives in
   hipEvent_t ready = nullptr; // recorded on the scalar queue after the last sort kernel
+  // merged sort (bases with window tables): the digits of all windows share ONE set of B buckets; W = 1 above, windows = the
+  // real window count, an entry's index field is (window << merged_shift) | scalar index
+  int merged_shift = 0, windows = 0;
 };
 // ntt.hip
 int ntt_prepare(kg_ctx* ctx, uint32_t log_n, int inverse);
@@ -228,7 +233,12 @@ int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, ui
 // ordered: the caller has already put the scalar queue (ctx->sort_stream, see scalar_queue()) behind the producer of
 // d_scalars; otherwise msm_sort orders it after everything enqueued on the main queue so far (stream semantics), or not
 // at all when the context's inputs are declared complete (kg_ctx_set_inputs_complete)
-int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered = false);
+// merged_c: 0, or the window width of the bases' tables (merged_window(n)): sort all windows into one set of buckets;
+// lane_mult: how many accumulation lanes each task of this sort will occupy (fused arrays, G2's lane pairs) -- sizes the tasks
+int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered = false, int merged_c = 0, int lane_mult = 1);
+int merged_window(const kg_ctx* ctx, size_t n);       // window width of the merged form for an n-scalar MSM, 0 = not offered at this length
+// does this registered array carry a window table that serves an n-scalar merged MSM?  (d_inf must be the registered flag array)
+bool has_window_table(const kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, size_t msm_len);
 int scalar_queue(kg_ctx* ctx, hipStream_t* out);     // the scalar-side queue, created on first use
 // several base arrays against one scalar sort, accumulated by one launch (at most 3; result slots in distinct run-space sets)
 // bases_complete: the base array is complete in device memory when the call is made (no ordering against the main queue)

@@ -400,7 +400,10 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   const int SL[5] = {slot_base + 1, slot_base + 2, slot_base + 3, slot_base + 4, slot_base + 5};
   {
     MsmSorted Sz;
-    rc = msm_sort(ctx, KG_FR, Z, nz, &Sz, true);
+    // window tables on all four vectors that meet z (kg_bases_precompute): one merged sort, one set of buckets for all windows
+    const bool tz = has_window_table(ctx, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, nz) && has_window_table(ctx, KG_G1, crs->d_a, crs->d_a_inf, nz, nz) &&
+                    has_window_table(ctx, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, nz, nz) && (!m_l_1 || has_window_table(ctx, KG_G1, crs->d_l, crs->d_l_inf, m_l_1, nz));
+    rc = msm_sort(ctx, KG_FR, Z, nz, &Sz, true, tz ? merged_window(ctx, nz) : 0, 2);
     // G2 first: its host finish (Fq2 arithmetic, ~3x a G1 finish) and its slow reduction then overlap the G1 accumulations
     if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, 0, SL[0]);
     if (rc == KG_OK) f_b2 = finish_async(KG_G2, SL[0], b2i);
@@ -444,7 +447,8 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
     MsmSorted Sq;
     hip_rc(hipEventRecord(ctx->ev_order, st), "hipEventRecord(order)");             // h's coefficients come off the main queue
     hip_rc(hipStreamWaitEvent(sq, ctx->ev_order, 0), "hipStreamWaitEvent(order)");
-    if (rc == KG_OK) rc = msm_sort(ctx, KG_FR, A, hn, &Sq, true);
+    const bool th = has_window_table(ctx, KG_G1, crs->d_h, crs->d_h_inf, hn, hn);
+    if (rc == KG_OK) rc = msm_sort(ctx, KG_FR, A, hn, &Sq, true, th ? merged_window(ctx, hn) : 0, 1);
     if (rc == KG_OK) rc = msm_run(ctx, Sq, KG_G1, crs->d_h, crs->d_h_inf, hn, 0, SL[4]);
     if (rc == KG_OK) f_q = finish_async(KG_G1, SL[4], q_p);
   } else msm_identity(KG_G1, q_p);

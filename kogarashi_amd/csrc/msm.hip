@@ -21,6 +21,7 @@
 #include "host_fp.h"
 #include "fp2s.h"
 #include <chrono>
+#include <cstdlib>
 #include <thread>
 
 using namespace kg;
@@ -186,6 +187,36 @@ __global__ void __launch_bounds__(256) k_prep_bases(const uint64_t* __restrict__
   BaseIO<F>::convert(bases + (size_t)i * W + W / 2, buf + PE);
   if (inf && inf[i]) buf[8] |= INF_BIT;
   uint2* dst = reinterpret_cast<uint2*>(out + (size_t)i * 2 * PE);
+#pragma unroll
+  for (int j = 0; j < PE; ++j) dst[j] = make_uint2(buf[2 * j], buf[2 * j + 1]);
+}
+
+// Window tables (kg_bases_precompute): next[i] = 2^c * prev[i], both in resident form.  c doublings in XYZZ and one inversion
+// per point -- a one-off per registered array (2^20 G1 points x 14 windows: ~50 ms), so no batching of the inversions.
+template <class P> __device__ __forceinline__ void put_limbs(const Fp<P>& a, uint32_t* w) {
+#pragma unroll
+  for (int j = 0; j < 9; ++j) w[j] = a.l[j];
+}
+template <class F> __device__ __forceinline__ void put_limbs(const Fp2<F>& a, uint32_t* w) { put_limbs(a.c0, w); put_limbs(a.c1, w + 9); }
+template <class F>
+__global__ void __launch_bounds__(64) k_table_next(const uint32_t* __restrict__ prev, size_t n, int c, uint32_t* __restrict__ next) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int PE = BaseIO<F>::PE;
+  Affine<F> a;
+  bool inf = BaseIO<F>::load_point(prev + i * 2 * PE, a.x, a.y);
+  uint32_t buf[2 * PE];
+#pragma unroll
+  for (int j = 0; j < 2 * PE; ++j) buf[j] = 0;
+  if (!inf) {
+    XYZZ<F> p = double_affine(a);
+    for (int k = 1; k < c; ++k) p = double_xyzz(p);
+    Affine<F> o;
+    inf = !to_affine(p, o);                          // a point of 2-power order (never in the prime-order groups) would end here
+    if (!inf) { put_limbs(reduce(o.x), buf); put_limbs(reduce(o.y), buf + PE); }
+  }
+  if (inf) buf[8] |= INF_BIT;
+  uint2* dst = reinterpret_cast<uint2*>(next + i * 2 * PE);
 #pragma unroll
   for (int j = 0; j < PE; ++j) dst[j] = make_uint2(buf[2 * j], buf[2 * j + 1]);
 }
@@ -375,16 +406,20 @@ __global__ void __launch_bounds__(1024) k_seg_table(const uint32_t* __restrict__
 constexpr int GS_NT = 256, GS_TILE = 1024, GS_MAXG = 1024;
 __global__ void __launch_bounds__(GS_NT) k_group_scatter(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len, int G,
                                                          const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ gstart,
-                                                         uint32_t* __restrict__ tmp) {
+                                                         uint32_t* __restrict__ tmp, const uint32_t* __restrict__ woff, int mshift) {
   KG_SERVICE_PRIO();
   __shared__ uint32_t cursor[GS_MAXG], hist[GS_MAXG], lstart[GS_MAXG], sh[40];    // hist doubles as the tile's address delta
   __shared__ uint32_t stage[GS_TILE];
   __shared__ uint16_t sg[GS_TILE];
   const int w = blockIdx.x, ch = blockIdx.y, nch = gridDim.y, tid = threadIdx.x;
   const int per = (G + GS_NT - 1) / GS_NT;            // groups a lane owns in the scans (consecutive; <= 4)
-  for (int g = tid; g < G; g += GS_NT) cursor[g] = cnt[((size_t)w * nch + ch) * G + g] + gstart[(size_t)w * G + g];
+  // merged sort (woff != nullptr): all windows share one run per group -- gstart is the merged table, woff[w][g] the entries
+  // of the windows in front of w inside the group's run, and the window number rides in the entry above the scalar index
+  if (woff) for (int g = tid; g < G; g += GS_NT) cursor[g] = cnt[((size_t)w * nch + ch) * G + g] + woff[(size_t)w * G + g] + gstart[g];
+  else for (int g = tid; g < G; g += GS_NT) cursor[g] = cnt[((size_t)w * nch + ch) * G + g] + gstart[(size_t)w * G + g];
   const size_t lo = (size_t)ch * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
-  uint32_t* dst = tmp + (size_t)w * n;
+  uint32_t* dst = woff ? tmp : tmp + (size_t)w * n;
+  const uint32_t wtag = woff ? (uint32_t)w << mshift : 0u;
   for (size_t tile = lo; tile < hi; tile += GS_TILE) {
     for (int g = tid; g < G; g += GS_NT) hist[g] = 0;
     __syncthreads();
@@ -398,7 +433,7 @@ __global__ void __launch_bounds__(GS_NT) k_group_scatter(const uint32_t* __restr
         const uint32_t m = window_digit(kt, n, i, w, c, W, neg);
         if (m) {
           const uint32_t g = (m - 1) >> FINE_BITS;
-          rec[r] = (uint32_t)i | (((m - 1) & (FINE - 1)) << 24) | (neg ? 0x80000000u : 0u);
+          rec[r] = ((uint32_t)i | wtag) | (((m - 1) & (FINE - 1)) << 24) | (neg ? 0x80000000u : 0u);
           key[r] = (g << 16) | atomicAdd(&hist[g], 1u);
         }
       }
@@ -474,6 +509,45 @@ __global__ void __launch_bounds__(GS_NT) k_group_scan(uint32_t* __restrict__ cnt
   if (tid == 0) segbase[(size_t)w * (G + 1) + G] = total;
   uint4* z = reinterpret_cast<uint4*>(bsize + (size_t)w * B);            // B is a multiple of 4 here (c >= 12)
   for (int b = threadIdx.x; b < B / 4; b += blockDim.x) z[b] = make_uint4(0, 0, 0, 0);
+}
+
+// Merged sort: the per-window group sizes of k_group_scan -> one run per group over all windows.  woff[w][g] = entries of
+// group g in the windows in front of w; gsize_m / gstart_m / segbase_m = the W' = 1 tables the fine pass works from.
+__global__ void __launch_bounds__(GS_NT) k_merge_groups(const uint32_t* __restrict__ gsize, int W, int G, uint32_t* __restrict__ woff,
+                                                        uint32_t* __restrict__ gsize_m, uint32_t* __restrict__ gstart_m,
+                                                        uint32_t* __restrict__ segbase_m) {
+  KG_SERVICE_PRIO();
+  __shared__ uint32_t sh[40];
+  const int tid = threadIdx.x;
+  const int per = (G + GS_NT - 1) / GS_NT;            // consecutive groups per lane (<= 4)
+  uint32_t run[4], ns[4], rsum = 0, nsum = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = tid * per + j;
+    run[j] = 0;
+    if (j < per && g < G) {
+      for (int w = 0; w < W; ++w) {
+        woff[(size_t)w * G + g] = run[j];
+        run[j] += gsize[(size_t)w * G + g];
+      }
+      gsize_m[g] = run[j];
+    }
+    ns[j] = (run[j] + SEG - 1) / SEG;
+    rsum += run[j]; nsum += ns[j];
+  }
+  uint32_t total;
+  uint32_t st = block_exclusive_scan_1024(rsum, sh, total);
+  uint32_t ex = block_exclusive_scan_1024(nsum, sh, total);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = tid * per + j;
+    if (j < per && g < G) {
+      gstart_m[g] = st;
+      segbase_m[g] = ex;
+      st += run[j]; ex += ns[j];
+    }
+  }
+  if (tid == 0) segbase_m[G] = total;
 }
 
 struct SegRange { int g; uint32_t lo, hi; };
@@ -764,13 +838,13 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restric
   const int lo = threadIdx.x * per, hi = lo + per < B ? lo + per : B;
   const uint32_t* src = bsize + (size_t)w * B;
   const bool vec = (per & 3) == 0 && hi - lo == per;       // every lane owns whole 16-byte groups
-  uint32_t ssum = 0, tsum = 0, mx = 0;
+  uint32_t ssum = 0, tsum = 0, mx = 0, full = 0;     // full: tasks of the full length T (one shared bin: counted per lane, added once)
   auto tally = [&](uint32_t v) {
     if (v) {
       const uint32_t nt = (v + T - 1) / T;
       ssum += v; tsum += nt; mx = v > mx ? v : mx;
       atomicAdd(&h[len_key(v - (nt - 1) * T)], 1u);
-      if (nt > 1) atomicAdd(&h[len_key(T)], nt - 1);
+      full += nt - 1;
     }
   };
   if (vec) {
@@ -778,6 +852,9 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restric
   } else {
     for (int b = lo; b < hi; ++b) tally(src[b]);
   }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) full += __shfl_xor(full, d);
+  if ((threadIdx.x & 63) == 0 && full) atomicAdd(&h[len_key(T)], full);
   uint32_t total_s, total_t;
   uint32_t run_s = block_exclusive_scan_1024(ssum, sh, total_s);
   uint32_t run_t = block_exclusive_scan_1024(tsum, sh, total_t);
@@ -863,6 +940,7 @@ struct AccSets {
   const uint32_t* pb[MAX_FUSED];      // packed bases of each array
   uint32_t idx_off[MAX_FUSED];        // scalars in front of the array (shared sort, z = x || w)
   uint32_t* partial[MAX_FUSED];       // partial sums, one per task
+  uint32_t tab_n[MAX_FUSED];          // merged sort: points per window of the array's table (pb = the table)
 };
 // G2: the compiler lands on 256 VGPRs + 1 AGPR = one wave per SIMD; asking for two waves costs a few spilled registers
 // and buys the second wave (the issue rate of this code at one wave per SIMD is ~69 % of its rate at four)
@@ -872,16 +950,16 @@ template <class F>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::MIN))) k_acc_tasks(AccSets A, const uint32_t* __restrict__ sorted,
                                                   const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bsize, Level L,
                                                   const uint32_t* __restrict__ task_bkt, const uint32_t* __restrict__ task_id,
-                                                  size_t n, int W, int B, uint32_t T, size_t pstride) {
+                                                  size_t n, int W, int B, uint32_t T, size_t pstride, int mshift) {
   const int set = A.nsets > 1 ? (int)(blockIdx.x % (unsigned)A.nsets) : 0;
   const uint32_t p = ((A.nsets > 1 ? blockIdx.x / (unsigned)A.nsets : blockIdx.x) * blockDim.x + threadIdx.x) / Lanes<F>::N;   // Fq2: a lane pair per task
   if (p >= L.base[W]) return;
   const uint32_t* __restrict__ pbases = A.pb[0];
-  uint32_t idx_off = A.idx_off[0];
+  uint32_t idx_off = A.idx_off[0], tab_n = A.tab_n[0];
   uint32_t* __restrict__ partial = A.partial[0];
 #pragma unroll
   for (int k = 1; k < MAX_FUSED; ++k)
-    if (set == k) { pbases = A.pb[k]; idx_off = A.idx_off[k]; partial = A.partial[k]; }
+    if (set == k) { pbases = A.pb[k]; idx_off = A.idx_off[k]; partial = A.partial[k]; tab_n = A.tab_n[k]; }
   const size_t bi = task_bkt[p];
   const uint32_t t = task_id[p];
   const int w = (int)(bi / B);
@@ -893,10 +971,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
   XYZZ<F> acc = XYZZ<F>::identity();
   for (uint32_t j = lo; j < hi; ++j) {
     const uint32_t e = list[j];
-    const uint32_t idx = e & 0x7fffffffu;
+    uint32_t idx = e & 0x7fffffffu;
+    size_t row = 0;                                      // merged sort: the entry names (window, scalar); the table row of the window
+    if (mshift) { row = (size_t)(idx >> mshift) * tab_n; idx &= (1u << mshift) - 1u; }
     if (idx < idx_off) continue;                         // scalars in front of this base array (shared sort, z = x || w)
     Affine<F> a;
-    if (BaseIO<F>::load_point(pbases + (size_t)(idx - idx_off) * PW, a.x, a.y)) continue;   // identity base (msm.rs:58-64 adds it as a no-op)
+    if (BaseIO<F>::load_point(pbases + (row + (idx - idx_off)) * PW, a.x, a.y)) continue;   // identity base (msm.rs:58-64 adds it as a no-op)
     acc = add_mixed_signed(acc, a, (e & 0x80000000u) != 0);
   }
   PointAoS<F>::store(partial, t, acc);
@@ -906,6 +986,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
 template <class F>
 __global__ void __launch_bounds__(64) k_sum_tasks(const uint32_t* __restrict__ pin, size_t in_stride, Level Lin, Level L, int W, int B, uint32_t T2,
                                                   uint32_t* __restrict__ pout, size_t out_stride) {
+  KG_SERVICE_PRIO();
   const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
   if (t >= L.base[W]) return;
   int w, b;
@@ -1136,38 +1217,72 @@ struct Carver {
 
 namespace kg {
 
-int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered) {
+// Window width of the merged form: one set of 2^(c-1) buckets for all windows, so the bucket reduction and the host finish
+// shrink by the window count and a wider window costs nothing extra -- c = 17 (15 windows) from 2^17 scalars.  Offered where
+// the two-pass sort runs and (window << ceil(log2 n)) | index fits an entry's 24-bit field.
+int merged_window(const kg_ctx* ctx, size_t n) {
+  if (n < ((size_t)1 << 16) || n > ((size_t)1 << 20)) return 0;
+  int c = n >= ((size_t)1 << 17) ? 17 : 16;
+  if (ctx && ctx->msm_window >= 15 && ctx->msm_window <= 18) c = ctx->msm_window;
+  int s = 0;
+  while (((size_t)1 << s) < n) ++s;
+  const int W = (255 + c - 1) / c;
+  if (((size_t)W << s) > ((size_t)1 << 24)) return 0;
+  return c;
+}
+
+int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered, int merged_c, int lane_mult) {
   if (n == 0 || n >= ((size_t)1 << 31)) return set_err(ctx, KG_ERR_BAD_ARG, "msm length must be in [1, 2^31)");
   host_trace("sort: enter");
   KG_HIP(ctx, hipSetDevice(ctx->device));
-  int c = pick_window(n, ctx->msm_window);
-  if (c > 16 && !(n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24))) c = 16;   // one-pass histogram: 2^(c-1) LDS counters
-  const int W = (255 + c - 1) / c;
+  const bool merged = merged_c != 0;
+  int c = merged ? merged_c : pick_window(n, ctx->msm_window);
+  if (!merged && c > 16 && !(n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24))) c = 16;   // one-pass histogram: 2^(c-1) LDS counters
+  const int W = (255 + c - 1) / c;                  // windows of the scalars
   const int B = 1 << (c - 1);
+  int mshift = 0;
+  if (merged) {
+    while (((size_t)1 << mshift) < n) ++mshift;
+    if (c < 15 || c > 18 || n < ((size_t)1 << 16) || ((size_t)W << mshift) > ((size_t)1 << 24))
+      return set_err(ctx, KG_ERR_BAD_ARG, "merged sort not offered for this length / window");
+  }
+  const int Wb = merged ? 1 : W;                    // windows of the BUCKET space: the merged form keeps one set for all digits
+  const size_t nv = merged ? (size_t)W * n : n;     // entries that can meet one bucket window
   int nch = (int)((n + 16383) / 16384);
   if (nch > 64) nch = 64;                         // (window, chunk) workgroups of the first sort pass: 1024 of them at 2^20
   if (nch < 1) nch = 1;
   size_t chunk_len = (n + nch - 1) / nch;
-  const size_t npts = (size_t)W * B;
+  const size_t npts = (size_t)Wb * B;
   // one task per bucket for uniform scalars: the unsigned top window of c = 15/16 holds twice the average load
   uint32_t T = (uint32_t)(4 * (n / B) + 32);
   if (T < 64) T = 64;
   if (T > 4096) T = 4096;
-  const size_t part_cap = (size_t)W * ((n + T - 1) / T) + npts;     // upper bound on round-1 tasks
+  if (merged) {
+    // a bucket holds ~W n / B entries (60 at 2^18, 240 at 2^20): cut so that the accumulation has about one resident round of
+    // lanes (4096 waves); every task beyond the first of a bucket costs one partial-sum addition afterwards
+    const size_t lanes = (size_t)(lane_mult < 1 ? 1 : lane_mult);
+    size_t t = nv * lanes / ((size_t)4096 * 64);
+    T = 16;
+    while (T < 128 && 2 * (size_t)T <= t) T *= 2;
+    if (const char* e = getenv("KG_MERGED_T")) { const int v = atoi(e); if (v >= 4 && v <= 4096) T = (uint32_t)v; }
+  }
+  const size_t part_cap = (size_t)Wb * ((nv + T - 1) / T) + npts;     // upper bound on round-1 tasks
 
   // two passes (bucket group, then bucket inside the group) once the sorted lists outgrow the L2; entries carry the
   // bucket's low FINE_BITS between the passes, which leaves 24 bits for the index
-  const bool two_pass = c - 1 >= FINE_BITS + 4 && n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24);
+  const bool two_pass = merged || (c - 1 >= FINE_BITS + 4 && n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24));
   const int G = two_pass ? B >> FINE_BITS : 0;      // bucket groups per window (<= 1024)
-  const int maxseg = two_pass ? G + (int)((n + SEG - 1) / SEG) : 0;
+  const int maxseg = two_pass ? G + (int)((nv + SEG - 1) / SEG) : 0;
   if (two_pass) chunk_len = (chunk_len + PREP_CH - 1) / PREP_CH * PREP_CH;   // k_prep_scalars_count: one chunk per workgroup
   Carver cv;
-  const size_t o_kt = cv.take(n * 32), o_cnt = cv.take((size_t)W * nch * (two_pass ? G : B) * 4), o_bsize = cv.take(npts * 4), o_bstart = cv.take(npts * 4);
+  const size_t o_kt = cv.take(n * 32), o_cnt = cv.take((size_t)W * nch * (two_pass ? G : B) * 4), o_bsize = cv.take((size_t)W * B * 4), o_bstart = cv.take(npts * 4);
   const size_t o_tmp = cv.take(two_pass ? (size_t)W * n * 4 : 0), o_gsize = cv.take((size_t)W * G * 4), o_gstart = cv.take((size_t)W * G * 4);
-  const size_t o_segbase = cv.take((size_t)W * (G + 1) * 4), o_segcnt = cv.take((size_t)W * maxseg * FINE * 4), o_segoff = cv.take((size_t)W * maxseg * FINE * 4);
-  const size_t o_sorted = cv.take((size_t)W * n * 4), o_lcnt = cv.take(npts * 4), o_lrel = cv.take(npts * 4), o_lbase = cv.take((size_t)(W + 1) * 4);
+  const size_t o_segbase = cv.take((size_t)W * (G + 1) * 4), o_segcnt = cv.take((size_t)Wb * maxseg * FINE * 4), o_segoff = cv.take((size_t)Wb * maxseg * FINE * 4);
+  const size_t o_sorted = cv.take((size_t)W * n * 4), o_lcnt = cv.take(npts * 4), o_lrel = cv.take(npts * 4), o_lbase = cv.take((size_t)(Wb + 1) * 4);
   const size_t o_rowtot = cv.take((size_t)W * 4), o_misc = cv.take(64), o_lenh = cv.take(2 * LEN_BINS * 4);
   const size_t o_tbkt = cv.take(part_cap * 4), o_tid = cv.take(part_cap * 4);
+  const size_t o_woff = cv.take(merged ? (size_t)W * G * 4 : 0), o_gsize_m = cv.take(merged ? (size_t)G * 4 : 0), o_gstart_m = cv.take(merged ? (size_t)G * 4 : 0);
+  const size_t o_segbase_m = cv.take(merged ? (size_t)(G + 1) * 4 : 0);
   // The scalar side runs on a queue of its own and alternates between two spaces: while MSM i accumulates (main queue,
   // reading set i & 1), MSM i+1 is sorted into the other set.  Ordering: the scalar queue waits for `after` (the producer
   // of d_scalars), or -- stream semantics -- for everything enqueued on the main queue so far, unless the context's inputs
@@ -1190,7 +1305,8 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   uint32_t* rowtot = (uint32_t*)(ws + o_rowtot);
   uint32_t* misc = (uint32_t*)(ws + o_misc);
   uint32_t* lenh = (uint32_t*)(ws + o_lenh);
-  S->n = n; S->c = c; S->W = W; S->B = B; S->T = T; S->npts = npts; S->part_cap = part_cap;
+  S->n = n; S->c = c; S->W = Wb; S->B = B; S->T = T; S->npts = npts; S->part_cap = part_cap;
+  S->merged_shift = mshift; S->windows = W;
   S->sorted = (uint32_t*)(ws + o_sorted); S->bsize = (uint32_t*)(ws + o_bsize); S->bstart = (uint32_t*)(ws + o_bstart);
   S->lcnt = (uint32_t*)(ws + o_lcnt); S->lrel = (uint32_t*)(ws + o_lrel); S->lbase = (uint32_t*)(ws + o_lbase);
   S->task_bkt = (uint32_t*)(ws + o_tbkt); S->task_id = (uint32_t*)(ws + o_tid);
@@ -1232,10 +1348,18 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
     uint32_t* segcnt = (uint32_t*)(ws + o_segcnt);
     uint32_t* segoff = (uint32_t*)(ws + o_segoff);
     zero_fill(st, misc, (o_lenh - o_misc) + 2 * LEN_BINS * 4);      // misc and the length histogram
+    uint32_t* woff = merged ? (uint32_t*)(ws + o_woff) : nullptr;
+    // the tables the fine pass and the task decomposition read: per window, or the merged single set
+    const uint32_t* f_gstart = merged ? (uint32_t*)(ws + o_gstart_m) : gstart;
+    const uint32_t* f_gsize = merged ? (uint32_t*)(ws + o_gsize_m) : gsize;
+    const uint32_t* f_segbase = merged ? (uint32_t*)(ws + o_segbase_m) : segbase;
     if (two_pass) {
       hipLaunchKernelGGL(k_group_scan, dim3(W), dim3(GS_NT), 0, st, cnt, nch, G, B, gsize, gstart, segbase, S->bsize);
-      hipLaunchKernelGGL(k_group_scatter, dim3(W, nch), dim3(GS_NT), 0, st, kt, n, c, W, chunk_len, G, cnt, gstart, tmp);
-      hipLaunchKernelGGL(k_fine_count, dim3(W, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, gstart, gsize, segbase, S->bsize, segcnt, segoff);
+      if (merged)
+        hipLaunchKernelGGL(k_merge_groups, dim3(1), dim3(GS_NT), 0, st, gsize, W, G, woff, (uint32_t*)(ws + o_gsize_m), (uint32_t*)(ws + o_gstart_m),
+                           (uint32_t*)(ws + o_segbase_m));
+      hipLaunchKernelGGL(k_group_scatter, dim3(W, nch), dim3(GS_NT), 0, st, kt, n, c, W, chunk_len, G, cnt, f_gstart, tmp, woff, mshift);
+      hipLaunchKernelGGL(k_fine_count, dim3(Wb, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bsize, segcnt, segoff);
     } else {
       hipLaunchKernelGGL(k_count, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, 0, cnt);
       hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, cnt, W, nch, B, S->bsize);
@@ -1243,15 +1367,15 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
     // task decomposition (needs only the bucket sizes); its two result words travel to the host while the
     // scatter below still runs, so the read-back does not stall the queue
     const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
-    hipLaunchKernelGGL(k_bucket_rows, dim3(W), dim3(BR_NT), 0, st, S->bsize, B, T, S->bstart, S->lcnt, S->lrel, rowtot, misc, lenh);
-    hipLaunchKernelGGL(k_task_bases, dim3(1), dim3(64), 0, st, rowtot, W, S->lbase, misc, misc + 4, lenh, lenh + LEN_BINS);
+    hipLaunchKernelGGL(k_bucket_rows, dim3(Wb), dim3(BR_NT), 0, st, S->bsize, B, T, S->bstart, S->lcnt, S->lrel, rowtot, misc, lenh);
+    hipLaunchKernelGGL(k_task_bases, dim3(1), dim3(64), 0, st, rowtot, Wb, S->lbase, misc, misc + 4, lenh, lenh + LEN_BINS);
     uint32_t* h_info = (uint32_t*)ctx->h_pinned;
     KG_HIP(ctx, hipMemcpyAsync(h_info, misc + 4, 8, hipMemcpyDeviceToHost, st));
     if (!ctx->ev_info) KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_info, hipEventDisableTiming));
     KG_HIP(ctx, hipEventRecord(ctx->ev_info, st));
     hipLaunchKernelGGL(k_len_scatter, dim3(g1024), dim3(1024), 0, st, S->bsize, S->lcnt, S->lrel, S->lbase, npts, B, T, lenh + LEN_BINS, S->task_bkt, S->task_id);
     if (two_pass)
-      hipLaunchKernelGGL(k_fine_scatter, dim3(W, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, gstart, gsize, segbase, S->bstart, segcnt, segoff, S->sorted);
+      hipLaunchKernelGGL(k_fine_scatter, dim3(Wb, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bstart, segcnt, segoff, S->sorted);
     else
       hipLaunchKernelGGL(k_scatter, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, 0, cnt, S->bstart, S->sorted);
     ph.end();
@@ -1291,7 +1415,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
   Lay lay[MAX_FUSED];
   AccSets A;
   A.nsets = njobs;
-  for (int k = 0; k < MAX_FUSED; ++k) { A.pb[k] = nullptr; A.idx_off[k] = 0; A.partial[k] = nullptr; }
+  for (int k = 0; k < MAX_FUSED; ++k) { A.pb[k] = nullptr; A.idx_off[k] = 0; A.partial[k] = nullptr; A.tab_n[k] = 0; }
   for (int k = 0; k < njobs; ++k) {
     const RunJob& J = jobs[k];
     Lay& Y = lay[k];
@@ -1305,9 +1429,14 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       // array is the registered one (same offset), or both are absent; any other combination converts per call
       const size_t off = off64 / BaseIO<F>::W;
       if (J.d_inf != (r.inf ? r.inf + off : nullptr)) continue;
-      reg_pb = r.packed + off * PW;
+      if (S.merged_shift) {                         // merged sort: the whole array through its window table
+        if (off != 0 || J.nbases != r.n || !r.table || r.table_c != c || r.table_W != S.windows) continue;
+        reg_pb = r.table;
+        A.tab_n[k] = (uint32_t)r.n;
+      } else reg_pb = r.packed + off * PW;
       break;
     }
+    if (S.merged_shift && !reg_pb) return set_err(ctx, KG_ERR_BAD_ARG, "merged sort against bases without a matching window table");
     Y.o_pb = cv.take(reg_pb ? 256 : J.nbases * PW * 4);
     for (int i = 0; i < 2; ++i) {
       Y.o_lc[i] = cv.take(npts * 4); Y.o_lr[i] = cv.take(npts * 4); Y.o_lb[i] = cv.take((size_t)(W + 1) * 4);
@@ -1353,7 +1482,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
   if (S.ntasks) {
     PhaseScope ph(ctx, "accumulate");
     hipLaunchKernelGGL(k_acc_tasks<F>, dim3(((S.ntasks + 63) / 64) * (unsigned)njobs), dim3(64), 0, st, A, S.sorted, S.bstart, S.bsize, L0, S.task_bkt, S.task_id,
-                       S.n, W, B, S.T, part_cap);
+                       S.n, W, B, S.T, part_cap, S.merged_shift);
     ph.end();
   }
   for (int k = 0; k < njobs; ++k) {
@@ -1369,10 +1498,16 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
     uint64_t* d_exp = (uint64_t*)(ws + Y.o_exp);
     // two reduction queues, by slot parity: a long reduction (G2: ~4x a G1 one) does not hold up the next MSM's
     hipStream_t side = (slot & 1) ? ctx->side2_stream : ctx->side_stream;
+    // Everything after the accumulation runs on a reduction queue, so that the main queue goes from one accumulation straight
+    // to the next: the partial-sum rounds, the dense bucket array (gather) and the c-1 latency-bound halving levels.
+    KG_HIP(ctx, hipEventRecord(ctx->ev_acc[set], st));
+    KG_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_acc[set], 0));
     Level L = L0;
     int pcur = 0;
     {
-      // skewed inputs: re-sum a bucket's partial sums until it owns one point
+      // buckets cut into several tasks (skewed inputs; every bucket of a merged sort): re-sum a bucket's partial sums until
+      // it owns one point
+      PhaseScope ph(ctx, "partial_sums", side);
       uint32_t max_cnt = S.max_cnt;
       int lv = -1;                                     // -1: level arrays of S; 0/1: local ping-pong
       const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
@@ -1381,24 +1516,21 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
         uint32_t* ncnt = (uint32_t*)(ws + o_lc[nx]);
         uint32_t* nrel = (uint32_t*)(ws + o_lr[nx]);
         uint32_t* nbase = (uint32_t*)(ws + o_lb[nx]);
-        KG_HIP(ctx, hipMemsetAsync(misc, 0, 64, st));
-        hipLaunchKernelGGL(k_task_count, dim3(g1024), dim3(1024), 0, st, L.cnt, npts, S.T2, ncnt, misc + 8);
-        hipLaunchKernelGGL(k_scan_rows, dim3(W), dim3(1024), 0, st, ncnt, B, nrel, rowtot);
-        hipLaunchKernelGGL(k_row_bases, dim3(1), dim3(64), 0, st, rowtot, W, nbase, (const uint32_t*)nullptr, misc + 4);
+        KG_HIP(ctx, hipMemsetAsync(misc, 0, 64, side));
+        hipLaunchKernelGGL(k_task_count, dim3(g1024), dim3(1024), 0, side, L.cnt, npts, S.T2, ncnt, misc + 8);
+        hipLaunchKernelGGL(k_scan_rows, dim3(W), dim3(1024), 0, side, ncnt, B, nrel, rowtot);
+        hipLaunchKernelGGL(k_row_bases, dim3(1), dim3(64), 0, side, rowtot, W, nbase, (const uint32_t*)nullptr, misc + 4);
         Level Lout{ncnt, nrel, nbase};
         // the task count of this round is bounded by the previous one; threads beyond base[W] exit
         const uint32_t bound = lv < 0 ? S.ntasks : (uint32_t)part_cap;
-        hipLaunchKernelGGL(k_sum_tasks<F>, dim3((bound + 63) / 64), dim3(64), 0, st, part[pcur], part_cap, L, Lout, W, B, S.T2, part[pcur ^ 1], part_cap);
+        hipLaunchKernelGGL(k_sum_tasks<F>, dim3((bound + 63) / 64), dim3(64), 0, side, part[pcur], part_cap, L, Lout, W, B, S.T2, part[pcur ^ 1], part_cap);
         pcur ^= 1;
         L = Lout;
         lv = nx;
         max_cnt = (max_cnt + S.T2 - 1) / S.T2;
       }
+      ph.end();
     }
-    // Everything after the accumulation runs on a reduction queue, so that the main queue goes from one accumulation straight
-    // to the next: the dense bucket array (gather) and the c-1 latency-bound halving levels.
-    KG_HIP(ctx, hipEventRecord(ctx->ev_acc[set], st));
-    KG_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_acc[set], 0));
     {
       PhaseScope ph(ctx, "gather", side);
       hipLaunchKernelGGL(k_gather_buckets<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, side, part[pcur], part_cap, L, W, B, pbuf[0]);
@@ -1472,6 +1604,14 @@ int msm_finish_t(kg_ctx* ctx, int slot, uint64_t* out_xyz) {
   return KG_OK;
 }
 
+bool has_window_table(const kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, size_t msm_len) {
+  const int c = merged_window(ctx, msm_len);
+  if (!c) return false;
+  for (const auto& r : ctx->registered)
+    if (r.base == d_bases && r.curve == curve && r.n == nbases && r.inf == d_inf && r.table && r.table_c == c) return true;
+  return false;
+}
+
 int scalar_queue(kg_ctx* ctx, hipStream_t* out) {
   KG_TRY(make_sort_stream(ctx));
   *out = ctx->sort_stream;
@@ -1536,7 +1676,8 @@ int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf
   if (!ctx || !out_xyz || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
   kg::MsmSorted S;
-  KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S));
+  const int mc = kg::has_window_table(ctx, curve, d_bases, d_inf, n, n) ? kg::merged_window(ctx, n) : 0;
+  KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S, false, mc));
   KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 0));
   return kg::msm_finish(ctx, curve, 0, out_xyz);
 }
@@ -1570,10 +1711,44 @@ int kg_bases_unregister(kg_ctx* ctx, const uint64_t* d_bases) {
     if (ctx->registered[i].base == d_bases) {
       kg_ctx_sync(ctx);
       hipFree(ctx->registered[i].packed);
+      if (ctx->registered[i].table) hipFree(ctx->registered[i].table);
       ctx->registered.erase(ctx->registered.begin() + i);
       return KG_OK;
     }
   }
+  return KG_OK;
+}
+
+int kg_bases_precompute(kg_ctx* ctx, const uint64_t* d_bases, size_t msm_len) {
+  if (!ctx || !d_bases) return KG_ERR_BAD_ARG;
+  KG_HIP(ctx, hipSetDevice(ctx->device));
+  kg_ctx::Registered* r = nullptr;
+  for (auto& e : ctx->registered) if (e.base == d_bases) r = &e;
+  if (!r) return set_err(ctx, KG_ERR_BAD_ARG, "kg_bases_precompute: the array is not registered");
+  if (msm_len == 0) msm_len = r->n;
+  if (msm_len < r->n) return set_err(ctx, KG_ERR_BAD_ARG, "kg_bases_precompute: msm_len is shorter than the array");
+  const int c = kg::merged_window(ctx, msm_len);
+  if (!c) return set_err(ctx, KG_ERR_BAD_ARG, "kg_bases_precompute: window tables are offered for MSMs of 2^16 .. 2^20 scalars");
+  if (r->table && r->table_c == c) return KG_OK;
+  if (r->table) { kg_ctx_sync(ctx); hipFree(r->table); r->table = nullptr; r->table_c = r->table_W = 0; }
+  const int W = (255 + c - 1) / c;
+  const size_t pw = r->curve == KG_G2 ? 36 : 18, row = r->n * pw;
+  uint32_t* table = nullptr;
+  if (hipError_t e = hipMalloc((void**)&table, (size_t)W * row * 4); e != hipSuccess) {
+    (void)hipGetLastError();
+    return set_err(ctx, KG_ERR_OOM, "window table allocation", e);
+  }
+  hipStream_t st = ctx->stream;
+  hipError_t e = hipMemcpyAsync(table, r->packed, row * 4, hipMemcpyDeviceToDevice, st);
+  const dim3 grid((unsigned)((r->n + 63) / 64));
+  for (int w = 1; w < W && e == hipSuccess; ++w) {
+    if (r->curve == KG_G1) hipLaunchKernelGGL(k_table_next<Fq>, grid, dim3(64), 0, st, table + (size_t)(w - 1) * row, r->n, c, table + (size_t)w * row);
+    else if (r->curve == KG_GRUMPKIN) hipLaunchKernelGGL(k_table_next<Fr>, grid, dim3(64), 0, st, table + (size_t)(w - 1) * row, r->n, c, table + (size_t)w * row);
+    else hipLaunchKernelGGL(k_table_next<Fq2>, grid, dim3(64), 0, st, table + (size_t)(w - 1) * row, r->n, c, table + (size_t)w * row);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) { hipFree(table); return set_err(ctx, KG_ERR_HIP, "window table build", e); }
+  r->table = table; r->table_c = c; r->table_W = W;
   return KG_OK;
 }
 
@@ -1582,7 +1757,8 @@ int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t*
   ctx->ticket_n[ticket] = n;
   if (n == 0) return KG_OK;
   kg::MsmSorted S;
-  KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S));
+  const int mc = kg::has_window_table(ctx, curve, d_bases, d_inf, n, n) ? kg::merged_window(ctx, n) : 0;
+  KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S, false, mc));
   if (ctx->ticket_fut[ticket].valid()) ctx->ticket_fut[ticket].wait();      // a ticket begun twice without its end: drop the older result
   KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 1 + ticket));      // slots 1..4 (slot 0: kg_msm; 6..15: the prover's two jobs)
   uint64_t* out = ctx->ticket_out[ticket];

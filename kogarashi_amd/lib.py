@@ -24,7 +24,7 @@ EXPORTS = [
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
     "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
-    "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete",
+    "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute",
 ]
 
 
@@ -192,6 +192,10 @@ class Context:
 
     def bases_register(self, curve: int, bases: int, inf: int, n: int):
         self._chk(self._lib.kg_bases_register(self._h, curve, _vp(bases), _vp(inf), C.c_size_t(n)), "kg_bases_register")
+
+    def bases_precompute(self, bases: int, msm_len: int = 0):
+        """window tables for a registered array (kg_bases_precompute); msm_len = length of the MSMs it meets (0: its own)"""
+        self._chk(self._lib.kg_bases_precompute(self._h, _vp(bases), C.c_size_t(msm_len)), "kg_bases_precompute")
 
     def bases_unregister(self, bases: int):
         self._chk(self._lib.kg_bases_unregister(self._h, _vp(bases)), "kg_bases_unregister")

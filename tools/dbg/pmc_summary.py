@@ -22,6 +22,13 @@ out["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                "(tools/collect_profiles.sh; counter passes serialise the dispatches, so k_acc_tasks does not share the caches with the next step's sort here); "
                "KB per dispatch as reported; gfx950 correction: FETCH_SIZE x2 for wide coalesced reads (MI355X_MICROARCH.md, HBM section) -- "
                "calibrated for 16-B-per-lane streams, an upper estimate for k_acc_tasks' 8-B gathers")
+def per_launch(kernel, algorithmic):
+    f = out["FETCH_SIZE"].get(kernel, {}).get("mean_KB", 0.0) * 1024
+    w = out["WRITE_SIZE"].get(kernel, {}).get("mean_KB", 0.0) * 1024
+    return {"fetch_reported": f, "fetch_corrected_x2": 2 * f, "write": w, "total_corrected": 2 * f + w, "algorithmic": algorithmic}
+# what bench.py's roofline.traffic reads (2^20 G1 pairs: 96 B per pair; 2^22 Fr elements: 32 B read + 32 B written per step)
+out["k_acc_tasks_traffic_bytes_per_launch"] = per_launch("k_acc_tasks", 96 << 20)
+out["k_ntt_step_traffic_bytes_per_launch_2_22"] = per_launch("k_ntt_step", 64 << 22)
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 for k in out["FETCH_SIZE"]:
     print(f"{k:32s} fetch {out['FETCH_SIZE'][k]['mean_KB']/1024:9.2f} MB  write {out['WRITE_SIZE'].get(k, {}).get('mean_KB', 0)/1024:9.2f} MB  vgpr {out['FETCH_SIZE'][k]['vgpr']} lds {out['FETCH_SIZE'][k]['lds_bytes']}")

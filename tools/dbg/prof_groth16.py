@@ -7,6 +7,6 @@ import bench
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 ctx = K.Context(0)
-st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st); ctx.set_stream(st.cuda_stream)
+ctx.set_inputs_complete(True)      # as bench.py: the library's own queues, inputs synchronised before use
 out = bench.bench_groth16(ctx, torch, dev, K, int(sys.argv[1]) if len(sys.argv) > 1 else 18, steps=5, cpu=False)
 print(out)
