@@ -250,7 +250,7 @@ def bench_ntt(ctx, torch, dev, K, log_n=22, steps=10):
     return out
 
 
-def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True, tables=True):
+def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True, tables=True, tickets=2):
     """secondary line: Groth16 prove at m = 2^log_m constraints (BASELINE.json configs[3]).  Circuit: the chain
     t_{i+1} = t_i * (t_i + 1) (x = [1, t_0], w = t_1..t_m); CRS:
     a real CRS from a fixed toxic waste, generated on the device; fixed (r, s).  The CPU leg runs the oracle's create_proof on the same inputs and compares the proof."""
@@ -297,13 +297,15 @@ def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True, tables=True):
     dt_blocking = (time.perf_counter() - t0) / steps
     # throughput: proofs issued back to back, two in flight (kg_groth16_prove_begin / _end) -- proof i+1's transforms and
     # sorts run under proof i's last reduction and host assembly; every proof is produced inside the timed region
-    def run(k):
+    def run(k, depth=tickets):
         last = None
-        ctx.groth16_prove_begin(*args_, 0)
-        for i in range(1, k):
-            ctx.groth16_prove_begin(*args_, i & 1)
-            last = ctx.groth16_prove_end((i - 1) & 1)
-        return ctx.groth16_prove_end((k - 1) & 1)
+        for i in range(k):
+            ctx.groth16_prove_begin(*args_, i % depth)
+            if i >= depth - 1:
+                last = ctx.groth16_prove_end((i - depth + 1) % depth)
+        for i in range(max(k - depth + 1, 0), k):
+            last = ctx.groth16_prove_end(i % depth)
+        return last
     run(2)
     torch.cuda.synchronize()
     k_pipe = max(2 * steps, 4)

@@ -116,9 +116,13 @@ class Prover:
 
     params: dict with "h", "l", "a", "b_g1" (G1 rows x|y), "b_g2" (G2 rows), optional "<name>_inf" flag arrays,
     "vk_g1" = rows alpha_g1, beta_g1, delta_g1 and "vk_g2" = rows beta_g2, delta_g2 (affine), optional
-    "delta_g1_inf"/"delta_g2_inf"."""
+    "delta_g1_inf"/"delta_g2_inf".
 
-    def __init__(self, params: dict, m: int, l: int, m_l_1: int, ctx: Context | None = None):
+    window_tables=True additionally stores every vector's window multiples (kg_bases_precompute: ceil(255 / 17) = 15 x the
+    CRS in device memory, built once): the five MSMs of a proof then use one bucket set each.  Offered for circuits whose
+    witness and h vectors hold 2^16 .. 2^20 entries; other sizes keep the plain resident form."""
+
+    def __init__(self, params: dict, m: int, l: int, m_l_1: int, ctx: Context | None = None, window_tables: bool = False):
         self.ctx = ctx or default_context()
         self.m, self.l, self.m_l_1 = m, l, m_l_1
         self._keep = []
@@ -148,6 +152,13 @@ class Prover:
         crs.delta_g1_inf = int(bool(params.get("delta_g1_inf", 0)))
         crs.delta_g2_inf = int(bool(params.get("delta_g2_inf", 0)))
         self.crs = crs
+        self.window_tables = False
+        nz, hn = l + m_l_1, m - 1
+        if window_tables and all((1 << 16) <= v <= (1 << 20) for v in (nz, hn)) and len(params["h"]) == hn:
+            for name in ("a", "b_g1", "b_g2", "l"):
+                self.ctx.bases_precompute(getattr(crs, "d_" + name), nz)      # l meets the whole witness vector z = x || w
+            self.ctx.bases_precompute(crs.d_h, hn)
+            self.window_tables = True
 
     def __del__(self):
         for p_ in getattr(self, "_registered", []):

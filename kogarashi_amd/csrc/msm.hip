@@ -891,6 +891,76 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restric
   }
   if (threadIdx.x < LEN_BINS && h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
 }
+// The same for long rows (B >= 8192: the c = 15..17 windows, and the single 2^16-bucket row of a merged sort), cut into
+// `nsplit` parts of B / nsplit buckets with a workgroup each: k_bucket_part sums a part (entries, tasks, largest bucket,
+// length histogram), k_bucket_fill adds the parts in front of its own and writes starts / task counts / task prefixes.
+// One workgroup per row took 80 us for 65536 buckets; sixteen parts take two launches of ~10 us.
+__global__ void __launch_bounds__(BR_NT) k_bucket_part(const uint32_t* __restrict__ bsize, int B, uint32_t T, int nsplit, uint32_t* __restrict__ part,
+                                                      uint32_t* __restrict__ maxv, uint32_t* __restrict__ ghist) {
+  KG_SERVICE_PRIO();
+  __shared__ uint32_t sh[40], h[LEN_BINS], red[16];
+  const int w = blockIdx.x, k = blockIdx.y, len = B / nsplit;
+  if (threadIdx.x < LEN_BINS) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int per = len / BR_NT;                           // len is a multiple of 4 * BR_NT (B >= 8192, nsplit <= B / 4096)
+  const uint32_t* src = bsize + (size_t)w * B + (size_t)k * len + (size_t)threadIdx.x * per;
+  uint32_t ssum = 0, tsum = 0, mx = 0, full = 0;
+  auto tally = [&](uint32_t v) {
+    if (v) {
+      const uint32_t nt = (v + T - 1) / T;
+      ssum += v; tsum += nt; mx = v > mx ? v : mx;
+      atomicAdd(&h[len_key(v - (nt - 1) * T)], 1u);
+      full += nt - 1;
+    }
+  };
+  for (int b = 0; b < per; b += 4) { const uint4 q = *reinterpret_cast<const uint4*>(src + b); tally(q.x); tally(q.y); tally(q.z); tally(q.w); }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { full += __shfl_xor(full, d); const uint32_t o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+  if ((threadIdx.x & 63) == 0) { if (full) atomicAdd(&h[len_key(T)], full); red[threadIdx.x >> 6] = mx; }
+  uint32_t total_s, total_t;
+  block_exclusive_scan_1024(ssum, sh, total_s);
+  block_exclusive_scan_1024(tsum, sh, total_t);
+  if (threadIdx.x == 0) {
+    uint32_t m = 0;
+    for (int i = 0; i < BR_NT / 64; ++i) m = red[i] > m ? red[i] : m;
+    if (m) atomicMax(maxv, m);
+    part[((size_t)w * nsplit + k) * 2] = total_s;
+    part[((size_t)w * nsplit + k) * 2 + 1] = total_t;
+  }
+  if (threadIdx.x < LEN_BINS && h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(BR_NT) k_bucket_fill(const uint32_t* __restrict__ bsize, int B, uint32_t T, int nsplit, const uint32_t* __restrict__ part,
+                                                      uint32_t* __restrict__ bstart, uint32_t* __restrict__ ntask, uint32_t* __restrict__ rel,
+                                                      uint32_t* __restrict__ row_total) {
+  KG_SERVICE_PRIO();
+  __shared__ uint32_t sh[40];
+  const int w = blockIdx.x, k = blockIdx.y, len = B / nsplit;
+  uint32_t base_s = 0, base_t = 0;
+  for (int j = 0; j < k; ++j) { base_s += part[((size_t)w * nsplit + j) * 2]; base_t += part[((size_t)w * nsplit + j) * 2 + 1]; }
+  const int per = len / BR_NT;
+  const size_t off = (size_t)w * B + (size_t)k * len + (size_t)threadIdx.x * per;
+  const uint32_t* src = bsize + off;
+  uint32_t ssum = 0, tsum = 0;
+  for (int b = 0; b < per; b += 4) {
+    const uint4 q = *reinterpret_cast<const uint4*>(src + b);
+    ssum += q.x + q.y + q.z + q.w;
+    tsum += (q.x + T - 1) / T + (q.y + T - 1) / T + (q.z + T - 1) / T + (q.w + T - 1) / T;
+  }
+  uint32_t total_s, total_t;
+  uint32_t run_s = base_s + block_exclusive_scan_1024(ssum, sh, total_s);
+  uint32_t run_t = base_t + block_exclusive_scan_1024(tsum, sh, total_t);
+  for (int b = 0; b < per; b += 4) {
+    const uint4 q = *reinterpret_cast<const uint4*>(src + b);
+    uint4 st, nt, rl;
+    nt.x = (q.x + T - 1) / T; nt.y = (q.y + T - 1) / T; nt.z = (q.z + T - 1) / T; nt.w = (q.w + T - 1) / T;
+    st.x = run_s; st.y = st.x + q.x; st.z = st.y + q.y; st.w = st.z + q.z; run_s = st.w + q.w;
+    rl.x = run_t; rl.y = rl.x + nt.x; rl.z = rl.y + nt.y; rl.w = rl.z + nt.z; run_t = rl.w + nt.w;
+    *reinterpret_cast<uint4*>(bstart + off + b) = st;
+    *reinterpret_cast<uint4*>(ntask + off + b) = nt;
+    *reinterpret_cast<uint4*>(rel + off + b) = rl;
+  }
+  if (k == nsplit - 1 && threadIdx.x == 0) row_total[w] = base_t + total_t;
+}
 // k_row_bases + k_len_scan in one launch (one wave): window task bases and the descending-length cursors
 __global__ void __launch_bounds__(64) k_task_bases(const uint32_t* __restrict__ row_total, int W, uint32_t* __restrict__ base,
                                                    const uint32_t* __restrict__ maxv, uint32_t* __restrict__ info,
@@ -1013,6 +1083,40 @@ __global__ void __launch_bounds__(256) k_gather_buckets(const uint32_t* __restri
   XYZZ<F> p = XYZZ<F>::identity();
   if (L.cnt[t]) p = PointAoS<F>::load(pin, (size_t)L.base[w] + L.rel[t]);
   PointIO<F>::store(buckets, total, t, p);
+}
+
+// Buckets cut into a few tasks (every bucket of a merged sort: W n / B entries in tasks of T): the dense bucket array straight
+// from the partial sums, a lane (lane pair for G2) per bucket adding its <= GATHER_SUM_MAX partial sums -- instead of a
+// partial-sum round (task count, row scan, bases, k_sum_tasks) followed by the gather: six launches and ~130 us less on the
+// reduction queue per MSM.  KF = F, or the lane-pair form of Fq2 reading the one-lane layout k_acc_tasks<Fq2> wrote.
+constexpr uint32_t GATHER_SUM_MAX = 32;
+template <class F, class KF> struct PartialIO {
+  static __device__ __forceinline__ XYZZ<KF> load(const uint32_t* base, size_t i) { return PointAoS<F>::load(base, i); }
+};
+template <class G> struct PartialIO<Fp2<G>, Fp2S<G>> {      // PointAoS<Fp2<G>>: x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1, nine words each
+  static __device__ __forceinline__ XYZZ<Fp2S<G>> load(const uint32_t* base, size_t i) {
+    const uint32_t* src = base + i * 72 + 9 * Fp2S<G>::half();
+    XYZZ<Fp2S<G>> p;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { p.x.v.l[k] = src[k]; p.y.v.l[k] = src[18 + k]; p.zz.v.l[k] = src[36 + k]; p.zzz.v.l[k] = src[54 + k]; }
+    return p;
+  }
+};
+template <class F, class KF>
+__global__ void __launch_bounds__(64) k_gather_sum(const uint32_t* __restrict__ pin, Level L, int W, int B, uint32_t* __restrict__ buckets) {
+  KG_SERVICE_PRIO();
+  const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<KF>::N;
+  const size_t total = (size_t)W * B;
+  if (t >= total) return;
+  const int w = (int)(t / B);
+  const uint32_t cnt = L.cnt[t];
+  XYZZ<KF> p = XYZZ<KF>::identity();
+  if (cnt) {
+    const size_t first = (size_t)L.base[w] + L.rel[t];
+    p = PartialIO<F, KF>::load(pin, first);
+    for (uint32_t j = 1; j < cnt; ++j) p = add_xyzz(p, PartialIO<F, KF>::load(pin, first + j));
+  }
+  PointIO<KF>::store(buckets, total, t, p);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1283,6 +1387,7 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   const size_t o_tbkt = cv.take(part_cap * 4), o_tid = cv.take(part_cap * 4);
   const size_t o_woff = cv.take(merged ? (size_t)W * G * 4 : 0), o_gsize_m = cv.take(merged ? (size_t)G * 4 : 0), o_gstart_m = cv.take(merged ? (size_t)G * 4 : 0);
   const size_t o_segbase_m = cv.take(merged ? (size_t)(G + 1) * 4 : 0);
+  const size_t o_bpart = cv.take((size_t)W * 32 * 2 * 4);           // k_bucket_part: (entries, tasks) of each part of each row
   // The scalar side runs on a queue of its own and alternates between two spaces: while MSM i accumulates (main queue,
   // reading set i & 1), MSM i+1 is sorted into the other set.  Ordering: the scalar queue waits for `after` (the producer
   // of d_scalars), or -- stream semantics -- for everything enqueued on the main queue so far, unless the context's inputs
@@ -1367,7 +1472,13 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
     // task decomposition (needs only the bucket sizes); its two result words travel to the host while the
     // scatter below still runs, so the read-back does not stall the queue
     const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
-    hipLaunchKernelGGL(k_bucket_rows, dim3(Wb), dim3(BR_NT), 0, st, S->bsize, B, T, S->bstart, S->lcnt, S->lrel, rowtot, misc, lenh);
+    if (B >= 8192) {
+      const int nsplit = B / 4096;                    // <= 16 parts per row
+      uint32_t* bpart = (uint32_t*)(ws + o_bpart);
+      hipLaunchKernelGGL(k_bucket_part, dim3(Wb, nsplit), dim3(BR_NT), 0, st, S->bsize, B, T, nsplit, bpart, misc, lenh);
+      hipLaunchKernelGGL(k_bucket_fill, dim3(Wb, nsplit), dim3(BR_NT), 0, st, S->bsize, B, T, nsplit, bpart, S->bstart, S->lcnt, S->lrel, rowtot);
+    } else
+      hipLaunchKernelGGL(k_bucket_rows, dim3(Wb), dim3(BR_NT), 0, st, S->bsize, B, T, S->bstart, S->lcnt, S->lrel, rowtot, misc, lenh);
     hipLaunchKernelGGL(k_task_bases, dim3(1), dim3(64), 0, st, rowtot, Wb, S->lbase, misc, misc + 4, lenh, lenh + LEN_BINS);
     uint32_t* h_info = (uint32_t*)ctx->h_pinned;
     KG_HIP(ctx, hipMemcpyAsync(h_info, misc + 4, 8, hipMemcpyDeviceToHost, st));
@@ -1511,7 +1622,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       uint32_t max_cnt = S.max_cnt;
       int lv = -1;                                     // -1: level arrays of S; 0/1: local ping-pong
       const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
-      while (max_cnt > 1) {
+      while (max_cnt > GATHER_SUM_MAX) {               // (at most GATHER_SUM_MAX partial sums per bucket are left to the gather below)
         const int nx = lv < 0 ? 0 : (lv ^ 1);
         uint32_t* ncnt = (uint32_t*)(ws + o_lc[nx]);
         uint32_t* nrel = (uint32_t*)(ws + o_lr[nx]);
@@ -1530,11 +1641,12 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
         max_cnt = (max_cnt + S.T2 - 1) / S.T2;
       }
       ph.end();
-    }
-    {
-      PhaseScope ph(ctx, "gather", side);
-      hipLaunchKernelGGL(k_gather_buckets<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, side, part[pcur], part_cap, L, W, B, pbuf[0]);
-      ph.end();
+      PhaseScope pg(ctx, "gather", side);
+      if (max_cnt > 1)
+        hipLaunchKernelGGL((k_gather_sum<F, KF>), dim3((unsigned)((npts * LPT + 63) / 64)), dim3(64), 0, side, part[pcur], L, W, B, pbuf[0]);
+      else
+        hipLaunchKernelGGL(k_gather_buckets<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, side, part[pcur], part_cap, L, W, B, pbuf[0]);
+      pg.end();
     }
     if (ctx->ws_idle_n[S.set] < kg_ctx::IDLE_EVS) {      // the gather is the last reader of the scalar-side set (level tables of S)
       KG_HIP(ctx, hipEventRecord(ctx->ev_ws_idle[S.set][ctx->ws_idle_n[S.set]], side));

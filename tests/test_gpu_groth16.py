@@ -319,3 +319,4 @@ def test_fixed_base_mul_windowed(ctx, oracle, curve, sfd, w, n):
     assert (dxy.numpy() == want_xy).all()
     ctx.fixed_base_mul(curve, dk.ptr, n, dxy.ptr, dinf.ptr)          # second call: cached table
     assert (dxy.numpy() == want_xy).all()
+

@@ -177,6 +177,14 @@ def test_groth16_2_18_matches_oracle(ctx, oracle):
     for g, w_, name in zip(got[:3], want[:3], "ABC"):
         assert (g == w_).all(), name
     assert (got[3] == want[3]).all() and not got[3].any()
-    jobs = [(cc.a_eval, cc.b_eval, cc.c_eval, cc.x, cc.w, r, s)] * 3
+    jobs = [(cc.a_eval, cc.b_eval, cc.c_eval, cc.x, cc.w, r, s)] * 5
     for pr in prover.create_proofs(jobs):
+        assert all((pr[i] == got[i]).all() for i in range(4))
+    # the same CRS with window tables (kg_bases_precompute on all five vectors): merged bucket sets, identical proofs
+    del prover
+    tabled = K.Prover(P, m, cc.l, cc.m_l_1, ctx=ctx, window_tables=True)
+    assert tabled.window_tables
+    pr = tabled.create_proof(cc.a_eval, cc.b_eval, cc.c_eval, cc.x, cc.w, r, s)
+    assert all((pr[i] == got[i]).all() for i in range(4))
+    for pr in tabled.create_proofs(jobs):
         assert all((pr[i] == got[i]).all() for i in range(4))
