@@ -64,6 +64,19 @@ impl ResidentCrs {
         let (d_a, d_a_inf) = upload(ctx, a, &mut bufs)?;
         let (d_b_g1, d_b_g1_inf) = upload(ctx, b_g1, &mut bufs)?;
         let (d_b_g2, d_b_g2_inf) = upload(ctx, b_g2, &mut bufs)?;
+        // Window tables (kg_bases_precompute: 2^(17 w) * P for every window, 15 x the CRS in device memory, built once): each of
+        // the proof's five MSMs then uses one bucket set.  Offered for 2^16 .. 2^20 scalars; KOGARASHI_AMD_NO_TABLES=1 keeps the
+        // plain resident form.  l meets the whole witness vector z = x || w, h its own m - 1 coefficients.
+        let nz = n_inputs + n_aux;
+        let in_range = |v: usize| (1usize << 16..=1usize << 20).contains(&v);
+        if std::env::var_os("KOGARASHI_AMD_NO_TABLES").is_none() && in_range(nz) && in_range(h.len()) && h.len() + 1 == m {
+            for (p, len) in [(d_a, nz), (d_b_g1, nz), (d_b_g2, nz), (d_l, nz), (d_h, h.len())] {
+                let rc = unsafe { sys::kg_bases_precompute(ctx.raw(), p, len) };
+                if rc != sys::KG_OK {
+                    return Err(Status(rc));
+                }
+            }
+        }
         let crs = sys::KgGroth16Crs {
             m, l: n_inputs, m_l_1: n_aux, d_h, d_h_inf, d_l, d_l_inf, d_a, d_a_inf, d_b_g1, d_b_g1_inf, d_b_g2, d_b_g2_inf,
             alpha_g1: words8(alpha_g1), beta_g1: words8(beta_g1), delta_g1: words8(delta_g1),
