@@ -235,7 +235,10 @@ int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, ui
 // at all when the context's inputs are declared complete (kg_ctx_set_inputs_complete)
 // merged_c: 0, or the window width of the bases' tables (merged_window(n)): sort all windows into one set of buckets;
 // lane_mult: how many accumulation lanes each task of this sort will occupy (fused arrays, G2's lane pairs) -- sizes the tasks
-int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered = false, int merged_c = 0, int lane_mult = 1);
+// wait_info = false: return once the sort is enqueued; msm_sort_wait(ctx, S) must follow before S is used (and before another sort)
+int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered = false, int merged_c = 0, int lane_mult = 1,
+             bool wait_info = true);
+int msm_sort_wait(kg_ctx* ctx, MsmSorted* S);
 int merged_window(const kg_ctx* ctx, size_t n);       // window width of the merged form for an n-scalar MSM, 0 = not offered at this length
 // does this registered array carry a window table that serves an n-scalar merged MSM?  (d_inf must be the registered flag array)
 bool has_window_table(const kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, size_t msm_len);

@@ -342,9 +342,13 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   uint64_t* Z = C + 4 * n;                                // z = x || w
   uint64_t* TMP = Z + 4 * (l + m_l_1);                    // 3 n elements of transform scratch
   // Queue layout.  The four MSMs against z = x || w need nothing from the transforms, and the transforms are short,
-  // latency-bound launches (2^18 points = 128..512 workgroups): the three idft -> coset_dft chains (prover.rs:36-41)
-  // run on three side queues UNDER the witness MSMs of the main queue, and h's MSM -- the only consumer of the
-  // transforms -- goes last.
+  // latency-bound launches (2^18 points = 128..512 workgroups): the witness sort goes out first (it gates the accumulations),
+  // the three idft -> coset_dft chains (prover.rs:36-41) run on three side queues beside it and in front of the witness MSMs
+  // of the main queue, and h's MSM -- the only consumer of the transforms -- goes last.
+  // (Measured and dropped: h's point-wise step and coset_idft IN FRONT of the accumulations with h's sort beside the G1
+  // accumulations, so that h's accumulation follows them at once -- the gap in front of h's accumulation closes (0.54 ->
+  // 0.03 ms), but the reductions of a, b_g1 and l, which used that gap (they do not fit beside an accumulation), then queue up
+  // behind h's: 3.28 -> 3.40 ms blocking, 2.97 -> 3.17 ms with two proofs in flight.)
   if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
   if (!ctx->aux_stream) KG_HIP(ctx, create_stream(ctx, &ctx->aux_stream, true));
   if (!ctx->aux2_stream) KG_HIP(ctx, create_stream(ctx, &ctx->aux2_stream, true));
@@ -354,56 +358,60 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   }
   KG_TRY(ntt_prepare(ctx, k, 0));
   KG_TRY(ntt_prepare(ctx, k, 1));
-  const uint64_t* src[3] = {d_a_eval, d_b_eval, d_c_eval};
-  uint64_t* dst[3] = {A, B, C};
-  hipStream_t lanes[3] = {ctx->aux_stream, ctx->aux2_stream, ctx->side_stream};
-  // stream semantics: the inputs may still be in flight on the main queue (and the twiddle tables are built there on first
-  // use); with complete inputs the chains start at once -- this ticket's buffers are free since its previous proof was collected
-  const bool fork = !ctx->inputs_complete || ctx->tw_fresh;
-  ctx->tw_fresh = false;
-  if (fork) KG_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
-  for (int v = 0; v < 3; ++v) {                         // prepare_fft zero padding, then idft + coset_dft
-    hipStream_t sv = lanes[v];
-    uint64_t* tmp = TMP + (size_t)v * 4 * n;
-    if (fork) KG_HIP(ctx, hipStreamWaitEvent(sv, ctx->ev_fork, 0));
-    KG_HIP(ctx, hipMemcpyAsync(dst[v], src[v], m * 32, hipMemcpyDeviceToDevice, sv));
-    if (n > m) KG_HIP(ctx, hipMemsetAsync(dst[v] + 4 * m, 0, (n - m) * 32, sv));
-    KG_TRY(ntt_enqueue(ctx, sv, tmp, dst[v], k, 1, 0));
-    KG_TRY(ntt_enqueue(ctx, sv, tmp, dst[v], k, 0, 1));
-    KG_HIP(ctx, hipEventRecord(ctx->ev_join[v], sv));
-  }
-
-  // The eight MSMs of prover.rs:51-65 as five: a_inputs + a_aux (:58-59,80) is one MSM of a[..] against
-  // z = x || w, likewise b_g1 (:61-62,85) and b_g2 (:64-65,86) -- the sums are what the proof uses.  The four MSMs
-  // that meet the witness share ONE scalar-side sort (l's bases start l entries into z).  q keeps its trailing
-  // zeros: zero scalars are skipped by the MSM, which is what Coefficients::new's trimming plus zip achieves in
-  // the reference (poly.rs:61-63, msm.rs:25).  Each MSM's 255-step host finish runs on a worker thread while the
-  // device continues with the next one.
   const size_t hn = (m - 1) < n ? (m - 1) : n;
   const size_t nz = l + m_l_1;
   hipStream_t sq;                                         // z is assembled on the scalar queue (its only reader is the sort)
   KG_TRY(scalar_queue(ctx, &sq));
-  if (!ctx->inputs_complete) {                            // stream semantics: d_x / d_w may still be in flight on the main queue
-    KG_HIP(ctx, hipEventRecord(ctx->ev_order, st));
-    KG_HIP(ctx, hipStreamWaitEvent(sq, ctx->ev_order, 0));
+  // stream semantics: the inputs may still be in flight on the main queue (and the twiddle tables are built there on first
+  // use); with complete inputs everything starts at once -- this ticket's buffers are free since its previous proof was collected
+  const bool fork = !ctx->inputs_complete || ctx->tw_fresh;
+  ctx->tw_fresh = false;
+  if (fork) {
+    KG_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+    KG_HIP(ctx, hipStreamWaitEvent(sq, ctx->ev_fork, 0));
   }
+  // The eight MSMs of prover.rs:51-65 as five: a_inputs + a_aux (:58-59,80) is one MSM of a[..] against
+  // z = x || w, likewise b_g1 (:61-62,85) and b_g2 (:64-65,86) -- the sums are what the proof uses.  The four MSMs
+  // that meet the witness share ONE scalar-side sort (l's bases start l entries into z); it is enqueued before the
+  // transform chains and its two result words are awaited after them.
   KG_HIP(ctx, hipMemcpyAsync(Z, d_x, l * 32, hipMemcpyDeviceToDevice, sq));
   if (m_l_1) KG_HIP(ctx, hipMemcpyAsync(Z + 4 * l, d_w, m_l_1 * 32, hipMemcpyDeviceToDevice, sq));
+  MsmSorted Sz;
+  // window tables on all four vectors that meet z (kg_bases_precompute): one merged sort, one set of buckets for all windows
+  const bool tz = has_window_table(ctx, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, nz) && has_window_table(ctx, KG_G1, crs->d_a, crs->d_a_inf, nz, nz) &&
+                  has_window_table(ctx, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, nz, nz) && (!m_l_1 || has_window_table(ctx, KG_G1, crs->d_l, crs->d_l_inf, m_l_1, nz));
+  KG_TRY(msm_sort(ctx, KG_FR, Z, nz, &Sz, true, tz ? merged_window(ctx, nz) : 0, 2, false));
+  int rc = KG_OK;
+  auto hip_rc = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == KG_OK) rc = set_err(ctx, e == hipErrorOutOfMemory ? KG_ERR_OOM : KG_ERR_HIP, what, e);
+  };
+  const uint64_t* src[3] = {d_a_eval, d_b_eval, d_c_eval};
+  uint64_t* dst[3] = {A, B, C};
+  hipStream_t lanes[3] = {ctx->aux_stream, ctx->aux2_stream, ctx->side_stream};
+  for (int v = 0; v < 3 && rc == KG_OK; ++v) {            // prepare_fft zero padding, then idft + coset_dft
+    hipStream_t sv = lanes[v];
+    uint64_t* tmp = TMP + (size_t)v * 4 * n;
+    if (fork) hip_rc(hipStreamWaitEvent(sv, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
+    hip_rc(hipMemcpyAsync(dst[v], src[v], m * 32, hipMemcpyDeviceToDevice, sv), "hipMemcpyAsync(evaluations)");
+    if (n > m) hip_rc(hipMemsetAsync(dst[v] + 4 * m, 0, (n - m) * 32, sv), "hipMemsetAsync(padding)");
+    if (rc == KG_OK) rc = ntt_enqueue(ctx, sv, tmp, dst[v], k, 1, 0);
+    if (rc == KG_OK) rc = ntt_enqueue(ctx, sv, tmp, dst[v], k, 0, 1);
+    hip_rc(hipEventRecord(ctx->ev_join[v], sv), "hipEventRecord(join)");
+  }
+  // q keeps its trailing zeros: zero scalars are skipped by the MSM, which is what Coefficients::new's trimming plus zip
+  // achieves in the reference (poly.rs:61-63, msm.rs:25).  Each MSM's 255-step host finish runs on a worker thread while the
+  // device continues with the next one.
   uint64_t *q_p = job->q_p, *l_p = job->l_p, *ai = job->ai, *b1i = job->b1i, *b2i = job->b2i;
   std::future<int>&f_q = job->f_q, &f_l = job->f_l, &f_a = job->f_a, &f_b1 = job->f_b1, &f_b2 = job->f_b2;
   auto finish_async = [&](int curve, int slot, uint64_t* out) {
     return std::async(std::launch::async, [ctx, curve, slot, out] { return msm_finish(ctx, curve, slot, out); });
   };
-  int rc = KG_OK;
   // result slots: consecutive MSMs alternate between the two reduction queues (slot parity), each with run space of
   // its own (slot mod 8); measured against giving G2's long reduction a queue of its own: 3.67 vs 3.84 ms per proof
   const int SL[5] = {slot_base + 1, slot_base + 2, slot_base + 3, slot_base + 4, slot_base + 5};
   {
-    MsmSorted Sz;
-    // window tables on all four vectors that meet z (kg_bases_precompute): one merged sort, one set of buckets for all windows
-    const bool tz = has_window_table(ctx, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, nz) && has_window_table(ctx, KG_G1, crs->d_a, crs->d_a_inf, nz, nz) &&
-                    has_window_table(ctx, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, nz, nz) && (!m_l_1 || has_window_table(ctx, KG_G1, crs->d_l, crs->d_l_inf, m_l_1, nz));
-    rc = msm_sort(ctx, KG_FR, Z, nz, &Sz, true, tz ? merged_window(ctx, nz) : 0, 2);
+    const int rw = msm_sort_wait(ctx, &Sz);                // always: the next sort may not start before this read-back
+    if (rc == KG_OK) rc = rw;
     // G2 first: its host finish (Fq2 arithmetic, ~3x a G1 finish) and its slow reduction then overlap the G1 accumulations
     if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, 0, SL[0]);
     if (rc == KG_OK) f_b2 = finish_async(KG_G2, SL[0], b2i);
@@ -421,27 +429,25 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   }
   // From here on host finishes may already be running on worker threads: no early return -- every failure travels
   // through rc into the assembly task below, which joins all of them before it reports.
-  auto hip_rc = [&](hipError_t e, const char* what) {
-    if (e != hipSuccess && rc == KG_OK) rc = set_err(ctx, e == hipErrorOutOfMemory ? KG_ERR_OOM : KG_ERR_HIP, what, e);
-  };
-  // h = (a o b - c) / Z on the coset, back to coefficients (prover.rs:43-47), then its MSM.  (Measured and dropped, again:
+  // h = (a o b - c) / Z on the coset, back to coefficients (prover.rs:43-47), then its MSM.  (Measured and dropped as well:
   // this chain on a service queue under the witness accumulations -- the transform's 512-thread, 74 KiB workgroups only
   // get onto a CU once an accumulation has drained, and then queue behind the reductions: 3.3 -> 3.85 ms per proof.)
   for (int v = 0; v < 3; ++v) hip_rc(hipStreamWaitEvent(st, ctx->ev_join[v], 0), "hipStreamWaitEvent(join)");
-  // (7^n - 1)^-1 on the host: n = 2^k squarings of 7
-  HostFr seven = HostFr::one();
   {
-    HostFr one = HostFr::one(), acc = HostFr::zero();
-    for (int i = 0; i < 7; ++i) acc = add(acc, one);
-    seven = acc;
+    HostFr seven = HostFr::one();                         // (7^n - 1)^-1 on the host: n = 2^k squarings of 7
+    {
+      HostFr one = HostFr::one(), acc = HostFr::zero();
+      for (int i = 0; i < 7; ++i) acc = add(acc, one);
+      seven = acc;
+    }
+    HostFr z = seven;
+    for (uint32_t i = 0; i < k; ++i) z = sqr(z);
+    z = inv(sub<4, 1>(z, HostFr::one()));                 // z_on_coset().invert() (fft.rs:141-151)
+    Words8 zw;
+    for (int i = 0; i < 4; ++i) { zw.w[2 * i] = (uint32_t)z.v[i]; zw.w[2 * i + 1] = (uint32_t)(z.v[i] >> 32); }
+    hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, C, n, zw);
+    hip_rc(hipGetLastError(), "k_qap_combine launch");
   }
-  HostFr z = seven;
-  for (uint32_t i = 0; i < k; ++i) z = sqr(z);
-  z = inv(sub<4, 1>(z, HostFr::one()));                 // z_on_coset().invert() (fft.rs:141-151)
-  Words8 zw;
-  for (int i = 0; i < 4; ++i) { zw.w[2 * i] = (uint32_t)z.v[i]; zw.w[2 * i + 1] = (uint32_t)(z.v[i] >> 32); }
-  hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, C, n, zw);
-  hip_rc(hipGetLastError(), "k_qap_combine launch");
   if (rc == KG_OK) rc = ntt_enqueue(ctx, st, TMP, A, k, 1, 1);                      // coset_idft (prover.rs:47)
   if (rc == KG_OK && hn) {
     MsmSorted Sq;

@@ -1335,7 +1335,7 @@ int merged_window(const kg_ctx* ctx, size_t n) {
   return c;
 }
 
-int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered, int merged_c, int lane_mult) {
+int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered, int merged_c, int lane_mult, bool wait_info) {
   if (n == 0 || n >= ((size_t)1 << 31)) return set_err(ctx, KG_ERR_BAD_ARG, "msm length must be in [1, 2^31)");
   host_trace("sort: enter");
   KG_HIP(ctx, hipSetDevice(ctx->device));
@@ -1493,12 +1493,19 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
     KG_HIP(ctx, hipGetLastError());
     KG_HIP(ctx, hipEventRecord(S->ready, st));
     host_trace("sort: enqueued");
-    KG_HIP(ctx, hipEventSynchronize(ctx->ev_info));
-    host_trace("sort: info back");
-    S->ntasks = h_info[0];
-    S->max_cnt = (h_info[1] + T - 1) / T;              // most tasks any bucket has
-    if (S->ntasks > part_cap) return set_err(ctx, KG_ERR_HIP, "task count exceeds its bound");
   }
+  return wait_info ? msm_sort_wait(ctx, S) : KG_OK;
+}
+
+// The task count and the largest bucket of the sort enqueued last (two words read back through pinned memory): the caller
+// may put other work on the queues between msm_sort(..., wait_info = false) and this, but no other sort.
+int msm_sort_wait(kg_ctx* ctx, MsmSorted* S) {
+  KG_HIP(ctx, hipEventSynchronize(ctx->ev_info));
+  host_trace("sort: info back");
+  const uint32_t* h_info = (const uint32_t*)ctx->h_pinned;
+  S->ntasks = h_info[0];
+  S->max_cnt = (h_info[1] + S->T - 1) / S->T;          // most tasks any bucket has
+  if (S->ntasks > S->part_cap) return set_err(ctx, KG_ERR_HIP, "task count exceeds its bound");
   return KG_OK;
 }
 

@@ -11,6 +11,7 @@ if os.environ.get("KG_ORDERED") != "1":
     ctx.set_inputs_complete(True)
 pipelined = len(sys.argv) > 2
 calls = [0]
+nth = int(os.environ.get("KG_TL_CALL", "3"))     # blocking mode: which call to record (3: plain CRS; 8: with window tables)
 if pipelined:
     orig = ctx.groth16_prove_begin
     def wrapped(*a, **k):
@@ -26,10 +27,10 @@ else:
     orig = ctx.groth16_prove
     def wrapped(*a, **k):
         calls[0] += 1
-        if calls[0] == 3:
+        if calls[0] == nth:
             ctx.profile_enable(True)
         out = orig(*a, **k)
-        if calls[0] == 3:
+        if calls[0] == nth:
             ctx.profile_summary(); ctx.profile_enable(False)
         return out
     ctx.groth16_prove = wrapped
