@@ -15,6 +15,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The library's queues (main, scalar, two reduction queues) want a hardware queue each; the runtime reads this when HIP
+# initialises, which torch does before the library is loaded (csrc/capi.cpp sets the same default for hosts that load it first).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 SEED = 0x4B6F676172617368
 LOG_N = 20

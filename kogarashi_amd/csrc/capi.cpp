@@ -1,5 +1,8 @@
 // capi.cpp -- context management and memory plumbing of the C ABI (include/kogarashi_amd.h).
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
+#include <string>
 
 using namespace kg;
 
@@ -9,7 +12,7 @@ namespace kg {
 void sync_all(kg_ctx* c) {
   hipStreamSynchronize(c->stream);
   if (c->own_stream && c->own_stream != c->stream) hipStreamSynchronize(c->own_stream);
-  for (hipStream_t s : {c->sort_stream, c->side_stream, c->side2_stream, c->aux_stream, c->aux2_stream, c->up_stream})
+  for (hipStream_t s : {c->sort_stream, c->side_stream, c->side2_stream, c->up_stream})
     if (s) hipStreamSynchronize(s);
 }
 int ensure_ws_sort(kg_ctx* c, int set, size_t bytes) {
@@ -21,6 +24,16 @@ int ensure_ws_sort(kg_ctx* c, int set, size_t bytes) {
   c->ws_sort_bytes[set] = want;
   return KG_OK;
 }
+// The context's queues (main, scalar, two reduction queues, an upload queue for kg_msm_host) should each own a hardware queue:
+// the runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with whatever else the process
+// creates), and two streams on one hardware queue run in submission order -- measured on the prover: 2.83 ms per proof with a
+// queue each against 3.28 ms at the default.  The variable is read when the HIP runtime initialises, so it is set (unless
+// the user has) when this library is loaded; a host that initialises HIP earlier exports it itself (bench.py does).
+namespace {
+struct HwQueueDefault {
+  HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+} hw_queue_default;
+}  // namespace
 // Queues of the context.  (CU-masked queues -- hipExtStreamCreateWithCUMask, a compute / service partition -- and queue
 // priorities were measured and dropped: tools/ubench/cumask_probe.hip; what makes concurrent queues
 // work is the wave priority of the service kernels, KG_SERVICE_PRIO.)
@@ -184,8 +197,6 @@ void kg_ctx_destroy(kg_ctx* c) {
   for (int i = 0; i < kg_ctx::RUN_SETS; ++i) { if (c->ws_run[i]) hipFree(c->ws_run[i]); if (c->ev_acc[i]) hipEventDestroy(c->ev_acc[i]); }
   if (c->side_stream) hipStreamDestroy(c->side_stream);
   if (c->side2_stream) { hipStreamSynchronize(c->side2_stream); hipStreamDestroy(c->side2_stream); }
-  if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); }
-  if (c->aux2_stream) { hipStreamSynchronize(c->aux2_stream); hipStreamDestroy(c->aux2_stream); }
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   for (int i = 0; i < 3; ++i) if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
   if (c->ev_info) hipEventDestroy(c->ev_info);
@@ -220,7 +231,7 @@ int kg_ctx_sync(kg_ctx* c) {
   if (!c) return KG_ERR_BAD_ARG;
   KG_HIP(c, hipSetDevice(c->device));
   KG_HIP(c, hipStreamSynchronize(c->stream));
-  for (hipStream_t s : {c->sort_stream, c->side_stream, c->side2_stream, c->aux_stream, c->aux2_stream})
+  for (hipStream_t s : {c->sort_stream, c->side_stream, c->side2_stream})
     if (s) KG_HIP(c, hipStreamSynchronize(s));
   return KG_OK;
 }

@@ -43,7 +43,6 @@ struct kg_ctx {
   size_t ws_run_bytes[RUN_SETS] = {};
   hipStream_t side_stream = nullptr;     // bucket reduction of MSM i overlaps the accumulation of MSM i+1
   hipStream_t side2_stream = nullptr;    // second reduction queue (odd slots): a slow G2 reduction does not hold up the next MSM's
-  hipStream_t aux_stream = nullptr, aux2_stream = nullptr;   // queues for the prover's independent transform chains
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_acc[RUN_SETS] = {};
   hipEvent_t ev_info = nullptr;          // marks the task-count read-back of msm_sort

@@ -343,15 +343,13 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   uint64_t* TMP = Z + 4 * (l + m_l_1);                    // 3 n elements of transform scratch
   // Queue layout.  The four MSMs against z = x || w need nothing from the transforms, and the transforms are short,
   // latency-bound launches (2^18 points = 128..512 workgroups): the witness sort goes out first (it gates the accumulations),
-  // the three idft -> coset_dft chains (prover.rs:36-41) run on three side queues beside it and in front of the witness MSMs
+  // the three idft -> coset_dft chains (prover.rs:36-41) run on the two reduction queues beside it and in front of the witness MSMs
   // of the main queue, and h's MSM -- the only consumer of the transforms -- goes last.
   // (Measured and dropped: h's point-wise step and coset_idft IN FRONT of the accumulations with h's sort beside the G1
   // accumulations, so that h's accumulation follows them at once -- the gap in front of h's accumulation closes (0.54 ->
   // 0.03 ms), but the reductions of a, b_g1 and l, which used that gap (they do not fit beside an accumulation), then queue up
   // behind h's: 3.28 -> 3.40 ms blocking, 2.97 -> 3.17 ms with two proofs in flight.)
   if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
-  if (!ctx->aux_stream) KG_HIP(ctx, create_stream(ctx, &ctx->aux_stream, true));
-  if (!ctx->aux2_stream) KG_HIP(ctx, create_stream(ctx, &ctx->aux2_stream, true));
   if (!ctx->ev_fork) {
     KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
@@ -387,7 +385,9 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   };
   const uint64_t* src[3] = {d_a_eval, d_b_eval, d_c_eval};
   uint64_t* dst[3] = {A, B, C};
-  hipStream_t lanes[3] = {ctx->aux_stream, ctx->aux2_stream, ctx->side_stream};
+  // the chains share the two reduction queues (queues of their own: 3.31 ms per proof against 2.83 -- transforms and halving
+  // levels do not fit the chip together with an accumulation anyway, and in one queue they do not fight each other for it)
+  hipStream_t lanes[3] = {ctx->side_stream, ctx->side2_stream, ctx->side_stream};
   for (int v = 0; v < 3 && rc == KG_OK; ++v) {            // prepare_fft zero padding, then idft + coset_dft
     hipStream_t sv = lanes[v];
     uint64_t* tmp = TMP + (size_t)v * 4 * n;
