@@ -143,6 +143,9 @@ int kg_bases_unregister(kg_ctx* ctx, const uint64_t* d_bases);
  * length; the Groth16 vector l meets the witness z = x || w, so its msm_len is |z|); offered for 2^16 <= msm_len <= 2^20,
  * KG_ERR_BAD_ARG otherwise.  The reference has no counterpart (groth16/src/msm.rs re-reads affine bases per call). */
 int kg_bases_precompute(kg_ctx* ctx, const uint64_t* d_bases, size_t msm_len);
+/* Window width c of the tables kg_bases_precompute builds for MSMs of msm_len scalars, 0 where none are offered: a table holds
+ * ceil(255 / c) rows of the array (72 B per G1 / Grumpkin point, 144 B per G2 point).  Pure function: no device, no context. */
+int kg_msm_table_window(size_t msm_len);
 /* Tuning knob: window width c (0 = automatic). */
 int kg_msm_set_window(kg_ctx* ctx, int c);
 /* The automatic rule: window width c for n pairs (W = ceil(255 / c) signed windows of 2^(c-1) buckets; the reference's

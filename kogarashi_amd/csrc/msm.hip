@@ -1802,6 +1802,7 @@ int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf
 }
 
 int kg_msm_pick_window(size_t n) { return pick_window(n ? n : 1, 0); }
+int kg_msm_table_window(size_t msm_len) { return kg::merged_window(nullptr, msm_len); }
 
 int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t n) {
   if (!ctx || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;

@@ -46,3 +46,23 @@ def test_shard_range_matches_dist_and_covers():
             assert prev == n
     with pytest.raises(lib.KogarashiError):
         lib.shard_range(10, 3, 3)
+
+
+def test_table_window_rule():
+    """kg_msm_table_window: where kg_bases_precompute offers window tables, the window fits the merged sort -- the top digit
+    stays inside the 2^(c-1) shared buckets, the bucket groups fit the first sort pass (<= 1024) and
+    (window << ceil(log2 n)) | index fits the 24-bit index field of a sorted entry"""
+    from kogarashi_amd import build, lib
+    build.build()
+    tw = lib.msm_table_window
+    for n in [1, 100, (1 << 16) - 1, (1 << 20) + 1, 1 << 24]:
+        assert tw(n) == 0
+    for n in [1 << 16, (1 << 16) + 1, (1 << 17) - 1, 1 << 17, 200001, 1 << 18, (1 << 19) + 5, 1 << 20]:
+        c = tw(n)
+        assert c in (16, 17)
+        w = (255 + c - 1) // c
+        assert 254 - (w - 1) * c <= c - 1                     # unsigned top digit within the bucket range
+        assert (1 << (c - 1)) >> 7 <= 1024                    # bucket groups of the first pass
+        s = (n - 1).bit_length()
+        assert (w << s) <= (1 << 24), (n, c)
+    assert tw(1 << 18) == 17 and tw(1 << 16) == 16
