@@ -1791,9 +1791,65 @@ int sum_affine_impl(const uint64_t* pts, const uint8_t* inf, size_t count, uint6
 
 extern "C" {
 
+// Sum of the slices' results (projective (x, y, 1) / (0, 1, 0) each) -> the same form
+static int sum_slices(kg_ctx* ctx, int curve, const uint64_t (*part)[24], int K, uint64_t* out_xyz) {
+  const int E = curve == KG_G2 ? 8 : 4;
+  if (K == 1) { std::memcpy(out_xyz, part[0], (size_t)3 * E * 8); return KG_OK; }
+  uint64_t pts[kg_ctx::UP_SLICES * 16];
+  uint8_t pinf[kg_ctx::UP_SLICES];
+  for (int j = 0; j < K; ++j) {
+    bool z0 = true;
+    for (int k = 0; k < E; ++k) z0 = z0 && part[j][2 * E + k] == 0;
+    pinf[j] = z0 ? 1 : 0;
+    std::memcpy(pts + (size_t)j * 2 * E, part[j], (size_t)2 * E * 8);
+  }
+  uint64_t xy[16];
+  uint8_t inf = 0;
+  KG_TRY(kg_points_sum_affine(ctx, curve, pts, pinf, (size_t)K, xy, &inf));
+  kg::msm_identity(curve, out_xyz);                        // (0, 1, 0); y doubles as the field's one
+  if (!inf) {
+    for (int k = 0; k < E; ++k) out_xyz[2 * E + k] = out_xyz[E + k];
+    std::memcpy(out_xyz, xy, (size_t)2 * E * 8);
+  }
+  return KG_OK;
+}
+
+// A large blocking MSM as a pipeline over index slices: slice j+1 is sorted (scalar queue) while slice j accumulates, and
+// the slices' reductions and host finishes run under the later accumulations; the slices' sums are added on the host.
+// Unsliced, the sort (4.0 ms of 25.8 at 2^24) sits in front of the accumulation.  The slices keep the
+// window width of the whole (c = 17), so the number of additions does not change; the extra bucket reductions are hidden.
+static int msm_sliced(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
+  constexpr int K = kg_ctx::UP_SLICES;
+  const size_t pw = curve == KG_G2 ? 16 : 8;               // u64 words per base
+  size_t lo[K + 1];
+  for (int j = 0; j <= K; ++j) lo[j] = n / K * j + (j == K ? n % K : 0);
+  const int saved_window = ctx->msm_window;
+  if (!saved_window) { const int cw = pick_window(n, 0), cs = pick_window(n / K, 0); ctx->msm_window = cw > cs ? cw : cs; }
+  std::future<int> fin[K];
+  uint64_t part[K][24];
+  int rc = KG_OK;
+  const int sfield = curve == KG_GRUMPKIN ? KG_FQ : KG_FR;
+  for (int j = 0; j < K && rc == KG_OK; ++j) {
+    const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
+    kg::MsmSorted S;
+    rc = kg::msm_sort(ctx, sfield, d_scalars + 4 * a, cnt, &S, j > 0);      // slice 0 orders the scalar queue behind the inputs' producer
+    if (rc != KG_OK) break;
+    rc = kg::msm_run(ctx, S, curve, d_bases + a * pw, d_inf ? d_inf + a : nullptr, cnt, 0, 16 + j);
+    if (rc != KG_OK) break;
+    uint64_t* out = part[j];
+    fin[j] = std::async(std::launch::async, [ctx, curve, j, out] { return kg::msm_finish(ctx, curve, 16 + j, out); });
+  }
+  ctx->msm_window = saved_window;
+  for (int j = 0; j < K; ++j)
+    if (fin[j].valid()) { const int r2 = fin[j].get(); if (rc == KG_OK) rc = r2; }
+  if (rc != KG_OK) { kg_ctx_sync(ctx); return rc; }
+  return sum_slices(ctx, curve, part, K, out_xyz);
+}
+
 int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
   if (!ctx || !out_xyz || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
+  if (n >= ((size_t)1 << 23)) return msm_sliced(ctx, curve, d_bases, d_inf, d_scalars, n, out_xyz);   // measured: 2^24 25.8 -> 23.0 ms, 2^23 13.1 -> 12.1; below that the slices' own tails cost more than the hidden sort
   kg::MsmSorted S;
   const int mc = kg::has_window_table(ctx, curve, d_bases, d_inf, n, n) ? kg::merged_window(ctx, n) : 0;
   KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S, false, mc));
@@ -1985,24 +2041,7 @@ int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* 
   for (int j = 0; j < K; ++j)
     if (fin[j].valid()) { const int r2 = fin[j].get(); if (rc == KG_OK) rc = r2; }
   if (rc != KG_OK) { kg_ctx_sync(ctx); return rc; }
-  if (K == 1) { std::memcpy(out_xyz, part[0], (size_t)3 * E * 8); return KG_OK; }
-  uint64_t pts[kg_ctx::UP_SLICES * 16];
-  uint8_t pinf[kg_ctx::UP_SLICES];
-  for (int j = 0; j < K; ++j) {
-    bool z0 = true;
-    for (int k = 0; k < E; ++k) z0 = z0 && part[j][2 * E + k] == 0;
-    pinf[j] = z0 ? 1 : 0;
-    std::memcpy(pts + (size_t)j * 2 * E, part[j], (size_t)2 * E * 8);
-  }
-  uint64_t xy[16];
-  uint8_t inf = 0;
-  KG_TRY(kg_points_sum_affine(ctx, curve, pts, pinf, (size_t)K, xy, &inf));
-  kg::msm_identity(curve, out_xyz);                        // (0, 1, 0); y doubles as the field's one
-  if (!inf) {
-    for (int k = 0; k < E; ++k) out_xyz[2 * E + k] = out_xyz[E + k];
-    std::memcpy(out_xyz, xy, (size_t)2 * E * 8);
-  }
-  return KG_OK;
+  return sum_slices(ctx, curve, part, K, out_xyz);
 }
 
 int kg_commit(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,
