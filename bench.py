@@ -212,7 +212,7 @@ def main():
             res_tab = run(args.steps)
             barrier()
             line["registered_bases"]["window_tables"] = {"ms_per_step": (time.perf_counter() - t0) / args.steps * 1e3, "build_ms": build_ms,
-                                                         "table_bytes": (15 if n >= (1 << 17) else 16) * 72 * n,
+                                                         "table_bytes": (15 if n >= (1 << 17) else 16) * 64 * n,
                                                          "matches_unregistered": bool((res_tab[0] == res[0]).all() and res_tab[1] == res[1])}
         ctx.bases_unregister(bases.data_ptr())
         if not args.no_ntt:
@@ -378,7 +378,7 @@ def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True, tables=True, 
         c_t = 17 if nz >= (1 << 17) else 16
         w_t = (255 + c_t - 1) // c_t
         out["window_tables"] = {"ms_per_proof": dt_t * 1e3, "ms_per_proof_blocking": dt_tb * 1e3, "value": 1.0 / dt_t, "build_ms": build_ms,
-                                "table_bytes": w_t * (72 * (3 * nz + (m - 1)) + 144 * nz),
+                                "table_bytes": w_t * (64 * (3 * nz + (m - 1)) + 128 * nz),
                                 "proofs_match": bool(all((proof_t[i] == proof[i]).all() and (proof_tp[i] == proof[i]).all() for i in range(4)))}
     for name in ("h", "l", "a", "b_g1", "b_g2"):
         ctx.bases_unregister(dev_arr[name].data_ptr())

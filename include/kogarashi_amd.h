@@ -135,7 +135,7 @@ int kg_points_sum_affine(kg_ctx* ctx, int curve, const uint64_t* h_points_xy, co
 int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t n);
 int kg_bases_unregister(kg_ctx* ctx, const uint64_t* d_bases);
 /* Window tables for a registered array (fixed bases: a CRS vector, a commitment key): stores 2^(c*w) * base[i] for every
- * window w next to the resident copy -- ceil(255 / c) x the array, 72 B per G1 / Grumpkin point and window, 144 B per G2
+ * window w next to the resident copy -- ceil(255 / c) x the array, 64 B per G1 / Grumpkin point and window, 128 B per G2
  * point.  An MSM over the WHOLE array (kg_msm, kg_msm_begin, kg_commit, and kg_groth16_prove_bn254 when all five CRS
  * vectors carry tables) then sorts the digits of all windows into ONE set of 2^(c-1) buckets: the bucket reduction and the
  * host finish shrink by the window count, and the window can be one bit wider (c = 17: 15 additions per scalar instead
@@ -144,7 +144,7 @@ int kg_bases_unregister(kg_ctx* ctx, const uint64_t* d_bases);
  * KG_ERR_BAD_ARG otherwise.  The reference has no counterpart (groth16/src/msm.rs re-reads affine bases per call). */
 int kg_bases_precompute(kg_ctx* ctx, const uint64_t* d_bases, size_t msm_len);
 /* Window width c of the tables kg_bases_precompute builds for MSMs of msm_len scalars, 0 where none are offered: a table holds
- * ceil(255 / c) rows of the array (72 B per G1 / Grumpkin point, 144 B per G2 point).  Pure function: no device, no context. */
+ * ceil(255 / c) rows of the array (64 B per G1 / Grumpkin point, 128 B per G2 point).  Pure function: no device, no context. */
 int kg_msm_table_window(size_t msm_len);
 /* Tuning knob: window width c (0 = automatic). */
 int kg_msm_set_window(kg_ctx* ctx, int c);

@@ -57,7 +57,7 @@ struct kg_ctx {
   uint64_t ticket_out[4][24] = {};
   // table: optional window multiples of the array (kg_bases_precompute): table[w][i] = 2^(table_c * w) * base[i] in resident
   // form, w < table_W -- an MSM against them needs one set of buckets for all windows (merged sort, msm.hip)
-  struct Registered { const uint64_t* base; const uint8_t* inf; size_t n; int curve; uint32_t* packed; uint32_t* table = nullptr; int table_c = 0, table_W = 0; };
+  struct Registered { const uint64_t* base; const uint8_t* inf; size_t n; int curve; uint32_t* packed; uint32_t* table = nullptr; int table_c = 0, table_W = 0; bool fmt64 = false, table64 = false; };   // fmt64 / table64: 64-byte points (msm.hip, BaseIO::load_point64)
   std::vector<Registered> registered;    // bases converted once by kg_bases_register     // lengths of the MSMs begun with kg_msm_begin                         // pinned result slots: MSMs in flight whose host finish is pending
   // kg_msm_host: cached device copies of the caller's host arrays (grow-only) and the upload queue
   void* up_buf[3] = {nullptr, nullptr, nullptr};     // bases, scalars, identity flags

@@ -110,6 +110,9 @@ __global__ void __launch_bounds__(PREP_NT) k_prep_scalars_count(const uint64_t* 
 // bytes per G1 / Grumpkin point and 144 per G2 point instead of the ABI's 64 / 128.  The gather pays 12.5 % more bytes
 // -- it is not what bounds the accumulation -- and the ~50 shift / mask instructions per addition that re-spread 8
 // words over 9 limbs disappear.  The identity flag rides in bit 31 of the first coordinate's top limb (< 2^23).
+template <class F> struct FieldOf;
+template <class Q> struct FieldOf<Fp<Q>> { using P = Q; };
+template <class G> struct FieldOf<Fp2<G>> { using P = typename G::Params; };
 template <class F> struct BaseIO;
 template <class P> struct BaseIO<Fp<P>> {
   static constexpr int W = 8;    // u32 words of an element in the ABI (= u64 words of a point)
@@ -126,6 +129,22 @@ template <class P> struct BaseIO<Fp<P>> {
 #pragma unroll
     for (int j = 0; j < 9; ++j) r.l[j] = w[j];
     return r;
+  }
+  // 64-byte form of the same point (used where the gathers leave the Infinity Cache -- arrays of >= 2^22 points, window
+  // tables): the limbs of a value < 2p < 2^255 re-packed into 8 words per coordinate, identity flag in bit 255 of x.  A
+  // 72-byte point always straddles two 64-byte sectors, a 64-byte one is exactly one; the price is ~50 shift / mask
+  // instructions per addition to spread the words over the limbs again.
+  static constexpr int PK = 8;   // u32 words of a packed element
+  static __device__ __forceinline__ void pack(const Fp<P>& v, uint32_t* dst) { words_from_limbs(v, dst); }
+  static __device__ __forceinline__ bool load_point64(const uint32_t* src, Fp<P>& x, Fp<P>& y) {
+    uint32_t w[16];
+    const uint4* p = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint4 v = p[j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
+    const bool inf = (w[7] & INF_BIT) != 0;
+    w[7] &= ~INF_BIT;
+    x = limbs_from_words<P>(w); y = limbs_from_words<P>(w + 8);
+    return inf;
   }
   // whole point (x | y, 18 words at an 8-byte aligned address); returns the identity flag
   static __device__ __forceinline__ bool load_point(const uint32_t* src, Fp<P>& x, Fp<P>& y) {
@@ -145,6 +164,20 @@ template <class F> struct BaseIO<Fp2<F>> {
   static __device__ __forceinline__ void convert(const uint64_t* src, uint32_t* dst) {
     BaseIO<F>::convert(src, dst);
     BaseIO<F>::convert(src + 4, dst + 9);
+  }
+  static constexpr int PK = 16;
+  static __device__ __forceinline__ void pack(const Fp2<F>& v, uint32_t* dst) { BaseIO<F>::pack(v.c0, dst); BaseIO<F>::pack(v.c1, dst + 8); }
+  static __device__ __forceinline__ bool load_point64(const uint32_t* src, Fp2<F>& x, Fp2<F>& y) {
+    uint32_t w[32];
+    const uint4* p = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const uint4 v = p[j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
+    const bool inf = (w[7] & INF_BIT) != 0;
+    w[7] &= ~INF_BIT;
+    using P = typename F::Params;
+    x = {limbs_from_words<P>(w), limbs_from_words<P>(w + 8)};
+    y = {limbs_from_words<P>(w + 16), limbs_from_words<P>(w + 24)};
+    return inf;
   }
   // whole point (x.c0 | x.c1 | y.c0 | y.c1, 36 words at a 16-byte aligned address)
   static __device__ __forceinline__ bool load_point(const uint32_t* src, Fp2<F>& x, Fp2<F>& y) {
@@ -175,7 +208,33 @@ template <class F> struct RawIO<Fp2S<F>> {
 namespace {
 
 // bases: ABI affine (x | y) -> resident form (limbs of x | limbs of y), 2*PE words per point; identity flag -> INF_BIT
+// a resident point from its limbs: 2 * PE words (fmt64 = 0) or the 64-byte form, 2 * PK words (fmt64 = 1)
 template <class F>
+__device__ __forceinline__ void store_resident(uint32_t* out, size_t i, uint32_t* buf /* 2 * PE limbs words, flag applied */, int fmt64) {
+  constexpr int PE = BaseIO<F>::PE, PK = BaseIO<F>::PK;
+  if (fmt64) {
+    const bool inf = (buf[8] & INF_BIT) != 0;
+    buf[8] &= ~INF_BIT;
+    uint32_t pk[2 * PK];
+#pragma unroll
+    for (int e = 0; e < PE / 9; ++e) {                       // PE / 9 base-field elements per coordinate
+      Fp<typename FieldOf<F>::P> vx, vy;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { vx.l[k] = buf[9 * e + k]; vy.l[k] = buf[PE + 9 * e + k]; }
+      words_from_limbs(vx, pk + 8 * e);
+      words_from_limbs(vy, pk + PK + 8 * e);
+    }
+    if (inf) pk[7] |= INF_BIT;
+    uint4* dst = reinterpret_cast<uint4*>(out + i * 2 * PK);
+#pragma unroll
+    for (int j = 0; j < PK / 2; ++j) dst[j] = make_uint4(pk[4 * j], pk[4 * j + 1], pk[4 * j + 2], pk[4 * j + 3]);
+    return;
+  }
+  uint2* dst = reinterpret_cast<uint2*>(out + i * 2 * PE);
+#pragma unroll
+  for (int j = 0; j < PE; ++j) dst[j] = make_uint2(buf[2 * j], buf[2 * j + 1]);
+}
+template <class F, bool P64>
 __global__ void __launch_bounds__(256) k_prep_bases(const uint64_t* __restrict__ bases, const uint8_t* __restrict__ inf, size_t n,
                                                     uint32_t* __restrict__ out) {
   KG_SERVICE_PRIO();
@@ -186,9 +245,14 @@ __global__ void __launch_bounds__(256) k_prep_bases(const uint64_t* __restrict__
   BaseIO<F>::convert(bases + (size_t)i * W, buf);            // W u32 words == W/2 u64 words per element
   BaseIO<F>::convert(bases + (size_t)i * W + W / 2, buf + PE);
   if (inf && inf[i]) buf[8] |= INF_BIT;
-  uint2* dst = reinterpret_cast<uint2*>(out + (size_t)i * 2 * PE);
-#pragma unroll
-  for (int j = 0; j < PE; ++j) dst[j] = make_uint2(buf[2 * j], buf[2 * j + 1]);
+  store_resident<F>(out, i, buf, P64 ? 1 : 0);          // compile-time: the 72-byte form keeps its 32 VGPRs (it runs beside accumulations)
+}
+
+template <class F>
+static void launch_prep_bases(hipStream_t st, const uint64_t* bases, const uint8_t* inf, size_t n, uint32_t* out, bool fmt64) {
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (fmt64) hipLaunchKernelGGL((k_prep_bases<F, true>), grid, dim3(256), 0, st, bases, inf, n, out);
+  else hipLaunchKernelGGL((k_prep_bases<F, false>), grid, dim3(256), 0, st, bases, inf, n, out);
 }
 
 // Window tables (kg_bases_precompute): next[i] = 2^c * prev[i], both in resident form.  c doublings in XYZZ and one inversion
@@ -199,12 +263,12 @@ template <class P> __device__ __forceinline__ void put_limbs(const Fp<P>& a, uin
 }
 template <class F> __device__ __forceinline__ void put_limbs(const Fp2<F>& a, uint32_t* w) { put_limbs(a.c0, w); put_limbs(a.c1, w + 9); }
 template <class F>
-__global__ void __launch_bounds__(64) k_table_next(const uint32_t* __restrict__ prev, size_t n, int c, uint32_t* __restrict__ next) {
+__global__ void __launch_bounds__(64) k_table_next(const uint32_t* __restrict__ prev, size_t n, int c, uint32_t* __restrict__ next, int fmt64) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  constexpr int PE = BaseIO<F>::PE;
+  constexpr int PE = BaseIO<F>::PE, PK = BaseIO<F>::PK;
   Affine<F> a;
-  bool inf = BaseIO<F>::load_point(prev + i * 2 * PE, a.x, a.y);
+  bool inf = fmt64 ? BaseIO<F>::load_point64(prev + i * 2 * PK, a.x, a.y) : BaseIO<F>::load_point(prev + i * 2 * PE, a.x, a.y);
   uint32_t buf[2 * PE];
 #pragma unroll
   for (int j = 0; j < 2 * PE; ++j) buf[j] = 0;
@@ -216,9 +280,7 @@ __global__ void __launch_bounds__(64) k_table_next(const uint32_t* __restrict__ 
     if (!inf) { put_limbs(reduce(o.x), buf); put_limbs(reduce(o.y), buf + PE); }
   }
   if (inf) buf[8] |= INF_BIT;
-  uint2* dst = reinterpret_cast<uint2*>(next + i * 2 * PE);
-#pragma unroll
-  for (int j = 0; j < PE; ++j) dst[j] = make_uint2(buf[2 * j], buf[2 * j + 1]);
+  store_resident<F>(next, i, buf, fmt64);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1011,6 +1073,7 @@ struct AccSets {
   uint32_t idx_off[MAX_FUSED];        // scalars in front of the array (shared sort, z = x || w)
   uint32_t* partial[MAX_FUSED];       // partial sums, one per task
   uint32_t tab_n[MAX_FUSED];          // merged sort: points per window of the array's table (pb = the table)
+  uint8_t fmt64[MAX_FUSED];           // the array is in the 64-byte resident form (BaseIO::load_point64)
 };
 // G2: the compiler lands on 256 VGPRs + 1 AGPR = one wave per SIMD; asking for two waves costs a few spilled registers
 // and buys the second wave (the issue rate of this code at one wave per SIMD is ~69 % of its rate at four)
@@ -1026,10 +1089,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
   if (p >= L.base[W]) return;
   const uint32_t* __restrict__ pbases = A.pb[0];
   uint32_t idx_off = A.idx_off[0], tab_n = A.tab_n[0];
+  bool fmt64 = A.fmt64[0] != 0;
   uint32_t* __restrict__ partial = A.partial[0];
 #pragma unroll
   for (int k = 1; k < MAX_FUSED; ++k)
-    if (set == k) { pbases = A.pb[k]; idx_off = A.idx_off[k]; partial = A.partial[k]; tab_n = A.tab_n[k]; }
+    if (set == k) { pbases = A.pb[k]; idx_off = A.idx_off[k]; partial = A.partial[k]; tab_n = A.tab_n[k]; fmt64 = A.fmt64[k] != 0; }
   const size_t bi = task_bkt[p];
   const uint32_t t = task_id[p];
   const int w = (int)(bi / B);
@@ -1046,7 +1110,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
     if (mshift) { row = (size_t)(idx >> mshift) * tab_n; idx &= (1u << mshift) - 1u; }
     if (idx < idx_off) continue;                         // scalars in front of this base array (shared sort, z = x || w)
     Affine<F> a;
-    if (BaseIO<F>::load_point(pbases + (row + (idx - idx_off)) * PW, a.x, a.y)) continue;   // identity base (msm.rs:58-64 adds it as a no-op)
+    const size_t at = row + (idx - idx_off);
+    if (fmt64 ? BaseIO<F>::load_point64(pbases + at * (2 * BaseIO<F>::PK), a.x, a.y) : BaseIO<F>::load_point(pbases + at * PW, a.x, a.y))
+      continue;                                          // identity base (msm.rs:58-64 adds it as a no-op)
     acc = add_mixed_signed(acc, a, (e & 0x80000000u) != 0);
   }
   PointAoS<F>::store(partial, t, acc);
@@ -1312,6 +1378,17 @@ void store_projective(const XYZZ<typename Cfg::HF>& p, uint64_t* out_xyz) {
   HostIO<HF>::store(HF::one(), out_xyz + 2 * E);
 }
 
+// Which resident form an array of n bases gets: 64-byte points once the array no longer fits the Infinity Cache (measured:
+// accumulation 12.4 G additions/s at 2^24 with 72-byte points against 14.7 G/s at 2^20); KG_FMT64_MIN_LOG overrides (experiments).
+static bool resident_fmt64(size_t n) {
+  static const int min_log = getenv("KG_FMT64_MIN_LOG") ? atoi(getenv("KG_FMT64_MIN_LOG")) : 22;
+  return n >= ((size_t)1 << min_log);
+}
+static bool table_fmt64() {
+  static const int on = getenv("KG_TABLE64") ? atoi(getenv("KG_TABLE64")) : 1;      // tables never fit the cache: 2^20 1.36 -> 1.30 ms per step, Groth16 2.94 -> 2.87
+  return on != 0;
+}
+
 struct Carver {
   size_t off = 0;
   size_t take(size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; }
@@ -1533,7 +1610,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
   Lay lay[MAX_FUSED];
   AccSets A;
   A.nsets = njobs;
-  for (int k = 0; k < MAX_FUSED; ++k) { A.pb[k] = nullptr; A.idx_off[k] = 0; A.partial[k] = nullptr; A.tab_n[k] = 0; }
+  for (int k = 0; k < MAX_FUSED; ++k) { A.pb[k] = nullptr; A.idx_off[k] = 0; A.partial[k] = nullptr; A.tab_n[k] = 0; A.fmt64[k] = 0; }
   for (int k = 0; k < njobs; ++k) {
     const RunJob& J = jobs[k];
     Lay& Y = lay[k];
@@ -1551,11 +1628,17 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
         if (off != 0 || J.nbases != r.n || !r.table || r.table_c != c || r.table_W != S.windows) continue;
         reg_pb = r.table;
         A.tab_n[k] = (uint32_t)r.n;
-      } else reg_pb = r.packed + off * PW;
+        A.fmt64[k] = r.table64 ? 1 : 0;
+      } else {
+        reg_pb = r.packed + off * (r.fmt64 ? 2 * BaseIO<F>::PK : PW);
+        A.fmt64[k] = r.fmt64 ? 1 : 0;
+      }
       break;
     }
     if (S.merged_shift && !reg_pb) return set_err(ctx, KG_ERR_BAD_ARG, "merged sort against bases without a matching window table");
-    Y.o_pb = cv.take(reg_pb ? 256 : J.nbases * PW * 4);
+    const bool conv64 = !reg_pb && resident_fmt64(J.nbases);          // per-call conversion: the same rule as registration
+    if (conv64) A.fmt64[k] = 1;
+    Y.o_pb = cv.take(reg_pb ? 256 : J.nbases * (conv64 ? 2 * BaseIO<F>::PK : PW) * 4);
     for (int i = 0; i < 2; ++i) {
       Y.o_lc[i] = cv.take(npts * 4); Y.o_lr[i] = cv.take(npts * 4); Y.o_lb[i] = cv.take((size_t)(W + 1) * 4);
       Y.o_part[i] = cv.take(part_cap * NW * 4); Y.o_pbuf[i] = cv.take(npts * NW * 4);
@@ -1586,7 +1669,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
         ordered_bases = true;
       }
       PhaseScope ph(ctx, "prep_bases", sq);
-      hipLaunchKernelGGL(k_prep_bases<F>, dim3((unsigned)((J.nbases + 255) / 256)), dim3(256), 0, sq, J.d_bases, J.d_inf, J.nbases, (uint32_t*)(Y.ws + Y.o_pb));
+      launch_prep_bases<F>(sq, J.d_bases, J.d_inf, J.nbases, (uint32_t*)(Y.ws + Y.o_pb), conv64);
       ph.end();
       converted = true;
     }
@@ -1866,18 +1949,20 @@ int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uin
   if (!d_bases) return KG_ERR_BAD_ARG;
   KG_HIP(ctx, hipSetDevice(ctx->device));
   kg_bases_unregister(ctx, d_bases);
-  const size_t pw = curve == KG_G2 ? 36 : 18;
+  const bool fmt64 = resident_fmt64(n);
+  const size_t pw = fmt64 ? (curve == KG_G2 ? 32 : 16) : (curve == KG_G2 ? 36 : 18);
   uint32_t* packed = nullptr;
   KG_HIP(ctx, hipMalloc((void**)&packed, n * pw * 4));
-  dim3 grid((unsigned)((n + 255) / 256));
-  if (curve == KG_G1) hipLaunchKernelGGL(k_prep_bases<Fq>, grid, dim3(256), 0, ctx->stream, d_bases, d_inf, n, packed);
-  else if (curve == KG_GRUMPKIN) hipLaunchKernelGGL(k_prep_bases<Fr>, grid, dim3(256), 0, ctx->stream, d_bases, d_inf, n, packed);
-  else hipLaunchKernelGGL(k_prep_bases<Fq2>, grid, dim3(256), 0, ctx->stream, d_bases, d_inf, n, packed);
+  if (curve == KG_G1) launch_prep_bases<Fq>(ctx->stream, d_bases, d_inf, n, packed, fmt64);
+  else if (curve == KG_GRUMPKIN) launch_prep_bases<Fr>(ctx->stream, d_bases, d_inf, n, packed, fmt64);
+  else launch_prep_bases<Fq2>(ctx->stream, d_bases, d_inf, n, packed, fmt64);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) {
     hipFree(packed);
     return set_err(ctx, KG_ERR_HIP, "k_prep_bases launch", e);
   }
-  ctx->registered.push_back({d_bases, d_inf, n, curve, packed});
+  kg_ctx::Registered reg{d_bases, d_inf, n, curve, packed};
+  reg.fmt64 = fmt64;
+  ctx->registered.push_back(reg);
   return KG_OK;
 }
 
@@ -1908,23 +1993,28 @@ int kg_bases_precompute(kg_ctx* ctx, const uint64_t* d_bases, size_t msm_len) {
   if (r->table && r->table_c == c) return KG_OK;
   if (r->table) { kg_ctx_sync(ctx); hipFree(r->table); r->table = nullptr; r->table_c = r->table_W = 0; }
   const int W = (255 + c - 1) / c;
-  const size_t pw = r->curve == KG_G2 ? 36 : 18, row = r->n * pw;
+  const bool t64 = table_fmt64();
+  const size_t pw = t64 ? (r->curve == KG_G2 ? 32 : 16) : (r->curve == KG_G2 ? 36 : 18), row = r->n * pw;
   uint32_t* table = nullptr;
   if (hipError_t e = hipMalloc((void**)&table, (size_t)W * row * 4); e != hipSuccess) {
     (void)hipGetLastError();
     return set_err(ctx, KG_ERR_OOM, "window table allocation", e);
   }
   hipStream_t st = ctx->stream;
-  hipError_t e = hipMemcpyAsync(table, r->packed, row * 4, hipMemcpyDeviceToDevice, st);
+  // row 0 from the caller's array (the resident copy may be in the other form), then one launch per further window
+  if (r->curve == KG_G1) launch_prep_bases<Fq>(st, r->base, r->inf, r->n, table, t64);
+  else if (r->curve == KG_GRUMPKIN) launch_prep_bases<Fr>(st, r->base, r->inf, r->n, table, t64);
+  else launch_prep_bases<Fq2>(st, r->base, r->inf, r->n, table, t64);
+  hipError_t e = hipGetLastError();
   const dim3 grid((unsigned)((r->n + 63) / 64));
   for (int w = 1; w < W && e == hipSuccess; ++w) {
-    if (r->curve == KG_G1) hipLaunchKernelGGL(k_table_next<Fq>, grid, dim3(64), 0, st, table + (size_t)(w - 1) * row, r->n, c, table + (size_t)w * row);
-    else if (r->curve == KG_GRUMPKIN) hipLaunchKernelGGL(k_table_next<Fr>, grid, dim3(64), 0, st, table + (size_t)(w - 1) * row, r->n, c, table + (size_t)w * row);
-    else hipLaunchKernelGGL(k_table_next<Fq2>, grid, dim3(64), 0, st, table + (size_t)(w - 1) * row, r->n, c, table + (size_t)w * row);
+    if (r->curve == KG_G1) hipLaunchKernelGGL(k_table_next<Fq>, grid, dim3(64), 0, st, table + (size_t)(w - 1) * row, r->n, c, table + (size_t)w * row, t64 ? 1 : 0);
+    else if (r->curve == KG_GRUMPKIN) hipLaunchKernelGGL(k_table_next<Fr>, grid, dim3(64), 0, st, table + (size_t)(w - 1) * row, r->n, c, table + (size_t)w * row, t64 ? 1 : 0);
+    else hipLaunchKernelGGL(k_table_next<Fq2>, grid, dim3(64), 0, st, table + (size_t)(w - 1) * row, r->n, c, table + (size_t)w * row, t64 ? 1 : 0);
     e = hipGetLastError();
   }
   if (e != hipSuccess) { hipFree(table); return set_err(ctx, KG_ERR_HIP, "window table build", e); }
-  r->table = table; r->table_c = c; r->table_W = W;
+  r->table = table; r->table_c = c; r->table_W = W; r->table64 = t64;
   return KG_OK;
 }
 

@@ -143,3 +143,51 @@ def test_precompute_argument_checks(ctx, oracle):
     finally:
         ctx.bases_unregister(db.ptr)
     assert (got == ctx.msm(0, db.ptr, 0, ds.ptr, n)).all()
+
+
+_FMT_SCRIPT = r"""
+import sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import kogarashi_amd as K
+from oracle import oracle as O
+SEED = 0x4B6F676172617368
+ctx = K.Context(0)
+out = {}
+for cv, curve, sfd, n in (("g1", 0, 0, 70001), ("gk", 1, 1, 5000), ("g2", 2, 0, 66000)):
+    if curve == 2:
+        dk = ctx.upload(O.gen_scalars(0, SEED + 980, 0, n))
+        dxy, dinf = ctx.empty((n, 16)), ctx.empty((n,), dtype=np.uint8)
+        ctx.fixed_base_mul(2, dk.ptr, n, dxy.ptr, dinf.ptr)
+        bases = dxy.numpy()
+    else:
+        bases = O.gen_bases(curve, SEED + 981 + curve, 0, n)
+    scal = O.gen_scalars(sfd, SEED + 982 + curve, 0, n)
+    inf = np.zeros(n, dtype=np.uint8); inf[[4, n - 2]] = 1
+    db, di, ds = ctx.upload(bases), ctx.upload(inf), ctx.upload(scal)
+    res = [ctx.msm(curve, db.ptr, di.ptr, ds.ptr, n)]                 # per-call conversion
+    ctx.bases_register(curve, db.ptr, di.ptr, n)
+    res.append(ctx.msm(curve, db.ptr, di.ptr, ds.ptr, n))             # resident copy
+    if n >= 1 << 16:
+        ctx.bases_precompute(db.ptr)
+        res.append(ctx.msm(curve, db.ptr, di.ptr, ds.ptr, n))         # window table
+    ctx.bases_unregister(db.ptr)
+    out[cv] = [r.tolist() for r in res]
+print("RESULT " + json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("env", [{"KG_FMT64_MIN_LOG": "0", "KG_TABLE64": "1"}, {"KG_FMT64_MIN_LOG": "30", "KG_TABLE64": "0"}])
+def test_resident_formats_agree(env):
+    """The 64-byte resident form (arrays of >= 2^22 points, window tables) and the 72-byte one give the same sums: the same
+    MSMs (per-call conversion, registered, with tables; identity flags set) in two processes that force one form each."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = []
+    for e in (env, {}):
+        p = subprocess.run([sys.executable, "-c", _FMT_SCRIPT, root], capture_output=True, text=True, env={**os.environ, **e}, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs.append(json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    assert runs[0] == runs[1]
+    for cv, res in runs[0].items():
+        assert all(r == res[0] for r in res), cv
