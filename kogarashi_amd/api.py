@@ -237,6 +237,54 @@ class NovaProver:
     def compute_cross_term(self, u1, x1, w1, u2, x2, w2) -> np.ndarray:
         return self.compute_cross_term_device(u1, x1, w1, u2, x2, w2).numpy()
 
+    def _one(self):
+        """the scalar field's one in Montgomery form, made by the device (to_mont of the integer 1)"""
+        if getattr(self, "_one_cache", None) is None:
+            d = self.ctx.upload(np.array([[1, 0, 0, 0]], dtype=np.uint64))
+            self.ctx.field_vec_op(self.field, "to_mont", d.ptr, 0, d.ptr, 1)
+            self._one_cache = d.numpy()[0].copy()
+        return self._one_cache
+
+    def prove(self, instance1: dict, witness1: dict, instance2: dict, witness2: dict, r):
+        """nova::Prover::prove (nova/src/prover.rs:24-50) with the challenge r supplied by the caller -- the transcript hash
+        that produces it is sequential host work outside the hot path.
+
+        instance1: relaxed instance {"commit_w": (xy, inf), "commit_e": (xy, inf), "u": limbs, "x": (k, 4)};
+        witness1: {"w": (n, 4), "e": (m, 4)}; instance2: {"commit_w": (xy, inf), "x": (k, 4)}; witness2: {"w": (n, 4)}.
+        Returns (instance, witness, commit_t) in the same shapes.  On the device: the cross term, its commitment and both
+        witness folds (W1 + r W2, E1 + r T: relaxed_r1cs/witness.rs:56-70); the instance fold (instance.rs:81-101) is two
+        two-point MSMs and a handful of scalars."""
+        c, fd, cid = self.ctx, self.field, self.ck.cid
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+        one = self._one()
+        u1 = np.ascontiguousarray(instance1["u"], dtype=np.uint64).reshape(4)
+        x1 = np.ascontiguousarray(instance1["x"], dtype=np.uint64).reshape(-1, 4)
+        x2 = np.ascontiguousarray(instance2["x"], dtype=np.uint64).reshape(-1, 4)
+        w1 = np.ascontiguousarray(witness1["w"], dtype=np.uint64).reshape(-1, 4)
+        w2 = np.ascontiguousarray(witness2["w"], dtype=np.uint64).reshape(-1, 4)
+        t = self.compute_cross_term_device(u1, x1, w1, one, x2, w2)
+        n = min(self.m, self.ck.len)
+        commit_t = c.commit(cid, self.ck._g.ptr, self.ck._inf.ptr if self.ck._inf else 0, t.ptr, n)
+        # witness fold
+        dw1, dw2, de1 = c.upload(w1), c.upload(w2), c.upload(np.ascontiguousarray(witness1["e"], dtype=np.uint64).reshape(-1, 4))
+        c.field_vec_axpy(fd, dw1.ptr, r, dw2.ptr, dw1.ptr, len(w1))
+        c.field_vec_axpy(fd, de1.ptr, r, t.ptr, de1.ptr, self.m)
+        # instance fold: u = u1 + r, x = x1 + r x2 (one small axpy over u | x against 1 | x2)
+        ux1, ux2 = c.upload(np.concatenate([u1.reshape(1, 4), x1])), c.upload(np.concatenate([one.reshape(1, 4), x2]))
+        c.field_vec_axpy(fd, ux1.ptr, r, ux2.ptr, ux1.ptr, 1 + len(x1))
+        ux = ux1.numpy()
+
+        def fold_point(p1, p2):                     # p1 + r * p2 as an affine point: msm([p1, p2], [1, r])
+            w = 16 if cid == KG_G2 else 8
+            pts = np.stack([np.ascontiguousarray(p1[0], dtype=np.uint64).reshape(w), np.ascontiguousarray(p2[0], dtype=np.uint64).reshape(w)])
+            flags = np.array([int(bool(p1[1])), int(bool(p2[1]))], dtype=np.uint8)
+            out = c.msm_host(cid, pts, flags, np.stack([one, r]), 2)
+            return out[:w].copy(), int(not out[w:].any())
+
+        instance = {"commit_w": fold_point(instance1["commit_w"], instance2["commit_w"]),
+                    "commit_e": fold_point(instance1["commit_e"], commit_t), "u": ux[0].copy(), "x": ux[1:].copy()}
+        return instance, {"w": dw1.numpy(), "e": de1.numpy()}, commit_t
+
     def commit_t(self, u1, x1, w1, u2, x2, w2):
         """(T, commit_T): the cross term and ck.commit(&t) (prover.rs:33-35); T never leaves the device in between"""
         t = self.compute_cross_term_device(u1, x1, w1, u2, x2, w2)

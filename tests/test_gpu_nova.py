@@ -100,3 +100,84 @@ def test_cross_term_of_a_satisfied_pair_folds(ctx, oracle):
     ctx.field_vec_scale(fd, cz.ptr, u, rhs.ptr, cs.m)
     ctx.field_vec_axpy(fd, rhs.ptr, r, dt.ptr, rhs.ptr, cs.m)                       # u CZ + r T   (E1 = 0)
     assert (lhs.numpy() == rhs.numpy()).all()
+
+
+@pytest.mark.parametrize("fd,curve,cv", [(0, 0, "g1"), (1, 1, "gk")])
+def test_folding_step_matches_big_integer_fold(ctx, oracle, pyoracle, fd, curve, cv):
+    """NovaProver.prove = nova::Prover::prove with the challenge supplied (prover.rs:24-50): two folding steps in a row --
+    the second starts from a relaxed instance with u != 1, E != 0 and a non-identity commit_e -- against the oracle's cross
+    term and commitments, big-integer folds of witness and instance (pyoracle point arithmetic), and the relaxed
+    satisfiability identity AZ o BZ = u CZ + E of the folded pair evaluated with device ops."""
+    import kogarashi_amd as K
+    from helpers import CURVES, I, L, np_to_pt, pt_to_np
+    O, P = oracle, pyoracle
+    cur = CURVES[cv][1]
+    p = cur.n                                        # the curve's scalar field = the circuit's field
+    one = O.f_consts(fd)["r"]
+    sat = fd == 0                                    # the oracle's chain circuit lives over Fr; the Fq run folds unsatisfied random data
+    if sat:
+        m = 300
+        css = [O.chain_r1cs(m, O.gen_scalars(0, SEED + 1100 + j, 0, 1)[0]) for j in range(3)]
+        shape = (css[0].a, css[0].b, css[0].c)
+        xs = [cs.x[1:] for cs in css]                # chain_r1cs columns are (x | w) with x[0] = 1 = the one-wire u
+        ws = [cs.w for cs in css]
+    else:
+        m, lx, lw = 300, 2, 200
+        shape = random_shape(O, fd, m, 1 + lx + lw, SEED + 1101)
+        xs = [O.gen_scalars(fd, SEED + 1102 + j, 0, lx) for j in range(3)]
+        ws = [O.gen_scalars(fd, SEED + 1105 + j, 0, lw) for j in range(3)]
+    g = O.gen_bases(curve, SEED + 1110, 0, m + 1)
+    ck = K.PedersenCommitment(g, curve=curve, ctx=ctx)
+    prover = K.NovaProver(shape, ck, ctx=ctx)
+    commit = lambda v: ck.commit(v)
+    to_int = lambda a: [P.from_mont(I(row), p) for row in np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)]
+    to_np = lambda vals: np.array([L(P.to_mont(v % p, p)) for v in vals], dtype=np.uint64).reshape(-1, 4)
+    pt = lambda c: np_to_pt(cur, c[0], c[1])
+
+    def fresh(j):                                    # R1csInstance / R1csWitness j (u = 1)
+        return {"commit_w": commit(ws[j]), "x": xs[j]}, {"w": ws[j]}
+
+    i1 = {"commit_w": commit(ws[0]), "commit_e": (np.zeros(8, dtype=np.uint64), 1), "u": one, "x": xs[0]}
+    w1 = {"w": ws[0], "e": np.zeros((m, 4), dtype=np.uint64)}
+    for step, seed in enumerate((1, 2)):
+        i2, w2 = fresh(seed)
+        r = O.gen_scalars(fd, SEED + 1120 + seed, 0, 1)[0]
+        inst, wit, commit_t = prover.prove(i1, w1, i2, w2, r)
+        # cross term and its commitment: the oracle's restatement
+        z1 = np.concatenate([np.asarray(i1["u"]).reshape(1, 4), i1["x"], w1["w"]])
+        z2 = np.concatenate([one.reshape(1, 4), i2["x"], w2["w"]])
+        t = O.nova_cross_term(fd, shape[0], shape[1], shape[2], z1, z2, np.asarray(i1["u"]).reshape(4), one)
+        nc = min(m, len(g))
+        wxy, winf = O.commit_naive(cv, g[:nc], t[:nc])
+        assert commit_t[1] == winf and (winf or (commit_t[0] == wxy).all())
+        # big-integer folds
+        ri = to_int(r)[0]
+        assert (wit["w"] == to_np([a + ri * b for a, b in zip(to_int(w1["w"]), to_int(w2["w"]))])).all()
+        assert (wit["e"] == to_np([a + ri * b for a, b in zip(to_int(w1["e"]), to_int(t))])).all()
+        assert (inst["u"] == to_np([to_int(i1["u"])[0] + ri])[0]).all()
+        assert (inst["x"] == to_np([a + ri * b for a, b in zip(to_int(i1["x"]), to_int(i2["x"]))])).all()
+        for name, a, b in (("commit_w", i1["commit_w"], i2["commit_w"]), ("commit_e", i1["commit_e"], commit_t)):
+            want = cur.add(pt(a), cur.mul(pt(b), ri))
+            got = inst[name]
+            assert (want is None) == bool(got[1]) and (want is None or (got[0] == pt_to_np(cur, want)).all()), (step, name)
+        # the commitments of the folded witness are the folded commitments
+        assert commit(wit["w"])[1] == inst["commit_w"][1] and (commit(wit["w"])[0] == inst["commit_w"][0]).all()
+        assert commit(wit["e"])[1] == inst["commit_e"][1] and (commit(wit["e"])[0] == inst["commit_e"][0]).all()
+        i1_next, w1_next = inst, wit
+        if not sat:
+            i1, w1 = i1_next, w1_next
+            continue
+        # the folded pair satisfies the relaxed relation (device ops only)
+        z = np.concatenate([inst["u"].reshape(1, 4), inst["x"], wit["w"]])
+        dz = ctx.upload(z)
+        outs = []
+        for dev in prover._dev:
+            o = ctx.empty((m, 4))
+            ctx.r1cs_prod(fd, dev[0].ptr, dev[1].ptr, dev[2].ptr, m, dz.ptr, o.ptr)
+            outs.append(o)
+        lhs, rhs, de = ctx.empty((m, 4)), ctx.empty((m, 4)), ctx.upload(wit["e"])
+        ctx.field_vec_op(fd, "mul", outs[0].ptr, outs[1].ptr, lhs.ptr, m)
+        ctx.field_vec_scale(fd, outs[2].ptr, inst["u"], rhs.ptr, m)
+        ctx.field_vec_op(fd, "add", rhs.ptr, de.ptr, rhs.ptr, m)
+        assert (lhs.numpy() == rhs.numpy()).all(), step
+        i1, w1 = i1_next, w1_next
