@@ -5,6 +5,7 @@
 //!   `groth16/src/fft.rs:92-154`     `Fft::<F>::{dft, idft, coset_dft, coset_idft, divide_by_z_on_coset}`
 //!   `nova/src/pedersen.rs:15`       `PedersenCommitment::<C>::commit(&self, m) -> C`
 //!   `groth16/src/prover.rs:20`      `Prover::create_proof`
+//!   `nova/src/prover.rs:53`         `Prover::compute_cross_term`
 //! The patches in `rust/patches/` add one `#[cfg(feature = "gpu")]` early return to each of them that calls the
 //! generic entry points below.  They dispatch on `TypeId` (the `'static` bound comes from the one-line patch to
 //! `zkstd::traits::Group`), so the reference's generic signatures stay as they are; a type the backend does not
@@ -24,6 +25,7 @@ use zkstd::common::{BNAffine, BNProjective, CurveGroup, Group};
 
 pub mod fft;
 pub mod groth16;
+pub mod nova;
 pub mod pedersen;
 
 /// A backend failure; callers in the patched crates treat it as "use the CPU body".

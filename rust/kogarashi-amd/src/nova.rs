@@ -1,0 +1,102 @@
+//! `nova/src/prover.rs:53-90` `compute_cross_term` on the device: T = AZ1 o BZ2 + AZ2 o BZ1 - u1 CZ2 - u2 CZ1 in one fused
+//! kernel (`kg_nova_cross_term`), the six sparse products of the reference (`SparseMatrix::prod`, zkstd/src/matrix.rs:32-47)
+//! included.  The shape matrices cross the ABI as CSR over z = (u | x | w) -- `SparseMatrix::to_csr`, added by
+//! `patches/zkstd_matrix_csr.diff`, applies `prod`'s own index rule (Instance(i) -> i, Witness(i) -> i + l) -- and stay
+//! resident: `R1csShape::matrices()` clones them on every call, so the cache is keyed by content (sizes plus a fingerprint
+//! of the first and last rows), not by address.
+use std::collections::HashMap;
+use std::sync::{Mutex, OnceLock};
+
+use kogarashi_amd_sys as sys;
+use zkstd::common::PrimeField;
+use zkstd::matrix::SparseMatrix;
+
+use crate::{contexts, scalar_words, Context, DeviceBuf};
+
+struct ResidentMatrix {
+    row_ptr: DeviceBuf,
+    col: DeviceBuf,
+    val: DeviceBuf,
+}
+impl ResidentMatrix {
+    fn csr(&self) -> sys::KgCsr {
+        sys::KgCsr { d_row_ptr: self.row_ptr.as_u64() as *const u64, d_col: self.col.as_u64() as *const u64, d_val: self.val.as_u64() as *const u64 }
+    }
+}
+struct ResidentShape {
+    m: [ResidentMatrix; 3],
+    fingerprint: Vec<u64>,
+}
+unsafe impl Send for ResidentShape {}
+
+static SHAPES: OnceLock<Mutex<HashMap<(usize, usize, usize, i32), ResidentShape>>> = OnceLock::new();
+
+struct HostCsr {
+    row_ptr: Vec<u64>,
+    col: Vec<u64>,
+    val: Vec<u64>,
+}
+impl HostCsr {
+    /// `SparseMatrix::to_csr` plus the coefficients as the ABI's words
+    fn of<F: PrimeField + 'static>(mat: &SparseMatrix<F>, l: usize) -> Option<Self> {
+        let (row_ptr, col, val) = mat.to_csr(l);
+        let (words, _) = scalar_words(&val)?;
+        let val = unsafe { core::slice::from_raw_parts(words, 4 * val.len()) }.to_vec();
+        Some(Self { row_ptr, col, val })
+    }
+    fn fingerprint(&self, out: &mut Vec<u64>) {
+        out.extend([self.row_ptr.len() as u64, self.col.len() as u64]);
+        out.extend(self.col.iter().take(8));
+        out.extend(self.col.iter().rev().take(8));
+        out.extend(self.val.iter().take(16));
+        out.extend(self.val.iter().rev().take(16));
+    }
+    fn upload(&self, ctx: &Context) -> Option<ResidentMatrix> {
+        let pad = [0u64; 4];
+        Some(ResidentMatrix {
+            row_ptr: DeviceBuf::from_words(ctx, &self.row_ptr).ok()?,
+            col: DeviceBuf::from_words(ctx, if self.col.is_empty() { &pad[..1] } else { &self.col }).ok()?,
+            val: DeviceBuf::from_words(ctx, if self.val.is_empty() { &pad[..] } else { &self.val }).ok()?,
+        })
+    }
+}
+
+/// The cross term of a folding step; `None` (no device, a field the backend does not serve, any non-zero status) lets the
+/// caller's CPU body run.  `l` = x.len() + 1 for both pairs (the relaxed instance and the fresh one share the shape).
+#[allow(clippy::too_many_arguments)]
+pub fn cross_term<F: PrimeField + 'static>(a: &SparseMatrix<F>, b: &SparseMatrix<F>, c: &SparseMatrix<F>, m: u64, l: usize, z1: &[F],
+                                           z2: &[F], u1: &F, u2: &F) -> Option<Vec<F>> {
+    let (_, field) = scalar_words(z1)?;
+    if z1.len() != z2.len() || m == 0 {
+        return None;
+    }
+    let ctxs = contexts()?;
+    let ctx = &ctxs[0];
+    let mut shapes = SHAPES.get_or_init(|| Mutex::new(HashMap::new())).lock().ok()?;
+    // the host CSR is rebuilt per call (the matrices arrive as fresh clones); the device copy is reused while its
+    // fingerprint matches
+    let host = [HostCsr::of(a, l)?, HostCsr::of(b, l)?, HostCsr::of(c, l)?];
+    let nnz: usize = host.iter().map(|h| h.col.len()).sum();
+    let key = (m as usize, l, nnz, field);
+    let mut print = Vec::new();
+    host.iter().for_each(|h| h.fingerprint(&mut print));
+    if shapes.get(&key).map(|s| s.fingerprint != print).unwrap_or(true) {
+        let m3 = [host[0].upload(ctx)?, host[1].upload(ctx)?, host[2].upload(ctx)?];
+        shapes.insert(key, ResidentShape { m: m3, fingerprint: print });
+    }
+    let shape = shapes.get(&key)?;
+    let words = |s: &[F]| unsafe { core::slice::from_raw_parts(s.as_ptr() as *const u64, 4 * s.len()) };
+    let (d1, d2) = (DeviceBuf::from_words(ctx, words(z1)).ok()?, DeviceBuf::from_words(ctx, words(z2)).ok()?);
+    let out = DeviceBuf::new(ctx, m as usize * 32).ok()?;
+    let (ca, cb, cc) = (shape.m[0].csr(), shape.m[1].csr(), shape.m[2].csr());
+    let rc = unsafe {
+        sys::kg_nova_cross_term(ctx.raw(), field, &ca, &cb, &cc, m as usize, d1.as_u64(), d2.as_u64(), u1 as *const F as *const u64,
+                                u2 as *const F as *const u64, out.as_u64())
+    };
+    if rc != sys::KG_OK {
+        return None;
+    }
+    let mut t = vec![F::zero(); m as usize];
+    out.read_words(unsafe { core::slice::from_raw_parts_mut(t.as_mut_ptr() as *mut u64, 4 * t.len()) }).ok()?;
+    Some(t)
+}

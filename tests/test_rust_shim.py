@@ -52,7 +52,7 @@ def test_glue_calls_match_the_header():
                 assert n_args == arity[name], (f, name, n_args, arity[name])
                 seen.add(name)
     for needed in ("kg_msm_host", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_sharded_key_create", "kg_sharded_key_commit",
-                   "kg_groth16_prove_bn254", "kg_bases_register"):
+                   "kg_groth16_prove_bn254", "kg_bases_register", "kg_bases_precompute", "kg_nova_cross_term"):
         assert needed in seen, needed
 
 
@@ -86,7 +86,7 @@ def test_patches_apply_to_the_reference(tmp_path):
     for d in ("groth16", "nova", "zkstd", "bn254"):
         subprocess.check_call(["cp", "-r", os.path.join("/root/reference", d), str(tmp_path / d)])
     patches = sorted(p for p in os.listdir(os.path.join(RUST, "patches")) if p.endswith(".diff"))
-    assert len(patches) >= 7
+    assert len(patches) >= 9
     for p in patches:
         with open(os.path.join(RUST, "patches", p)) as f:
             subprocess.run(["patch", "-p1", "-s"], stdin=f, cwd=str(tmp_path), check=True)
@@ -95,3 +95,5 @@ def test_patches_apply_to_the_reference(tmp_path):
     assert "kogarashi_amd::pedersen::commit" in (tmp_path / "nova/src/pedersen.rs").read_text()
     assert "kogarashi_amd::groth16::resident" in (tmp_path / "groth16/src/prover.rs").read_text()
     assert (tmp_path / "groth16/src/fft.rs").read_text().count("gpu::transform") == 5
+    assert "kogarashi_amd::nova::cross_term" in (tmp_path / "nova/src/prover.rs").read_text()
+    assert "pub fn to_csr" in (tmp_path / "zkstd/src/matrix.rs").read_text()
