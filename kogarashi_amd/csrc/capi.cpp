@@ -54,6 +54,14 @@ int make_sort_stream(kg_ctx* c) {
   if ((e = hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
   return KG_OK;
 }
+int ensure_ws_vec(kg_ctx* c, size_t bytes) {
+  if (bytes <= c->ws_vec_bytes) return KG_OK;
+  if (c->ws_vec) { sync_all(c); hipFree(c->ws_vec); c->ws_vec = nullptr; c->ws_vec_bytes = 0; }
+  hipError_t e = hipMalloc(&c->ws_vec, bytes);
+  if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "workspace allocation", e);
+  c->ws_vec_bytes = bytes;
+  return KG_OK;
+}
 int ensure_ws2(kg_ctx* c, size_t bytes) {
   if (bytes <= c->ws2_bytes) return KG_OK;
   if (c->ws2) { sync_all(c); hipFree(c->ws2); c->ws2 = nullptr; c->ws2_bytes = 0; }
@@ -192,6 +200,7 @@ void kg_ctx_destroy(kg_ctx* c) {
   if (c->ev_order) hipEventDestroy(c->ev_order);
   if (c->sort_stream) { hipStreamSynchronize(c->sort_stream); hipStreamDestroy(c->sort_stream); }
   if (c->ws2) hipFree(c->ws2);
+  if (c->ws_vec) hipFree(c->ws_vec);
   for (int i = 0; i < 2; ++i) if (c->ws3[i]) hipFree(c->ws3[i]);
   if (c->side_stream) hipStreamSynchronize(c->side_stream);
   for (int i = 0; i < kg_ctx::RUN_SETS; ++i) { if (c->ws_run[i]) hipFree(c->ws_run[i]); if (c->ev_acc[i]) hipEventDestroy(c->ev_acc[i]); }

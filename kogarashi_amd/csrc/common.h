@@ -34,6 +34,8 @@ struct kg_ctx {
   hipEvent_t ev_order = nullptr;         // stream-order hand-over main -> scalar queue
   bool inputs_complete = false;          // kg_ctx_set_inputs_complete: MSM inputs are complete when the call is made
 
+  void* ws_vec = nullptr;                // kg_r1cs_prod: work list of long rows (grow-only)
+  size_t ws_vec_bytes = 0;
   void* ws2 = nullptr;                   // NTT ping-pong buffer
   size_t ws2_bytes = 0;
   void* ws3[2] = {nullptr, nullptr};     // prover polynomial buffers (a, b, c, z, transform scratch), one set per proof ticket
@@ -106,6 +108,7 @@ int ensure_ws_sort(kg_ctx* c, int set, size_t bytes);
 int make_sort_stream(kg_ctx* c);
 hipError_t create_stream(kg_ctx* c, hipStream_t* out, bool service);
 int ensure_ws2(kg_ctx* c, size_t bytes);
+int ensure_ws_vec(kg_ctx* c, size_t bytes);
 int ensure_ws3(kg_ctx* c, int which, size_t bytes);
 int ensure_ws_run(kg_ctx* c, int which, size_t bytes);
 int ensure_slot(kg_ctx* c, int slot, size_t bytes);

@@ -5,6 +5,7 @@
 // point-wise polynomial ops groth16/src/poly.rs:168-195.  HBM-bound for add/sub/mul (96 B/element).
 #include "common.h"
 #include "vecops.h"
+#include "host_fp.h"
 
 using namespace kg;
 
@@ -86,9 +87,8 @@ __global__ void __launch_bounds__(256) k_vec_axpy(const uint64_t* a, Words8 s, c
 }
 
 // CSR sparse matrix-vector product (zkstd/src/matrix/row.rs:43-51, matrix.rs:36-48), G lanes per row: lanes stride over the
-// row's entries, partial sums meet through log2(G) shuffle steps.  G = 64 (one wave per row) for kg_r1cs_evaluate, whose
-// callers include the transposed system of the setup -- there one column (the constant-one wire) touches every
-// constraint, so a row may hold millions of entries; G = 8 for Nova's cross term, whose rows are constraint rows.
+// row's entries, partial sums meet through log2(G) shuffle steps.  G = 1 (a lane per row) for constraint rows, G = 64 (a
+// wave per row) for the long rows of kg_r1cs_prod's work list.
 template <class P>
 __device__ __forceinline__ Fp<P> shfl_xor_f(const Fp<P>& a, int mask) {
   Fp<P> r;
@@ -96,8 +96,10 @@ __device__ __forceinline__ Fp<P> shfl_xor_f(const Fp<P>& a, int mask) {
   for (int k = 0; k < 9; ++k) r.l[k] = __shfl_xor(a.l[k], mask);
   return r;
 }
-// sum_e val[e] * z[col[e]] over the row, for one or two z vectors; the result (every lane of the group holds it) stays in the
-// ABI's Montgomery domain: raw(z) * internal(val) = z * val * 2^256
+// sum_e val[e] * z[col[e]] over the row, for one or two z vectors (every lane of the group holds the result).  Both factors are
+// used as they lie in memory (x * 2^256), so a term is ONE Montgomery product -- z * val * 2^251 -- and the sums live in that
+// "raw product" domain; the caller's next multiplication carries the constant that leaves it (C_FROM_REF for a plain
+// matrix-vector product, the folded constants of cross_term_row).  Converting each coefficient first cost a second product per entry.
 template <class P, int G, int NZ>
 __device__ __forceinline__ void row_dot(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col, const uint64_t* __restrict__ val,
                                         size_t row, int lane, const uint64_t* __restrict__ z1, const uint64_t* __restrict__ z2, Fp<P> (&sum)[NZ]) {
@@ -106,7 +108,7 @@ __device__ __forceinline__ void row_dot(const uint64_t* __restrict__ row_ptr, co
   for (uint64_t e = row_ptr[row] + lane; e < row_ptr[row + 1]; e += G) {
     uint32_t wv[8], wz[8];
     load_words(val, e, wv);
-    const Fp<P> v = from_ref<P>(wv);
+    const Fp<P> v = limbs_from_words<P>(wv);
     const uint64_t c = col[e];
     load_words(z1, c, wz);
     sum[0] = dot_step(sum[0], limbs_from_words<P>(wz), v);
@@ -115,47 +117,76 @@ __device__ __forceinline__ void row_dot(const uint64_t* __restrict__ row_ptr, co
       sum[NZ - 1] = dot_step(sum[NZ - 1], limbs_from_words<P>(wz), v);
     }
   }
+  if (G > 1) {
 #pragma unroll
-  for (int d = G / 2; d >= 1; d >>= 1)
+    for (int d = G / 2; d >= 1; d >>= 1)
 #pragma unroll
-    for (int q = 0; q < NZ; ++q) sum[q] = dot_merge(sum[q], shfl_xor_f(sum[q], d));
+      for (int q = 0; q < NZ; ++q) sum[q] = dot_merge(sum[q], shfl_xor_f(sum[q], d));
+  }
 }
 
+// Matrix-vector product in two launches.  Constraint rows hold a handful of terms, so a lane takes a whole row (a wave per
+// row kept 63 of 64 lanes idle: 0.45 ms per 2^18-row product); a row of more than SHORT_ROW terms -- the transposed systems
+// of the setup have one per heavily used wire, the constant-one wire touching every constraint -- is put on a work list
+// instead and summed by a whole wave in the second launch.
+constexpr uint32_t SHORT_ROW = 48;
 template <class P>
-__global__ void __launch_bounds__(256) k_r1cs_evaluate(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
-                                                       const uint64_t* __restrict__ val, size_t m, const uint64_t* __restrict__ z,
-                                                       uint64_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_r1cs_rows_short(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
+                                                         const uint64_t* __restrict__ val, size_t m, const uint64_t* __restrict__ z,
+                                                         uint64_t* __restrict__ out, uint32_t* __restrict__ long_rows, uint32_t* __restrict__ long_count) {
   KG_SERVICE_PRIO();
-  const size_t row = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= m) return;
+  if (row_ptr[row + 1] - row_ptr[row] > SHORT_ROW) {
+    long_rows[atomicAdd(long_count, 1u)] = (uint32_t)row;
+    return;
+  }
   Fp<P> sum[1];
-  row_dot<P, 64, 1>(row_ptr, col, val, row, lane, z, z, sum);
-  if (lane == 0) {
-    uint32_t wo[8];
-    words_from_limbs(reduce_2p(sum[0]), wo);
-    store_words(out, row, wo);
+  row_dot<P, 1, 1>(row_ptr, col, val, row, 0, z, z, sum);
+  uint32_t wo[8];
+  words_from_limbs(reduce_2p(mul(sum[0], Fp<P>::from_const(P::C_FROM_REF))), wo);        // raw product domain -> the ABI's
+  store_words(out, row, wo);
+}
+template <class P>
+__global__ void __launch_bounds__(256) k_r1cs_rows_long(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
+                                                        const uint64_t* __restrict__ val, const uint64_t* __restrict__ z, uint64_t* __restrict__ out,
+                                                        const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ long_count) {
+  KG_SERVICE_PRIO();
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6), wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const uint32_t total = *long_count;
+  for (uint32_t i = wave; i < total; i += nwaves) {      // wave-uniform trip count: the shuffles inside row_dot see full waves
+    const size_t row = long_rows[i];
+    Fp<P> sum[1];
+    row_dot<P, 64, 1>(row_ptr, col, val, row, lane, z, z, sum);
+    if (lane == 0) {
+      uint32_t wo[8];
+      words_from_limbs(reduce_2p(mul(sum[0], Fp<P>::from_const(P::C_FROM_REF))), wo);
+      store_words(out, row, wo);
+    }
   }
 }
 
 // Nova's cross term (nova/src/prover.rs:53-90): T = AZ1 o BZ2 + AZ2 o BZ1 - u1 * CZ2 - u2 * CZ1, one kernel: every matrix row
-// is read once for both z vectors, the six matrix-vector products never touch memory.  8 lanes per constraint row.
+// is read once for both z vectors, the six matrix-vector products never touch memory.  ONE lane per constraint row: R1CS
+// rows hold a handful of terms (1.3 per matrix in the chain circuit), so a lane group per row leaves most lanes idle in the
+// entry loops and pays shuffle-tree merges for nothing -- 8 lanes per row ran at 230 GB/s of algorithmic traffic
+// (1.17 ms at 2^20 rows, instruction-bound), this form is bound by its ~12 products per row.  A long row only delays its own wave.
+// u1s, u2s: u * 2^266 as limbs (host-side), the factor form cross_term_row wants next to raw row sums.
 struct CsrView { const uint64_t* row_ptr; const uint64_t* col; const uint64_t* val; };
-constexpr int XT_G = 8;
+struct Limbs9 { uint32_t l[9]; };
 template <class P>
 __global__ void __launch_bounds__(256) k_nova_cross_term(CsrView A, CsrView B, CsrView C, size_t m, const uint64_t* __restrict__ z1,
-                                                         const uint64_t* __restrict__ z2, Words8 u1, Words8 u2, uint64_t* __restrict__ out) {
+                                                         const uint64_t* __restrict__ z2, Limbs9 u1s, Limbs9 u2s, uint64_t* __restrict__ out) {
   KG_SERVICE_PRIO();
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t row = t / XT_G;
-  const int lane = (int)(t % XT_G);
-  if (row >= m) return;                                  // whole groups leave together: XT_G divides the wave and the block
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= m) return;
   Fp<P> az[2], bz[2], cz[2];
-  row_dot<P, XT_G, 2>(A.row_ptr, A.col, A.val, row, lane, z1, z2, az);
-  row_dot<P, XT_G, 2>(B.row_ptr, B.col, B.val, row, lane, z1, z2, bz);
-  row_dot<P, XT_G, 2>(C.row_ptr, C.col, C.val, row, lane, z1, z2, cz);
-  if (lane != 0) return;
-  const Fp<P> r = cross_term_row(az[0], az[1], bz[0], bz[1], cz[0], cz[1], from_ref<P>(u1.w), from_ref<P>(u2.w), Fp<P>::from_const(P::C_FROM_REF));
+  row_dot<P, 1, 2>(A.row_ptr, A.col, A.val, row, 0, z1, z2, az);
+  row_dot<P, 1, 2>(B.row_ptr, B.col, B.val, row, 0, z1, z2, bz);
+  row_dot<P, 1, 2>(C.row_ptr, C.col, C.val, row, 0, z1, z2, cz);
+  const Fp<P> r = cross_term_row(az[0], az[1], bz[0], bz[1], cz[0], cz[1], Fp<P>::from_const(u1s.l), Fp<P>::from_const(u2s.l),
+                                 Fp<P>::from_const(P::C_XT_HAD));
   uint32_t wo[8];
   words_from_limbs(reduce_2p(r), wo);
   store_words(out, row, wo);
@@ -328,9 +359,19 @@ int kg_r1cs_prod(kg_ctx* c, int field, const uint64_t* row_ptr, const uint64_t* 
   if (m == 0) return KG_OK;
   if (!row_ptr || !col || !val || !z || !out) return KG_ERR_BAD_ARG;
   KG_HIP(c, hipSetDevice(c->device));
-  const dim3 grid((unsigned)((m + 3) / 4));
-  if (field == KG_FR) hipLaunchKernelGGL(k_r1cs_evaluate<FrParams>, grid, dim3(256), 0, c->stream, row_ptr, col, val, m, z, out);
-  else hipLaunchKernelGGL(k_r1cs_evaluate<FqParams>, grid, dim3(256), 0, c->stream, row_ptr, col, val, m, z, out);
+  if (m >= ((size_t)1 << 32)) return set_err(c, KG_ERR_BAD_ARG, "more than 2^32 rows");
+  KG_TRY(ensure_ws_vec(c, (m + 16) * 4));                 // work list of long rows + its counter (first word)
+  uint32_t* count = (uint32_t*)c->ws_vec;
+  uint32_t* list = count + 16;
+  KG_HIP(c, hipMemsetAsync(count, 0, 4, c->stream));
+  const dim3 grid((unsigned)((m + 255) / 256));
+  if (field == KG_FR) {
+    hipLaunchKernelGGL(k_r1cs_rows_short<FrParams>, grid, dim3(256), 0, c->stream, row_ptr, col, val, m, z, out, list, count);
+    hipLaunchKernelGGL(k_r1cs_rows_long<FrParams>, dim3(256), dim3(256), 0, c->stream, row_ptr, col, val, z, out, list, count);
+  } else {
+    hipLaunchKernelGGL(k_r1cs_rows_short<FqParams>, grid, dim3(256), 0, c->stream, row_ptr, col, val, m, z, out, list, count);
+    hipLaunchKernelGGL(k_r1cs_rows_long<FqParams>, dim3(256), dim3(256), 0, c->stream, row_ptr, col, val, z, out, list, count);
+  }
   KG_HIP(c, hipGetLastError());
   return KG_OK;
 }
@@ -347,13 +388,21 @@ int kg_nova_cross_term(kg_ctx* c, int field, const kg_csr* a, const kg_csr* b, c
   for (const kg_csr* x : {a, b, cm})
     if (!x->d_row_ptr || !x->d_col || !x->d_val) return KG_ERR_BAD_ARG;
   KG_HIP(c, hipSetDevice(c->device));
-  Words8 u1, u2;
-  for (int i = 0; i < 4; ++i) {
-    u1.w[2 * i] = (uint32_t)h_u1[i]; u1.w[2 * i + 1] = (uint32_t)(h_u1[i] >> 32);
-    u2.w[2 * i] = (uint32_t)h_u2[i]; u2.w[2 * i + 1] = (uint32_t)(h_u2[i] >> 32);
-  }
+  // u * 2^266 mod p as limbs: ten modular doublings of the ABI form u * 2^256
+  auto scaled = [&](const uint64_t* h_u, bool fr) {
+    Limbs9 out;
+    uint64_t w64[4];
+    if (fr) { HostFr x = HostFr::from_words(h_u); for (int i = 0; i < 10; ++i) x = dbl(x); for (int i = 0; i < 4; ++i) w64[i] = x.v[i]; }
+    else { HostFq x = HostFq::from_words(h_u); for (int i = 0; i < 10; ++i) x = dbl(x); for (int i = 0; i < 4; ++i) w64[i] = x.v[i]; }
+    uint32_t w[8];
+    for (int i = 0; i < 4; ++i) { w[2 * i] = (uint32_t)w64[i]; w[2 * i + 1] = (uint32_t)(w64[i] >> 32); }
+    const Fp<FrParams> lim = limbs_from_words<FrParams>(w);        // the spreading is the same for both fields
+    for (int k = 0; k < 9; ++k) out.l[k] = lim.l[k];
+    return out;
+  };
+  const Limbs9 u1 = scaled(h_u1, field == KG_FR), u2 = scaled(h_u2, field == KG_FR);
   const CsrView A{a->d_row_ptr, a->d_col, a->d_val}, B{b->d_row_ptr, b->d_col, b->d_val}, C{cm->d_row_ptr, cm->d_col, cm->d_val};
-  const dim3 grid((unsigned)((m * XT_G + 255) / 256));
+  const dim3 grid((unsigned)((m + 255) / 256));
   if (field == KG_FR) hipLaunchKernelGGL(k_nova_cross_term<FrParams>, grid, dim3(256), 0, c->stream, A, B, C, m, d_z1, d_z2, u1, u2, d_out);
   else hipLaunchKernelGGL(k_nova_cross_term<FqParams>, grid, dim3(256), 0, c->stream, A, B, C, m, d_z1, d_z2, u1, u2, d_out);
   KG_HIP(c, hipGetLastError());

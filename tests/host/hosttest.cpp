@@ -178,11 +178,12 @@ static void cross_term(const uint32_t* va, const uint32_t* vb, const uint32_t* v
   using P = typename F::Params;
   auto dot = [&](const uint32_t* v, const uint32_t* z) {
     F lane[4] = {F::zero(), F::zero(), F::zero(), F::zero()};
-    for (size_t k = 0; k < cnt; ++k) lane[k & 3] = dot_step(lane[k & 3], RawIn<F>::in(z + 8 * k), Conv<F>::in(v + 8 * k));
+    for (size_t k = 0; k < cnt; ++k) lane[k & 3] = dot_step(lane[k & 3], RawIn<F>::in(z + 8 * k), RawIn<F>::in(v + 8 * k));
     return dot_merge(dot_merge(lane[0], lane[1]), dot_merge(lane[2], lane[3]));
   };
-  const F r = cross_term_row(dot(va, z1), dot(va, z2), dot(vb, z1), dot(vb, z2), dot(vc, z1), dot(vc, z2), Conv<F>::in(u1), Conv<F>::in(u2),
-                             F::from_const(P::C_FROM_REF));
+  const F ku = F::from_const(P::C_XT_U);                 // u * 2^256 -> u * 2^266 (the kernel gets it from ten host-side doublings)
+  const F r = cross_term_row(dot(va, z1), dot(va, z2), dot(vb, z1), dot(vb, z2), dot(vc, z1), dot(vc, z2), mul(RawIn<F>::in(u1), ku),
+                             mul(RawIn<F>::in(u2), ku), F::from_const(P::C_XT_HAD));
   raw_out(r, out);
 }
 extern "C" void ht_cross_term(int field, int checked, const uint32_t* va, const uint32_t* vb, const uint32_t* vc, const uint32_t* z1,
