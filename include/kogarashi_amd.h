@@ -236,6 +236,15 @@ int kg_r1cs_prod(kg_ctx* ctx, int field, const uint64_t* d_row_ptr, const uint64
 typedef struct { const uint64_t* d_row_ptr; const uint64_t* d_col; const uint64_t* d_val; } kg_csr;
 int kg_nova_cross_term(kg_ctx* ctx, int field, const kg_csr* a, const kg_csr* b, const kg_csr* c, size_t m, const uint64_t* d_z1,
                        const uint64_t* d_z2, const uint64_t* h_u1, const uint64_t* h_u2, uint64_t* d_out);
+/* create_proof with cs.evaluate() (zkstd/src/r1cs.rs:137-142, prover.rs:33) on the device as well: the constraint matrices
+ * a, b, c (CSR over z = x || w, m = crs->m rows; resident, uploaded once per circuit) take the place of the three
+ * evaluation vectors -- each transform chain starts with its matrix-vector product.  Otherwise as kg_groth16_prove_bn254 /
+ * kg_groth16_prove_begin (the proof is collected with kg_groth16_prove_end). */
+int kg_groth16_prove_r1cs_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const kg_csr* a, const kg_csr* b, const kg_csr* c,
+                                const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r, const uint64_t* s, uint64_t* proof_out,
+                                uint8_t* proof_inf);
+int kg_groth16_prove_r1cs_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const kg_csr* a, const kg_csr* b, const kg_csr* c,
+                                const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r, const uint64_t* s, int ticket);
 
 /* ---- deterministic synthetic inputs (identical streams in oracle/) -------------------- */
 int kg_gen_scalars(kg_ctx* ctx, int field, uint64_t seed, size_t start, size_t n, uint64_t* d_out);

@@ -175,6 +175,24 @@ class Prover:
         da, db, dc, dx, dw = up(a_eval), up(b_eval), up(c_eval), up(x), up(w)
         return self.ctx.groth16_prove(self.crs, da.ptr, db.ptr, dc.ptr, dx.ptr, dw.ptr, r, s)
 
+    def attach_constraint_system(self, a, b, c):
+        """The circuit's constraint matrices (CSR triples (row_ptr, col, val) over z = x || w, cs.matrices()): uploaded once;
+        create_proof_from_witness then runs cs.evaluate() (zkstd/src/r1cs.rs:137-142) on the device as well."""
+        self._cs = []
+        for rp, col, val in (a, b, c):
+            val = np.ascontiguousarray(val, dtype=np.uint64).reshape(-1, 4)
+            col = np.ascontiguousarray(col, dtype=np.uint64)
+            self._cs.append((self.ctx.upload(np.ascontiguousarray(rp, dtype=np.uint64)),
+                             self.ctx.upload(col if len(col) else np.zeros(1, dtype=np.uint64)),
+                             self.ctx.upload(val if len(val) else np.zeros((1, 4), dtype=np.uint64))))
+
+    def create_proof_from_witness(self, x, w, r, s):
+        """create_proof from (x, w) alone: the evaluation vectors are made on the device (kg_groth16_prove_r1cs_bn254)"""
+        up = lambda v: self.ctx.upload(np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4))
+        dx, dw = up(x), up(w)
+        ptrs = [tuple(d.ptr for d in trip) for trip in self._cs]
+        return self.ctx.groth16_prove_r1cs(self.crs, ptrs[0], ptrs[1], ptrs[2], dx.ptr, dw.ptr, r, s)
+
     def create_proofs(self, jobs):
         """Proofs for an iterable of (a_eval, b_eval, c_eval, x, w, r, s), two in flight (kg_groth16_prove_begin / _end):
         proof i+1 is enqueued before proof i is collected, so its transforms and sorts overlap proof i's last reduction

@@ -229,6 +229,9 @@ struct MsmSorted {
   // real window count, an entry's index field is (window << merged_shift) | scalar index
   int merged_shift = 0, windows = 0;
 };
+// vec.hip: CSR matrix-vector product on a given queue; scratch = (m + 16) words (kg_ctx::ws_vec holds three such regions)
+int r1cs_prod_enqueue(kg_ctx* c, hipStream_t st, int field, const uint64_t* row_ptr, const uint64_t* col, const uint64_t* val, size_t m,
+                      const uint64_t* z, uint64_t* out, uint32_t* scratch);
 // ntt.hip
 int ntt_prepare(kg_ctx* ctx, uint32_t log_n, int inverse);
 int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, uint32_t log_n, int inverse, int coset);

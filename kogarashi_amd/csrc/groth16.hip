@@ -319,10 +319,16 @@ ProofJob* job_of(kg_ctx* ctx, int i) {
 
 // Enqueues the whole proof on the device and starts the host-side assembly on a worker thread; returns once h's MSM is
 // on the queue (the scalar sorts read two words back, so this call spans most of the proof's device time).
+// mats != nullptr: the constraint matrices (CSR over z = x || w) instead of the three evaluation vectors -- cs.evaluate()
+// (zkstd/src/r1cs.rs:137-142) then runs on the device as the first step of each transform chain.
 int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
                   const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
-                  const uint64_t* s, ProofJob* job, int slot_base) {
-  if (!ctx || !crs || !d_a_eval || !d_b_eval || !d_c_eval || !d_x || !r || !s) return KG_ERR_BAD_ARG;
+                  const uint64_t* s, ProofJob* job, int slot_base, const kg_csr* const* mats = nullptr) {
+  if (!ctx || !crs || !d_x || !r || !s) return KG_ERR_BAD_ARG;
+  if (!mats && (!d_a_eval || !d_b_eval || !d_c_eval)) return KG_ERR_BAD_ARG;
+  if (mats)
+    for (int v = 0; v < 3; ++v)
+      if (!mats[v] || !mats[v]->d_row_ptr || !mats[v]->d_col || !mats[v]->d_val) return KG_ERR_BAD_ARG;
   const size_t m = crs->m, l = crs->l, m_l_1 = crs->m_l_1;
   if (m < 1 || l < 1 || (m_l_1 && !d_w)) return KG_ERR_BAD_ARG;
   KG_HIP(ctx, hipSetDevice(ctx->device));
@@ -374,6 +380,11 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // transform chains and its two result words are awaited after them.
   KG_HIP(ctx, hipMemcpyAsync(Z, d_x, l * 32, hipMemcpyDeviceToDevice, sq));
   if (m_l_1) KG_HIP(ctx, hipMemcpyAsync(Z + 4 * l, d_w, m_l_1 * 32, hipMemcpyDeviceToDevice, sq));
+  if (mats) {
+    if (m >= ((size_t)1 << 32)) return set_err(ctx, KG_ERR_BAD_ARG, "more than 2^32 constraints");
+    KG_TRY(ensure_ws_vec(ctx, 3 * (m + 16) * 4));
+    KG_HIP(ctx, hipEventRecord(ctx->ev_order, sq));       // z is complete: the matrix-vector products of the chains wait for it
+  }
   MsmSorted Sz;
   // window tables on all four vectors that meet z (kg_bases_precompute): one merged sort, one set of buckets for all windows
   const bool tz = has_window_table(ctx, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, nz) && has_window_table(ctx, KG_G1, crs->d_a, crs->d_a_inf, nz, nz) &&
@@ -392,7 +403,12 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
     hipStream_t sv = lanes[v];
     uint64_t* tmp = TMP + (size_t)v * 4 * n;
     if (fork) hip_rc(hipStreamWaitEvent(sv, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
-    hip_rc(hipMemcpyAsync(dst[v], src[v], m * 32, hipMemcpyDeviceToDevice, sv), "hipMemcpyAsync(evaluations)");
+    if (mats) {                                           // row v of cs.evaluate(): M_v z, z as the scalar queue assembled it
+      hip_rc(hipStreamWaitEvent(sv, ctx->ev_order, 0), "hipStreamWaitEvent(z)");
+      if (rc == KG_OK) rc = r1cs_prod_enqueue(ctx, sv, KG_FR, mats[v]->d_row_ptr, mats[v]->d_col, mats[v]->d_val, m, Z, dst[v],
+                                              (uint32_t*)ctx->ws_vec + (size_t)v * (m + 16));
+    } else
+      hip_rc(hipMemcpyAsync(dst[v], src[v], m * 32, hipMemcpyDeviceToDevice, sv), "hipMemcpyAsync(evaluations)");
     if (n > m) hip_rc(hipMemsetAsync(dst[v] + 4 * m, 0, (n - m) * 32, sv), "hipMemsetAsync(padding)");
     if (rc == KG_OK) rc = ntt_enqueue(ctx, sv, tmp, dst[v], k, 1, 0);
     if (rc == KG_OK) rc = ntt_enqueue(ctx, sv, tmp, dst[v], k, 0, 1);
@@ -545,6 +561,23 @@ int kg_groth16_prove_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
                            const uint64_t* s, int ticket) {
   if (!ctx || ticket < 0 || ticket > 1 || job_of(ctx, ticket)->active) return KG_ERR_BAD_ARG;
   return prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job_of(ctx, ticket), 5 + 5 * ticket);
+}
+// The same with cs.evaluate() on the device: the constraint matrices (resident CSR) instead of the evaluation vectors
+int kg_groth16_prove_r1cs_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const kg_csr* a, const kg_csr* b, const kg_csr* c,
+                                const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r, const uint64_t* s, uint64_t* proof_out,
+                                uint8_t* proof_inf) {
+  if (!ctx || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
+  ProofJob* job = job_of(ctx, 0);
+  if (job->active) return KG_ERR_BAD_ARG;
+  const kg_csr* mats[3] = {a, b, c};
+  KG_TRY(prove_enqueue(ctx, crs, nullptr, nullptr, nullptr, d_x, d_w, r, s, job, 5, mats));
+  return prove_collect(ctx, job, proof_out, proof_inf);
+}
+int kg_groth16_prove_r1cs_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const kg_csr* a, const kg_csr* b, const kg_csr* c,
+                                const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r, const uint64_t* s, int ticket) {
+  if (!ctx || ticket < 0 || ticket > 1 || job_of(ctx, ticket)->active) return KG_ERR_BAD_ARG;
+  const kg_csr* mats[3] = {a, b, c};
+  return prove_enqueue(ctx, crs, nullptr, nullptr, nullptr, d_x, d_w, r, s, job_of(ctx, ticket), 5 + 5 * ticket, mats);
 }
 int kg_groth16_prove_end(kg_ctx* ctx, int ticket, uint64_t* proof_out, uint8_t* proof_inf) {
   if (!ctx || ticket < 0 || ticket > 1 || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;

@@ -354,26 +354,38 @@ int kg_field_vec_axpy(kg_ctx* c, int field, const uint64_t* a, const uint64_t* h
   return KG_OK;
 }
 
+}  // extern "C"
+
+namespace kg {
+// The product on a queue of the caller's choice; scratch: (m + 16) words for the work list of long rows.
+int r1cs_prod_enqueue(kg_ctx* c, hipStream_t st, int field, const uint64_t* row_ptr, const uint64_t* col, const uint64_t* val, size_t m,
+                      const uint64_t* z, uint64_t* out, uint32_t* scratch) {
+  uint32_t* count = scratch;
+  uint32_t* list = scratch + 16;
+  KG_HIP(c, hipMemsetAsync(count, 0, 4, st));
+  const dim3 grid((unsigned)((m + 255) / 256));
+  if (field == KG_FR) {
+    hipLaunchKernelGGL(k_r1cs_rows_short<FrParams>, grid, dim3(256), 0, st, row_ptr, col, val, m, z, out, list, count);
+    hipLaunchKernelGGL(k_r1cs_rows_long<FrParams>, dim3(256), dim3(256), 0, st, row_ptr, col, val, z, out, list, count);
+  } else {
+    hipLaunchKernelGGL(k_r1cs_rows_short<FqParams>, grid, dim3(256), 0, st, row_ptr, col, val, m, z, out, list, count);
+    hipLaunchKernelGGL(k_r1cs_rows_long<FqParams>, dim3(256), dim3(256), 0, st, row_ptr, col, val, z, out, list, count);
+  }
+  KG_HIP(c, hipGetLastError());
+  return KG_OK;
+}
+}  // namespace kg
+
+extern "C" {
+
 int kg_r1cs_prod(kg_ctx* c, int field, const uint64_t* row_ptr, const uint64_t* col, const uint64_t* val, size_t m, const uint64_t* z, uint64_t* out) {
   if (!c || (field != KG_FR && field != KG_FQ)) return KG_ERR_BAD_ARG;
   if (m == 0) return KG_OK;
   if (!row_ptr || !col || !val || !z || !out) return KG_ERR_BAD_ARG;
   KG_HIP(c, hipSetDevice(c->device));
   if (m >= ((size_t)1 << 32)) return set_err(c, KG_ERR_BAD_ARG, "more than 2^32 rows");
-  KG_TRY(ensure_ws_vec(c, (m + 16) * 4));                 // work list of long rows + its counter (first word)
-  uint32_t* count = (uint32_t*)c->ws_vec;
-  uint32_t* list = count + 16;
-  KG_HIP(c, hipMemsetAsync(count, 0, 4, c->stream));
-  const dim3 grid((unsigned)((m + 255) / 256));
-  if (field == KG_FR) {
-    hipLaunchKernelGGL(k_r1cs_rows_short<FrParams>, grid, dim3(256), 0, c->stream, row_ptr, col, val, m, z, out, list, count);
-    hipLaunchKernelGGL(k_r1cs_rows_long<FrParams>, dim3(256), dim3(256), 0, c->stream, row_ptr, col, val, z, out, list, count);
-  } else {
-    hipLaunchKernelGGL(k_r1cs_rows_short<FqParams>, grid, dim3(256), 0, c->stream, row_ptr, col, val, m, z, out, list, count);
-    hipLaunchKernelGGL(k_r1cs_rows_long<FqParams>, dim3(256), dim3(256), 0, c->stream, row_ptr, col, val, z, out, list, count);
-  }
-  KG_HIP(c, hipGetLastError());
-  return KG_OK;
+  KG_TRY(ensure_ws_vec(c, 3 * (m + 16) * 4));             // work lists of long rows (three: the prover runs three products at once)
+  return kg::r1cs_prod_enqueue(c, c->stream, field, row_ptr, col, val, m, z, out, (uint32_t*)c->ws_vec);
 }
 
 int kg_r1cs_evaluate(kg_ctx* c, const uint64_t* row_ptr, const uint64_t* col, const uint64_t* val, size_t m, const uint64_t* z, uint64_t* out) {

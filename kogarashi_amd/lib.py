@@ -24,7 +24,7 @@ EXPORTS = [
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
     "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
-    "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window",
+    "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_r1cs_begin",
 ]
 
 
@@ -287,6 +287,31 @@ class Context:
         rc = self._lib.kg_groth16_prove_begin(self._h, C.byref(crs), _vp(a_eval), _vp(b_eval), _vp(c_eval), _vp(x), _vp(w),
                                               r.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), int(ticket))
         self._chk(rc, "kg_groth16_prove_begin")
+
+    def groth16_prove_r1cs(self, crs: "Groth16Crs", a, b, c, x: int, w: int, r: np.ndarray, s: np.ndarray):
+        """kg_groth16_prove_r1cs_bn254: a, b, c = (row_ptr, col, val) device pointers of the constraint matrices (CSR over x || w)"""
+        mk = lambda t: Csr(_vp(t[0]), _vp(t[1]), _vp(t[2]))
+        ca, cb, cc = mk(a), mk(b), mk(c)
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        s = np.ascontiguousarray(s, dtype=np.uint64)
+        out = np.zeros(32, dtype=np.uint64)
+        inf = np.zeros(3, dtype=np.uint8)
+        rc = self._lib.kg_groth16_prove_r1cs_bn254(self._h, C.byref(crs), C.byref(ca), C.byref(cb), C.byref(cc), _vp(x), _vp(w),
+                                                   r.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p),
+                                                   out.ctypes.data_as(C.c_void_p), inf.ctypes.data_as(C.c_void_p))
+        if rc == -6:
+            raise ProverSubVersionCrsAttack("delta is the identity")
+        self._chk(rc, "kg_groth16_prove_r1cs_bn254")
+        return out[:8].copy(), out[8:24].copy(), out[24:].copy(), inf
+
+    def groth16_prove_r1cs_begin(self, crs: "Groth16Crs", a, b, c, x: int, w: int, r: np.ndarray, s: np.ndarray, ticket: int):
+        mk = lambda t: Csr(_vp(t[0]), _vp(t[1]), _vp(t[2]))
+        ca, cb, cc = mk(a), mk(b), mk(c)
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        s = np.ascontiguousarray(s, dtype=np.uint64)
+        rc = self._lib.kg_groth16_prove_r1cs_begin(self._h, C.byref(crs), C.byref(ca), C.byref(cb), C.byref(cc), _vp(x), _vp(w),
+                                                   r.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), int(ticket))
+        self._chk(rc, "kg_groth16_prove_r1cs_begin")
 
     def groth16_prove_end(self, ticket: int):
         out = np.zeros(32, dtype=np.uint64)

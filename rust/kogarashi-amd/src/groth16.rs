@@ -1,20 +1,25 @@
 //! `groth16/src/prover.rs:20-99` on the device: the CRS (`Parameters`, params.rs:6-28) is uploaded and converted to
-//! the MSM's internal form once per `Prover` (it is immutable); a proof uploads `cs.evaluate()`, `cs.x()`, `cs.w()`,
-//! runs 7 transforms, the fused h = (a o b - c) / Z, five MSMs (the reference's eight, merged) and the host assembly
-//! inside `kg_groth16_prove_bn254`, and returns the three affine points.
+//! the MSM's internal form once per `Prover` (it is immutable), and so are the constraint matrices of the circuit; a proof
+//! uploads `cs.x()`, `cs.w()`, runs `cs.evaluate()` (three sparse products), 7 transforms, the fused h = (a o b - c) / Z,
+//! five MSMs (the reference's eight, merged) and the host assembly inside `kg_groth16_prove_r1cs_bn254`, and returns the
+//! three affine points.  (`prove` takes host-side evaluation vectors instead.)
 use std::collections::HashMap;
 use std::sync::{Arc, Mutex, OnceLock};
 
 use bn_254::{Fr, G1Affine, G2Affine};
 use kogarashi_amd_sys as sys;
 use zkstd::common::CurveGroup;
+use zkstd::matrix::SparseMatrix;
 
+use crate::csr::ResidentShape;
 use crate::{contexts, marshal, DeviceBuf, GpuCurve, Status};
 
 /// Device-resident `Parameters` (+ the vk points the assembly needs).  Built once, e.g. in `Prover::new`/first proof.
 pub struct ResidentCrs {
     crs: sys::KgGroth16Crs,
     _bufs: Vec<DeviceBuf>,
+    /// the circuit's constraint matrices, resident as CSR (uploaded by the first `prove_cs`, replaced when the content changes)
+    shape: Mutex<Option<ResidentShape>>,
 }
 unsafe impl Send for ResidentCrs {}
 unsafe impl Sync for ResidentCrs {}
@@ -83,7 +88,36 @@ impl ResidentCrs {
             beta_g2: words16(beta_g2), delta_g2: words16(delta_g2),
             delta_g1_inf: delta_g1.is_identity() as u8, delta_g2_inf: delta_g2.is_identity() as u8,
         };
-        Ok(Self { crs, _bufs: bufs })
+        Ok(Self { crs, _bufs: bufs, shape: Mutex::new(None) })
+    }
+
+    /// One proof from the constraint system itself: (a, b, c) = cs.matrices(), x = cs.x(), w = cs.w(); `cs.evaluate()` runs on
+    /// the device (each transform chain starts with its matrix-vector product).  (r, s) as for `prove`.
+    #[allow(clippy::too_many_arguments)]
+    pub fn prove_cs(&self, a: &SparseMatrix<Fr>, b: &SparseMatrix<Fr>, c: &SparseMatrix<Fr>, x: &[Fr], w: &[Fr], r: &Fr, s: &Fr)
+                    -> Result<(G1Affine, G2Affine, G1Affine), Status> {
+        let ctxs = contexts().ok_or(Status(sys::KG_ERR_NO_DEVICE))?;
+        let ctx = &ctxs[0];
+        let mut shape = self.shape.lock().map_err(|_| Status(sys::KG_ERR_BAD_ARG))?;
+        let (host, print) = ResidentShape::host(a, b, c, x.len()).ok_or(Status(sys::KG_ERR_BAD_ARG))?;
+        if shape.as_ref().map(|s| s.fingerprint != print).unwrap_or(true) {
+            *shape = Some(ResidentShape::upload(ctx, &host, print).ok_or(Status(sys::KG_ERR_OOM))?);
+        }
+        let m3 = &shape.as_ref().unwrap().m;
+        let (ca, cb, cc) = (m3[0].csr(), m3[1].csr(), m3[2].csr());
+        let up = |v: &[Fr]| DeviceBuf::from_words(ctx, unsafe { core::slice::from_raw_parts(v.as_ptr() as *const u64, 4 * v.len()) });
+        let (dx, dw) = (up(x)?, up(w)?);
+        let mut out = [0u64; 32];
+        let mut inf = [0u8; 3];
+        let rc = unsafe {
+            sys::kg_groth16_prove_r1cs_bn254(ctx.raw(), &self.crs, &ca, &cb, &cc, dx.as_u64(), dw.as_u64(), r.inner().as_ptr(),
+                                             s.inner().as_ptr(), out.as_mut_ptr(), inf.as_mut_ptr())
+        };
+        if rc != sys::KG_OK {
+            return Err(Status(rc));
+        }
+        Ok((G1Affine::affine_from(&out[0..8], inf[0] != 0), G2Affine::affine_from(&out[8..24], inf[1] != 0),
+            G1Affine::affine_from(&out[24..32], inf[2] != 0)))
     }
 
     /// One proof: (a, b, c) = cs.evaluate(), x = cs.x(), w = cs.w(), (r, s) drawn by the caller from its rng exactly

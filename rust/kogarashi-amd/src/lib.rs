@@ -23,6 +23,7 @@ use grumpkin::{Affine as GkAffine, Projective as GkProjective};
 use kogarashi_amd_sys as sys;
 use zkstd::common::{BNAffine, BNProjective, CurveGroup, Group};
 
+mod csr;
 pub mod fft;
 pub mod groth16;
 pub mod nova;

@@ -11,55 +11,10 @@ use kogarashi_amd_sys as sys;
 use zkstd::common::PrimeField;
 use zkstd::matrix::SparseMatrix;
 
-use crate::{contexts, scalar_words, Context, DeviceBuf};
-
-struct ResidentMatrix {
-    row_ptr: DeviceBuf,
-    col: DeviceBuf,
-    val: DeviceBuf,
-}
-impl ResidentMatrix {
-    fn csr(&self) -> sys::KgCsr {
-        sys::KgCsr { d_row_ptr: self.row_ptr.as_u64() as *const u64, d_col: self.col.as_u64() as *const u64, d_val: self.val.as_u64() as *const u64 }
-    }
-}
-struct ResidentShape {
-    m: [ResidentMatrix; 3],
-    fingerprint: Vec<u64>,
-}
-unsafe impl Send for ResidentShape {}
+use crate::csr::ResidentShape;
+use crate::{contexts, scalar_words, DeviceBuf};
 
 static SHAPES: OnceLock<Mutex<HashMap<(usize, usize, usize, i32), ResidentShape>>> = OnceLock::new();
-
-struct HostCsr {
-    row_ptr: Vec<u64>,
-    col: Vec<u64>,
-    val: Vec<u64>,
-}
-impl HostCsr {
-    /// `SparseMatrix::to_csr` plus the coefficients as the ABI's words
-    fn of<F: PrimeField + 'static>(mat: &SparseMatrix<F>, l: usize) -> Option<Self> {
-        let (row_ptr, col, val) = mat.to_csr(l);
-        let (words, _) = scalar_words(&val)?;
-        let val = unsafe { core::slice::from_raw_parts(words, 4 * val.len()) }.to_vec();
-        Some(Self { row_ptr, col, val })
-    }
-    fn fingerprint(&self, out: &mut Vec<u64>) {
-        out.extend([self.row_ptr.len() as u64, self.col.len() as u64]);
-        out.extend(self.col.iter().take(8));
-        out.extend(self.col.iter().rev().take(8));
-        out.extend(self.val.iter().take(16));
-        out.extend(self.val.iter().rev().take(16));
-    }
-    fn upload(&self, ctx: &Context) -> Option<ResidentMatrix> {
-        let pad = [0u64; 4];
-        Some(ResidentMatrix {
-            row_ptr: DeviceBuf::from_words(ctx, &self.row_ptr).ok()?,
-            col: DeviceBuf::from_words(ctx, if self.col.is_empty() { &pad[..1] } else { &self.col }).ok()?,
-            val: DeviceBuf::from_words(ctx, if self.val.is_empty() { &pad[..] } else { &self.val }).ok()?,
-        })
-    }
-}
 
 /// The cross term of a folding step; `None` (no device, a field the backend does not serve, any non-zero status) lets the
 /// caller's CPU body run.  `l` = x.len() + 1 for both pairs (the relaxed instance and the fresh one share the shape).
@@ -75,14 +30,11 @@ pub fn cross_term<F: PrimeField + 'static>(a: &SparseMatrix<F>, b: &SparseMatrix
     let mut shapes = SHAPES.get_or_init(|| Mutex::new(HashMap::new())).lock().ok()?;
     // the host CSR is rebuilt per call (the matrices arrive as fresh clones); the device copy is reused while its
     // fingerprint matches
-    let host = [HostCsr::of(a, l)?, HostCsr::of(b, l)?, HostCsr::of(c, l)?];
+    let (host, print) = ResidentShape::host(a, b, c, l)?;
     let nnz: usize = host.iter().map(|h| h.col.len()).sum();
     let key = (m as usize, l, nnz, field);
-    let mut print = Vec::new();
-    host.iter().for_each(|h| h.fingerprint(&mut print));
     if shapes.get(&key).map(|s| s.fingerprint != print).unwrap_or(true) {
-        let m3 = [host[0].upload(ctx)?, host[1].upload(ctx)?, host[2].upload(ctx)?];
-        shapes.insert(key, ResidentShape { m: m3, fingerprint: print });
+        shapes.insert(key, ResidentShape::upload(ctx, &host, print)?);
     }
     let shape = shapes.get(&key)?;
     let words = |s: &[F]| unsafe { core::slice::from_raw_parts(s.as_ptr() as *const u64, 4 * s.len()) };

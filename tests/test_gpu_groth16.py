@@ -320,3 +320,44 @@ def test_fixed_base_mul_windowed(ctx, oracle, curve, sfd, w, n):
     ctx.fixed_base_mul(curve, dk.ptr, n, dxy.ptr, dinf.ptr)          # second call: cached table
     assert (dxy.numpy() == want_xy).all()
 
+
+
+@pytest.mark.parametrize("m", [300, 5000, 70000])
+def test_proof_from_witness_evaluates_on_the_device(ctx, oracle, m):
+    """kg_groth16_prove_r1cs_bn254 / _begin: the constraint matrices take the place of cs.evaluate()'s three vectors (each
+    transform chain starts with its matrix-vector product) -- the proofs equal those made from host-side evaluations, blocking
+    and in flight, in both input-ordering modes."""
+    import kogarashi_amd as K
+    O = oracle
+    if m <= 5000:
+        cs = O.chain_r1cs(m, O.gen_scalars(0, SEED + 1500 + m, 0, 1)[0])
+        params = O.groth16_params(cs, O.gen_scalars(0, SEED + 1501, 0, 5), threads=8)
+        params["vk_g2"] = params["vk_g2"][:2]
+        shape, x, w, l, m_l_1 = (cs.a, cs.b, cs.c), cs.x, cs.w, cs.l, cs.m_l_1
+        a_ev, b_ev, c_ev = cs.evaluate()
+    else:                                            # device setup for the larger circuit
+        from kogarashi_amd import synthetic as syn
+        from kogarashi_amd.api import groth16_setup
+        cc = syn.ChainCircuit(m)
+        params = groth16_setup(cc.a, cc.b, cc.c, m, cc.l, cc.m_l_1, syn.fixed_toxic(), syn.FrOps, ctx=ctx)
+        shape, x, w, l, m_l_1 = (cc.a, cc.b, cc.c), cc.x, cc.w, cc.l, cc.m_l_1
+        a_ev, b_ev, c_ev = cc.a_eval, cc.b_eval, cc.c_eval
+    r, s = O.gen_scalars(0, SEED + 1502, 0, 2)
+    prover = K.Prover(params, m, l, m_l_1, ctx=ctx)
+    want = prover.create_proof(a_ev, b_ev, c_ev, x, w, r, s)
+    prover.attach_constraint_system(*shape)
+    got = prover.create_proof_from_witness(x, w, r, s)
+    assert all((got[i] == want[i]).all() for i in range(4))
+    up = lambda v: ctx.upload(np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4))
+    dx, dw = up(x), up(w)
+    ptrs = [tuple(d.ptr for d in trip) for trip in prover._cs]
+    for complete in (False, True):
+        ctx.set_inputs_complete(complete)
+        try:
+            ctx.groth16_prove_r1cs_begin(prover.crs, ptrs[0], ptrs[1], ptrs[2], dx.ptr, dw.ptr, r, s, 0)
+            ctx.groth16_prove_r1cs_begin(prover.crs, ptrs[0], ptrs[1], ptrs[2], dx.ptr, dw.ptr, r, s, 1)
+            for t in (0, 1):
+                g = ctx.groth16_prove_end(t)
+                assert all((g[i] == want[i]).all() for i in range(4)), (complete, t)
+        finally:
+            ctx.set_inputs_complete(False)
