@@ -106,8 +106,8 @@ __global__ void __launch_bounds__(PREP_NT) k_prep_scalars_count(const uint64_t* 
   }
 }
 
-// Resident form of a base: the 9 x 29-bit limbs of each coordinate as they are (internal Montgomery form, < 2p), i.e. 72
-// bytes per G1 / Grumpkin point and 144 per G2 point instead of the ABI's 64 / 128.  The gather pays 12.5 % more bytes
+// Limb form of a resident base (KG_FMT64_MIN_LOG=30; the default is the 64-byte form below): the 9 x 29-bit limbs of each
+// coordinate as they are (internal Montgomery form, < 2p), i.e. 72 bytes per G1 / Grumpkin point and 144 per G2 point.  The gather pays 12.5 % more bytes
 // -- it is not what bounds the accumulation -- and the ~50 shift / mask instructions per addition that re-spread 8
 // words over 9 limbs disappear.  The identity flag rides in bit 31 of the first coordinate's top limb (< 2^23).
 template <class F> struct FieldOf;
@@ -130,10 +130,9 @@ template <class P> struct BaseIO<Fp<P>> {
     for (int j = 0; j < 9; ++j) r.l[j] = w[j];
     return r;
   }
-  // 64-byte form of the same point (used where the gathers leave the Infinity Cache -- arrays of >= 2^22 points, window
-  // tables): the limbs of a value < 2p < 2^255 re-packed into 8 words per coordinate, identity flag in bit 255 of x.  A
-  // 72-byte point always straddles two 64-byte sectors, a 64-byte one is exactly one; the price is ~50 shift / mask
-  // instructions per addition to spread the words over the limbs again.
+  // 64-byte form of the same point (the default, see resident_fmt64): the limbs of a value < 2p < 2^255 re-packed into 8
+  // words per coordinate, identity flag in bit 255 of x.  A 72-byte point always straddles two 64-byte sectors, a 64-byte
+  // one is exactly one; the price is ~50 shift / mask instructions per addition to spread the words over the limbs again.
   static constexpr int PK = 8;   // u32 words of a packed element
   static __device__ __forceinline__ void pack(const Fp<P>& v, uint32_t* dst) { words_from_limbs(v, dst); }
   static __device__ __forceinline__ bool load_point64(const uint32_t* src, Fp<P>& x, Fp<P>& y) {
@@ -1378,10 +1377,13 @@ void store_projective(const XYZZ<typename Cfg::HF>& p, uint64_t* out_xyz) {
   HostIO<HF>::store(HF::one(), out_xyz + 2 * E);
 }
 
-// Which resident form an array of n bases gets: 64-byte points once the array no longer fits the Infinity Cache (measured:
-// accumulation 12.4 G additions/s at 2^24 with 72-byte points against 14.7 G/s at 2^20); KG_FMT64_MIN_LOG overrides (experiments).
+// Which resident form an array of n bases gets.  The 64-byte point is the default at every size: its ~50 re-spreading
+// instructions per addition cost 1-2 % of the accumulation when it runs alone, but in the pipeline -- where the next sort and
+// the previous reductions compete for the memory system -- halving the sectors per gather wins (2^20: 1.452 -> 1.421 ms per
+// step; 2^22 blocking 6.40 -> 6.19 ms; the PMC traffic of a launch halves).  KG_FMT64_MIN_LOG=30 brings the 72-byte form back
+// (experiments, and the cross-format test).
 static bool resident_fmt64(size_t n) {
-  static const int min_log = getenv("KG_FMT64_MIN_LOG") ? atoi(getenv("KG_FMT64_MIN_LOG")) : 22;
+  static const int min_log = getenv("KG_FMT64_MIN_LOG") ? atoi(getenv("KG_FMT64_MIN_LOG")) : 0;
   return n >= ((size_t)1 << min_log);
 }
 static bool table_fmt64() {
