@@ -15,7 +15,8 @@ def last_json_line(path):
     raise SystemExit(f"no JSON line in {path}")
 
 
-for name, out in (("bench.json", f"{rnd}_bench.json"), ("bench_under_rocprof.json", f"{rnd}_bench_under_rocprof.json")):
+for name, out in (("bench.json", f"{rnd}_bench.json"), ("bench_under_rocprof.json", f"{rnd}_bench_under_rocprof.json"),
+                  ("msm_under_rocprof.json", f"{rnd}_msm_under_rocprof.json")):
     json.dump(last_json_line(os.path.join(src, name)), open(os.path.join(dst, out), "w"), indent=1)
 for d, out in (("kt_bench", f"{rnd}_bench_kernel_stats.csv"), ("kt_msm", f"{rnd}_msm_kernel_stats.csv")):
     f = glob.glob(os.path.join(src, d, "*", "*kernel_stats.csv"))[0]
