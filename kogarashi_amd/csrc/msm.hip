@@ -404,12 +404,6 @@ __device__ __forceinline__ void scan_row(const uint32_t* __restrict__ in, int B,
   }
   if (threadIdx.x == 0 && row_total) row_total[w] = total;
 }
-// per window: exclusive prefix of bucket sizes -> bucket start inside the window's sorted list
-__global__ void __launch_bounds__(1024) k_scan_buckets(const uint32_t* __restrict__ bsize, int B, uint32_t* __restrict__ bstart) {
-  KG_SERVICE_PRIO();
-  scan_row(bsize, B, bstart, nullptr, blockIdx.x);
-}
-
 // shift = 0: final entries (index | sign << 31) in bucket order.  shift = FINE_BITS: first pass of the two-pass sort --
 // entries land in their bucket GROUP and carry the bucket's low bits (index | fine << 24 | sign << 31).  A workgroup then
 // has only B >> shift open output runs, so the L2 sees every line completed before it is evicted (the one-pass
@@ -445,18 +439,6 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint32_t* __restrict__ k
 // LDS and copies it out run by run, so consecutive lanes write consecutive addresses.
 // ---------------------------------------------------------------------------------------------------
 constexpr int FINE_BITS = 7, FINE = 1 << FINE_BITS, SEG = 8192;
-
-// segbase[w][g] = first segment of group g (exclusive prefix of ceil(size / SEG)); segbase[w][G] = segments of window w
-__global__ void __launch_bounds__(1024) k_seg_table(const uint32_t* __restrict__ gsize, int G, uint32_t* __restrict__ segbase) {
-  KG_SERVICE_PRIO();
-  __shared__ uint32_t sh[40];
-  const int w = blockIdx.x, g = threadIdx.x;
-  const uint32_t ns = g < G ? (gsize[(size_t)w * G + g] + SEG - 1) / SEG : 0;
-  uint32_t total;
-  const uint32_t ex = block_exclusive_scan_1024(ns, sh, total);
-  if (g < G) segbase[(size_t)w * (G + 1) + g] = ex;
-  if (g == 0) segbase[(size_t)w * (G + 1) + G] = total;
-}
 
 // First pass of the two-pass sort, staged through LDS: a workgroup walks its (scalar chunk, window) pair in tiles of
 // GS_TILE entries, ranks a tile's entries inside their bucket group with LDS atomics, lays the tile out group by group
@@ -822,31 +804,6 @@ struct PointAoS<Fp2S<G>> {
 constexpr int LEN_BINS = 256;
 __device__ __forceinline__ uint32_t len_key(uint32_t len) { return len > 255u ? 255u : len; }
 
-__global__ void __launch_bounds__(1024) k_len_hist(const uint32_t* __restrict__ bsize, const uint32_t* __restrict__ ntask, size_t total, uint32_t T,
-                                                   uint32_t* __restrict__ ghist) {
-  KG_SERVICE_PRIO();
-  __shared__ uint32_t h[LEN_BINS];
-  if (threadIdx.x < LEN_BINS) h[threadIdx.x] = 0;
-  __syncthreads();
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < total) {
-    const uint32_t nt = ntask[t];
-    if (nt) {
-      const uint32_t rem = bsize[t] - (nt - 1) * T;
-      atomicAdd(&h[len_key(rem)], 1u);
-      if (nt > 1) atomicAdd(&h[len_key(T)], nt - 1);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < LEN_BINS && h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
-}
-// cursor[k] = number of tasks with a larger key (descending layout)
-__global__ void k_len_scan(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ cursor) {
-  KG_SERVICE_PRIO();
-  if (threadIdx.x || blockIdx.x) return;
-  uint32_t run = 0;
-  for (int k = LEN_BINS - 1; k >= 0; --k) { cursor[k] = run; run += ghist[k]; }
-}
 __global__ void __launch_bounds__(1024) k_len_scatter(const uint32_t* __restrict__ bsize, const uint32_t* __restrict__ ntask,
                                                       const uint32_t* __restrict__ rel, const uint32_t* __restrict__ base, size_t total, int B,
                                                       uint32_t T, uint32_t* __restrict__ cursor, uint32_t* __restrict__ task_bkt,
@@ -885,7 +842,7 @@ __global__ void __launch_bounds__(1024) k_len_scatter(const uint32_t* __restrict
 
 // One workgroup per window over the bucket sizes: bucket starts (exclusive prefix), tasks per bucket and their prefix,
 // the window's task total, the largest bucket, and the histogram of task lengths -- everything the task decomposition
-// needs from one read of the sizes (k_task_count + k_scan_rows + k_scan_buckets + k_len_hist of the multi-round path).
+// needs from one read of the sizes.
 constexpr int BR_NT = 256;
 __global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restrict__ bsize, int B, uint32_t T, uint32_t* __restrict__ bstart,
                                                       uint32_t* __restrict__ ntask, uint32_t* __restrict__ rel, uint32_t* __restrict__ row_total,
@@ -2064,7 +2021,6 @@ int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* 
   KG_HIP(ctx, hipSetDevice(ctx->device));
   host_trace("host: enter");
   const size_t pb = curve == KG_G2 ? 128 : 64;             // bytes per base
-  const int E = curve == KG_G2 ? 8 : 4;
   KG_TRY(grow_device(ctx, 0, n * pb));
   KG_TRY(grow_device(ctx, 1, n * 32));
   if (h_inf) KG_TRY(grow_device(ctx, 2, n));
