@@ -1078,7 +1078,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
 template <class F>
 __global__ void __launch_bounds__(64) k_sum_tasks(const uint32_t* __restrict__ pin, size_t in_stride, Level Lin, Level L, int W, int B, uint32_t T2,
                                                   uint32_t* __restrict__ pout, size_t out_stride) {
-  KG_SERVICE_PRIO();
+  KG_REDUCE_PRIO();
   const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
   if (t >= L.base[W]) return;
   int w, b;
@@ -1097,7 +1097,7 @@ __global__ void __launch_bounds__(64) k_sum_tasks(const uint32_t* __restrict__ p
 template <class F>
 __global__ void __launch_bounds__(256) k_gather_buckets(const uint32_t* __restrict__ pin, size_t in_stride, Level L, int W, int B,
                                                         uint32_t* __restrict__ buckets) {
-  KG_SERVICE_PRIO();
+  KG_REDUCE_PRIO();
   const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
   const size_t total = (size_t)W * B;
   if (t >= total) return;
@@ -1126,7 +1126,7 @@ template <class G> struct PartialIO<Fp2<G>, Fp2S<G>> {      // PointAoS<Fp2<G>>:
 };
 template <class F, class KF>
 __global__ void __launch_bounds__(64) k_gather_sum(const uint32_t* __restrict__ pin, Level L, int W, int B, uint32_t* __restrict__ buckets) {
-  KG_SERVICE_PRIO();
+  KG_REDUCE_PRIO();
   const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<KF>::N;
   const size_t total = (size_t)W * B;
   if (t >= total) return;
@@ -1151,7 +1151,7 @@ __global__ void __launch_bounds__(64) k_gather_sum(const uint32_t* __restrict__ 
 template <class F>
 __global__ void __launch_bounds__(64) k_halve(const uint32_t* __restrict__ in, size_t in_stride, uint32_t* __restrict__ out, size_t out_stride,
                                               int W, int narr_in, uint32_t n_out) {
-  KG_SERVICE_PRIO();
+  KG_REDUCE_PRIO();
   const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
   const size_t per_w = (size_t)narr_in * n_out;
   if (t >= per_w * W) return;
@@ -1218,7 +1218,7 @@ template <class G> struct TailCfg<Fp2S<G>> { static constexpr int L = 256; }; //
 template <class F, int E64>
 __global__ void __launch_bounds__(512) k_reduce_tail(const uint32_t* __restrict__ in, size_t in_stride, int narr_in, uint32_t L, int c,
                                                      uint64_t* __restrict__ out) {
-  KG_SERVICE_PRIO();
+  KG_REDUCE_PRIO();
   extern __shared__ uint32_t lds[];
   constexpr int LPT = Lanes<F>::N;
   const uint32_t cap = L * LPT;                        // lane-items the image holds
