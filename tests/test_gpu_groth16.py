@@ -170,7 +170,7 @@ def test_groth16_two_proofs_in_flight_match_blocking_calls(ctx, oracle):
 
 @pytest.mark.parametrize("seed", [int(x) for x in __import__("os").environ.get("KG_SOAK_SEEDS", "99,7,2026").split(",")])
 def test_interleaved_calls_share_one_context(ctx, oracle, seed):
-    """Soak: blocking MSMs on three curves, MSMs in flight, NTTs, blocking proofs and proofs in flight, registered and
+    """Soak: blocking MSMs on three curves, MSMs in flight, NTTs, blocking proofs and proofs in flight, registered (one with a window table) and
     plain base arrays, issued in a seeded random order on ONE context -- the calls share result slots, run-space sets,
     reduction queues and the sort work space, so every result is compared with the value the same call gave alone."""
     import kogarashi_amd as K
@@ -201,6 +201,7 @@ def test_interleaved_calls_share_one_context(ctx, oracle, seed):
     want_msm = {k: ctx.msm(c_, b.ptr, 0, s.ptr, n) for k, (c_, n, b, s) in msm_in.items()}
     want_proof = prover.create_proof(*proof_args)
     want_ntt = fft.coset_dft(ntt_v)
+    ctx.bases_precompute(msm_in["g1a"][2].ptr)      # from here on g1a's MSMs take the merged sort over its window table
     try:
         pending_msm, pending_proof = {}, {}
         for step in range(60):
