@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- BN254 G1 MSM throughput at 2^20 pairs per GPU (BASELINE.json configs[1]) on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Under torch.distributed.run (WORLD_SIZE set) this process IS a rank; started bare, it spawns
+the N ranks itself as child processes BEFORE anything touches the GPU (launch_ranks) and exits with their status.  Either
+way the process group's world size must equal --gpus.
 
 A step is one full MSM (kg_msm: scalars + bases resident in HBM -> one projective point on the host).  With N > 1
 the index range of an N * 2^20 commitment is sharded: every rank runs the same pipeline on its own 2^20 slice and
 the per-rank affine partial sums (17 words) are all-gathered over RCCL and added (weak scaling).
-Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the roofline / cpu_baseline fields."""
+Every N also reports `nova_commit` (BASELINE.json configs[4]: ONE 2^24-pair Pedersen commitment cut over the N ranks by
+kg_shard_range, G1 / Fr and Grumpkin / Fq), `ntt` (2^22 forward transforms, one replica per rank: the transform does not
+shard) and `groth16` (2^18-constraint proofs, one prover per rank).  Rank 0 prints ONE JSON line; see DESIGN.md
+"Measurement" for the roofline / cpu_baseline fields."""
 import argparse
 import json
 import os
@@ -27,7 +34,8 @@ MADD_PEAK_G = 16.5              # measured: the bucket kernel's addition routine
 MAD_PEAK_T = 33.0               # measured chip-wide v_mad_u64_u32 issue rate, T instructions/s (profiles/r01_valu_rates.txt)
 MADS_PER_ADDITION = 1467        # add_mixed_signed (curve.h): 6 products x 162 + 2 squares x 126 + one double product x 243 multiply-accumulates (fp29.h)
 MUL_PEAK_G = 174.0              # measured Montgomery products/s (profiles/r01_mul_rate.txt)
-NTT_MULS_PER_ELEMENT_22 = 13    # 2^22 = 2^8 * 2^7 * 2^7: 11 butterfly products + one inter-step twiddle product per element at each of the two step boundaries (the twiddle itself is read from the direct table, ntt.hip)
+NTT_MULS_PER_ELEMENT = {22: 13}  # 2^22 = 2^8 * 2^7 * 2^7: 11 butterfly products + one inter-step twiddle product per element at each of the two step boundaries (the twiddle itself is read from the direct table, ntt.hip)
+NTT_KERNEL_NOTE = "k_ntt_step x 3 (one HBM round trip each: 192 B moved per element)"
 
 
 def window_adds(n):
@@ -35,6 +43,42 @@ def window_adds(n):
     lg = n.bit_length() - 1
     c = 17 if 21 <= lg <= 24 and n <= (1 << 24) else (16 if lg >= 19 else (15 if lg >= 14 else min(max(lg - 3, 2), 10)))   # pick_window, msm.hip
     return ((255 + c - 1) // c) * n
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` started bare (no WORLD_SIZE): start the N ranks as CHILD processes of this one, before
+    anything here has touched the GPU (no torch, no HIP library loaded yet -- a process that has initialised the GPU must
+    never be replaced), wait for all of them and exit non-zero if any failed.  Rank 0 inherits stdout and prints the line."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sk:                 # a free rendezvous port on the loop-back interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for pr in list(pending):
+                code = pr.poll()
+                if code is None:
+                    continue
+                pending.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    for other in pending:        # one rank failed: the others would wait in a collective for ever
+                        other.send_signal(signal.SIGTERM)
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
 
 
 def main():
@@ -46,38 +90,52 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-groth16", action="store_true")
+    ap.add_argument("--no-nova", action="store_true")
+    ap.add_argument("--nova-log-n", type=int, default=24, help="pairs of the Nova commitment (whole job, cut over the ranks)")
     ap.add_argument("--groth16-log-m", type=int, default=18)
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--depth", type=int, default=4, help="MSM steps in flight (1..4)")
     ap.add_argument("--stream-ordered-inputs", action="store_true", help="do not declare the (static, synchronised) inputs complete")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
 
     import numpy as np
     import torch
     import kogarashi_amd as K
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # KG_BENCH_SELFTEST=1: control-flow check of the N > 1 path on a ONE-GPU box -- every rank uses cuda:0 and the
+    # exchange goes over gloo with host tensors (RCCL refuses two ranks on one device).  Never a measurement.
+    selftest = world > 1 and os.environ.get("KG_BENCH_SELFTEST") == "1"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # KG_BENCH_SELFTEST=1: control-flow check of this N > 1 path on a ONE-GPU box -- every rank uses cuda:0 and the
-        # exchange goes over gloo with host tensors (RCCL refuses two ranks on one device).  Never a measurement.
-        selftest = os.environ.get("KG_BENCH_SELFTEST") == "1"
         if selftest:
             local_rank = 0
+        elif torch.cuda.device_count() <= local_rank:       # counting devices does not initialise the GPU
+            sys.exit(f"bench.py: rank {rank} needs cuda:{local_rank} but this box has {torch.cuda.device_count()} GPU(s) "
+                     "(KG_BENCH_SELFTEST=1 runs the N > 1 control flow with every rank on cuda:0 -- not a measurement)")
         torch.cuda.set_device(local_rank)
         if selftest:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     else:
         torch.cuda.set_device(0)
         local_rank = 0
     dev = torch.device("cuda", local_rank)
-    xdev = None if (world > 1 and os.environ.get("KG_BENCH_SELFTEST") == "1") else dev     # where exchanged tensors live
+    xdev = None if selftest else dev     # where exchanged tensors live
     n = 1 << args.log_n
 
     ctx = K.Context(local_rank)
@@ -127,6 +185,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=xdev if xdev is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     run(40)                                   # untimed: first-touch allocations and the clock ramp of a cold GPU (~70 ms)
     if args.warmup:
         run(args.warmup)
@@ -140,10 +205,7 @@ def main():
     ctx.profile_enable(False)
     acc_avg_ms = summary["accumulate"][0] / summary["accumulate"][1]
     phase_avg = {k_: v_[0] / v_[1] for k_, v_ in summary.items()}
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev if xdev is not None else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
 
     value = world * n * args.steps / elapsed
     achieved = G1_BYTES_PER_PAIR * n / (acc_avg_ms * 1e-3) / 1e9
@@ -152,8 +214,10 @@ def main():
     # step shorter and the kernel's own launch longer.
     barrier()
     ctx.profile_enable(True)
+    t0 = time.perf_counter()
     for _ in range(5):
         ctx.msm(K.KG_G1, bases.data_ptr(), 0, scalars.data_ptr(), n)
+    blocking_ms = (time.perf_counter() - t0) / 5 * 1e3
     iso = ctx.profile_summary()
     ctx.profile_enable(False)
     iso_ms = iso["accumulate"][0] / iso["accumulate"][1]
@@ -166,6 +230,7 @@ def main():
         "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 64-bit accumulate)", "data": "synthetic",
         "config": {"workload": f"bn254 G1 MSM, 2^{args.log_n} uniform Fr scalars x uniform G1 bases per GPU, inputs resident in HBM",
                    "pairs_per_gpu": n, "sharding": "index range" if world > 1 else "none"},
+        "blocking_ms": blocking_ms,            # wall time of one isolated kg_msm call (nothing in flight), host finish included
         "roofline": {"bound": "hbm", "kernel": "k_acc_tasks (bucket accumulation, one launch per MSM)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic["corrected"] if traffic else None, "kernel_ms": acc_avg_ms, "algorithmic_bytes_per_launch": G1_BYTES_PER_PAIR * n,
@@ -215,15 +280,22 @@ def main():
                                                          "table_bytes": (15 if n >= (1 << 17) else 16) * 64 * n,
                                                          "matches_unregistered": bool((res_tab[0] == res[0]).all() and res_tab[1] == res[1])}
         ctx.bases_unregister(bases.data_ptr())
-        if not args.no_ntt:
-            line["ntt"] = bench_ntt(ctx, torch, dev, K)
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ctx, K, bases, scalars, n, res)
-        if not args.no_groth16:
-            line["groth16"] = bench_groth16(ctx, torch, dev, K, args.groth16_log_m, cpu=not args.no_cpu_baseline)
+    cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if cpu:
+        line["cpu_baseline"] = cpu_baseline(ctx, K, bases, scalars, n, res)
+        line["cpu_plumbing_2_10"] = cpu_plumbing(ctx, K)
+    del bases, scalars
+    env = {"world": world, "rank": rank, "barrier": barrier, "max_over_ranks": max_over_ranks, "xdev": xdev, "kdist": kdist}
+    if not args.no_ntt:
+        line["ntt"] = bench_ntt(ctx, torch, dev, K, env)
+    if not args.no_nova:
+        line["nova_commit"] = bench_nova_commit(ctx, torch, dev, K, env, args.nova_log_n, cpu=cpu)
+    if not args.no_groth16:
+        line["groth16"] = bench_groth16(ctx, torch, dev, K, env, args.groth16_log_m, cpu=cpu)
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -243,38 +315,148 @@ def pmc_traffic(log_n):
     return None
 
 
-def bench_ntt(ctx, torch, dev, K, log_n=22, steps=10):
-    """secondary line: forward Fr NTT at 2^22 (BASELINE.json configs[2]), 64 algorithmic bytes per element."""
+def bench_ntt(ctx, torch, dev, K, env, log_n=22, steps=10):
+    """secondary line: forward Fr NTT at 2^22 (BASELINE.json configs[2]), 64 algorithmic bytes per element.  The transform
+    does not shard (it would need an all-to-all transpose): with N ranks every rank transforms its own vector
+    (replicas) and `value` is the aggregate."""
+    world, rank = env["world"], env["rank"]
     n = 1 << log_n
     data = torch.empty(n * 4, dtype=torch.int64, device=dev)
-    ctx.gen_scalars(K.KG_FR, SEED + 3, 0, n, data.data_ptr())
+    ctx.gen_scalars(K.KG_FR, SEED + 3, rank * n, n, data.data_ptr())
     for _ in range(2):
         ctx.ntt(data.data_ptr(), log_n, False, False)
     ctx.sync()
     # the library brackets every transform with HIP events on the queue it launches on ("ntt" phase)
     ctx.profile_enable(True)
+    env["barrier"]()
+    t0 = time.perf_counter()
     for _ in range(steps):
         ctx.ntt(data.data_ptr(), log_n, False, False)
+    ctx.sync()
+    env["barrier"]()
+    wall_ms = env["max_over_ranks"](time.perf_counter() - t0) / steps * 1e3
     tot, cnt = ctx.profile_summary()["ntt"]
     ctx.profile_enable(False)
     ms = tot / cnt
     gbs = 64.0 * n / (ms * 1e-3) / 1e9
-    muls = NTT_MULS_PER_ELEMENT_22 if log_n == 22 else None
-    out = {"metric": "bn254_fr_ntt_elements_per_sec", "log_n": log_n, "value": n / (ms * 1e-3), "ms": ms,
+    muls = NTT_MULS_PER_ELEMENT.get(log_n)
+    out = {"metric": "bn254_fr_ntt_elements_per_sec", "log_n": log_n, "value": world * n / (wall_ms * 1e-3), "ms": ms, "wall_ms": wall_ms,
+           "replicas": world, "note": "value = replicas x n / wall time per transform (max over ranks); ms = HIP-event duration of one transform on rank 0",
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "algorithmic_bytes": 64 * n, "kernel": "k_ntt_step x 3 (one HBM round trip each: 192 B moved per element)"}}
+                        "algorithmic_bytes": 64 * n, "kernel": NTT_KERNEL_NOTE}}
     if muls:
         out["valu_roofline"] = {"bound": "valu", "unit": "G Montgomery products/s", "products_per_element": muls,
                                 "achieved": muls * n / (ms * 1e-3) / 1e9, "peak": MUL_PEAK_G, "frac": muls * n / (ms * 1e-3) / 1e9 / MUL_PEAK_G}
     return out
 
 
-def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True, tables=True, tickets=2):
+def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5):
+    """BASELINE.json configs[4]: Nova's Pedersen commitment (nova/src/pedersen.rs:15-20) over 2^24 generators, on both
+    curves of the cycle (bn254 G1 with Fr scalars, Grumpkin with Fq scalars; nova/src/driver.rs:9-42).  ONE commitment of
+    2^log_n pairs is cut over the N ranks by kg_shard_range; every rank commits its slice (kg_commit) and the N affine
+    partial sums are all-gathered and added (strong scaling of a fixed job: ms_per_commit is the number to watch).  The key
+    g is fixed by PedersenCommitment::new, so it is registered (resident internal form) like a CRS vector.
+    CPU legs (N = 1 only): the reference's naive fold timed on a prefix and extrapolated (2^24 of it would take hours), and
+    the oracle's Pippenger restatement (msm_curve_addition) on all 2^24 pairs -- which also checks the GPU point."""
+    import numpy as np
+    from kogarashi_amd.lib import shard_range
+    world, rank, kdist, xdev = env["world"], env["rank"], env["kdist"], env["xdev"]
+    total = 1 << log_n
+    lo, hi = shard_range(total, rank, world)
+    nl = hi - lo
+    out = {"metric": "nova_pedersen_commit_pairs_per_sec", "log_n": log_n, "pairs_total": total, "pairs_per_rank": nl, "ranks": world,
+           "scaling": "strong (one 2^%d-pair commitment cut over the ranks by kg_shard_range)" % log_n,
+           "key": "registered (kg_bases_register: the generators are fixed by PedersenCommitment::new)",
+           "algorithmic_bytes_per_commit": 96 * total}
+    for name, curve, fld, cv in (("g1_fr", K.KG_G1, K.KG_FR, "g1"), ("grumpkin_fq", K.KG_GRUMPKIN, K.KG_FQ, "gk")):
+        g = torch.empty(nl * 8, dtype=torch.int64, device=dev)
+        m = torch.empty(nl * 4, dtype=torch.int64, device=dev)
+        ctx.gen_bases(curve, SEED + 40 + curve, lo, nl, g.data_ptr())
+        ctx.gen_scalars(fld, SEED + 41, lo, nl, m.data_ptr())
+        ctx.sync()
+        ctx.bases_register(curve, g.data_ptr(), 0, nl)
+
+        def one():
+            xy, inf = ctx.commit(curve, g.data_ptr(), 0, m.data_ptr(), nl)
+            if world > 1:
+                xy, inf = kdist.combine_partials(ctx, curve, xy, inf, device=xdev)
+            return xy, inf
+        one()
+        env["barrier"]()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            got = one()
+        env["barrier"]()
+        dt = env["max_over_ranks"](time.perf_counter() - t0) / steps
+        leg = {"ms_per_commit": dt * 1e3, "value": total / dt, "unit": "pairs/s",
+               "roofline": {"bound": "hbm", "achieved": 96 * total / dt / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                            "frac": 96 * total / dt / 1e9 / (HBM_PEAK_GBS * world)}}
+        if cpu:
+            from oracle import oracle as O
+            hg = g.cpu().numpy().view(np.uint64).reshape(nl, 8)
+            hm = m.cpu().numpy().view(np.uint64).reshape(nl, 4)
+            # (1) the reference's own commit: a sequential fold of naive scalar multiplications (pedersen.rs:15-20)
+            k = 1 << 12
+            t0 = time.perf_counter()
+            O.commit_naive(cv, hg[:k], hm[:k])
+            cdt = time.perf_counter() - t0
+            if cdt < 1.6 and nl >= (1 << 14):
+                k = 1 << 14
+                t0 = time.perf_counter()
+                O.commit_naive(cv, hg[:k], hm[:k])
+                cdt = time.perf_counter() - t0
+            leg["cpu_naive_fold"] = {"value": k / cdt, "unit": "pairs/s", "cores": 1, "kind": "port",
+                                     "sample": f"first {k} pairs, {cdt:.2f} s; the fold is sequential in the reference",
+                                     "extrapolated_s_per_commit": cdt * total / k}
+            # (2) like for like at full size: the oracle's restatement of msm_curve_addition, one thread per window
+            lg = nl.bit_length()
+            c_ref = (lg * 69 // 100) + 2
+            threads = max(1, min(256 // c_ref + 1, os.cpu_count() or 1))
+            t0 = time.perf_counter()
+            want = O.to_affine(cv, O.msm(cv, hg, hm, None, threads=threads))
+            cdt = time.perf_counter() - t0
+            leg["cpu_pippenger"] = {"value": nl / cdt, "unit": "pairs/s", "cores": threads, "kind": "port",
+                                    "sample": f"all {nl} pairs, reference window rule (c = {c_ref}), {cdt:.2f} s",
+                                    "gpu_matches_cpu_at_full_size": bool(want[1] == got[1] and (want[1] or (want[0] == got[0]).all()))}
+            del hg, hm
+        ctx.bases_unregister(g.data_ptr())
+        del g, m
+        out[name] = leg
+    out["value"] = out["g1_fr"]["value"]
+    return out
+
+
+def cpu_plumbing(ctx, K, log_n=10):
+    """BASELINE.json configs[0]: bn254 G1 MSM over 2^10 random pairs on the CPU (the reference's bn254/benches size; no GPU
+    number is claimed at this size -- a blocking kg_msm_host of 2^10 pairs is latency, reported beside it for the record)."""
+    import numpy as np
+    from oracle import oracle as O
+    n = 1 << log_n
+    hb = O.gen_bases(0, SEED + 1, 0, n)
+    hs = O.gen_scalars(0, SEED + 2, 0, n)
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = O.msm("g1", hb, hs, None, threads=1)
+    dt = (time.perf_counter() - t0) / reps
+    xy, inf = O.to_affine("g1", r)
+    inf0 = np.zeros(n, dtype=np.uint8)
+    got = ctx.msm_host(K.KG_G1, hb, inf0, hs, n)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        got = ctx.msm_host(K.KG_G1, hb, inf0, hs, n)
+    gdt = (time.perf_counter() - t0) / reps
+    return {"value": n / dt, "unit": "pairs/s", "cores": 1, "kind": "port", "sample": f"{reps} x 2^{log_n} pairs, {dt * 1e3:.2f} ms each, one thread",
+            "gpu_host_call_ms": gdt * 1e3, "gpu_matches_cpu": bool(not inf and (got[:8] == xy).all())}
+
+
+def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=True, tickets=2):
     """secondary line: Groth16 prove at m = 2^log_m constraints (BASELINE.json configs[3]).  Circuit: the chain
     t_{i+1} = t_i * (t_i + 1) (x = [1, t_0], w = t_1..t_m); CRS:
     a real CRS from a fixed toxic waste, generated on the device; fixed (r, s).  The CPU leg runs the oracle's create_proof on the same inputs and compares the proof."""
     import numpy as np
     from kogarashi_amd.lib import Groth16Crs
+    world, sync, mx = env["world"], env["barrier"], env["max_over_ranks"]     # N ranks: one prover per rank (replicas), aggregate proofs/s
     from kogarashi_amd import synthetic as syn
     m = 1 << log_m
     cc = syn.ChainCircuit(m)
@@ -308,12 +490,12 @@ def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True, tables=True, 
     args_ = (crs, d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), d_x.data_ptr(), d_w.data_ptr(), r, s_)
     prove = lambda: ctx.groth16_prove(*args_)
     proof = prove()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         proof = prove()
-    torch.cuda.synchronize()
-    dt_blocking = (time.perf_counter() - t0) / steps
+    sync()
+    dt_blocking = mx(time.perf_counter() - t0) / steps
     # throughput: proofs issued back to back, two in flight (kg_groth16_prove_begin / _end) -- proof i+1's transforms and
     # sorts run under proof i's last reduction and host assembly; every proof is produced inside the timed region
     def run(k, depth=tickets):
@@ -326,13 +508,13 @@ def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True, tables=True, 
             last = ctx.groth16_prove_end(i % depth)
         return last
     run(2)
-    torch.cuda.synchronize()
+    sync()
     k_pipe = max(2 * steps, 4)
     t0 = time.perf_counter()
     proof_p = run(k_pipe)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / k_pipe
-    out = {"metric": "groth16_proofs_per_sec", "log_m": log_m, "value": 1.0 / dt, "ms_per_proof": dt * 1e3,
+    sync()
+    dt = mx(time.perf_counter() - t0) / k_pipe
+    out = {"metric": "groth16_proofs_per_sec", "log_m": log_m, "value": world / dt, "ms_per_proof": dt * 1e3, "replicas": world,
            "ms_per_proof_blocking": dt_blocking * 1e3, "pipelining": "two proofs in flight (kg_groth16_prove_begin / _end)",
            "crs": "resident and registered (kg_bases_register: converted to the internal form once, as api.Prover does)",
            "pipelined_matches_blocking": bool(all((proof_p[i] == proof[i]).all() for i in range(4))),
@@ -363,18 +545,18 @@ def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True, tables=True, 
         ctx.sync()
         build_ms = (time.perf_counter() - t0) * 1e3
         proof_t = prove()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             proof_t = prove()
-        torch.cuda.synchronize()
-        dt_tb = (time.perf_counter() - t0) / steps
+        sync()
+        dt_tb = mx(time.perf_counter() - t0) / steps
         run(2)
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         proof_tp = run(k_pipe)
-        torch.cuda.synchronize()
-        dt_t = (time.perf_counter() - t0) / k_pipe
+        sync()
+        dt_t = mx(time.perf_counter() - t0) / k_pipe
         c_t = 17 if nz >= (1 << 17) else 16
         w_t = (255 + c_t - 1) // c_t
         # and from the witness alone: the constraint matrices resident as CSR, cs.evaluate() on the device at the head of the
@@ -394,13 +576,13 @@ def bench_groth16(ctx, torch, dev, K, log_m=18, steps=8, cpu=True, tables=True, 
                 last = ctx.groth16_prove_end(i % depth)
             return last
         run_w(2)
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         proof_w = run_w(k_pipe)
-        torch.cuda.synchronize()
-        dt_w = (time.perf_counter() - t0) / k_pipe
+        sync()
+        dt_w = mx(time.perf_counter() - t0) / k_pipe
         out["window_tables"] = {"ms_per_proof": dt_t * 1e3, "ms_per_proof_from_witness": dt_w * 1e3,
-                                "from_witness_matches": bool(all((proof_w[i] == proof[i]).all() for i in range(4))), "ms_per_proof_blocking": dt_tb * 1e3, "value": 1.0 / dt_t, "build_ms": build_ms,
+                                "from_witness_matches": bool(all((proof_w[i] == proof[i]).all() for i in range(4))), "ms_per_proof_blocking": dt_tb * 1e3, "value": world / dt_t, "build_ms": build_ms,
                                 "table_bytes": w_t * (64 * (3 * nz + (m - 1)) + 128 * nz),
                                 "proofs_match": bool(all((proof_t[i] == proof[i]).all() and (proof_tp[i] == proof[i]).all() for i in range(4)))}
     for name in ("h", "l", "a", "b_g1", "b_g2"):
