@@ -216,7 +216,7 @@ struct FatZ;
   struct FatZ<P, C_, T_> {                                                        \
     static KG_HD uint32_t at(int i) { return P::Z##C_##_##T_[i]; }                \
   };
-KG_FATZ(4, 1) KG_FATZ(8, 1) KG_FATZ(16, 1) KG_FATZ(32, 1) KG_FATZ(4, 3) KG_FATZ(8, 3) KG_FATZ(16, 3) KG_FATZ(32, 3)
+KG_FATZ(2, 1) KG_FATZ(4, 1) KG_FATZ(8, 1) KG_FATZ(16, 1) KG_FATZ(32, 1) KG_FATZ(4, 3) KG_FATZ(8, 3) KG_FATZ(16, 3) KG_FATZ(32, 3)
 #undef KG_FATZ
 
 // lazy difference a + C*p - b, limb-wise without borrows.  Requires limbs 0..7 of b <= T*2^29 - T and

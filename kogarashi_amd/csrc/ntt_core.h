@@ -33,10 +33,10 @@ KG_HD void dit_step(F (&x)[1 << G], bool trivial_first, const TwFn& tw) {
         x[k1] = sub<4, 1>(a, b);
       }
     } else {
-      F tt = mul(x[k1], tw(T, k0));
-      F a = x[k0];
+      F tt = mul(x[k1], tw(T, k0));                  // < 2p, normalised: the 2p fat constant dominates it, so the value bound of
+      F a = x[k0];                                   // the never-multiplied path grows by 2p per stage (a 2^11-point tile: < 40p)
       x[k0] = add(a, tt);
-      x[k1] = sub<4, 1>(a, tt);
+      x[k1] = sub<2, 1>(a, tt);
     }
     if constexpr (PI + 1 < (1 << (G - 1))) dit_step<G, T, PI + 1>(x, trivial_first, tw);
     else dit_step<G, T + 1, 0>(x, trivial_first, tw);

@@ -1,0 +1,433 @@
+// ntt_tile.h -- one step of the Fr NTT on a tile held in LDS, with every size a compile-time constant.
+//
+// Replaces the arithmetic of groth16/src/fft.rs:166-218 (classic_fft_arithmetic / butterfly_arithmetic) for one
+// factor m = 2^LOG_M of the transform length: a tile is 2^LOG_TC adjacent DFTs of m points each.  The radix-2 DIT
+// stages run two at a time in registers (ntt_core.h).  The first register pass is fused with the global load and the
+// last one with the global store, so a tile of m points makes ceil(LOG_M / 2) - 1 LDS round trips; between them the
+// tile lives in LDS as nine 29-bit limb planes.  All index arithmetic is shifts and masks by constants.
+//
+// Every function here is a per-thread body, generic over the field type F and over the tile store: the kernel
+// (ntt.hip) instantiates it with Fr and LDS planes, tests/host/hosttest.cpp runs the same code thread by thread on the
+// host with the bound-checking FrC and checks whole transforms against the oracle.
+#pragma once
+#include <cstddef>
+#include "fp29.h"
+#include "ntt_core.h"
+
+namespace kg {
+
+constexpr int NTT_TW_LOG = 11;   // in-tile twiddle table: w_2048^e, e < 1024, [e][9] words
+constexpr int NTT_MAX_LOG_M = 11;
+
+struct NttStepArgs {
+  const uint64_t* in;
+  uint64_t* out;
+  const uint32_t* tw_m;        // w_2048^e (e < 1024), direction of the transform
+  const uint32_t* tw_direct;   // column steps: inter-step twiddles [row][inner column], or nullptr
+  const uint32_t* tw_lo;       // two-level w_n^e = lo[e & mask] * hi[e >> lo_bits] (inter-step fallback above the direct tables)
+  const uint32_t* tw_hi;
+  const uint32_t* cos_lo;      // coset shift g^(+-e) [* n^-1 when inverse], two-level like w_n
+  const uint32_t* cos_hi;
+  uint64_t mult;               // column steps: exponent multiplier of the fallback twiddle w_n^(row * column * mult); 0 = none
+  uint32_t lo_bits;
+  uint32_t log_inner;          // column steps: log2 of the contiguous run (elements) between two rows of a DFT
+  uint32_t log_G;              // row steps: log2 of the number of DFTs (= output stride)
+  uint32_t log_n1;             // row steps: DFT g = i1 + n1 * i2 reads row i1 * (G / n1) + i2
+  uint32_t scale_mode;         // 0 none; 1: input element j * cos(j) (coset_dft, fft.rs:109-116); 2: output element i * cos(i)
+                               // (coset_idft, fft.rs:119-127); 3: output * cos(0) (= n^-1: idft, fft.rs:100-106)
+  uint32_t tile_shift;         // XCD-aware tile order: tile = (block % 8) << tile_shift | block / 8 when tile_shift != 0
+};
+
+// ---- compile-time bit maps: thread bit j carries logical bit map[j] -------------------------------------------
+struct BitMap {
+  int n;
+  int map[16];
+};
+// logical tile index idx = (p << LOG_TC) | col (p: position in the DIT working order, col: which DFT of the tile); LDS word
+// = idx with its low five bits XORed with the higher five-bit groups.  ds_read_b32 / ds_write_b32 bank = word mod 32 per
+// 32-lane half: a pass is conflict-free when the five idx bits its lanes vary sit in five different residue classes mod 5.
+template <int B>
+KG_HD uint32_t tile_phys(uint32_t idx) {
+  if constexpr (B <= 5) return idx;
+  else if constexpr (B <= 10) return idx ^ ((idx >> 5) & 31u);
+  else return idx ^ ((idx >> 5) & 31u) ^ ((idx >> 10) & 31u);
+}
+// register pass over idx bits [F0, F0 + FW): the other B - FW bits come from the thread id
+template <int B, int F0, int FW>
+constexpr BitMap mid_map() {
+  BitMap m{B - FW, {}};
+  bool used[16] = {};
+  for (int b = F0; b < F0 + FW; ++b) used[b] = true;
+  int j = 0;
+  if (B >= 10) {
+    for (int r = 0; r < 5; ++r) {                  // lane bits: the lowest free idx bit of each residue class
+      int b = r;
+      while (used[b]) b += 5;
+      m.map[j++] = b;
+      used[b] = true;
+    }
+  }
+  for (int b = 0; b < B; ++b)
+    if (!used[b]) { m.map[j++] = b; used[b] = true; }
+  return m;
+}
+// first pass of a column step: source index s = (r_low << LOG_TC) | col; the lanes keep the columns (global runs) and take
+// the r_low bits whose LDS destination bits (bit-reversed: r_low bit b -> idx bit B - 1 - b) fill the remaining residues
+template <int B, int LOG_TC, int RL>
+constexpr BitMap first_col_map() {
+  BitMap m{LOG_TC + RL, {}};
+  bool used[16] = {};
+  int j = 0;
+  for (int b = 0; b < LOG_TC; ++b) { m.map[j++] = b; used[b] = true; }
+  if (LOG_TC < 5 && B >= 10) {
+    const int want = 5 - LOG_TC;
+    int b0 = B % 5;
+    if (b0 + want > RL) b0 = RL - want > 0 ? RL - want : 0;
+    for (int b = b0; b < b0 + want && b < RL; ++b) { m.map[j++] = LOG_TC + b; used[LOG_TC + b] = true; }
+  }
+  for (int b = 0; b < LOG_TC + RL; ++b)
+    if (!used[b]) { m.map[j++] = b; used[b] = true; }
+  return m;
+}
+constexpr int run_len(const BitMap& m, int j) {
+  int len = 1;
+  while (j + len < m.n && m.map[j + len] == m.map[j] + len) ++len;
+  return len;
+}
+template <class MapFn, int J>
+KG_HD uint32_t scatter_bits(uint32_t t) {
+  constexpr BitMap M = MapFn::get();
+  if constexpr (J >= M.n) return 0u;
+  else {
+    constexpr int len = run_len(M, J);
+    constexpr uint32_t mask = (1u << len) - 1u;
+    return (((t >> J) & mask) << M.map[J]) | scatter_bits<MapFn, J + len>(t);
+  }
+}
+template <int B, int F0, int FW> struct MidMapFn { static constexpr BitMap get() { return mid_map<B, F0, FW>(); } };
+template <int B, int LOG_TC, int RL> struct FirstColMapFn { static constexpr BitMap get() { return first_col_map<B, LOG_TC, RL>(); } };
+
+template <int BITS>
+KG_HD uint32_t brev_bits(uint32_t v) {
+  if constexpr (BITS == 0) return 0u;
+  else {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(v) >> (32 - BITS);
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < BITS; ++i) r |= ((v >> i) & 1u) << (BITS - 1 - i);
+    return r;
+#endif
+  }
+}
+
+// ---- memory -----------------------------------------------------------------------------------------------
+KG_HD void ntt_ld_words(const uint64_t* base, size_t elem, uint32_t w[8]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint4* p = reinterpret_cast<const uint4*>(base) + 2 * elem;
+  const uint4 a = p[0], b = p[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+#else
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(base) + 8 * elem;
+  for (int i = 0; i < 8; ++i) w[i] = p[i];
+#endif
+}
+KG_HD void ntt_st_words(uint64_t* base, size_t elem, const uint32_t w[8]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint4* p = reinterpret_cast<uint4*>(base) + 2 * elem;
+  p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+#else
+  uint32_t* p = reinterpret_cast<uint32_t*>(base) + 8 * elem;
+  for (int i = 0; i < 8; ++i) p[i] = w[i];
+#endif
+}
+// field-type adapters (the bound-checking type supplies its own in tests/host/hosttest.cpp)
+template <class F> struct NttIO;
+template <class P> struct NttIO<Fp<P>> {
+  static KG_HD Fp<P> raw(const uint32_t w[8]) { return limbs_from_words<P>(w); }          // any 256-bit value, no domain change
+  static KG_HD Fp<P> table(const uint32_t* tab, size_t e) {                                // table entry: normalised, < 2p
+    Fp<P> r;
+    const uint32_t* p = tab + e * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.l[k] = p[k];
+    return r;
+  }
+  static KG_HD void words(const Fp<P>& a, uint32_t w[8]) { words_from_limbs(a, w); }
+};
+template <class F>
+KG_HD F ntt_two_level(const uint32_t* lo, const uint32_t* hi, uint32_t lo_bits, uint64_t e) {
+  const uint64_t el = e & ((1ull << lo_bits) - 1), eh = e >> lo_bits;
+  F a = NttIO<F>::table(lo, el);
+  if (eh == 0) return a;
+  return mul(a, NttIO<F>::table(hi, eh));
+}
+
+// the kernel's tile store: limb k of LDS word w at base[k * ELEMS + w]
+template <int ELEMS>
+struct LdsPlanes {
+  uint32_t* base;
+  template <class P>
+  KG_HD void store(uint32_t w, const Fp<P>& a) const {
+#ifdef KG_NTT_EXP_NOLDS     // phase-off experiment: one word per element instead of nine
+    base[w] = a.l[0] ^ a.l[1] ^ a.l[2] ^ a.l[3] ^ a.l[4] ^ a.l[5] ^ a.l[6] ^ a.l[7] ^ a.l[8];
+    return;
+#endif
+#pragma unroll
+    for (int k = 0; k < 9; ++k) base[k * ELEMS + w] = a.l[k];
+  }
+  template <class F>
+  KG_HD F load(uint32_t w) const {
+    F r;
+#ifdef KG_NTT_EXP_NOLDS
+    const uint32_t v = base[w];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.l[k] = (v >> k) & M29;
+    return r;
+#endif
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.l[k] = base[k * ELEMS + w];
+    return r;
+  }
+};
+
+// ---- one tile ------------------------------------------------------------------------------------------------
+// ROW = false ("column step"): the DFT runs over rows that lie `inner` elements apart; the tile is 2^LOG_TC adjacent
+//   columns; results go back to the same places (of `out`), multiplied by the inter-step twiddle; not canonical (< 2p).
+// ROW = true ("row step", always the last): each DFT is a contiguous row of m elements; output element i of DFT g goes to
+//   out[g + i * G] (adjacent DFTs -> adjacent addresses), canonical.
+template <class F, int LOG_M, int LOG_TC, bool ROW>
+struct NttTile {
+  static constexpr int B = LOG_M + LOG_TC;
+  static constexpr int ELEMS = 1 << B;
+  static constexpr int NT = ELEMS / 4 >= 64 ? ELEMS / 4 : 64;
+  static constexpr int G0 = (LOG_M & 1) ? 1 : 2;            // stages of the first pass (fused with the load)
+  static constexpr int RL = LOG_M - G0;                     // bits of r_low in the first pass
+  static constexpr bool SINGLE = LOG_M <= 2;                // one pass: load -> butterflies -> store, no LDS
+  static constexpr int S_LAST = LOG_M - 2;                  // first stage index of the last pass (fused with the store)
+  static constexpr int M = 1 << LOG_M, TC = 1 << LOG_TC;
+
+  const NttStepArgs& A;
+  uint32_t tile;
+
+  // twiddles of a register pass over stages s0+1 .. s0+G: w_{2^s}^j, j = r mod 2^(s-1)
+  struct Tw {
+    const uint32_t* tw_m;
+    uint32_t s0, r_low;
+    KG_HD F operator()(int t, int k0) const {
+      const uint32_t s = s0 + (uint32_t)t;
+      const uint32_t j = (((uint32_t)k0 & ((1u << (t - 1)) - 1u)) << s0) | r_low;
+#ifdef KG_NTT_EXP_NOTW      // phase-off experiment (tools/dbg): every twiddle is the same table entry
+      return NttIO<F>::table(tw_m, (size_t)(j & 0u) + 5);
+#endif
+      return NttIO<F>::table(tw_m, (size_t)j << (NTT_TW_LOG - s));
+    }
+  };
+
+  // ---- addresses ----
+  KG_HD uint64_t col_base() const {         // column step: address of (row 0, column 0 of the tile)
+    const uint64_t g0 = (uint64_t)tile << LOG_TC;
+    return ((g0 >> A.log_inner) << (LOG_M + A.log_inner)) + (g0 & ((1ull << A.log_inner) - 1));
+  }
+  KG_HD uint64_t row_in(uint32_t col) const {   // row step: first element of DFT g0 + col
+    const uint64_t g = ((uint64_t)tile << LOG_TC) + col;
+    const uint64_t i1 = g & ((1ull << A.log_n1) - 1), i2 = g >> A.log_n1;
+    return ((i1 << (A.log_G - A.log_n1)) + i2) << LOG_M;
+  }
+
+  KG_HD F load_elem(uint64_t addr) const {
+    uint32_t w[8];
+    ntt_ld_words(A.in, addr, w);
+    F v = NttIO<F>::raw(w);
+    if (A.scale_mode == 1) v = mul(v, ntt_two_level<F>(A.cos_lo, A.cos_hi, A.lo_bits, addr));
+    return v;
+  }
+  // x: lazy output of the last stage; i: output row; col: DFT of the tile
+  KG_HD void store_elem(const F& x, uint32_t i, uint32_t col) const {
+    uint32_t w[8];
+    if constexpr (ROW) {
+      const uint64_t addr = (((uint64_t)tile << LOG_TC) + col) + ((uint64_t)i << A.log_G);
+      F v;
+      if (A.scale_mode == 2) v = mul(x, ntt_two_level<F>(A.cos_lo, A.cos_hi, A.lo_bits, addr));
+      else if (A.scale_mode == 3) v = mul(x, NttIO<F>::table(A.cos_lo, 0));
+      else v = vred(norm(x));
+      NttIO<F>::words(reduce_2p(v), w);
+      ntt_st_words(A.out, addr, w);
+    } else {
+      const uint64_t off = ((uint64_t)i << A.log_inner) + ((((uint64_t)tile << LOG_TC) & ((1ull << A.log_inner) - 1)) + col);
+      const uint64_t slab = ((((uint64_t)tile << LOG_TC) >> A.log_inner) << (LOG_M + A.log_inner));
+      F v;
+      if (A.tw_direct) v = mul(x, NttIO<F>::table(A.tw_direct, off));
+      else if (A.mult) v = mul(x, ntt_two_level<F>(A.tw_lo, A.tw_hi, A.lo_bits, (uint64_t)i * ((off & ((1ull << A.log_inner) - 1)) * A.mult)));
+      else v = vred(norm(x));
+      NttIO<F>::words(v, w);                      // < 2p < 2^255: the next step reads it as a raw 256-bit value
+      ntt_st_words(A.out, slab + off, w);
+    }
+  }
+
+  // ---- first pass: global load, stages 1..G0 (all twiddles trivial but w_4), tile -> store ----
+  template <class Store>
+  KG_HD void first(uint32_t tid, const Store& st) const {
+    constexpr int groups = ELEMS >> G0;
+    constexpr int iters = (groups + NT - 1) / NT;
+#pragma unroll
+    for (int it = 0; it < iters; ++it) {
+      const uint32_t q = tid + (uint32_t)it * NT;
+      if (groups < NT && q >= (uint32_t)groups) break;
+      uint32_t col, r_low;
+      if constexpr (ROW) {
+        r_low = q & ((1u << RL) - 1u);
+        col = q >> RL;
+      } else {
+        const uint32_t s = scatter_bits<FirstColMapFn<B, LOG_TC, RL>, 0>(q);
+        col = s & (TC - 1u);
+        r_low = s >> LOG_TC;
+      }
+      F x[1 << G0];
+      const uint64_t base = ROW ? row_in(col) + r_low : col_base() + col + ((uint64_t)r_low << A.log_inner);
+#pragma unroll
+      for (int k = 0; k < (1 << G0); ++k) {
+        const uint32_t j = brev_bits<G0>((uint32_t)k);                    // position bit k <-> row bit (reversed)
+        const uint64_t addr = ROW ? base + ((uint64_t)j << RL) : base + (((uint64_t)j << RL) << A.log_inner);
+        x[k] = load_elem(addr);
+      }
+      Tw tw{A.tw_m, 0u, 0u};
+      dit_network<G0>(x, true, tw);
+      if constexpr (SINGLE) {
+#pragma unroll
+        for (int k = 0; k < (1 << G0); ++k) store_elem(x[k], (uint32_t)k, col);
+      } else {
+        const uint32_t p_high = brev_bits<RL>(r_low);
+#pragma unroll
+        for (int k = 0; k < (1 << G0); ++k)
+          st.store(tile_phys<B>((((p_high << G0) | (uint32_t)k) << LOG_TC) | col), norm(x[k]));
+      }
+    }
+  }
+
+  // ---- middle pass over stages S0+1, S0+2: LDS -> LDS, in place ----
+  template <int S0, class Store>
+  KG_HD void mid(uint32_t tid, const Store& st) const {
+    constexpr int F0 = LOG_TC + S0;
+    if (ELEMS / 4 < NT && tid >= (uint32_t)(ELEMS / 4)) return;
+    const uint32_t others = scatter_bits<MidMapFn<B, F0, 2>, 0>(tid);
+    const uint32_t r_low = (others >> LOG_TC) & ((1u << S0) - 1u);
+    const uint32_t w0 = tile_phys<B>(others);
+    F x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = st.template load<F>(w0 ^ tile_phys<B>((uint32_t)k << F0));
+    Tw tw{A.tw_m, (uint32_t)S0, r_low};
+    dit_network<2>(x, false, tw);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st.store(w0 ^ tile_phys<B>((uint32_t)k << F0), norm(x[k]));
+  }
+
+  // ---- last pass over stages LOG_M-1, LOG_M: LDS -> inter-step twiddle / scaling -> global store ----
+  template <class Store>
+  KG_HD void last(uint32_t tid, const Store& st) const {
+    constexpr int F0 = LOG_TC + S_LAST;
+    if (ELEMS / 4 < NT && tid >= (uint32_t)(ELEMS / 4)) return;
+    const uint32_t col = tid & (TC - 1u), p_low = tid >> LOG_TC;
+    const uint32_t w0 = tile_phys<B>((p_low << LOG_TC) | col);
+    F x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = st.template load<F>(w0 ^ tile_phys<B>((uint32_t)k << F0));
+    Tw tw{A.tw_m, (uint32_t)S_LAST, p_low};
+    dit_network<2>(x, false, tw);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) store_elem(x[k], p_low + ((uint32_t)k << S_LAST), col);
+  }
+
+  // the passes between first() and last(), in order; sync() separates them
+  template <int S0, class Store, class Sync>
+  KG_HD void mids(uint32_t tid, const Store& st, const Sync& sync) const {
+    if constexpr (S0 < S_LAST) {
+      mid<S0>(tid, st);
+      sync();
+      mids<S0 + 2>(tid, st, sync);
+    }
+  }
+};
+
+}  // namespace kg
+
+// ---- table entries (shared by the device table kernels and the host test) ----------------------------------------
+namespace kg {
+// ROOT_OF_UNITY^(+-1) squared (28 - log) times: a primitive 2^log-th root (fft.rs:34,44)
+template <class F>
+KG_HD F ntt_root_of(uint32_t log, int inverse) {
+  using P = typename F::Params;
+  F g = F::from_const(inverse ? P::ROOT_OF_UNITY_INV : P::ROOT_OF_UNITY);
+  for (uint32_t i = log; i < 28; ++i) g = sqr(g);
+  return g;
+}
+template <class F>
+KG_HD F ntt_pow(F base, uint64_t e) {
+  F r = F::one();
+  while (e) {
+    if (e & 1) r = mul(r, base);
+    base = sqr(base);
+    e >>= 1;
+  }
+  return r;
+}
+
+// ---- plan: which tile shapes transform 2^log_n elements --------------------------------------------------------
+// n = n1 * n2 * n3 with the Cooley-Tukey index map j = j1*n2*n3 + j2*n3 + j3 -> i = i1 + n1*i2 + n1*n2*i3 (natural order in
+// and out, no bit-reversal pass):
+//   step A (column)  n1-point DFTs over j1, * w_n^(i1 * (j2*n3 + j3)),          data -> scratch
+//   step B (column)  n2-point DFTs over j2 inside each i1 slab, * w_n^(n1*i2*j3), scratch in place   [three-step plans only]
+//   step C (row)     n3-point DFTs over j3 along contiguous rows, written transposed, scratch -> data
+// Two steps (n2 = 1) up to 2^22: two HBM round trips, factors up to 2^11 (a 4096-element tile is 144 KiB of LDS).
+struct NttStepDesc { int log_m, log_tc; bool row; };
+inline int ntt_tile_log(int log_m, int want) {        // tile = 2^(log_m + log_tc) elements: 1024, 2048 or 4096
+  return want < log_m ? log_m : want;
+}
+// steps: 0 = automatic (one step up to 2^11, two up to 2^22, three above); 3 forces three steps from 2^18 up.
+// tile: 0 = automatic, else log2 of the tile size wanted (10..12)
+inline int ntt_plan(uint32_t log_n, int steps, NttStepDesc out[3], int tile = 0) {
+  const int k = (int)log_n;
+  if (k <= NTT_MAX_LOG_M) { out[0] = {k, 0, true}; return 1; }
+  const bool three = k > 2 * NTT_MAX_LOG_M || (steps == 3 && k >= 18);
+  if (!three) {
+    const int k1 = (k + 1) / 2, k3 = k - k1;
+    const int want = tile ? tile : (k <= 19 ? 10 : (k <= 21 ? 11 : 12));
+    out[0] = {k1, ntt_tile_log(k1, want) - k1, false};
+    out[1] = {k3, ntt_tile_log(k3, want) - k3, true};
+    return 2;
+  }
+  const int k1 = (k + 2) / 3, k2 = (k - k1 + 1) / 2, k3 = k - k1 - k2;
+  const int want = tile ? tile : (k <= 20 ? 10 : 11);
+  out[0] = {k1, ntt_tile_log(k1, want) - k1, false};
+  out[1] = {k2, ntt_tile_log(k2, want) - k2, false};
+  out[2] = {k3, ntt_tile_log(k3, want) - k3, true};
+  return 3;
+}
+}  // namespace kg
+
+namespace kg {
+// the arguments of step i of a plan; returns the number of tiles (= workgroups)
+struct NttTables { const uint32_t *small, *lo, *hi, *cos_lo, *cos_hi, *direct0, *direct1; uint32_t lo_bits; };
+inline uint32_t ntt_step_args(uint32_t log_n, int nsteps, const NttStepDesc* d, int i, const NttTables& T, uint64_t* data, uint64_t* tmp,
+                              int inverse, int coset, NttStepArgs& a) {
+  a = NttStepArgs{};
+  a.tw_m = T.small; a.tw_lo = T.lo; a.tw_hi = T.hi; a.cos_lo = T.cos_lo; a.cos_hi = T.cos_hi; a.lo_bits = T.lo_bits;
+  const uint32_t pre = (coset && !inverse) ? 1u : 0u;                     // coset_dft: * 7^j before the transform
+  const uint32_t post = inverse ? (coset ? 2u : 3u) : 0u;                 // coset_idft: * n^-1 * 7^-i ; idft: * n^-1 (cos_lo[0] of the inverse tables)
+  const uint32_t lt = log_n - (uint32_t)(d[i].log_m + d[i].log_tc);      // log2(number of tiles)
+  a.tile_shift = lt >= 3 ? lt - 3 : 0;
+  if (nsteps == 1) {
+    a.in = data; a.out = data; a.scale_mode = pre ? 1u : post;
+    return 1u;
+  }
+  const uint32_t k1 = (uint32_t)d[0].log_m, k3 = (uint32_t)d[nsteps - 1].log_m;
+  if (i == 0) {                                    // step A: data -> tmp
+    a.in = data; a.out = tmp; a.log_inner = log_n - k1; a.mult = 1; a.tw_direct = T.direct0; a.scale_mode = pre;
+  } else if (i < nsteps - 1) {                     // step B: tmp in place
+    a.in = tmp; a.out = tmp; a.log_inner = k3; a.mult = 1ull << k1; a.tw_direct = T.direct1;
+  } else {                                         // step C: tmp -> data, transposed write
+    a.in = tmp; a.out = data; a.log_G = log_n - k3; a.log_n1 = k1; a.scale_mode = post;
+  }
+  return 1u << lt;
+}
+}  // namespace kg
