@@ -380,8 +380,9 @@ KG_HD F ntt_pow(F base, uint64_t e) {
 //   step C (row)     n3-point DFTs over j3 along contiguous rows, written transposed, scratch -> data
 // Two steps (n2 = 1) up to 2^22: two HBM round trips, factors up to 2^11 (a 4096-element tile is 144 KiB of LDS).
 struct NttStepDesc { int log_m, log_tc; bool row; };
-inline int ntt_tile_log(int log_m, int want) {        // tile = 2^(log_m + log_tc) elements: 1024, 2048 or 4096
-  return want < log_m ? log_m : want;
+inline int ntt_tile_log(int log_m, int want, bool forced = false) {   // tile = 2^(log_m + log_tc) elements: 1024, 2048 or 4096
+  const int least = forced ? log_m : log_m + 1;        // automatic plans keep at least two adjacent DFTs per tile (64-byte runs)
+  return want < least ? least : want;
 }
 // steps: 0 = automatic (one step up to 2^11, two up to 2^22, three above); 3 forces three steps from 2^18 up.
 // tile: 0 = automatic, else log2 of the tile size wanted (10..12)
@@ -392,15 +393,15 @@ inline int ntt_plan(uint32_t log_n, int steps, NttStepDesc out[3], int tile = 0)
   if (!three) {
     const int k1 = (k + 1) / 2, k3 = k - k1;
     const int want = tile ? tile : (k <= 19 ? 10 : (k <= 21 ? 11 : 12));
-    out[0] = {k1, ntt_tile_log(k1, want) - k1, false};
-    out[1] = {k3, ntt_tile_log(k3, want) - k3, true};
+    out[0] = {k1, ntt_tile_log(k1, want, tile != 0) - k1, false};
+    out[1] = {k3, ntt_tile_log(k3, want, tile != 0) - k3, true};
     return 2;
   }
   const int k1 = (k + 2) / 3, k2 = (k - k1 + 1) / 2, k3 = k - k1 - k2;
   const int want = tile ? tile : (k <= 20 ? 10 : 11);
-  out[0] = {k1, ntt_tile_log(k1, want) - k1, false};
-  out[1] = {k2, ntt_tile_log(k2, want) - k2, false};
-  out[2] = {k3, ntt_tile_log(k3, want) - k3, true};
+  out[0] = {k1, ntt_tile_log(k1, want, tile != 0) - k1, false};
+  out[1] = {k2, ntt_tile_log(k2, want, tile != 0) - k2, false};
+  out[2] = {k3, ntt_tile_log(k3, want, tile != 0) - k3, true};
   return 3;
 }
 }  // namespace kg

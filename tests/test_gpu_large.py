@@ -89,6 +89,27 @@ def test_commit_2_24_properties(ctx, curve, sfd):
     assert not is_ and inf == 0 and (xy == cs).all()
 
 
+@pytest.mark.parametrize("curve,sfd,cv", [(0, 0, "g1"), (1, 1, "gk")])
+def test_commit_2_24_matches_the_oracles_pippenger(ctx, oracle, curve, sfd, cv):
+    """BASELINE.json configs[4] at full size against the oracle: commit(m) = affine(msm_curve_addition(g, m)) -- the
+    restatement of groth16/src/msm.rs:6-48 runs the 2^24 pairs in ~10 s (one thread per window, c = 19) and is itself
+    equal to the naive fold of nova/src/pedersen.rs:15-20 where both are feasible (tests/test_oracle_pinning.py)."""
+    import kogarashi_amd as K
+    n = 1 << 24
+    fld = K.KG_FR if sfd == 0 else K.KG_FQ
+    g, m = ctx.empty((n, 8)), ctx.empty((n, 4))
+    ctx.gen_bases(curve, SEED + 40 + curve, 0, n, g.ptr)
+    ctx.gen_scalars(fld, SEED + 41, 0, n, m.ptr)
+    got_xy, got_inf = ctx.commit(curve, g.ptr, 0, m.ptr, n)
+    want_xy, want_inf = oracle.to_affine(cv, oracle.msm(cv, g.numpy(), m.numpy(), None, threads=14))
+    assert got_inf == want_inf == 0 and (got_xy == want_xy).all()
+    # and with the key resident (kg_bases_register), as PedersenCommitment { g } is
+    ctx.bases_register(curve, g.ptr, 0, n)
+    reg_xy, reg_inf = ctx.commit(curve, g.ptr, 0, m.ptr, n)
+    ctx.bases_unregister(g.ptr)
+    assert reg_inf == 0 and (reg_xy == want_xy).all()
+
+
 def test_ntt_2_22_all_variants_match_oracle(ctx, oracle):
     """BASELINE.json configs[2] against the oracle's restatement of Fft<Fr> (fft.rs:92-127), all four transforms."""
     import kogarashi_amd as K

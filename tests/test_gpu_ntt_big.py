@@ -1,0 +1,124 @@
+"""Every transform length the ABI accepts beyond the sizes tests/test_gpu_parity.py and test_gpu_large.py compare with
+the oracle: the odd lengths 2^19, 2^21, 2^23 and 2^25 against the oracle's Fft<Fr> (fft.rs:92-127), 2^26 against the
+(oracle-checked) 2^25 path through the decimation identity, 2^27 and 2^28 (S = 28, bn254/src/fr.rs:53) through impulse
+responses, round trips and linearity evaluated on the device.  Three-step plans (ntt_tile.h) start at 2^23."""
+import numpy as np
+import pytest
+
+from helpers import L
+
+pytestmark = pytest.mark.gpu
+SEED = 0x4B6F676172617368
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import kogarashi_amd as K
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+def _tensor(n_words):
+    import torch
+    return torch.empty(n_words, dtype=torch.int64, device="cuda:0")
+
+
+def _mont(pyoracle, x):
+    return L(pyoracle.to_mont(x % pyoracle.R_MOD, pyoracle.R_MOD))
+
+
+@pytest.mark.parametrize("k", [19, 21, 23])
+def test_odd_sizes_match_oracle(ctx, oracle, k):
+    import kogarashi_amd as K
+    n = 1 << k
+    d, work = ctx.empty((n, 4)), ctx.empty((n, 4))
+    ctx.gen_scalars(K.KG_FR, SEED + 200 + k, 0, n, d.ptr)
+    v = d.numpy()
+    fo = oracle.Fft(k)
+    for name, inv, coset in (("dft", False, False), ("idft", True, False), ("coset_dft", False, True), ("coset_idft", True, True)):
+        ctx.copy_d2d(work.ptr, d.ptr, n * 32)
+        ctx.ntt(work.ptr, k, inv, coset)
+        assert (work.numpy() == getattr(fo, name)(v, threads=16)).all(), (k, name)
+
+
+def test_2_25_matches_oracle(ctx, oracle):
+    import kogarashi_amd as K
+    k = 25
+    n = 1 << k
+    d = ctx.empty((n, 4))
+    ctx.gen_scalars(K.KG_FR, SEED + 225, 0, n, d.ptr)
+    v = d.numpy()
+    ctx.ntt(d.ptr, k, False, False)
+    got = d.numpy()
+    want = oracle.Fft(k).dft(v, threads=16)
+    assert (got == want).all()
+    del want
+    ctx.ntt(d.ptr, k, True, False)
+    assert (d.numpy() == v).all()
+
+
+def test_2_26_by_decimation_against_2_25(ctx, pyoracle):
+    """X[i] = E[i] + w^i O[i], X[i + n/2] = E[i] - w^i O[i] with E, O the 2^25-point transforms of the even / odd samples
+    (the first butterfly level of fft.rs:195-218 written out), w = ROOT_OF_UNITY^(2^(28-26))."""
+    import torch
+    import kogarashi_amd as K
+    k = 26
+    n, h = 1 << k, 1 << (k - 1)
+    x = _tensor(4 * n)
+    ctx.gen_scalars(K.KG_FR, SEED + 226, 0, n, x.data_ptr())
+    ctx.sync()
+    xv = x.view(n, 4)
+    e, o = xv[0::2].contiguous(), xv[1::2].contiguous()
+    torch.cuda.synchronize()
+    ctx.ntt(x.data_ptr(), k, False, False)
+    ctx.ntt(e.data_ptr(), k - 1, False, False)
+    ctx.ntt(o.data_ptr(), k - 1, False, False)
+    pw = _tensor(4 * h)
+    ctx.field_powers(K.KG_FR, _mont(pyoracle, 1), _mont(pyoracle, pyoracle.fr_omega(k)), pw.data_ptr(), h)
+    ctx.field_vec_op(K.KG_FR, "mul", o.data_ptr(), pw.data_ptr(), o.data_ptr(), h)
+    ctx.field_vec_op(K.KG_FR, "add", e.data_ptr(), o.data_ptr(), pw.data_ptr(), h)      # pw <- E + w^i O
+    ctx.field_vec_op(K.KG_FR, "sub", e.data_ptr(), o.data_ptr(), e.data_ptr(), h)       # e  <- E - w^i O
+    ctx.sync()
+    assert torch.equal(x[: 4 * h], pw) and torch.equal(x[4 * h:], e.view(-1))
+
+
+@pytest.mark.parametrize("k", [24, 27, 28])
+def test_huge_sizes_by_device_side_properties(ctx, pyoracle, k):
+    """impulse responses against kg_field_powers (dft of a delta_j0 + b delta_j1 is a w^(i j0) + b w^(i j1), every output
+    index), both round trips and linearity on random vectors; all comparisons on the device."""
+    import torch
+    import kogarashi_amd as K
+    P = pyoracle
+    n = 1 << k
+    w = P.fr_omega(k)
+    x, y, t = _tensor(4 * n), _tensor(4 * n), _tensor(4 * n)
+    j0, j1 = 1, (n // 3) | 1
+    a, b = 0x1234567 + k, P.R_MOD - 99
+    x.zero_()
+    torch.cuda.synchronize()
+    ctx.write(x.data_ptr() + 32 * j0, _mont(P, a).reshape(1, 4))
+    ctx.write(x.data_ptr() + 32 * j1, _mont(P, b).reshape(1, 4))
+    ctx.ntt(x.data_ptr(), k, False, False)
+    ctx.field_powers(K.KG_FR, _mont(P, a), _mont(P, pow(w, j0, P.R_MOD)), y.data_ptr(), n)
+    ctx.field_powers(K.KG_FR, _mont(P, b), _mont(P, pow(w, j1, P.R_MOD)), t.data_ptr(), n)
+    ctx.field_vec_op(K.KG_FR, "add", y.data_ptr(), t.data_ptr(), y.data_ptr(), n)
+    ctx.sync()
+    assert torch.equal(x, y), "impulse response"
+    # round trips (fft_transformation_test, fft.rs:246-257) and linearity on random data
+    ctx.gen_scalars(K.KG_FR, SEED + 300 + k, 0, n, x.data_ptr())
+    ctx.gen_scalars(K.KG_FR, SEED + 400 + k, 0, n, y.data_ptr())
+    ctx.sync()
+    t.copy_(x)
+    torch.cuda.synchronize()
+    for coset in (False, True):
+        ctx.ntt(t.data_ptr(), k, False, coset)
+        ctx.ntt(t.data_ptr(), k, True, coset)
+        ctx.sync()
+        assert torch.equal(t, x), ("round trip", coset)
+    ctx.field_vec_op(K.KG_FR, "add", x.data_ptr(), y.data_ptr(), t.data_ptr(), n)
+    for v in (x, y, t):
+        ctx.ntt(v.data_ptr(), k, False, False)
+    ctx.field_vec_op(K.KG_FR, "add", x.data_ptr(), y.data_ptr(), x.data_ptr(), n)
+    ctx.sync()
+    assert torch.equal(x, t), "linearity"
