@@ -27,13 +27,9 @@ int ensure_ws_sort(kg_ctx* c, int set, size_t bytes) {
 // The context's queues (main, scalar, two reduction queues, an upload queue for kg_msm_host) should each own a hardware queue:
 // the runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with whatever else the process
 // creates), and two streams on one hardware queue run in submission order -- measured on the prover: 2.83 ms per proof with a
-// queue each against 3.28 ms at the default.  The variable is read when the HIP runtime initialises, so it is set (unless
-// the user has) when this library is loaded; a host that initialises HIP earlier exports it itself (bench.py does).
-namespace {
-struct HwQueueDefault {
-  HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
-} hw_queue_default;
-}  // namespace
+// queue each against 3.28 ms at the default.  The variable is read when the HIP runtime initialises.  The library never
+// touches the environment on its own: a host that wants the setting calls kg_init() (or exports the variable) before
+// anything initialises HIP; kg_hw_queue_setting() reports what the process has.
 // Queues of the context.  (CU-masked queues -- hipExtStreamCreateWithCUMask, a compute / service partition -- and queue
 // priorities were measured and dropped: tools/ubench/cumask_probe.hip; what makes concurrent queues
 // work is the wave priority of the service kernels, KG_SERVICE_PRIO.)
@@ -148,6 +144,15 @@ void tw_cache_free(kg_ctx* c);   // ntt.hip
 
 extern "C" {
 
+int kg_init(void) {
+  // setenv is not thread-safe against concurrent getenv: call this from the host's start-up path, before threads exist
+  if (getenv("GPU_MAX_HW_QUEUES")) return 0;
+  return setenv("GPU_MAX_HW_QUEUES", "16", 0) == 0 ? 1 : 0;
+}
+int kg_hw_queue_setting(void) {
+  const char* e = getenv("GPU_MAX_HW_QUEUES");
+  return e ? atoi(e) : 0;
+}
 int kg_version(void) { return 1; }
 
 int kg_device_count(void) {

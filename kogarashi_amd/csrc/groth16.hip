@@ -256,20 +256,26 @@ int fixed_base_t(kg_ctx* ctx, int curve, const uint64_t* d_k, size_t n, uint64_t
     // (w = 31: d * 2^248 may exceed the group order; it is used as a plain integer multiple, which is what the table needs --
     // the double-and-add below takes the canonical 254 bits of k mod p only, so reduce on the host instead)
     uint64_t *d_tk = nullptr, *d_txy = nullptr; uint8_t* d_tinf = nullptr; uint32_t* table = nullptr;
-    KG_HIP(ctx, hipMalloc((void**)&d_tk, tn * 32));
-    KG_HIP(ctx, hipMalloc((void**)&d_txy, tn * 2 * E64 * 8));
-    KG_HIP(ctx, hipMalloc((void**)&d_tinf, tn));
-    KG_HIP(ctx, hipMalloc((void**)&table, tn * PW * 4));
-    KG_HIP(ctx, hipMemcpyAsync(d_tk, hk.data(), tn * 32, hipMemcpyHostToDevice, st));
-    KG_HIP(ctx, hipStreamSynchronize(st));
+    auto release = [&](bool keep_table) {             // every exit below frees what was allocated before it
+      hipFree(d_tk); hipFree(d_txy); hipFree(d_tinf);
+      if (!keep_table) hipFree(table);
+    };
+    hipError_t e = hipMalloc((void**)&d_tk, tn * 32);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_txy, tn * 2 * E64 * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_tinf, tn);
+    if (e == hipSuccess) e = hipMalloc((void**)&table, tn * PW * 4);
+    if (e != hipSuccess) { release(false); return set_err(ctx, KG_ERR_OOM, "fixed-base table allocation", e); }
+    e = hipMemcpyAsync(d_tk, hk.data(), tn * 32, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { release(false); return set_err(ctx, KG_ERR_HIP, "fixed-base table upload", e); }
     int rc = kg_field_vec_op(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, KG_OP_TO_MONT, d_tk, nullptr, d_tk, tn);
     if (rc == KG_OK) {
       hipLaunchKernelGGL((k_fixed_base_mul<F, SP, E64>), dim3((unsigned)((tn + 63) / 64)), dim3(64), 0, st, d_tk, tn, d_txy, d_tinf);
       hipLaunchKernelGGL((k_fb_pack<F, E64>), dim3((unsigned)((tn + 63) / 64)), dim3(64), 0, st, d_txy, tn, table);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = set_err(ctx, KG_ERR_HIP, "fixed-base table construction");
     }
-    hipFree(d_tk); hipFree(d_txy); hipFree(d_tinf);
-    if (rc != KG_OK) { hipFree(table); return rc; }
+    release(rc == KG_OK);
+    if (rc != KG_OK) return rc;
     ctx->fb_table[curve] = table;
   }
   constexpr int NW = PointIO<F>::NW;

@@ -18,7 +18,7 @@ KG_FR, KG_FQ = 0, 1
 KG_G1, KG_GRUMPKIN, KG_G2 = 0, 1, 2
 OPS = {"add": 0, "sub": 1, "mul": 2, "square": 3, "neg": 4, "double": 5, "invert": 6, "from_mont": 7, "to_mont": 8}
 EXPORTS = [
-    "kg_version", "kg_device_count", "kg_strerror", "kg_ctx_create", "kg_ctx_destroy", "kg_last_error", "kg_ctx_set_stream",
+    "kg_version", "kg_init", "kg_hw_queue_setting", "kg_device_count", "kg_strerror", "kg_ctx_create", "kg_ctx_destroy", "kg_last_error", "kg_ctx_set_stream",
     "kg_ctx_sync", "kg_malloc", "kg_free", "kg_memcpy_h2d", "kg_memcpy_d2h", "kg_memcpy_d2d", "kg_field_vec_op",
     "kg_field_vec_scale", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_msm", "kg_msm_host", "kg_commit",
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
@@ -78,6 +78,17 @@ def load():
         _lib.kg_sharded_key_destroy.argtypes = [C.c_void_p]
         _lib.kg_sharded_key_destroy.restype = None
     return _lib
+
+
+def init() -> bool:
+    """kg_init: one hardware queue per library queue (GPU_MAX_HW_QUEUES=16 unless set).  Explicit and optional: call it
+    before anything initialises HIP (importing torch does not; the first torch.cuda call or Context does).  The package
+    never changes the environment by itself."""
+    return bool(load().kg_init())
+
+
+def hw_queue_setting() -> int:
+    return int(load().kg_hw_queue_setting())
 
 
 def msm_table_window(msm_len: int) -> int:

@@ -20,13 +20,9 @@ impl HostCsr {
         let val = unsafe { core::slice::from_raw_parts(words, 4 * val.len()) }.to_vec();
         Some(Self { row_ptr, col, val })
     }
-    /// sizes plus the first and last entries: the matrices reach the glue as fresh clones, so residency is keyed by content
-    pub fn fingerprint(&self, out: &mut Vec<u64>) {
-        out.extend([self.row_ptr.len() as u64, self.col.len() as u64]);
-        out.extend(self.col.iter().take(8));
-        out.extend(self.col.iter().rev().take(8));
-        out.extend(self.val.iter().take(16));
-        out.extend(self.val.iter().rev().take(16));
+    /// largest column index (what z must cover), 0 for an empty matrix
+    pub fn max_col(&self) -> u64 {
+        self.col.iter().copied().max().unwrap_or(0)
     }
     pub fn upload(&self, ctx: &Context) -> Option<ResidentMatrix> {
         let pad = [0u64; 4];
@@ -49,22 +45,58 @@ impl ResidentMatrix {
     }
 }
 
-/// Three matrices of one constraint system, resident; `fingerprint` as `HostCsr::fingerprint` of the three in order.
+/// 128-bit content hash of (a, b, c): every row boundary, column index and coefficient word goes in, so two constraint
+/// systems share resident matrices only if they are the same matrices.  One pass over the entries
+/// (`SparseMatrix::for_each_entry`, patches/zkstd_matrix_csr.diff), no allocation: this is what a proof pays instead of
+/// rebuilding and re-uploading the CSR.
+pub(crate) fn content_hash<F: PrimeField + 'static>(mats: [&SparseMatrix<F>; 3], l: usize) -> Option<[u64; 2]> {
+    scalar_words::<F>(&[])?;                                   // a field the backend serves: 4 x u64 per element
+    let (mut h1, mut h2) = (0xcbf2_9ce4_8422_2325u64, 0x9e37_79b9_7f4a_7c15u64);
+    let mut mix = |w: u64| {
+        h1 = (h1 ^ w).wrapping_mul(0x0000_0100_0000_01b3);                                       // FNV-1a over 64-bit words
+        h2 = (h2.rotate_left(23) ^ w).wrapping_mul(0xff51_afd7_ed55_8ccd).wrapping_add(0x2545_f491_4f6c_dd1d);
+    };
+    for (k, mat) in mats.iter().enumerate() {
+        mix(0xa5a5_0000_0000_0000 | k as u64);
+        let mut last_row = usize::MAX;
+        mat.for_each_entry(l, |row, col, coeff| {
+            if row != last_row {
+                mix(0x5a5a_0000_0000_0000 ^ row as u64);       // row boundary (empty rows shift every later row index)
+                last_row = row;
+            }
+            mix(col);
+            let w = unsafe { &*(coeff as *const F as *const [u64; 4]) };
+            w.iter().for_each(|&x| mix(x));
+        });
+        mix(mat.rows() as u64);
+    }
+    Some([h1, h2])
+}
+
+/// Three matrices of one constraint system, resident; `fingerprint` = `content_hash` of the three.
 pub(crate) struct ResidentShape {
     pub m: [ResidentMatrix; 3],
-    pub fingerprint: Vec<u64>,
+    pub fingerprint: [u64; 2],
+    /// rows of each matrix and the largest column index any of them holds: what a call's (m, z) must cover
+    pub rows: usize,
+    pub max_col: u64,
 }
 unsafe impl Send for ResidentShape {}
 
 impl ResidentShape {
-    /// Host CSR of (a, b, c) with its fingerprint; `upload` only when the resident copy (if any) does not match.
-    pub fn host<F: PrimeField + 'static>(a: &SparseMatrix<F>, b: &SparseMatrix<F>, c: &SparseMatrix<F>, l: usize) -> Option<([HostCsr; 3], Vec<u64>)> {
+    /// Builds the host CSR of (a, b, c) and uploads it: only when no resident copy carries this fingerprint.
+    pub fn build<F: PrimeField + 'static>(ctx: &Context, a: &SparseMatrix<F>, b: &SparseMatrix<F>, c: &SparseMatrix<F>, l: usize,
+                                           fingerprint: [u64; 2]) -> Option<Self> {
         let host = [HostCsr::of(a, l)?, HostCsr::of(b, l)?, HostCsr::of(c, l)?];
-        let mut print = Vec::new();
-        host.iter().for_each(|h| h.fingerprint(&mut print));
-        Some((host, print))
+        let rows = host[0].row_ptr.len() - 1;
+        if host.iter().any(|h| h.row_ptr.len() != rows + 1) {
+            return None;                                       // the three matrices of a shape have one row per constraint
+        }
+        let max_col = host.iter().map(|h| h.max_col()).max().unwrap_or(0);
+        Some(Self { m: [host[0].upload(ctx)?, host[1].upload(ctx)?, host[2].upload(ctx)?], fingerprint, rows, max_col })
     }
-    pub fn upload(ctx: &Context, host: &[HostCsr; 3], fingerprint: Vec<u64>) -> Option<Self> {
-        Some(Self { m: [host[0].upload(ctx)?, host[1].upload(ctx)?, host[2].upload(ctx)?], fingerprint })
+    /// the kernels index row_ptr[0..=m] and z[col]: refuse a call the resident matrices do not cover (the reference would panic)
+    pub fn covers(&self, m: usize, z_len: usize) -> bool {
+        self.rows == m && (self.max_col as usize) < z_len.max(1)
     }
 }

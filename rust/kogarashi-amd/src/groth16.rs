@@ -4,14 +4,14 @@
 //! five MSMs (the reference's eight, merged) and the host assembly inside `kg_groth16_prove_r1cs_bn254`, and returns the
 //! three affine points.  (`prove` takes host-side evaluation vectors instead.)
 use std::collections::HashMap;
-use std::sync::{Arc, Mutex, OnceLock};
+use std::sync::{Arc, Mutex};
 
 use bn_254::{Fr, G1Affine, G2Affine};
 use kogarashi_amd_sys as sys;
 use zkstd::common::CurveGroup;
 use zkstd::matrix::SparseMatrix;
 
-use crate::csr::ResidentShape;
+use crate::csr::{content_hash, ResidentShape};
 use crate::{contexts, marshal, DeviceBuf, GpuCurve, Status};
 
 /// Device-resident `Parameters` (+ the vk points the assembly needs).  Built once, e.g. in `Prover::new`/first proof.
@@ -99,9 +99,13 @@ impl ResidentCrs {
         let ctxs = contexts().ok_or(Status(sys::KG_ERR_NO_DEVICE))?;
         let ctx = &ctxs[0];
         let mut shape = self.shape.lock().map_err(|_| Status(sys::KG_ERR_BAD_ARG))?;
-        let (host, print) = ResidentShape::host(a, b, c, x.len()).ok_or(Status(sys::KG_ERR_BAD_ARG))?;
+        // one hashing pass over the entries; the host CSR is rebuilt (and uploaded) only when the circuit changed
+        let print = content_hash([a, b, c], x.len()).ok_or(Status(sys::KG_ERR_BAD_ARG))?;
         if shape.as_ref().map(|s| s.fingerprint != print).unwrap_or(true) {
-            *shape = Some(ResidentShape::upload(ctx, &host, print).ok_or(Status(sys::KG_ERR_OOM))?);
+            *shape = Some(ResidentShape::build(ctx, a, b, c, x.len(), print).ok_or(Status(sys::KG_ERR_OOM))?);
+        }
+        if !shape.as_ref().unwrap().covers(self.crs.m, x.len() + w.len()) {
+            return Err(Status(sys::KG_ERR_BAD_ARG));
         }
         let m3 = &shape.as_ref().unwrap().m;
         let (ca, cb, cc) = (m3[0].csr(), m3[1].csr(), m3[2].csr());
@@ -148,7 +152,9 @@ impl ResidentCrs {
 pub fn resident(h: &[G1Affine], l: &[G1Affine], a: &[G1Affine], b_g1: &[G1Affine], b_g2: &[G2Affine], alpha_g1: &G1Affine,
                 beta_g1: &G1Affine, delta_g1: &G1Affine, beta_g2: &G2Affine, delta_g2: &G2Affine, m: usize, n_inputs: usize,
                 n_aux: usize) -> Option<Arc<ResidentCrs>> {
-    static CACHE: OnceLock<Mutex<HashMap<(usize, usize), (Arc<ResidentCrs>, [u64; 16])>>> = OnceLock::new();
+    // const `Mutex::new` (the pinned nightly-2022-11-14 has no stable `OnceLock`); a failed upload is cached as `None` so that
+    // later proofs go straight to the CPU path instead of repeating the CRS upload and the table build
+    static CACHE: Mutex<Option<HashMap<(usize, usize), (Option<Arc<ResidentCrs>>, [u64; 16], usize)>>> = Mutex::new(None);
     if a.is_empty() {
         return None;
     }
@@ -159,15 +165,16 @@ pub fn resident(h: &[G1Affine], l: &[G1Affine], a: &[G1Affine], b_g1: &[G1Affine
         g
     };
     let key = (a.as_ptr() as usize, a.len());
-    let mut cache = CACHE.get_or_init(|| Mutex::new(HashMap::new())).lock().ok()?;
-    if let Some((crs, g)) = cache.get(&key) {
-        if *g == guard && crs.crs.m == m {
-            return Some(crs.clone());
+    let mut lock = CACHE.lock().ok()?;
+    let cache = lock.get_or_insert_with(HashMap::new);
+    if let Some((crs, g, cm)) = cache.get(&key) {
+        if *g == guard && *cm == m {
+            return crs.clone();
         }
     }
-    let crs = Arc::new(ResidentCrs::new(h, l, a, b_g1, b_g2, alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, m, n_inputs, n_aux).ok()?);
-    cache.insert(key, (crs.clone(), guard));
-    Some(crs)
+    let crs = ResidentCrs::new(h, l, a, b_g1, b_g2, alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, m, n_inputs, n_aux).ok().map(Arc::new);
+    cache.insert(key, (crs.clone(), guard, m));
+    crs
 }
 
 impl Drop for ResidentCrs {

@@ -108,28 +108,46 @@ impl Drop for DeviceBuf {
 
 mod global {
     use super::*;
-    use std::sync::{Mutex, MutexGuard, OnceLock};
+    use std::sync::{Mutex, MutexGuard};
 
-    static CTXS: OnceLock<Option<Mutex<Vec<Context>>>> = OnceLock::new();
+    // `Mutex::new` is const on the reference's pinned toolchain (nightly-2022-11-14); `OnceLock` is not stable there.
+    // None: not probed yet; Some(vec): probed -- an empty vec means "no device", and is never probed again.
+    static CTXS: Mutex<Option<Vec<Context>>> = Mutex::new(None);
+
+    /// The contexts of the visible GPUs (one each), created on first use, behind the process-wide lock.
+    pub struct Contexts(MutexGuard<'static, Option<Vec<Context>>>);
+    impl core::ops::Deref for Contexts {
+        type Target = Vec<Context>;
+        fn deref(&self) -> &Vec<Context> {
+            self.0.as_ref().unwrap()
+        }
+    }
 
     /// One context per visible GPU, created on first use; `None` when no device is present (CPU bodies run).
-    pub fn contexts() -> Option<MutexGuard<'static, Vec<Context>>> {
-        CTXS.get_or_init(|| {
-            let n = Context::device_count();
-            if n <= 0 {
-                return None;
-            }
+    pub fn contexts() -> Option<Contexts> {
+        let mut guard = CTXS.lock().ok()?;
+        if guard.is_none() {
             let mut v = Vec::new();
-            for d in 0..n {
+            // one hardware queue per library queue; a no-op when the host exported GPU_MAX_HW_QUEUES or initialised HIP itself.
+            // The glue's first backend call is the host's opt-in (`gpu` feature): call `kogarashi_amd::contexts()` from the
+            // start-up path if other threads may be reading the environment later.
+            unsafe { sys::kg_init() };
+            let n = Context::device_count();
+            for d in 0..n.max(0) {
                 match Context::new(d) {
                     Ok(c) => v.push(c),
-                    Err(_) => return None,
+                    Err(_) => {
+                        v.clear();
+                        break;
+                    }
                 }
             }
-            Some(Mutex::new(v))
-        })
-        .as_ref()
-        .and_then(|m| m.lock().ok())
+            *guard = Some(v);
+        }
+        if guard.as_ref().map(|v| v.is_empty()).unwrap_or(true) {
+            return None;
+        }
+        Some(Contexts(guard))
     }
 }
 pub use global::contexts;

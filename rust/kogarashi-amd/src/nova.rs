@@ -2,19 +2,21 @@
 //! kernel (`kg_nova_cross_term`), the six sparse products of the reference (`SparseMatrix::prod`, zkstd/src/matrix.rs:32-47)
 //! included.  The shape matrices cross the ABI as CSR over z = (u | x | w) -- `SparseMatrix::to_csr`, added by
 //! `patches/zkstd_matrix_csr.diff`, applies `prod`'s own index rule (Instance(i) -> i, Witness(i) -> i + l) -- and stay
-//! resident: `R1csShape::matrices()` clones them on every call, so the cache is keyed by content (sizes plus a fingerprint
-//! of the first and last rows), not by address.
+//! resident: `R1csShape::matrices()` clones them on every call, so the cache is keyed by content (a 128-bit hash over every
+//! row boundary, column and coefficient: `csr::content_hash`), not by address; a call whose hash matches the resident copy
+//! builds no host CSR and uploads nothing but z1, z2.
 use std::collections::HashMap;
-use std::sync::{Mutex, OnceLock};
+use std::sync::Mutex;
 
 use kogarashi_amd_sys as sys;
 use zkstd::common::PrimeField;
 use zkstd::matrix::SparseMatrix;
 
-use crate::csr::ResidentShape;
+use crate::csr::{content_hash, ResidentShape};
 use crate::{contexts, scalar_words, DeviceBuf};
 
-static SHAPES: OnceLock<Mutex<HashMap<(usize, usize, usize, i32), ResidentShape>>> = OnceLock::new();
+// const `Mutex::new` (available on the pinned nightly-2022-11-14; `OnceLock` is not): the map is made on first use
+static SHAPES: Mutex<Option<HashMap<(usize, usize, i32), ResidentShape>>> = Mutex::new(None);
 
 /// The cross term of a folding step; `None` (no device, a field the backend does not serve, any non-zero status) lets the
 /// caller's CPU body run.  `l` = x.len() + 1 for both pairs (the relaxed instance and the fresh one share the shape).
@@ -27,16 +29,17 @@ pub fn cross_term<F: PrimeField + 'static>(a: &SparseMatrix<F>, b: &SparseMatrix
     }
     let ctxs = contexts()?;
     let ctx = &ctxs[0];
-    let mut shapes = SHAPES.get_or_init(|| Mutex::new(HashMap::new())).lock().ok()?;
-    // the host CSR is rebuilt per call (the matrices arrive as fresh clones); the device copy is reused while its
-    // fingerprint matches
-    let (host, print) = ResidentShape::host(a, b, c, l)?;
-    let nnz: usize = host.iter().map(|h| h.col.len()).sum();
-    let key = (m as usize, l, nnz, field);
+    let print = content_hash([a, b, c], l)?;
+    let mut guard = SHAPES.lock().ok()?;
+    let shapes = guard.get_or_insert_with(HashMap::new);
+    let key = (m as usize, l, field);
     if shapes.get(&key).map(|s| s.fingerprint != print).unwrap_or(true) {
-        shapes.insert(key, ResidentShape::upload(ctx, &host, print)?);
+        shapes.insert(key, ResidentShape::build(ctx, a, b, c, l, print)?);
     }
     let shape = shapes.get(&key)?;
+    if !shape.covers(m as usize, z1.len()) {
+        return None;                                           // row count or a column index outside (m, z): let the CPU body decide
+    }
     let words = |s: &[F]| unsafe { core::slice::from_raw_parts(s.as_ptr() as *const u64, 4 * s.len()) };
     let (d1, d2) = (DeviceBuf::from_words(ctx, words(z1)).ok()?, DeviceBuf::from_words(ctx, words(z2)).ok()?);
     let out = DeviceBuf::new(ctx, m as usize * 32).ok()?;

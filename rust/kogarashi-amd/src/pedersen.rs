@@ -4,7 +4,7 @@
 //! affine partial sums are added on the host (`kg_sharded_key_commit`).  The reference re-reads `g` on every call and
 //! folds naive double-and-add scalar multiplications.
 use std::collections::HashMap;
-use std::sync::{Mutex, OnceLock};
+use std::sync::Mutex;
 
 use kogarashi_amd_sys as sys;
 use zkstd::common::BNAffine;
@@ -22,7 +22,7 @@ unsafe impl Send for Resident {}
 /// keys by (address of g, length): `PedersenCommitment` derives Clone / Encode / Decode / PartialEq, so the device handle
 /// lives here instead of in the struct; the fingerprint (first, middle and last generator) guards against a freed and
 /// re-used allocation.
-static KEYS: OnceLock<Mutex<HashMap<(usize, usize, i32), Resident>>> = OnceLock::new();
+static KEYS: Mutex<Option<HashMap<(usize, usize, i32), Resident>>> = Mutex::new(None);     // const `Mutex::new`: no `OnceLock` on the pinned nightly
 
 fn fingerprint(xy: &[u64], words: usize, n: usize) -> [u64; 6] {
     let at = |i: usize| (xy[i * words], xy[i * words + words / 2]);
@@ -35,7 +35,8 @@ fn commit_typed<C: GpuCurve>(g: &[C], m: *const u64, m_len: usize) -> Option<C> 
         return None;
     }
     let ctxs = contexts()?;
-    let mut keys = KEYS.get_or_init(|| Mutex::new(HashMap::new())).lock().ok()?;
+    let mut keys_guard = KEYS.lock().ok()?;
+    let keys = keys_guard.get_or_insert_with(HashMap::new);
     let id = (g.as_ptr() as usize, g.len(), C::CURVE);
     // the probe marshals three points only; the whole key is marshalled when it is first seen
     let probe = {

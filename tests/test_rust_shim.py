@@ -97,3 +97,51 @@ def test_patches_apply_to_the_reference(tmp_path):
     assert (tmp_path / "groth16/src/fft.rs").read_text().count("gpu::transform") == 5
     assert "kogarashi_amd::nova::cross_term" in (tmp_path / "nova/src/prover.rs").read_text()
     assert "pub fn to_csr" in (tmp_path / "zkstd/src/matrix.rs").read_text()
+
+
+# std / core items stabilised after the reference's pinned toolchain (rust-toolchain: nightly-2022-11-14, i.e. 1.67-dev);
+# the glue crate must compile there, and no compiler is available here to say so
+TOO_NEW = [
+    r"\bOnceLock\b", r"\bLazyLock\b", r"\bLazyCell\b", r"\bOnceCell\b",          # 1.70 / 1.80
+    r"\.is_some_and\(", r"\.is_ok_and\(", r"\.is_err_and\(", r"\.is_none_or\(",      # 1.70 / 1.82
+    r"\.inspect_err\(", r"\.div_ceil\(", r"\.next_multiple_of\(",                   # 1.76 / 1.73
+    r"\.checked_ilog2\(", r"\.ilog2\(", r"\.ilog10\(", r"\.ilog\(",                  # 1.67 (release after the pin)
+    r"\bstd::iter::repeat_n\b", r"\.array_chunks\b", r"\bhint::black_box\b",
+    r"\bCStr::from_bytes_until_nul\b", r"\bc\"",                                    # 1.69 / C-string literals 1.77
+]
+
+
+def test_glue_avoids_std_items_newer_than_the_pinned_toolchain():
+    pin = open("/root/reference/rust-toolchain").read().strip() if os.path.exists("/root/reference/rust-toolchain") else "nightly-2022-11-14"
+    assert pin == "nightly-2022-11-14"
+    for crate in ("kogarashi-amd", "kogarashi-amd-sys"):
+        for dirpath, _, files in os.walk(os.path.join(RUST, crate)):
+            for f in files:
+                if not f.endswith(".rs"):
+                    continue
+                for ln, line in enumerate(open(os.path.join(dirpath, f)).read().splitlines(), 1):
+                    code = line.split("//")[0]
+                    for pat in TOO_NEW:
+                        assert not re.search(pat, code), f"{crate}/{f}:{ln}: `{pat}` is not available on {pin}"
+
+
+def test_process_wide_state_uses_const_mutexes():
+    """every `static` of the glue is a `Mutex<Option<..>>` initialised by the const `Mutex::new(None)`"""
+    n = 0
+    for f in os.listdir(os.path.join(RUST, "kogarashi-amd", "src")):
+        for m in re.finditer(r"^\s*static\s+([A-Z_]+)\s*:\s*([^=]+)=\s*([^;]+);", open(os.path.join(RUST, "kogarashi-amd", "src", f)).read(), re.M):
+            n += 1
+            assert m.group(2).strip().startswith("Mutex<Option<") and m.group(3).strip().startswith("Mutex::new(None)"), (f, m.group(0))
+    assert n >= 4
+
+
+def test_resident_matrices_are_keyed_by_a_hash_of_all_their_content():
+    csr = open(os.path.join(RUST, "kogarashi-amd", "src", "csr.rs")).read()
+    assert "pub(crate) fn content_hash" in csr and "for_each_entry" in csr and ".take(8)" not in csr
+    assert "pub fn covers" in csr
+    for f, needle in (("nova.rs", "content_hash([a, b, c], l)"), ("groth16.rs", "content_hash([a, b, c], x.len())")):
+        src = open(os.path.join(RUST, "kogarashi-amd", "src", f)).read()
+        assert needle in src and ".covers(" in src, f
+        assert "ResidentShape::host" not in src          # no host CSR rebuild on the per-call path
+    patch = open(os.path.join(RUST, "patches", "zkstd_matrix_csr.diff")).read()
+    assert "pub fn for_each_entry" in patch and "pub fn rows" in patch

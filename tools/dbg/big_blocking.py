@@ -2,6 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import kogarashi_amd as K
+K.init()          # one hardware queue per library queue (kg_init), before anything initialises HIP
 ctx = K.Context(0)
 for lg in [int(a) for a in sys.argv[1:]] or [21, 22, 24]:
     n = 1 << lg

@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import kogarashi_amd as K
+K.init()          # one hardware queue per library queue (kg_init), before anything initialises HIP
 ctx = K.Context(0)
 for mode in ("stream-ordered", "inputs complete"):
     ctx.set_inputs_complete(mode != "stream-ordered")

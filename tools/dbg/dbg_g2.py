@@ -2,6 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import kogarashi_amd as K
+K.init()          # one hardware queue per library queue (kg_init), before anything initialises HIP
 from oracle import oracle as O
 ctx = K.Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1

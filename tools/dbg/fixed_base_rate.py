@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import kogarashi_amd as K
+K.init()          # one hardware queue per library queue (kg_init), before anything initialises HIP
 ctx = K.Context(0)
 n = 1 << 18
 dk = ctx.empty((n, 4)); ctx.gen_scalars(K.KG_FR, 7, 0, n, dk.ptr)

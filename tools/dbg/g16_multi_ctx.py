@@ -8,6 +8,7 @@ if os.environ.get('KG_WITH_TORCH') == '1':
     torch.cuda.set_device(0)
     _t = torch.zeros(1 << 20, device='cuda'); torch.cuda.synchronize()
 import kogarashi_amd as K
+K.init()          # one hardware queue per library queue (kg_init), before anything initialises HIP
 from kogarashi_amd import synthetic as syn
 from kogarashi_amd.api import groth16_setup
 if os.environ.get('KG_HIPFLAGS'):

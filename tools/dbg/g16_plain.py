@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 import torch
 import kogarashi_amd as K
+K.init()          # one hardware queue per library queue (kg_init), before anything initialises HIP
 from kogarashi_amd import synthetic as syn
 from kogarashi_amd.api import groth16_setup
 tickets = int(sys.argv[1]) if len(sys.argv) > 1 else 2

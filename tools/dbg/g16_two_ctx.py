@@ -3,6 +3,7 @@ import os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import kogarashi_amd as K
+K.init()          # one hardware queue per library queue (kg_init), before anything initialises HIP
 import bench
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 ctx = K.Context(0)

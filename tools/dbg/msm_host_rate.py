@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import kogarashi_amd as K
+K.init()          # one hardware queue per library queue (kg_init), before anything initialises HIP
 SEED = 0x4B6F676172617368
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 ctx = K.Context(0)

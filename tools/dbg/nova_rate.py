@@ -4,6 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import kogarashi_amd as K
+K.init()          # one hardware queue per library queue (kg_init), before anything initialises HIP
 from kogarashi_amd import synthetic as syn
 ctx = K.Context(0)
 for lg in [int(a) for a in sys.argv[1:]] or [18, 20]:

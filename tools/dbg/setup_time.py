@@ -2,6 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import kogarashi_amd as K
+K.init()          # one hardware queue per library queue (kg_init), before anything initialises HIP
 from kogarashi_amd import synthetic as syn
 from kogarashi_amd.api import groth16_setup
 ctx = K.Context(0)

@@ -3,6 +3,7 @@ python tools/dbg/table_rate.py 18 20        (KG_MERGED_T=<n> overrides the task 
 import sys, time
 import numpy as np
 import kogarashi_amd as K
+K.init()          # one hardware queue per library queue (kg_init), before anything initialises HIP
 
 ctx = K.Context(0)
 ctx.set_inputs_complete(True)
