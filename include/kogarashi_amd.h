@@ -225,6 +225,19 @@ int kg_groth16_prove_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
                            const uint64_t* s, int ticket);
 int kg_groth16_prove_end(kg_ctx* ctx, int ticket, uint64_t* proof_out, uint8_t* proof_inf);
 
+/* One proof over n_ctx contexts (normally one per GPU of the node; several contexts on one GPU also work), task-parallel
+ * -- the MSMs of prover.rs:51-65 are independent until the assembly, the G2 query is the long pole.  Context 0
+ * runs the b_g2 query against z = x || w, context 1 % n the three G1 queries against z (a, b_g1, l), context 2 % n the
+ * transforms, h = (a o b - c) / Z and h's MSM; the five sums meet on the host (5 x 72..144 B), where prover.rs:75-92 runs.
+ * crs[i] and the d_*[i] inputs are context i's OWN copies (device pointers of its device).  A context needs only what its
+ * part reads: d_b_g2 (+ x, w) for the first, d_a / d_b_g1 / d_l (+ x, w) for the second, d_h and the three evaluation
+ * vectors for the third (which reads neither x nor w); everything else may be NULL.  m, l, m_l_1 must agree; alpha, beta, delta
+ * are taken from crs[0].  Contexts beyond the third are left idle.  The proof is bit-identical to
+ * kg_groth16_prove_bn254's.  No proof may be in flight (ticket 0) on the contexts used. */
+int kg_groth16_prove_sharded(kg_ctx* const* ctxs, int n_ctx, const kg_groth16_crs* const* crs, const uint64_t* const* d_a_eval,
+                             const uint64_t* const* d_b_eval, const uint64_t* const* d_c_eval, const uint64_t* const* d_x,
+                             const uint64_t* const* d_w, const uint64_t* r, const uint64_t* s, uint64_t* proof_out, uint8_t* proof_inf);
+
 /* ---- R1CS evaluation -------------------------------------------------------------------------------
  * zkstd/src/matrix.rs:31-33 SparseMatrix::evaluate_with_z (row.rs:43-51): out[i] = sum_e val[e] * z[col[e]] over the
  * entries row_ptr[i] <= e < row_ptr[i+1] of a CSR matrix with m rows; z = x || w (instance wires first).  The step

@@ -219,6 +219,81 @@ class Prover:
                     pass
 
 
+class ShardedProver:
+    """groth16::Prover over several contexts (normally one per GPU), task-parallel: SURVEY.md 8e -- the MSMs of
+    prover.rs:51-65 are independent until the assembly and the G2 query is the long pole.  Context 0 holds b_g2 and runs
+    that query, context 1 % n holds a, b_g1, l (the three G1 queries against z = x || w), context 2 % n holds h and runs the
+    transforms and h's MSM (kg_groth16_prove_sharded); each vector is uploaded and registered only where it is used."""
+
+    ROLE_VECTORS = (("b_g2",), ("a", "b_g1", "l"), ("h",))
+
+    def __init__(self, params: dict, m: int, l: int, m_l_1: int, ctxs):
+        from .lib import groth16_prove_sharded
+        self._prove = groth16_prove_sharded
+        self.ctxs = list(ctxs)
+        n = len(self.ctxs)
+        self.owner = [0, 1 % n, 2 % n]
+        self.m, self.l, self.m_l_1 = m, l, m_l_1
+        self._keep, self._registered = [], []
+        g1 = np.ascontiguousarray(params["vk_g1"], dtype=np.uint64).reshape(-1, 8)
+        g2 = np.ascontiguousarray(params["vk_g2"], dtype=np.uint64).reshape(-1, 16)
+        self.crs = []
+        for ci, ctx in enumerate(self.ctxs):
+            crs = Groth16Crs()
+            crs.m, crs.l, crs.m_l_1 = m, l, m_l_1
+            for role, names in enumerate(self.ROLE_VECTORS):
+                if self.owner[role] != ci:
+                    continue
+                for name in names:
+                    w = 16 if name == "b_g2" else 8
+                    arr = np.ascontiguousarray(params[name], dtype=np.uint64).reshape(-1, w)
+                    d = ctx.upload(arr)
+                    self._keep.append(d)
+                    setattr(crs, "d_" + name, d.ptr)
+                    inf = params.get(name + "_inf")
+                    di = None
+                    if inf is not None and np.any(inf):
+                        di = ctx.upload(np.ascontiguousarray(inf, dtype=np.uint8))
+                        self._keep.append(di)
+                        setattr(crs, "d_" + name + "_inf", di.ptr)
+                    ctx.bases_register(KG_G2 if w == 16 else KG_G1, d.ptr, di.ptr if di else 0, len(arr))
+                    self._registered.append((ctx, d.ptr))
+            for i in range(8):
+                crs.alpha_g1[i], crs.beta_g1[i], crs.delta_g1[i] = int(g1[0, i]), int(g1[1, i]), int(g1[2, i])
+            for i in range(16):
+                crs.beta_g2[i], crs.delta_g2[i] = int(g2[0, i]), int(g2[1, i])
+            crs.delta_g1_inf = int(bool(params.get("delta_g1_inf", 0)))
+            crs.delta_g2_inf = int(bool(params.get("delta_g2_inf", 0)))
+            self.crs.append(crs)
+
+    def __del__(self):
+        for ctx, p_ in getattr(self, "_registered", []):
+            try:
+                ctx.bases_unregister(p_)
+            except Exception:
+                pass
+
+    def create_proof(self, a_eval, b_eval, c_eval, x, w, r, s):
+        """as Prover.create_proof; the witness goes to the contexts that run the queries against z, the evaluation vectors to
+        the one that runs the transforms"""
+        n = len(self.ctxs)
+        up = lambda ctx, v: ctx.upload(np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4))
+        keep, ptr = [], {k: [0] * n for k in "abcxw"}
+        for ci, ctx in enumerate(self.ctxs):
+            if ci in self.owner[:2]:
+                for k, v in (("x", x), ("w", w)):
+                    d = up(ctx, v)
+                    keep.append(d)
+                    ptr[k][ci] = d.ptr
+            if ci == self.owner[2]:
+                for k, v in (("a", a_eval), ("b", b_eval), ("c", c_eval)):
+                    d = up(ctx, v)
+                    keep.append(d)
+                    ptr[k][ci] = d.ptr
+        return self._prove(self.ctxs, self.crs, ptr["a"], ptr["b"], ptr["c"], ptr["x"], ptr["w"], r, s)
+
+
+
 class NovaProver:
     """nova::Prover { ck, shape } as far as the hot path goes: the cross term T of a folding step and its commitment
     (nova/src/prover.rs:31-35, 53-90).  shape: the R1CS matrices (a, b, c) as CSR triples (row_ptr, col, val) over

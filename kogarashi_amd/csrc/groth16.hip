@@ -315,6 +315,8 @@ struct ProofJob {
   std::future<int> f_q, f_l, f_a, f_b1, f_b2, assembly;
   uint64_t proof[32];
   uint8_t inf[3];
+  uint64_t rr[4], ss[4];     // the blinding scalars, copied when the proof is enqueued
+  int rc0 = 0;               // status of the enqueue, reported by the assembly after it has joined every host finish
   bool active = false;
 };
 struct ProofJobs { ProofJob j[2]; };   // job 0: kg_groth16_prove_bn254 and ticket 0 (result slots 6..10); job 1: ticket 1 (slots 11..15)
@@ -327,16 +329,26 @@ ProofJob* job_of(kg_ctx* ctx, int i) {
 // on the queue (the scalar sorts read two words back, so this call spans most of the proof's device time).
 // mats != nullptr: the constraint matrices (CSR over z = x || w) instead of the three evaluation vectors -- cs.evaluate()
 // (zkstd/src/r1cs.rs:137-142) then runs on the device as the first step of each transform chain.
+// roles: which of the proof's independent parts this context runs (kg_groth16_prove_sharded spreads them over several
+// contexts; a single-context proof runs all three).  defer_assembly: leave the host finishes in the job's futures and do not
+// start the assembly -- the sharded entry assembles from several jobs.
+enum { ROLE_G2 = 1, ROLE_G1W = 2, ROLE_H = 4, ROLE_ALL = 7 };
+int assemble_proof(const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t* ss, int rc0, ProofJob* j_g2, ProofJob* j_g1w, ProofJob* j_h,
+                   uint64_t* proof, uint8_t* inf);
 int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
                   const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
-                  const uint64_t* s, ProofJob* job, int slot_base, const kg_csr* const* mats = nullptr) {
-  if (!ctx || !crs || !d_x || !r || !s) return KG_ERR_BAD_ARG;
-  if (!mats && (!d_a_eval || !d_b_eval || !d_c_eval)) return KG_ERR_BAD_ARG;
+                  const uint64_t* s, ProofJob* job, int slot_base, const kg_csr* const* mats = nullptr, int roles = ROLE_ALL,
+                  bool defer_assembly = false) {
+  if (!ctx || !crs || !r || !s) return KG_ERR_BAD_ARG;
+  const bool do_g2 = (roles & ROLE_G2) != 0, do_g1w = (roles & ROLE_G1W) != 0, do_h = (roles & ROLE_H) != 0;
+  const bool need_z = do_g2 || do_g1w || mats != nullptr;      // z = x || w feeds the witness MSMs and cs.evaluate()
+  if (need_z && !d_x) return KG_ERR_BAD_ARG;
+  if (!mats && do_h && (!d_a_eval || !d_b_eval || !d_c_eval)) return KG_ERR_BAD_ARG;
   if (mats)
     for (int v = 0; v < 3; ++v)
       if (!mats[v] || !mats[v]->d_row_ptr || !mats[v]->d_col || !mats[v]->d_val) return KG_ERR_BAD_ARG;
   const size_t m = crs->m, l = crs->l, m_l_1 = crs->m_l_1;
-  if (m < 1 || l < 1 || (m_l_1 && !d_w)) return KG_ERR_BAD_ARG;
+  if (m < 1 || l < 1 || (need_z && m_l_1 && !d_w)) return KG_ERR_BAD_ARG;
   KG_HIP(ctx, hipSetDevice(ctx->device));
   uint32_t k = 0;
   size_t n = 1;
@@ -366,8 +378,10 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
     KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
   }
-  KG_TRY(ntt_prepare(ctx, k, 0));
-  KG_TRY(ntt_prepare(ctx, k, 1));
+  if (do_h) {
+    KG_TRY(ntt_prepare(ctx, k, 0));
+    KG_TRY(ntt_prepare(ctx, k, 1));
+  }
   const size_t hn = (m - 1) < n ? (m - 1) : n;
   const size_t nz = l + m_l_1;
   hipStream_t sq;                                         // z is assembled on the scalar queue (its only reader is the sort)
@@ -384,18 +398,19 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // z = x || w, likewise b_g1 (:61-62,85) and b_g2 (:64-65,86) -- the sums are what the proof uses.  The four MSMs
   // that meet the witness share ONE scalar-side sort (l's bases start l entries into z); it is enqueued before the
   // transform chains and its two result words are awaited after them.
-  KG_HIP(ctx, hipMemcpyAsync(Z, d_x, l * 32, hipMemcpyDeviceToDevice, sq));
-  if (m_l_1) KG_HIP(ctx, hipMemcpyAsync(Z + 4 * l, d_w, m_l_1 * 32, hipMemcpyDeviceToDevice, sq));
-  if (mats) {
+  if (need_z) KG_HIP(ctx, hipMemcpyAsync(Z, d_x, l * 32, hipMemcpyDeviceToDevice, sq));
+  if (need_z && m_l_1) KG_HIP(ctx, hipMemcpyAsync(Z + 4 * l, d_w, m_l_1 * 32, hipMemcpyDeviceToDevice, sq));
+  if (mats && do_h) {
     if (m >= ((size_t)1 << 32)) return set_err(ctx, KG_ERR_BAD_ARG, "more than 2^32 constraints");
     KG_TRY(ensure_ws_vec(ctx, 3 * (m + 16) * 4));
     KG_HIP(ctx, hipEventRecord(ctx->ev_order, sq));       // z is complete: the matrix-vector products of the chains wait for it
   }
   MsmSorted Sz;
   // window tables on all four vectors that meet z (kg_bases_precompute): one merged sort, one set of buckets for all windows
-  const bool tz = has_window_table(ctx, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, nz) && has_window_table(ctx, KG_G1, crs->d_a, crs->d_a_inf, nz, nz) &&
-                  has_window_table(ctx, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, nz, nz) && (!m_l_1 || has_window_table(ctx, KG_G1, crs->d_l, crs->d_l_inf, m_l_1, nz));
-  KG_TRY(msm_sort(ctx, KG_FR, Z, nz, &Sz, true, tz ? merged_window(ctx, nz) : 0, 2, false));
+  const bool tz = (!do_g2 || has_window_table(ctx, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, nz)) &&
+                  (!do_g1w || (has_window_table(ctx, KG_G1, crs->d_a, crs->d_a_inf, nz, nz) && has_window_table(ctx, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, nz, nz) &&
+                               (!m_l_1 || has_window_table(ctx, KG_G1, crs->d_l, crs->d_l_inf, m_l_1, nz))));
+  if (do_g2 || do_g1w) KG_TRY(msm_sort(ctx, KG_FR, Z, nz, &Sz, true, tz ? merged_window(ctx, nz) : 0, 2, false));
   int rc = KG_OK;
   auto hip_rc = [&](hipError_t e, const char* what) {
     if (e != hipSuccess && rc == KG_OK) rc = set_err(ctx, e == hipErrorOutOfMemory ? KG_ERR_OOM : KG_ERR_HIP, what, e);
@@ -405,7 +420,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // the chains share the two reduction queues (queues of their own: 3.31 ms per proof against 2.83 -- transforms and halving
   // levels do not fit the chip together with an accumulation anyway, and in one queue they do not fight each other for it)
   hipStream_t lanes[3] = {ctx->side_stream, ctx->side2_stream, ctx->side_stream};
-  for (int v = 0; v < 3 && rc == KG_OK; ++v) {            // prepare_fft zero padding, then idft + coset_dft
+  for (int v = 0; v < 3 && rc == KG_OK && do_h; ++v) {    // prepare_fft zero padding, then idft + coset_dft
     hipStream_t sv = lanes[v];
     uint64_t* tmp = TMP + (size_t)v * 4 * n;
     if (fork) hip_rc(hipStreamWaitEvent(sv, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
@@ -431,22 +446,22 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // result slots: consecutive MSMs alternate between the two reduction queues (slot parity), each with run space of
   // its own (slot mod 8); measured against giving G2's long reduction a queue of its own: 3.67 vs 3.84 ms per proof
   const int SL[5] = {slot_base + 1, slot_base + 2, slot_base + 3, slot_base + 4, slot_base + 5};
-  {
+  if (do_g2 || do_g1w) {
     const int rw = msm_sort_wait(ctx, &Sz);                // always: the next sort may not start before this read-back
     if (rc == KG_OK) rc = rw;
     // G2 first: its host finish (Fq2 arithmetic, ~3x a G1 finish) and its slow reduction then overlap the G1 accumulations
-    if (rc == KG_OK) rc = msm_run(ctx, Sz, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, 0, SL[0]);
-    if (rc == KG_OK) f_b2 = finish_async(KG_G2, SL[0], b2i);
+    if (rc == KG_OK && do_g2) rc = msm_run(ctx, Sz, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, 0, SL[0]);
+    if (rc == KG_OK && do_g2) f_b2 = finish_async(KG_G2, SL[0], b2i);
     // the three G1 queries against z (a, b_g1, l) are accumulated by ONE launch: 13 000 waves instead of three
     // one-round launches of 4 352 (see k_acc_tasks)
-    if (rc == KG_OK) {
+    if (rc == KG_OK && do_g1w) {
       MsmRunJob jobs3[3] = {{crs->d_a, crs->d_a_inf, nz, 0u, SL[1]}, {crs->d_b_g1, crs->d_b_g1_inf, nz, 0u, SL[2]},
                             {crs->d_l, crs->d_l_inf, m_l_1, (uint32_t)l, SL[3]}};
       rc = msm_run_multi(ctx, Sz, KG_G1, jobs3, m_l_1 ? 3 : 2);
     }
-    if (rc == KG_OK) f_a = finish_async(KG_G1, SL[1], ai);
-    if (rc == KG_OK) f_b1 = finish_async(KG_G1, SL[2], b1i);
-    if (rc == KG_OK && m_l_1) f_l = finish_async(KG_G1, SL[3], l_p);
+    if (rc == KG_OK && do_g1w) f_a = finish_async(KG_G1, SL[1], ai);
+    if (rc == KG_OK && do_g1w) f_b1 = finish_async(KG_G1, SL[2], b1i);
+    if (rc == KG_OK && do_g1w && m_l_1) f_l = finish_async(KG_G1, SL[3], l_p);
     else msm_identity(KG_G1, l_p);
   }
   // From here on host finishes may already be running on worker threads: no early return -- every failure travels
@@ -454,8 +469,8 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // h = (a o b - c) / Z on the coset, back to coefficients (prover.rs:43-47), then its MSM.  (Measured and dropped as well:
   // this chain on a service queue under the witness accumulations -- the transform's 512-thread, 74 KiB workgroups only
   // get onto a CU once an accumulation has drained, and then queue behind the reductions: 3.3 -> 3.85 ms per proof.)
-  for (int v = 0; v < 3; ++v) hip_rc(hipStreamWaitEvent(st, ctx->ev_join[v], 0), "hipStreamWaitEvent(join)");
-  {
+  for (int v = 0; v < 3 && do_h; ++v) hip_rc(hipStreamWaitEvent(st, ctx->ev_join[v], 0), "hipStreamWaitEvent(join)");
+  if (do_h) {
     HostFr seven = HostFr::one();                         // (7^n - 1)^-1 on the host: n = 2^k squarings of 7
     {
       HostFr one = HostFr::one(), acc = HostFr::zero();
@@ -470,8 +485,8 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
     hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, C, n, zw);
     hip_rc(hipGetLastError(), "k_qap_combine launch");
   }
-  if (rc == KG_OK) rc = ntt_enqueue(ctx, st, TMP, A, k, 1, 1);                      // coset_idft (prover.rs:47)
-  if (rc == KG_OK && hn) {
+  if (rc == KG_OK && do_h) rc = ntt_enqueue(ctx, st, TMP, A, k, 1, 1);             // coset_idft (prover.rs:47)
+  if (rc == KG_OK && hn && do_h) {
     MsmSorted Sq;
     hip_rc(hipEventRecord(ctx->ev_order, st), "hipEventRecord(order)");             // h's coefficients come off the main queue
     hip_rc(hipStreamWaitEvent(sq, ctx->ev_order, 0), "hipStreamWaitEvent(order)");
@@ -482,56 +497,64 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   } else msm_identity(KG_G1, q_p);
   // Host side of the proof on a worker thread: first the parts of the assembly (prover.rs:75-77) that depend on no MSM
   // result, then A, B and C up to h's term as the witness MSMs' host finishes arrive, then h's term.
-  uint64_t rr[4], ss[4];
-  for (int i = 0; i < 4; ++i) { rr[i] = r[i]; ss[i] = s[i]; }
-  const kg_groth16_crs vk = *crs;                       // the host-resident part (alpha, beta, delta) is read by value
+  for (int i = 0; i < 4; ++i) { job->rr[i] = r[i]; job->ss[i] = s[i]; }
+  job->rc0 = rc;
   job->active = true;
-  job->assembly = std::async(std::launch::async, [job, vk, rr, ss, rc0 = rc]() -> int {
-    int rc = rc0;
-    uint64_t *q_p = job->q_p, *l_p = job->l_p, *ai = job->ai, *b1i = job->b1i, *b2i = job->b2i;
-    HostFr rm = HostFr::from_words(rr), sm = HostFr::from_words(ss);
-    HostFr raw_one{{1, 0, 0, 0}};
-    HostFr rk = mul(rm, raw_one), sk = mul(sm, raw_one), rsk = mul(mul(rm, sm), raw_one);   // out of Montgomery form
-    XYZZ<HostFq> alpha = from_affine(h_load_aff<HostFq, 4>(vk.alpha_g1)), beta1 = from_affine(h_load_aff<HostFq, 4>(vk.beta_g1)),
-                 delta1 = from_affine(h_load_aff<HostFq, 4>(vk.delta_g1));
-    XYZZ<HostFq2> beta2 = from_affine(h_load_aff<HostFq2, 8>(vk.beta_g2)), delta2 = from_affine(h_load_aff<HostFq2, 8>(vk.delta_g2));
-    const bool bad_delta = vk.delta_g1_inf || vk.delta_g2_inf;
-    XYZZ<HostFq> g_a = XYZZ<HostFq>::identity(), g_c = g_a;
-    XYZZ<HostFq2> g_b = XYZZ<HostFq2>::identity();
-    if (rc == KG_OK && !bad_delta) {
-      g_a = add_xyzz(h_scalar_mul(delta1, rk.v), alpha);                                                    // :75
-      g_b = add_xyzz(h_scalar_mul(delta2, sk.v), beta2);                                                    // :76
-      g_c = add_xyzz(add_xyzz(h_scalar_mul(delta1, rsk.v), h_scalar_mul(alpha, sk.v)), h_scalar_mul(beta1, rk.v));   // :77
-    }
-    auto join = [&](std::future<int>& f) { if (f.valid()) { int r2 = f.get(); if (rc == KG_OK) rc = r2; } };
-    auto g1pt = [](const uint64_t* xyz) {
-      bool inf = !(xyz[8] | xyz[9] | xyz[10] | xyz[11]);
-      return h_from_abi<HostFq>(h_load_aff<HostFq, 4>(xyz), inf);
-    };
-    auto g2pt = [](const uint64_t* xyz) {
-      bool inf = true;
-      for (int i = 16; i < 24; ++i) inf = inf && xyz[i] == 0;
-      return h_from_abi<HostFq2>(h_load_aff<HostFq2, 8>(xyz), inf);
-    };
-    // everything that does not need h's MSM is assembled while the device is still working on it
-    join(job->f_b2); join(job->f_a); join(job->f_b1); join(job->f_l);
-    if (rc == KG_OK && !bad_delta) {
-      XYZZ<HostFq> a_ans = g1pt(ai), b1_ans = g1pt(b1i);
-      XYZZ<HostFq2> b2_ans = g2pt(b2i);
-      g_a = add_xyzz(g_a, a_ans);                                                                          // :81
-      g_b = add_xyzz(g_b, b2_ans);                                                                         // :88
-      g_c = add_xyzz(g_c, h_scalar_mul2(a_ans, sk.v, b1_ans, rk.v));                                       // :83,90
-      g_c = add_xyzz(g_c, g1pt(l_p));                                                                      // :92 (l part)
-      h_store_affine<HostFq, 4>(g_a, job->proof, job->inf);
-      h_store_affine<HostFq2, 8>(g_b, job->proof + 8, job->inf + 1);
-    }
-    join(job->f_q);
-    if (rc != KG_OK) return rc;
-    if (bad_delta) return KG_ERR_CRS;                     // prover.rs:67-69 (the message is set by prove_collect, on the caller's thread)
-    g_c = add_xyzz(g_c, g1pt(q_p));                                                                        // :92 (h part)
-    h_store_affine<HostFq, 4>(g_c, job->proof + 24, job->inf + 2);
-    return KG_OK;
+  if (defer_assembly) return KG_OK;
+  const kg_groth16_crs vk = *crs;                       // the host-resident part (alpha, beta, delta) is read by value
+  job->assembly = std::async(std::launch::async, [job, vk]() -> int {
+    return assemble_proof(vk, job->rr, job->ss, job->rc0, job, job, job, job->proof, job->inf);
   });
+  return KG_OK;
+}
+
+// prover.rs:75-92 on the host.  The five MSM sums may come from up to three jobs (one per context of a sharded proof):
+// j_g2 holds b2i, j_g1w holds ai / b1i / l_p, j_h holds q_p, each with the futures of its host finishes.
+int assemble_proof(const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t* ss, int rc0, ProofJob* j_g2, ProofJob* j_g1w, ProofJob* j_h,
+                   uint64_t* proof, uint8_t* inf) {
+  int rc = rc0;
+  uint64_t *q_p = j_h->q_p, *l_p = j_g1w->l_p, *ai = j_g1w->ai, *b1i = j_g1w->b1i, *b2i = j_g2->b2i;
+  HostFr rm = HostFr::from_words(rr), sm = HostFr::from_words(ss);
+  HostFr raw_one{{1, 0, 0, 0}};
+  HostFr rk = mul(rm, raw_one), sk = mul(sm, raw_one), rsk = mul(mul(rm, sm), raw_one);   // out of Montgomery form
+  XYZZ<HostFq> alpha = from_affine(h_load_aff<HostFq, 4>(vk.alpha_g1)), beta1 = from_affine(h_load_aff<HostFq, 4>(vk.beta_g1)),
+               delta1 = from_affine(h_load_aff<HostFq, 4>(vk.delta_g1));
+  XYZZ<HostFq2> beta2 = from_affine(h_load_aff<HostFq2, 8>(vk.beta_g2)), delta2 = from_affine(h_load_aff<HostFq2, 8>(vk.delta_g2));
+  const bool bad_delta = vk.delta_g1_inf || vk.delta_g2_inf;
+  XYZZ<HostFq> g_a = XYZZ<HostFq>::identity(), g_c = g_a;
+  XYZZ<HostFq2> g_b = XYZZ<HostFq2>::identity();
+  if (rc == KG_OK && !bad_delta) {
+    g_a = add_xyzz(h_scalar_mul(delta1, rk.v), alpha);                                                    // :75
+    g_b = add_xyzz(h_scalar_mul(delta2, sk.v), beta2);                                                    // :76
+    g_c = add_xyzz(add_xyzz(h_scalar_mul(delta1, rsk.v), h_scalar_mul(alpha, sk.v)), h_scalar_mul(beta1, rk.v));   // :77
+  }
+  auto join = [&](std::future<int>& f) { if (f.valid()) { int r2 = f.get(); if (rc == KG_OK) rc = r2; } };
+  auto g1pt = [](const uint64_t* xyz) {
+    bool pinf = !(xyz[8] | xyz[9] | xyz[10] | xyz[11]);
+    return h_from_abi<HostFq>(h_load_aff<HostFq, 4>(xyz), pinf);
+  };
+  auto g2pt = [](const uint64_t* xyz) {
+    bool pinf = true;
+    for (int i = 16; i < 24; ++i) pinf = pinf && xyz[i] == 0;
+    return h_from_abi<HostFq2>(h_load_aff<HostFq2, 8>(xyz), pinf);
+  };
+  // everything that does not need h's MSM is assembled while the device is still working on it
+  join(j_g2->f_b2); join(j_g1w->f_a); join(j_g1w->f_b1); join(j_g1w->f_l);
+  if (rc == KG_OK && !bad_delta) {
+    XYZZ<HostFq> a_ans = g1pt(ai), b1_ans = g1pt(b1i);
+    XYZZ<HostFq2> b2_ans = g2pt(b2i);
+    g_a = add_xyzz(g_a, a_ans);                                                                          // :81
+    g_b = add_xyzz(g_b, b2_ans);                                                                         // :88
+    g_c = add_xyzz(g_c, h_scalar_mul2(a_ans, sk.v, b1_ans, rk.v));                                       // :83,90
+    g_c = add_xyzz(g_c, g1pt(l_p));                                                                      // :92 (l part)
+    h_store_affine<HostFq, 4>(g_a, proof, inf);
+    h_store_affine<HostFq2, 8>(g_b, proof + 8, inf + 1);
+  }
+  join(j_h->f_q);
+  if (rc != KG_OK) return rc;
+  if (bad_delta) return KG_ERR_CRS;                     // prover.rs:67-69 (the message is set by prove_collect, on the caller's thread)
+  g_c = add_xyzz(g_c, g1pt(q_p));                                                                        // :92 (h part)
+  h_store_affine<HostFq, 4>(g_c, proof + 24, inf + 2);
   return KG_OK;
 }
 
@@ -588,6 +611,68 @@ int kg_groth16_prove_r1cs_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const kg
 int kg_groth16_prove_end(kg_ctx* ctx, int ticket, uint64_t* proof_out, uint8_t* proof_inf) {
   if (!ctx || ticket < 0 || ticket > 1 || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
   return prove_collect(ctx, job_of(ctx, ticket), proof_out, proof_inf);
+}
+
+
+// One proof over several contexts, task-parallel (the MSMs of prover.rs:51-65 are independent of each other and
+// of the transforms until the assembly): role G2 (the b_g2 query against z -- the long pole), role G1W (the a, b_g1 and l
+// queries against z, one fused accumulation) and role H (three idft -> coset_dft chains, h = (a o b - c) / Z, coset_idft,
+// h's MSM) go to contexts 0, 1 % n and 2 % n.  Every context enqueues its part from a host thread of its own (a sort reads
+// two words back); the five sums meet on the host, where the assembly of prover.rs:75-92 runs once.
+int kg_groth16_prove_sharded(kg_ctx* const* ctxs, int n_ctx, const kg_groth16_crs* const* crs, const uint64_t* const* d_a_eval,
+                             const uint64_t* const* d_b_eval, const uint64_t* const* d_c_eval, const uint64_t* const* d_x,
+                             const uint64_t* const* d_w, const uint64_t* r, const uint64_t* s, uint64_t* proof_out, uint8_t* proof_inf) {
+  if (!ctxs || n_ctx < 1 || n_ctx > 8 || !crs || !d_x || !d_w || !r || !s || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;   // d_x, d_w: the arrays; entries of contexts that do not read z may be NULL
+  for (int i = 0; i < n_ctx; ++i)
+    if (!ctxs[i] || !crs[i]) return KG_ERR_BAD_ARG;
+  for (int i = 0; i < n_ctx; ++i)
+    for (int j = 0; j < i; ++j)
+      if (ctxs[i] == ctxs[j]) return set_err(ctxs[0], KG_ERR_BAD_ARG, "a context is listed twice");
+  const int owner[3] = {0, 1 % n_ctx, 2 % n_ctx};         // of ROLE_G2, ROLE_G1W, ROLE_H
+  int roles[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  roles[owner[0]] |= ROLE_G2; roles[owner[1]] |= ROLE_G1W; roles[owner[2]] |= ROLE_H;
+  for (int i = 0; i < n_ctx; ++i) {
+    if (!roles[i]) continue;
+    if (crs[i]->m != crs[0]->m || crs[i]->l != crs[0]->l || crs[i]->m_l_1 != crs[0]->m_l_1) return set_err(ctxs[0], KG_ERR_BAD_ARG, "the contexts' CRS copies differ in shape");
+    if (job_of(ctxs[i], 0)->active) return set_err(ctxs[i], KG_ERR_BAD_ARG, "a proof is in flight on this context");
+    if ((roles[i] & ROLE_H) && (!d_a_eval || !d_b_eval || !d_c_eval || !d_a_eval[i] || !d_b_eval[i] || !d_c_eval[i])) return KG_ERR_BAD_ARG;
+  }
+  std::vector<std::future<int>> enq;
+  std::vector<int> who;
+  for (int i = 0; i < n_ctx; ++i) {
+    if (!roles[i]) continue;
+    who.push_back(i);
+    enq.push_back(std::async(std::launch::async, [=]() -> int {
+      return prove_enqueue(ctxs[i], crs[i], d_a_eval ? d_a_eval[i] : nullptr, d_b_eval ? d_b_eval[i] : nullptr, d_c_eval ? d_c_eval[i] : nullptr,
+                           d_x[i], d_w[i], r, s, job_of(ctxs[i], 0), 5, nullptr, roles[i], true);
+    }));
+  }
+  int rc = KG_OK;
+  for (size_t t = 0; t < enq.size(); ++t) {
+    const int r2 = enq[t].get();
+    if (rc == KG_OK) rc = r2;
+  }
+  ProofJob* jg2 = job_of(ctxs[owner[0]], 0);
+  ProofJob* jg1 = job_of(ctxs[owner[1]], 0);
+  ProofJob* jh = job_of(ctxs[owner[2]], 0);
+  for (int i : who) {                                     // a failed enqueue may have left host finishes running on the others: the
+    ProofJob* j = job_of(ctxs[i], 0);                     // assembly joins every future before it reports
+    if (rc == KG_OK && j->rc0 != KG_OK) rc = j->rc0;
+  }
+  uint64_t proof[32];
+  uint8_t inf[3] = {0, 0, 0};
+  rc = assemble_proof(*crs[0], r, s, rc, jg2, jg1, jh, proof, inf);
+  for (int i : who) {
+    ProofJob* j = job_of(ctxs[i], 0);
+    for (std::future<int>* f : {&j->f_q, &j->f_l, &j->f_a, &j->f_b1, &j->f_b2})
+      if (f->valid()) f->get();
+    j->active = false;
+  }
+  if (rc == KG_ERR_CRS) return set_err(ctxs[0], KG_ERR_CRS, "delta is the identity");
+  if (rc != KG_OK) return rc;
+  for (int i = 0; i < 32; ++i) proof_out[i] = proof[i];
+  for (int i = 0; i < 3; ++i) proof_inf[i] = inf[i];
+  return KG_OK;
 }
 
 }  // extern "C"

@@ -24,7 +24,7 @@ EXPORTS = [
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
     "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
-    "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_r1cs_begin",
+    "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_r1cs_begin", "kg_groth16_prove_sharded",
 ]
 
 
@@ -403,6 +403,26 @@ def msm_sharded(ctxs, curve: int, bases, infs, scalars, n_local) -> np.ndarray:
     out = np.zeros(24 if curve == KG_G2 else 12, dtype=np.uint64)
     ctxs[0]._chk(load().kg_msm_sharded(h, k, curve, pb, pi, ps, nl, out.ctypes.data_as(C.c_void_p)), "kg_msm_sharded")
     return out
+
+
+def groth16_prove_sharded(ctxs, crss, a_eval, b_eval, c_eval, x, w, r: np.ndarray, s: np.ndarray):
+    """kg_groth16_prove_sharded: one proof over the contexts `ctxs`, task-parallel (G2 query | G1 queries | transforms + h).
+    crss: one Groth16Crs per context (its own device pointers); a_eval .. w: per-context device pointers (0 where a context
+    does not read the vector).  Returns (A, B, C, inf) like Context.groth16_prove."""
+    k = len(ctxs)
+    h = (C.c_void_p * k)(*[c._h for c in ctxs])
+    pc = (C.POINTER(Groth16Crs) * k)(*[C.pointer(c) for c in crss])
+    arrs = [_ptr_array(C.c_void_p, v) for v in (a_eval, b_eval, c_eval, x, w)]
+    r = np.ascontiguousarray(r, dtype=np.uint64)
+    s = np.ascontiguousarray(s, dtype=np.uint64)
+    out = np.zeros(32, dtype=np.uint64)
+    inf = np.zeros(3, dtype=np.uint8)
+    rc = load().kg_groth16_prove_sharded(h, k, pc, *arrs, r.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p),
+                                         out.ctypes.data_as(C.c_void_p), inf.ctypes.data_as(C.c_void_p))
+    if rc == -6:
+        raise ProverSubVersionCrsAttack("delta is the identity")
+    ctxs[0]._chk(rc, "kg_groth16_prove_sharded")
+    return out[:8].copy(), out[8:24].copy(), out[24:].copy(), inf
 
 
 class ShardedKey:

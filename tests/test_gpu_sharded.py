@@ -107,3 +107,60 @@ def test_sharded_key_commit(ctxs, oracle, cv, curve, sfd, w):
             got = key.commit(m[:small])
             assert got[1] == oinf and (got[0] == oxy).all()
         key.close()
+
+
+@pytest.mark.parametrize("n_ctx", [1, 2, 3, 4])
+@pytest.mark.parametrize("m", [37, 1024])
+def test_groth16_proof_over_several_contexts(oracle, n_ctx, m):
+    """kg_groth16_prove_sharded (the MSMs of prover.rs:51-65 spread task-parallel, G2 query | G1 queries |
+    transforms + h) against the single-context proof and the oracle; the contexts share device 0 on the one-GPU box."""
+    import kogarashi_amd as K
+    O = oracle
+    cs = O.chain_r1cs(m, O.gen_scalars(0, SEED + 700 + m, 0, 1)[0])
+    params = O.groth16_params(cs, O.gen_scalars(0, SEED + 701, 0, 5), threads=8)
+    r, s = O.gen_scalars(0, SEED + 702, 0, 2)
+    a, b, c = cs.evaluate()
+    want = O.groth16_prove(cs, params, r, s, evals=(a, b, c))
+    params["vk_g2"] = params["vk_g2"][:2]
+    ctxs = [K.Context(0) for _ in range(n_ctx)]
+    try:
+        sp = K.ShardedProver(params, cs.m, cs.l, cs.m_l_1, ctxs)
+        for _ in range(2):                                  # twice: the contexts' jobs and buffers are reusable
+            got = sp.create_proof(a, b, c, cs.x, cs.w, r, s)
+            for g, w_, name in zip(got[:3], want[:3], "ABC"):
+                assert (g == w_).all(), (name, n_ctx)
+            assert (got[3] == want[3]).all()
+        single = K.Prover(params, cs.m, cs.l, cs.m_l_1, ctx=ctxs[0]).create_proof(a, b, c, cs.x, cs.w, r, s)
+        assert all((g == w_).all() for g, w_ in zip(single[:3], want[:3]))
+        del sp
+    finally:
+        for c_ in ctxs:
+            c_.close()
+
+
+def test_sharded_proof_rejects_identity_delta_and_bad_arguments(oracle):
+    import kogarashi_amd as K
+    from kogarashi_amd.lib import ProverSubVersionCrsAttack, KogarashiError
+    O = oracle
+    cs = O.chain_r1cs(4, O.gen_scalars(0, SEED + 710, 0, 1)[0])
+    params = O.groth16_params(cs, O.gen_scalars(0, SEED + 711, 0, 5))
+    a, b, c = cs.evaluate()
+    r, s = O.gen_scalars(0, SEED + 712, 0, 2)
+    want = O.groth16_prove(cs, params, r, s, evals=(a, b, c))
+    params["vk_g2"] = params["vk_g2"][:2]
+    ctxs = [K.Context(0) for _ in range(2)]
+    try:
+        bad = dict(params, delta_g2_inf=1)
+        with pytest.raises(ProverSubVersionCrsAttack):
+            K.ShardedProver(bad, cs.m, cs.l, cs.m_l_1, ctxs).create_proof(a, b, c, cs.x, cs.w, r, s)
+        sp = K.ShardedProver(params, cs.m, cs.l, cs.m_l_1, ctxs)
+        sp.ctxs = [ctxs[0], ctxs[0]]                        # the same context twice
+        with pytest.raises(KogarashiError):
+            sp.create_proof(a, b, c, cs.x, cs.w, r, s)
+        sp.ctxs = ctxs
+        got = sp.create_proof(a, b, c, cs.x, cs.w, r, s)    # and the contexts are still usable afterwards
+        assert all((g == w_).all() for g, w_ in zip(got[:3], want[:3]))
+        del sp
+    finally:
+        for c_ in ctxs:
+            c_.close()
