@@ -13,6 +13,7 @@
 // add/sub/norm discipline of fp29.h is written out explicitly and machine-checked in tests/host/.
 #pragma once
 #include "fp29.h"
+#include "fp_inv.h"
 
 namespace kg {
 
@@ -151,7 +152,7 @@ KG_HD Affine<F> neg_affine(const Affine<F>& a) { return {a.x, vred(norm(sub<4, 1
 template <class F>
 KG_HD bool to_affine(const XYZZ<F>& p, Affine<F>& out) {
   if (is_identity(p)) return false;
-  F zi = inv(p.zzz);                    // ZZZ^-1
+  F zi = inv_fast(p.zzz);               // ZZZ^-1 (binary GCD, fp_inv.h)
   F zzi = mul(mul(zi, zi), sqr(p.zz));  // ZZ^-1 = ZZZ^-2 * ZZ^2   (ZZ^3 = ZZZ^2)
   out.x = mul(p.x, zzi);
   out.y = mul(p.y, zi);

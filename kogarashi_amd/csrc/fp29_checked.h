@@ -180,6 +180,9 @@ inline FpChecked<P> inv(const FpChecked<P>& a) {
   return {inv(a.v), (double)M29, 2.0 * FpChecked<P>::ptop1(), 2.0};
 }
 
+template <class P>
+inline FpChecked<P> inv_fast(const FpChecked<P>& a) { return inv(a); }      // same value; the binary GCD has no column bounds to track
+
 using FqC = FpChecked<FqParams>;
 using FrC = FpChecked<FrParams>;
 using Fq2C = Fp2<FqC>;

@@ -155,6 +155,8 @@ inline HostFp<P> inv(const HostFp<P>& a) {
   }
   return r;
 }
+template <class P>
+inline HostFp<P> inv_fast(const HostFp<P>& a) { return inv(a); }          // host finish: one inversion per MSM, the 4 x 64-bit ladder is fine
 
 using HostFq = HostFp<HostFqP>;
 using HostFr = HostFp<HostFrP>;

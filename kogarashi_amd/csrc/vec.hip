@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) k_vec_op(int op, const uint64_t* a, const
     case KG_OP_SQUARE: words_from_limbs(reduce_2p(mul(sqr(A), F::from_const(P::C_FROM_REF))), wo); break;
     case KG_OP_NEG: words_from_limbs(reduce_2p(vred(norm(sub<8, 1>(F::zero(), A)))), wo); break;
     case KG_OP_DOUBLE: words_from_limbs(reduce_2p(vred(norm(dbl(A)))), wo); break;
-    case KG_OP_INVERT: to_ref(inv(from_ref<P>(wa)), wo); break;
+    case KG_OP_INVERT: to_ref(inv_fast(from_ref<P>(wa)), wo); break;
     case KG_OP_FROM_MONT: ref_to_int<P>(wa, wo); break;
     case KG_OP_TO_MONT: int_to_ref<P>(wa, wo); break;
     default: return;

@@ -35,7 +35,7 @@ template <class F> struct Conv<Fp2<F>> {
 
 template <class F> static F xsub(const F& a, const F& b) { return norm(sub<4, 1>(a, b)); }
 
-// op: 0 mul, 1 sqr, 2 add, 3 sub, 4 neg, 5 dbl, 6 inv, 7 (a*b+a*a) via lazy chain, 8 identity round trip
+// op: 0 mul, 1 sqr, 2 add, 3 sub, 4 neg, 5 dbl, 6 inv, 7 (a*b+a*a) via lazy chain, 8 identity round trip, 9 inv by binary GCD
 template <class F>
 static void field_ops(int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n) {
   const int W = Conv<F>::W;
@@ -51,6 +51,7 @@ static void field_ops(int op, const uint32_t* a, const uint32_t* b, uint32_t* o,
       case 6: r = inv(x); break;
       case 7: r = mul(norm(add(mul(x, y), sqr(x))), F::one()); break;
       case 8: r = x; break;
+      case 9: r = inv_fast(x); break;          // binary-GCD inversion (fp_inv.h)
     }
     Conv<F>::out(r, o + W * i);
   }

@@ -39,6 +39,10 @@ def test_prime_field_ops_match_oracle(hostlib, oracle, fd):
     exp = np.stack([O.f_invert(fd, a[i]) if a[i].any() else np.zeros(4, dtype=np.uint64) for i in range(m)])
     for chk in (0, 1):
         assert (field_ops(hostlib, fd, chk, 6, a[:m].copy(), b[:m].copy()) == exp).all()
+    # the binary-GCD inversion the kernels use (fp_inv.h) against the oracle's invert on every element, edge values included
+    # (0 -> 0, 1, -1, p - 1 squared's operand, equal operands)
+    exp = np.stack([O.f_invert(fd, a[i]) if a[i].any() else np.zeros(4, dtype=np.uint64) for i in range(n)])
+    assert (field_ops(hostlib, fd, 0, 9, a.copy(), b.copy()) == exp).all()
 
 
 @pytest.mark.parametrize("fd", [0, 1])
@@ -66,6 +70,8 @@ def test_fq2_ops_match_oracle(hostlib, oracle):
     exp = np.stack([O.f2_invert(a[i]) for i in range(3, 15)])
     for chk in (0, 1):
         assert (field_ops(hostlib, 2, chk, 6, a[3:15].copy(), b[3:15].copy()) == exp).all()
+    exp = np.stack([O.f2_invert(a[i]) for i in range(3, 200)])
+    assert (field_ops(hostlib, 2, 0, 9, a[3:200].copy(), b[3:200].copy()) == exp).all()          # Fq2 through the binary GCD
 
 
 def curve_sum(H, cid, cur, chk, mode, pts, inf):
