@@ -198,6 +198,81 @@ KG_HD Fp<P> mul2sub(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>&
   return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Product with a precomputed constant (Shoup / Barrett form): c = {w, q = floor(w * 2^261 / p)}, w canonical.
+// Returns a * w mod p -- NO Montgomery factor: the operand keeps its domain -- as a normalised value below
+// (2 + Ka / 169) p.  143 multiply-accumulates and no v_mul_lo against the 162 + 9 of mul(): the quotient estimate takes
+// columns 7..16 of a * q (the dropped columns are worth less than one unit of the quotient), the remainder the nine low
+// columns of a * w + qe * (2^261 - p).  Needs limbs of a below ~2^31 (9 * max_a * 2^29 + 9 * 2^58 + carry < 2^64) and
+// a < 2^261 (Ka < 169).  The transforms' twiddles are such constants (ntt_tile.h).
+// ---------------------------------------------------------------------------------------------
+template <class P>
+struct FpConst {
+  uint32_t w[9], q[9];
+};
+template <class P>
+KG_HD Fp<P> mulc(const Fp<P>& a, const FpConst<P>& c) {
+  uint32_t qe[9];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i <= 7; ++i) acc += (uint64_t)a.l[i] * c.q[7 - i];
+  acc >>= 29;
+#pragma unroll
+  for (int i = 0; i <= 8; ++i) acc += (uint64_t)a.l[i] * c.q[8 - i];
+  acc >>= 29;
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)a.l[i] * c.q[k - i];
+    qe[k - 9] = (uint32_t)acc & M29;
+    acc >>= 29;
+  }
+  qe[8] = (uint32_t)acc;                       // floor(a * q / 2^261) or one less; < 2^261 / 2 ... fits (a * q < 2^522)
+  Fp<P> r;
+  acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * c.w[k - i];
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (uint64_t)qe[i] * P::PBAR[k - i];
+#if defined(__HIP_DEVICE_COMPILE__)
+    // only the low 29 bits of the last column are used: without this the compiler narrows its 18 multiply-accumulates to
+    // v_mul_lo_u32 + v_add, which issue at about half the rate of v_mad_u64_u32
+    if (k == 8) asm volatile("" : "+v"(acc));
+#endif
+    r.l[k] = (uint32_t)acc & M29;              // the true remainder is below 3p < 2^256: bits 261 and up are the q * 2^261 term
+    acc >>= 29;
+  }
+  return r;
+}
+// q = floor(w * 2^261 / p) for a canonical w (restoring division, 261 steps; table construction only)
+template <class P>
+KG_HD FpConst<P> make_const(const Fp<P>& w_canonical) {
+  FpConst<P> c;
+  uint32_t rem[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { c.w[i] = w_canonical.l[i]; c.q[i] = 0; rem[i] = w_canonical.l[i]; }
+  for (int step = 260; step >= 0; --step) {
+    uint32_t cy = 0;                           // rem <<= 1 (rem < p < 2^254: no overflow of the top limb)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const uint32_t v = (rem[i] << 1) | cy; rem[i] = v & M29; cy = v >> 29; }
+    rem[8] = (rem[8] << 1) | cy;
+    uint32_t d[9], borrow = 0;                 // d = rem - p
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const uint32_t v = rem[i] - P::P[i] - borrow;
+      borrow = v >> 31;
+      d[i] = i < 8 ? (v & M29) : v;
+    }
+    const bool ge = borrow == 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rem[i] = ge ? d[i] : rem[i];
+    c.q[step / 29] |= (ge ? 1u : 0u) << (step % 29);
+  }
+  return c;
+}
+
 // lazy limb-wise sum (no carries)
 template <class P>
 KG_HD Fp<P> add(const Fp<P>& a, const Fp<P>& b) {
@@ -216,7 +291,7 @@ struct FatZ;
   struct FatZ<P, C_, T_> {                                                        \
     static KG_HD uint32_t at(int i) { return P::Z##C_##_##T_[i]; }                \
   };
-KG_FATZ(2, 1) KG_FATZ(4, 1) KG_FATZ(8, 1) KG_FATZ(16, 1) KG_FATZ(32, 1) KG_FATZ(4, 3) KG_FATZ(8, 3) KG_FATZ(16, 3) KG_FATZ(32, 3)
+KG_FATZ(2, 1) KG_FATZ(3, 1) KG_FATZ(4, 1) KG_FATZ(8, 1) KG_FATZ(16, 1) KG_FATZ(32, 1) KG_FATZ(4, 3) KG_FATZ(8, 3) KG_FATZ(16, 3) KG_FATZ(32, 3)
 #undef KG_FATZ
 
 // lazy difference a + C*p - b, limb-wise without borrows.  Requires limbs 0..7 of b <= T*2^29 - T and

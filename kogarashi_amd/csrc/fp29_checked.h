@@ -65,6 +65,20 @@ inline FpChecked<P> mul(const FpChecked<P>& a, const FpChecked<P>& b) {
   return r;
 }
 template <class P>
+inline FpChecked<P> mulc(const FpChecked<P>& a, const FpConst<P>& c) {
+  a.check_actual();
+  const double A = a.lb > a.tb ? a.lb : a.tb;
+  const double s = 9.0 * A * (double)M29 + 9.0 * (double)M29 * (double)M29 + 68719476736.0;     // worst column of either phase
+  if (!(s < chk::TWO64)) BoundFail::fail("mulc 64-bit column accumulator", s, chk::TWO64);
+  if (!(a.kb < FpChecked<P>::RHO())) BoundFail::fail("mulc operand above 2^261", a.kb, FpChecked<P>::RHO());
+  for (int i = 0; i < 9; ++i)
+    if (c.w[i] > M29 || (i < 8 && c.q[i] > M29)) BoundFail::fail("mulc constant limbs not normalised", c.w[i], (double)M29);
+  const double ko = 2.0 + a.kb / FpChecked<P>::RHO();
+  FpChecked<P> r{mulc(a.v, c), (double)M29, ko * FpChecked<P>::ptop1(), ko};
+  r.check_actual();
+  return r;
+}
+template <class P>
 inline FpChecked<P> sqr(const FpChecked<P>& a) {
   a.check_actual();
   if (!(2.0 * a.lb < 4294967296.0 && 2.0 * a.tb < 4294967296.0)) BoundFail::fail("sqr doubled limb", 2 * a.lb, 4294967296.0);

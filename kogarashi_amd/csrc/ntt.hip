@@ -23,7 +23,7 @@ struct kg_tw_cache {
   uint32_t log_n;
   int inverse;
   uint32_t lo_bits;
-  uint32_t* small = nullptr;   // w_2048^e, e < 1024         [e][9]
+  uint32_t* small = nullptr;   // w_2048^e, e < 1024, Shoup form [e][18]
   uint32_t* lo = nullptr;      // w_n^e, e < 2^lo_bits        [e][9]
   uint32_t* hi = nullptr;      // w_n^(e << lo_bits)          [e][9]
   uint32_t* cos_lo = nullptr;  // g^(+-e) (g = 7), e < 2^lo_bits, for the coset shift [* n^-1 when inverse]
@@ -53,7 +53,14 @@ __global__ void __launch_bounds__(64) k_build_table(int kind, uint32_t log_n, in
   uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= count) return;
   Fr v;
-  if (kind == 0) v = pow_u64(root_of(NTT_TW_LOG, inverse), e);
+  if (kind == 0) {                         // Shoup-form constant: the plain canonical root power and its quotient (fp29.h mulc)
+    Fr raw_one = Fr::zero();
+    raw_one.l[0] = 1;
+    const FpConst<FrParams> c = make_const(reduce_2p(mul(pow_u64(root_of(NTT_TW_LOG, inverse), e), raw_one)));
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { tab[e * 18 + k] = c.w[k]; tab[e * 18 + 9 + k] = c.q[k]; }
+    return;
+  }
   else if (kind == 1) v = pow_u64(root_of(log_n, inverse), e);
   else if (kind == 2) v = pow_u64(root_of(log_n, inverse), (uint64_t)e << lo_bits);
   else {
@@ -79,7 +86,7 @@ __global__ void __launch_bounds__(64) k_build_direct(uint32_t log_n, int inverse
 
 // One tile per workgroup; see ntt_tile.h.  NT = tile / 4 threads (one radix-4 group per lane and pass).
 template <int LOG_M, int LOG_TC, bool ROW>
-__global__ void __launch_bounds__((NttTile<Fr, LOG_M, LOG_TC, ROW>::NT)) k_ntt_tile(NttStepArgs A) {
+__global__ void __launch_bounds__((NttTile<Fr, LOG_M, LOG_TC, ROW>::NT)) __attribute__((amdgpu_waves_per_eu(4))) k_ntt_tile(NttStepArgs A) {   // <= 128 VGPRs: LDS admits four waves per SIMD
   KG_SERVICE_PRIO();
   using T = NttTile<Fr, LOG_M, LOG_TC, ROW>;
   extern __shared__ uint32_t lds[];
@@ -143,7 +150,7 @@ int get_tables(kg_ctx* ctx, uint32_t log_n, int inverse, kg_tw_cache** out) {
   const size_t cnt_a = (nsteps >= 2 && log_n <= DIRECT_A_MAX_LOG) ? (size_t)1 << log_n : 0;
   const size_t cnt_b = nsteps == 3 ? (size_t)1 << (d[1].log_m + d[2].log_m) : 0;
   auto alloc = [&](uint32_t** p, size_t entries) { return entries == 0 || hipMalloc((void**)p, entries * 36) == hipSuccess; };
-  if (!alloc(&t->small, 1u << (NTT_TW_LOG - 1)) || !alloc(&t->lo, n_lo) || !alloc(&t->hi, n_hi) || !alloc(&t->cos_lo, n_lo) ||
+  if (!alloc(&t->small, 2u << (NTT_TW_LOG - 1)) || !alloc(&t->lo, n_lo) || !alloc(&t->hi, n_hi) || !alloc(&t->cos_lo, n_lo) ||
       !alloc(&t->cos_hi, n_hi) || !alloc(&t->zinv, 1) || !alloc(&t->direct[0], cnt_a) || !alloc(&t->direct[1], cnt_b)) {
     (void)hipGetLastError();
     free_tables(t);                                    // releases whatever was allocated before the failure

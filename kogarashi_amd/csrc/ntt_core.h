@@ -11,7 +11,8 @@
 namespace kg {
 
 // x[k], k in [0, 2^G): element whose G "middle" index bits equal k.  Stage t (1..G) pairs k0 / k0 + 2^(t-1).
-// tw(t, k0) returns the twiddle of that butterfly; trivial_first: this pass runs global stages 1..G.
+// tw.mul(x, t, k0) returns x times the twiddle of that butterfly (the kernel: a Shoup-form constant product, fp29.h mulc);
+// trivial_first: this pass runs global stages 1..G.
 // (compile-time recursion instead of loops: every x[] index is a constant expression, so the array stays in registers)
 template <int G, int T, int PI, class F, class TwFn>
 KG_HD void dit_step(F (&x)[1 << G], bool trivial_first, const TwFn& tw) {
@@ -33,16 +34,22 @@ KG_HD void dit_step(F (&x)[1 << G], bool trivial_first, const TwFn& tw) {
         x[k1] = sub<4, 1>(a, b);
       }
     } else {
-      F tt = mul(x[k1], tw(T, k0));                  // < 2p, normalised: the 2p fat constant dominates it, so the value bound of
-      F a = x[k0];                                   // the never-multiplied path grows by 2p per stage (a 2^11-point tile: < 40p)
+      F tt = tw.mul(x[k1], T, k0);                   // < 2.4p, normalised (mulc, or mul: < 2p): the 3p fat constant dominates it,
+      F a = x[k0];                                   // so the value bound of the never-multiplied path grows by 3p per stage
       x[k0] = add(a, tt);
-      x[k1] = sub<2, 1>(a, tt);
+      x[k1] = sub<3, 1>(a, tt);
     }
     if constexpr (PI + 1 < (1 << (G - 1))) dit_step<G, T, PI + 1>(x, trivial_first, tw);
     else dit_step<G, T + 1, 0>(x, trivial_first, tw);
   }
 }
 template <int G, class F, class TwFn>
-KG_HD void dit_network(F (&x)[1 << G], bool trivial_first, const TwFn& tw) { dit_step<G, 1, 0>(x, trivial_first, tw); }
+KG_HD void dit_network(F (&x)[1 << G], bool trivial_first, const TwFn& tw) {
+#ifdef KG_NTT_EXP_NOMATH      // phase-off experiment (tools/dbg): data movement only
+  (void)trivial_first; (void)tw;
+  return;
+#endif
+  dit_step<G, 1, 0>(x, trivial_first, tw);
+}
 
 }  // namespace kg

@@ -16,7 +16,7 @@
 
 namespace kg {
 
-constexpr int NTT_TW_LOG = 11;   // in-tile twiddle table: w_2048^e, e < 1024, [e][9] words
+constexpr int NTT_TW_LOG = 11;   // in-tile twiddle table: w_2048^e, e < 1024, as Shoup-form constants {w, floor(w 2^261 / p)}: [e][18] words
 constexpr int NTT_MAX_LOG_M = 11;
 
 struct NttStepArgs {
@@ -154,6 +154,13 @@ template <class P> struct NttIO<Fp<P>> {
     return r;
   }
   static KG_HD void words(const Fp<P>& a, uint32_t w[8]) { words_from_limbs(a, w); }
+  static KG_HD FpConst<P> twc(const uint32_t* tab, size_t e) {                             // in-tile twiddle: {w, floor(w 2^261 / p)}
+    FpConst<P> c;
+    const uint32_t* p = tab + e * 18;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { c.w[k] = p[k]; c.q[k] = p[9 + k]; }
+    return c;
+  }
 };
 template <class F>
 KG_HD F ntt_two_level(const uint32_t* lo, const uint32_t* hi, uint32_t lo_bits, uint64_t e) {
@@ -209,28 +216,33 @@ struct NttTile {
 
   const NttStepArgs& A;
   uint32_t tile;
+#ifdef KG_NTT_EXP_NOMEM        // phase-off experiment: every workgroup works on one of tiles 0..63 (8 MB: the data stays in the L2 / Infinity Cache)
+#define KG_NTT_TILE_ID (tile & 63u)
+#else
+#define KG_NTT_TILE_ID tile
+#endif
 
   // twiddles of a register pass over stages s0+1 .. s0+G: w_{2^s}^j, j = r mod 2^(s-1)
   struct Tw {
     const uint32_t* tw_m;
     uint32_t s0, r_low;
-    KG_HD F operator()(int t, int k0) const {
+    KG_HD F mul(const F& x, int t, int k0) const {
       const uint32_t s = s0 + (uint32_t)t;
       const uint32_t j = (((uint32_t)k0 & ((1u << (t - 1)) - 1u)) << s0) | r_low;
 #ifdef KG_NTT_EXP_NOTW      // phase-off experiment (tools/dbg): every twiddle is the same table entry
-      return NttIO<F>::table(tw_m, (size_t)(j & 0u) + 5);
+      return mulc(x, NttIO<F>::twc(tw_m, (size_t)(j & 0u) + 5));
 #endif
-      return NttIO<F>::table(tw_m, (size_t)j << (NTT_TW_LOG - s));
+      return mulc(x, NttIO<F>::twc(tw_m, (size_t)j << (NTT_TW_LOG - s)));
     }
   };
 
   // ---- addresses ----
   KG_HD uint64_t col_base() const {         // column step: address of (row 0, column 0 of the tile)
-    const uint64_t g0 = (uint64_t)tile << LOG_TC;
+    const uint64_t g0 = (uint64_t)KG_NTT_TILE_ID << LOG_TC;
     return ((g0 >> A.log_inner) << (LOG_M + A.log_inner)) + (g0 & ((1ull << A.log_inner) - 1));
   }
   KG_HD uint64_t row_in(uint32_t col) const {   // row step: first element of DFT g0 + col
-    const uint64_t g = ((uint64_t)tile << LOG_TC) + col;
+    const uint64_t g = ((uint64_t)KG_NTT_TILE_ID << LOG_TC) + col;
     const uint64_t i1 = g & ((1ull << A.log_n1) - 1), i2 = g >> A.log_n1;
     return ((i1 << (A.log_G - A.log_n1)) + i2) << LOG_M;
   }
@@ -246,7 +258,7 @@ struct NttTile {
   KG_HD void store_elem(const F& x, uint32_t i, uint32_t col) const {
     uint32_t w[8];
     if constexpr (ROW) {
-      const uint64_t addr = (((uint64_t)tile << LOG_TC) + col) + ((uint64_t)i << A.log_G);
+      const uint64_t addr = (((uint64_t)KG_NTT_TILE_ID << LOG_TC) + col) + ((uint64_t)i << A.log_G);
       F v;
       if (A.scale_mode == 2) v = mul(x, ntt_two_level<F>(A.cos_lo, A.cos_hi, A.lo_bits, addr));
       else if (A.scale_mode == 3) v = mul(x, NttIO<F>::table(A.cos_lo, 0));
@@ -254,9 +266,13 @@ struct NttTile {
       NttIO<F>::words(reduce_2p(v), w);
       ntt_st_words(A.out, addr, w);
     } else {
-      const uint64_t off = ((uint64_t)i << A.log_inner) + ((((uint64_t)tile << LOG_TC) & ((1ull << A.log_inner) - 1)) + col);
-      const uint64_t slab = ((((uint64_t)tile << LOG_TC) >> A.log_inner) << (LOG_M + A.log_inner));
+      const uint64_t off = ((uint64_t)i << A.log_inner) + ((((uint64_t)KG_NTT_TILE_ID << LOG_TC) & ((1ull << A.log_inner) - 1)) + col);
+      const uint64_t slab = ((((uint64_t)KG_NTT_TILE_ID << LOG_TC) >> A.log_inner) << (LOG_M + A.log_inner));
       F v;
+#ifdef KG_NTT_EXP_NOMATH
+      if (A.tw_direct) v = add(x, NttIO<F>::table(A.tw_direct, off));
+      else
+#endif
       if (A.tw_direct) v = mul(x, NttIO<F>::table(A.tw_direct, off));
       else if (A.mult) v = mul(x, ntt_two_level<F>(A.tw_lo, A.tw_hi, A.lo_bits, (uint64_t)i * ((off & ((1ull << A.log_inner) - 1)) * A.mult)));
       else v = vred(norm(x));
@@ -318,8 +334,11 @@ struct NttTile {
     for (int k = 0; k < 4; ++k) x[k] = st.template load<F>(w0 ^ tile_phys<B>((uint32_t)k << F0));
     Tw tw{A.tw_m, (uint32_t)S0, r_low};
     dit_network<2>(x, false, tw);
+    // the never-multiplied path gains 3p per stage: a 2^11-point tile would pass the 42p the final value reduction
+    // admits, so its middle pass stores value-reduced elements (45 instructions per element, once)
+    constexpr bool REDUCE_HERE = LOG_M >= 11 && S0 == 5;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) st.store(w0 ^ tile_phys<B>((uint32_t)k << F0), norm(x[k]));
+    for (int k = 0; k < 4; ++k) st.store(w0 ^ tile_phys<B>((uint32_t)k << F0), REDUCE_HERE ? vred(norm(x[k])) : norm(x[k]));
   }
 
   // ---- last pass over stages LOG_M-1, LOG_M: LDS -> inter-step twiddle / scaling -> global store ----

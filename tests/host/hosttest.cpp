@@ -160,7 +160,11 @@ static void ntt_network(const uint32_t* data, const uint32_t* tw, int rounds, in
   for (int k = 0; k < 8; ++k) x[k] = RawIn<F>::in(data + 8 * k);
   for (int k = 0; k < 7; ++k) w[k] = Conv<F>::in(tw + 8 * k);
   for (int r = 0; r < rounds; ++r) {
-    dit_network<3>(x, trivial_first && r == 0, [&](int t, int k0) { return t == 1 ? w[0] : (t == 2 ? w[1 + (k0 & 1)] : w[3 + (k0 & 3)]); });
+    struct MontTw {                                  // twiddles in Montgomery form here; the kernel's are Shoup-form constants (hosttest_ntt.cpp)
+      const F* w;
+      F mul(const F& v, int t, int k0) const { return kg::mul(v, t == 1 ? w[0] : (t == 2 ? w[1 + (k0 & 1)] : w[3 + (k0 & 3)])); }
+    } tw{w};
+    dit_network<3>(x, trivial_first && r == 0, tw);
     for (int k = 0; k < 8; ++k) x[k] = norm(x[k]);
   }
   for (int k = 0; k < 8; ++k) raw_out(x[k], out + 8 * k);

@@ -14,6 +14,7 @@ namespace kg {
 template <class P> struct NttIO<FpChecked<P>> {
   static FpChecked<P> raw(const uint32_t w[8]) { return FpChecked<P>::wrap(limbs_from_words<P>(w), 5.4); }       // any 256-bit value
   static FpChecked<P> table(const uint32_t* tab, size_t e) { return FpChecked<P>::wrap(NttIO<Fp<P>>::table(tab, e), 2.0); }
+  static FpConst<P> twc(const uint32_t* tab, size_t e) { return NttIO<Fp<P>>::twc(tab, e); }
   static void words(const FpChecked<P>& a, uint32_t w[8]) {
     a.check_actual();
     if (!(a.lb <= (double)M29 && a.kb <= 5.4)) BoundFail::fail("store of a value that is not a normalised 256-bit integer", a.lb, a.kb);
@@ -128,13 +129,23 @@ int ht_ntt(int checked, uint32_t log_n, int steps, int inverse, int coset, uint6
   const int nsteps = ntt_plan(log_n, steps, d);
   // tables: the formulas of k_build_table / k_build_direct / (ntt.hip)
   const uint32_t lo_bits = (log_n + 1) / 2, n_lo = 1u << lo_bits, n_hi = 1u << (log_n - lo_bits);
-  std::vector<uint32_t> small(9u << (NTT_TW_LOG - 1)), lo(9u * n_lo), hi(9u * n_hi), cos_lo(9u * n_lo), cos_hi(9u * n_hi), d0, d1;
+  std::vector<uint32_t> small(18u << (NTT_TW_LOG - 1)), lo(9u * n_lo), hi(9u * n_hi), cos_lo(9u * n_lo), cos_hi(9u * n_hi), d0, d1;
   auto fill_pow = [&](std::vector<uint32_t>& tab, size_t cnt, Fr start, Fr ratio) {
     Fr v = start;
     for (size_t e = 0; e < cnt; ++e) { st_tw(tab, e, mul(v, Fr::one())); v = mul(v, ratio); }     // mul by one: normalised, < 2p like the device entries
   };
   const Fr wn = ntt_root_of<Fr>(log_n, inverse);
-  fill_pow(small, 1u << (NTT_TW_LOG - 1), Fr::one(), ntt_root_of<Fr>(NTT_TW_LOG, inverse));
+  {                                             // in-tile twiddles as Shoup-form constants, like k_build_table kind 0
+    Fr raw_one = Fr::zero();
+    raw_one.l[0] = 1;
+    Fr v = Fr::one();
+    const Fr ratio = ntt_root_of<Fr>(NTT_TW_LOG, inverse);
+    for (size_t e = 0; e < ((size_t)1 << (NTT_TW_LOG - 1)); ++e) {
+      const FpConst<FrParams> c = make_const(reduce_2p(mul(v, raw_one)));
+      for (int k = 0; k < 9; ++k) { small[e * 18 + k] = c.w[k]; small[e * 18 + 9 + k] = c.q[k]; }
+      v = mul(v, ratio);
+    }
+  }
   fill_pow(lo, n_lo, Fr::one(), wn);
   fill_pow(hi, n_hi, Fr::one(), ntt_pow<Fr>(wn, (uint64_t)1 << lo_bits));
   const Fr g = Fr::from_const(inverse ? FrParams::GEN7_INV : FrParams::GEN7);
