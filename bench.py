@@ -34,8 +34,10 @@ MADD_PEAK_G = 16.5              # measured: the bucket kernel's addition routine
 MAD_PEAK_T = 33.0               # measured chip-wide v_mad_u64_u32 issue rate, T instructions/s (profiles/r01_valu_rates.txt)
 MADS_PER_ADDITION = 1467        # add_mixed_signed (curve.h): 6 products x 162 + 2 squares x 126 + one double product x 243 multiply-accumulates (fp29.h)
 MUL_PEAK_G = 174.0              # measured Montgomery products/s (profiles/r01_mul_rate.txt)
-NTT_MULS_PER_ELEMENT = {22: 13}  # 2^22 = 2^8 * 2^7 * 2^7: 11 butterfly products + one inter-step twiddle product per element at each of the two step boundaries (the twiddle itself is read from the direct table, ntt.hip)
-NTT_KERNEL_NOTE = "k_ntt_step x 3 (one HBM round trip each: 192 B moved per element)"
+# 2^22 = 2^11 * 2^11 (ntt_tile.h: two steps, two HBM round trips).  Per element: 10 in-tile twiddle products in Shoup form (fp29.h mulc:
+# 143 multiply-accumulates each; stage 1 of either tile has none) + 1 inter-step Montgomery product (162 + 9 v_mul_lo)
+NTT_MADS_PER_ELEMENT = {22: 10 * 143 + 171}
+NTT_KERNEL_NOTE = "k_ntt_tile<11,1,col> + k_ntt_tile<11,1,row> (two HBM round trips: 128 B of data moved per element, + 36 B of inter-step twiddle table)"
 
 
 def window_adds(n):
@@ -91,6 +93,7 @@ def main():
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-groth16", action="store_true")
     ap.add_argument("--no-nova", action="store_true")
+    ap.add_argument("--ntt-only", action="store_true", help="profiling aid: only the NTT leg (tools/collect_profiles.sh); prints {\"ntt\": ...}")
     ap.add_argument("--nova-log-n", type=int, default=24, help="pairs of the Nova commitment (whole job, cut over the ranks)")
     ap.add_argument("--groth16-log-m", type=int, default=18)
     ap.add_argument("--window", type=int, default=0)
@@ -139,6 +142,11 @@ def main():
     n = 1 << args.log_n
 
     ctx = K.Context(local_rank)
+    if args.ntt_only:
+        torch.cuda.synchronize()
+        env = {"world": world, "rank": rank, "barrier": torch.cuda.synchronize, "max_over_ranks": lambda x: x, "xdev": dev, "kdist": None}
+        print(json.dumps({"ntt": bench_ntt(ctx, torch, dev, K, env, steps=max(args.steps, 10))}), flush=True)
+        return
     # The library launches on its own queues (main queue: accumulations; scalar-side queue: digit extraction, sort, base
     # conversion; two reduction queues) and brackets its phases with HIP events recorded on those queues; the timed region
     # is bracketed by device-wide synchronisation.
@@ -300,17 +308,18 @@ def main():
 
 
 def pmc_traffic(log_n):
-    """Memory-side bytes per k_acc_tasks launch from the committed rocprofv3 --pmc passes (profiles/): FETCH_SIZE and
+    """KG_BENCH_PMC=<file>: a fresh pmc_summary.py JSON (same-day FETCH_SIZE / WRITE_SIZE passes) instead of the committed one.
+    Memory-side bytes per k_acc_tasks launch from the committed rocprofv3 --pmc passes (profiles/): FETCH_SIZE and
     WRITE_SIZE are collected in separate runs of this same command.  MI355X_MICROARCH.md prescribes doubling FETCH_SIZE on
     gfx950 for wide coalesced streams; this kernel's reads are scattered 8-byte-per-lane gathers, for which the correction is
     uncalibrated -- both figures are reported.  Only valid for the configuration it was measured on (2^20 pairs); null otherwise."""
-    for name in ("r02_pmc_hbm.json", "r01_m_pmc_hbm.json"):
-        path = os.path.join(ROOT, "profiles", name)
+    for name in ("r03_pmc_hbm.json", "r02_pmc_hbm.json", "r01_m_pmc_hbm.json"):
+        path = os.environ.get("KG_BENCH_PMC") or os.path.join(ROOT, "profiles", name)
         if log_n == LOG_N and os.path.exists(path):
             with open(path) as f:
                 t = json.load(f)["k_acc_tasks_traffic_bytes_per_launch"]
             return {"uncorrected": t["fetch_reported"] + t["write"], "corrected": t["total_corrected"], "fetch_reported": t["fetch_reported"],
-                    "write": t["write"], "source": "profiles/" + name,
+                    "write": t["write"], "source": os.path.relpath(path, ROOT),
                     "note": "FETCH_SIZE x2 is calibrated for 16-B-per-lane streams; 8-B gathers out of L2 / Infinity Cache make it an upper estimate"}
     return None
 
@@ -339,14 +348,16 @@ def bench_ntt(ctx, torch, dev, K, env, log_n=22, steps=10):
     ctx.profile_enable(False)
     ms = tot / cnt
     gbs = 64.0 * n / (ms * 1e-3) / 1e9
-    muls = NTT_MULS_PER_ELEMENT.get(log_n)
+    mads = NTT_MADS_PER_ELEMENT.get(log_n)
     out = {"metric": "bn254_fr_ntt_elements_per_sec", "log_n": log_n, "value": world * n / (wall_ms * 1e-3), "ms": ms, "wall_ms": wall_ms,
            "replicas": world, "note": "value = replicas x n / wall time per transform (max over ranks); ms = HIP-event duration of one transform on rank 0",
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes": 64 * n, "kernel": NTT_KERNEL_NOTE}}
-    if muls:
-        out["valu_roofline"] = {"bound": "valu", "unit": "G Montgomery products/s", "products_per_element": muls,
-                                "achieved": muls * n / (ms * 1e-3) / 1e9, "peak": MUL_PEAK_G, "frac": muls * n / (ms * 1e-3) / 1e9 / MUL_PEAK_G}
+    if mads:
+        out["valu_roofline"] = {"bound": "valu", "unit": "T v_mad_u64_u32/s", "mads_per_element": mads,
+                                "achieved": mads * n / (ms * 1e-3) / 1e12, "peak": MAD_PEAK_T, "frac": mads * n / (ms * 1e-3) / 1e12 / MAD_PEAK_T,
+                                "note": "multiply-accumulates are ~55 % of the kernel's VALU instructions; rocprofv3 SQ counters: VALU issue on ~2/3 of the SIMD "
+                                        "cycles, waves parked at barriers / waits for ~48 % of their lifetime (DESIGN.md section 4)"}
     return out
 
 

@@ -170,7 +170,10 @@ KG_HD F ntt_two_level(const uint32_t* lo, const uint32_t* hi, uint32_t lo_bits, 
   return mul(a, NttIO<F>::table(hi, eh));
 }
 
-// the kernel's tile store: limb k of LDS word w at base[k * ELEMS + w]
+// the kernel's tile store: limbs (2j, 2j+1) of LDS word w as one 8-byte pair at plane j (j < 4), limb 8 in a fifth plane of
+// 4-byte words: four ds_read_b64 / ds_write_b64 and one b32 per element instead of nine b32 (a b64 wave access moves 512 B in
+// the two LDS cycles a b32 one needs for 256 B).  Banks: a pair at word w sits on banks 2w, 2w + 1 mod 64 -- the 32 lanes of a
+// half are conflict-free exactly when their w differ mod 32, the same rule as for b32 (tile_phys).
 template <int ELEMS>
 struct LdsPlanes {
   uint32_t* base;
@@ -180,8 +183,14 @@ struct LdsPlanes {
     base[w] = a.l[0] ^ a.l[1] ^ a.l[2] ^ a.l[3] ^ a.l[4] ^ a.l[5] ^ a.l[6] ^ a.l[7] ^ a.l[8];
     return;
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint2* b2 = reinterpret_cast<uint2*>(base);
 #pragma unroll
+    for (int j = 0; j < 4; ++j) b2[j * ELEMS + w] = make_uint2(a.l[2 * j], a.l[2 * j + 1]);
+    base[8 * ELEMS + w] = a.l[8];
+#else
     for (int k = 0; k < 9; ++k) base[k * ELEMS + w] = a.l[k];
+#endif
   }
   template <class F>
   KG_HD F load(uint32_t w) const {
@@ -192,8 +201,14 @@ struct LdsPlanes {
     for (int k = 0; k < 9; ++k) r.l[k] = (v >> k) & M29;
     return r;
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint2* b2 = reinterpret_cast<const uint2*>(base);
 #pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint2 v = b2[j * ELEMS + w]; r.l[2 * j] = v.x; r.l[2 * j + 1] = v.y; }
+    r.l[8] = base[8 * ELEMS + w];
+#else
     for (int k = 0; k < 9; ++k) r.l[k] = base[k * ELEMS + w];
+#endif
     return r;
   }
 };

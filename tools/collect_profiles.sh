@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the artefacts profiles/ holds for a round, on the GPU box:
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
 # then, back in the container:  python tools/install_profiles.py r02
 # Every leg is bounded by its own timeout; PMC passes run alone (never with a trace domain).
 set -u
@@ -18,5 +18,12 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d "$O/pmc_$c" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-groth16 > "$O/pmc_$c.json" 2> "$O/pmc_$c.err"
 done
-ls -R "$O" | head -60
+# 5. the transform alone (2^22 forward NTT: the two k_ntt_tile kernels without the prover's 2^18 launches in the averages)
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_ntt" -- python3 bench.py --ntt-only --steps 20 > "$O/ntt_under_rocprof.json" 2> "$O/kt_ntt.err"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d "$O/pmcntt_$c" -- python3 bench.py --ntt-only --steps 10 > "$O/pmcntt_$c.json" 2> "$O/pmcntt_$c.err"
+done
+# 6. SQ issue / wait counters of the same leg
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$O/pmcntt_SQ" -- python3 bench.py --ntt-only --steps 10 > "$O/pmcntt_SQ.json" 2> "$O/pmcntt_SQ.err"
+ls -R "$O" | head -80
 tail -c 600 "$O/bench.json"

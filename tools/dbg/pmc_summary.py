@@ -14,6 +14,8 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         key = m.group(1) + (m.group(2) if m and m.group(2) and ("Fp2" in m.group(2)) else "") if m else name[:40]
         if m and m.group(2) and "Fp2" in m.group(2):
             key = m.group(1) + "<Fq2>"
+        if m and m.group(1) == "k_ntt_tile" and m.group(2):
+            key = "k_ntt_tile" + m.group(2).replace(" ", "") + "/grid" + r.get("Grid_Size", "?")     # one key per tile shape and transform size
         a = acc.setdefault(key, {"dispatches": 0, "sum": 0.0, "vgpr": int(r["VGPR_Count"]), "lds": int(r["LDS_Block_Size"]), "wg": int(r["Workgroup_Size"])})
         a["dispatches"] += 1
         a["sum"] += float(r["Counter_Value"])
@@ -28,7 +30,10 @@ def per_launch(kernel, algorithmic):
     return {"fetch_reported": f, "fetch_corrected_x2": 2 * f, "write": w, "total_corrected": 2 * f + w, "algorithmic": algorithmic}
 # what bench.py's roofline.traffic reads (2^20 G1 pairs: 96 B per pair; 2^22 Fr elements: 32 B read + 32 B written per step)
 out["k_acc_tasks_traffic_bytes_per_launch"] = per_launch("k_acc_tasks", 96 << 20)
-out["k_ntt_step_traffic_bytes_per_launch_2_22"] = per_launch("k_ntt_step", 64 << 22)
+for shape in ("<11,1,false>", "<11,1,true>"):      # the two steps of a 2^22 transform: 32 B read + 32 B written per element each (+ 36 B of twiddle table in the first)
+    k = f"k_ntt_tile{shape}/grid{1 << 20}"
+    if k in out["FETCH_SIZE"]:
+        out[f"{k}_traffic_bytes_per_launch"] = per_launch(k, 64 << 22)
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 for k in out["FETCH_SIZE"]:
     print(f"{k:32s} fetch {out['FETCH_SIZE'][k]['mean_KB']/1024:9.2f} MB  write {out['WRITE_SIZE'].get(k, {}).get('mean_KB', 0)/1024:9.2f} MB  vgpr {out['FETCH_SIZE'][k]['vgpr']} lds {out['FETCH_SIZE'][k]['lds_bytes']}")

@@ -23,4 +23,24 @@ for d, out in (("kt_bench", f"{rnd}_bench_kernel_stats.csv"), ("kt_msm", f"{rnd}
     shutil.copy(f, os.path.join(dst, out))
 subprocess.check_call([sys.executable, os.path.join(root, "tools", "dbg", "pmc_summary.py"), os.path.join(src, "pmc_"),
                        os.path.join(dst, f"{rnd}_pmc_hbm.json")])
+# the transform alone: kernel averages, HBM counters, SQ issue / wait counters
+if os.path.isdir(os.path.join(src, "kt_ntt")):
+    shutil.copy(glob.glob(os.path.join(src, "kt_ntt", "*", "*kernel_stats.csv"))[0], os.path.join(dst, f"{rnd}_ntt_kernel_stats.csv"))
+    json.dump(last_json_line(os.path.join(src, "ntt_under_rocprof.json")), open(os.path.join(dst, f"{rnd}_ntt_under_rocprof.json"), "w"), indent=1)
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "dbg", "pmc_summary.py"), os.path.join(src, "pmcntt_"),
+                           os.path.join(dst, f"{rnd}_ntt_pmc_hbm.json")])
+    import csv, collections, re
+    f = glob.glob(os.path.join(src, "pmcntt_SQ", "*", "*counter_collection.csv"))
+    if f:
+        acc, cnt = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
+        for r in csv.DictReader(open(f[0])):
+            if "k_ntt_tile" not in r["Kernel_Name"]:
+                continue
+            key = re.search(r"k_ntt_tile<[^>]*>", r["Kernel_Name"]).group(0).replace(" ", "") + "/grid" + r["Grid_Size"]
+            acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[key] += r["Counter_Name"] == "SQ_WAVE_CYCLES"
+        out = {k: {"dispatches": cnt[k], **{c: v / max(cnt[k], 1) for c, v in d.items()}} for k, d in acc.items()}
+        out["note"] = ("per dispatch; SQ_* in quad-cycles summed over all waves (SQ_WAIT_ANY: parked at s_waitcnt / barrier, SQ_WAIT_INST_ANY: waiting "
+                       "to issue, SQ_ACTIVE_INST_ANY: issuing); GRBM_GUI_ACTIVE summed over the 8 XCDs")
+        json.dump(out, open(os.path.join(dst, f"{rnd}_ntt_sq_counters.json"), "w"), indent=1)
 print("installed into", dst)
