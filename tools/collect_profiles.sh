@@ -13,10 +13,10 @@ timeout -s KILL 400 python3 bench.py > "$O/bench.json" 2> "$O/bench.err"
 # 2. the same command under the kernel trace (kernel averages must agree with the line's HIP-event figures)
 timeout -s KILL 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_bench" -- python3 bench.py --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/kt_bench.err"
 # 3. MSM legs only (the kernels of the headline metric without NTT / Groth16 launches in the averages)
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_msm" -- python3 bench.py --no-cpu-baseline --no-ntt --no-groth16 > "$O/msm_under_rocprof.json" 2> "$O/kt_msm.err"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_msm" -- python3 bench.py --no-cpu-baseline --no-ntt --no-groth16 --no-nova > "$O/msm_under_rocprof.json" 2> "$O/kt_msm.err"
 # 4. HBM traffic: one counter per pass
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d "$O/pmc_$c" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-groth16 > "$O/pmc_$c.json" 2> "$O/pmc_$c.err"
+  timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d "$O/pmc_$c" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-groth16 --no-nova > "$O/pmc_$c.json" 2> "$O/pmc_$c.err"
 done
 # 5. the transform alone (2^22 forward NTT: the two k_ntt_tile kernels without the prover's 2^18 launches in the averages)
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_ntt" -- python3 bench.py --ntt-only --steps 20 > "$O/ntt_under_rocprof.json" 2> "$O/kt_ntt.err"
