@@ -31,14 +31,24 @@ struct kg_tw_cache {
   uint32_t* zinv = nullptr;    // (7^n - 1)^-1, one entry (fft.rs:141-154)
   // inter-step twiddles read instead of generated: direct[s][r * inner + c] = w_n^(r * c * mult) for step s (0: A, 1: B).
   // Step B's table is n2 * n3 <= 2^16 entries; step A's is n entries and is kept only while it stays cache-resident
-  // is worth its memory (log_n <= DIRECT_A_MAX_LOG = 22: 36 MB at 2^20, 151 MB at 2^22).  Saves the running-product update (one of the
+  // is worth its memory (log_n <= direct_a_max_log() = 22: 36 MB at 2^20, 151 MB at 2^22).  Saves the running-product update (one of the
   // two products per element): 2^18 59 -> 52 us, 2^20 164 -> 145 us, 2^22 557 -> 548 us.
   uint32_t* direct[2] = {nullptr, nullptr};
 };
 
 namespace {
 
-constexpr uint32_t DIRECT_A_MAX_LOG = 22;
+// Largest transform whose step-A inter-step twiddles are read from a direct table of n entries (36 B each: 36 MB at 2^20,
+// 151 MB at 2^22, per direction) instead of being composed from the two-level tables (one more product per element).
+// KG_NTT_DIRECT_MAX_LOG lowers it for hosts that would rather keep the memory (0 = never).
+uint32_t direct_a_max_log() {
+  static const uint32_t v = [] {
+    const char* e = getenv("KG_NTT_DIRECT_MAX_LOG");
+    const long x = e ? atol(e) : 22;
+    return (uint32_t)(x < 0 ? 0 : (x > 22 ? 22 : x));
+  }();
+  return v;
+}
 
 __device__ __forceinline__ Fr ld_tw(const uint32_t* __restrict__ tab, size_t e) { return NttIO<Fr>::table(tab, e); }
 __device__ __forceinline__ void st_tw(uint32_t* tab, size_t e, const Fr& a) {
@@ -147,7 +157,7 @@ int get_tables(kg_ctx* ctx, uint32_t log_n, int inverse, kg_tw_cache** out) {
   const int nsteps = ntt_plan(log_n, plan_steps_env(), d, plan_tile_env());
   // direct inter-step tables: step A w_n^(i1 * c), c < n / n1 (n entries; kept while it is worth its memory: 36 MB at 2^20,
   // 151 MB at 2^22), step B of a three-step plan w_n^(n1 * i2 * j3) (n2 * n3 entries)
-  const size_t cnt_a = (nsteps >= 2 && log_n <= DIRECT_A_MAX_LOG) ? (size_t)1 << log_n : 0;
+  const size_t cnt_a = (nsteps >= 2 && log_n <= direct_a_max_log()) ? (size_t)1 << log_n : 0;
   const size_t cnt_b = nsteps == 3 ? (size_t)1 << (d[1].log_m + d[2].log_m) : 0;
   auto alloc = [&](uint32_t** p, size_t entries) { return entries == 0 || hipMalloc((void**)p, entries * 36) == hipSuccess; };
   if (!alloc(&t->small, 2u << (NTT_TW_LOG - 1)) || !alloc(&t->lo, n_lo) || !alloc(&t->hi, n_hi) || !alloc(&t->cos_lo, n_lo) ||

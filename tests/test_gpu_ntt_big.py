@@ -122,3 +122,33 @@ def test_huge_sizes_by_device_side_properties(ctx, pyoracle, k):
     ctx.field_vec_op(K.KG_FR, "add", x.data_ptr(), y.data_ptr(), x.data_ptr(), n)
     ctx.sync()
     assert torch.equal(x, t), "linearity"
+
+
+_PLAN_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import kogarashi_amd as K
+from oracle import oracle as O
+ctx = K.Context(0)
+for k in (13, 18, 20):
+    v = O.gen_scalars(0, 0x4B6F676172617368 + 900 + k, 0, 1 << k)
+    fo, fg = O.Fft(k), K.Fft(k, ctx=ctx)
+    assert (fg.dft(v) == fo.dft(v, threads=8)).all(), ("dft", k)
+    assert (fg.coset_idft(v) == fo.coset_idft(v, threads=8)).all(), ("coset_idft", k)
+    assert (fg.idft(fg.coset_dft(v)) == fo.idft(fo.coset_dft(v, threads=8), threads=8)).all(), ("mixed", k)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("env", [{"KG_NTT_STEPS": "3"}, {"KG_NTT_STEPS": "3", "KG_NTT_TILE": "10"}, {"KG_NTT_TILE": "11"},
+                                 {"KG_NTT_DIRECT_MAX_LOG": "0"}, {"KG_NTT_DIRECT_MAX_LOG": "0", "KG_NTT_STEPS": "3"}])
+def test_every_plan_knob_gives_the_same_transform(env):
+    """the plan knobs are read once per process: three-step plans, other tile sizes and the table-free inter-step twiddles
+    (two-level composition instead of the direct table) against the oracle, each in a child process"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _PLAN_SCRIPT % root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (env, r.stderr[-2000:])

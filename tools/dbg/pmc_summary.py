@@ -3,7 +3,8 @@ JSON: per kernel the mean KB per dispatch, plus VGPR / LDS use.  python tools/db
 import csv, glob, json, re, sys, collections
 out = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(f"{sys.argv[1]}{counter}/*/*counter_collection.csv")[0]
+    import os
+    f = max(glob.glob(f"{sys.argv[1]}{counter}/*/*counter_collection.csv"), key=os.path.getmtime)      # gpurun_out keeps earlier collections' files
     acc = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:

@@ -8,6 +8,14 @@ src = os.path.join(root, "gpurun_out", "collect")
 dst = os.path.join(root, "profiles")
 
 
+def newest(pattern):
+    """gpurun merges every call's output into gpurun_out/: an earlier collection's files stay beside the latest"""
+    files = glob.glob(pattern)
+    if not files:
+        raise SystemExit(f"nothing matches {pattern}")
+    return max(files, key=os.path.getmtime)
+
+
 def last_json_line(path):
     for line in reversed(open(path).read().splitlines()):
         if line.startswith("{"):
@@ -19,18 +27,18 @@ for name, out in (("bench.json", f"{rnd}_bench.json"), ("bench_under_rocprof.jso
                   ("msm_under_rocprof.json", f"{rnd}_msm_under_rocprof.json")):
     json.dump(last_json_line(os.path.join(src, name)), open(os.path.join(dst, out), "w"), indent=1)
 for d, out in (("kt_bench", f"{rnd}_bench_kernel_stats.csv"), ("kt_msm", f"{rnd}_msm_kernel_stats.csv")):
-    f = glob.glob(os.path.join(src, d, "*", "*kernel_stats.csv"))[0]
+    f = newest(os.path.join(src, d, "*", "*kernel_stats.csv"))
     shutil.copy(f, os.path.join(dst, out))
 subprocess.check_call([sys.executable, os.path.join(root, "tools", "dbg", "pmc_summary.py"), os.path.join(src, "pmc_"),
                        os.path.join(dst, f"{rnd}_pmc_hbm.json")])
 # the transform alone: kernel averages, HBM counters, SQ issue / wait counters
 if os.path.isdir(os.path.join(src, "kt_ntt")):
-    shutil.copy(glob.glob(os.path.join(src, "kt_ntt", "*", "*kernel_stats.csv"))[0], os.path.join(dst, f"{rnd}_ntt_kernel_stats.csv"))
+    shutil.copy(newest(os.path.join(src, "kt_ntt", "*", "*kernel_stats.csv")), os.path.join(dst, f"{rnd}_ntt_kernel_stats.csv"))
     json.dump(last_json_line(os.path.join(src, "ntt_under_rocprof.json")), open(os.path.join(dst, f"{rnd}_ntt_under_rocprof.json"), "w"), indent=1)
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "dbg", "pmc_summary.py"), os.path.join(src, "pmcntt_"),
                            os.path.join(dst, f"{rnd}_ntt_pmc_hbm.json")])
     import csv, collections, re
-    f = glob.glob(os.path.join(src, "pmcntt_SQ", "*", "*counter_collection.csv"))
+    f = [newest(os.path.join(src, "pmcntt_SQ", "*", "*counter_collection.csv"))]
     if f:
         acc, cnt = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
         for r in csv.DictReader(open(f[0])):
