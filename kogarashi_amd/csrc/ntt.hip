@@ -198,21 +198,18 @@ int launch_tile(kg_ctx* ctx, hipStream_t st, const NttStepArgs& a, uint32_t ntil
   hipLaunchKernelGGL((k_ntt_tile<LOG_M, LOG_TC, ROW>), dim3(ntiles), dim3(T::NT), lds_bytes, st, a);
   return KG_OK;
 }
-#define KG_NTT_SHAPES(X) \
-  X(6, 4) X(7, 3) X(7, 4) X(8, 2) X(8, 3) X(9, 1) X(9, 2) X(10, 1) X(11, 1)
 int launch_step(kg_ctx* ctx, hipStream_t st, const NttStepDesc& d, const NttStepArgs& a, uint32_t ntiles) {
   const int key = d.log_m * 16 + d.log_tc;
   if (!d.row) {
     switch (key) {
 #define X(m, tc) case (m) * 16 + (tc): return launch_tile<m, tc, false>(ctx, st, a, ntiles);
-      KG_NTT_SHAPES(X) X(10, 0) X(11, 0)
+      KG_NTT_SHAPES(X) KG_NTT_SHAPES_COL_ONLY(X)
 #undef X
     }
   } else {
     switch (key) {
 #define X(m, tc) case (m) * 16 + (tc): return launch_tile<m, tc, true>(ctx, st, a, ntiles);
-      KG_NTT_SHAPES(X)
-      X(1, 0) X(2, 0) X(3, 0) X(4, 0) X(5, 0) X(6, 0) X(7, 0) X(8, 0) X(9, 0) X(10, 0) X(11, 0)
+      KG_NTT_SHAPES(X) KG_NTT_SHAPES_ROW_ONLY(X)
 #undef X
     }
   }

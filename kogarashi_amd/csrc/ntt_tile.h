@@ -414,9 +414,29 @@ KG_HD F ntt_pow(F base, uint64_t e) {
 //   step C (row)     n3-point DFTs over j3 along contiguous rows, written transposed, scratch -> data
 // Two steps (n2 = 1) up to 2^22: two HBM round trips, factors up to 2^11 (a 4096-element tile is 144 KiB of LDS).
 struct NttStepDesc { int log_m, log_tc; bool row; };
+// The tile shapes (LOG_M, LOG_TC) that exist as kernels: every shape the automatic plans use, the three-step plans' and the
+// 2048-element tiles of 2^10- / 2^11-point factors; row steps also run the single-step transforms (LOG_TC = 0).
+#define KG_NTT_SHAPES(X) X(6, 4) X(7, 3) X(7, 4) X(8, 2) X(8, 3) X(9, 1) X(9, 2) X(10, 1) X(11, 1)
+#define KG_NTT_SHAPES_COL_ONLY(X) X(10, 0) X(11, 0)
+#define KG_NTT_SHAPES_ROW_ONLY(X) X(1, 0) X(2, 0) X(3, 0) X(4, 0) X(5, 0) X(6, 0) X(7, 0) X(8, 0) X(9, 0) X(10, 0) X(11, 0)
+inline bool ntt_shape_exists(int log_m, int log_tc, bool row) {
+#define X(m, tc) if (log_m == (m) && log_tc == (tc)) return true;
+  KG_NTT_SHAPES(X)
+  if (row) { KG_NTT_SHAPES_ROW_ONLY(X) } else { KG_NTT_SHAPES_COL_ONLY(X) }
+#undef X
+  return false;
+}
 inline int ntt_tile_log(int log_m, int want, bool forced = false) {   // tile = 2^(log_m + log_tc) elements: 1024, 2048 or 4096
   const int least = forced ? log_m : log_m + 1;        // automatic plans keep at least two adjacent DFTs per tile (64-byte runs)
   return want < least ? least : want;
+}
+// a forced tile size falls back to the automatic one for a factor whose shape does not exist as a kernel
+inline NttStepDesc ntt_step_desc(int log_m, int want_auto, int tile, bool row) {
+  if (tile) {
+    const int t = ntt_tile_log(log_m, tile, true);
+    if (ntt_shape_exists(log_m, t - log_m, row)) return {log_m, t - log_m, row};
+  }
+  return {log_m, ntt_tile_log(log_m, want_auto) - log_m, row};
 }
 // steps: 0 = automatic (one step up to 2^11, two up to 2^22, three above); 3 forces three steps from 2^18 up.
 // tile: 0 = automatic, else log2 of the tile size wanted (10..12)
@@ -426,16 +446,16 @@ inline int ntt_plan(uint32_t log_n, int steps, NttStepDesc out[3], int tile = 0)
   const bool three = k > 2 * NTT_MAX_LOG_M || (steps == 3 && k >= 18);
   if (!three) {
     const int k1 = (k + 1) / 2, k3 = k - k1;
-    const int want = tile ? tile : (k <= 19 ? 10 : (k <= 21 ? 11 : 12));
-    out[0] = {k1, ntt_tile_log(k1, want, tile != 0) - k1, false};
-    out[1] = {k3, ntt_tile_log(k3, want, tile != 0) - k3, true};
+    const int want = k <= 19 ? 10 : (k <= 21 ? 11 : 12);
+    out[0] = ntt_step_desc(k1, want, tile, false);
+    out[1] = ntt_step_desc(k3, want, tile, true);
     return 2;
   }
   const int k1 = (k + 2) / 3, k2 = (k - k1 + 1) / 2, k3 = k - k1 - k2;
-  const int want = tile ? tile : (k <= 20 ? 10 : 11);
-  out[0] = {k1, ntt_tile_log(k1, want, tile != 0) - k1, false};
-  out[1] = {k2, ntt_tile_log(k2, want, tile != 0) - k2, false};
-  out[2] = {k3, ntt_tile_log(k3, want, tile != 0) - k3, true};
+  const int want = k <= 20 ? 10 : 11;
+  out[0] = ntt_step_desc(k1, want, tile, false);
+  out[1] = ntt_step_desc(k2, want, tile, false);
+  out[2] = ntt_step_desc(k3, want, tile, true);
   return 3;
 }
 }  // namespace kg

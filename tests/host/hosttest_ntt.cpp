@@ -93,11 +93,13 @@ static void run_tiles(const NttStepArgs& A, uint32_t ntiles) {
 }
 
 #ifdef KG_NTT_HOST_FEW      // sanitizer build (tests/test_sanitizers.py): a few shapes keep the compile short
-#define KG_NTT_SHAPES(X) X(6, 4) X(7, 3)
-#define KG_NTT_SINGLES(X) X(5, 0) X(11, 0)
-#else
-#define KG_NTT_SHAPES(X) X(6, 4) X(7, 3) X(7, 4) X(8, 2) X(8, 3) X(9, 1) X(9, 2) X(10, 1) X(11, 1)
-#define KG_NTT_SINGLES(X) X(1, 0) X(2, 0) X(3, 0) X(4, 0) X(5, 0) X(6, 0) X(7, 0) X(8, 0) X(9, 0) X(10, 0) X(11, 0)
+#define HT_SHAPES(X) X(6, 4) X(7, 3)
+#define HT_COL_ONLY(X)
+#define HT_ROW_ONLY(X) X(5, 0) X(11, 0)
+#else                       // every shape that exists as a kernel (ntt_tile.h)
+#define HT_SHAPES(X) KG_NTT_SHAPES(X)
+#define HT_COL_ONLY(X) KG_NTT_SHAPES_COL_ONLY(X)
+#define HT_ROW_ONLY(X) KG_NTT_SHAPES_ROW_ONLY(X)
 #endif
 template <class F>
 static int run_step(const NttStepDesc& d, const NttStepArgs& a, uint32_t ntiles) {
@@ -105,13 +107,13 @@ static int run_step(const NttStepDesc& d, const NttStepArgs& a, uint32_t ntiles)
   if (!d.row) {
     switch (key) {
 #define X(m, tc) case (m) * 16 + (tc): run_tiles<F, m, tc, false>(a, ntiles); return 0;
-      KG_NTT_SHAPES(X)
+      HT_SHAPES(X) HT_COL_ONLY(X)
 #undef X
     }
   } else {
     switch (key) {
 #define X(m, tc) case (m) * 16 + (tc): run_tiles<F, m, tc, true>(a, ntiles); return 0;
-      KG_NTT_SHAPES(X) KG_NTT_SINGLES(X)
+      HT_SHAPES(X) HT_ROW_ONLY(X)
 #undef X
     }
   }
@@ -123,10 +125,10 @@ static void st_tw(std::vector<uint32_t>& tab, size_t e, const Fr& a) { for (int 
 extern "C" {
 // data: n = 2^log_n elements in the ABI form, transformed in place like kg_ntt_bn254_fr.  steps: 0 automatic, 3 forces
 // three steps (ntt_plan).  checked: run with FrC.  Returns 0, or -1 for a shape the dispatch does not know.
-int ht_ntt(int checked, uint32_t log_n, int steps, int inverse, int coset, uint64_t* data, long* lds_cycles, long* lds_ideal) {
+int ht_ntt_tile(int checked, uint32_t log_n, int steps, int tile, int inverse, int coset, uint64_t* data, long* lds_cycles, long* lds_ideal) {
   const size_t n = (size_t)1 << log_n;
   NttStepDesc d[3];
-  const int nsteps = ntt_plan(log_n, steps, d);
+  const int nsteps = ntt_plan(log_n, steps, d, tile);
   // tables: the formulas of k_build_table / k_build_direct / (ntt.hip)
   const uint32_t lo_bits = (log_n + 1) / 2, n_lo = 1u << lo_bits, n_hi = 1u << (log_n - lo_bits);
   std::vector<uint32_t> small(18u << (NTT_TW_LOG - 1)), lo(9u * n_lo), hi(9u * n_hi), cos_lo(9u * n_lo), cos_hi(9u * n_hi), d0, d1;
@@ -181,9 +183,12 @@ int ht_ntt(int checked, uint32_t log_n, int steps, int inverse, int coset, uint6
   if (lds_ideal) *lds_ideal = g_lds_ideal;
   return 0;
 }
-int ht_ntt_plan(uint32_t log_n, int steps, int* out9) {
+int ht_ntt(int checked, uint32_t log_n, int steps, int inverse, int coset, uint64_t* data, long* lds_cycles, long* lds_ideal) {
+  return ht_ntt_tile(checked, log_n, steps, 0, inverse, coset, data, lds_cycles, lds_ideal);
+}
+int ht_ntt_plan(uint32_t log_n, int steps, int tile, int* out9) {
   NttStepDesc d[3];
-  const int c = ntt_plan(log_n, steps, d);
+  const int c = ntt_plan(log_n, steps, d, tile);
   for (int i = 0; i < c; ++i) { out9[3 * i] = d[i].log_m; out9[3 * i + 1] = d[i].log_tc; out9[3 * i + 2] = d[i].row; }
   return c;
 }

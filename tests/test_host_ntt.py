@@ -66,15 +66,29 @@ def test_big_tiles(nttlib, oracle, k, steps):
 
 
 def test_plans_use_only_instantiated_shapes(nttlib):
-    """every (DFT size, tile width) ntt_plan can ask for, 2^1..2^28 in both modes, is in the kernel's dispatch table"""
-    src = open(os.path.join(ROOT, "kogarashi_amd", "csrc", "ntt.hip")).read()
+    """every (DFT size, tile width) ntt_plan can ask for -- 2^1..2^28, automatic and three-step plans, every forced tile size
+    (a forced size falls back to the automatic one where the shape does not exist) -- is a shape the kernel dispatch knows"""
     import re
-    shapes = set(re.findall(r"X\((\d+), (\d+)\)", src))
+    hdr = open(os.path.join(ROOT, "kogarashi_amd", "csrc", "ntt_tile.h")).read()
+    both = set(re.findall(r"X\((\d+), (\d+)\)", re.search(r"#define KG_NTT_SHAPES\(X\)(.*)", hdr).group(1)))
+    col = both | set(re.findall(r"X\((\d+), (\d+)\)", re.search(r"#define KG_NTT_SHAPES_COL_ONLY\(X\)(.*)", hdr).group(1)))
+    row = both | set(re.findall(r"X\((\d+), (\d+)\)", re.search(r"#define KG_NTT_SHAPES_ROW_ONLY\(X\)(.*)", hdr).group(1)))
     out = (C.c_int * 9)()
     for steps in (0, 3):
-        for k in range(1, 29):
-            c = nttlib.ht_ntt_plan(k, steps, out)
-            assert 1 <= c <= 3 and sum(out[3 * i] for i in range(c)) == k
-            for i in range(c):
-                assert (str(out[3 * i]), str(out[3 * i + 1])) in shapes, (k, steps, out[3 * i], out[3 * i + 1])
-                assert bool(out[3 * i + 2]) == (i == c - 1)
+        for tile in (0, 10, 11, 12):
+            for k in range(1, 29):
+                c = nttlib.ht_ntt_plan(k, steps, tile, out)
+                assert 1 <= c <= 3 and sum(out[3 * i] for i in range(c)) == k
+                for i in range(c):
+                    shape = (str(out[3 * i]), str(out[3 * i + 1]))
+                    assert shape in (row if out[3 * i + 2] else col), (k, steps, tile, shape)
+                    assert bool(out[3 * i + 2]) == (i == c - 1)
+
+
+@pytest.mark.parametrize("k,steps,tile", [(13, 0, 11), (16, 0, 11), (18, 3, 11), (20, 0, 10), (21, 0, 11)])
+def test_forced_tile_sizes(nttlib, oracle, k, steps, tile):
+    """KG_NTT_TILE plans: the 2048-element tiles of small factors, single-column tiles of 2^10- and 2^11-point factors"""
+    v = oracle.gen_scalars(0, SEED + 50 + k, 0, 1 << k)
+    d = np.ascontiguousarray(v.copy())
+    assert nttlib.ht_ntt_tile(1 if k <= 18 else 0, k, steps, tile, 0, 1, d.ctypes.data_as(C.c_void_p), None, None) == 0
+    assert (d == oracle.Fft(k).coset_dft(v, threads=8)).all()
