@@ -29,10 +29,10 @@ struct kg_tw_cache {
   uint32_t* cos_lo = nullptr;  // g^(+-e) (g = 7), e < 2^lo_bits, for the coset shift [* n^-1 when inverse]
   uint32_t* cos_hi = nullptr;  // g^(+-(e << lo_bits))
   uint32_t* zinv = nullptr;    // (7^n - 1)^-1, one entry (fft.rs:141-154)
-  // inter-step twiddles read instead of generated: direct[s][r * inner + c] = w_n^(r * c * mult) for step s (0: A, 1: B).
-  // Step B's table is n2 * n3 <= 2^16 entries; step A's is n entries and is kept only while it stays cache-resident
-  // is worth its memory (log_n <= direct_a_max_log() = 22: 36 MB at 2^20, 151 MB at 2^22).  Saves the running-product update (one of the
-  // two products per element): 2^18 59 -> 52 us, 2^20 164 -> 145 us, 2^22 557 -> 548 us.
+  // inter-step twiddles read instead of composed: direct[s][r * inner + c] = w_n^(r * c * mult) for step s (0: A, 1: B),
+  // Montgomery form, 36 B per entry.  Step A's table has n entries and exists up to direct_a_max_log() (36 MB at 2^20,
+  // 151 MB at 2^22, per direction); step B's (three-step plans) has n2 * n3 <= 2^18 entries.  Without a table the step
+  // composes the twiddle from lo / hi: one more product per element.
   uint32_t* direct[2] = {nullptr, nullptr};
 };
 
