@@ -152,3 +152,23 @@ def test_every_plan_knob_gives_the_same_transform(env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _PLAN_SCRIPT % root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (env, r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("k", [11, 12, 17, 20])
+def test_extreme_values(ctx, oracle, k):
+    """inputs that push the lazy sums hardest: every element p - 1, alternating 0 / p - 1, a single non-zero element --
+    one-step, 1024-, and 2048-element-tile plans, all four transforms"""
+    import kogarashi_amd as K
+    O = oracle
+    n = 1 << k
+    c = O.f_consts(0)
+    pm1 = c["p"].copy()
+    pm1[0] -= 1
+    top = O.f_to_mont(0, pm1)                              # p - 1 in the ABI's Montgomery form
+    fo, fg = O.Fft(k), K.Fft(k, ctx=ctx)
+    cases = [np.tile(top, (n, 1)), np.zeros((n, 4), dtype=np.uint64), np.zeros((n, 4), dtype=np.uint64)]
+    cases[1][0::2] = top
+    cases[2][n - 1] = top
+    for v in cases:
+        for name in ("dft", "idft", "coset_dft", "coset_idft"):
+            assert (getattr(fg, name)(v) == getattr(fo, name)(v, threads=8)).all(), (k, name)
