@@ -11,6 +11,7 @@
 // Same interface as Fp2<F> as far as curve.h uses it, so XYZZ<Fp2S<F>> and the point formulas are the same templates.
 #pragma once
 #include "fp29.h"
+#include "curve.h"
 
 namespace kg {
 
@@ -80,6 +81,13 @@ __device__ __forceinline__ bool is_zero(const Fp2S<F>& a) {
   const int z = is_zero(a.v) ? 1 : 0;
   const int o = __shfl_xor(z, 1);
   return (z & o) != 0;
+}
+
+// P + (+-a) for the bucket kernel: like Fq2 in one lane, the point is negated first (curve.h: the folded form's R reaches
+// K = 12, which the Fq2 square's inner subtraction does not admit)
+template <class G>
+__device__ __forceinline__ XYZZ<Fp2S<G>> add_mixed_signed(const XYZZ<Fp2S<G>>& p, const Affine<Fp2S<G>>& a, bool negate) {
+  return add_mixed(p, negate ? neg_affine(a) : a);
 }
 
 // lanes that cooperate on one task

@@ -206,6 +206,38 @@ template <class F> struct RawIO<Fp2S<F>> {
 }  // namespace kg
 namespace {
 
+// A resident G2 point read by a lane pair (fp2s.h): the even lane takes c0 of x and y, the odd lane c1 -- the same bytes a
+// single lane reads through BaseIO<Fp2<G>>, half each.  The identity flag lives in the even lane's x and is shared by a
+// lane exchange (both lanes of the pair always execute it).
+template <class G> struct BaseIO<Fp2S<G>> {
+  static constexpr int W = 16, PE = 18, PK = 16;
+  using P = typename G::Params;
+  static __device__ __forceinline__ bool load_point64(const uint32_t* src, Fp2S<G>& x, Fp2S<G>& y) {
+    const int h = Fp2S<G>::half();
+    const uint4* p = reinterpret_cast<const uint4*>(src);
+    uint32_t w[16];
+    const uint4 a0 = p[2 * h], a1 = p[2 * h + 1], b0 = p[4 + 2 * h], b1 = p[5 + 2 * h];
+    w[0] = a0.x; w[1] = a0.y; w[2] = a0.z; w[3] = a0.w; w[4] = a1.x; w[5] = a1.y; w[6] = a1.z; w[7] = a1.w;
+    w[8] = b0.x; w[9] = b0.y; w[10] = b0.z; w[11] = b0.w; w[12] = b1.x; w[13] = b1.y; w[14] = b1.z; w[15] = b1.w;
+    int flag = (h == 0 && (w[7] & INF_BIT) != 0) ? 1 : 0;
+    flag |= __shfl_xor(flag, 1);
+    if (h == 0) w[7] &= ~INF_BIT;
+    x.v = limbs_from_words<P>(w); y.v = limbs_from_words<P>(w + 8);
+    return flag != 0;
+  }
+  static __device__ __forceinline__ bool load_point(const uint32_t* src, Fp2S<G>& x, Fp2S<G>& y) {
+    const int h = Fp2S<G>::half();
+    uint32_t wx[9], wy[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { wx[k] = src[9 * h + k]; wy[k] = src[18 + 9 * h + k]; }
+    int flag = (h == 0 && (wx[8] & INF_BIT) != 0) ? 1 : 0;
+    flag |= __shfl_xor(flag, 1);
+    if (h == 0) wx[8] &= ~INF_BIT;
+    x.v = BaseIO<G>::from_words(wx); y.v = BaseIO<G>::from_words(wy);
+    return flag != 0;
+  }
+};
+
 // bases: ABI affine (x | y) -> resident form (limbs of x | limbs of y), 2*PE words per point; identity flag -> INF_BIT
 // a resident point from its limbs: 2 * PE words (fmt64 = 0) or the 64-byte form, 2 * PK words (fmt64 = 1)
 template <class F>
@@ -1033,6 +1065,18 @@ struct AccSets {
 };
 // G2: the compiler lands on 256 VGPRs + 1 AGPR = one wave per SIMD; asking for two waves costs a few spilled registers
 // and buys the second wave (the issue rate of this code at one wave per SIMD is ~69 % of its rate at four)
+// where a task's partial sum goes: the one-lane array-of-structures layout, also when a lane pair computed it (the later
+// rounds and the gather read that layout either way)
+template <class F> struct AccStore {
+  static __device__ __forceinline__ void store(uint32_t* base, size_t i, const XYZZ<F>& p) { PointAoS<F>::store(base, i, p); }
+};
+template <class G> struct AccStore<Fp2S<G>> {
+  static __device__ __forceinline__ void store(uint32_t* base, size_t i, const XYZZ<Fp2S<G>>& p) {
+    uint32_t* dst = base + i * 72 + 9 * Fp2S<G>::half();          // PointAoS<Fp2<G>>: x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { dst[k] = p.x.v.l[k]; dst[18 + k] = p.y.v.l[k]; dst[36 + k] = p.zz.v.l[k]; dst[54 + k] = p.zzz.v.l[k]; }
+  }
+};
 template <class F> struct AccWaves { static constexpr int MIN = 1; };
 template <class G> struct AccWaves<Fp2<G>> { static constexpr int MIN = 2; };
 template <class F>
@@ -1071,7 +1115,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
       continue;                                          // identity base (msm.rs:58-64 adds it as a no-op)
     acc = add_mixed_signed(acc, a, (e & 0x80000000u) != 0);
   }
-  PointAoS<F>::store(partial, t, acc);
+  AccStore<F>::store(partial, t, acc);
 }
 
 // round r > 1: partial sums of the previous round (grouped by bucket through Lin) -> fewer partial sums
@@ -1641,6 +1685,11 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
   } else if (S.ready) KG_HIP(ctx, hipStreamWaitEvent(st, S.ready, 0));   // the scalar queue's sort of this set
   if (S.ntasks) {
     PhaseScope ph(ctx, "accumulate");
+    static const bool pair_acc = [] { const char* e = getenv("KG_G2_PAIR_ACC"); return e && atoi(e) != 0; }();
+    if (LPT > 1 && pair_acc)          // experiment: G2 accumulation on lane pairs, ~150 VGPRs instead of 256
+      hipLaunchKernelGGL(k_acc_tasks<KF>, dim3((unsigned)(((size_t)S.ntasks * LPT + 63) / 64) * (unsigned)njobs), dim3(64), 0, st, A, S.sorted, S.bstart, S.bsize, L0,
+                         S.task_bkt, S.task_id, S.n, W, B, S.T, part_cap, S.merged_shift);
+    else
     hipLaunchKernelGGL(k_acc_tasks<F>, dim3(((S.ntasks + 63) / 64) * (unsigned)njobs), dim3(64), 0, st, A, S.sorted, S.bstart, S.bsize, L0, S.task_bkt, S.task_id,
                        S.n, W, B, S.T, part_cap, S.merged_shift);
     ph.end();

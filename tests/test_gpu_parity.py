@@ -564,3 +564,38 @@ def test_msm_host_slices_match_device_call(ctx, oracle, cv, curve, sfd, n):
     assert (ctx.msm_host(curve, bases, inf, scal, m) == ctx.msm(curve, db.ptr, di.ptr, ds.ptr, m)).all()
     nb = 8 if curve == 2 else 4
     assert gpu_aff(want, nb) == aff(O, cv, O.msm(cv, bases, scal, inf, threads=8))
+
+
+def test_g2_accumulation_on_lane_pairs_gives_the_same_sum(oracle):
+    """KG_G2_PAIR_ACC=1 (read once per process): k_acc_tasks<Fp2S> -- a lane pair per task, c0 on the even lane, c1 on the odd
+    one, partial sums written in the one-lane layout -- against the oracle, in a child process; identity bases and zero
+    scalars included, registered and per-call bases"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import kogarashi_amd as K
+from oracle import oracle as O
+S = 0x4B6F676172617368
+ctx = K.Context(0)
+n = 70001
+dk = ctx.empty((n, 4)); ctx.gen_scalars(K.KG_FR, S + 950, 0, n, dk.ptr)
+ctx.write(dk.ptr + 32 * 5, np.zeros((1, 4), dtype=np.uint64))
+dxy, dinf = ctx.empty((n, 16)), ctx.empty((n,), dtype=np.uint8)
+ctx.fixed_base_mul(K.KG_G2, dk.ptr, n, dxy.ptr, dinf.ptr)
+ds = ctx.empty((n, 4)); ctx.gen_scalars(K.KG_FR, S + 951, 0, n, ds.ptr)
+ctx.write(ds.ptr + 32 * 9, np.zeros((1, 4), dtype=np.uint64))
+want = O.to_affine("g2", O.msm("g2", dxy.numpy(), ds.numpy(), dinf.numpy(), threads=8))
+got = ctx.msm(K.KG_G2, dxy.ptr, dinf.ptr, ds.ptr, n)
+assert not want[1] and (got[:16] == want[0]).all()
+ctx.bases_register(K.KG_G2, dxy.ptr, dinf.ptr, n)
+got = ctx.msm(K.KG_G2, dxy.ptr, dinf.ptr, ds.ptr, n)
+assert (got[:16] == want[0]).all()
+print("ok")
+""" % root
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, KG_G2_PAIR_ACC="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
