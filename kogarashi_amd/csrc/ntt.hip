@@ -106,8 +106,12 @@ __global__ void __launch_bounds__((NttTile<Fr, LOG_M, LOG_TC, ROW>::NT)) __attri
   const LdsPlanes<T::ELEMS> st{lds};
   t.first(threadIdx.x, st);
   if constexpr (!T::SINGLE) {
-    __syncthreads();
-    t.template mids<T::G0>(threadIdx.x, st, [] { __syncthreads(); });
+    const auto full = [] { __syncthreads(); };
+    // between two wave-private passes: the wave's own LDS writes are ordered before its reads by the in-order LDS queue; the
+    // fence keeps the compiler from moving them across the boundary
+    const auto wave = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    t.after_first(full, wave);
+    t.template mids<T::G0>(threadIdx.x, st, full, wave);
     t.last(threadIdx.x, st);
   }
 }

@@ -107,6 +107,73 @@ KG_HD uint32_t scatter_bits(uint32_t t) {
 template <int B, int F0, int FW> struct MidMapFn { static constexpr BitMap get() { return mid_map<B, F0, FW>(); } };
 template <int B, int LOG_TC, int RL> struct FirstColMapFn { static constexpr BitMap get() { return first_col_map<B, LOG_TC, RL>(); } };
 
+// ---- wave-private passes ------------------------------------------------------------------------------------
+// A wave (64 lanes x 4 elements) owns the 256 tile elements whose idx shares its high bits ("block" = idx >> 8 = wave id).
+// A register pass whose field lies inside the low eight idx bits touches only the wave's own block, and so does the first
+// pass of a column step when the wave takes the rows that land in its block: between two such passes no workgroup barrier is
+// needed (one wave's LDS operations execute in order), only where a pass exchanges data between blocks.  That removes 3 of
+// the 5 barriers of a 2^11-point tile and 3 of the 4 of a 2^9-point one, and lets the waves of a workgroup drift apart.
+// pick the lane bits (thread bits 0..5) among `cand` idx bits so that the first five fall into different residue classes
+// mod 5 where possible (bank rule above); thread bits 6.. are the block
+constexpr void lanes_by_residue(BitMap& m, int& j, const bool (&cand)[16]) {
+  bool taken[16] = {};
+  bool res[5] = {};
+  for (int round = 0; round < 2; ++round)
+    for (int b = 0; b < 16; ++b) {
+      if (!cand[b] || taken[b]) continue;
+      if (round == 0 && (res[b % 5] || j >= 5)) continue;
+      m.map[j++] = b;
+      taken[b] = true;
+      res[b % 5] = true;
+    }
+}
+template <int B, int F0>
+constexpr BitMap mid_private_map() {                  // field [F0, F0 + 2) inside idx bits [0, 8)
+  BitMap m{B - 2, {}};
+  bool cand[16] = {};
+  for (int b = 0; b < 8; ++b) cand[b] = !(b >= F0 && b < F0 + 2);
+  int j = 0;
+  lanes_by_residue(m, j, cand);
+  for (int b = 8; b < B; ++b) m.map[j++] = b;          // wave id = block
+  return m;
+}
+// first pass of a column step, wave-private: thread bits -> source bits s = (r_low << LOG_TC) | col.  The block a row lands
+// in is brev(low NB bits of r_low) (bit-reversed placement), so the wave id supplies those bits reversed; the lanes (and the
+// iteration bit of a radix-2 first pass) supply the columns and the remaining r_low bits, ordered by the residues of the idx
+// bits they end up on (r_low bit NB + i -> idx bit 7 - i).
+template <int B, int LOG_TC, int RL, int G0>
+constexpr BitMap first_col_private_map() {
+  constexpr int NB = B - 8;
+  BitMap m{LOG_TC + RL, {}};
+  int j = 0;
+  // lanes: destination idx bits available = col bits (idx 0..LOG_TC-1) and idx bits 7 - i for r_low bit NB + i; the field bits
+  // [LOG_TC, LOG_TC + G0) are the register index
+  bool cand[16] = {};
+  for (int b = 0; b < LOG_TC; ++b) cand[b] = true;
+  for (int i = 0; i < RL - NB; ++i) cand[7 - i] = true;
+  BitMap dst{0, {}};
+  int jd = 0;
+  lanes_by_residue(dst, jd, cand);
+  // the columns must stay the fastest lane bits (global runs): put them first, then the rest in residue order
+  for (int b = 0; b < LOG_TC; ++b) m.map[j++] = b;
+  for (int t = 0; t < jd; ++t) {
+    const int d = dst.map[t];
+    if (d < LOG_TC) continue;
+    if (j == 6) break;                                 // six lane bits
+    m.map[j++] = LOG_TC + NB + (7 - d);
+  }
+  // wave bits 6..6+NB-1: r_low bit NB - 1 - i for wave bit i
+  for (int i = 0; i < NB; ++i) m.map[j++] = LOG_TC + (NB - 1 - i);
+  // what is left (the iteration bit of a radix-2 first pass): the remaining r_low bits
+  bool used[16] = {};
+  for (int t = 0; t < j; ++t) used[m.map[t]] = true;
+  for (int b = 0; b < LOG_TC + RL; ++b)
+    if (!used[b]) m.map[j++] = b;
+  return m;
+}
+template <int B, int F0> struct MidPrivateMapFn { static constexpr BitMap get() { return mid_private_map<B, F0>(); } };
+template <int B, int LOG_TC, int RL, int G0> struct FirstColPrivateMapFn { static constexpr BitMap get() { return first_col_private_map<B, LOG_TC, RL, G0>(); } };
+
 template <int BITS>
 KG_HD uint32_t brev_bits(uint32_t v) {
   if constexpr (BITS == 0) return 0u;
@@ -228,6 +295,14 @@ struct NttTile {
   static constexpr bool SINGLE = LOG_M <= 2;                // one pass: load -> butterflies -> store, no LDS
   static constexpr int S_LAST = LOG_M - 2;                  // first stage index of the last pass (fused with the store)
   static constexpr int M = 1 << LOG_M, TC = 1 << LOG_TC;
+  // wave-private passes (see above): tiles of at least four waves, lanes and blocks as thread bits 0..5 / 6..
+#ifdef KG_NTT_NO_WAVE_PRIVATE
+  static constexpr bool WAVE_OK = false;
+#else
+  static constexpr bool WAVE_OK = B >= 10 && NT == ELEMS / 4;
+#endif
+  static constexpr bool FIRST_PRIVATE = WAVE_OK && !ROW;       // a row step loads contiguous rows: its first pass scatters over the blocks
+  template <int S0> static constexpr bool mid_private() { return WAVE_OK && LOG_TC + S0 + 2 <= 8; }
 
   const NttStepArgs& A;
   uint32_t tile;
@@ -309,6 +384,10 @@ struct NttTile {
       if constexpr (ROW) {
         r_low = q & ((1u << RL) - 1u);
         col = q >> RL;
+      } else if constexpr (FIRST_PRIVATE) {
+        const uint32_t s = scatter_bits<FirstColPrivateMapFn<B, LOG_TC, RL, G0>, 0>(q);
+        col = s & (TC - 1u);
+        r_low = s >> LOG_TC;
       } else {
         const uint32_t s = scatter_bits<FirstColMapFn<B, LOG_TC, RL>, 0>(q);
         col = s & (TC - 1u);
@@ -341,7 +420,9 @@ struct NttTile {
   KG_HD void mid(uint32_t tid, const Store& st) const {
     constexpr int F0 = LOG_TC + S0;
     if (ELEMS / 4 < NT && tid >= (uint32_t)(ELEMS / 4)) return;
-    const uint32_t others = scatter_bits<MidMapFn<B, F0, 2>, 0>(tid);
+    uint32_t others;
+    if constexpr (mid_private<S0>()) others = scatter_bits<MidPrivateMapFn<B, F0>, 0>(tid);
+    else others = scatter_bits<MidMapFn<B, F0, 2>, 0>(tid);
     const uint32_t r_low = (others >> LOG_TC) & ((1u << S0) - 1u);
     const uint32_t w0 = tile_phys<B>(others);
     F x[4];
@@ -372,13 +453,20 @@ struct NttTile {
     for (int k = 0; k < 4; ++k) store_elem(x[k], p_low + ((uint32_t)k << S_LAST), col);
   }
 
-  // the passes between first() and last(), in order; sync() separates them
-  template <int S0, class Store, class Sync>
-  KG_HD void mids(uint32_t tid, const Store& st, const Sync& sync) const {
+  // the passes between first() and last(), in order.  full(): workgroup barrier; wave(): only this wave's LDS operations need
+  // ordering (both neighbours of the boundary are wave-private passes)
+  template <class Full, class Wave>
+  KG_HD void after_first(const Full& full, const Wave& wave) const {
+    if constexpr (G0 < S_LAST && FIRST_PRIVATE && mid_private<G0>()) wave();
+    else full();
+  }
+  template <int S0, class Store, class Full, class Wave>
+  KG_HD void mids(uint32_t tid, const Store& st, const Full& full, const Wave& wave) const {
     if constexpr (S0 < S_LAST) {
       mid<S0>(tid, st);
-      sync();
-      mids<S0 + 2>(tid, st, sync);
+      if constexpr (S0 + 2 < S_LAST && mid_private<S0>() && mid_private<S0 + 2>()) wave();
+      else full();
+      mids<S0 + 2>(tid, st, full, wave);
     }
   }
 };

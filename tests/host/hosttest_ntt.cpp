@@ -3,6 +3,7 @@
 // table formulas the device uses) are compared with the oracle by tests/test_host_ntt.py, and FrC proves that no column,
 // limb or value bound of fp29.h can overflow in any pass.  Also counts LDS bank conflicts of every pass.  Test
 // infrastructure only.
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <vector>
@@ -26,12 +27,17 @@ using namespace kg;
 
 // tile store of the emulation: one F per LDS word, plus the bank-conflict bookkeeping of the current wave instruction
 static long g_lds_cycles = 0, g_lds_ideal = 0;
+static long g_private_passes = 0, g_barriers = 0;
 template <class F>
 struct HostStore {
   F* arr;
   mutable std::vector<uint32_t>* trace;     // LDS words touched by the current thread, in program order
-  void store(uint32_t w, const F& a) const { arr[w] = a; trace->push_back(w); }
-  template <class G> G load(uint32_t w) const { trace->push_back(w); return arr[w]; }
+  int block;                                // >= 0: this pass is wave-private -- every access must stay in the wave's block (word >> 8 = wave id)
+  void check(uint32_t w) const {
+    if (block >= 0 && (int)(w >> 8) != block) { std::fprintf(stderr, "wave-private pass touches LDS word %u outside block %d\n", w, block); std::abort(); }
+  }
+  void store(uint32_t w, const F& a) const { check(w); arr[w] = a; trace->push_back(w); }
+  template <class G> G load(uint32_t w) const { check(w); trace->push_back(w); return arr[w]; }
 };
 // accesses[t] = words thread t touched in one pass (same count for every active thread): instruction i of a wave is the
 // i-th access of its 64 lanes; ds_read_b32 / ds_write_b32 cost per 32-lane half = max distinct words on one bank (mod 32)
@@ -69,25 +75,30 @@ static void run_tiles(const NttStepArgs& A, uint32_t ntiles) {
     if (A.tile_shift) tile = ((tile & 7u) << A.tile_shift) | (tile >> 3);
     const T t{A, tile};
     std::vector<std::vector<uint32_t>> acc(T::NT);
-    auto pass = [&](auto body) {
+    auto pass = [&](bool wave_private, auto body) {
       for (auto& a : acc) a.clear();
       for (uint32_t tid = 0; tid < (uint32_t)T::NT; ++tid) {
-        HostStore<F> st{lds.data(), &acc[tid]};
+        HostStore<F> st{lds.data(), &acc[tid], wave_private ? (int)(tid >> 6) : -1};
         body(tid, st);
       }
-      if (blk == 0) count_conflicts(acc);
+      if (blk == 0) { count_conflicts(acc); g_private_passes += wave_private; }
     };
-    pass([&](uint32_t tid, const HostStore<F>& st) { t.first(tid, st); });
+    // the kernel's synchronisation plan, replayed: a wave-private pass may only touch its wave's block; a boundary between two
+    // wave-private passes has no workgroup barrier (the emulation runs pass by pass, so what it checks is the block discipline
+    // that makes the missing barrier safe)
+    pass(T::FIRST_PRIVATE, [&](uint32_t tid, const HostStore<F>& st) { t.first(tid, st); });
     if constexpr (!T::SINGLE) {
+      t.after_first([&] { if (blk == 0) ++g_barriers; }, [] {});
       auto mids = [&](auto self, auto s0c) -> void {
         constexpr int S0 = decltype(s0c)::value;
         if constexpr (S0 < T::S_LAST) {
-          pass([&](uint32_t tid, const HostStore<F>& st) { t.template mid<S0>(tid, st); });
+          pass(T::template mid_private<S0>(), [&](uint32_t tid, const HostStore<F>& st) { t.template mid<S0>(tid, st); });
+          if constexpr (!(S0 + 2 < T::S_LAST && T::template mid_private<S0>() && T::template mid_private<S0 + 2>())) { if (blk == 0) ++g_barriers; }
           self(self, std::integral_constant<int, S0 + 2>{});
         }
       };
       mids(mids, std::integral_constant<int, T::G0>{});
-      pass([&](uint32_t tid, const HostStore<F>& st) { t.last(tid, st); });
+      pass(false, [&](uint32_t tid, const HostStore<F>& st) { t.last(tid, st); });
     }
   }
 }
@@ -173,6 +184,7 @@ int ht_ntt_tile(int checked, uint32_t log_n, int steps, int tile, int inverse, i
                        d1.empty() ? nullptr : d1.data(), lo_bits};
   std::vector<uint64_t> tmp(4 * n);
   g_lds_cycles = g_lds_ideal = 0;
+  g_private_passes = g_barriers = 0;
   for (int i = 0; i < nsteps; ++i) {
     NttStepArgs a;
     const uint32_t ntiles = ntt_step_args(log_n, nsteps, d, i, tabs, data, tmp.data(), inverse, coset, a);
@@ -186,6 +198,8 @@ int ht_ntt_tile(int checked, uint32_t log_n, int steps, int tile, int inverse, i
 int ht_ntt(int checked, uint32_t log_n, int steps, int inverse, int coset, uint64_t* data, long* lds_cycles, long* lds_ideal) {
   return ht_ntt_tile(checked, log_n, steps, 0, inverse, coset, data, lds_cycles, lds_ideal);
 }
+// wave-private passes and workgroup barriers of the first tile of every step of the last ht_ntt call
+void ht_ntt_sync_counts(long* private_passes, long* barriers) { *private_passes = g_private_passes; *barriers = g_barriers; }
 int ht_ntt_plan(uint32_t log_n, int steps, int tile, int* out9) {
   NttStepDesc d[3];
   const int c = ntt_plan(log_n, steps, d, tile);
