@@ -256,7 +256,8 @@ def main():
                           "routine_relative": {"unit": "G point additions/s", "achieved": adds / (iso_ms * 1e-3) / 1e9, "peak": MADD_PEAK_G,
                                                "frac": adds / (iso_ms * 1e-3) / 1e9 / MADD_PEAK_G},
                           "note": "isolated launches; the remaining ~30 % of issue slots go to the shifts / masks / carries of the 29-bit limbs, "
-                                  "the lazy-reduction bookkeeping and the gathers"},
+                                  "the lazy-reduction bookkeeping and the gathers; rocprofv3 SQ counters (profiles/r03_msm_sq_counters.json): VALU issue "
+                                  "busy 89 % of the SIMD cycles of a launch"},
         "phases_ms_per_step": phase_avg, "pipelining": f"{depth} MSM steps in flight (kg_msm_begin / kg_msm_end), inputs declared complete",
     }
 
