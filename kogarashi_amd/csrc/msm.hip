@@ -653,6 +653,7 @@ __global__ void __launch_bounds__(512) k_fine_count(const uint32_t* __restrict__
   __syncthreads();
   SegRange r;
   if (!seg_locate(sb, G, s, gstart, gsize, w, r)) return;
+  if (gsize[(size_t)w * G + r.g] <= (uint32_t)SEG) return;       // a group that is one segment is sorted by k_fine_local
   const uint32_t* src = tmp + (size_t)w * n;
   for (uint32_t i = r.lo + threadIdx.x; i < r.hi; i += blockDim.x) atomicAdd(&hist[(src[i] >> 24) & (FINE - 1)], 1u);
   __syncthreads();
@@ -662,6 +663,61 @@ __global__ void __launch_bounds__(512) k_fine_count(const uint32_t* __restrict__
     segcnt[o] = cnt;
     segoff[o] = cnt ? atomicAdd(&bsize[(size_t)w * B + (size_t)r.g * FINE + threadIdx.x], cnt) : 0u;
   }
+}
+
+// Second pass, segment-local form: a bucket group that fits ONE segment (<= SEG entries -- every group of a uniform input:
+// 4096 entries at 2^20, c = 16) is histogrammed, ordered and written by a single workgroup in a single read of the
+// intermediate.  The group's run in `sorted` is contiguous and its buckets follow each other inside it, so bucket starts need no
+// global prefix: bstart = gstart + the local exclusive prefix (what k_bucket_rows computes from the sizes written here), no
+// atomics on the bucket sizes, and the copy out is one coalesced stream.  Groups of several segments (skewed witnesses, every
+// group of a merged sort) keep the two-kernel path (k_fine_count reserves, k_fine_scatter places).
+__global__ void __launch_bounds__(512) k_fine_local(const uint32_t* __restrict__ tmp, size_t n, int G, int B, const uint32_t* __restrict__ gstart,
+                                                    const uint32_t* __restrict__ gsize, const uint32_t* __restrict__ segbase,
+                                                    uint32_t* __restrict__ bsize, uint32_t* __restrict__ sorted) {
+  KG_SERVICE_PRIO();
+  __shared__ uint32_t sb[1025];
+  __shared__ uint32_t hist[FINE], cursor[FINE], wsum;
+  __shared__ uint32_t stage[SEG];
+  const int w = blockIdx.x;
+  const uint32_t s = blockIdx.y;
+  for (int g = threadIdx.x; g <= G; g += blockDim.x) sb[g] = segbase[(size_t)w * (G + 1) + g];
+  if (threadIdx.x < FINE) hist[threadIdx.x] = 0;
+  __syncthreads();
+  SegRange r;
+  if (!seg_locate(sb, G, s, gstart, gsize, w, r)) return;
+  if (gsize[(size_t)w * G + r.g] > (uint32_t)SEG) return;        // several segments: the two-kernel path
+  const uint32_t* src = tmp + (size_t)w * n;
+  constexpr int PER = SEG / 512;                                 // entries a lane keeps in registers between the two phases
+  uint32_t rec[PER];
+  const uint32_t len = r.hi - r.lo;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const uint32_t i = threadIdx.x + (uint32_t)k * 512u;
+    rec[k] = i < len ? src[r.lo + i] : 0u;
+    if (i < len) atomicAdd(&hist[(rec[k] >> 24) & (FINE - 1)], 1u);
+  }
+  __syncthreads();
+  uint32_t cnt = 0, inc = 0;
+  if (threadIdx.x < FINE) {                                      // exclusive prefix of the FINE counters (two waves), sizes out
+    cnt = hist[threadIdx.x];
+    bsize[(size_t)w * B + (size_t)r.g * FINE + threadIdx.x] = cnt;
+    inc = cnt;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o2 = __shfl_up(inc, d); if (lane >= d) inc += o2; }
+    if (threadIdx.x == 63) wsum = inc;
+  }
+  __syncthreads();
+  if (threadIdx.x < FINE) cursor[threadIdx.x] = inc - cnt + (threadIdx.x >= 64 ? wsum : 0u);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const uint32_t i = threadIdx.x + (uint32_t)k * 512u;
+    if (i < len) stage[atomicAdd(&cursor[(rec[k] >> 24) & (FINE - 1)], 1u)] = rec[k] & 0x80ffffffu;
+  }
+  __syncthreads();
+  uint32_t* dst = sorted + (size_t)w * n + r.lo;                 // r.lo = the group's start: its only segment
+  for (uint32_t p = threadIdx.x; p < len; p += blockDim.x) dst[p] = stage[p];
 }
 
 __global__ void __launch_bounds__(512) k_fine_scatter(const uint32_t* __restrict__ tmp, size_t n, int G, int B, int maxseg,
@@ -679,6 +735,7 @@ __global__ void __launch_bounds__(512) k_fine_scatter(const uint32_t* __restrict
   __syncthreads();
   SegRange r;
   if (!seg_locate(sb, G, s, gstart, gsize, w, r)) return;
+  if (gsize[(size_t)w * G + r.g] <= (uint32_t)SEG) return;       // done by k_fine_local
   uint32_t cnt = 0, inc = 0;
   if (threadIdx.x < FINE) {                          // exclusive prefix of the segment's FINE counters (two waves)
     const size_t o = ((size_t)w * maxseg + s) * FINE + threadIdx.x;
@@ -1544,6 +1601,7 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
         hipLaunchKernelGGL(k_merge_groups, dim3(1), dim3(GS_NT), 0, st, gsize, W, G, woff, (uint32_t*)(ws + o_gsize_m), (uint32_t*)(ws + o_gstart_m),
                            (uint32_t*)(ws + o_segbase_m));
       hipLaunchKernelGGL(k_group_scatter, dim3(W, nch), dim3(GS_NT), 0, st, kt, n, c, W, chunk_len, G, cnt, f_gstart, tmp, woff, mshift);
+      hipLaunchKernelGGL(k_fine_local, dim3(Wb, maxseg), dim3(512), 0, st, tmp, n, G, B, f_gstart, f_gsize, f_segbase, S->bsize, S->sorted);
       hipLaunchKernelGGL(k_fine_count, dim3(Wb, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bsize, segcnt, segoff);
     } else {
       hipLaunchKernelGGL(k_count, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, 0, cnt);
