@@ -1,0 +1,263 @@
+// kogarashi_amd.hpp -- C++ host-side mirror of the reference's call sites for the hot path, header-only, over the C ABI of
+// kogarashi_amd.h.  The reference is compiled code (Rust) and its toolchain is absent from the build image, so this is the
+// compiled-language counterpart of rust/kogarashi-amd: the same names, argument meaning and error behaviour as
+//
+//   msm_curve_addition(bases, coeffs)                                    groth16/src/msm.rs:6-48
+//   Fft(k).dft / idft / coset_dft / coset_idft / divide_by_z_on_coset    groth16/src/fft.rs:27-154
+//   PedersenCommitment(g).commit(m)                                      nova/src/pedersen.rs:6-20
+//   Prover(params).create_proof(a, b, c, x, w, r, s)                     groth16/src/prover.rs:14-99
+//
+// with the reference's in-memory data: a field element is 4 x uint64 Montgomery limbs (Fr / Fq), an affine point x | y plus an
+// identity flag.  Nothing here computes: every call goes to libkogarashi_amd.so; without the library or a device the
+// constructors throw (there is no CPU path).  tests/host/abi_cpp_test.cpp drives it against the oracle on the GPU box.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "kogarashi_amd.h"
+
+namespace kogarashi {
+
+using Fe = std::array<uint64_t, 4>;        // Fr or Fq, Montgomery form (bn254/src/fr.rs:71, fq.rs:48)
+
+struct Error : std::runtime_error {
+  int status;
+  Error(int st, const std::string& what) : std::runtime_error(what + ": " + kg_strerror(st)), status(st) {}
+};
+// groth16::Error::ProverSubVersionCrsAttack (groth16/src/error.rs:2-8, prover.rs:67-69)
+struct ProverSubVersionCrsAttack : Error {
+  ProverSubVersionCrsAttack() : Error(KG_ERR_CRS, "create_proof") {}
+};
+
+// affine points as the reference holds them (bn254/src/g1.rs:18-22, g2.rs:16-20): coordinates + is_infinity
+struct G1Affine { Fe x, y; bool is_infinity = false; };
+struct G2Affine { Fe x0, x1, y0, y1; bool is_infinity = false; };
+// msm_curve_addition's result: the projective sum normalised to z = 1, or (0, 1, 0)
+struct G1Projective { Fe x, y, z; };
+
+class Context {
+ public:
+  explicit Context(int device = 0) {
+    const int rc = kg_ctx_create(device, &ctx_);
+    if (rc != KG_OK) throw Error(rc, "kg_ctx_create (libkogarashi_amd needs a visible MI355X; there is no CPU path)");
+  }
+  ~Context() { if (ctx_) kg_ctx_destroy(ctx_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  kg_ctx* raw() const { return ctx_; }
+  void check(int rc, const char* what) const {
+    if (rc == KG_ERR_CRS) throw ProverSubVersionCrsAttack();
+    if (rc != KG_OK) throw Error(rc, std::string(what) + " [" + kg_last_error(ctx_) + "]");
+  }
+
+ private:
+  kg_ctx* ctx_ = nullptr;
+};
+
+// device allocation owned by a context
+class DeviceBuffer {
+ public:
+  DeviceBuffer(const Context& c, size_t bytes) : c_(c), bytes_(bytes) { c.check(kg_malloc(c.raw(), bytes ? bytes : 1, &p_), "kg_malloc"); }
+  DeviceBuffer(const Context& c, const void* host, size_t bytes) : DeviceBuffer(c, bytes) {
+    if (bytes) c.check(kg_memcpy_h2d(c.raw(), p_, host, bytes), "kg_memcpy_h2d");
+  }
+  ~DeviceBuffer() { if (p_) kg_free(c_.raw(), p_); }
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  template <class T> T* as() const { return static_cast<T*>(p_); }
+  void download(void* host) const { if (bytes_) c_.check(kg_memcpy_d2h(c_.raw(), host, p_, bytes_), "kg_memcpy_d2h"); }
+  size_t bytes() const { return bytes_; }
+
+ private:
+  const Context& c_;
+  void* p_ = nullptr;
+  size_t bytes_;
+};
+
+namespace detail {
+inline void marshal(const std::vector<G1Affine>& pts, size_t n, std::vector<uint64_t>& xy, std::vector<uint8_t>& inf) {
+  xy.resize(8 * n); inf.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    for (int k = 0; k < 4; ++k) { xy[8 * i + k] = pts[i].x[k]; xy[8 * i + 4 + k] = pts[i].y[k]; }
+    inf[i] = pts[i].is_infinity;
+  }
+}
+inline void marshal(const std::vector<G2Affine>& pts, size_t n, std::vector<uint64_t>& xy, std::vector<uint8_t>& inf) {
+  xy.resize(16 * n); inf.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    for (int k = 0; k < 4; ++k) {
+      xy[16 * i + k] = pts[i].x0[k]; xy[16 * i + 4 + k] = pts[i].x1[k];
+      xy[16 * i + 8 + k] = pts[i].y0[k]; xy[16 * i + 12 + k] = pts[i].y1[k];
+    }
+    inf[i] = pts[i].is_infinity;
+  }
+}
+inline G1Affine g1_from(const uint64_t* w, bool inf) {
+  G1Affine p;
+  for (int k = 0; k < 4; ++k) { p.x[k] = w[k]; p.y[k] = w[4 + k]; }
+  p.is_infinity = inf;
+  return p;
+}
+inline G2Affine g2_from(const uint64_t* w, bool inf) {
+  G2Affine p;
+  for (int k = 0; k < 4; ++k) { p.x0[k] = w[k]; p.x1[k] = w[4 + k]; p.y0[k] = w[8 + k]; p.y1[k] = w[12 + k]; }
+  p.is_infinity = inf;
+  return p;
+}
+}  // namespace detail
+
+// groth16/src/msm.rs:6 msm_curve_addition(bases, coeffs): zips (min of the lengths), identity bases are no-ops.
+// curve: KG_G1 (Fr scalars) or KG_GRUMPKIN (Fq scalars); host arrays in, one point out (kg_msm_host).
+inline G1Projective msm_curve_addition(const Context& c, const std::vector<G1Affine>& bases, const std::vector<Fe>& coeffs, int curve = KG_G1) {
+  const size_t n = bases.size() < coeffs.size() ? bases.size() : coeffs.size();
+  std::vector<uint64_t> xy;
+  std::vector<uint8_t> inf;
+  detail::marshal(bases, n, xy, inf);
+  uint64_t out[12];
+  c.check(kg_msm_host(c.raw(), curve, xy.data(), inf.data(), reinterpret_cast<const uint64_t*>(coeffs.data()), n, out), "kg_msm_host");
+  G1Projective r;
+  for (int k = 0; k < 4; ++k) { r.x[k] = out[k]; r.y[k] = out[4 + k]; r.z[k] = out[8 + k]; }
+  return r;
+}
+
+// groth16/src/fft.rs:27-154 Fft<Fr>: 2^k-point transforms, natural order; shorter inputs are zero padded (prepare_fft :157-162)
+class Fft {
+ public:
+  Fft(const Context& c, uint32_t k) : c_(c), k_(k), n_((size_t)1 << k) {
+    if (k < 1 || k > 28) throw std::invalid_argument("Fft: 1 <= k <= 28 (S = 28, bn254/src/fr.rs:53)");
+  }
+  size_t size() const { return n_; }
+  std::vector<Fe> dft(const std::vector<Fe>& v) const { return run(v, 0, 0); }
+  std::vector<Fe> idft(const std::vector<Fe>& v) const { return run(v, 1, 0); }
+  std::vector<Fe> coset_dft(const std::vector<Fe>& v) const { return run(v, 0, 1); }
+  std::vector<Fe> coset_idft(const std::vector<Fe>& v) const { return run(v, 1, 1); }
+  std::vector<Fe> divide_by_z_on_coset(const std::vector<Fe>& v) const {
+    std::vector<Fe> buf = padded(v);
+    DeviceBuffer d(c_, buf.data(), n_ * 32);
+    c_.check(kg_fr_divide_by_z_on_coset(c_.raw(), d.as<uint64_t>(), k_), "kg_fr_divide_by_z_on_coset");
+    d.download(buf.data());
+    return buf;
+  }
+
+ private:
+  std::vector<Fe> padded(const std::vector<Fe>& v) const {
+    std::vector<Fe> buf(n_, Fe{0, 0, 0, 0});
+    for (size_t i = 0; i < v.size() && i < n_; ++i) buf[i] = v[i];
+    return buf;
+  }
+  std::vector<Fe> run(const std::vector<Fe>& v, int inverse, int coset) const {
+    std::vector<Fe> buf = padded(v);
+    DeviceBuffer d(c_, buf.data(), n_ * 32);
+    c_.check(kg_ntt_bn254_fr(c_.raw(), d.as<uint64_t>(), k_, inverse, coset), "kg_ntt_bn254_fr");
+    d.download(buf.data());
+    return buf;
+  }
+  const Context& c_;
+  uint32_t k_;
+  size_t n_;
+};
+
+// nova/src/pedersen.rs:6-20 PedersenCommitment<C> { g }: the generators go to the device once and stay resident in the
+// MSM's internal form (kg_bases_register); commit(m) = affine(sum_i m[i] * g[i]) over min(len) pairs.
+class PedersenCommitment {
+ public:
+  PedersenCommitment(const Context& c, const std::vector<G1Affine>& g, int curve = KG_G1) : c_(c), curve_(curve), n_(g.size()) {
+    std::vector<uint64_t> xy;
+    std::vector<uint8_t> inf;
+    detail::marshal(g, n_, xy, inf);
+    bool any = false;
+    for (uint8_t f : inf) any = any || f;
+    g_.reset(new DeviceBuffer(c, xy.data(), xy.size() * 8));
+    if (any) inf_.reset(new DeviceBuffer(c, inf.data(), inf.size()));
+    c.check(kg_bases_register(c.raw(), curve, g_->as<uint64_t>(), any ? inf_->as<uint8_t>() : nullptr, n_), "kg_bases_register");
+  }
+  ~PedersenCommitment() { kg_bases_unregister(c_.raw(), g_->as<uint64_t>()); }
+  G1Affine commit(const std::vector<Fe>& m) const {
+    const size_t n = m.size() < n_ ? m.size() : n_;
+    DeviceBuffer d(c_, m.data(), n * 32);
+    uint64_t xy[8];
+    uint8_t inf = 0;
+    c_.check(kg_commit(c_.raw(), curve_, g_->as<uint64_t>(), inf_ ? inf_->as<uint8_t>() : nullptr, d.as<uint64_t>(), n, xy, &inf), "kg_commit");
+    return detail::g1_from(xy, inf != 0);
+  }
+
+ private:
+  const Context& c_;
+  int curve_;
+  size_t n_;
+  std::unique_ptr<DeviceBuffer> g_, inf_;
+};
+
+// groth16/src/params.rs:6-28 Parameters (the prover's part) and groth16/src/proof.rs Proof { a, b, c }
+struct Parameters {
+  std::vector<G1Affine> h, l, a, b_g1;
+  std::vector<G2Affine> b_g2;
+  G1Affine alpha_g1, beta_g1, delta_g1;
+  G2Affine beta_g2, delta_g2;
+};
+struct Proof { G1Affine a; G2Affine b; G1Affine c; };
+
+// groth16/src/prover.rs:14-99 Prover { params }: the CRS is uploaded and registered once; create_proof takes the synthesised
+// constraint system's evaluations (cs.evaluate()), x = cs.x(), w = cs.w() and the blinding scalars the reference draws from its
+// rng (prover.rs:71-72).  Throws ProverSubVersionCrsAttack like prover.rs:67-69.
+class Prover {
+ public:
+  Prover(const Context& c, const Parameters& p, size_t m, size_t l, size_t m_l_1) : c_(c) {
+    crs_ = kg_groth16_crs{};
+    crs_.m = m; crs_.l = l; crs_.m_l_1 = m_l_1;
+    upload(p.h, KG_G1, crs_.d_h, crs_.d_h_inf);
+    upload(p.l, KG_G1, crs_.d_l, crs_.d_l_inf);
+    upload(p.a, KG_G1, crs_.d_a, crs_.d_a_inf);
+    upload(p.b_g1, KG_G1, crs_.d_b_g1, crs_.d_b_g1_inf);
+    upload(p.b_g2, KG_G2, crs_.d_b_g2, crs_.d_b_g2_inf);
+    for (int k = 0; k < 4; ++k) {
+      crs_.alpha_g1[k] = p.alpha_g1.x[k]; crs_.alpha_g1[4 + k] = p.alpha_g1.y[k];
+      crs_.beta_g1[k] = p.beta_g1.x[k]; crs_.beta_g1[4 + k] = p.beta_g1.y[k];
+      crs_.delta_g1[k] = p.delta_g1.x[k]; crs_.delta_g1[4 + k] = p.delta_g1.y[k];
+      crs_.beta_g2[k] = p.beta_g2.x0[k]; crs_.beta_g2[4 + k] = p.beta_g2.x1[k]; crs_.beta_g2[8 + k] = p.beta_g2.y0[k]; crs_.beta_g2[12 + k] = p.beta_g2.y1[k];
+      crs_.delta_g2[k] = p.delta_g2.x0[k]; crs_.delta_g2[4 + k] = p.delta_g2.x1[k]; crs_.delta_g2[8 + k] = p.delta_g2.y0[k]; crs_.delta_g2[12 + k] = p.delta_g2.y1[k];
+    }
+    crs_.delta_g1_inf = p.delta_g1.is_infinity;
+    crs_.delta_g2_inf = p.delta_g2.is_infinity;
+  }
+  ~Prover() {
+    for (const uint64_t* p : {crs_.d_h, crs_.d_l, crs_.d_a, crs_.d_b_g1, crs_.d_b_g2})
+      if (p) kg_bases_unregister(c_.raw(), p);
+  }
+  Proof create_proof(const std::vector<Fe>& a_eval, const std::vector<Fe>& b_eval, const std::vector<Fe>& c_eval, const std::vector<Fe>& x,
+                     const std::vector<Fe>& w, const Fe& r, const Fe& s) const {
+    DeviceBuffer da(c_, a_eval.data(), a_eval.size() * 32), db(c_, b_eval.data(), b_eval.size() * 32), dc(c_, c_eval.data(), c_eval.size() * 32);
+    DeviceBuffer dx(c_, x.data(), x.size() * 32), dw(c_, w.data(), w.size() * 32);
+    uint64_t out[32];
+    uint8_t inf[3];
+    c_.check(kg_groth16_prove_bn254(c_.raw(), &crs_, da.as<uint64_t>(), db.as<uint64_t>(), dc.as<uint64_t>(), dx.as<uint64_t>(), dw.as<uint64_t>(),
+                                    r.data(), s.data(), out, inf), "kg_groth16_prove_bn254");
+    return {detail::g1_from(out, inf[0] != 0), detail::g2_from(out + 8, inf[1] != 0), detail::g1_from(out + 24, inf[2] != 0)};
+  }
+
+ private:
+  template <class Pt>
+  void upload(const std::vector<Pt>& pts, int curve, const uint64_t*& d_xy, const uint8_t*& d_inf) {
+    std::vector<uint64_t> xy;
+    std::vector<uint8_t> inf;
+    detail::marshal(pts, pts.size(), xy, inf);
+    bool any = false;
+    for (uint8_t f : inf) any = any || f;
+    keep_.emplace_back(new DeviceBuffer(c_, xy.data(), xy.size() * 8));
+    d_xy = keep_.back()->template as<uint64_t>();
+    d_inf = nullptr;
+    if (any) {
+      keep_.emplace_back(new DeviceBuffer(c_, inf.data(), inf.size()));
+      d_inf = keep_.back()->template as<uint8_t>();
+    }
+    if (!pts.empty()) c_.check(kg_bases_register(c_.raw(), curve, d_xy, d_inf, pts.size()), "kg_bases_register");
+  }
+  const Context& c_;
+  kg_groth16_crs crs_;
+  std::vector<std::unique_ptr<DeviceBuffer>> keep_;
+};
+
+}  // namespace kogarashi
