@@ -471,6 +471,7 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint32_t* __restrict__ k
 // LDS and copies it out run by run, so consecutive lanes write consecutive addresses.
 // ---------------------------------------------------------------------------------------------------
 constexpr int FINE_BITS = 7, FINE = 1 << FINE_BITS, SEG = 8192;
+constexpr uint32_t MULTI_SEG = 0x80000000u;          // flag in a window's segment total (segbase[G]): a group of several segments exists
 
 // First pass of the two-pass sort, staged through LDS: a workgroup walks its (scalar chunk, window) pair in tiles of
 // GS_TILE entries, ranks a tile's entries inside their bucket group with LDS atomics, lays the tile out group by group
@@ -581,7 +582,9 @@ __global__ void __launch_bounds__(GS_NT) k_group_scan(uint32_t* __restrict__ cnt
       st += run[j]; ex += ns[j];
     }
   }
-  if (tid == 0) segbase[(size_t)w * (G + 1) + G] = total;
+  // bit 31 of the segment total: some group of this window is more than one segment (the two-kernel fine path has work)
+  const int any_multi = __syncthreads_or((ns[0] > 1) | (ns[1] > 1) | (ns[2] > 1) | (ns[3] > 1));
+  if (tid == 0) segbase[(size_t)w * (G + 1) + G] = total | (any_multi ? MULTI_SEG : 0u);
   uint4* z = reinterpret_cast<uint4*>(bsize + (size_t)w * B);            // B is a multiple of 4 here (c >= 12)
   for (int b = threadIdx.x; b < B / 4; b += blockDim.x) z[b] = make_uint4(0, 0, 0, 0);
 }
@@ -622,14 +625,15 @@ __global__ void __launch_bounds__(GS_NT) k_merge_groups(const uint32_t* __restri
       st += run[j]; ex += ns[j];
     }
   }
-  if (tid == 0) segbase_m[G] = total;
+  const int any_multi = __syncthreads_or((ns[0] > 1) | (ns[1] > 1) | (ns[2] > 1) | (ns[3] > 1));
+  if (tid == 0) segbase_m[G] = total | (any_multi ? MULTI_SEG : 0u);
 }
 
 struct SegRange { int g; uint32_t lo, hi; };
 // which group / entry range does segment s of window w cover?  (sb: the window's segbase row in LDS)
 __device__ __forceinline__ bool seg_locate(const uint32_t* sb, int G, uint32_t s, const uint32_t* __restrict__ gstart,
                                            const uint32_t* __restrict__ gsize, int w, SegRange& r) {
-  if (s >= sb[G]) return false;
+  if (s >= (sb[G] & ~MULTI_SEG)) return false;
   int lo = 0, hi = G;                                // largest g with sb[g] <= s (empty groups repeat the value: take the last)
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sb[mid] <= s) lo = mid; else hi = mid; }
   r.g = lo;
@@ -648,6 +652,7 @@ __global__ void __launch_bounds__(512) k_fine_count(const uint32_t* __restrict__
   __shared__ uint32_t hist[FINE];
   const int w = blockIdx.x;
   const uint32_t s = blockIdx.y;
+  if (!(segbase[(size_t)w * (G + 1) + G] & MULTI_SEG)) return;      // every group of this window is one segment: k_fine_local did it all
   for (int g = threadIdx.x; g <= G; g += blockDim.x) sb[g] = segbase[(size_t)w * (G + 1) + g];
   if (threadIdx.x < FINE) hist[threadIdx.x] = 0;
   __syncthreads();
@@ -731,6 +736,7 @@ __global__ void __launch_bounds__(512) k_fine_scatter(const uint32_t* __restrict
   __shared__ uint32_t stage[SEG];
   const int w = blockIdx.x;
   const uint32_t s = blockIdx.y;
+  if (!(segbase[(size_t)w * (G + 1) + G] & MULTI_SEG)) return;      // every group of this window is one segment: k_fine_local did it all
   for (int g = threadIdx.x; g <= G; g += blockDim.x) sb[g] = segbase[(size_t)w * (G + 1) + g];
   __syncthreads();
   SegRange r;
