@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--groth16-log-m", type=int, default=18)
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--depth", type=int, default=4, help="MSM steps in flight (1..4)")
+    ap.add_argument("--prewarm", type=int, default=200, help="untimed steps before the W warm-up steps (first touch, clock ramp)")
     ap.add_argument("--stream-ordered-inputs", action="store_true", help="do not declare the (static, synchronised) inputs complete")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -200,7 +201,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    run(40)                                   # untimed: first-touch allocations and the clock ramp of a cold GPU (~70 ms)
+    run(args.prewarm)                         # untimed: first-touch allocations and the clock ramp of a cold GPU (~0.3 s)
     if args.warmup:
         run(args.warmup)
     ctx.profile_enable(True)
