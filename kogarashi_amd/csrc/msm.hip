@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint32_t* __restrict__ k
 // ---------------------------------------------------------------------------------------------------
 // second pass of the two-pass sort.  A bucket group's entries are contiguous after the first pass; they are cut into
 // segments of at most SEG entries, one workgroup per segment (so a 0/1-heavy witness, whose entries pile into one
-// group, still spreads over the chip).  k_fine_count histograms a segment by the bucket's low bits and reserves the
+// group, still spreads over the chip).  k_fine_local histograms a segment by the bucket's low bits and reserves the
 // segment's place inside each bucket (atomicAdd on the bucket size returns it); k_fine_scatter sorts the segment in
 // LDS and copies it out run by run, so consecutive lanes write consecutive addresses.
 // ---------------------------------------------------------------------------------------------------
@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(GS_NT) k_group_scatter(const uint32_t* __restr
 }
 
 // One workgroup per window, one lane per bucket group: exclusive prefix of the group's counters over the chunks (in
-// place), group sizes and starts, the segment table, and the window's bucket sizes zeroed for k_fine_count.
+// place), group sizes and starts, the segment table, and the window's bucket sizes zeroed for k_fine_local.
 __global__ void __launch_bounds__(GS_NT) k_group_scan(uint32_t* __restrict__ cnt, int nch, int G, int B, uint32_t* __restrict__ gsize,
                                                        uint32_t* __restrict__ gstart, uint32_t* __restrict__ segbase, uint32_t* __restrict__ bsize) {
   KG_SERVICE_PRIO();
@@ -643,42 +643,16 @@ __device__ __forceinline__ bool seg_locate(const uint32_t* sb, int G, uint32_t s
   return true;
 }
 
-__global__ void __launch_bounds__(512) k_fine_count(const uint32_t* __restrict__ tmp, size_t n, int G, int B, int maxseg,
-                                                    const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gsize,
-                                                    const uint32_t* __restrict__ segbase, uint32_t* __restrict__ bsize,
-                                                    uint32_t* __restrict__ segcnt, uint32_t* __restrict__ segoff) {
-  KG_SERVICE_PRIO();
-  __shared__ uint32_t sb[1025];
-  __shared__ uint32_t hist[FINE];
-  const int w = blockIdx.x;
-  const uint32_t s = blockIdx.y;
-  if (!(segbase[(size_t)w * (G + 1) + G] & MULTI_SEG)) return;      // every group of this window is one segment: k_fine_local did it all
-  for (int g = threadIdx.x; g <= G; g += blockDim.x) sb[g] = segbase[(size_t)w * (G + 1) + g];
-  if (threadIdx.x < FINE) hist[threadIdx.x] = 0;
-  __syncthreads();
-  SegRange r;
-  if (!seg_locate(sb, G, s, gstart, gsize, w, r)) return;
-  if (gsize[(size_t)w * G + r.g] <= (uint32_t)SEG) return;       // a group that is one segment is sorted by k_fine_local
-  const uint32_t* src = tmp + (size_t)w * n;
-  for (uint32_t i = r.lo + threadIdx.x; i < r.hi; i += blockDim.x) atomicAdd(&hist[(src[i] >> 24) & (FINE - 1)], 1u);
-  __syncthreads();
-  if (threadIdx.x < FINE) {
-    const uint32_t cnt = hist[threadIdx.x];
-    const size_t o = ((size_t)w * maxseg + s) * FINE + threadIdx.x;
-    segcnt[o] = cnt;
-    segoff[o] = cnt ? atomicAdd(&bsize[(size_t)w * B + (size_t)r.g * FINE + threadIdx.x], cnt) : 0u;
-  }
-}
-
 // Second pass, segment-local form: a bucket group that fits ONE segment (<= SEG entries -- every group of a uniform input:
 // 4096 entries at 2^20, c = 16) is histogrammed, ordered and written by a single workgroup in a single read of the
 // intermediate.  The group's run in `sorted` is contiguous and its buckets follow each other inside it, so bucket starts need no
 // global prefix: bstart = gstart + the local exclusive prefix (what k_bucket_rows computes from the sizes written here), no
 // atomics on the bucket sizes, and the copy out is one coalesced stream.  Groups of several segments (skewed witnesses, every
-// group of a merged sort) keep the two-kernel path (k_fine_count reserves, k_fine_scatter places).
-__global__ void __launch_bounds__(512) k_fine_local(const uint32_t* __restrict__ tmp, size_t n, int G, int B, const uint32_t* __restrict__ gstart,
+// group of a merged sort) are only counted here (place reserved per segment and bucket); k_fine_scatter places them.
+__global__ void __launch_bounds__(512) k_fine_local(const uint32_t* __restrict__ tmp, size_t n, int G, int B, int maxseg, const uint32_t* __restrict__ gstart,
                                                     const uint32_t* __restrict__ gsize, const uint32_t* __restrict__ segbase,
-                                                    uint32_t* __restrict__ bsize, uint32_t* __restrict__ sorted) {
+                                                    uint32_t* __restrict__ bsize, uint32_t* __restrict__ segcnt, uint32_t* __restrict__ segoff,
+                                                    uint32_t* __restrict__ sorted) {
   KG_SERVICE_PRIO();
   __shared__ uint32_t sb[1025];
   __shared__ uint32_t hist[FINE], cursor[FINE], wsum;
@@ -690,8 +664,20 @@ __global__ void __launch_bounds__(512) k_fine_local(const uint32_t* __restrict__
   __syncthreads();
   SegRange r;
   if (!seg_locate(sb, G, s, gstart, gsize, w, r)) return;
-  if (gsize[(size_t)w * G + r.g] > (uint32_t)SEG) return;        // several segments: the two-kernel path
   const uint32_t* src = tmp + (size_t)w * n;
+  if (gsize[(size_t)w * G + r.g] > (uint32_t)SEG) {
+    // a segment of a larger group: histogram it and reserve its place inside each bucket (the atomicAdd on the bucket size returns
+    // the segment's offset there); k_fine_scatter places the entries once the bucket starts are known
+    for (uint32_t i = r.lo + threadIdx.x; i < r.hi; i += blockDim.x) atomicAdd(&hist[(src[i] >> 24) & (FINE - 1)], 1u);
+    __syncthreads();
+    if (threadIdx.x < FINE) {
+      const uint32_t cnt = hist[threadIdx.x];
+      const size_t o = ((size_t)w * maxseg + s) * FINE + threadIdx.x;
+      segcnt[o] = cnt;
+      segoff[o] = cnt ? atomicAdd(&bsize[(size_t)w * B + (size_t)r.g * FINE + threadIdx.x], cnt) : 0u;
+    }
+    return;
+  }
   constexpr int PER = SEG / 512;                                 // entries a lane keeps in registers between the two phases
   uint32_t rec[PER];
   const uint32_t len = r.hi - r.lo;
@@ -1607,8 +1593,7 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
         hipLaunchKernelGGL(k_merge_groups, dim3(1), dim3(GS_NT), 0, st, gsize, W, G, woff, (uint32_t*)(ws + o_gsize_m), (uint32_t*)(ws + o_gstart_m),
                            (uint32_t*)(ws + o_segbase_m));
       hipLaunchKernelGGL(k_group_scatter, dim3(W, nch), dim3(GS_NT), 0, st, kt, n, c, W, chunk_len, G, cnt, f_gstart, tmp, woff, mshift);
-      hipLaunchKernelGGL(k_fine_local, dim3(Wb, maxseg), dim3(512), 0, st, tmp, n, G, B, f_gstart, f_gsize, f_segbase, S->bsize, S->sorted);
-      hipLaunchKernelGGL(k_fine_count, dim3(Wb, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bsize, segcnt, segoff);
+      hipLaunchKernelGGL(k_fine_local, dim3(Wb, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bsize, segcnt, segoff, S->sorted);
     } else {
       hipLaunchKernelGGL(k_count, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, 0, cnt);
       hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, cnt, W, nch, B, S->bsize);
