@@ -6,6 +6,8 @@
 //   Fft(k).dft / idft / coset_dft / coset_idft / divide_by_z_on_coset    groth16/src/fft.rs:27-154
 //   PedersenCommitment(g).commit(m)                                      nova/src/pedersen.rs:6-20
 //   Prover(params).create_proof(a, b, c, x, w, r, s)                     groth16/src/prover.rs:14-99
+//   R1csShape(a, b, c).prod / compute_cross_term(z1, z2, u1, u2)         zkstd/src/matrix.rs:36-48, nova/src/prover.rs:53-90
+//   ShardedPedersenCommitment(ctxs, g).commit(m)                         nova/src/pedersen.rs:6-20 over every GPU of the node
 //
 // with the reference's in-memory data: a field element is 4 x uint64 Montgomery limbs (Fr / Fq), an affine point x | y plus an
 // identity flag.  Nothing here computes: every call goes to libkogarashi_amd.so; without the library or a device the
@@ -258,6 +260,98 @@ class Prover {
   const Context& c_;
   kg_groth16_crs crs_;
   std::vector<std::unique_ptr<DeviceBuffer>> keep_;
+};
+
+// zkstd::matrix::SparseMatrix as compressed sparse rows over z = (u | x | w): Wire::Instance(i) -> column i, Wire::Witness(i) ->
+// column i + l (the index rule of SparseMatrix::prod, matrix.rs:36-48), resolved by whoever builds the CSR
+struct SparseMatrix {
+  std::vector<uint64_t> row_ptr, col;
+  std::vector<Fe> val;
+  size_t rows() const { return row_ptr.empty() ? 0 : row_ptr.size() - 1; }
+};
+
+// nova::R1csShape's three matrices, resident on the device: prod (SparseMatrix::prod) and Prover::compute_cross_term
+// (nova/src/prover.rs:53-90: T = AZ1 o BZ2 + AZ2 o BZ1 - u1 CZ2 - u2 CZ1, one fused kernel).  field: KG_FR for the bn254 driver,
+// KG_FQ for the Grumpkin driver (nova/src/driver.rs:9-42).
+class R1csShape {
+ public:
+  R1csShape(const Context& c, const SparseMatrix& a, const SparseMatrix& b, const SparseMatrix& cm, int field = KG_FR) : c_(c), field_(field), m_(a.rows()) {
+    if (b.rows() != m_ || cm.rows() != m_) throw std::invalid_argument("R1csShape: the three matrices have one row per constraint");
+    const SparseMatrix* mats[3] = {&a, &b, &cm};
+    for (int k = 0; k < 3; ++k) {
+      const uint64_t pad64 = 0;
+      const Fe padfe{0, 0, 0, 0};
+      const SparseMatrix& M = *mats[k];
+      if (M.col.size() != M.val.size() || M.row_ptr.size() != m_ + 1 || M.row_ptr.back() != M.col.size()) throw std::invalid_argument("R1csShape: malformed CSR");
+      for (uint64_t cidx : M.col) max_col_ = cidx > max_col_ ? cidx : max_col_;
+      buf_[3 * k].reset(new DeviceBuffer(c, M.row_ptr.data(), M.row_ptr.size() * 8));
+      buf_[3 * k + 1].reset(new DeviceBuffer(c, M.col.empty() ? &pad64 : M.col.data(), (M.col.empty() ? 1 : M.col.size()) * 8));
+      buf_[3 * k + 2].reset(new DeviceBuffer(c, M.val.empty() ? &padfe : M.val.data(), (M.val.empty() ? 1 : M.val.size()) * 32));
+      csr_[k] = kg_csr{buf_[3 * k]->as<uint64_t>(), buf_[3 * k + 1]->as<uint64_t>(), buf_[3 * k + 2]->as<uint64_t>()};
+    }
+  }
+  size_t m() const { return m_; }
+  // SparseMatrix::prod of matrix `which` (0 = A, 1 = B, 2 = C) with z
+  std::vector<Fe> prod(int which, const std::vector<Fe>& z) const {
+    covers(z);
+    DeviceBuffer dz(c_, z.data(), z.size() * 32), out(c_, m_ * 32);
+    c_.check(kg_r1cs_prod(c_.raw(), field_, csr_[which].d_row_ptr, csr_[which].d_col, csr_[which].d_val, m_, dz.as<uint64_t>(), out.as<uint64_t>()), "kg_r1cs_prod");
+    std::vector<Fe> r(m_);
+    out.download(r.data());
+    return r;
+  }
+  std::vector<Fe> compute_cross_term(const std::vector<Fe>& z1, const std::vector<Fe>& z2, const Fe& u1, const Fe& u2) const {
+    covers(z1);
+    covers(z2);
+    DeviceBuffer d1(c_, z1.data(), z1.size() * 32), d2(c_, z2.data(), z2.size() * 32), out(c_, m_ * 32);
+    c_.check(kg_nova_cross_term(c_.raw(), field_, &csr_[0], &csr_[1], &csr_[2], m_, d1.as<uint64_t>(), d2.as<uint64_t>(), u1.data(), u2.data(), out.as<uint64_t>()),
+             "kg_nova_cross_term");
+    std::vector<Fe> t(m_);
+    out.download(t.data());
+    return t;
+  }
+
+ private:
+  void covers(const std::vector<Fe>& z) const {          // the reference would panic on an index past z; the kernels do not check
+    if (m_ && z.size() <= max_col_) throw std::out_of_range("R1csShape: z is shorter than the largest column index");
+  }
+  const Context& c_;
+  int field_;
+  size_t m_;
+  uint64_t max_col_ = 0;
+  std::unique_ptr<DeviceBuffer> buf_[9];
+  kg_csr csr_[3];
+};
+
+// nova/src/pedersen.rs:6-20 with the key g cut over several contexts (one per GPU of the node): slice i is uploaded to and
+// registered on context i once (kg_sharded_key_create); commit uploads each device's slice of m, every device runs the whole
+// pipeline on its slice and the affine partial sums are added on the host (index-range sharding).
+class ShardedPedersenCommitment {
+ public:
+  ShardedPedersenCommitment(const std::vector<const Context*>& ctxs, const std::vector<G1Affine>& g, int curve = KG_G1) : first_(*ctxs.at(0)) {
+    std::vector<uint64_t> xy;
+    std::vector<uint8_t> inf;
+    detail::marshal(g, g.size(), xy, inf);
+    bool any = false;
+    for (uint8_t f : inf) any = any || f;
+    std::vector<kg_ctx*> raw;
+    for (const Context* c : ctxs) raw.push_back(c->raw());
+    first_.check(kg_sharded_key_create(raw.data(), (int)raw.size(), curve, xy.data(), any ? inf.data() : nullptr, g.size(), &key_), "kg_sharded_key_create");
+  }
+  ~ShardedPedersenCommitment() { if (key_) kg_sharded_key_destroy(key_); }
+  ShardedPedersenCommitment(const ShardedPedersenCommitment&) = delete;
+  ShardedPedersenCommitment& operator=(const ShardedPedersenCommitment&) = delete;
+  size_t len() const { return kg_sharded_key_len(key_); }
+  G1Affine commit(const std::vector<Fe>& m) const {
+    uint64_t xy[8];
+    uint8_t inf = 0;
+    first_.check(kg_sharded_key_commit(key_, reinterpret_cast<const uint64_t*>(m.data()), m.size(), xy, &inf), "kg_sharded_key_commit");
+    return detail::g1_from(xy, inf != 0);
+  }
+
+ private:
+  const Context& first_;
+  kg_sharded_key* key_ = nullptr;
 };
 
 }  // namespace kogarashi

@@ -1,7 +1,8 @@
 // abi_cpp_test.cpp -- the C++ mirror of the reference's call sites (include/kogarashi_amd.hpp) against the oracle's C
 // restatement, on the GPU box: msm_curve_addition (G1 and Grumpkin, identity bases and zero scalars mixed in), Fft (all five
 // operations, ragged input), PedersenCommitment (against the reference's naive fold), Prover::create_proof on the chain
-// circuit (CRS from the oracle's setup) and the ProverSubVersionCrsAttack error.  Test infrastructure: built and run by
+// circuit (CRS from the oracle's setup) and the ProverSubVersionCrsAttack error, SparseMatrix::prod and Nova's cross term on both
+// scalar fields, the commitment key spread over two contexts.  Test infrastructure: built and run by
 // tests/test_gpu_cpp_host.py; links libkogarashi_amd.so and liboracle.so.
 #include <cstdio>
 #include <cstring>
@@ -32,6 +33,9 @@ int kgo_groth16_setup_scalars(const u64* a_rp, const u64* a_col, const u64* a_va
                               u64* h_s, u64* l_s, u64* a_s, u64* b_s, u64* ic_s);
 void kgo_fixed_base_mul(int curve, const u64* k, size_t n, u64* xy, unsigned char* inf, int threads);
 void kgo_r1cs_evaluate(const u64* row_ptr, const u64* col, const u64* val, size_t m, const u64* z, u64* out);
+void kgo_matrix_prod(int fd, const u64* row_ptr, const u64* col, const u64* val, size_t m, const u64* z, u64* out);
+void kgo_nova_cross_term(int fd, const u64* a_rp, const u64* a_col, const u64* a_val, const u64* b_rp, const u64* b_col, const u64* b_val,
+                         const u64* c_rp, const u64* c_col, const u64* c_val, size_t m, const u64* z1, const u64* z2, const u64* u1, const u64* u2, u64* out);
 int kgo_groth16_prove(const u64* a_ev, const u64* b_ev, const u64* c_ev, size_t m, const u64* x, size_t l, const u64* w, size_t m_l_1,
                       const u64* h, const unsigned char* h_inf, const u64* lq, const unsigned char* l_inf, const u64* a, const unsigned char* a_inf,
                       const u64* bg1, const unsigned char* bg1_inf, const u64* bg2, const unsigned char* bg2_inf, const u64* vk_g1, const u64* vk_g2,
@@ -198,6 +202,51 @@ static void test_prover(const Context& ctx) {
   CHECK(threw, "Error::ProverSubVersionCrsAttack");
 }
 
+// a random sparse system: rows of 0..5 entries (one row empty, one long), both scalar fields
+static void test_nova(const Context& ctx, int field) {
+  const size_t m = 1500, nz = 300;
+  unsigned long long st = 0x9e3779b97f4a7c15ull + field;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+  SparseMatrix M[3];
+  for (int k = 0; k < 3; ++k) {
+    M[k].row_ptr.push_back(0);
+    for (size_t i = 0; i < m; ++i) {
+      size_t cnt = rnd() % 6;
+      if (i == 7) cnt = 0;
+      if (i == 9) cnt = 70;
+      for (size_t e = 0; e < cnt; ++e) M[k].col.push_back(rnd() % nz);
+      M[k].row_ptr.push_back(M[k].col.size());
+    }
+    M[k].val = scalars(field, SEED + 50 + k, M[k].col.size());
+  }
+  const std::vector<Fe> z1 = scalars(field, SEED + 60, nz), z2 = scalars(field, SEED + 61, nz), us = scalars(field, SEED + 62, 2);
+  R1csShape shape(ctx, M[0], M[1], M[2], field);
+  auto UC = [](const std::vector<Fe>& v) { return reinterpret_cast<const u64*>(v.data()); };
+  std::vector<Fe> want(m);
+  kgo_matrix_prod(field, M[1].row_ptr.data(), M[1].col.data(), UC(M[1].val), m, UC(z1), reinterpret_cast<u64*>(want.data()));
+  CHECK(shape.prod(1, z1) == want, "SparseMatrix::prod");
+  kgo_nova_cross_term(field, M[0].row_ptr.data(), M[0].col.data(), UC(M[0].val), M[1].row_ptr.data(), M[1].col.data(), UC(M[1].val), M[2].row_ptr.data(),
+                      M[2].col.data(), UC(M[2].val), m, UC(z1), UC(z2), us[0].data(), us[1].data(), reinterpret_cast<u64*>(want.data()));
+  CHECK(shape.compute_cross_term(z1, z2, us[0], us[1]) == want, "Prover::compute_cross_term");
+  bool threw = false;
+  try { shape.prod(0, std::vector<Fe>(nz - 200)); } catch (const std::out_of_range&) { threw = true; }
+  CHECK(threw, "short z is refused");
+}
+
+// the commitment key over two contexts (sharing device 0 on a one-GPU box) against the single-context commitment
+static void test_sharded_commit(const Context& ctx) {
+  const size_t n = 9001;
+  std::vector<u64> xy(8 * n);
+  kgo_gen_bases(0, SEED + 71, 0, n, xy.data());
+  const std::vector<G1Affine> g = points(xy.data(), nullptr, n);
+  const std::vector<Fe> m = scalars(0, SEED + 72, n);
+  Context second(0);
+  ShardedPedersenCommitment key({&ctx, &second}, g);
+  CHECK(key.len() == n, "sharded key length");
+  const G1Affine a = key.commit(m), b = PedersenCommitment(ctx, g).commit(m);
+  CHECK(a.x == b.x && a.y == b.y && a.is_infinity == b.is_infinity, "sharded commit = single-context commit");
+}
+
 int main() {
   kg_init();
   try {
@@ -208,10 +257,13 @@ int main() {
     test_fft(ctx, 13);
     test_commit(ctx);
     test_prover(ctx);
+    test_nova(ctx, KG_FR);
+    test_nova(ctx, KG_FQ);
+    test_sharded_commit(ctx);
   } catch (const std::exception& e) {
     std::printf("FAIL exception: %s\n", e.what());
     return 2;
   }
-  std::printf(failures ? "FAILED: %d checks\n" : "ok: msm_curve_addition, Fft, PedersenCommitment, Prover match the oracle\n", failures);
+  std::printf(failures ? "FAILED: %d checks\n" : "ok: msm_curve_addition, Fft, PedersenCommitment, Prover, R1csShape, ShardedPedersenCommitment match the oracle\n", failures);
   return failures ? 1 : 0;
 }
