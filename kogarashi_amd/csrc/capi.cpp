@@ -153,7 +153,7 @@ int kg_hw_queue_setting(void) {
   const char* e = getenv("GPU_MAX_HW_QUEUES");
   return e ? atoi(e) : 0;
 }
-int kg_version(void) { return 1; }
+int kg_version(void) { return 3; }      // the round the ABI was last extended in (3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded)
 
 int kg_device_count(void) {
   int n = 0;
