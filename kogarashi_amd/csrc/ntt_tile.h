@@ -7,7 +7,7 @@
 // tile lives in LDS as nine 29-bit limb planes.  All index arithmetic is shifts and masks by constants.
 //
 // Every function here is a per-thread body, generic over the field type F and over the tile store: the kernel
-// (ntt.hip) instantiates it with Fr and LDS planes, tests/host/hosttest.cpp runs the same code thread by thread on the
+// (ntt.hip) instantiates it with Fr and LDS planes, tests/host/hosttest_ntt.cpp runs the same code thread by thread on the
 // host with the bound-checking FrC and checks whole transforms against the oracle.
 #pragma once
 #include <cstddef>
@@ -209,7 +209,7 @@ KG_HD void ntt_st_words(uint64_t* base, size_t elem, const uint32_t w[8]) {
   for (int i = 0; i < 8; ++i) p[i] = w[i];
 #endif
 }
-// field-type adapters (the bound-checking type supplies its own in tests/host/hosttest.cpp)
+// field-type adapters (the bound-checking type supplies its own in tests/host/hosttest_ntt.cpp)
 template <class F> struct NttIO;
 template <class P> struct NttIO<Fp<P>> {
   static KG_HD Fp<P> raw(const uint32_t w[8]) { return limbs_from_words<P>(w); }          // any 256-bit value, no domain change
