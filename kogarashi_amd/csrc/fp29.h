@@ -19,6 +19,7 @@
 // every formula in curve.h / the kernels are machine-checked on the host by instantiating the same
 // templates with FpChecked (tests/host/, `-DKG_HOST_TEST`).
 #pragma once
+#include <type_traits>
 #include <cstdint>
 #include "fp_consts.h"
 
@@ -54,6 +55,118 @@ struct Fp {
   static KG_HD Fp one() { return from_const(P::ONE); }
 };
 
+// f(integral_constant<int, I>) for I in [LO, HI): the column index of a product is a compile-time constant
+template <int I, int HI, class Fn>
+KG_HD void static_for(Fn&& f) {
+  if constexpr (I < HI) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, HI>(f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// acc += sum x[j] * y[j] as ONE chain of v_mad_u64_u32 whose addend is the running column sum.  Written as instructions on the
+// device: left to itself the compiler's reassociation starts every column with a fresh zero-seeded chain and joins the
+// carried-in sum with a separate 64-bit add (v_lshl_add_u64, the issue cost of a multiply-accumulate) -- 20-22 of them per
+// product, a tenth of its instructions.  One asm statement per chain: the compiler separates dependent asm statements by a
+// wait state (it must assume an inline instruction writes a partial register).  macs_k: y are compile-time constants (limbs
+// of p), kept in scalar registers; macs_i: signed 32-bit factors, signed sum.  The carry-out mask of the 64-bit sum is never
+// set (column bounds) and never read.
+// ---------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KG_NO_ASM_MAC)
+#define KG_ASM_MAC 1
+#endif
+template <int N>
+KG_HD void macs(uint64_t& acc, const uint32_t (&x)[N], const uint32_t (&y)[N]) {
+  static_assert(N >= 1 && N <= 9, "one column of a 9-limb product");
+#ifdef KG_ASM_MAC
+  uint64_t cy;
+  if constexpr (N == 1) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]));
+  else if constexpr (N == 2) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]));
+  else if constexpr (N == 3) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
+  else if constexpr (N == 4) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
+  else if constexpr (N == 5) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]));
+  else if constexpr (N == 6) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]));
+  else if constexpr (N == 7) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" "v_mad_u64_u32 %0, %1, %14, %15, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]));
+  else if constexpr (N == 8) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" "v_mad_u64_u32 %0, %1, %14, %15, %0\n\t" "v_mad_u64_u32 %0, %1, %16, %17, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]));
+  else if constexpr (N == 9) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" "v_mad_u64_u32 %0, %1, %14, %15, %0\n\t" "v_mad_u64_u32 %0, %1, %16, %17, %0\n\t" "v_mad_u64_u32 %0, %1, %18, %19, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]));
+#else
+  for (int j = 0; j < N; ++j) acc += (uint64_t)x[j] * y[j];
+#endif
+}
+template <int N>
+KG_HD void macs_k(uint64_t& acc, const uint32_t (&x)[N], const uint32_t (&y)[N]) {
+  static_assert(N >= 1 && N <= 9, "one column of a 9-limb product");
+#ifdef KG_ASM_MAC
+  uint64_t cy;
+  if constexpr (N == 1) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]));
+  else if constexpr (N == 2) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]));
+  else if constexpr (N == 3) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]));
+  else if constexpr (N == 4) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]));
+  else if constexpr (N == 5) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]));
+  else if constexpr (N == 6) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]));
+  else if constexpr (N == 7) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" "v_mad_u64_u32 %0, %1, %14, %15, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]));
+  else if constexpr (N == 8) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" "v_mad_u64_u32 %0, %1, %14, %15, %0\n\t" "v_mad_u64_u32 %0, %1, %16, %17, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]));
+  else if constexpr (N == 9) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" "v_mad_u64_u32 %0, %1, %14, %15, %0\n\t" "v_mad_u64_u32 %0, %1, %16, %17, %0\n\t" "v_mad_u64_u32 %0, %1, %18, %19, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]));
+#else
+  for (int j = 0; j < N; ++j) acc += (uint64_t)x[j] * y[j];
+#endif
+}
+template <int N>
+KG_HD void macs_i(int64_t& acc, const int32_t (&x)[N], const int32_t (&y)[N]) {
+  static_assert(N >= 1 && N <= 9, "one column of a 9-limb product");
+#ifdef KG_ASM_MAC
+  uint64_t cy;
+  if constexpr (N == 1) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]));
+  else if constexpr (N == 2) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]));
+  else if constexpr (N == 3) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
+  else if constexpr (N == 4) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
+  else if constexpr (N == 5) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t" "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]));
+  else if constexpr (N == 6) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t" "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t" "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]));
+  else if constexpr (N == 7) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t" "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t" "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t" "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]));
+  else if constexpr (N == 8) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t" "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t" "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t" "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t" "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]));
+  else if constexpr (N == 9) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t" "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t" "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t" "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t" "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t" "v_mad_i64_i32 %0, %1, %18, %19, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]));
+#else
+  for (int j = 0; j < N; ++j) acc += (int64_t)x[j] * (int64_t)y[j];
+#endif
+}
+// signed columns (mul2sub, mul2pm): the unsigned chains on the two's-complement bit pattern
+template <int N>
+KG_HD void macs(int64_t& acc, const uint32_t (&x)[N], const uint32_t (&y)[N]) { uint64_t u = (uint64_t)acc; macs(u, x, y); acc = (int64_t)u; }
+template <int N>
+KG_HD void macs_k(int64_t& acc, const uint32_t (&x)[N], const uint32_t (&y)[N]) { uint64_t u = (uint64_t)acc; macs_k(u, x, y); acc = (int64_t)u; }
+// column k of x * y: sum over i in [LO, HI] of x[i] * y[k - i]  (Y0: index of y[0] inside the array passed, for the constant tables)
+template <int K, int LO, int HI, class Acc, class X, class Y>
+KG_HD void mac_col(Acc& acc, const X& x, const Y& y) {
+  if constexpr (HI >= LO) {
+    uint32_t xs[HI - LO + 1], ys[HI - LO + 1];
+#pragma unroll
+    for (int i = LO; i <= HI; ++i) { xs[i - LO] = x[i]; ys[i - LO] = y[K - i]; }
+    macs(acc, xs, ys);
+  }
+}
+// the same against a constant table: Tab::at(j), j = K - i, a compile-time constant (an immediate, not a load)
+template <class P> struct ModulusLimbs { static KG_HD constexpr uint32_t at(int j) { return P::P[j]; } };
+template <class P> struct ModulusBarLimbs { static KG_HD constexpr uint32_t at(int j) { return P::PBAR[j]; } };
+template <class Tab, int K, int LO, int HI, class Acc, class X>
+KG_HD void mac_col_k(Acc& acc, const X& x) {
+  if constexpr (HI >= LO) {
+    uint32_t xs[HI - LO + 1], ys[HI - LO + 1];
+#pragma unroll
+    for (int i = LO; i <= HI; ++i) { xs[i - LO] = x[i]; ys[i - LO] = Tab::at(K - i); }
+    macs_k(acc, xs, ys);
+  }
+}
+template <int K, int LO, int HI, class X, class Y>
+KG_HD void mac_col_i(int64_t& acc, const X& x, const Y& y) {
+  if constexpr (HI >= LO) {
+    int32_t xs[HI - LO + 1], ys[HI - LO + 1];
+#pragma unroll
+    for (int i = LO; i <= HI; ++i) { xs[i - LO] = (int32_t)x[i]; ys[i - LO] = (int32_t)y[K - i]; }
+    macs_i(acc, xs, ys);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Montgomery product a*b/2^261 (finely integrated product scanning; one 64-bit accumulator)
 // ---------------------------------------------------------------------------------------------
@@ -62,25 +175,21 @@ KG_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
   uint32_t m[9];
   Fp<P> r;
   uint64_t acc = 0;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-#pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-    for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::P[k - i];
+  static_for<0, 9>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, 0, k>(acc, a.l, b.l);
+    mac_col_k<ModulusLimbs<P>, k, 0, k - 1>(acc, m);
     m[k] = ((uint32_t)acc * P::INV) & M29;
-    acc += (uint64_t)m[k] * P::P[0];
+    mac_col_k<ModulusLimbs<P>, k, k, k>(acc, m);
     acc >>= 29;
-  }
-#pragma unroll
-  for (int k = 9; k < 17; ++k) {
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)m[i] * P::P[k - i];
+  });
+  static_for<9, 17>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, k - 8, 8>(acc, a.l, b.l);
+    mac_col_k<ModulusLimbs<P>, k, k - 8, 8>(acc, m);
     r.l[k - 9] = (uint32_t)acc & M29;
     acc >>= 29;
-  }
+  });
   r.l[8] = (uint32_t)acc;
   return r;
 }
@@ -93,27 +202,23 @@ KG_HD Fp<P> sqr(const Fp<P>& a) {
   for (int i = 0; i < 9; ++i) d[i] = a.l[i] << 1;
   Fp<P> r;
   uint64_t acc = 0;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-#pragma unroll
-    for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)d[i] * a.l[k - i];
-    if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
-#pragma unroll
-    for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::P[k - i];
+  static_for<0, 9>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, 0, (k + 1) / 2 - 1>(acc, d, a.l);                 // the cross products: 2 i < k
+    if constexpr ((k & 1) == 0) mac_col<k, k / 2, k / 2>(acc, a.l, a.l);
+    mac_col_k<ModulusLimbs<P>, k, 0, k - 1>(acc, m);
     m[k] = ((uint32_t)acc * P::INV) & M29;
-    acc += (uint64_t)m[k] * P::P[0];
+    mac_col_k<ModulusLimbs<P>, k, k, k>(acc, m);
     acc >>= 29;
-  }
-#pragma unroll
-  for (int k = 9; k < 17; ++k) {
-#pragma unroll
-    for (int i = k - 8; 2 * i < k; ++i) acc += (uint64_t)d[i] * a.l[k - i];
-    if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)m[i] * P::P[k - i];
+  });
+  static_for<9, 17>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, k - 8, (k + 1) / 2 - 1>(acc, d, a.l);
+    if constexpr ((k & 1) == 0) mac_col<k, k / 2, k / 2>(acc, a.l, a.l);
+    mac_col_k<ModulusLimbs<P>, k, k - 8, 8>(acc, m);
     r.l[k - 9] = (uint32_t)acc & M29;
     acc >>= 29;
-  }
+  });
   r.l[8] = (uint32_t)acc;
   return r;
 }
@@ -125,29 +230,23 @@ KG_HD Fp<P> mul2add(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>&
   uint32_t m[9];
   Fp<P> r;
   uint64_t acc = 0;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-#pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (uint64_t)c.l[i] * d.l[k - i];
-#pragma unroll
-    for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::P[k - i];
+  static_for<0, 9>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, 0, k>(acc, a.l, b.l);
+    mac_col<k, 0, k>(acc, c.l, d.l);
+    mac_col_k<ModulusLimbs<P>, k, 0, k - 1>(acc, m);
     m[k] = ((uint32_t)acc * P::INV) & M29;
-    acc += (uint64_t)m[k] * P::P[0];
+    mac_col_k<ModulusLimbs<P>, k, k, k>(acc, m);
     acc >>= 29;
-  }
-#pragma unroll
-  for (int k = 9; k < 17; ++k) {
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)c.l[i] * d.l[k - i];
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)m[i] * P::P[k - i];
+  });
+  static_for<9, 17>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, k - 8, 8>(acc, a.l, b.l);
+    mac_col<k, k - 8, 8>(acc, c.l, d.l);
+    mac_col_k<ModulusLimbs<P>, k, k - 8, 8>(acc, m);
     r.l[k - 9] = (uint32_t)acc & M29;
     acc >>= 29;
-  }
+  });
   r.l[8] = (uint32_t)acc;
   return r;
 }
@@ -162,29 +261,23 @@ KG_HD Fp<P> mul2sub(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>&
   for (int i = 0; i < 9; ++i) nc[i] = -(int32_t)c.l[i];
   Fp<P> r;
   int64_t acc = 0;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-#pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (int64_t)((uint64_t)a.l[i] * b.l[k - i]);
-#pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (int64_t)nc[i] * (int64_t)(int32_t)d.l[k - i];
-#pragma unroll
-    for (int i = 0; i < k; ++i) acc += (int64_t)((uint64_t)m[i] * P::P[k - i]);
+  static_for<0, 9>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, 0, k>(acc, a.l, b.l);
+    mac_col_i<k, 0, k>(acc, nc, d.l);
+    mac_col_k<ModulusLimbs<P>, k, 0, k - 1>(acc, m);
     m[k] = ((uint32_t)acc * P::INV) & M29;
-    acc += (int64_t)((uint64_t)m[k] * P::P[0]);
+    mac_col_k<ModulusLimbs<P>, k, k, k>(acc, m);
     acc >>= 29;
-  }
-#pragma unroll
-  for (int k = 9; k < 17; ++k) {
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (int64_t)((uint64_t)a.l[i] * b.l[k - i]);
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (int64_t)nc[i] * (int64_t)(int32_t)d.l[k - i];
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (int64_t)((uint64_t)m[i] * P::P[k - i]);
+  });
+  static_for<9, 17>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, k - 8, 8>(acc, a.l, b.l);
+    mac_col_i<k, k - 8, 8>(acc, nc, d.l);
+    mac_col_k<ModulusLimbs<P>, k, k - 8, 8>(acc, m);
     r.l[k - 9] = (uint32_t)acc & M29;
     acc >>= 29;
-  }
+  });
   // value in (-p, 2p): add p when negative, then propagate carries
   const uint32_t neg_mask = (uint32_t)((int32_t)(acc >> 32) >> 31);
   uint32_t cy = 0;
@@ -214,37 +307,68 @@ template <class P>
 KG_HD Fp<P> mulc(const Fp<P>& a, const FpConst<P>& c) {
   uint32_t qe[9];
   uint64_t acc = 0;
-#pragma unroll
-  for (int i = 0; i <= 7; ++i) acc += (uint64_t)a.l[i] * c.q[7 - i];
+  mac_col<7, 0, 7>(acc, a.l, c.q);
   acc >>= 29;
-#pragma unroll
-  for (int i = 0; i <= 8; ++i) acc += (uint64_t)a.l[i] * c.q[8 - i];
+  mac_col<8, 0, 8>(acc, a.l, c.q);
   acc >>= 29;
-#pragma unroll
-  for (int k = 9; k < 17; ++k) {
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (uint64_t)a.l[i] * c.q[k - i];
+  static_for<9, 17>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, k - 8, 8>(acc, a.l, c.q);
     qe[k - 9] = (uint32_t)acc & M29;
     acc >>= 29;
-  }
+  });
   qe[8] = (uint32_t)acc;                       // floor(a * q / 2^261) or one less; < 2^261 / 2 ... fits (a * q < 2^522)
   Fp<P> r;
   acc = 0;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-#pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * c.w[k - i];
-#pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (uint64_t)qe[i] * P::PBAR[k - i];
-#if defined(__HIP_DEVICE_COMPILE__)
-    // only the low 29 bits of the last column are used: without this the compiler narrows its 18 multiply-accumulates to
-    // v_mul_lo_u32 + v_add, which issue at about half the rate of v_mad_u64_u32
-    if (k == 8) asm volatile("" : "+v"(acc));
-#endif
+  static_for<0, 9>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, 0, k>(acc, a.l, c.w);
+    mac_col_k<ModulusBarLimbs<P>, k, 0, k>(acc, qe);
+    // (only the low 29 bits of the last column are used; as instructions its 18 multiply-accumulates stay multiply-accumulates)
     r.l[k] = (uint32_t)acc & M29;              // the true remainder is below 3p < 2^256: bits 261 and up are the q * 2^261 term
     acc >>= 29;
-  }
+  });
   return r;
+}
+// Two independent constant products with their column chains interleaved: consecutive instruction groups never depend on
+// each other, so the wait state the compiler puts between dependent asm statements disappears and each chain's latency hides
+// behind the other's issue.
+template <class P>
+KG_HD void mulc_pair(const Fp<P>& a0, const FpConst<P>& c0, const Fp<P>& a1, const FpConst<P>& c1, Fp<P>& r0, Fp<P>& r1) {
+  uint32_t qe0[9], qe1[9];
+  uint64_t acc0 = 0, acc1 = 0;
+  mac_col<7, 0, 7>(acc0, a0.l, c0.q);
+  mac_col<7, 0, 7>(acc1, a1.l, c1.q);
+  acc0 >>= 29;
+  acc1 >>= 29;
+  mac_col<8, 0, 8>(acc0, a0.l, c0.q);
+  mac_col<8, 0, 8>(acc1, a1.l, c1.q);
+  acc0 >>= 29;
+  acc1 >>= 29;
+  static_for<9, 17>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, k - 8, 8>(acc0, a0.l, c0.q);
+    mac_col<k, k - 8, 8>(acc1, a1.l, c1.q);
+    qe0[k - 9] = (uint32_t)acc0 & M29;
+    qe1[k - 9] = (uint32_t)acc1 & M29;
+    acc0 >>= 29;
+    acc1 >>= 29;
+  });
+  qe0[8] = (uint32_t)acc0;
+  qe1[8] = (uint32_t)acc1;
+  acc0 = 0;
+  acc1 = 0;
+  static_for<0, 9>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, 0, k>(acc0, a0.l, c0.w);
+    mac_col<k, 0, k>(acc1, a1.l, c1.w);
+    mac_col_k<ModulusBarLimbs<P>, k, 0, k>(acc0, qe0);
+    mac_col_k<ModulusBarLimbs<P>, k, 0, k>(acc1, qe1);
+    r0.l[k] = (uint32_t)acc0 & M29;
+    r1.l[k] = (uint32_t)acc1 & M29;
+    acc0 >>= 29;
+    acc1 >>= 29;
+  });
 }
 // q = floor(w * 2^261 / p) for a canonical w (restoring division, 261 steps; table construction only)
 template <class P>
@@ -468,29 +592,23 @@ KG_HD Fp<P> mul2pm(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& 
   for (int i = 0; i < 9; ++i) sc[i] = negate ? -(int32_t)c.l[i] : (int32_t)c.l[i];
   Fp<P> r;
   int64_t acc = 0;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-#pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (int64_t)((uint64_t)a.l[i] * b.l[k - i]);
-#pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (int64_t)sc[i] * (int64_t)(int32_t)d.l[k - i];
-#pragma unroll
-    for (int i = 0; i < k; ++i) acc += (int64_t)((uint64_t)m[i] * P::P[k - i]);
+  static_for<0, 9>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, 0, k>(acc, a.l, b.l);
+    mac_col_i<k, 0, k>(acc, sc, d.l);
+    mac_col_k<ModulusLimbs<P>, k, 0, k - 1>(acc, m);
     m[k] = ((uint32_t)acc * P::INV) & M29;
-    acc += (int64_t)((uint64_t)m[k] * P::P[0]);
+    mac_col_k<ModulusLimbs<P>, k, k, k>(acc, m);
     acc >>= 29;
-  }
-#pragma unroll
-  for (int k = 9; k < 17; ++k) {
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (int64_t)((uint64_t)a.l[i] * b.l[k - i]);
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (int64_t)sc[i] * (int64_t)(int32_t)d.l[k - i];
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (int64_t)((uint64_t)m[i] * P::P[k - i]);
+  });
+  static_for<9, 17>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    mac_col<k, k - 8, 8>(acc, a.l, b.l);
+    mac_col_i<k, k - 8, 8>(acc, sc, d.l);
+    mac_col_k<ModulusLimbs<P>, k, k - 8, 8>(acc, m);
     r.l[k - 9] = (uint32_t)acc & M29;
     acc >>= 29;
-  }
+  });
   // value in (-p, 2p): add p when negative, then propagate carries
   const uint32_t neg_mask = (uint32_t)((int32_t)(acc >> 32) >> 31);
   uint32_t cy = 0;

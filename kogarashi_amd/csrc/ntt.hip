@@ -106,7 +106,11 @@ __global__ void __launch_bounds__((NttTile<Fr, LOG_M, LOG_TC, ROW>::NT)) __attri
   const LdsPlanes<T::ELEMS> st{lds};
   t.first(threadIdx.x, st);
   if constexpr (!T::SINGLE) {
+#ifdef KG_NTT_EXP_NOBAR      // phase-off experiment (tools/dbg): no workgroup barriers (results are wrong, timing only)
+    const auto full = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+#else
     const auto full = [] { __syncthreads(); };
+#endif
     // between two wave-private passes: the wave's own LDS writes are ordered before its reads by the in-order LDS queue; the
     // fence keeps the compiler from moving them across the boundary
     const auto wave = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
