@@ -34,10 +34,17 @@ MADD_PEAK_G = 16.5              # measured: the bucket kernel's addition routine
 MAD_PEAK_T = 33.0               # measured chip-wide v_mad_u64_u32 issue rate, T instructions/s (profiles/r01_valu_rates.txt)
 MADS_PER_ADDITION = 1467        # add_mixed_signed (curve.h): 6 products x 162 + 2 squares x 126 + one double product x 243 multiply-accumulates (fp29.h)
 MUL_PEAK_G = 174.0              # measured Montgomery products/s (profiles/r01_mul_rate.txt)
-# 2^22 = 2^11 * 2^11 (ntt_tile.h: two steps, two HBM round trips).  Per element: 10 in-tile twiddle products in Shoup form (fp29.h mulc:
-# 143 multiply-accumulates each; stage 1 of either tile has none) + 1 inter-step Montgomery product (162 + 9 v_mul_lo)
-NTT_MADS_PER_ELEMENT = {22: 10 * 143 + 171}
-NTT_KERNEL_NOTE = "k_ntt_tile<11,1,col> + k_ntt_tile<11,1,row> (two HBM round trips: 128 B of data moved per element, + 36 B of inter-step twiddle table)"
+def ntt_cost(K, log_n):
+    """Multiply-accumulates per element and a description of the kernels of a 2^log_n transform, from the library's own plan
+    (kg_ntt_plan).  A step of 2^m points has m radix-2 stages; stage 1 has no twiddle products, stage 2 on half of its butterflies,
+    every later stage half a product per element: m/2 - 0.75 in-tile products per element in Shoup form (fp29.h mulc: 143
+    multiply-accumulates), plus one Montgomery product (162) per element between two steps."""
+    plan = K.lib.ntt_plan(log_n)
+    mads = sum((m / 2 - 0.75) * 143 for m, _ in plan) + (len(plan) - 1) * 162
+    kern = " + ".join(f"k_ntt_tile<2^{m} points, {1 << t}-element tiles>" for m, t in plan)
+    note = (f"{kern}: {len(plan)} HBM round trip(s), {64 * len(plan)} B of data moved per element"
+            + (f" + {36 * (len(plan) - 1)} B of inter-step twiddle tables" if len(plan) > 1 else ""))
+    return mads, note, plan
 
 
 def window_adds(n):
@@ -350,16 +357,16 @@ def bench_ntt(ctx, torch, dev, K, env, log_n=22, steps=10):
     ctx.profile_enable(False)
     ms = tot / cnt
     gbs = 64.0 * n / (ms * 1e-3) / 1e9
-    mads = NTT_MADS_PER_ELEMENT.get(log_n)
+    mads, kernel_note, plan = ntt_cost(K, log_n)
     out = {"metric": "bn254_fr_ntt_elements_per_sec", "log_n": log_n, "value": world * n / (wall_ms * 1e-3), "ms": ms, "wall_ms": wall_ms,
            "replicas": world, "note": "value = replicas x n / wall time per transform (max over ranks); ms = HIP-event duration of one transform on rank 0",
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "algorithmic_bytes": 64 * n, "kernel": NTT_KERNEL_NOTE}}
+                        "algorithmic_bytes": 64 * n, "kernel": kernel_note},
+           "plan": [{"log_m": m, "log_tile": t} for m, t in plan]}
     if mads:
         out["valu_roofline"] = {"bound": "valu", "unit": "T v_mad_u64_u32/s", "mads_per_element": mads,
                                 "achieved": mads * n / (ms * 1e-3) / 1e12, "peak": MAD_PEAK_T, "frac": mads * n / (ms * 1e-3) / 1e12 / MAD_PEAK_T,
-                                "note": "multiply-accumulates are ~55 % of the kernel's VALU instructions; rocprofv3 SQ counters: VALU issue on ~2/3 of the SIMD "
-                                        "cycles, waves parked at barriers / waits for ~48 % of their lifetime (DESIGN.md section 4)"}
+                                "note": "multiply-accumulates are ~60 % of the kernels' VALU instructions (DESIGN.md section 4)"}
     return out
 
 

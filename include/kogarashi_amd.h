@@ -106,6 +106,10 @@ int kg_field_vec_scale(kg_ctx* ctx, int field, const uint64_t* d_a, const uint64
  * place; 1 <= log_n <= 28 (S = 28, bn254/src/fr.rs:53).  The caller zero-pads (prepare_fft :157-162). */
 int kg_ntt_bn254_fr(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n, int inverse, int coset);
 int kg_fr_divide_by_z_on_coset(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n);
+/* How a transform of 2^log_n elements is decomposed (no device needed; reporting only: bench.py prices the roofline with it):
+ * returns the number of steps s in 1..3 (one HBM round trip each, 0 for log_n outside 1..28); log_m[i] = log2 of step i's DFT
+ * length (they sum to log_n), log_tile[i] = log2 of the elements one workgroup holds in LDS.  KG_NTT_STEPS / KG_NTT_TILE apply. */
+int kg_ntt_plan(uint32_t log_n, uint32_t* log_m, uint32_t* log_tile);   /* three entries each */
 
 /* ---- MSM -------------------------------------------------------------------------------------------
  * groth16/src/msm.rs:6-48 msm_curve_addition(bases, coeffs): sum_i coeffs[i] * bases[i] over n pairs

@@ -330,46 +330,6 @@ KG_HD Fp<P> mulc(const Fp<P>& a, const FpConst<P>& c) {
   });
   return r;
 }
-// Two independent constant products with their column chains interleaved: consecutive instruction groups never depend on
-// each other, so the wait state the compiler puts between dependent asm statements disappears and each chain's latency hides
-// behind the other's issue.
-template <class P>
-KG_HD void mulc_pair(const Fp<P>& a0, const FpConst<P>& c0, const Fp<P>& a1, const FpConst<P>& c1, Fp<P>& r0, Fp<P>& r1) {
-  uint32_t qe0[9], qe1[9];
-  uint64_t acc0 = 0, acc1 = 0;
-  mac_col<7, 0, 7>(acc0, a0.l, c0.q);
-  mac_col<7, 0, 7>(acc1, a1.l, c1.q);
-  acc0 >>= 29;
-  acc1 >>= 29;
-  mac_col<8, 0, 8>(acc0, a0.l, c0.q);
-  mac_col<8, 0, 8>(acc1, a1.l, c1.q);
-  acc0 >>= 29;
-  acc1 >>= 29;
-  static_for<9, 17>([&](auto kc) {
-    constexpr int k = decltype(kc)::value;
-    mac_col<k, k - 8, 8>(acc0, a0.l, c0.q);
-    mac_col<k, k - 8, 8>(acc1, a1.l, c1.q);
-    qe0[k - 9] = (uint32_t)acc0 & M29;
-    qe1[k - 9] = (uint32_t)acc1 & M29;
-    acc0 >>= 29;
-    acc1 >>= 29;
-  });
-  qe0[8] = (uint32_t)acc0;
-  qe1[8] = (uint32_t)acc1;
-  acc0 = 0;
-  acc1 = 0;
-  static_for<0, 9>([&](auto kc) {
-    constexpr int k = decltype(kc)::value;
-    mac_col<k, 0, k>(acc0, a0.l, c0.w);
-    mac_col<k, 0, k>(acc1, a1.l, c1.w);
-    mac_col_k<ModulusBarLimbs<P>, k, 0, k>(acc0, qe0);
-    mac_col_k<ModulusBarLimbs<P>, k, 0, k>(acc1, qe1);
-    r0.l[k] = (uint32_t)acc0 & M29;
-    r1.l[k] = (uint32_t)acc1 & M29;
-    acc0 >>= 29;
-    acc1 >>= 29;
-  });
-}
 // q = floor(w * 2^261 / p) for a canonical w (restoring division, 261 steps; table construction only)
 template <class P>
 KG_HD FpConst<P> make_const(const Fp<P>& w_canonical) {

@@ -143,7 +143,7 @@ int plan_tile_env() {        // KG_NTT_TILE=10..12: log2 of the tile size (exper
   static const int v = [] { const char* e = getenv("KG_NTT_TILE"); return e ? atoi(e) : 0; }();
   return v;
 }
-int plan_steps_env() {       // KG_NTT_STEPS=3: three-step plans from 2^18 up (experiments; default: ntt_plan's automatic rule)
+int plan_steps_env() {       // KG_NTT_STEPS=3: three-step plans from 2^18 up; 2: two steps up to 2^22 (experiments; default: ntt_plan's automatic rule)
   static const int v = [] { const char* e = getenv("KG_NTT_STEPS"); return e ? atoi(e) : 0; }();
   return v;
 }
@@ -277,6 +277,17 @@ int kg_ntt_bn254_fr(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n, int inverse, 
     tmp = (uint64_t*)ctx->ws2;
   }
   return kg::ntt_enqueue(ctx, ctx->stream, tmp, d_data, log_n, inverse, coset);
+}
+
+int kg_ntt_plan(uint32_t log_n, uint32_t* log_m, uint32_t* log_tile) {
+  if (log_n < 1 || log_n > 28 || !log_m || !log_tile) return 0;
+  NttStepDesc d[3];
+  const int s = ntt_plan(log_n, plan_steps_env(), d, plan_tile_env());
+  for (int i = 0; i < 3; ++i) {
+    log_m[i] = i < s ? (uint32_t)d[i].log_m : 0u;
+    log_tile[i] = i < s ? (uint32_t)(d[i].log_m + d[i].log_tc) : 0u;
+  }
+  return s;
 }
 
 int kg_fr_divide_by_z_on_coset(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n) {

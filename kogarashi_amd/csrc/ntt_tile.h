@@ -500,7 +500,7 @@ KG_HD F ntt_pow(F base, uint64_t e) {
 //   step A (column)  n1-point DFTs over j1, * w_n^(i1 * (j2*n3 + j3)),          data -> scratch
 //   step B (column)  n2-point DFTs over j2 inside each i1 slab, * w_n^(n1*i2*j3), scratch in place   [three-step plans only]
 //   step C (row)     n3-point DFTs over j3 along contiguous rows, written transposed, scratch -> data
-// Two steps (n2 = 1) up to 2^22: two HBM round trips, factors up to 2^11 (a 4096-element tile is 144 KiB of LDS).
+// Two steps (n2 = 1) up to 2^21 (2^22 on request): two HBM round trips, factors up to 2^11 (a 4096-element tile is 144 KiB of LDS).
 struct NttStepDesc { int log_m, log_tc; bool row; };
 // The tile shapes (LOG_M, LOG_TC) that exist as kernels: every shape the automatic plans use, the three-step plans' and the
 // 2048-element tiles of 2^10- / 2^11-point factors; row steps also run the single-step transforms (LOG_TC = 0).
@@ -526,12 +526,16 @@ inline NttStepDesc ntt_step_desc(int log_m, int want_auto, int tile, bool row) {
   }
   return {log_m, ntt_tile_log(log_m, want_auto) - log_m, row};
 }
-// steps: 0 = automatic (one step up to 2^11, two up to 2^22, three above); 3 forces three steps from 2^18 up.
+// steps: 0 = automatic (one step up to 2^11, two up to 2^21, three above); 2 forces two steps up to 2^22, 3 three from 2^18 up.
 // tile: 0 = automatic, else log2 of the tile size wanted (10..12)
+// Measured (tools/dbg/ntt_plans.py, round 3): at 2^22 two steps of 2^11 points -- 4096-element tiles, one 16-wave workgroup per
+// CU, six register passes per step of which the first is a lone radix-2 stage -- take 508-522 us, three steps on 1024-element
+// tiles (four workgroups per CU) 462-481 us although they move the data once more and multiply once more per element; at
+// 2^21 two steps still win (213-221 against 231-240 us).
 inline int ntt_plan(uint32_t log_n, int steps, NttStepDesc out[3], int tile = 0) {
   const int k = (int)log_n;
   if (k <= NTT_MAX_LOG_M) { out[0] = {k, 0, true}; return 1; }
-  const bool three = k > 2 * NTT_MAX_LOG_M || (steps == 3 && k >= 18);
+  const bool three = k > 2 * NTT_MAX_LOG_M || (steps == 3 && k >= 18) || (steps != 2 && k >= 22);
   if (!three) {
     const int k1 = (k + 1) / 2, k3 = k - k1;
     const int want = k <= 19 ? 10 : (k <= 21 ? 11 : 12);
@@ -539,8 +543,13 @@ inline int ntt_plan(uint32_t log_n, int steps, NttStepDesc out[3], int tile = 0)
     out[1] = ntt_step_desc(k3, want, tile, true);
     return 2;
   }
-  const int k1 = (k + 2) / 3, k2 = (k - k1 + 1) / 2, k3 = k - k1 - k2;
-  const int want = k <= 20 ? 10 : 11;
+  // a factor of 2^m costs ceil(m / 2) register passes (an odd m starts with a lone radix-2 stage): balanced factors, then two
+  // odd ones trade a stage so that both become even -- 22 = 8 + 8 + 6 (11 passes) instead of 8 + 7 + 7 (12)
+  int k1 = (k + 2) / 3, k2 = (k - k1 + 1) / 2, k3 = k - k1 - k2;
+  if ((k2 & 1) && (k3 & 1) && k2 + 1 <= NTT_MAX_LOG_M) { ++k2; --k3; }
+  else if ((k1 & 1) && (k2 & 1) && k1 + 1 <= NTT_MAX_LOG_M) { ++k1; --k2; }
+  else if ((k1 & 1) && (k3 & 1) && k1 + 1 <= NTT_MAX_LOG_M) { ++k1; --k3; }
+  const int want = k <= 24 ? 10 : 11;               // 1024-element tiles while the factors allow them: 2^22 478 / 494, 2^24 1783 / 1834 us
   out[0] = ntt_step_desc(k1, want, tile, false);
   out[1] = ntt_step_desc(k2, want, tile, false);
   out[2] = ntt_step_desc(k3, want, tile, true);

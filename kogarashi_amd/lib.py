@@ -24,7 +24,7 @@ EXPORTS = [
     "kg_points_sum_affine", "kg_msm_set_window", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
     "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
-    "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_r1cs_begin", "kg_groth16_prove_sharded",
+    "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_r1cs_begin", "kg_groth16_prove_sharded", "kg_ntt_plan",
 ]
 
 
@@ -94,6 +94,13 @@ def hw_queue_setting() -> int:
 def msm_table_window(msm_len: int) -> int:
     """window width of the tables kg_bases_precompute builds for MSMs of msm_len scalars (0: none offered); no device needed"""
     return int(load().kg_msm_table_window(C.c_size_t(msm_len)))
+
+
+def ntt_plan(log_n: int) -> list[tuple[int, int]]:
+    """kg_ntt_plan: [(log2 DFT length, log2 tile elements)] per step of a 2^log_n transform (no device needed)"""
+    m, t = (C.c_uint32 * 3)(), (C.c_uint32 * 3)()
+    s = int(load().kg_ntt_plan(C.c_uint32(log_n), m, t))
+    return [(int(m[i]), int(t[i])) for i in range(s)]
 
 
 def msm_pick_window(n: int) -> int:

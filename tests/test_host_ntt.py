@@ -56,9 +56,10 @@ def test_larger_plans(nttlib, oracle, k, steps):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("k,steps", [(20, 0), (21, 0), (22, 0), (22, 3), (23, 0)])
+@pytest.mark.parametrize("k,steps", [(20, 0), (21, 0), (22, 0), (22, 2), (23, 0)])
 def test_big_tiles(nttlib, oracle, k, steps):
-    """the 2048- and 4096-element tiles (2^10- and 2^11-point column and row steps) and a plan above the direct tables"""
+    """the 2048- and 4096-element tiles (2^10- and 2^11-point column and row steps), the automatic three-step plan of 2^22
+    (8 + 8 + 6) beside its two-step form, and a plan above the direct tables"""
     f = oracle.Fft(k)
     v, got, cyc, ideal = _run(nttlib, oracle, k, steps, 0, 0, checked=True)
     assert (got == f.dft(v, threads=8)).all()
@@ -74,7 +75,7 @@ def test_plans_use_only_instantiated_shapes(nttlib):
     col = both | set(re.findall(r"X\((\d+), (\d+)\)", re.search(r"#define KG_NTT_SHAPES_COL_ONLY\(X\)(.*)", hdr).group(1)))
     row = both | set(re.findall(r"X\((\d+), (\d+)\)", re.search(r"#define KG_NTT_SHAPES_ROW_ONLY\(X\)(.*)", hdr).group(1)))
     out = (C.c_int * 9)()
-    for steps in (0, 3):
+    for steps in (0, 2, 3):
         for tile in (0, 10, 11, 12):
             for k in range(1, 29):
                 c = nttlib.ht_ntt_plan(k, steps, tile, out)
