@@ -47,6 +47,11 @@ def ntt_cost(K, log_n):
     return mads, note, plan
 
 
+def single_rank_env(torch, dev):
+    """the rank environment of the legs for one process without a process group (--ntt-only, tools/dbg)"""
+    return {"world": 1, "rank": 0, "barrier": torch.cuda.synchronize, "max_over_ranks": lambda x: x, "xdev": dev, "kdist": None}
+
+
 def window_adds(n):
     """bucket additions of one MSM: one per (window, scalar) pair with a non-zero digit ~ W * n"""
     lg = n.bit_length() - 1
@@ -152,7 +157,7 @@ def main():
     ctx = K.Context(local_rank)
     if args.ntt_only:
         torch.cuda.synchronize()
-        env = {"world": world, "rank": rank, "barrier": torch.cuda.synchronize, "max_over_ranks": lambda x: x, "xdev": dev, "kdist": None}
+        env = single_rank_env(torch, dev)
         print(json.dumps({"ntt": bench_ntt(ctx, torch, dev, K, env, steps=max(args.steps, 10))}), flush=True)
         return
     # The library launches on its own queues (main queue: accumulations; scalar-side queue: digit extraction, sort, base

@@ -537,7 +537,7 @@ inline int ntt_plan(uint32_t log_n, int steps, NttStepDesc out[3], int tile = 0)
   if (k <= NTT_MAX_LOG_M) { out[0] = {k, 0, true}; return 1; }
   const bool three = k > 2 * NTT_MAX_LOG_M || (steps == 3 && k >= 18) || (steps != 2 && k >= 22);
   if (!three) {
-    const int k1 = (k + 1) / 2, k3 = k - k1;
+    const int k1 = (k + 1) / 2, k3 = k - k1;       // (two odd halves stay: 18 = 10 + 8 saves a pass but leaves step A 128 workgroups: 48 against 40 us)
     const int want = k <= 19 ? 10 : (k <= 21 ? 11 : 12);
     out[0] = ntt_step_desc(k1, want, tile, false);
     out[1] = ntt_step_desc(k3, want, tile, true);

@@ -25,5 +25,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # 6. SQ issue / wait counters of the same leg
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$O/pmcntt_SQ" -- python3 bench.py --ntt-only --steps 10 > "$O/pmcntt_SQ.json" 2> "$O/pmcntt_SQ.err"
+# 7. the multiplier and the transform's register pass alone (tools/ubench; built in-tree before the call)
+if [ -x tools/ubench/mul_rate ]; then
+  ( cd tools/ubench; echo "== fp29.h as shipped (one multiply-accumulate chain per column)"; timeout -s KILL 120 ./mul_rate | grep -E "SIMD=(1|2|4|8) "
+    if [ -x ./mul_rate_c ]; then echo "== -DKG_NO_ASM_MAC (the columns left to the compiler)"; timeout -s KILL 120 ./mul_rate_c | grep -E "SIMD=(1|2|4|8) "; fi ) > "$O/mul_rate.txt" 2>&1
+fi
+if [ -x tools/ubench/ntt_pass_rate ]; then ( cd tools/ubench; timeout -s KILL 120 ./ntt_pass_rate ) > "$O/ntt_pass_rate.txt" 2>&1; fi
 ls -R "$O" | head -80
 tail -c 600 "$O/bench.json"

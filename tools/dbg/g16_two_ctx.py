@@ -14,7 +14,7 @@ def cap(*a):
     captured["args"] = a
     return orig(*a)
 ctx.groth16_prove = cap
-out = bench.bench_groth16(ctx, torch, dev, K, 18, steps=6, cpu=False)
+out = bench.bench_groth16(ctx, torch, dev, K, bench.single_rank_env(torch, dev), 18, steps=6, cpu=False)
 print("one ctx: pipelined", round(out["ms_per_proof"], 3), "blocking", round(out["ms_per_proof_blocking"], 3))
 args = captured["args"]
 nthreads = int(sys.argv[1]) if len(sys.argv) > 1 else 2

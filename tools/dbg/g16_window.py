@@ -10,5 +10,5 @@ ctx = K.Context(0)
 st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st); ctx.set_stream(st.cuda_stream)
 for c in [int(a) for a in sys.argv[2:]]:
     ctx.set_msm_window(c)
-    out = bench.bench_groth16(ctx, torch, dev, K, int(sys.argv[1]), steps=10, cpu=False)
+    out = bench.bench_groth16(ctx, torch, dev, K, bench.single_rank_env(torch, dev), int(sys.argv[1]), steps=10, cpu=False)
     print(c, "pipelined", round(out["ms_per_proof"], 3), "blocking", round(out.get("ms_per_proof_blocking", 0), 3), flush=True)

@@ -31,9 +31,8 @@ def per_launch(kernel, algorithmic):
     return {"fetch_reported": f, "fetch_corrected_x2": 2 * f, "write": w, "total_corrected": 2 * f + w, "algorithmic": algorithmic}
 # what bench.py's roofline.traffic reads (2^20 G1 pairs: 96 B per pair; 2^22 Fr elements: 32 B read + 32 B written per step)
 out["k_acc_tasks_traffic_bytes_per_launch"] = per_launch("k_acc_tasks", 96 << 20)
-for shape in ("<11,1,false>", "<11,1,true>"):      # the two steps of a 2^22 transform: 32 B read + 32 B written per element each (+ 36 B of twiddle table in the first)
-    k = f"k_ntt_tile{shape}/grid{1 << 20}"
-    if k in out["FETCH_SIZE"]:
+for k in list(out["FETCH_SIZE"]):                # the steps of a 2^22 transform: 32 B read + 32 B written per element each (+ 36 B of twiddle table in a column step)
+    if k.startswith("k_ntt_tile") and k.endswith(f"/grid{1 << 20}"):      # (steps A and B of a three-step plan can share a shape: one mean over both)
         out[f"{k}_traffic_bytes_per_launch"] = per_launch(k, 64 << 22)
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 for k in out["FETCH_SIZE"]:

@@ -9,6 +9,6 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 ctx = K.Context(0)
 ctx.set_inputs_complete(True)      # as bench.py: the library's own queues, inputs synchronised before use
-out = bench.bench_groth16(ctx, torch, dev, K, int(sys.argv[1]) if len(sys.argv) > 1 else 18, steps=5, cpu=False,
+out = bench.bench_groth16(ctx, torch, dev, K, bench.single_rank_env(torch, dev), int(sys.argv[1]) if len(sys.argv) > 1 else 18, steps=5, cpu=False,
                           tickets=int(sys.argv[2]) if len(sys.argv) > 2 else 2)
 print(out)

@@ -51,4 +51,7 @@ if os.path.isdir(os.path.join(src, "kt_ntt")):
         out["note"] = ("per dispatch; SQ_* in quad-cycles summed over all waves (SQ_WAIT_ANY: parked at s_waitcnt / barrier, SQ_WAIT_INST_ANY: waiting "
                        "to issue, SQ_ACTIVE_INST_ANY: issuing); GRBM_GUI_ACTIVE summed over the 8 XCDs")
         json.dump(out, open(os.path.join(dst, f"{rnd}_ntt_sq_counters.json"), "w"), indent=1)
+for name in ("mul_rate.txt", "ntt_pass_rate.txt"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
 print("installed into", dst)
