@@ -1126,7 +1126,11 @@ template <class G> struct AccStore<Fp2S<G>> {
     for (int k = 0; k < 9; ++k) { dst[k] = p.x.v.l[k]; dst[18 + k] = p.y.v.l[k]; dst[36 + k] = p.zz.v.l[k]; dst[54 + k] = p.zzz.v.l[k]; }
   }
 };
+#ifdef KG_EXP_ACC_WAVES      // experiment (tools/dbg/build_variants.sh): base-field accumulation capped for this many waves per SIMD
+template <class F> struct AccWaves { static constexpr int MIN = KG_EXP_ACC_WAVES; };
+#else
 template <class F> struct AccWaves { static constexpr int MIN = 1; };
+#endif
 template <class G> struct AccWaves<Fp2<G>> { static constexpr int MIN = 2; };
 template <class F>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::MIN))) k_acc_tasks(AccSets A, const uint32_t* __restrict__ sorted,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Times every build/exp/libkg_*.so (tools/dbg/build_ntt_variants.sh) on this box, two alternating rounds; KG_NTT_TILE / KG_NTT_STEPS
+# Times every build/exp/libkg_*.so (tools/dbg/build_variants.sh) on this box, two alternating rounds; KG_NTT_TILE / KG_NTT_STEPS
 # pass through:   gpurun -- 'KG_NTT_TILE=11 bash tools/dbg/run_ntt_variants.sh 20 22'
 cd "$(dirname "$0")/../.."
 for rep in 1 2; do
