@@ -30,10 +30,12 @@ SEED = 0x4B6F676172617368
 LOG_N = 20
 G1_BYTES_PER_PAIR = 96          # 32 B scalar + 64 B affine base
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
-MADD_PEAK_G = 16.5              # measured: the bucket kernel's addition routine, operands in registers, 4 waves/SIMD (profiles/r01_mul_rate.txt)
+MADD_PEAK_G = 17.3              # measured: the bucket kernel's addition routine, operands in registers, 4 waves/SIMD (profiles/r03_mul_rate.txt; 16.5 before round 3's column chains)
 MAD_PEAK_T = 33.0               # measured chip-wide v_mad_u64_u32 issue rate, T instructions/s (profiles/r01_valu_rates.txt)
 MADS_PER_ADDITION = 1467        # add_mixed_signed (curve.h): 6 products x 162 + 2 squares x 126 + one double product x 243 multiply-accumulates (fp29.h)
-MUL_PEAK_G = 174.0              # measured Montgomery products/s (profiles/r01_mul_rate.txt)
+MUL_PEAK_G = 175.0              # measured Montgomery products/s, 4 waves/SIMD (profiles/r03_mul_rate.txt)
+
+
 def ntt_cost(K, log_n):
     """Multiply-accumulates per element and a description of the kernels of a 2^log_n transform, from the library's own plan
     (kg_ntt_plan).  A step of 2^m points has m radix-2 stages; stage 1 has no twiddle products, stage 2 on half of its butterflies,

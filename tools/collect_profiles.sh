@@ -25,6 +25,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # 6. SQ issue / wait counters of the same leg
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$O/pmcntt_SQ" -- python3 bench.py --ntt-only --steps 10 > "$O/pmcntt_SQ.json" 2> "$O/pmcntt_SQ.err"
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$O/pmc_SQ" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ntt --no-groth16 --no-nova > "$O/pmc_SQ.json" 2> "$O/pmc_SQ.err"
 # 7. the multiplier and the transform's register pass alone (tools/ubench; built in-tree before the call)
 if [ -x tools/ubench/mul_rate ]; then
   ( cd tools/ubench; echo "== fp29.h as shipped (one multiply-accumulate chain per column)"; timeout -s KILL 120 ./mul_rate | grep -E "SIMD=(1|2|4|8) "

@@ -23,6 +23,27 @@ def last_json_line(path):
     raise SystemExit(f"no JSON line in {path}")
 
 
+def sq_counters(pass_dir, out_path, only=None):
+    """per-kernel means of a rocprofv3 --pmc SQ_* pass"""
+    import csv, collections, re
+    f = newest(os.path.join(pass_dir, "*", "*counter_collection.csv"))
+    acc, cnt = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"]
+        if only and only not in name:
+            continue
+        if "k_ntt_tile" in name:
+            key = re.search(r"k_ntt_tile<[^>]*>", name).group(0).replace(" ", "") + "/grid" + r["Grid_Size"]
+        else:
+            key = re.sub(r"\(anonymous namespace\)::", "", name); key = re.sub(r"^void ", "", key); key = re.sub(r"\(.*", "", key)
+        acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[key] += r["Counter_Name"] == "SQ_WAVE_CYCLES"
+    out = {k: {"dispatches": cnt[k], **{c: v / max(cnt[k], 1) for c, v in d.items()}} for k, d in acc.items()}
+    out["note"] = ("per dispatch; SQ_* in quad-cycles summed over all waves (SQ_WAIT_ANY: parked at s_waitcnt / barrier, SQ_WAIT_INST_ANY: waiting "
+                   "to issue, SQ_ACTIVE_INST_ANY: issuing); GRBM_GUI_ACTIVE summed over the 8 XCDs; counter passes serialise the dispatches")
+    json.dump(out, open(out_path, "w"), indent=1)
+
+
 for name, out in (("bench.json", f"{rnd}_bench.json"), ("bench_under_rocprof.json", f"{rnd}_bench_under_rocprof.json"),
                   ("msm_under_rocprof.json", f"{rnd}_msm_under_rocprof.json")):
     json.dump(last_json_line(os.path.join(src, name)), open(os.path.join(dst, out), "w"), indent=1)
@@ -37,20 +58,9 @@ if os.path.isdir(os.path.join(src, "kt_ntt")):
     json.dump(last_json_line(os.path.join(src, "ntt_under_rocprof.json")), open(os.path.join(dst, f"{rnd}_ntt_under_rocprof.json"), "w"), indent=1)
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "dbg", "pmc_summary.py"), os.path.join(src, "pmcntt_"),
                            os.path.join(dst, f"{rnd}_ntt_pmc_hbm.json")])
-    import csv, collections, re
-    f = [newest(os.path.join(src, "pmcntt_SQ", "*", "*counter_collection.csv"))]
-    if f:
-        acc, cnt = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
-        for r in csv.DictReader(open(f[0])):
-            if "k_ntt_tile" not in r["Kernel_Name"]:
-                continue
-            key = re.search(r"k_ntt_tile<[^>]*>", r["Kernel_Name"]).group(0).replace(" ", "") + "/grid" + r["Grid_Size"]
-            acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
-            cnt[key] += r["Counter_Name"] == "SQ_WAVE_CYCLES"
-        out = {k: {"dispatches": cnt[k], **{c: v / max(cnt[k], 1) for c, v in d.items()}} for k, d in acc.items()}
-        out["note"] = ("per dispatch; SQ_* in quad-cycles summed over all waves (SQ_WAIT_ANY: parked at s_waitcnt / barrier, SQ_WAIT_INST_ANY: waiting "
-                       "to issue, SQ_ACTIVE_INST_ANY: issuing); GRBM_GUI_ACTIVE summed over the 8 XCDs")
-        json.dump(out, open(os.path.join(dst, f"{rnd}_ntt_sq_counters.json"), "w"), indent=1)
+    sq_counters(os.path.join(src, "pmcntt_SQ"), os.path.join(dst, f"{rnd}_ntt_sq_counters.json"), only="k_ntt_tile")
+if os.path.isdir(os.path.join(src, "pmc_SQ")):
+    sq_counters(os.path.join(src, "pmc_SQ"), os.path.join(dst, f"{rnd}_msm_sq_counters.json"))
 for name in ("mul_rate.txt", "ntt_pass_rate.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
