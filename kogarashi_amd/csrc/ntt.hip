@@ -4,7 +4,7 @@
 // entries per proof), prepare_fft (:157-162, bit-reversal swaps), classic_fft_arithmetic (:166-192, recursive
 // DIT) and butterfly_arithmetic (:195-218).  dft(v)[i] = sum_j v[j] w^(ij) with w = ROOT_OF_UNITY^(2^(28-k)).
 //
-// Decomposition n = n1*n2*n3 (ntt_tile.h: ntt_plan): one step (n <= 2^11), two (n <= 2^22: factors up to 2^11, two HBM
+// Decomposition n = n1*n2*n3 (ntt_tile.h: ntt_plan): one step (n <= 2^11), two (n <= 2^21: factors up to 2^11, two HBM
 // round trips) or three; no separate bit-reversal pass exists and every step is one HBM round trip.  A step works on
 // tiles of 1024-4096 elements that live in LDS as nine 29-bit limb planes (36-144 KiB); its kernel is instantiated per
 // (DFT size, tile width), so index arithmetic is constant shifts, the first register pass is fused with the load and the
