@@ -27,6 +27,18 @@ def test_header_symbols_are_exported(lib):
     assert so.kg_strerror(-1) == b"no HIP device"
 
 
+def test_ntt_plan_is_reported_without_a_device(lib):
+    """kg_ntt_plan (what bench.py prices the transform's roofline with): the factors of every accepted size multiply to n, a
+    tile holds at least one DFT and at most 4096 elements, and sizes outside 2^1..2^28 are refused."""
+    for k in range(1, 29):
+        plan = lib.ntt_plan(k)
+        assert 1 <= len(plan) <= 3 and sum(m for m, _ in plan) == k, (k, plan)
+        assert all(1 <= m <= 11 and m <= t <= 12 for m, t in plan), (k, plan)
+        assert len(plan) == (1 if k <= 11 else 2 if k <= 21 else 3), (k, plan)
+    assert lib.ntt_plan(22) == [(8, 10), (8, 10), (6, 10)]         # the bench's transform (DESIGN.md section 4)
+    assert lib.ntt_plan(0) == [] and lib.ntt_plan(29) == []
+
+
 def test_no_cpu_fallback_without_device(lib):
     import torch
     if torch.cuda.is_available():
