@@ -76,20 +76,38 @@ KG_HD void static_for(Fn&& f) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(KG_NO_ASM_MAC)
 #define KG_ASM_MAC 1
 #endif
+// operands of a chain statement: %0 the 64-bit sum, %1 the carry-out pair, then (x[j], y[j]) as %(2 + 2j), %(3 + 2j)
+#define KG_MAD(op, a, b) op " %0, %1, %" #a ", %" #b ", %0\n\t"
+#define KG_CHAIN_1(op) KG_MAD(op, 2, 3)
+#define KG_CHAIN_2(op) KG_CHAIN_1(op) KG_MAD(op, 4, 5)
+#define KG_CHAIN_3(op) KG_CHAIN_2(op) KG_MAD(op, 6, 7)
+#define KG_CHAIN_4(op) KG_CHAIN_3(op) KG_MAD(op, 8, 9)
+#define KG_CHAIN_5(op) KG_CHAIN_4(op) KG_MAD(op, 10, 11)
+#define KG_CHAIN_6(op) KG_CHAIN_5(op) KG_MAD(op, 12, 13)
+#define KG_CHAIN_7(op) KG_CHAIN_6(op) KG_MAD(op, 14, 15)
+#define KG_CHAIN_8(op) KG_CHAIN_7(op) KG_MAD(op, 16, 17)
+#define KG_CHAIN_9(op) KG_CHAIN_8(op) KG_MAD(op, 18, 19)
+#define KG_IN_1(yc) "v"(x[0]), yc(y[0])
+#define KG_IN_2(yc) KG_IN_1(yc), "v"(x[1]), yc(y[1])
+#define KG_IN_3(yc) KG_IN_2(yc), "v"(x[2]), yc(y[2])
+#define KG_IN_4(yc) KG_IN_3(yc), "v"(x[3]), yc(y[3])
+#define KG_IN_5(yc) KG_IN_4(yc), "v"(x[4]), yc(y[4])
+#define KG_IN_6(yc) KG_IN_5(yc), "v"(x[5]), yc(y[5])
+#define KG_IN_7(yc) KG_IN_6(yc), "v"(x[6]), yc(y[6])
+#define KG_IN_8(yc) KG_IN_7(yc), "v"(x[7]), yc(y[7])
+#define KG_IN_9(yc) KG_IN_8(yc), "v"(x[8]), yc(y[8])
+#define KG_Y_VGPR(e) "v"(e)
+#define KG_Y_SGPR(e) "s"(e)
+#define KG_CHAIN_CASE(n, op, yc) if constexpr (N == n) asm(KG_CHAIN_##n(op) : "+v"(acc), "=&s"(cy) : KG_IN_##n(yc));
+#define KG_CHAIN_CASES(op, yc)                                                                                          \
+  KG_CHAIN_CASE(1, op, yc) KG_CHAIN_CASE(2, op, yc) KG_CHAIN_CASE(3, op, yc) KG_CHAIN_CASE(4, op, yc) KG_CHAIN_CASE(5, op, yc) \
+  KG_CHAIN_CASE(6, op, yc) KG_CHAIN_CASE(7, op, yc) KG_CHAIN_CASE(8, op, yc) KG_CHAIN_CASE(9, op, yc)
 template <int N>
 KG_HD void macs(uint64_t& acc, const uint32_t (&x)[N], const uint32_t (&y)[N]) {
   static_assert(N >= 1 && N <= 9, "one column of a 9-limb product");
 #ifdef KG_ASM_MAC
   uint64_t cy;
-  if constexpr (N == 1) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]));
-  else if constexpr (N == 2) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]));
-  else if constexpr (N == 3) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
-  else if constexpr (N == 4) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
-  else if constexpr (N == 5) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]));
-  else if constexpr (N == 6) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]));
-  else if constexpr (N == 7) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" "v_mad_u64_u32 %0, %1, %14, %15, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]));
-  else if constexpr (N == 8) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" "v_mad_u64_u32 %0, %1, %14, %15, %0\n\t" "v_mad_u64_u32 %0, %1, %16, %17, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]));
-  else if constexpr (N == 9) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" "v_mad_u64_u32 %0, %1, %14, %15, %0\n\t" "v_mad_u64_u32 %0, %1, %16, %17, %0\n\t" "v_mad_u64_u32 %0, %1, %18, %19, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]));
+  KG_CHAIN_CASES("v_mad_u64_u32", KG_Y_VGPR)
 #else
   for (int j = 0; j < N; ++j) acc += (uint64_t)x[j] * y[j];
 #endif
@@ -99,15 +117,7 @@ KG_HD void macs_k(uint64_t& acc, const uint32_t (&x)[N], const uint32_t (&y)[N])
   static_assert(N >= 1 && N <= 9, "one column of a 9-limb product");
 #ifdef KG_ASM_MAC
   uint64_t cy;
-  if constexpr (N == 1) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]));
-  else if constexpr (N == 2) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]));
-  else if constexpr (N == 3) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]));
-  else if constexpr (N == 4) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]));
-  else if constexpr (N == 5) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]));
-  else if constexpr (N == 6) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]));
-  else if constexpr (N == 7) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" "v_mad_u64_u32 %0, %1, %14, %15, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]));
-  else if constexpr (N == 8) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" "v_mad_u64_u32 %0, %1, %14, %15, %0\n\t" "v_mad_u64_u32 %0, %1, %16, %17, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]));
-  else if constexpr (N == 9) asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\t" "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t" "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t" "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t" "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t" "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t" "v_mad_u64_u32 %0, %1, %14, %15, %0\n\t" "v_mad_u64_u32 %0, %1, %16, %17, %0\n\t" "v_mad_u64_u32 %0, %1, %18, %19, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]));
+  KG_CHAIN_CASES("v_mad_u64_u32", KG_Y_SGPR)
 #else
   for (int j = 0; j < N; ++j) acc += (uint64_t)x[j] * y[j];
 #endif
@@ -117,15 +127,7 @@ KG_HD void macs_i(int64_t& acc, const int32_t (&x)[N], const int32_t (&y)[N]) {
   static_assert(N >= 1 && N <= 9, "one column of a 9-limb product");
 #ifdef KG_ASM_MAC
   uint64_t cy;
-  if constexpr (N == 1) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]));
-  else if constexpr (N == 2) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]));
-  else if constexpr (N == 3) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
-  else if constexpr (N == 4) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
-  else if constexpr (N == 5) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t" "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]));
-  else if constexpr (N == 6) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t" "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t" "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]));
-  else if constexpr (N == 7) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t" "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t" "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t" "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]));
-  else if constexpr (N == 8) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t" "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t" "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t" "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t" "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]));
-  else if constexpr (N == 9) asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t" "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t" "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t" "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t" "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t" "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t" "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t" "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t" "v_mad_i64_i32 %0, %1, %18, %19, %0\n\t" : "+v"(acc), "=&s"(cy) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]));
+  KG_CHAIN_CASES("v_mad_i64_i32", KG_Y_VGPR)
 #else
   for (int j = 0; j < N; ++j) acc += (int64_t)x[j] * (int64_t)y[j];
 #endif
@@ -135,7 +137,7 @@ template <int N>
 KG_HD void macs(int64_t& acc, const uint32_t (&x)[N], const uint32_t (&y)[N]) { uint64_t u = (uint64_t)acc; macs(u, x, y); acc = (int64_t)u; }
 template <int N>
 KG_HD void macs_k(int64_t& acc, const uint32_t (&x)[N], const uint32_t (&y)[N]) { uint64_t u = (uint64_t)acc; macs_k(u, x, y); acc = (int64_t)u; }
-// column k of x * y: sum over i in [LO, HI] of x[i] * y[k - i]  (Y0: index of y[0] inside the array passed, for the constant tables)
+// column K of x * y: sum over i in [LO, HI] of x[i] * y[K - i]
 template <int K, int LO, int HI, class Acc, class X, class Y>
 KG_HD void mac_col(Acc& acc, const X& x, const Y& y) {
   if constexpr (HI >= LO) {
