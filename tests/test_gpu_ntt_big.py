@@ -125,13 +125,13 @@ def test_huge_sizes_by_device_side_properties(ctx, pyoracle, k):
 
 
 _PLAN_SCRIPT = r"""
-import sys
+import os, sys
 sys.path.insert(0, %r)
 import numpy as np
 import kogarashi_amd as K
 from oracle import oracle as O
 ctx = K.Context(0)
-for k in (13, 18, 20):
+for k in [int(a) for a in os.environ.get("KG_TEST_NTT_SIZES", "13,18,20").split(",")]:
     v = O.gen_scalars(0, 0x4B6F676172617368 + 900 + k, 0, 1 << k)
     fo, fg = O.Fft(k), K.Fft(k, ctx=ctx)
     assert (fg.dft(v) == fo.dft(v, threads=8)).all(), ("dft", k)
@@ -142,10 +142,12 @@ print("ok")
 
 
 @pytest.mark.parametrize("env", [{"KG_NTT_STEPS": "3"}, {"KG_NTT_STEPS": "3", "KG_NTT_TILE": "10"}, {"KG_NTT_TILE": "11"},
-                                 {"KG_NTT_DIRECT_MAX_LOG": "0"}, {"KG_NTT_DIRECT_MAX_LOG": "0", "KG_NTT_STEPS": "3"}])
+                                 {"KG_NTT_DIRECT_MAX_LOG": "0"}, {"KG_NTT_DIRECT_MAX_LOG": "0", "KG_NTT_STEPS": "3"},
+                                 {"KG_NTT_STEPS": "2", "KG_TEST_NTT_SIZES": "22"}, {"KG_NTT_TILE": "11", "KG_TEST_NTT_SIZES": "22"}])
 def test_every_plan_knob_gives_the_same_transform(env):
-    """the plan knobs are read once per process: three-step plans, other tile sizes and the table-free inter-step twiddles
-    (two-level composition instead of the direct table) against the oracle, each in a child process"""
+    """the plan knobs are read once per process: three-step plans, other tile sizes, the table-free inter-step twiddles
+    (two-level composition instead of the direct table) and the two-step form of 2^22 (4096-element tiles; the automatic plan
+    there has three steps) against the oracle, each in a child process"""
     import os
     import subprocess
     import sys
