@@ -340,7 +340,7 @@ def pmc_traffic(log_n):
     return None
 
 
-def bench_ntt(ctx, torch, dev, K, env, log_n=22, steps=10):
+def bench_ntt(ctx, torch, dev, K, env, log_n=22, steps=10, warmup=100):
     """secondary line: forward Fr NTT at 2^22 (BASELINE.json configs[2]), 64 algorithmic bytes per element.  The transform
     does not shard (it would need an all-to-all transpose): with N ranks every rank transforms its own vector
     (replicas) and `value` is the aggregate."""
@@ -348,7 +348,7 @@ def bench_ntt(ctx, torch, dev, K, env, log_n=22, steps=10):
     n = 1 << log_n
     data = torch.empty(n * 4, dtype=torch.int64, device=dev)
     ctx.gen_scalars(K.KG_FR, SEED + 3, rank * n, n, data.data_ptr())
-    for _ in range(2):
+    for _ in range(warmup):       # untimed: tables, first touch, and the clock ramp after the CPU legs (the GPU sat idle behind them)
         ctx.ntt(data.data_ptr(), log_n, False, False)
     ctx.sync()
     # the library brackets every transform with HIP events on the queue it launches on ("ntt" phase)
@@ -366,7 +366,8 @@ def bench_ntt(ctx, torch, dev, K, env, log_n=22, steps=10):
     gbs = 64.0 * n / (ms * 1e-3) / 1e9
     mads, kernel_note, plan = ntt_cost(K, log_n)
     out = {"metric": "bn254_fr_ntt_elements_per_sec", "log_n": log_n, "value": world * n / (wall_ms * 1e-3), "ms": ms, "wall_ms": wall_ms,
-           "replicas": world, "note": "value = replicas x n / wall time per transform (max over ranks); ms = HIP-event duration of one transform on rank 0",
+           "replicas": world, "steps": steps, "warmup": warmup,
+           "note": "value = replicas x n / wall time per transform (max over ranks); ms = HIP-event duration of one transform on rank 0",
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes": 64 * n, "kernel": kernel_note},
            "plan": [{"log_m": m, "log_tile": t} for m, t in plan]}
