@@ -19,7 +19,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d "$O/pmc_$c" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-groth16 --no-nova > "$O/pmc_$c.json" 2> "$O/pmc_$c.err"
 done
 # 5. the transform alone (2^22 forward NTT: the two k_ntt_tile kernels without the prover's 2^18 launches in the averages)
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_ntt" -- python3 bench.py --ntt-only --steps 20 > "$O/ntt_under_rocprof.json" 2> "$O/kt_ntt.err"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_ntt" -- python3 bench.py --ntt-only --steps 300 > "$O/ntt_under_rocprof.json" 2> "$O/kt_ntt.err"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d "$O/pmcntt_$c" -- python3 bench.py --ntt-only --steps 10 > "$O/pmcntt_$c.json" 2> "$O/pmcntt_$c.err"
 done
