@@ -41,12 +41,16 @@ def ntt_cost(K, log_n):
     """Multiply-accumulates per element and a description of the kernels of a 2^log_n transform, from the library's own plan
     (kg_ntt_plan).  A step of 2^m points has m radix-2 stages; stage 1 has no twiddle products, stage 2 on half of its butterflies,
     every later stage half a product per element: m/2 - 0.75 in-tile products per element in Shoup form (fp29.h mulc: 143
-    multiply-accumulates), plus one Montgomery product (162) per element between two steps."""
+    multiply-accumulates), plus one Montgomery product (162) per element between two steps; above 2^22 (ntt.hip direct_a_max_log,
+    KG_NTT_DIRECT_MAX_LOG) the first boundary composes its twiddle from two table entries (one more product) instead of reading it
+    from a table of n entries (36 B of HBM traffic per element)."""
     plan = K.lib.ntt_plan(log_n)
-    mads = sum((m / 2 - 0.75) * 143 for m, _ in plan) + (len(plan) - 1) * 162
+    direct_a = len(plan) >= 2 and log_n <= min(22, int(os.environ.get("KG_NTT_DIRECT_MAX_LOG", "22")))
+    composed = len(plan) >= 2 and not direct_a
+    mads = sum((m / 2 - 0.75) * 143 for m, _ in plan) + (len(plan) - 1 + (1 if composed else 0)) * 162
     kern = " + ".join(f"k_ntt_tile<2^{m} points, {1 << t}-element tiles>" for m, t in plan)
     note = (f"{kern}: {len(plan)} HBM round trip(s), {64 * len(plan)} B of data moved per element"
-            + (f" + {36 * (len(plan) - 1)} B of inter-step twiddle tables" if len(plan) > 1 else ""))
+            + (" + 36 B of inter-step twiddle table" if direct_a else ""))
     return mads, note, plan
 
 

@@ -143,7 +143,8 @@ print("ok")
 
 @pytest.mark.parametrize("env", [{"KG_NTT_STEPS": "3"}, {"KG_NTT_STEPS": "3", "KG_NTT_TILE": "10"}, {"KG_NTT_TILE": "11"},
                                  {"KG_NTT_DIRECT_MAX_LOG": "0"}, {"KG_NTT_DIRECT_MAX_LOG": "0", "KG_NTT_STEPS": "3"},
-                                 {"KG_NTT_STEPS": "2", "KG_TEST_NTT_SIZES": "22"}, {"KG_NTT_TILE": "11", "KG_TEST_NTT_SIZES": "22"}])
+                                 {"KG_NTT_STEPS": "2", "KG_TEST_NTT_SIZES": "22"}, {"KG_NTT_TILE": "11", "KG_TEST_NTT_SIZES": "22"},
+                                 {"KG_NTT_DIRECT_MAX_LOG": "0", "KG_TEST_NTT_SIZES": "22"}])
 def test_every_plan_knob_gives_the_same_transform(env):
     """the plan knobs are read once per process: three-step plans, other tile sizes, the table-free inter-step twiddles
     (two-level composition instead of the direct table) and the two-step form of 2^22 (4096-element tiles; the automatic plan
