@@ -39,6 +39,23 @@ def test_ntt_plan_is_reported_without_a_device(lib):
     assert lib.ntt_plan(0) == [] and lib.ntt_plan(29) == []
 
 
+def test_no_built_artefact_is_tracked():
+    """the history stays source-only: no ELF object, library or microbenchmark binary among the tracked files"""
+    import subprocess
+    try:
+        files = subprocess.run(["git", "ls-files"], cwd=ROOT, capture_output=True, text=True, check=True).stdout.split()
+    except (OSError, subprocess.CalledProcessError):
+        pytest.skip("not a git checkout")
+    elf = []
+    for f in files:
+        path = os.path.join(ROOT, f)
+        if os.path.isfile(path):
+            with open(path, "rb") as fh:
+                if fh.read(4) == b"\x7fELF":
+                    elf.append(f)
+    assert not elf, elf
+
+
 def test_no_cpu_fallback_without_device(lib):
     import torch
     if torch.cuda.is_available():
