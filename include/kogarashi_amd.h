@@ -47,7 +47,7 @@ enum { KG_G1 = 0, KG_GRUMPKIN = 1, KG_G2 = 2 };      /* curve ids */
 
 typedef struct kg_ctx kg_ctx;
 
-int kg_version(void);                    /* 3: the last extension added kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded; only additions since 1 */
+int kg_version(void);                    /* 3: the last extension added kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
 /* Optional process-level setup; call it (or export the variable yourself) BEFORE anything in the process initialises the
  * HIP runtime -- before the first kg_device_count / kg_ctx_create and before any other HIP user -- and before the host
  * starts threads (it calls setenv).  Sets GPU_MAX_HW_QUEUES=16 unless the variable is already set, so that each of a
