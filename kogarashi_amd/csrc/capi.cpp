@@ -14,6 +14,8 @@ void sync_all(kg_ctx* c) {
   if (c->own_stream && c->own_stream != c->stream) hipStreamSynchronize(c->own_stream);
   for (hipStream_t s : {c->sort_stream, c->side_stream, c->side2_stream, c->up_stream})
     if (s) hipStreamSynchronize(s);
+  for (hipStream_t s : c->acc_stream)
+    if (s) hipStreamSynchronize(s);
 }
 int ensure_ws_sort(kg_ctx* c, int set, size_t bytes) {
   if (bytes <= c->ws_sort_bytes[set]) return KG_OK;
@@ -42,12 +44,17 @@ int make_sort_stream(kg_ctx* c) {
   hipError_t e = create_stream(c, &c->sort_stream, true);
   if (e != hipSuccess) return set_err(c, KG_ERR_HIP, "scalar-queue creation", e);
   for (int i = 0; i < 2; ++i) {
-    if ((e = hipEventCreateWithFlags(&c->ev_sorted[i], hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
+    for (int g = 0; g < kg_ctx::MAX_GROUPS; ++g)
+      if ((e = hipEventCreateWithFlags(&c->ev_sorted[i][g], hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
     for (int j = 0; j < kg_ctx::IDLE_EVS; ++j)
       if ((e = hipEventCreateWithFlags(&c->ev_ws_idle[i][j], hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
   }
   if ((e = hipEventCreateWithFlags(&c->ev_bases, hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
   if ((e = hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
+  if ((e = hipEventCreateWithFlags(&c->ev_pb, hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
+  if ((e = hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
+  for (int g = 0; g < kg_ctx::MAX_GROUPS; ++g)
+    if ((e = hipEventCreateWithFlags(&c->ev_info[g], hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
   return KG_OK;
 }
 int ensure_ws_vec(kg_ctx* c, size_t bytes) {
@@ -93,9 +100,10 @@ int ensure_slot(kg_ctx* c, int slot, size_t bytes) {
   if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation");
   if (bytes <= s.bytes) return KG_OK;
   if (s.host) hipHostFree(s.host);
-  s.host = nullptr; s.bytes = 0;
+  s.host = nullptr; s.host_dev = nullptr; s.bytes = 0;
   hipError_t e = hipHostMalloc(&s.host, bytes, hipHostMallocDefault);
   if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "pinned slot allocation", e);
+  if ((e = hipHostGetDevicePointer(&s.host_dev, s.host, 0)) != hipSuccess) return set_err(c, KG_ERR_HIP, "pinned slot device view", e);
   s.bytes = bytes;
   return KG_OK;
 }
@@ -115,6 +123,7 @@ int ensure_pinned(kg_ctx* c, size_t bytes) {
   c->h_pinned = nullptr; c->h_pinned_bytes = 0;
   hipError_t e = hipHostMalloc(&c->h_pinned, bytes, hipHostMallocDefault);
   if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "pinned staging allocation", e);
+  if ((e = hipHostGetDevicePointer(&c->h_pinned_dev, c->h_pinned, 0)) != hipSuccess) return set_err(c, KG_ERR_HIP, "pinned staging device view", e);
   c->h_pinned_bytes = bytes;
   return KG_OK;
 }
@@ -198,7 +207,7 @@ void kg_ctx_destroy(kg_ctx* c) {
   tw_cache_free(c);
   for (int i = 0; i < 2; ++i) {
     if (c->ws_sort[i]) hipFree(c->ws_sort[i]);
-    if (c->ev_sorted[i]) hipEventDestroy(c->ev_sorted[i]);
+    for (int g = 0; g < kg_ctx::MAX_GROUPS; ++g) if (c->ev_sorted[i][g]) hipEventDestroy(c->ev_sorted[i][g]);
     for (int j = 0; j < kg_ctx::IDLE_EVS; ++j) if (c->ev_ws_idle[i][j]) hipEventDestroy(c->ev_ws_idle[i][j]);
   }
   if (c->ev_bases) hipEventDestroy(c->ev_bases);
@@ -213,7 +222,13 @@ void kg_ctx_destroy(kg_ctx* c) {
   if (c->side2_stream) { hipStreamSynchronize(c->side2_stream); hipStreamDestroy(c->side2_stream); }
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   for (int i = 0; i < 3; ++i) if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
-  if (c->ev_info) hipEventDestroy(c->ev_info);
+  for (int g = 0; g < kg_ctx::MAX_GROUPS; ++g) {
+    if (c->ev_info[g]) hipEventDestroy(c->ev_info[g]);
+    if (c->acc_stream[g]) { hipStreamSynchronize(c->acc_stream[g]); hipStreamDestroy(c->acc_stream[g]); }
+  }
+  if (c->ev_pb) hipEventDestroy(c->ev_pb);
+  if (c->ev_prep) hipEventDestroy(c->ev_prep);
+  if (c->ws_pb) hipFree(c->ws_pb);
   for (auto& sl : c->slots) { if (sl.host) hipHostFree(sl.host); if (sl.done) hipEventDestroy(sl.done); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
   for (void* b : c->up_buf) if (b) hipFree(b);
@@ -246,6 +261,8 @@ int kg_ctx_sync(kg_ctx* c) {
   KG_HIP(c, hipSetDevice(c->device));
   KG_HIP(c, hipStreamSynchronize(c->stream));
   for (hipStream_t s : {c->sort_stream, c->side_stream, c->side2_stream})
+    if (s) KG_HIP(c, hipStreamSynchronize(s));
+  for (hipStream_t s : c->acc_stream)
     if (s) KG_HIP(c, hipStreamSynchronize(s));
   return KG_OK;
 }

@@ -26,7 +26,18 @@ struct kg_ctx {
   size_t ws_sort_bytes[2] = {0, 0};
   unsigned sort_seq = 0;
   hipStream_t sort_stream = nullptr;     // scalar-side queue (prep_scalars, sort, task bookkeeping); == stream when no overlap is possible
-  hipEvent_t ev_sorted[2] = {nullptr, nullptr};     // sort of the set complete (recorded on the scalar queue)
+  // A blocking MSM pipelines against itself by WINDOW GROUPS (msm.hip, kg_msm): the scalars are converted once, then the
+  // windows are sorted, accumulated and reduced group by group, top windows first -- group g+1 is sorted under group g's
+  // accumulation, group g is reduced under group g+1's accumulation, and the host's double-and-add chain starts with the top
+  // group's sums while the lower groups are still on the device.  No extra work (index slices add reduction tails).
+  static constexpr int MAX_GROUPS = 4;
+  hipEvent_t ev_sorted[2][MAX_GROUPS] = {};         // sort of the set's window group complete (recorded on the scalar queue)
+  hipStream_t acc_stream[MAX_GROUPS] = {};          // accumulation queues of window groups 1.. (group 0: the main queue), so that the
+                                                    // groups' launches share the chip instead of draining one after the other
+  void* ws_pb = nullptr;                            // per-call resident form of the bases, shared by the window groups of one MSM
+  size_t ws_pb_bytes = 0;
+  hipEvent_t ev_pb = nullptr;                       // its conversion complete
+  hipEvent_t ev_prep = nullptr;                     // scalar conversion on the main queue complete (the scalar queue's sorts follow it)
   static constexpr int IDLE_EVS = 8;                // readers of one set whose completion the next sort into it waits for
   hipEvent_t ev_ws_idle[2][IDLE_EVS] = {};          // a bucket gather that read the set's level tables is complete (reduction queues)
   int ws_idle_n[2] = {0, 0};
@@ -47,9 +58,9 @@ struct kg_ctx {
   hipStream_t side2_stream = nullptr;    // second reduction queue (odd slots): a slow G2 reduction does not hold up the next MSM's
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_acc[RUN_SETS] = {};
-  hipEvent_t ev_info = nullptr;          // marks the task-count read-back of msm_sort
-  struct Slot { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0; bool busy = false; };
-  static constexpr int NSLOTS = 20;      // 0 kg_msm, 1..4 kg_msm_begin tickets, 6..10 prover job 0, 11..15 prover job 1, 16..19 slices of kg_msm_host (disjoint: calls may interleave)
+  hipEvent_t ev_info[MAX_GROUPS] = {};   // marks the task-count read-back of msm_sort (per window group)
+  struct Slot { void* host = nullptr; void* host_dev = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0, w0 = 0; bool busy = false; };   // w0: first window of the group the slot holds
+  static constexpr int NSLOTS = 24;      // 0 kg_msm, 1..4 kg_msm_begin tickets, 6..10 prover job 0, 11..15 prover job 1, 16..19 slices of kg_msm_host / window groups of kg_msm (disjoint: calls may interleave)
   Slot slots[NSLOTS];
   std::shared_ptr<void> prover_jobs;     // groth16.hip: proofs in flight (kg_groth16_prove_begin / _end)
   size_t ticket_n[4] = {0, 0, 0, 0};
@@ -71,6 +82,7 @@ struct kg_ctx {
   size_t fb_tmp_bytes = 0;
   uint32_t* fb_table[3] = {nullptr, nullptr, nullptr};   // kg_fixed_base_mul: 32 x 255 generator multiples d * 2^(8w) * G per curve, resident form
   void* h_pinned = nullptr;              // small pinned staging buffer for results
+  void* h_pinned_dev = nullptr;          // its device view (kernels write the sort's result words straight into it)
   size_t h_pinned_bytes = 0;
   std::vector<kg_tw_cache*> tw;          // per-(log_n, inverse) twiddle tables
   bool tw_fresh = false;                 // tables were built on the main queue since the last fork (transform lanes must wait for them)
@@ -234,6 +246,12 @@ struct MsmSorted {
   uint32_t *task_bkt = nullptr, *task_id = nullptr;
   int set = 0;                // which scalar-side space it lives in
   hipEvent_t ready = nullptr; // recorded on the scalar queue after the last sort kernel
+  // window group (kg_msm): this object covers windows [w0, w0 + W) of an MSM with `windows_total` windows; its pointers are
+  // offset to the group, so the base side treats it like an MSM of W windows.  group = index of its read-back words / events.
+  int w0 = 0, group = 0;
+  hipStream_t acc_stream = nullptr;   // queue of the group's accumulation (nullptr: the context's main queue)
+  bool reduce_inline = false;         // the bucket reduction follows the accumulation on the same queue
+  hipStream_t sorted_on = nullptr;    // queue the sort was enqueued on
   // merged sort (bases with window tables): the digits of all windows share ONE set of B buckets; W = 1 above, windows = the
   // real window count, an entry's index field is (window << merged_shift) | scalar index
   int merged_shift = 0, windows = 0;
@@ -253,16 +271,43 @@ int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, ui
 int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered = false, int merged_c = 0, int lane_mult = 1,
              bool wait_info = true);
 int msm_sort_wait(kg_ctx* ctx, MsmSorted* S);
+// The same sort in two steps, for window groups: msm_sort_begin converts the scalars and lays the space out for `ngroups`
+// groups of gw[0], gw[1], ... windows counted from the TOP window down (ngroups = 1: all windows; groups need the two-pass
+// sort, see msm_group_plan); msm_sort_group enqueues group g's sort (any order, each once) and msm_sort_wait reads its two
+// result words back.
+struct MsmSortPlan {
+  size_t n = 0, chunk_len = 0, nv = 0;
+  int c = 0, W = 0, B = 0, Wb = 0, G = 0, nch = 0, maxseg = 0, mshift = 0, set = 0, ngroups = 1;
+  bool merged = false, two_pass = false;
+  uint32_t T = 0;
+  int gw0[kg_ctx::MAX_GROUPS] = {}, gW[kg_ctx::MAX_GROUPS] = {};
+  char* ws = nullptr;
+  size_t o_kt = 0, o_cnt = 0, o_bsize = 0, o_bstart = 0, o_tmp = 0, o_gsize = 0, o_gstart = 0, o_segbase = 0, o_segcnt = 0, o_segoff = 0, o_sorted = 0,
+         o_lcnt = 0, o_lrel = 0, o_rowtot = 0, o_bpart = 0, o_woff = 0, o_gsize_m = 0, o_gstart_m = 0, o_segbase_m = 0;
+  size_t o_lbase[kg_ctx::MAX_GROUPS] = {}, o_misc[kg_ctx::MAX_GROUPS] = {}, o_lenh[kg_ctx::MAX_GROUPS] = {}, o_tbkt[kg_ctx::MAX_GROUPS] = {},
+         o_tid[kg_ctx::MAX_GROUPS] = {}, part_cap[kg_ctx::MAX_GROUPS] = {};
+};
+int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSortPlan* P, bool ordered, int merged_c, int lane_mult,
+                   int ngroups = 1, const int* gw = nullptr, bool on_main = false);
+int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& P, int g, MsmSorted* S, bool on_main = false);
+// window groups a blocking n-pair MSM is cut into (0 = not offered: one-pass sort, merged sort); gw[g] = windows of group g, top first
+int msm_group_plan(const kg_ctx* ctx, size_t n, int* gw);
 int merged_window(const kg_ctx* ctx, size_t n);       // window width of the merged form for an n-scalar MSM, 0 = not offered at this length
 // does this registered array carry a window table that serves an n-scalar merged MSM?  (d_inf must be the registered flag array)
 bool has_window_table(const kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, size_t msm_len);
 int scalar_queue(kg_ctx* ctx, hipStream_t* out);     // the scalar-side queue, created on first use
 // several base arrays against one scalar sort, accumulated by one launch (at most 3; result slots in distinct run-space sets)
 // bases_complete: the base array is complete in device memory when the call is made (no ordering against the main queue)
-struct MsmRunJob { const uint64_t* d_bases; const uint8_t* d_inf; size_t nbases; uint32_t idx_off; int slot; bool bases_complete = false; };
+// packed: the caller holds the array's resident form already (kg_msm converts once for all its window groups); the job's
+// queue must be ordered behind its producer by the caller
+struct MsmRunJob { const uint64_t* d_bases; const uint8_t* d_inf; size_t nbases; uint32_t idx_off; int slot; bool bases_complete = false;
+                   const uint32_t* packed = nullptr; bool packed64 = false; };
 int msm_run_multi(kg_ctx* ctx, const MsmSorted& S, int curve, const MsmRunJob* jobs, int njobs);
 int msm_run(kg_ctx* ctx, const MsmSorted& S, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, uint32_t idx_off, int slot);
 int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz);
+// the same over the slots of an MSM's window groups, top group first: one double-and-add chain, each slot awaited when the
+// chain reaches its windows
+int msm_finish_groups(kg_ctx* ctx, int curve, const int* slots, int nslots, uint64_t* out_xyz);
 void msm_identity(int curve, uint64_t* out_xyz);
 
 }  // namespace kg

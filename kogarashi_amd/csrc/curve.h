@@ -141,6 +141,82 @@ KG_HD XYZZ<F> add_xyzz(const XYZZ<F>& p, const XYZZ<F>& q_) {
   return {x3, y3, mul(mul(p.zz, q_.zz), pp), mul(mul(p.zzz, q_.zzz), ppp)};
 }
 
+// P + Q and 2P with the operands read coordinate by coordinate through accessors (x(), y(), zz(), zzz() return a field
+// element) and the result written the same way (x(v), ...): the operations of add_xyzz / double_xyzz in an order that keeps at
+// most six field elements live, so that a kernel built on it fits the registers a resident accumulation leaves free
+// (k_halve: 96 VGPRs instead of 160, no scratch).  A coordinate that is needed twice is read twice -- the second read comes out of
+// the cache.  The output must not alias the inputs.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KG_STREAM_FENCE() __asm__ volatile("" ::: "memory")     // keeps a later read of a coordinate from being merged with an earlier one
+#else
+#define KG_STREAM_FENCE() ((void)0)
+#endif
+template <class F, class A, class D>
+KG_HD void double_xyzz_stream(const A& p, D& out) {      // p is not the identity
+  F v, w;
+  {
+    const F u = norm(dbl(p.y()));
+    v = sqr(u);
+    w = mul(u, v);
+  }
+  KG_STREAM_FENCE();
+  out.zz(mul(v, p.zz()));
+  KG_STREAM_FENCE();
+  out.zzz(mul(w, p.zzz()));
+  KG_STREAM_FENCE();
+  F s, m;
+  {
+    const F x = p.x();
+    s = mul(x, v);
+    const F xx = sqr(x);
+    m = norm(add(dbl(xx), xx));
+  }
+  const F x3 = vred(norm(sub<4, 1>(sqr(m), norm(dbl(s)))));
+  out.x(x3);
+  KG_STREAM_FENCE();
+  out.y(vred(norm(sub<4, 1>(mul(m, norm(sub<4, 1>(s, x3))), mul(w, p.y())))));
+}
+template <class F, class A, class D>
+KG_HD void copy_xyzz_stream(const A& p, D& out) { out.x(p.x()); out.y(p.y()); out.zz(p.zz()); out.zzz(p.zzz()); }
+
+template <class F, class A, class B, class D>
+KG_HD void add_xyzz_stream(const A& p, const B& q_, D& out) {
+  F u1, pp_, zz12;
+  {
+    const F zz1 = p.zz(), zz2 = q_.zz();
+    if (is_zero_2p(zz1)) { copy_xyzz_stream<F>(q_, out); return; }
+    if (is_zero_2p(zz2)) { copy_xyzz_stream<F>(p, out); return; }
+    u1 = mul(p.x(), zz2);
+    KG_STREAM_FENCE();
+    pp_ = norm(sub<4, 1>(mul(q_.x(), zz1), u1));
+    zz12 = mul(zz1, zz2);
+  }
+  KG_STREAM_FENCE();
+  F s1, r;
+  {
+    s1 = mul(p.y(), q_.zzz());
+    KG_STREAM_FENCE();
+    r = norm(sub<4, 1>(mul(q_.y(), p.zzz()), s1));
+  }
+  KG_STREAM_FENCE();
+  const F pp = sqr(pp_);
+  if (is_zero_2p(pp)) {                 // weierstrass.rs:114-120
+    if (is_zero(r)) { double_xyzz_stream<F>(p, out); return; }
+    const F z = F::zero();
+    out.x(z); out.y(z); out.zz(z); out.zzz(z);
+    return;
+  }
+  const F ppp = mul(pp_, pp);
+  const F q = mul(u1, pp);
+  out.zz(mul(zz12, pp));
+  KG_STREAM_FENCE();
+  out.zzz(mul(mul(p.zzz(), q_.zzz()), ppp));
+  KG_STREAM_FENCE();
+  const F x3 = vred(norm(sub<8, 3>(sqr(r), add(ppp, dbl(q)))));   // PPP + 2Q stays lazy, as in add_xyzz
+  out.x(x3);
+  out.y(mul2sub(r, norm(sub<4, 1>(q, x3)), s1, ppp));
+}
+
 // -P
 template <class F>
 KG_HD XYZZ<F> neg_xyzz(const XYZZ<F>& p) { return {p.x, vred(norm(sub<4, 1>(F::zero(), p.y))), p.zz, p.zzz}; }

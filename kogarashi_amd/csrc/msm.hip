@@ -22,6 +22,7 @@
 #include "fp2s.h"
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 
 using namespace kg;
@@ -482,12 +483,12 @@ constexpr uint32_t MULTI_SEG = 0x80000000u;          // flag in a window's segme
 constexpr int GS_NT = 256, GS_TILE = 1024, GS_MAXG = 1024;
 __global__ void __launch_bounds__(GS_NT) k_group_scatter(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len, int G,
                                                          const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ gstart,
-                                                         uint32_t* __restrict__ tmp, const uint32_t* __restrict__ woff, int mshift) {
+                                                         uint32_t* __restrict__ tmp, const uint32_t* __restrict__ woff, int mshift, int w0) {
   KG_SERVICE_PRIO();
   __shared__ uint32_t cursor[GS_MAXG], hist[GS_MAXG], lstart[GS_MAXG], sh[40];    // hist doubles as the tile's address delta
   __shared__ uint32_t stage[GS_TILE];
   __shared__ uint16_t sg[GS_TILE];
-  const int w = blockIdx.x, ch = blockIdx.y, nch = gridDim.y, tid = threadIdx.x;
+  const int w = (int)blockIdx.x + w0, ch = blockIdx.y, nch = gridDim.y, tid = threadIdx.x;   // w0: first window of the group being sorted (all tables are indexed by the absolute window)
   const int per = (G + GS_NT - 1) / GS_NT;            // groups a lane owns in the scans (consecutive; <= 4)
   // merged sort (woff != nullptr): all windows share one run per group -- gstart is the merged table, woff[w][g] the entries
   // of the windows in front of w inside the group's run, and the window number rides in the entry above the scalar index
@@ -547,11 +548,14 @@ __global__ void __launch_bounds__(GS_NT) k_group_scatter(const uint32_t* __restr
 
 // One workgroup per window, one lane per bucket group: exclusive prefix of the group's counters over the chunks (in
 // place), group sizes and starts, the segment table, and the window's bucket sizes zeroed for k_fine_local.
+// (workgroup 0 also clears the `zwords` words at `zero`: the task decomposition's counters and length histogram)
 __global__ void __launch_bounds__(GS_NT) k_group_scan(uint32_t* __restrict__ cnt, int nch, int G, int B, uint32_t* __restrict__ gsize,
-                                                       uint32_t* __restrict__ gstart, uint32_t* __restrict__ segbase, uint32_t* __restrict__ bsize) {
+                                                       uint32_t* __restrict__ gstart, uint32_t* __restrict__ segbase, uint32_t* __restrict__ bsize,
+                                                       uint32_t* __restrict__ zero, int zwords) {
   KG_SERVICE_PRIO();
   __shared__ uint32_t sh[40];
   const int w = blockIdx.x, tid = threadIdx.x;
+  if (w == 0) for (int t = tid; t < zwords; t += GS_NT) zero[t] = 0;
   const int per = (G + GS_NT - 1) / GS_NT;            // consecutive groups per lane (<= 4)
   uint32_t run[4], ns[4], rsum = 0, nsum = 0;
 #pragma unroll
@@ -711,6 +715,7 @@ __global__ void __launch_bounds__(512) k_fine_local(const uint32_t* __restrict__
   for (uint32_t p = threadIdx.x; p < len; p += blockDim.x) dst[p] = stage[p];
 }
 
+constexpr int FS_ROWS = 64;                          // workgroups per window: a workgroup walks the window's segments in steps of gridDim.y
 __global__ void __launch_bounds__(512) k_fine_scatter(const uint32_t* __restrict__ tmp, size_t n, int G, int B, int maxseg,
                                                       const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gsize,
                                                       const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ bstart,
@@ -721,42 +726,47 @@ __global__ void __launch_bounds__(512) k_fine_scatter(const uint32_t* __restrict
   __shared__ uint32_t lstart[FINE], cursor[FINE], gbase[FINE], wsum;
   __shared__ uint32_t stage[SEG];
   const int w = blockIdx.x;
-  const uint32_t s = blockIdx.y;
-  if (!(segbase[(size_t)w * (G + 1) + G] & MULTI_SEG)) return;      // every group of this window is one segment: k_fine_local did it all
+  // every group of this window is one segment (any uniform input): k_fine_local did it all.  (A launch of one workgroup per
+  // segment that only returned cost 36 us per 2^20-pair sort: hence the few rows and the loop.)
+  if (!(segbase[(size_t)w * (G + 1) + G] & MULTI_SEG)) return;
   for (int g = threadIdx.x; g <= G; g += blockDim.x) sb[g] = segbase[(size_t)w * (G + 1) + g];
   __syncthreads();
-  SegRange r;
-  if (!seg_locate(sb, G, s, gstart, gsize, w, r)) return;
-  if (gsize[(size_t)w * G + r.g] <= (uint32_t)SEG) return;       // done by k_fine_local
-  uint32_t cnt = 0, inc = 0;
-  if (threadIdx.x < FINE) {                          // exclusive prefix of the segment's FINE counters (two waves)
-    const size_t o = ((size_t)w * maxseg + s) * FINE + threadIdx.x;
-    cnt = segcnt[o];
-    gbase[threadIdx.x] = bstart[(size_t)w * B + (size_t)r.g * FINE + threadIdx.x] + segoff[o];
-    inc = cnt;
-    const int lane = threadIdx.x & 63;
+  const uint32_t nseg = sb[G] & ~MULTI_SEG;
+  for (uint32_t s = blockIdx.y; s < nseg; s += gridDim.y) {
+    SegRange r;
+    seg_locate(sb, G, s, gstart, gsize, w, r);
+    if (gsize[(size_t)w * G + r.g] <= (uint32_t)SEG) continue;     // done by k_fine_local (uniform over the workgroup)
+    __syncthreads();                                 // the previous segment's stage / tables are no longer read
+    uint32_t cnt = 0, inc = 0;
+    if (threadIdx.x < FINE) {                          // exclusive prefix of the segment's FINE counters (two waves)
+      const size_t o = ((size_t)w * maxseg + s) * FINE + threadIdx.x;
+      cnt = segcnt[o];
+      gbase[threadIdx.x] = bstart[(size_t)w * B + (size_t)r.g * FINE + threadIdx.x] + segoff[o];
+      inc = cnt;
+      const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t o2 = __shfl_up(inc, d); if (lane >= d) inc += o2; }
-    if (threadIdx.x == 63) wsum = inc;
-  }
-  __syncthreads();
-  if (threadIdx.x < FINE) {
-    const uint32_t ex = inc - cnt + (threadIdx.x >= 64 ? wsum : 0u);
-    lstart[threadIdx.x] = ex;
-    cursor[threadIdx.x] = ex;
-  }
-  __syncthreads();
-  const uint32_t* src = tmp + (size_t)w * n;
-  for (uint32_t i = r.lo + threadIdx.x; i < r.hi; i += blockDim.x) {
-    const uint32_t rec = src[i];
-    stage[atomicAdd(&cursor[(rec >> 24) & (FINE - 1)], 1u)] = rec;
-  }
-  __syncthreads();
-  uint32_t* dst = sorted + (size_t)w * n;
-  const uint32_t len = r.hi - r.lo;
-  for (uint32_t p = threadIdx.x; p < len; p += blockDim.x) {
-    const uint32_t rec = stage[p], f = (rec >> 24) & (FINE - 1);
-    dst[gbase[f] + (p - lstart[f])] = rec & 0x80ffffffu;
+      for (int d = 1; d < 64; d <<= 1) { uint32_t o2 = __shfl_up(inc, d); if (lane >= d) inc += o2; }
+      if (threadIdx.x == 63) wsum = inc;
+    }
+    __syncthreads();
+    if (threadIdx.x < FINE) {
+      const uint32_t ex = inc - cnt + (threadIdx.x >= 64 ? wsum : 0u);
+      lstart[threadIdx.x] = ex;
+      cursor[threadIdx.x] = ex;
+    }
+    __syncthreads();
+    const uint32_t* src = tmp + (size_t)w * n;
+    for (uint32_t i = r.lo + threadIdx.x; i < r.hi; i += blockDim.x) {
+      const uint32_t rec = src[i];
+      stage[atomicAdd(&cursor[(rec >> 24) & (FINE - 1)], 1u)] = rec;
+    }
+    __syncthreads();
+    uint32_t* dst = sorted + (size_t)w * n;
+    const uint32_t len = r.hi - r.lo;
+    for (uint32_t p = threadIdx.x; p < len; p += blockDim.x) {
+      const uint32_t rec = stage[p], f = (rec >> 24) & (FINE - 1);
+      dst[gbase[f] + (p - lstart[f])] = rec & 0x80ffffffu;
+    }
   }
 }
 
@@ -1061,17 +1071,22 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_fill(const uint32_t* __restric
   if (k == nsplit - 1 && threadIdx.x == 0) row_total[w] = base_t + total_t;
 }
 // k_row_bases + k_len_scan in one launch (one wave): window task bases and the descending-length cursors
+// host_info: the two result words go straight into pinned host memory (a copy kernel at the default wave priority crawled
+// beside a resident accumulation: 4 us alone, 69 us there)
 __global__ void __launch_bounds__(64) k_task_bases(const uint32_t* __restrict__ row_total, int W, uint32_t* __restrict__ base,
                                                    const uint32_t* __restrict__ maxv, uint32_t* __restrict__ info,
-                                                   const uint32_t* __restrict__ ghist, uint32_t* __restrict__ cursor) {
+                                                   const uint32_t* __restrict__ ghist, uint32_t* __restrict__ cursor, uint32_t* __restrict__ host_info) {
   KG_SERVICE_PRIO();
   const int lane = threadIdx.x;
   if (lane == 0) {
     uint32_t run = 0;
     for (int w = 0; w < W; ++w) { base[w] = run; run += row_total[w]; }
     base[W] = run;
+    const uint32_t mx = *maxv;
     info[0] = run;
-    info[1] = *maxv;
+    info[1] = mx;
+    host_info[0] = run;
+    host_info[1] = mx;
   }
   static_assert(LEN_BINS == 256, "four bins per lane");
   const uint32_t h0 = ghist[4 * lane], h1 = ghist[4 * lane + 1], h2 = ghist[4 * lane + 2], h3 = ghist[4 * lane + 3];
@@ -1245,23 +1260,135 @@ __global__ void __launch_bounds__(64) k_gather_sum(const uint32_t* __restrict__ 
 // all buckets; sum_b (b+1)*B_b = A + sum_l 2^l T_l.
 // Layout: point (window w, array a, item i) at index (w * narr + a) * len + i of a PointIO buffer.
 // ---------------------------------------------------------------------------------------------------
+// One point of a PointIO buffer (structure of arrays), coordinates read / written on demand (add_xyzz_stream).  Buffer
+// addressing: the descriptor and the limb plane's offset are wave-uniform (SGPRs), the item's byte offset is ONE 32-bit VGPR
+// per point -- flat loads cost a 64-bit address pair per limb plane (72 planes: the compiler kept ~70 VGPRs of addresses
+// live).  The buffers stay far below the 4 GiB a descriptor spans (72 planes x 15 x 2^17 items x 4 B = 566 MB for G2, c = 18).
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ BufRsrc soa_rsrc(const uint32_t* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(base), 0, 0xffffffffu, 0x00020000);
+}
+template <class F> struct SoaLimbs;
+template <class P> struct SoaLimbs<Fp<P>> {
+  static __device__ __forceinline__ Fp<P> load(BufRsrc rs, uint32_t plane, uint32_t stride4, uint32_t off) {     // stride4: bytes per plane
+    Fp<P> r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.l[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, (plane + (uint32_t)k) * stride4, 0);
+    return r;
+  }
+  static __device__ __forceinline__ void store(BufRsrc rs, uint32_t plane, uint32_t stride4, uint32_t off, const Fp<P>& a) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) __builtin_amdgcn_raw_buffer_store_b32(a.l[k], rs, off, (plane + (uint32_t)k) * stride4, 0);
+  }
+};
+template <class G> struct SoaLimbs<Fp2S<G>> {       // the pair's halves: c0 planes, then c1 planes (RawIO<Fp2S>); the half goes into the lane offset
+  static __device__ __forceinline__ Fp2S<G> load(BufRsrc rs, uint32_t plane, uint32_t stride4, uint32_t off) {
+    return {SoaLimbs<G>::load(rs, plane, stride4, off + 9u * (uint32_t)Fp2S<G>::half() * stride4)};
+  }
+  static __device__ __forceinline__ void store(BufRsrc rs, uint32_t plane, uint32_t stride4, uint32_t off, const Fp2S<G>& a) {
+    SoaLimbs<G>::store(rs, plane, stride4, off + 9u * (uint32_t)Fp2S<G>::half() * stride4, a.v);
+  }
+};
+template <class F> struct SoaSrc {
+  BufRsrc rs; uint32_t stride4, off;                 // off = item * 4
+  static constexpr uint32_t E = RawIO<F>::NW;
+  __device__ __forceinline__ F x() const { return SoaLimbs<F>::load(rs, 0, stride4, off); }
+  __device__ __forceinline__ F y() const { return SoaLimbs<F>::load(rs, E, stride4, off); }
+  __device__ __forceinline__ F zz() const { return SoaLimbs<F>::load(rs, 2 * E, stride4, off); }
+  __device__ __forceinline__ F zzz() const { return SoaLimbs<F>::load(rs, 3 * E, stride4, off); }
+};
+template <class F> struct SoaDst {
+  BufRsrc rs; uint32_t stride4, off;
+  static constexpr uint32_t E = RawIO<F>::NW;
+  __device__ __forceinline__ void x(const F& v) { SoaLimbs<F>::store(rs, 0, stride4, off, v); }
+  __device__ __forceinline__ void y(const F& v) { SoaLimbs<F>::store(rs, E, stride4, off, v); }
+  __device__ __forceinline__ void zz(const F& v) { SoaLimbs<F>::store(rs, 2 * E, stride4, off, v); }
+  __device__ __forceinline__ void zzz(const F& v) { SoaLimbs<F>::store(rs, 3 * E, stride4, off, v); }
+};
+template <class F> struct HalveWaves { static constexpr int MIN = 5; };
+template <class G> struct HalveWaves<Fp2S<G>> { static constexpr int MIN = 4; };     // 110 VGPRs as it comes (was 170); nothing fits beside a G2 accumulation anyway
+#ifndef KG_HALVE_ATTR
+#define KG_HALVE_ATTR __attribute__((amdgpu_waves_per_eu(HalveWaves<F>::MIN)))
+#endif
+// Five waves per SIMD = 96 VGPRs: what four resident accumulation waves (4 x 104) leave free, so a halving level runs beside
+// an accumulation instead of waiting for its tail.  With both operands loaded up front the kernel took 160.
 template <class F>
-__global__ void __launch_bounds__(64) k_halve(const uint32_t* __restrict__ in, size_t in_stride, uint32_t* __restrict__ out, size_t out_stride,
+__global__ void __launch_bounds__(64) KG_HALVE_ATTR k_halve(const uint32_t* in, size_t in_stride, uint32_t* out, size_t out_stride,
                                               int W, int narr_in, uint32_t n_out) {
   KG_REDUCE_PRIO();
-  const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
-  const size_t per_w = (size_t)narr_in * n_out;
-  if (t >= per_w * W) return;
-  const int w = (int)(t / per_w);
-  const size_t r = t % per_w;
-  const int a = (int)(r / n_out);
-  const uint32_t i = (uint32_t)(r % n_out);
-  const int narr_out = narr_in + 1;
-  const size_t src = ((size_t)w * narr_in + a) * (2 * (size_t)n_out) + 2 * (size_t)i;
-  XYZZ<F> p0 = PointIO<F>::load(in, in_stride, src);
-  XYZZ<F> p1 = PointIO<F>::load(in, in_stride, src + 1);
-  PointIO<F>::store(out, out_stride, ((size_t)w * narr_out + a) * n_out + i, add_xyzz(p0, p1));
-  if (a == 0) PointIO<F>::store(out, out_stride, ((size_t)w * narr_out + narr_in) * n_out + i, p1);
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;       // < 2^27 items (W * B <= 15 * 2^17)
+  const uint32_t per_w = (uint32_t)narr_in * n_out;
+  if (t >= per_w * (uint32_t)W) return;
+  const uint32_t w = t / per_w;
+  const uint32_t r = t % per_w;
+  const uint32_t a = r / n_out;
+  const uint32_t i = r % n_out;
+  const uint32_t narr_out = (uint32_t)narr_in + 1;
+  const uint32_t src = (w * narr_in + a) * (2 * n_out) + 2 * i;
+  const BufRsrc rin = soa_rsrc(in), rout = soa_rsrc(out);
+  const uint32_t is4 = (uint32_t)in_stride * 4u, os4 = (uint32_t)out_stride * 4u;
+  const SoaSrc<F> p0{rin, is4, src * 4u}, p1{rin, is4, src * 4u + 4u};
+  SoaDst<F> sum{rout, os4, ((w * narr_out + a) * n_out + i) * 4u};
+  add_xyzz_stream<F>(p0, p1, sum);
+  if (a == 0) {
+    SoaDst<F> odd{rout, os4, ((w * narr_out + narr_in) * n_out + i) * 4u};
+    copy_xyzz_stream<F>(p1, odd);
+  }
+}
+
+// The dense bucket array and the first halving level in one launch (buckets that own a single partial sum: every bucket of a
+// uniform input): lane i of window w reads the partial sums of buckets 2i and 2i + 1 where the accumulation left them
+// (array-of-structures, by task id) and writes level 1 -- the pair sum and the odd item -- instead of k_gather_buckets
+// writing W * B points that k_halve reads back: one launch and 2 x 75 MB of traffic less per 2^20-pair MSM.
+template <class F> struct AosSrc;                   // a partial sum in the PointAoS layout the accumulation writes, read coordinate by coordinate
+template <class P> struct AosSrc<Fp<P>> {
+  BufRsrc rs; uint32_t off; bool valid;             // off: byte offset of the point; !valid: an empty bucket (the identity)
+  __device__ __forceinline__ Fp<P> get(int coord) const {
+    Fp<P> r = Fp<P>::zero();
+    if (valid) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) r.l[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, off + (uint32_t)(coord * 9 + k) * 4u, 0, 0);
+    }
+    return r;
+  }
+  __device__ __forceinline__ Fp<P> x() const { return get(0); }
+  __device__ __forceinline__ Fp<P> y() const { return get(1); }
+  __device__ __forceinline__ Fp<P> zz() const { return get(2); }
+  __device__ __forceinline__ Fp<P> zzz() const { return get(3); }
+};
+template <class G> struct AosSrc<Fp2S<G>> {         // PointAoS<Fp2<G>>: x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1, nine words each; a lane reads its half
+  BufRsrc rs; uint32_t off; bool valid;
+  __device__ __forceinline__ Fp2S<G> get(int coord) const {
+    Fp2S<G> r = Fp2S<G>::zero();
+    if (valid) {
+      const uint32_t o = off + (uint32_t)(coord * 18 + 9 * Fp2S<G>::half()) * 4u;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) r.v.l[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, o + (uint32_t)k * 4u, 0, 0);
+    }
+    return r;
+  }
+  __device__ __forceinline__ Fp2S<G> x() const { return get(0); }
+  __device__ __forceinline__ Fp2S<G> y() const { return get(1); }
+  __device__ __forceinline__ Fp2S<G> zz() const { return get(2); }
+  __device__ __forceinline__ Fp2S<G> zzz() const { return get(3); }
+};
+template <class KF>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HalveWaves<KF>::MIN))) k_gather_halve(const uint32_t* pin, Level L, int W, int B, uint32_t* out, size_t out_stride) {
+  KG_REDUCE_PRIO();
+  constexpr uint32_t NWB = (uint32_t)PointIO<KF>::NW * 4u;       // bytes per partial sum (PointIO<Fp2S>::NW counts both halves of the lane pair)
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / Lanes<KF>::N;
+  const uint32_t n_out = (uint32_t)B / 2;
+  if (t >= n_out * (uint32_t)W) return;
+  const uint32_t w = t / n_out, i = t % n_out;
+  const uint32_t b0 = w * (uint32_t)B + 2 * i;
+  const uint32_t first = L.base[w];
+  const uint2 cnt = *reinterpret_cast<const uint2*>(L.cnt + b0), rel = *reinterpret_cast<const uint2*>(L.rel + b0);
+  const BufRsrc rin = soa_rsrc(pin), rout = soa_rsrc(out);
+  const AosSrc<KF> p0{rin, (first + rel.x) * NWB, cnt.x != 0}, p1{rin, (first + rel.y) * NWB, cnt.y != 0};
+  const uint32_t os4 = (uint32_t)out_stride * 4u;
+  SoaDst<KF> sum{rout, os4, ((w * 2) * n_out + i) * 4u}, odd{rout, os4, ((w * 2 + 1) * n_out + i) * 4u};
+  add_xyzz_stream<KF>(p0, p1, sum);
+  copy_xyzz_stream<KF>(p1, odd);
 }
 
 // raw internal XYZZ -> ABI words (x | y | zz | zzz), array-of-structures for the D2H copy
@@ -1276,97 +1403,101 @@ __device__ __forceinline__ void export_el(const Fp2<F>& a, uint64_t* dst) { expo
 template <class F>
 __device__ __forceinline__ void export_el(const Fp2S<F>& a, uint64_t* dst) { export_el(a.v, dst + 4 * Fp2S<F>::half()); }
 // ---- fused tail of the reduction --------------------------------------------------------------------------------
-// Once the arrays are short (L <= TAIL_L items) the remaining log2(L) levels run inside ONE launch: a workgroup per
+// Once the arrays are short (L <= TailCfg::L items) the remaining log2(L) levels run inside ONE launch: a workgroup per
 // (window, array) keeps its items in LDS and walks the levels with barriers instead of kernel launches, then converts its
 // results to the ABI form itself (the export).  Array 0 (the pair sums A) also spawns the new odd-index arrays T_s, T_s+1, ...
-// and sums them on the lanes the halving frees: at step t it holds t live arrays of L >> (t - 1) items (A at LDS item 0,
-// the array spawned at step j + 1 at item L >> (j + 1)), i.e. t * (L >> t) pairs <= L / 2 lanes.  Reads and writes of a
-// step are separated by a barrier, so every array shrinks in place.
-// LDS image: structure of arrays, word k of lane-item q at lds[k * cap + q] (consecutive lanes, consecutive banks); an Fq2
+// and sums them on the lanes the halving frees: step t reads t live arrays of 2 * (L >> t) items and writes t + 1 arrays of
+// L >> t items (array k at item k * (L >> t); the odd items of A become array t), i.e. t * (L >> t) pairs <= L / 2 lanes.
+// Two LDS images used in turn (odd steps write A: L items, even steps write B: 3 L / 4 items), so a step's operands are read
+// coordinate by coordinate while other lanes already write (add_xyzz_stream: the kernel fits the 96 VGPRs a resident
+// accumulation leaves free; with both operands in registers and one image shrinking in place it took 159) and a step needs one
+// barrier, not two.
+// LDS image: structure of arrays, word k of lane-item q at img[k * stride + q] (consecutive lanes, consecutive banks); an Fq2
 // item is two lane-items (the pair's halves).
-template <class F> struct TailIO {                  // one lane's 36 words of a point
-  static __device__ __forceinline__ void get(const XYZZ<F>& p, uint32_t (&w)[36]) {
+template <class P> __device__ __forceinline__ uint32_t (&tail_limbs(Fp<P>& a))[9] { return a.l; }
+template <class G> __device__ __forceinline__ uint32_t (&tail_limbs(Fp2S<G>& a))[9] { return a.v.l; }
+template <class P> __device__ __forceinline__ const uint32_t (&tail_limbs(const Fp<P>& a))[9] { return a.l; }
+template <class G> __device__ __forceinline__ const uint32_t (&tail_limbs(const Fp2S<G>& a))[9] { return a.v.l; }
+template <class F> struct LdsPt {                   // one lane-item of an LDS image, coordinates read / written on demand
+  uint32_t* img; uint32_t stride, li;
+  __device__ __forceinline__ F get(int coord) const {
+    F r;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { w[k] = p.x.l[k]; w[9 + k] = p.y.l[k]; w[18 + k] = p.zz.l[k]; w[27 + k] = p.zzz.l[k]; }
+    for (int k = 0; k < 9; ++k) tail_limbs(r)[k] = img[(uint32_t)(coord * 9 + k) * stride + li];
+    return r;
   }
-  static __device__ __forceinline__ XYZZ<F> put(const uint32_t (&w)[36]) {
-    XYZZ<F> p;
+  __device__ __forceinline__ void put(int coord, const F& v) const {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { p.x.l[k] = w[k]; p.y.l[k] = w[9 + k]; p.zz.l[k] = w[18 + k]; p.zzz.l[k] = w[27 + k]; }
-    return p;
+    for (int k = 0; k < 9; ++k) img[(uint32_t)(coord * 9 + k) * stride + li] = tail_limbs(v)[k];
   }
+  __device__ __forceinline__ F x() const { return get(0); }
+  __device__ __forceinline__ F y() const { return get(1); }
+  __device__ __forceinline__ F zz() const { return get(2); }
+  __device__ __forceinline__ F zzz() const { return get(3); }
+  __device__ __forceinline__ void x(const F& v) const { put(0, v); }
+  __device__ __forceinline__ void y(const F& v) const { put(1, v); }
+  __device__ __forceinline__ void zz(const F& v) const { put(2, v); }
+  __device__ __forceinline__ void zzz(const F& v) const { put(3, v); }
 };
-template <class G> struct TailIO<Fp2S<G>> {
-  using F = Fp2S<G>;
-  static __device__ __forceinline__ void get(const XYZZ<F>& p, uint32_t (&w)[36]) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { w[k] = p.x.v.l[k]; w[9 + k] = p.y.v.l[k]; w[18 + k] = p.zz.v.l[k]; w[27 + k] = p.zzz.v.l[k]; }
-  }
-  static __device__ __forceinline__ XYZZ<F> put(const uint32_t (&w)[36]) {
-    XYZZ<F> p;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { p.x.v.l[k] = w[k]; p.y.v.l[k] = w[9 + k]; p.zz.v.l[k] = w[18 + k]; p.zzz.v.l[k] = w[27 + k]; }
-    return p;
-  }
-};
-template <class F> struct TailCfg { static constexpr int L = 512; };          // items per array the fused tail takes over at
-template <class G> struct TailCfg<Fp2S<G>> { static constexpr int L = 256; }; // (72 KiB of LDS either way)
+template <class F> struct TailCfg { static constexpr int L = 256; };          // items per array the fused tail takes over at
+template <class G> struct TailCfg<Fp2S<G>> { static constexpr int L = 128; }; // (63 KiB of LDS either way: images of L and 3 L / 4 items)
+static inline size_t tail_lds_bytes(uint32_t L, int lpt) { const uint32_t b = 3 * L / 4 ? 3 * L / 4 : 1; return (size_t)36 * (L + b) * lpt * 4; }
 
-template <class F, int E64>
-__global__ void __launch_bounds__(512) k_reduce_tail(const uint32_t* __restrict__ in, size_t in_stride, int narr_in, uint32_t L, int c,
+// LT: the array length as a compile-time constant (the usual case, TailCfg<F>::L: every LDS access is then base register +
+// immediate offset), or 0 for the run-time length of a small window (B < TailCfg::L)
+template <class F, int E64, int LT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveWaves<F>::MIN))) k_reduce_tail(const uint32_t* in, size_t in_stride, int narr_in, uint32_t Lrt, int c,
                                                      uint64_t* __restrict__ out) {
   KG_REDUCE_PRIO();
   extern __shared__ uint32_t lds[];
-  constexpr int LPT = Lanes<F>::N;
-  const uint32_t cap = L * LPT;                        // lane-items the image holds
-  const int w = (int)(blockIdx.x / (unsigned)narr_in), a = (int)(blockIdx.x % (unsigned)narr_in);
-  const uint32_t lane_item = threadIdx.x;              // LPT consecutive lanes form a task
-  const uint32_t task = lane_item / LPT, half = lane_item % LPT;
+  constexpr uint32_t LPT = Lanes<F>::N;
+  const uint32_t L = LT ? (uint32_t)LT : Lrt;
+  const uint32_t capA = L * LPT, capB = (3 * L / 4 ? 3 * L / 4 : 1) * LPT;       // lane-items per image
+  const uint32_t S = capA + capB;                    // the images are interleaved: word k of image A's item q at lds[k * S + q], of image B's at lds[k * S + capA + q]
+  uint32_t* const imgA = lds;
+  uint32_t* const imgB = lds + capA;
+  const uint32_t w = blockIdx.x / (uint32_t)narr_in, a = blockIdx.x % (uint32_t)narr_in;
+  const uint32_t task = threadIdx.x / LPT, half = threadIdx.x % LPT;           // LPT consecutive lanes form a task
   const bool spawns = a == 0;
   int steps = 0;
   while ((1u << steps) < L) ++steps;
-  auto lds_put = [&](uint32_t item, const XYZZ<F>& p) {
-    uint32_t wds[36];
-    TailIO<F>::get(p, wds);
-#pragma unroll
-    for (int k = 0; k < 36; ++k) lds[k * cap + item * LPT + half] = wds[k];
-  };
-  auto lds_get = [&](uint32_t item) {
-    uint32_t wds[36];
-#pragma unroll
-    for (int k = 0; k < 36; ++k) wds[k] = lds[k * cap + item * LPT + half];
-    return TailIO<F>::put(wds);
-  };
-  const size_t src0 = ((size_t)w * narr_in + a) * L;
+  const BufRsrc rin = soa_rsrc(in);
+  const uint32_t is4 = (uint32_t)in_stride * 4u;
+  const uint32_t src0 = (w * (uint32_t)narr_in + a) * L;
   for (int t = 1; t <= steps; ++t) {
     const uint32_t per = L >> t;                       // pairs per live array in this step
     const uint32_t live = spawns ? (uint32_t)t : 1u;
-    const bool active = task < live * per;
-    const uint32_t k = active ? task / per : 0u, q = active ? task % per : 0u;
-    const uint32_t base = k == 0 ? 0u : (L >> k);      // array k >= 1 was spawned at step k at item L >> k
-    XYZZ<F> p0, p1;
-    if (active) {
-      if (t == 1) { p0 = PointIO<F>::load(in, in_stride, src0 + 2 * q); p1 = PointIO<F>::load(in, in_stride, src0 + 2 * q + 1); }
-      else { p0 = lds_get(base + 2 * q); p1 = lds_get(base + 2 * q + 1); }
+    const bool odd_step = (t & 1) != 0;
+    uint32_t* const oimg = odd_step ? imgA : imgB;
+    uint32_t* const iimg = odd_step ? imgB : imgA;
+    const uint32_t ocap = S, icap = S;
+    if (task < live * per) {
+      const uint32_t k = task / per, q = task % per;
+      const LdsPt<F> sum{oimg, ocap, (k * per + q) * LPT + half};
+      const LdsPt<F> spawn{oimg, ocap, ((uint32_t)t * per + q) * LPT + half};    // the odd items of A become array t
+      if (t == 1) {
+        const SoaSrc<F> p0{rin, is4, (src0 + 2 * q) * 4u}, p1{rin, is4, (src0 + 2 * q + 1) * 4u};
+        add_xyzz_stream<F>(p0, p1, sum);
+        if (spawns) copy_xyzz_stream<F>(p1, spawn);
+      } else {
+        const LdsPt<F> p0{iimg, icap, (k * 2 * per + 2 * q) * LPT + half}, p1{iimg, icap, (k * 2 * per + 2 * q + 1) * LPT + half};
+        add_xyzz_stream<F>(p0, p1, sum);
+        if (spawns && k == 0) copy_xyzz_stream<F>(p1, spawn);
+      }
     }
-    __syncthreads();                                   // every read of this step before any write
-    if (active) {
-      lds_put(base + q, add_xyzz(p0, p1));
-      if (spawns && k == 0) lds_put(per + q, p1);      // the odd items of A become the array spawned at this step
-    }
-    __syncthreads();
+    __syncthreads();                                   // this step's image is complete; the other one is free to be overwritten
   }
-  // results: A (or this workgroup's T array) at item 0; the array spawned at step j at item L >> j (one item each)
+  // results: one item per array -- A (or this workgroup's T array) is item 0, the array spawned at step j item j
   const uint32_t nres = spawns ? (uint32_t)steps + 1u : 1u;
   if (task < nres) {
-    const uint32_t item = task == 0 ? 0u : (L >> task);
-    const int arr = task == 0 ? a : narr_in - 1 + (int)task;        // 0 = A, 1 + l = T_l
-    const XYZZ<F> p = lds_get(item);
+    const bool in_a = (steps & 1) != 0;
+    const LdsPt<F> p{in_a ? imgA : imgB, S, task * LPT + half};
+    const int arr = task == 0 ? (int)a : narr_in - 1 + (int)task;        // 0 = A, 1 + l = T_l
     uint64_t* dst = out + ((size_t)w * c + arr) * 4 * E64;
-    export_el(p.x, dst);
-    export_el(p.y, dst + E64);
-    export_el(p.zz, dst + 2 * E64);
-    export_el(p.zzz, dst + 3 * E64);
+    export_el(p.x(), dst);
+    export_el(p.y(), dst + E64);
+    export_el(p.zz(), dst + 2 * E64);
+    export_el(p.zzz(), dst + 3 * E64);
   }
 }
 
@@ -1468,7 +1599,41 @@ int merged_window(const kg_ctx* ctx, size_t n) {
   return c;
 }
 
-int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered, int merged_c, int lane_mult, bool wait_info) {
+// Window groups of a blocking MSM (see msm_grouped): offered where the two-pass sort runs.  KG_MSM_GROUPS = 0 / 1 switches
+// them off, = k asks for k equal groups, = "a,b,c" names the groups' window counts from the top window down (experiments).
+int msm_group_plan(const kg_ctx* ctx, size_t n, int* gw) {
+  if (n < ((size_t)1 << 16) || n > ((size_t)1 << 24)) return 0;
+  const int c = pick_window(n, ctx ? ctx->msm_window : 0);
+  if (c - 1 < FINE_BITS + 4) return 0;
+  const int W = (255 + c - 1) / c;
+  // measured (MI355X, blocking kg_msm, two accumulation queues): two groups give 2^17 0.70 -> 0.68 ms, 2^18 0.88 -> 0.82, 2^19 1.195 -> 1.116,
+  // 2^20 1.87 -> 1.79, 2^21 3.16 -> 3.01, 2^22 6.14 -> 5.97; three or four groups pay more launches and more sort beside the
+  // accumulations than their shorter reduction tail returns (2^20: 1.98 / 2.03 ms)
+  int NG = n >= ((size_t)1 << 17) ? 2 : 0;
+  static const char* env = getenv("KG_MSM_GROUPS");
+  if (env) {
+    if (strchr(env, ',')) {
+      int k = 0, sum = 0;
+      const char* p = env;
+      while (*p && k < kg_ctx::MAX_GROUPS) {
+        const int v = atoi(p);
+        if (v < 1) return 0;
+        gw[k++] = v; sum += v;
+        while (*p && *p != ',') ++p;
+        if (*p == ',') ++p;
+      }
+      if (sum == W && !*p) return k;                 // a list that does not fit this window count falls through to the default
+    } else NG = atoi(env);
+  }
+  if (NG > kg_ctx::MAX_GROUPS) NG = kg_ctx::MAX_GROUPS;
+  if (NG > W) NG = W;
+  if (NG < 2) return 0;
+  for (int g = 0; g < NG; ++g) gw[g] = W / NG + (g < W % NG ? 1 : 0);
+  return NG;
+}
+
+int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSortPlan* P, bool ordered, int merged_c, int lane_mult,
+                   int ngroups, const int* gw, bool on_main) {
   if (n == 0 || n >= ((size_t)1 << 31)) return set_err(ctx, KG_ERR_BAD_ARG, "msm length must be in [1, 2^31)");
   host_trace("sort: enter");
   KG_HIP(ctx, hipSetDevice(ctx->device));
@@ -1489,7 +1654,6 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   if (nch > 64) nch = 64;                         // (window, chunk) workgroups of the first sort pass: 1024 of them at 2^20
   if (nch < 1) nch = 1;
   size_t chunk_len = (n + nch - 1) / nch;
-  const size_t npts = (size_t)Wb * B;
   // one task per bucket for uniform scalars: the unsigned top window of c = 15/16 holds twice the average load
   uint32_t T = (uint32_t)(4 * (n / B) + 32);
   if (T < 64) T = 64;
@@ -1503,24 +1667,43 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
     while (T < 128 && 2 * (size_t)T <= t) T *= 2;
     if (const char* e = getenv("KG_MERGED_T")) { const int v = atoi(e); if (v >= 4 && v <= 4096) T = (uint32_t)v; }
   }
-  const size_t part_cap = (size_t)Wb * ((nv + T - 1) / T) + npts;     // upper bound on round-1 tasks
-
   // two passes (bucket group, then bucket inside the group) once the sorted lists outgrow the L2; entries carry the
   // bucket's low FINE_BITS between the passes, which leaves 24 bits for the index
   const bool two_pass = merged || (c - 1 >= FINE_BITS + 4 && n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24));
   const int G = two_pass ? B >> FINE_BITS : 0;      // bucket groups per window (<= 1024)
   const int maxseg = two_pass ? G + (int)((nv + SEG - 1) / SEG) : 0;
   if (two_pass) chunk_len = (chunk_len + PREP_CH - 1) / PREP_CH * PREP_CH;   // k_prep_scalars_count: one chunk per workgroup
+  // window groups: gw[0] windows from the top, then gw[1], ... (the host's double-and-add chain consumes them in that order)
+  if (ngroups < 1 || ngroups > kg_ctx::MAX_GROUPS) return set_err(ctx, KG_ERR_BAD_ARG, "bad number of window groups");
+  if (ngroups > 1 && (!two_pass || merged || !gw)) return set_err(ctx, KG_ERR_BAD_ARG, "window groups need the two-pass, unmerged sort");
+  MsmSortPlan& Q = *P;
+  Q = MsmSortPlan();
+  {
+    int top = Wb, sum = 0;
+    for (int g = 0; g < ngroups; ++g) {
+      const int wg = ngroups == 1 ? Wb : gw[g];
+      if (wg < 1) return set_err(ctx, KG_ERR_BAD_ARG, "empty window group");
+      top -= wg; sum += wg;
+      Q.gw0[g] = top; Q.gW[g] = wg;
+    }
+    if (sum != Wb) return set_err(ctx, KG_ERR_BAD_ARG, "window groups do not add up to the window count");
+  }
   Carver cv;
-  const size_t o_kt = cv.take(n * 32), o_cnt = cv.take((size_t)W * nch * (two_pass ? G : B) * 4), o_bsize = cv.take((size_t)W * B * 4), o_bstart = cv.take(npts * 4);
-  const size_t o_tmp = cv.take(two_pass ? (size_t)W * n * 4 : 0), o_gsize = cv.take((size_t)W * G * 4), o_gstart = cv.take((size_t)W * G * 4);
-  const size_t o_segbase = cv.take((size_t)W * (G + 1) * 4), o_segcnt = cv.take((size_t)Wb * maxseg * FINE * 4), o_segoff = cv.take((size_t)Wb * maxseg * FINE * 4);
-  const size_t o_sorted = cv.take((size_t)W * n * 4), o_lcnt = cv.take(npts * 4), o_lrel = cv.take(npts * 4), o_lbase = cv.take((size_t)(Wb + 1) * 4);
-  const size_t o_rowtot = cv.take((size_t)W * 4), o_misc = cv.take(64), o_lenh = cv.take(2 * LEN_BINS * 4);
-  const size_t o_tbkt = cv.take(part_cap * 4), o_tid = cv.take(part_cap * 4);
-  const size_t o_woff = cv.take(merged ? (size_t)W * G * 4 : 0), o_gsize_m = cv.take(merged ? (size_t)G * 4 : 0), o_gstart_m = cv.take(merged ? (size_t)G * 4 : 0);
-  const size_t o_segbase_m = cv.take(merged ? (size_t)(G + 1) * 4 : 0);
-  const size_t o_bpart = cv.take((size_t)W * 32 * 2 * 4);           // k_bucket_part: (entries, tasks) of each part of each row
+  Q.o_kt = cv.take(n * 32); Q.o_cnt = cv.take((size_t)W * nch * (two_pass ? G : B) * 4); Q.o_bsize = cv.take((size_t)W * B * 4);
+  Q.o_bstart = cv.take((size_t)Wb * B * 4);
+  Q.o_tmp = cv.take(two_pass ? (size_t)W * n * 4 : 0); Q.o_gsize = cv.take((size_t)W * G * 4); Q.o_gstart = cv.take((size_t)W * G * 4);
+  Q.o_segbase = cv.take((size_t)W * (G + 1) * 4); Q.o_segcnt = cv.take((size_t)Wb * maxseg * FINE * 4); Q.o_segoff = cv.take((size_t)Wb * maxseg * FINE * 4);
+  Q.o_sorted = cv.take((size_t)W * n * 4); Q.o_lcnt = cv.take((size_t)Wb * B * 4); Q.o_lrel = cv.take((size_t)Wb * B * 4);
+  Q.o_rowtot = cv.take((size_t)W * 4);
+  Q.o_woff = cv.take(merged ? (size_t)W * G * 4 : 0); Q.o_gsize_m = cv.take(merged ? (size_t)G * 4 : 0); Q.o_gstart_m = cv.take(merged ? (size_t)G * 4 : 0);
+  Q.o_segbase_m = cv.take(merged ? (size_t)(G + 1) * 4 : 0);
+  Q.o_bpart = cv.take((size_t)W * 32 * 2 * 4);           // k_bucket_part: (entries, tasks) of each part of each row
+  for (int g = 0; g < ngroups; ++g) {                     // what the task decomposition keeps per group
+    Q.part_cap[g] = (size_t)Q.gW[g] * ((nv + T - 1) / T) + (size_t)Q.gW[g] * B;     // upper bound on round-1 tasks
+    Q.o_lbase[g] = cv.take((size_t)(Q.gW[g] + 1) * 4);
+    Q.o_misc[g] = cv.take(64); Q.o_lenh[g] = cv.take(2 * LEN_BINS * 4);             // adjacent: one zero fill covers both
+    Q.o_tbkt[g] = cv.take(Q.part_cap[g] * 4); Q.o_tid[g] = cv.take(Q.part_cap[g] * 4);
+  }
   // The scalar side runs on a queue of its own and alternates between two spaces: while MSM i accumulates (main queue,
   // reading set i & 1), MSM i+1 is sorted into the other set.  Ordering: the scalar queue waits for `after` (the producer
   // of d_scalars), or -- stream semantics -- for everything enqueued on the main queue so far, unless the context's inputs
@@ -1530,24 +1713,19 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
   KG_TRY(ensure_pinned(ctx, 4096));
   KG_TRY(make_sort_stream(ctx));
   char* ws = (char*)ctx->ws_sort[set];
-  hipStream_t st = ctx->sort_stream;
-  if (!ordered && !ctx->inputs_complete) {
+  // on_main: the conversion runs on the main queue (a blocking call whose first window group is sorted and accumulated there:
+  // no cross-queue hand-over in front of the first accumulation); the scalar queue is put behind it by the caller
+  hipStream_t st = on_main ? ctx->stream : ctx->sort_stream;
+  if (!on_main && !ordered && !ctx->inputs_complete) {
     KG_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
     KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_order, 0));
   }
   for (int j = 0; j < ctx->ws_idle_n[set]; ++j) KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_ws_idle[set][j], 0));
   ctx->ws_idle_n[set] = 0;
-  S->set = set; S->ready = ctx->ev_sorted[set];
-  uint32_t* kt = (uint32_t*)(ws + o_kt);
-  uint32_t* cnt = (uint32_t*)(ws + o_cnt);
-  uint32_t* rowtot = (uint32_t*)(ws + o_rowtot);
-  uint32_t* misc = (uint32_t*)(ws + o_misc);
-  uint32_t* lenh = (uint32_t*)(ws + o_lenh);
-  S->n = n; S->c = c; S->W = Wb; S->B = B; S->T = T; S->npts = npts; S->part_cap = part_cap;
-  S->merged_shift = mshift; S->windows = W;
-  S->sorted = (uint32_t*)(ws + o_sorted); S->bsize = (uint32_t*)(ws + o_bsize); S->bstart = (uint32_t*)(ws + o_bstart);
-  S->lcnt = (uint32_t*)(ws + o_lcnt); S->lrel = (uint32_t*)(ws + o_lrel); S->lbase = (uint32_t*)(ws + o_lbase);
-  S->task_bkt = (uint32_t*)(ws + o_tbkt); S->task_id = (uint32_t*)(ws + o_tid);
+  Q.n = n; Q.chunk_len = chunk_len; Q.nv = nv; Q.c = c; Q.W = W; Q.B = B; Q.Wb = Wb; Q.G = G; Q.nch = nch; Q.maxseg = maxseg; Q.mshift = mshift;
+  Q.set = set; Q.ngroups = ngroups; Q.merged = merged; Q.two_pass = two_pass; Q.T = T; Q.ws = ws;
+  uint32_t* kt = (uint32_t*)(ws + Q.o_kt);
+  uint32_t* cnt = (uint32_t*)(ws + Q.o_cnt);
 
   Words8 H;                                          // bias H = sum_{w < W-1} 2^(w*c + c - 1)
   for (int j = 0; j < 8; ++j) H.w[j] = 0;
@@ -1572,6 +1750,37 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
     else hipLaunchKernelGGL(k_prep_scalars<FqParams>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
     ph.end();
   }
+  KG_HIP(ctx, hipGetLastError());
+  return KG_OK;
+}
+
+// Sort of one window group: windows [w0, w0 + Wg) of the plan (all of them for the one-pass and the merged sort).  The
+// per-window tables are window-major, so a group's view is a pointer offset; only k_group_scatter needs the absolute window
+// (the digit's position in the scalar).
+int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool on_main) {
+  if (g < 0 || g >= Q.ngroups) return set_err(ctx, KG_ERR_BAD_ARG, "bad window group");
+  KG_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = Q.n, nv = Q.nv;
+  const int c = Q.c, W = Q.W, B = Q.B, G = Q.G, nch = Q.nch, maxseg = Q.maxseg;
+  const bool merged = Q.merged, two_pass = Q.two_pass;
+  const int w0 = Q.gw0[g], Wg = Q.gW[g];              // bucket-space windows of the group (merged: the single set)
+  const int sw0 = merged ? 0 : w0, sWg = merged ? W : Wg;      // scalar windows the group's first pass covers
+  const uint32_t T = Q.T;
+  char* ws = Q.ws;
+  hipStream_t st = on_main ? ctx->stream : ctx->sort_stream;
+  const size_t npts = (size_t)Wg * B;
+  uint32_t* kt = (uint32_t*)(ws + Q.o_kt);
+  uint32_t* cnt = (uint32_t*)(ws + Q.o_cnt);
+  uint32_t* rowtot = (uint32_t*)(ws + Q.o_rowtot) + w0;
+  uint32_t* misc = (uint32_t*)(ws + Q.o_misc[g]);
+  uint32_t* lenh = (uint32_t*)(ws + Q.o_lenh[g]);
+  S->set = Q.set; S->ready = ctx->ev_sorted[Q.set][g];
+  S->n = n; S->c = c; S->W = Wg; S->B = B; S->T = T; S->npts = npts; S->part_cap = Q.part_cap[g];
+  S->merged_shift = Q.mshift; S->windows = W; S->w0 = w0; S->group = g; S->acc_stream = nullptr; S->sorted_on = st;
+  S->sorted = (uint32_t*)(ws + Q.o_sorted) + (size_t)w0 * n; S->bsize = (uint32_t*)(ws + Q.o_bsize) + (size_t)w0 * B;
+  S->bstart = (uint32_t*)(ws + Q.o_bstart) + (size_t)w0 * B;
+  S->lcnt = (uint32_t*)(ws + Q.o_lcnt) + (size_t)w0 * B; S->lrel = (uint32_t*)(ws + Q.o_lrel) + (size_t)w0 * B; S->lbase = (uint32_t*)(ws + Q.o_lbase[g]);
+  S->task_bkt = (uint32_t*)(ws + Q.o_tbkt[g]); S->task_id = (uint32_t*)(ws + Q.o_tid[g]);
   {
     PhaseScope ph(ctx, "sort", st);
     const size_t lds = (size_t)(two_pass ? G : B) * 4;
@@ -1579,27 +1788,30 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
       KG_HIP(ctx, hipFuncSetAttribute((const void*)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       KG_HIP(ctx, hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    uint32_t* tmp = (uint32_t*)(ws + o_tmp);
-    uint32_t* gsize = (uint32_t*)(ws + o_gsize);
-    uint32_t* gstart = (uint32_t*)(ws + o_gstart);
-    uint32_t* segbase = (uint32_t*)(ws + o_segbase);
-    uint32_t* segcnt = (uint32_t*)(ws + o_segcnt);
-    uint32_t* segoff = (uint32_t*)(ws + o_segoff);
-    zero_fill(st, misc, (o_lenh - o_misc) + 2 * LEN_BINS * 4);      // misc and the length histogram
-    uint32_t* woff = merged ? (uint32_t*)(ws + o_woff) : nullptr;
-    // the tables the fine pass and the task decomposition read: per window, or the merged single set
-    const uint32_t* f_gstart = merged ? (uint32_t*)(ws + o_gstart_m) : gstart;
-    const uint32_t* f_gsize = merged ? (uint32_t*)(ws + o_gsize_m) : gsize;
-    const uint32_t* f_segbase = merged ? (uint32_t*)(ws + o_segbase_m) : segbase;
+    uint32_t* tmp = (uint32_t*)(ws + Q.o_tmp);
+    uint32_t* gsize = (uint32_t*)(ws + Q.o_gsize);
+    uint32_t* gstart = (uint32_t*)(ws + Q.o_gstart);
+    uint32_t* segbase = (uint32_t*)(ws + Q.o_segbase);
+    uint32_t* segcnt = (uint32_t*)(ws + Q.o_segcnt) + (size_t)w0 * maxseg * FINE;
+    uint32_t* segoff = (uint32_t*)(ws + Q.o_segoff) + (size_t)w0 * maxseg * FINE;
+    const size_t zbytes = (Q.o_lenh[g] - Q.o_misc[g]) + 2 * LEN_BINS * 4;     // misc and the length histogram: cleared by k_group_scan, or
+    if (!two_pass) zero_fill(st, misc, zbytes);
+    uint32_t* woff = merged ? (uint32_t*)(ws + Q.o_woff) : nullptr;
+    // the tables the fine pass and the task decomposition read: per window (the group's rows), or the merged single set
+    const uint32_t* f_gstart = merged ? (uint32_t*)(ws + Q.o_gstart_m) : gstart + (size_t)w0 * G;
+    const uint32_t* f_gsize = merged ? (uint32_t*)(ws + Q.o_gsize_m) : gsize + (size_t)w0 * G;
+    const uint32_t* f_segbase = merged ? (uint32_t*)(ws + Q.o_segbase_m) : segbase + (size_t)w0 * (G + 1);
+    const uint32_t* f_tmp = merged ? tmp : tmp + (size_t)w0 * n;
     if (two_pass) {
-      hipLaunchKernelGGL(k_group_scan, dim3(W), dim3(GS_NT), 0, st, cnt, nch, G, B, gsize, gstart, segbase, S->bsize);
+      hipLaunchKernelGGL(k_group_scan, dim3(sWg), dim3(GS_NT), 0, st, cnt + (size_t)sw0 * nch * G, nch, G, B, gsize + (size_t)sw0 * G, gstart + (size_t)sw0 * G,
+                         segbase + (size_t)sw0 * (G + 1), (uint32_t*)(ws + Q.o_bsize) + (size_t)sw0 * B, misc, (int)(zbytes / 4));
       if (merged)
-        hipLaunchKernelGGL(k_merge_groups, dim3(1), dim3(GS_NT), 0, st, gsize, W, G, woff, (uint32_t*)(ws + o_gsize_m), (uint32_t*)(ws + o_gstart_m),
-                           (uint32_t*)(ws + o_segbase_m));
-      hipLaunchKernelGGL(k_group_scatter, dim3(W, nch), dim3(GS_NT), 0, st, kt, n, c, W, chunk_len, G, cnt, f_gstart, tmp, woff, mshift);
-      hipLaunchKernelGGL(k_fine_local, dim3(Wb, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bsize, segcnt, segoff, S->sorted);
+        hipLaunchKernelGGL(k_merge_groups, dim3(1), dim3(GS_NT), 0, st, gsize, W, G, woff, (uint32_t*)(ws + Q.o_gsize_m), (uint32_t*)(ws + Q.o_gstart_m),
+                           (uint32_t*)(ws + Q.o_segbase_m));
+      hipLaunchKernelGGL(k_group_scatter, dim3(sWg, nch), dim3(GS_NT), 0, st, kt, n, c, W, Q.chunk_len, G, cnt, merged ? f_gstart : gstart, tmp, woff, Q.mshift, sw0);
+      hipLaunchKernelGGL(k_fine_local, dim3(Wg, maxseg), dim3(512), 0, st, f_tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bsize, segcnt, segoff, S->sorted);
     } else {
-      hipLaunchKernelGGL(k_count, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, 0, cnt);
+      hipLaunchKernelGGL(k_count, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, Q.chunk_len, 0, cnt);
       hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, cnt, W, nch, B, S->bsize);
     }
     // task decomposition (needs only the bucket sizes); its two result words travel to the host while the
@@ -1607,35 +1819,41 @@ int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n,
     const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
     if (B >= 8192) {
       const int nsplit = B / 4096;                    // <= 16 parts per row
-      uint32_t* bpart = (uint32_t*)(ws + o_bpart);
-      hipLaunchKernelGGL(k_bucket_part, dim3(Wb, nsplit), dim3(BR_NT), 0, st, S->bsize, B, T, nsplit, bpart, misc, lenh);
-      hipLaunchKernelGGL(k_bucket_fill, dim3(Wb, nsplit), dim3(BR_NT), 0, st, S->bsize, B, T, nsplit, bpart, S->bstart, S->lcnt, S->lrel, rowtot);
+      uint32_t* bpart = (uint32_t*)(ws + Q.o_bpart) + (size_t)w0 * nsplit * 2;
+      hipLaunchKernelGGL(k_bucket_part, dim3(Wg, nsplit), dim3(BR_NT), 0, st, S->bsize, B, T, nsplit, bpart, misc, lenh);
+      hipLaunchKernelGGL(k_bucket_fill, dim3(Wg, nsplit), dim3(BR_NT), 0, st, S->bsize, B, T, nsplit, bpart, S->bstart, S->lcnt, S->lrel, rowtot);
     } else
-      hipLaunchKernelGGL(k_bucket_rows, dim3(Wb), dim3(BR_NT), 0, st, S->bsize, B, T, S->bstart, S->lcnt, S->lrel, rowtot, misc, lenh);
-    hipLaunchKernelGGL(k_task_bases, dim3(1), dim3(64), 0, st, rowtot, Wb, S->lbase, misc, misc + 4, lenh, lenh + LEN_BINS);
-    uint32_t* h_info = (uint32_t*)ctx->h_pinned;
-    KG_HIP(ctx, hipMemcpyAsync(h_info, misc + 4, 8, hipMemcpyDeviceToHost, st));
-    if (!ctx->ev_info) KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_info, hipEventDisableTiming));
-    KG_HIP(ctx, hipEventRecord(ctx->ev_info, st));
+      hipLaunchKernelGGL(k_bucket_rows, dim3(Wg), dim3(BR_NT), 0, st, S->bsize, B, T, S->bstart, S->lcnt, S->lrel, rowtot, misc, lenh);
+    hipLaunchKernelGGL(k_task_bases, dim3(1), dim3(64), 0, st, rowtot, Wg, S->lbase, misc, misc + 4, lenh, lenh + LEN_BINS, (uint32_t*)ctx->h_pinned_dev + 4 * g);
+    KG_HIP(ctx, hipEventRecord(ctx->ev_info[g], st));
     hipLaunchKernelGGL(k_len_scatter, dim3(g1024), dim3(1024), 0, st, S->bsize, S->lcnt, S->lrel, S->lbase, npts, B, T, lenh + LEN_BINS, S->task_bkt, S->task_id);
     if (two_pass)
-      hipLaunchKernelGGL(k_fine_scatter, dim3(Wb, maxseg), dim3(512), 0, st, tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bstart, segcnt, segoff, S->sorted);
+      hipLaunchKernelGGL(k_fine_scatter, dim3(Wg, maxseg < FS_ROWS ? maxseg : FS_ROWS), dim3(512), 0, st, f_tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bstart, segcnt, segoff, S->sorted);
     else
-      hipLaunchKernelGGL(k_scatter, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, chunk_len, 0, cnt, S->bstart, S->sorted);
+      hipLaunchKernelGGL(k_scatter, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, Q.chunk_len, 0, cnt, S->bstart, S->sorted);
     ph.end();
     KG_HIP(ctx, hipGetLastError());
     KG_HIP(ctx, hipEventRecord(S->ready, st));
     host_trace("sort: enqueued");
   }
+  (void)nv;
+  return KG_OK;
+}
+
+int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered, int merged_c, int lane_mult, bool wait_info) {
+  MsmSortPlan Q;
+  KG_TRY(msm_sort_begin(ctx, scalar_field, d_scalars, n, &Q, ordered, merged_c, lane_mult));
+  KG_TRY(msm_sort_group(ctx, Q, 0, S));
   return wait_info ? msm_sort_wait(ctx, S) : KG_OK;
 }
 
-// The task count and the largest bucket of the sort enqueued last (two words read back through pinned memory): the caller
-// may put other work on the queues between msm_sort(..., wait_info = false) and this, but no other sort.
+// The task count and the largest bucket of a sort (two words read back through pinned memory, one pair per window group):
+// the caller may put other work on the queues between msm_sort(..., wait_info = false) and this, but no other sort with the
+// same group index.
 int msm_sort_wait(kg_ctx* ctx, MsmSorted* S) {
-  KG_HIP(ctx, hipEventSynchronize(ctx->ev_info));
+  KG_HIP(ctx, hipEventSynchronize(ctx->ev_info[S->group]));
   host_trace("sort: info back");
-  const uint32_t* h_info = (const uint32_t*)ctx->h_pinned;
+  const uint32_t* h_info = (const uint32_t*)ctx->h_pinned + 4 * S->group;
   S->ntasks = h_info[0];
   S->max_cnt = (h_info[1] + S->T - 1) / S->T;          // most tasks any bucket has
   if (S->ntasks > S->part_cap) return set_err(ctx, KG_ERR_HIP, "task count exceeds its bound");
@@ -1645,7 +1863,7 @@ int msm_sort_wait(kg_ctx* ctx, MsmSorted* S) {
 // Base-side half: accumulate + reduce against up to MAX_FUSED base arrays that share the scalar sort S, export, and start
 // the copy of each result into its host slot.  One accumulation launch serves all arrays (see k_acc_tasks); everything
 // after it runs per array, its reduction on one of the two side queues.
-struct RunJob { const uint64_t* d_bases; const uint8_t* d_inf; size_t nbases; uint32_t idx_off; int slot; bool bases_complete; };
+struct RunJob { const uint64_t* d_bases; const uint8_t* d_inf; size_t nbases; uint32_t idx_off; int slot; bool bases_complete; const uint32_t* packed; bool packed64; };
 
 template <class Cfg>
 int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njobs) {
@@ -1658,11 +1876,15 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
   const int W = S.W, B = S.B, c = S.c;
   const size_t npts = S.npts, part_cap = S.part_cap, nexp = (size_t)W * c;
   const size_t exp_bytes = nexp * 4 * Cfg::E64 * 8;
-  hipStream_t st = ctx->stream, sq;
+  hipStream_t st = S.acc_stream ? S.acc_stream : ctx->stream, sq;      // a window group may accumulate on a queue of its own
   KG_TRY(scalar_queue(ctx, &sq));
-  bool ordered_bases = false, converted = false;
+  bool ordered_bases = false, converted = false, shared_pb = false;
   if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
-  struct Lay { size_t o_pb, o_lc[2], o_lr[2], o_lb[2], o_part[2], o_pbuf[2], o_rowtot, o_misc, o_exp; char* ws; const uint32_t* pb; int set; };
+  if (st != ctx->stream && !ctx->inputs_complete) {      // stream semantics: the group's queue follows what the main queue holds so far
+    KG_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
+    KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_order, 0));
+  }
+  struct Lay { size_t o_pb, o_lc[2], o_lr[2], o_lb[2], o_part[2], o_pbuf[2], o_rowtot, o_misc; char* ws; const uint32_t* pb; int set; };
   Lay lay[MAX_FUSED];
   AccSets A;
   A.nsets = njobs;
@@ -1672,7 +1894,12 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
     Lay& Y = lay[k];
     Carver cv;
     const uint32_t* reg_pb = nullptr;               // bases inside a registered array are already in packed internal form
+    if (J.packed) {                                 // or the caller converted them (kg_msm: once for all window groups)
+      if (S.merged_shift) return set_err(ctx, KG_ERR_BAD_ARG, "merged sort against caller-converted bases");
+      reg_pb = J.packed; A.fmt64[k] = J.packed64 ? 1 : 0; shared_pb = true;
+    }
     for (const auto& r : ctx->registered) {
+      if (reg_pb) break;
       if (r.curve != Cfg::ID || J.d_bases < r.base) continue;
       const size_t off64 = (size_t)(J.d_bases - r.base);
       if (off64 % (size_t)BaseIO<F>::W != 0 || off64 / BaseIO<F>::W + J.nbases > r.n) continue;
@@ -1700,7 +1927,6 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       Y.o_part[i] = cv.take(part_cap * NW * 4); Y.o_pbuf[i] = cv.take(npts * NW * 4);
     }
     Y.o_rowtot = cv.take((size_t)W * 4); Y.o_misc = cv.take(64);
-    Y.o_exp = cv.take(exp_bytes);
     Y.set = J.slot % kg_ctx::RUN_SETS;              // run space per set: the reductions of the previous MSMs may still read the other sets
     for (int k2 = 0; k2 < k; ++k2)
       if (lay[k2].set == Y.set) return set_err(ctx, KG_ERR_BAD_ARG, "fused MSMs need result slots in different run-space sets");
@@ -1735,9 +1961,10 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
   if (converted) {                                                       // later on the scalar queue than the sort: covers both
     KG_HIP(ctx, hipEventRecord(ctx->ev_bases, sq));
     KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_bases, 0));
-  } else if (S.ready) KG_HIP(ctx, hipStreamWaitEvent(st, S.ready, 0));   // the scalar queue's sort of this set
+  } else if (S.ready && S.sorted_on != st) KG_HIP(ctx, hipStreamWaitEvent(st, S.ready, 0));   // the scalar queue's sort of this set
+  if (shared_pb) KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_pb, 0));     // the caller's conversion of the bases
   if (S.ntasks) {
-    PhaseScope ph(ctx, "accumulate");
+    PhaseScope ph(ctx, "accumulate", st);
     static const bool pair_acc = [] { const char* e = getenv("KG_G2_PAIR_ACC"); return e && atoi(e) != 0; }();
     if (LPT > 1 && pair_acc)          // experiment: G2 accumulation on lane pairs, ~150 VGPRs instead of 256
       hipLaunchKernelGGL(k_acc_tasks<KF>, dim3((unsigned)(((size_t)S.ntasks * LPT + 63) / 64) * (unsigned)njobs), dim3(64), 0, st, A, S.sorted, S.bstart, S.bsize, L0,
@@ -1757,15 +1984,18 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
     uint32_t* pbuf[2] = {(uint32_t*)(ws + Y.o_pbuf[0]), (uint32_t*)(ws + Y.o_pbuf[1])};
     uint32_t* rowtot = (uint32_t*)(ws + Y.o_rowtot);
     uint32_t* misc = (uint32_t*)(ws + Y.o_misc);
-    uint64_t* d_exp = (uint64_t*)(ws + Y.o_exp);
+    kg_ctx::Slot& sl = ctx->slots[slot];
     // two reduction queues, by slot parity: a long reduction (G2: ~4x a G1 one) does not hold up the next MSM's
-    hipStream_t side = (slot & 1) ? ctx->side2_stream : ctx->side_stream;
+    hipStream_t side = S.reduce_inline ? st : ((slot & 1) ? ctx->side2_stream : ctx->side_stream);     // reduce_inline: behind the accumulation on its own queue (the last window group: no cross-queue hand-over on the critical path)
     // Everything after the accumulation runs on a reduction queue, so that the main queue goes from one accumulation straight
     // to the next: the partial-sum rounds, the dense bucket array (gather) and the c-1 latency-bound halving levels.
-    KG_HIP(ctx, hipEventRecord(ctx->ev_acc[set], st));
-    KG_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_acc[set], 0));
+    if (side != st) {
+      KG_HIP(ctx, hipEventRecord(ctx->ev_acc[set], st));
+      KG_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_acc[set], 0));
+    }
     Level L = L0;
     int pcur = 0;
+    bool fused_first = false;
     {
       // buckets cut into several tasks (skewed inputs; every bucket of a merged sort): re-sum a bucket's partial sums until
       // it owns one point
@@ -1793,8 +2023,12 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       }
       ph.end();
       PhaseScope pg(ctx, "gather", side);
+      static const bool fuse_ok = !(getenv("KG_GATHER_FUSE") && atoi(getenv("KG_GATHER_FUSE")) == 0);
+      fused_first = fuse_ok && max_cnt <= 1 && (uint32_t)B > (uint32_t)TailCfg<KF>::L && (size_t)part_cap * NW * 4 < ((size_t)1 << 32);
       if (max_cnt > 1)
         hipLaunchKernelGGL((k_gather_sum<F, KF>), dim3((unsigned)((npts * LPT + 63) / 64)), dim3(64), 0, side, part[pcur], L, W, B, pbuf[0]);
+      else if (fused_first)        // the dense bucket array is never written: level 1 straight from the partial sums
+        hipLaunchKernelGGL(k_gather_halve<KF>, dim3((unsigned)((npts / 2 * LPT + 63) / 64)), dim3(64), 0, side, part[pcur], L, W, B, pbuf[0], (size_t)W * 2 * (B / 2));
       else
         hipLaunchKernelGGL(k_gather_buckets<F>, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, side, part[pcur], part_cap, L, W, B, pbuf[0]);
       pg.end();
@@ -1809,6 +2043,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       size_t in_stride = npts;                     // level 0 reads the bucket array: stride = W*B items
       int narr = 1;
       uint32_t len = (uint32_t)B;                  // items per array
+      if (fused_first) { narr = 2; len = (uint32_t)B / 2; in_stride = (size_t)W * 2 * len; }     // k_gather_halve wrote level 1
       constexpr uint32_t TL = (uint32_t)TailCfg<KF>::L;
       for (; len > TL; len /= 2) {                 // the wide levels: one launch each
         const uint32_t n_out = len / 2;
@@ -1821,17 +2056,21 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
         ++narr;
       }
       // the remaining log2(len) levels and the export in one launch (W * narr workgroups)
-      const size_t tail_lds = (size_t)36 * len * LPT * 4;
+      const size_t tail_lds = tail_lds_bytes(len, (int)LPT);
       const unsigned tail_threads = (unsigned)(len / 2 * LPT) < 64u ? 64u : (unsigned)(len / 2 * LPT);
-      KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_reduce_tail<KF, Cfg::E64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
-      hipLaunchKernelGGL((k_reduce_tail<KF, Cfg::E64>), dim3((unsigned)(W * narr)), dim3(tail_threads), tail_lds, side, pbuf[cur], in_stride, narr, len, c, d_exp);
+      // the sums go straight into the slot's pinned host buffer (its device view): no copy kernel behind the tail
+      if (len == TL) {
+        KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_reduce_tail<KF, Cfg::E64, (int)TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
+        hipLaunchKernelGGL((k_reduce_tail<KF, Cfg::E64, (int)TL>), dim3((unsigned)(W * narr)), dim3(tail_threads), tail_lds, side, pbuf[cur], in_stride, narr, len, c, (uint64_t*)sl.host_dev);
+      } else {
+        KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_reduce_tail<KF, Cfg::E64, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
+        hipLaunchKernelGGL((k_reduce_tail<KF, Cfg::E64, 0>), dim3((unsigned)(W * narr)), dim3(tail_threads), tail_lds, side, pbuf[cur], in_stride, narr, len, c, (uint64_t*)sl.host_dev);
+      }
       ph.end();
     }
     KG_HIP(ctx, hipGetLastError());
-    kg_ctx::Slot& sl = ctx->slots[slot];
-    KG_HIP(ctx, hipMemcpyAsync(sl.host, d_exp, exp_bytes, hipMemcpyDeviceToHost, side));
     KG_HIP(ctx, hipEventRecord(sl.done, side));
-    sl.W = W; sl.c = c; sl.busy = true;
+    sl.W = W; sl.c = c; sl.w0 = S.w0; sl.busy = true;
   }
   host_trace("run: enqueued");
   return KG_OK;
@@ -1839,29 +2078,36 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
 
 // Host half: wait for the slot's copy, then the 255-step double-and-add over the c*W bit-plane sums.
 // Window w contributes 2^(w*c) * (A_w + sum_l 2^l T_{w,l}); array 0 = A, array 1 + l = T_l.
+// An MSM cut into window groups holds one slot per group, top windows first: the chain runs through the groups in that
+// order and waits for a slot only when it reaches the slot's windows, so the top of the chain is computed while the lower
+// groups are still on the device.
 template <class Cfg>
-int msm_finish_t(kg_ctx* ctx, int slot, uint64_t* out_xyz) {
+int msm_finish_t(kg_ctx* ctx, const int* slots, int nslots, uint64_t* out_xyz) {
   using HF = typename Cfg::HF;
-  kg_ctx::Slot& sl = ctx->slots[slot];
   hipSetDevice(ctx->device);
   host_trace("finish: enter");
-  if (hipEventSynchronize(sl.done) != hipSuccess) return KG_ERR_HIP;
-  host_trace("finish: slot ready");
-  const auto t0 = std::chrono::steady_clock::now();
-  const uint64_t* hp = (const uint64_t*)sl.host;
   constexpr int PE = 4 * Cfg::E64;
-  const int W = sl.W, c = sl.c;
   XYZZ<HF> acc = XYZZ<HF>::identity();
-  for (int bit = W * c - 1; bit >= 0; --bit) {
-    acc = double_xyzz(acc);
-    const int w = bit / c, l = bit % c;
-    if (c > 1 && l < c - 1) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c + 1 + l) * PE));
-    if (l == 0) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c) * PE));
+  long long busy_us = 0;
+  for (int s = 0; s < nslots; ++s) {
+    kg_ctx::Slot& sl = ctx->slots[slots[s]];
+    if (hipEventSynchronize(sl.done) != hipSuccess) return KG_ERR_HIP;
+    host_trace("finish: slot ready");
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint64_t* hp = (const uint64_t*)sl.host;
+    const int W = sl.W, c = sl.c, w0 = sl.w0;
+    for (int bit = (w0 + W) * c - 1; bit >= w0 * c; --bit) {
+      acc = double_xyzz(acc);
+      const int w = bit / c - w0, l = bit % c;
+      if (c > 1 && l < c - 1) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c + 1 + l) * PE));
+      if (l == 0) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c) * PE));
+    }
+    if (s == nslots - 1) store_projective<Cfg>(acc, out_xyz);
+    busy_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
   }
-  store_projective<Cfg>(acc, out_xyz);
   host_trace("finish: done");
   if (ctx->prof) {
-    ctx->host_finish_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    ctx->host_finish_us += busy_us;
     ctx->host_finish_calls += 1;
   }
   return KG_OK;
@@ -1884,7 +2130,8 @@ int scalar_queue(kg_ctx* ctx, hipStream_t* out) {
 int msm_run_multi(kg_ctx* ctx, const MsmSorted& S, int curve, const MsmRunJob* jobs, int njobs) {
   RunJob rj[MAX_FUSED];
   if (njobs < 1 || njobs > MAX_FUSED) return KG_ERR_BAD_ARG;
-  for (int k = 0; k < njobs; ++k) rj[k] = RunJob{jobs[k].d_bases, jobs[k].d_inf, jobs[k].nbases, jobs[k].idx_off, jobs[k].slot, jobs[k].bases_complete};
+  for (int k = 0; k < njobs; ++k)
+    rj[k] = RunJob{jobs[k].d_bases, jobs[k].d_inf, jobs[k].nbases, jobs[k].idx_off, jobs[k].slot, jobs[k].bases_complete, jobs[k].packed, jobs[k].packed64};
   switch (curve) {
     case KG_G1: return msm_run_multi_t<G1Cfg>(ctx, S, rj, njobs);
     case KG_GRUMPKIN: return msm_run_multi_t<GkCfg>(ctx, S, rj, njobs);
@@ -1893,17 +2140,19 @@ int msm_run_multi(kg_ctx* ctx, const MsmSorted& S, int curve, const MsmRunJob* j
   }
 }
 int msm_run(kg_ctx* ctx, const MsmSorted& S, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, uint32_t idx_off, int slot) {
-  const MsmRunJob j{d_bases, d_inf, nbases, idx_off, slot, false};
+  const MsmRunJob j{d_bases, d_inf, nbases, idx_off, slot, false, nullptr, false};
   return msm_run_multi(ctx, S, curve, &j, 1);
 }
-int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz) {
+int msm_finish_groups(kg_ctx* ctx, int curve, const int* slots, int nslots, uint64_t* out_xyz) {
+  if (nslots < 1) return KG_ERR_BAD_ARG;
   switch (curve) {
-    case KG_G1: return msm_finish_t<G1Cfg>(ctx, slot, out_xyz);
-    case KG_GRUMPKIN: return msm_finish_t<GkCfg>(ctx, slot, out_xyz);
-    case KG_G2: return msm_finish_t<G2Cfg>(ctx, slot, out_xyz);
+    case KG_G1: return msm_finish_t<G1Cfg>(ctx, slots, nslots, out_xyz);
+    case KG_GRUMPKIN: return msm_finish_t<GkCfg>(ctx, slots, nslots, out_xyz);
+    case KG_G2: return msm_finish_t<G2Cfg>(ctx, slots, nslots, out_xyz);
     default: return KG_ERR_BAD_ARG;
   }
 }
+int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz) { return msm_finish_groups(ctx, curve, &slot, 1, out_xyz); }
 void msm_identity(int curve, uint64_t* out_xyz) {
   if (curve == KG_G2) store_projective<G2Cfg>(XYZZ<HostFq2>::identity(), out_xyz);
   else if (curve == KG_GRUMPKIN) store_projective<GkCfg>(XYZZ<HostFr>::identity(), out_xyz);
@@ -1990,12 +2239,100 @@ static int msm_sliced(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uin
   return sum_slices(ctx, curve, part, K, out_xyz);
 }
 
+// A blocking MSM pipelined against itself by window groups (kg_ctx::MAX_GROUPS): the windows of one MSM are independent
+// until the host's double-and-add, so after ONE conversion of the scalars (k_prep_scalars_count peels all digits) the top
+// group is sorted, then accumulated while the next group is sorted, reduced while the next group accumulates, and its sums
+// feed the top of the host chain while the lower groups are still on the device.  Exactly the work of the unsplit call
+// (an index slice would add a bucket reduction and a host chain per slice); the groups' accumulations go to queues of
+// their own so that a group's tail and the next group's head share the chip.
+static int msm_grouped(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, const int* gw, int NG,
+                       uint64_t* out_xyz) {
+  KG_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
+  KG_TRY(make_sort_stream(ctx));
+  for (int g = 1; g < NG; ++g)
+    if (!ctx->acc_stream[g]) KG_HIP(ctx, create_stream(ctx, &ctx->acc_stream[g], false));
+  kg::MsmSortPlan Q;
+  static const int main_first = getenv("KG_GROUP_MAIN_FIRST") ? atoi(getenv("KG_GROUP_MAIN_FIRST")) : 1;
+  KG_TRY(kg::msm_sort_begin(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &Q, false, 0, 1, NG, gw, main_first != 0));
+  if (main_first) {                                        // the scalar queue (the later groups' sorts) follows the conversion
+    KG_HIP(ctx, hipEventRecord(ctx->ev_prep, ctx->stream));
+    KG_HIP(ctx, hipStreamWaitEvent(ctx->sort_stream, ctx->ev_prep, 0));
+  }
+  // the bases: a registered array is resident already; otherwise ONE conversion for all groups, on a reduction queue (idle
+  // at this point) beside the scalar conversion
+  const size_t pw64 = curve == KG_G2 ? 16 : 8;             // u64 words per ABI point
+  bool resident = false;
+  for (const auto& r : ctx->registered) {
+    if (r.curve != curve || d_bases < r.base) continue;
+    const size_t off64 = (size_t)(d_bases - r.base);
+    if (off64 % pw64 != 0 || off64 / pw64 + n > r.n) continue;
+    if (d_inf != (r.inf ? r.inf + off64 / pw64 : nullptr)) continue;
+    resident = true;
+    break;
+  }
+  const bool f64 = resident_fmt64(n);
+  if (!resident) {
+    const size_t bytes = n * (f64 ? (curve == KG_G2 ? 128 : 64) : (curve == KG_G2 ? 144 : 72));
+    if (bytes > ctx->ws_pb_bytes) {
+      if (ctx->ws_pb) { sync_all(ctx); hipFree(ctx->ws_pb); ctx->ws_pb = nullptr; ctx->ws_pb_bytes = 0; }
+      const hipError_t e = hipMalloc(&ctx->ws_pb, bytes + bytes / 8);
+      if (e != hipSuccess) return set_err(ctx, KG_ERR_OOM, "resident-bases allocation", e);
+      ctx->ws_pb_bytes = bytes + bytes / 8;
+    }
+    hipStream_t cq = ctx->side_stream;
+    if (!ctx->inputs_complete) {                          // stream semantics: the bases may still be in flight on the main queue
+      KG_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
+      KG_HIP(ctx, hipStreamWaitEvent(cq, ctx->ev_order, 0));
+    }
+    PhaseScope ph(ctx, "prep_bases", cq);
+    if (curve == KG_G1) launch_prep_bases<Fq>(cq, d_bases, d_inf, n, (uint32_t*)ctx->ws_pb, f64);
+    else if (curve == KG_GRUMPKIN) launch_prep_bases<Fr>(cq, d_bases, d_inf, n, (uint32_t*)ctx->ws_pb, f64);
+    else launch_prep_bases<Fq2>(cq, d_bases, d_inf, n, (uint32_t*)ctx->ws_pb, f64);
+    ph.end();
+    KG_HIP(ctx, hipGetLastError());
+    KG_HIP(ctx, hipEventRecord(ctx->ev_pb, cq));
+  }
+  kg::MsmSorted S[kg_ctx::MAX_GROUPS];
+  int slots[kg_ctx::MAX_GROUPS];
+  int rc = kg::msm_sort_group(ctx, Q, 0, &S[0], main_first != 0);
+  if (rc == KG_OK && NG > 1) rc = kg::msm_sort_group(ctx, Q, 1, &S[1]);
+  int launched = 0;
+  for (int g = 0; g < NG && rc == KG_OK; ++g) {
+    rc = kg::msm_sort_wait(ctx, &S[g]);
+    if (rc != KG_OK) break;
+    // accumulation queues the groups rotate over: 2 (the main queue and one more).  On ONE queue a group's launch waits for the
+    // previous group's last wave -- and the top window's tasks are twice as long as the others (unsigned digits: half the buckets),
+    // so the chip idles behind them: 2^20 in two groups 2.09 ms on one queue, 1.80 on two; a queue per group (four) is no better
+    // than two, and more than ~4 busy hardware queues start to delay each other's hand-overs
+    static const int accq = getenv("KG_GROUP_ACCQ") ? atoi(getenv("KG_GROUP_ACCQ")) : 2;
+    S[g].acc_stream = (accq > 1 && g % accq) ? ctx->acc_stream[g % accq] : nullptr;
+    static const int rinl = getenv("KG_GROUP_REDUCE_INLINE") ? atoi(getenv("KG_GROUP_REDUCE_INLINE")) : 1;
+    S[g].reduce_inline = rinl && g == NG - 1;
+    static const int one_side = getenv("KG_GROUP_ONE_SIDE") ? atoi(getenv("KG_GROUP_ONE_SIDE")) : 0;
+    slots[g] = one_side ? 16 + 2 * g : 16 + g;
+    kg::MsmRunJob job{d_bases, d_inf, n, 0u, slots[g], false, resident ? nullptr : (const uint32_t*)ctx->ws_pb, f64};
+    rc = kg::msm_run_multi(ctx, S[g], curve, &job, 1);
+    if (rc != KG_OK) break;
+    ++launched;
+    if (g + 2 < NG) rc = kg::msm_sort_group(ctx, Q, g + 2, &S[g + 2]);
+  }
+  if (rc != KG_OK) { sync_all(ctx); return rc; }
+  (void)launched;
+  return kg::msm_finish_groups(ctx, curve, slots, NG, out_xyz);
+}
+
 int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
   if (!ctx || !out_xyz || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
   if (n >= ((size_t)1 << 23)) return msm_sliced(ctx, curve, d_bases, d_inf, d_scalars, n, out_xyz);   // measured: 2^24 25.8 -> 23.0 ms, 2^23 13.1 -> 12.1; below that the slices' own tails cost more than the hidden sort
   kg::MsmSorted S;
   const int mc = kg::has_window_table(ctx, curve, d_bases, d_inf, n, n) ? kg::merged_window(ctx, n) : 0;
+  if (!mc) {
+    int gw[kg_ctx::MAX_GROUPS];
+    const int NG = kg::msm_group_plan(ctx, n, gw);
+    if (NG > 1) return msm_grouped(ctx, curve, d_bases, d_inf, d_scalars, n, gw, NG, out_xyz);
+  }
   KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S, false, mc));
   KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 0));
   return kg::msm_finish(ctx, curve, 0, out_xyz);
