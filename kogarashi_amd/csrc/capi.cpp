@@ -35,13 +35,110 @@ int ensure_ws_sort(kg_ctx* c, int set, size_t bytes) {
 // Queues of the context.  (CU-masked queues -- hipExtStreamCreateWithCUMask, a compute / service partition -- and queue
 // priorities were measured and dropped: tools/ubench/cumask_probe.hip; what makes concurrent queues
 // work is the wave priority of the service kernels, KG_SERVICE_PRIO.)
+// KG_STREAM_PAD=n0,n1,...: experiment -- n_i never-used streams are created in front of the context's i-th queue (creation
+// order: main, scalar, reduction 1, reduction 2, ...), which shifts the queues over the hardware queues / pipes
+static int stream_pad(int idx) {
+  const char* e = getenv("KG_STREAM_PAD");
+  if (!e) return 0;
+  for (int i = 0; i < idx && e; ++i) { e = strchr(e, ','); if (e) ++e; }
+  return e ? atoi(e) : 0;
+}
 hipError_t create_stream(kg_ctx* c, hipStream_t* out, bool service) {
-  (void)c; (void)service;
+  (void)service;
+  static std::atomic<int> created{0};
+  const int idx = created++;
+  for (int i = stream_pad(idx); i > 0; --i) { hipStream_t dummy; if (hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking) == hipSuccess) { /* leaked on purpose: experiment only */ } }
+  (void)c;
   return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
 }
+// ---- queue placement ---------------------------------------------------------------------------------------------------
+// Measured (round 4, tools/dbg/pad_sweep.sh): the runtime deals a process's streams over the hardware queues in creation order,
+// and hardware queue k is served by compute pipe k mod 4.  A pipe that is launching the workgroups of a big dispatch -- an
+// accumulation of several resident rounds keeps it busy until its LAST round is placed -- serves no other queue meanwhile, so a
+// queue that shares the main queue's pipe starts its sort or reduction ~0.7 ms late.  Which of the library's queues share a
+// pipe used to be an accident of how many streams the host had created first: with one never-used stream in front of the scalar
+// queue the 2^20 MSM step went 1.37 -> 1.50 ms and the Groth16 proof 2.93 -> 3.18 ms (two in flight), with three 1.65 / 3.25.
+// So the service queues are PLACED: eight candidate streams are created, one probe finds the candidates that share the main
+// queue's pipe (a kernel of many short workgroups on the main queue, a one-wave kernel behind an event on every candidate: a
+// candidate on the same pipe finishes with the long dispatch, the others at once), and the scalar queue and the two reduction
+// queues take one candidate from each of the three other pipes; the second accumulation queue of a blocking MSM's window
+// groups takes the main queue's pipe on purpose (its launch then follows the first group's last placed workgroup).
+// KG_QUEUE_PLACEMENT=0: creation order as before (experiments).
+__global__ void __launch_bounds__(64) k_probe_busy(unsigned long long ticks) {
+  extern __shared__ uint32_t probe_pad[];
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+  if (ticks == ~0ull) probe_pad[threadIdx.x] = 1;      // keeps the LDS allocation (64 KiB: two workgroups per CU, wave slots stay free)
+}
+__global__ void __launch_bounds__(64) k_probe_nop(uint32_t* p) { if (p) *p = 1; }
+
+static int place_queues(kg_ctx* c) {
+  if (c->queues_placed) return KG_OK;
+  c->queues_placed = true;
+  constexpr int NC = 8;
+  hipStream_t cand[NC] = {};
+  hipError_t e = hipSuccess;
+  for (int j = 0; j < NC && e == hipSuccess; ++j) e = create_stream(c, &cand[j], true);
+  if (e != hipSuccess) return set_err(c, KG_ERR_HIP, "queue creation", e);
+  int cls[NC];
+  for (int j = 0; j < NC; ++j) cls[j] = -1;
+  static const bool enabled = !(getenv("KG_QUEUE_PLACEMENT") && atoi(getenv("KG_QUEUE_PLACEMENT")) == 0);
+  bool ok = enabled;
+  if (ok) {
+    hipEvent_t ev_s = nullptr, ev_a = nullptr, ev_b[NC] = {};
+    ok = hipEventCreate(&ev_s) == hipSuccess && hipEventCreate(&ev_a) == hipSuccess;
+    for (int j = 0; j < NC && ok; ++j) ok = hipEventCreate(&ev_b[j]) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)k_probe_busy, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess;
+    bool shares[NC] = {};
+    for (int rep = 0; rep < 2 && ok; ++rep) {             // the first pass also warms the queues up; the second one counts
+      ok = hipEventRecord(ev_s, c->stream) == hipSuccess;
+      hipLaunchKernelGGL(k_probe_busy, dim3(6144), dim3(64), 64 * 1024, c->stream, 1000ull);      // 12 rounds of 512 resident workgroups x 10 us
+      ok = ok && hipEventRecord(ev_a, c->stream) == hipSuccess;
+      for (int j = 0; j < NC && ok; ++j) {
+        ok = hipStreamWaitEvent(cand[j], ev_s, 0) == hipSuccess;
+        hipLaunchKernelGGL(k_probe_nop, dim3(1), dim3(64), 0, cand[j], (uint32_t*)nullptr);
+        ok = ok && hipEventRecord(ev_b[j], cand[j]) == hipSuccess;
+      }
+      ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+      for (int j = 0; j < NC && ok; ++j) ok = hipStreamSynchronize(cand[j]) == hipSuccess;
+      float ta = 0.f;
+      ok = ok && hipEventElapsedTime(&ta, ev_s, ev_a) == hipSuccess;
+      for (int j = 0; j < NC && ok; ++j) {
+        float tb = 0.f;
+        ok = hipEventElapsedTime(&tb, ev_s, ev_b[j]) == hipSuccess;
+        shares[j] = tb > 0.5f * ta;
+      }
+    }
+    (void)hipGetLastError();
+    if (ev_s) hipEventDestroy(ev_s);
+    if (ev_a) hipEventDestroy(ev_a);
+    for (int j = 0; j < NC; ++j) if (ev_b[j]) hipEventDestroy(ev_b[j]);
+    // the expected picture: exactly the candidates j0, j0 + 4 share the main queue's pipe
+    int j0 = -1;
+    for (int j = 0; j < 4 && ok; ++j) if (shares[j]) { j0 = j; break; }
+    ok = ok && j0 >= 0;
+    for (int j = 0; j < NC && ok; ++j) ok = shares[j] == ((j - j0) % 4 == 0);
+    if (ok) for (int j = 0; j < NC; ++j) cls[j] = ((j - j0) % 4 + 4) % 4;      // 0: the main queue's pipe
+    c->placement = ok ? 1 + j0 : -1;
+  }
+  auto take = [&](int want) -> hipStream_t {                // first unused candidate of the class (any class when the probe gave no picture)
+    for (int j = 0; j < NC; ++j)
+      if (cand[j] && (cls[j] == want || !ok)) { hipStream_t t = cand[j]; cand[j] = nullptr; return t; }
+    for (int j = 0; j < NC; ++j) if (cand[j]) { hipStream_t t = cand[j]; cand[j] = nullptr; return t; }
+    return nullptr;
+  };
+  c->sort_stream = take(1);
+  c->side_stream = take(2);
+  c->side2_stream = take(3);
+  c->acc_stream[1] = take(0);
+  c->up_stream = take(3);                                 // kg_msm_host's upload queue: copies only
+  for (int j = 0; j < NC; ++j) if (cand[j]) hipStreamDestroy(cand[j]);
+  return KG_OK;
+}
 int make_sort_stream(kg_ctx* c) {
-  if (c->sort_stream) return KG_OK;
-  hipError_t e = create_stream(c, &c->sort_stream, true);
+  if (c->sort_events) return KG_OK;
+  KG_TRY(place_queues(c));
+  hipError_t e = c->sort_stream ? hipSuccess : create_stream(c, &c->sort_stream, true);
   if (e != hipSuccess) return set_err(c, KG_ERR_HIP, "scalar-queue creation", e);
   for (int i = 0; i < 2; ++i) {
     for (int g = 0; g < kg_ctx::MAX_GROUPS; ++g)
@@ -55,6 +152,7 @@ int make_sort_stream(kg_ctx* c) {
   if ((e = hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
   for (int g = 0; g < kg_ctx::MAX_GROUPS; ++g)
     if ((e = hipEventCreateWithFlags(&c->ev_info[g], hipEventDisableTiming)) != hipSuccess) return set_err(c, KG_ERR_HIP, "event creation", e);
+  c->sort_events = true;
   return KG_OK;
 }
 int ensure_ws_vec(kg_ctx* c, size_t bytes) {
@@ -111,9 +209,11 @@ int ensure_slot(kg_ctx* c, int slot, size_t bytes) {
 // (A lowest-priority stream was measured and made no difference: the two queues do not compete for issue slots.)
 int make_side_stream(kg_ctx* c) {
   // (stream priorities were measured, high and low, for the prover and the MSM pipeline: no gain either way)
-  hipError_t e = create_stream(c, &c->side_stream, true);
+  if (c->side_stream && c->side2_stream) return KG_OK;
+  KG_TRY(place_queues(c));
+  hipError_t e = c->side_stream ? hipSuccess : create_stream(c, &c->side_stream, true);
   if (e != hipSuccess) return set_err(c, KG_ERR_HIP, "side stream creation", e);
-  e = create_stream(c, &c->side2_stream, true);
+  e = c->side2_stream ? hipSuccess : create_stream(c, &c->side2_stream, true);
   if (e != hipSuccess) return set_err(c, KG_ERR_HIP, "side stream creation", e);
   return KG_OK;
 }

@@ -25,6 +25,8 @@ struct kg_ctx {
   void* ws_sort[2] = {nullptr, nullptr};
   size_t ws_sort_bytes[2] = {0, 0};
   unsigned sort_seq = 0;
+  bool queues_placed = false, sort_events = false;   // capi.cpp place_queues: the service queues were created (and dealt over the compute pipes)
+  int placement = 0;                     // 0: not probed; 1 + j: the probe's picture (candidate j shares the main queue's pipe); -1: no clear picture, creation order
   hipStream_t sort_stream = nullptr;     // scalar-side queue (prep_scalars, sort, task bookkeeping); == stream when no overlap is possible
   // A blocking MSM pipelines against itself by WINDOW GROUPS (msm.hip, kg_msm): the scalars are converted once, then the
   // windows are sorted, accumulated and reduced group by group, top windows first -- group g+1 is sorted under group g's
@@ -268,8 +270,10 @@ int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, ui
 // merged_c: 0, or the window width of the bases' tables (merged_window(n)): sort all windows into one set of buckets;
 // lane_mult: how many accumulation lanes each task of this sort will occupy (fused arrays, G2's lane pairs) -- sizes the tasks
 // wait_info = false: return once the sort is enqueued; msm_sort_wait(ctx, S) must follow before S is used (and before another sort)
+// info_idx: which pair of read-back words / event the sort uses (< kg_ctx::MAX_GROUPS): two sorts whose read-backs are both
+// pending (the prover's witness sort and h's) need different ones
 int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered = false, int merged_c = 0, int lane_mult = 1,
-             bool wait_info = true);
+             bool wait_info = true, int info_idx = 0);
 int msm_sort_wait(kg_ctx* ctx, MsmSorted* S);
 // The same sort in two steps, for window groups: msm_sort_begin converts the scalars and lays the space out for `ngroups`
 // groups of gw[0], gw[1], ... windows counted from the TOP window down (ngroups = 1: all windows; groups need the two-pass
@@ -277,7 +281,7 @@ int msm_sort_wait(kg_ctx* ctx, MsmSorted* S);
 // result words back.
 struct MsmSortPlan {
   size_t n = 0, chunk_len = 0, nv = 0;
-  int c = 0, W = 0, B = 0, Wb = 0, G = 0, nch = 0, maxseg = 0, mshift = 0, set = 0, ngroups = 1;
+  int c = 0, W = 0, B = 0, Wb = 0, G = 0, nch = 0, maxseg = 0, mshift = 0, set = 0, ngroups = 1, info_base = 0;
   bool merged = false, two_pass = false;
   uint32_t T = 0;
   int gw0[kg_ctx::MAX_GROUPS] = {}, gW[kg_ctx::MAX_GROUPS] = {};

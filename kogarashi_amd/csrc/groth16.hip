@@ -333,12 +333,24 @@ ProofJob* job_of(kg_ctx* ctx, int i) {
 // contexts; a single-context proof runs all three).  defer_assembly: leave the host finishes in the job's futures and do not
 // start the assembly -- the sharded entry assembles from several jobs.
 enum { ROLE_G2 = 1, ROLE_G1W = 2, ROLE_H = 4, ROLE_ALL = 7 };
+static bool g16_h_early() {                               // KG_G16_H_EARLY=0: the blocking proof in the order of the pipelined ones (experiments)
+  static const bool on = !(getenv("KG_G16_H_EARLY") && atoi(getenv("KG_G16_H_EARLY")) == 0);
+  return on;
+}
+static bool g16_h_first() {                               // KG_G16_H_EARLY=2: h's point-wise step and coset_idft in front of the G2 accumulation (experiments)
+  static const bool on = getenv("KG_G16_H_EARLY") && atoi(getenv("KG_G16_H_EARLY")) == 2;
+  return on;
+}
+static bool g16_h_early_pipelined() {                     // KG_G16_H_EARLY_PIPE=1: the same order for proofs in flight (experiments)
+  static const bool on = getenv("KG_G16_H_EARLY_PIPE") && atoi(getenv("KG_G16_H_EARLY_PIPE")) != 0;
+  return on;
+}
 int assemble_proof(const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t* ss, int rc0, ProofJob* j_g2, ProofJob* j_g1w, ProofJob* j_h,
                    uint64_t* proof, uint8_t* inf);
 int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
                   const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
                   const uint64_t* s, ProofJob* job, int slot_base, const kg_csr* const* mats = nullptr, int roles = ROLE_ALL,
-                  bool defer_assembly = false) {
+                  bool defer_assembly = false, bool h_early = false) {
   if (!ctx || !crs || !r || !s) return KG_ERR_BAD_ARG;
   const bool do_g2 = (roles & ROLE_G2) != 0, do_g1w = (roles & ROLE_G1W) != 0, do_h = (roles & ROLE_H) != 0;
   const bool need_z = do_g2 || do_g1w || mats != nullptr;      // z = x || w feeds the witness MSMs and cs.evaluate()
@@ -446,12 +458,47 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // result slots: consecutive MSMs alternate between the two reduction queues (slot parity), each with run space of
   // its own (slot mod 8); measured against giving G2's long reduction a queue of its own: 3.67 vs 3.84 ms per proof
   const int SL[5] = {slot_base + 1, slot_base + 2, slot_base + 3, slot_base + 4, slot_base + 5};
+  // Order of the main queue.  Two proofs in flight (h_early = false): G2, the fused G1 accumulation, then h's chain -- the
+  // point-wise step, coset_idft, h's sort and MSM go LAST, so that the transforms (queued behind the previous proof's
+  // reductions) never hold up an accumulation.  ONE blocking proof (h_early): nothing else is in flight, the three chains are
+  // done before the witness sort is, and in the old order 1.4 ms of h's chain ran serially after the G1 accumulation on an
+  // otherwise idle chip; so h's point-wise step and coset_idft follow the G2 accumulation at once (G2's long reduction
+  // gets the chip meanwhile), h's sort runs beside the G1 accumulation and h's accumulation follows it directly.
+  MsmSorted Sq;
+  bool h_sorted = false;
+  auto h_front = [&]() {                                  // h = (a o b - c) / Z on the coset, back to coefficients (prover.rs:43-47)
+    for (int v = 0; v < 3; ++v) hip_rc(hipStreamWaitEvent(st, ctx->ev_join[v], 0), "hipStreamWaitEvent(join)");
+    HostFr seven = HostFr::one();                         // (7^n - 1)^-1 on the host: n = 2^k squarings of 7
+    {
+      HostFr one = HostFr::one(), acc = HostFr::zero();
+      for (int i = 0; i < 7; ++i) acc = add(acc, one);
+      seven = acc;
+    }
+    HostFr z = seven;
+    for (uint32_t i = 0; i < k; ++i) z = sqr(z);
+    z = inv(sub<4, 1>(z, HostFr::one()));                 // z_on_coset().invert() (fft.rs:141-151)
+    Words8 zw;
+    for (int i = 0; i < 4; ++i) { zw.w[2 * i] = (uint32_t)z.v[i]; zw.w[2 * i + 1] = (uint32_t)(z.v[i] >> 32); }
+    hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, C, n, zw);
+    hip_rc(hipGetLastError(), "k_qap_combine launch");
+    if (rc == KG_OK) rc = ntt_enqueue(ctx, st, TMP, A, k, 1, 1);             // coset_idft (prover.rs:47)
+  };
+  auto h_sort = [&](bool wait) {                           // h's coefficients come off the main queue
+    hip_rc(hipEventRecord(ctx->ev_order, st), "hipEventRecord(order)");
+    hip_rc(hipStreamWaitEvent(sq, ctx->ev_order, 0), "hipStreamWaitEvent(order)");
+    const bool th = has_window_table(ctx, KG_G1, crs->d_h, crs->d_h_inf, hn, hn);
+    if (rc == KG_OK) rc = msm_sort(ctx, KG_FR, A, hn, &Sq, true, th ? merged_window(ctx, hn) : 0, 1, wait, 1);
+    h_sorted = rc == KG_OK;
+  };
+  const bool early = h_early && do_h && hn && (do_g2 || do_g1w);
   if (do_g2 || do_g1w) {
     const int rw = msm_sort_wait(ctx, &Sz);                // always: the next sort may not start before this read-back
     if (rc == KG_OK) rc = rw;
     // G2 first: its host finish (Fq2 arithmetic, ~3x a G1 finish) and its slow reduction then overlap the G1 accumulations
+    if (early && g16_h_first() && rc == KG_OK) { h_front(); h_sort(false); }
     if (rc == KG_OK && do_g2) rc = msm_run(ctx, Sz, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, 0, SL[0]);
     if (rc == KG_OK && do_g2) f_b2 = finish_async(KG_G2, SL[0], b2i);
+    if (early && !g16_h_first() && rc == KG_OK) { h_front(); h_sort(false); }
     // the three G1 queries against z (a, b_g1, l) are accumulated by ONE launch: 13 000 waves instead of three
     // one-round launches of 4 352 (see k_acc_tasks)
     if (rc == KG_OK && do_g1w) {
@@ -466,32 +513,12 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   }
   // From here on host finishes may already be running on worker threads: no early return -- every failure travels
   // through rc into the assembly task below, which joins all of them before it reports.
-  // h = (a o b - c) / Z on the coset, back to coefficients (prover.rs:43-47), then its MSM.  (Measured and dropped as well:
-  // this chain on a service queue under the witness accumulations -- the transform's 512-thread, 74 KiB workgroups only
+  // (Measured and dropped: h's chain on a service queue under the witness accumulations -- the transform's workgroups only
   // get onto a CU once an accumulation has drained, and then queue behind the reductions: 3.3 -> 3.85 ms per proof.)
-  for (int v = 0; v < 3 && do_h; ++v) hip_rc(hipStreamWaitEvent(st, ctx->ev_join[v], 0), "hipStreamWaitEvent(join)");
-  if (do_h) {
-    HostFr seven = HostFr::one();                         // (7^n - 1)^-1 on the host: n = 2^k squarings of 7
-    {
-      HostFr one = HostFr::one(), acc = HostFr::zero();
-      for (int i = 0; i < 7; ++i) acc = add(acc, one);
-      seven = acc;
-    }
-    HostFr z = seven;
-    for (uint32_t i = 0; i < k; ++i) z = sqr(z);
-    z = inv(sub<4, 1>(z, HostFr::one()));                 // z_on_coset().invert() (fft.rs:141-151)
-    Words8 zw;
-    for (int i = 0; i < 4; ++i) { zw.w[2 * i] = (uint32_t)z.v[i]; zw.w[2 * i + 1] = (uint32_t)(z.v[i] >> 32); }
-    hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, C, n, zw);
-    hip_rc(hipGetLastError(), "k_qap_combine launch");
-  }
-  if (rc == KG_OK && do_h) rc = ntt_enqueue(ctx, st, TMP, A, k, 1, 1);             // coset_idft (prover.rs:47)
+  if (do_h && !early) h_front();
   if (rc == KG_OK && hn && do_h) {
-    MsmSorted Sq;
-    hip_rc(hipEventRecord(ctx->ev_order, st), "hipEventRecord(order)");             // h's coefficients come off the main queue
-    hip_rc(hipStreamWaitEvent(sq, ctx->ev_order, 0), "hipStreamWaitEvent(order)");
-    const bool th = has_window_table(ctx, KG_G1, crs->d_h, crs->d_h_inf, hn, hn);
-    if (rc == KG_OK) rc = msm_sort(ctx, KG_FR, A, hn, &Sq, true, th ? merged_window(ctx, hn) : 0, 1);
+    if (!h_sorted) h_sort(true);
+    else { const int rw = msm_sort_wait(ctx, &Sq); if (rc == KG_OK) rc = rw; }
     if (rc == KG_OK) rc = msm_run(ctx, Sq, KG_G1, crs->d_h, crs->d_h_inf, hn, 0, SL[4]);
     if (rc == KG_OK) f_q = finish_async(KG_G1, SL[4], q_p);
   } else msm_identity(KG_G1, q_p);
@@ -578,7 +605,7 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   if (!ctx || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
   ProofJob* job = job_of(ctx, 0);
   if (job->active) return KG_ERR_BAD_ARG;                // a proof begun with ticket 0 has not been collected
-  KG_TRY(prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job, 5));
+  KG_TRY(prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job, 5, nullptr, ROLE_ALL, false, g16_h_early()));
   return prove_collect(ctx, job, proof_out, proof_inf);
 }
 
@@ -589,7 +616,7 @@ int kg_groth16_prove_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
                            const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
                            const uint64_t* s, int ticket) {
   if (!ctx || ticket < 0 || ticket > 1 || job_of(ctx, ticket)->active) return KG_ERR_BAD_ARG;
-  return prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job_of(ctx, ticket), 5 + 5 * ticket);
+  return prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job_of(ctx, ticket), 5 + 5 * ticket, nullptr, ROLE_ALL, false, g16_h_early_pipelined());
 }
 // The same with cs.evaluate() on the device: the constraint matrices (resident CSR) instead of the evaluation vectors
 int kg_groth16_prove_r1cs_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const kg_csr* a, const kg_csr* b, const kg_csr* c,
@@ -599,14 +626,14 @@ int kg_groth16_prove_r1cs_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const kg
   ProofJob* job = job_of(ctx, 0);
   if (job->active) return KG_ERR_BAD_ARG;
   const kg_csr* mats[3] = {a, b, c};
-  KG_TRY(prove_enqueue(ctx, crs, nullptr, nullptr, nullptr, d_x, d_w, r, s, job, 5, mats));
+  KG_TRY(prove_enqueue(ctx, crs, nullptr, nullptr, nullptr, d_x, d_w, r, s, job, 5, mats, ROLE_ALL, false, g16_h_early()));
   return prove_collect(ctx, job, proof_out, proof_inf);
 }
 int kg_groth16_prove_r1cs_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const kg_csr* a, const kg_csr* b, const kg_csr* c,
                                 const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r, const uint64_t* s, int ticket) {
   if (!ctx || ticket < 0 || ticket > 1 || job_of(ctx, ticket)->active) return KG_ERR_BAD_ARG;
   const kg_csr* mats[3] = {a, b, c};
-  return prove_enqueue(ctx, crs, nullptr, nullptr, nullptr, d_x, d_w, r, s, job_of(ctx, ticket), 5 + 5 * ticket, mats);
+  return prove_enqueue(ctx, crs, nullptr, nullptr, nullptr, d_x, d_w, r, s, job_of(ctx, ticket), 5 + 5 * ticket, mats, ROLE_ALL, false, g16_h_early_pipelined());
 }
 int kg_groth16_prove_end(kg_ctx* ctx, int ticket, uint64_t* proof_out, uint8_t* proof_inf) {
   if (!ctx || ticket < 0 || ticket > 1 || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;

@@ -1186,25 +1186,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
   AccStore<F>::store(partial, t, acc);
 }
 
-// round r > 1: partial sums of the previous round (grouped by bucket through Lin) -> fewer partial sums
-template <class F>
-__global__ void __launch_bounds__(64) k_sum_tasks(const uint32_t* __restrict__ pin, size_t in_stride, Level Lin, Level L, int W, int B, uint32_t T2,
-                                                  uint32_t* __restrict__ pout, size_t out_stride) {
-  KG_REDUCE_PRIO();
-  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / Lanes<F>::N;
-  if (t >= L.base[W]) return;
-  int w, b;
-  uint32_t seg;
-  locate_task(L, W, B, t, w, b, seg);
-  const size_t bi = (size_t)w * B + b;
-  const uint32_t len_all = Lin.cnt[bi];
-  const uint32_t lo = seg * T2, hi = lo + T2 < len_all ? lo + T2 : len_all;
-  const size_t first = (size_t)Lin.base[w] + Lin.rel[bi];
-  XYZZ<F> acc = PointAoS<F>::load(pin, first + lo);
-  for (uint32_t j = lo + 1; j < hi; ++j) acc = add_xyzz(acc, PointAoS<F>::load(pin, first + j));
-  PointAoS<F>::store(pout, t, acc);
-}
-
 // final: dense bucket array for the halving reduction
 template <class F>
 __global__ void __launch_bounds__(256) k_gather_buckets(const uint32_t* __restrict__ pin, size_t in_stride, Level L, int W, int B,
@@ -1236,23 +1217,6 @@ template <class G> struct PartialIO<Fp2<G>, Fp2S<G>> {      // PointAoS<Fp2<G>>:
     return p;
   }
 };
-template <class F, class KF>
-__global__ void __launch_bounds__(64) k_gather_sum(const uint32_t* __restrict__ pin, Level L, int W, int B, uint32_t* __restrict__ buckets) {
-  KG_REDUCE_PRIO();
-  const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / Lanes<KF>::N;
-  const size_t total = (size_t)W * B;
-  if (t >= total) return;
-  const int w = (int)(t / B);
-  const uint32_t cnt = L.cnt[t];
-  XYZZ<KF> p = XYZZ<KF>::identity();
-  if (cnt) {
-    const size_t first = (size_t)L.base[w] + L.rel[t];
-    p = PartialIO<F, KF>::load(pin, first);
-    for (uint32_t j = 1; j < cnt; ++j) p = add_xyzz(p, PartialIO<F, KF>::load(pin, first + j));
-  }
-  PointIO<KF>::store(buckets, total, t, p);
-}
-
 // ---------------------------------------------------------------------------------------------------
 // bucket reduction by halving.  Arrays per window at level s: A (pair sums so far) and T_0..T_{s-1}
 // (odd-index sums), each of length 2*n_out; the level emits A', the halved T's and a new T_s = odd items of A.
@@ -1389,6 +1353,80 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HalveWa
   SoaDst<KF> sum{rout, os4, ((w * 2) * n_out + i) * 4u}, odd{rout, os4, ((w * 2 + 1) * n_out + i) * 4u};
   add_xyzz_stream<KF>(p0, p1, sum);
   copy_xyzz_stream<KF>(p1, odd);
+}
+
+// Buckets cut into a few tasks (every bucket of a merged sort; skewed inputs): the dense bucket array straight from the partial
+// sums, a lane (lane pair for G2) per bucket.  The running sum lives in the bucket's own slot of the output array and every
+// addition streams both operands (add_xyzz_stream is safe in place on its first operand): ~90 VGPRs instead of 141, so the
+// gather of a proof's merged MSMs runs beside the next accumulation.
+template <class F, class KF>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HalveWaves<KF>::MIN))) k_gather_sum(const uint32_t* pin, Level L, int W, int B, uint32_t* buckets) {
+  KG_REDUCE_PRIO();
+  constexpr uint32_t NWB = (uint32_t)PointIO<KF>::NW * 4u;
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / Lanes<KF>::N;
+  const uint32_t total = (uint32_t)W * (uint32_t)B;
+  if (t >= total) return;
+  const uint32_t w = t / (uint32_t)B;
+  const uint32_t cnt = L.cnt[t];
+  const BufRsrc rin = soa_rsrc(pin), rout = soa_rsrc(buckets);
+  const uint32_t first = cnt ? L.base[w] + L.rel[t] : 0u;
+  SoaDst<KF> dst{rout, total * 4u, t * 4u};
+  const SoaSrc<KF> cur{rout, total * 4u, t * 4u};
+  copy_xyzz_stream<KF>(AosSrc<KF>{rin, first * NWB, cnt != 0}, dst);
+  for (uint32_t j = 1; j < cnt; ++j) {
+    KG_STREAM_FENCE();
+    add_xyzz_stream<KF>(cur, AosSrc<KF>{rin, (first + j) * NWB, true}, dst);
+  }
+}
+
+// round r > 1: partial sums of the previous round (grouped by bucket through Lin) -> fewer partial sums.  Like k_gather_sum the
+// running sum lives in its output slot (array of structures here) and both operands are streamed.
+template <class F> struct AosDst;
+template <class P> struct AosDst<Fp<P>> {
+  BufRsrc rs; uint32_t off;
+  __device__ __forceinline__ void put(int coord, const Fp<P>& v) const {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) __builtin_amdgcn_raw_buffer_store_b32(v.l[k], rs, off + (uint32_t)(coord * 9 + k) * 4u, 0, 0);
+  }
+  __device__ __forceinline__ void x(const Fp<P>& v) const { put(0, v); }
+  __device__ __forceinline__ void y(const Fp<P>& v) const { put(1, v); }
+  __device__ __forceinline__ void zz(const Fp<P>& v) const { put(2, v); }
+  __device__ __forceinline__ void zzz(const Fp<P>& v) const { put(3, v); }
+};
+template <class G> struct AosDst<Fp2S<G>> {
+  BufRsrc rs; uint32_t off;
+  __device__ __forceinline__ void put(int coord, const Fp2S<G>& v) const {
+    const uint32_t o = off + (uint32_t)(coord * 18 + 9 * Fp2S<G>::half()) * 4u;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) __builtin_amdgcn_raw_buffer_store_b32(v.v.l[k], rs, o + (uint32_t)k * 4u, 0, 0);
+  }
+  __device__ __forceinline__ void x(const Fp2S<G>& v) const { put(0, v); }
+  __device__ __forceinline__ void y(const Fp2S<G>& v) const { put(1, v); }
+  __device__ __forceinline__ void zz(const Fp2S<G>& v) const { put(2, v); }
+  __device__ __forceinline__ void zzz(const Fp2S<G>& v) const { put(3, v); }
+};
+template <class KF>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HalveWaves<KF>::MIN))) k_sum_tasks(const uint32_t* pin, Level Lin, Level L, int W, int B, uint32_t T2,
+                                                  uint32_t* pout) {
+  KG_REDUCE_PRIO();
+  constexpr uint32_t NWB = (uint32_t)PointIO<KF>::NW * 4u;
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / Lanes<KF>::N;
+  if (t >= L.base[W]) return;
+  int w, b;
+  uint32_t seg;
+  locate_task(L, W, B, t, w, b, seg);
+  const size_t bi = (size_t)w * B + b;
+  const uint32_t len_all = Lin.cnt[bi];
+  const uint32_t lo = seg * T2, hi = lo + T2 < len_all ? lo + T2 : len_all;
+  const uint32_t first = Lin.base[w] + Lin.rel[bi];
+  const BufRsrc rin = soa_rsrc(pin), rout = soa_rsrc(pout);
+  const AosDst<KF> dst{rout, t * NWB};
+  const AosSrc<KF> cur{rout, t * NWB, true};
+  copy_xyzz_stream<KF>(AosSrc<KF>{rin, (first + lo) * NWB, true}, dst);
+  for (uint32_t j = lo + 1; j < hi; ++j) {
+    KG_STREAM_FENCE();
+    add_xyzz_stream<KF>(cur, AosSrc<KF>{rin, (first + j) * NWB, true}, dst);
+  }
 }
 
 // raw internal XYZZ -> ABI words (x | y | zz | zzz), array-of-structures for the D2H copy
@@ -1776,7 +1814,9 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
   uint32_t* lenh = (uint32_t*)(ws + Q.o_lenh[g]);
   S->set = Q.set; S->ready = ctx->ev_sorted[Q.set][g];
   S->n = n; S->c = c; S->W = Wg; S->B = B; S->T = T; S->npts = npts; S->part_cap = Q.part_cap[g];
-  S->merged_shift = Q.mshift; S->windows = W; S->w0 = w0; S->group = g; S->acc_stream = nullptr; S->sorted_on = st;
+  const int gi = Q.info_base + g;                     // read-back words / event of this sort
+  if (gi >= kg_ctx::MAX_GROUPS) return set_err(ctx, KG_ERR_BAD_ARG, "bad read-back index");
+  S->merged_shift = Q.mshift; S->windows = W; S->w0 = w0; S->group = gi; S->acc_stream = nullptr; S->sorted_on = st;
   S->sorted = (uint32_t*)(ws + Q.o_sorted) + (size_t)w0 * n; S->bsize = (uint32_t*)(ws + Q.o_bsize) + (size_t)w0 * B;
   S->bstart = (uint32_t*)(ws + Q.o_bstart) + (size_t)w0 * B;
   S->lcnt = (uint32_t*)(ws + Q.o_lcnt) + (size_t)w0 * B; S->lrel = (uint32_t*)(ws + Q.o_lrel) + (size_t)w0 * B; S->lbase = (uint32_t*)(ws + Q.o_lbase[g]);
@@ -1824,8 +1864,8 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
       hipLaunchKernelGGL(k_bucket_fill, dim3(Wg, nsplit), dim3(BR_NT), 0, st, S->bsize, B, T, nsplit, bpart, S->bstart, S->lcnt, S->lrel, rowtot);
     } else
       hipLaunchKernelGGL(k_bucket_rows, dim3(Wg), dim3(BR_NT), 0, st, S->bsize, B, T, S->bstart, S->lcnt, S->lrel, rowtot, misc, lenh);
-    hipLaunchKernelGGL(k_task_bases, dim3(1), dim3(64), 0, st, rowtot, Wg, S->lbase, misc, misc + 4, lenh, lenh + LEN_BINS, (uint32_t*)ctx->h_pinned_dev + 4 * g);
-    KG_HIP(ctx, hipEventRecord(ctx->ev_info[g], st));
+    hipLaunchKernelGGL(k_task_bases, dim3(1), dim3(64), 0, st, rowtot, Wg, S->lbase, misc, misc + 4, lenh, lenh + LEN_BINS, (uint32_t*)ctx->h_pinned_dev + 4 * gi);
+    KG_HIP(ctx, hipEventRecord(ctx->ev_info[gi], st));
     hipLaunchKernelGGL(k_len_scatter, dim3(g1024), dim3(1024), 0, st, S->bsize, S->lcnt, S->lrel, S->lbase, npts, B, T, lenh + LEN_BINS, S->task_bkt, S->task_id);
     if (two_pass)
       hipLaunchKernelGGL(k_fine_scatter, dim3(Wg, maxseg < FS_ROWS ? maxseg : FS_ROWS), dim3(512), 0, st, f_tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bstart, segcnt, segoff, S->sorted);
@@ -1840,9 +1880,10 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
   return KG_OK;
 }
 
-int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered, int merged_c, int lane_mult, bool wait_info) {
+int msm_sort(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSorted* S, bool ordered, int merged_c, int lane_mult, bool wait_info, int info_idx) {
   MsmSortPlan Q;
   KG_TRY(msm_sort_begin(ctx, scalar_field, d_scalars, n, &Q, ordered, merged_c, lane_mult));
+  Q.info_base = info_idx;
   KG_TRY(msm_sort_group(ctx, Q, 0, S));
   return wait_info ? msm_sort_wait(ctx, S) : KG_OK;
 }
@@ -2015,7 +2056,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
         Level Lout{ncnt, nrel, nbase};
         // the task count of this round is bounded by the previous one; threads beyond base[W] exit
         const uint32_t bound = lv < 0 ? S.ntasks : (uint32_t)part_cap;
-        hipLaunchKernelGGL(k_sum_tasks<F>, dim3((bound + 63) / 64), dim3(64), 0, side, part[pcur], part_cap, L, Lout, W, B, S.T2, part[pcur ^ 1], part_cap);
+        hipLaunchKernelGGL(k_sum_tasks<KF>, dim3((unsigned)(((size_t)bound * LPT + 63) / 64)), dim3(64), 0, side, part[pcur], L, Lout, W, B, S.T2, part[pcur ^ 1]);
         pcur ^= 1;
         L = Lout;
         lv = nx;
@@ -2253,7 +2294,11 @@ static int msm_grouped(kg_ctx* ctx, int curve, const uint64_t* d_bases, const ui
   for (int g = 1; g < NG; ++g)
     if (!ctx->acc_stream[g]) KG_HIP(ctx, create_stream(ctx, &ctx->acc_stream[g], false));
   kg::MsmSortPlan Q;
-  static const int main_first = getenv("KG_GROUP_MAIN_FIRST") ? atoi(getenv("KG_GROUP_MAIN_FIRST")) : 1;
+  // KG_GROUP_MAIN_FIRST=1 (experiment): conversion and the first group's sort on the main queue, in front of its accumulation -- no
+  // cross-queue hand-over there, but the second group's sort then runs BESIDE the first one's, the two accumulations start 50 us
+  // apart, share the chip from the start and neither finishes early: 1.93-2.04 ms against 1.77-1.85 with both sorts in turn on the
+  // scalar queue (2^20, same box, alternating runs; unsplit 1.85-1.90)
+  static const int main_first = getenv("KG_GROUP_MAIN_FIRST") ? atoi(getenv("KG_GROUP_MAIN_FIRST")) : 0;
   KG_TRY(kg::msm_sort_begin(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &Q, false, 0, 1, NG, gw, main_first != 0));
   if (main_first) {                                        // the scalar queue (the later groups' sorts) follows the conversion
     KG_HIP(ctx, hipEventRecord(ctx->ev_prep, ctx->stream));
@@ -2325,7 +2370,8 @@ static int msm_grouped(kg_ctx* ctx, int curve, const uint64_t* d_bases, const ui
 int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
   if (!ctx || !out_xyz || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
-  if (n >= ((size_t)1 << 23)) return msm_sliced(ctx, curve, d_bases, d_inf, d_scalars, n, out_xyz);   // measured: 2^24 25.8 -> 23.0 ms, 2^23 13.1 -> 12.1; below that the slices' own tails cost more than the hidden sort
+  static const bool sliced_ok = !(getenv("KG_MSM_SLICED") && atoi(getenv("KG_MSM_SLICED")) == 0);     // experiments: window groups instead of index slices
+  if (n >= ((size_t)1 << 23) && sliced_ok) return msm_sliced(ctx, curve, d_bases, d_inf, d_scalars, n, out_xyz);   // measured: 2^24 25.8 -> 23.0 ms, 2^23 13.1 -> 12.1; below that the slices' own tails cost more than the hidden sort
   kg::MsmSorted S;
   const int mc = kg::has_window_table(ctx, curve, d_bases, d_inf, n, n) ? kg::merged_window(ctx, n) : 0;
   if (!mc) {
@@ -2463,8 +2509,9 @@ int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* 
   KG_TRY(grow_device(ctx, 0, n * pb));
   KG_TRY(grow_device(ctx, 1, n * 32));
   if (h_inf) KG_TRY(grow_device(ctx, 2, n));
-  if (!ctx->up_stream) {
-    KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+  if (!ctx->ev_up_s[0]) {
+    KG_TRY(make_sort_stream(ctx));                         // places the context's queues, the upload queue among them
+    if (!ctx->up_stream) KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
     for (int i = 0; i < kg_ctx::UP_SLICES; ++i) {
       KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_up_s[i], hipEventDisableTiming));
       KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_up_b[i], hipEventDisableTiming));
