@@ -73,32 +73,39 @@ def launch_ranks(args):
     import signal
     import socket
     import subprocess
-    with socket.socket() as sk:                 # a free rendezvous port on the loop-back interface
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
-    try:
-        pending = list(procs)
-        while pending:
-            for pr in list(pending):
-                code = pr.poll()
-                if code is None:
-                    continue
-                pending.remove(pr)
-                if code != 0 and rc == 0:
-                    rc = code if code > 0 else 1
-                    for other in pending:        # one rank failed: the others would wait in a collective for ever
-                        other.send_signal(signal.SIGTERM)
-            time.sleep(0.05)
-    finally:
-        for pr in procs:
-            if pr.poll() is None:
-                pr.kill()
+    for attempt in range(3):
+        with socket.socket() as sk:                 # a free rendezvous port on the loop-back interface
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        # (the port is free when it is picked, not reserved: if another process takes it before rank 0 binds it, the ranks fail
+        # within seconds and the launch is repeated with a new one)
+        t_start = time.time()
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rc = 0
+        try:
+            pending = list(procs)
+            while pending:
+                for pr in list(pending):
+                    code = pr.poll()
+                    if code is None:
+                        continue
+                    pending.remove(pr)
+                    if code != 0 and rc == 0:
+                        rc = code if code > 0 else 1
+                        for other in pending:        # one rank failed: the others would wait in a collective for ever
+                            other.send_signal(signal.SIGTERM)
+                time.sleep(0.05)
+        finally:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+        if rc == 0 or time.time() - t_start > 30.0:    # a late failure is not a rendezvous problem: report it
+            break
     return rc
 
 
@@ -112,6 +119,7 @@ def main():
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-groth16", action="store_true")
     ap.add_argument("--no-nova", action="store_true")
+    ap.add_argument("--no-skew", action="store_true", help="skip the skewed-scalar legs (msm_skewed, groth16.skewed_witness)")
     ap.add_argument("--ntt-only", action="store_true", help="profiling aid: only the NTT leg (tools/collect_profiles.sh); prints {\"ntt\": ...}")
     ap.add_argument("--nova-log-n", type=int, default=24, help="pairs of the Nova commitment (whole job, cut over the ranks)")
     ap.add_argument("--groth16-log-m", type=int, default=18)
@@ -312,6 +320,8 @@ def main():
                                                          "matches_unregistered": bool((res_tab[0] == res[0]).all() and res_tab[1] == res[1])}
         ctx.bases_unregister(bases.data_ptr())
     cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if rank == 0 and world == 1 and not args.no_skew:
+        line["msm_skewed"] = bench_msm_skewed(ctx, torch, dev, K, bases, n, run, barrier, args.steps, elapsed / args.steps * 1e3, blocking_ms, cpu)
     if cpu:
         line["cpu_baseline"] = cpu_baseline(ctx, K, bases, scalars, n, res)
         line["cpu_plumbing_2_10"] = cpu_plumbing(ctx, K)
@@ -323,6 +333,17 @@ def main():
         line["nova_commit"] = bench_nova_commit(ctx, torch, dev, K, env, args.nova_log_n, cpu=cpu)
     if not args.no_groth16:
         line["groth16"] = bench_groth16(ctx, torch, dev, K, env, args.groth16_log_m, cpu=cpu)
+        if not args.no_skew:
+            # the same proof size on a circuit whose witness is 0/1-heavy (prover.rs:53-65 meets such aux vectors)
+            sk = bench_groth16(ctx, torch, dev, K, env, args.groth16_log_m, steps=4, cpu=cpu, circuit="boolean", from_witness=False)
+            line["groth16"]["skewed_witness"] = {
+                "circuit": "30 % chain constraints, 70 % booleanity constraints: z = x || w is half ones, a fifth zeros, the rest uniform",
+                "ms_per_proof": sk["ms_per_proof"], "ms_per_proof_blocking": sk["ms_per_proof_blocking"],
+                "ratio_to_uniform": sk["ms_per_proof"] / line["groth16"]["ms_per_proof"],
+                "pipelined_matches_blocking": sk["pipelined_matches_blocking"],
+                "window_tables": {k_: sk["window_tables"][k_] for k_ in ("ms_per_proof", "ms_per_proof_blocking", "proofs_match")} if "window_tables" in sk else None,
+                "window_tables_ratio_to_uniform": (sk["window_tables"]["ms_per_proof"] / line["groth16"]["window_tables"]["ms_per_proof"]) if "window_tables" in sk and "window_tables" in line["groth16"] else None,
+                "cpu_baseline": sk.get("cpu_baseline")}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -424,6 +445,7 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5):
         env["barrier"]()
         dt = env["max_over_ranks"](time.perf_counter() - t0) / steps
         leg = {"ms_per_commit": dt * 1e3, "value": total / dt, "unit": "pairs/s",
+               "point": {"xy_hex": "".join(f"{int(v_):016x}" for v_ in got[0]), "is_identity": bool(got[1])},     # the commitment itself: equal for every N
                "roofline": {"bound": "hbm", "achieved": 96 * total / dt / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                             "frac": 96 * total / dt / 1e9 / (HBM_PEAK_GBS * world)}}
         if cpu:
@@ -508,7 +530,61 @@ def cpu_plumbing(ctx, K, log_n=10):
             "gpu_host_call_ms": gdt * 1e3, "gpu_matches_cpu": bool(not inf and (got[:8] == xy).all())}
 
 
-def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=True, tickets=2):
+def bench_msm_skewed(ctx, torch, dev, K, bases, n, run_uniform, barrier, steps, uniform_ms, uniform_blocking_ms, cpu):
+    """The headline MSM with scalars distributed like a Groth16 aux vector (half ones, a fifth zeros, a tenth -1, a tenth a small
+    value, a tenth uniform: kogarashi_amd.synthetic.witness_like) instead of uniform ones -- SURVEY.md 7, hard part (iii): half of
+    window 0's entries meet one bucket and the upper windows of the small values are empty, so the sort's segments, the task
+    cutting and the partial-sum rounds carry the load balance.  Same bases, same pipeline depth; `partial_rounds_per_msm` counts
+    the extra summation rounds (k_sum_tasks) an MSM needed."""
+    import numpy as np
+    from kogarashi_amd import synthetic as syn
+    sc = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    ctx.gen_scalars(K.KG_FR, SEED + 7, 0, n, sc.data_ptr())
+    ctx.sync()
+    h = sc.cpu().numpy().view(np.uint64).reshape(n, 4).copy()
+    syn.witness_like(h, 11)
+    sc.copy_(torch.from_numpy(h.view(np.int64).reshape(-1)))
+    torch.cuda.synchronize()
+
+    def run(k, depth=4):
+        res = None
+        for i in range(k):
+            ctx.msm_begin(K.KG_G1, bases.data_ptr(), 0, sc.data_ptr(), n, i % 4)
+            if i >= depth - 1:
+                res = ctx.msm_end(K.KG_G1, (i - depth + 1) % 4)
+        for i in range(max(k - depth + 1, 0), k):
+            res = ctx.msm_end(K.KG_G1, i % 4)
+        return res
+    run(8)
+    barrier()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    res = run(steps)
+    barrier()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    summ = ctx.profile_summary()
+    ctx.profile_enable(False)
+    for _ in range(2):
+        blk = ctx.msm(K.KG_G1, bases.data_ptr(), 0, sc.data_ptr(), n)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        blk = ctx.msm(K.KG_G1, bases.data_ptr(), 0, sc.data_ptr(), n)
+    blocking = (time.perf_counter() - t0) / 5 * 1e3
+    out = {"ms_per_step": ms, "ratio_to_uniform": ms / uniform_ms, "blocking_ms": blocking, "blocking_ratio_to_uniform": blocking / uniform_blocking_ms,
+           "partial_rounds_per_msm": (summ["partial_round"][1] / steps) if "partial_round" in summ else 0.0,
+           "phases_ms_per_step": {k_: v_[0] / v_[1] for k_, v_ in summ.items() if k_ != "partial_round"},
+           "pipelined_matches_blocking": bool((res == blk).all()),
+           "scalars": "witness-like: 50 % ones, 20 % zeros, 10 % -1, 10 % the value 5, 10 % uniform (synthetic.witness_like)"}
+    if cpu:
+        from oracle import oracle as O
+        hb = bases.cpu().numpy().view(np.uint64).reshape(n, 8)
+        want_xy, want_inf = O.to_affine("g1", O.msm("g1", hb, h, None, threads=17))
+        out["gpu_matches_cpu_at_full_size"] = bool(not want_inf and (res[:8] == want_xy).all())
+    del sc
+    return out
+
+
+def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=True, tickets=2, circuit="chain", from_witness=True):
     """secondary line: Groth16 prove at m = 2^log_m constraints (BASELINE.json configs[3]).  Circuit: the chain
     t_{i+1} = t_i * (t_i + 1) (x = [1, t_0], w = t_1..t_m); CRS:
     a real CRS from a fixed toxic waste, generated on the device; fixed (r, s).  The CPU leg runs the oracle's create_proof on the same inputs and compares the proof."""
@@ -517,7 +593,7 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
     world, sync, mx = env["world"], env["barrier"], env["max_over_ranks"]     # N ranks: one prover per rank (replicas), aggregate proofs/s
     from kogarashi_amd import synthetic as syn
     m = 1 << log_m
-    cc = syn.ChainCircuit(m)
+    cc = syn.ChainCircuit(m) if circuit == "chain" else syn.BooleanHeavyCircuit(m)
     l, m_l_1 = cc.l, cc.m_l_1
     a_ev, b_ev, c_ev, x, w = cc.a_eval, cc.b_eval, cc.c_eval, cc.x, cc.w
     up = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(dev)
@@ -596,6 +672,7 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
                                "sample": f"one full proof at m = 2^{log_m}, {cdt:.2f} s", "gpu_matches_cpu_at_full_size": bool(same)}
     # the same proofs with window tables on the five CRS vectors (kg_bases_precompute: 2^(c w) * P for every window, built once
     # per CRS): one bucket set for all windows of an MSM; proofs must be bit-identical
+    tables = tables and (1 << 16) <= (l + m_l_1) <= (1 << 20) and (m - 1) >= (1 << 16)      # kg_bases_precompute: MSMs of 2^16 .. 2^20 scalars
     if tables:
         nz = l + m_l_1
         t0 = time.perf_counter()
@@ -621,6 +698,10 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
         dt_t = mx(time.perf_counter() - t0) / k_pipe
         c_t = 17 if nz >= (1 << 17) else 16
         w_t = (255 + c_t - 1) // c_t
+        out["window_tables"] = {"ms_per_proof": dt_t * 1e3, "ms_per_proof_blocking": dt_tb * 1e3, "value": world / dt_t, "build_ms": build_ms,
+                                "table_bytes": w_t * (64 * (3 * nz + (m - 1)) + 128 * nz),
+                                "proofs_match": bool(all((proof_t[i] == proof[i]).all() and (proof_tp[i] == proof[i]).all() for i in range(4)))}
+    if tables and from_witness:
         # and from the witness alone: the constraint matrices resident as CSR, cs.evaluate() on the device at the head of the
         # transform chains (kg_groth16_prove_r1cs_begin) -- what the patched create_proof calls
         csr_dev = [tuple(torch.from_numpy(np.ascontiguousarray(np.asarray(x_, dtype=np.uint64)).view(np.int64).reshape(-1)).to(dev) for x_ in trip)
@@ -643,12 +724,39 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
         proof_w = run_w(k_pipe)
         sync()
         dt_w = mx(time.perf_counter() - t0) / k_pipe
-        out["window_tables"] = {"ms_per_proof": dt_t * 1e3, "ms_per_proof_from_witness": dt_w * 1e3,
-                                "from_witness_matches": bool(all((proof_w[i] == proof[i]).all() for i in range(4))), "ms_per_proof_blocking": dt_tb * 1e3, "value": world / dt_t, "build_ms": build_ms,
-                                "table_bytes": w_t * (64 * (3 * nz + (m - 1)) + 128 * nz),
-                                "proofs_match": bool(all((proof_t[i] == proof[i]).all() and (proof_tp[i] == proof[i]).all() for i in range(4)))}
+        out["window_tables"].update({"ms_per_proof_from_witness": dt_w * 1e3, "from_witness_matches": bool(all((proof_w[i] == proof[i]).all() for i in range(4)))})
     for name in ("h", "l", "a", "b_g1", "b_g2"):
         ctx.bases_unregister(dev_arr[name].data_ptr())
+    if world > 1 and circuit == "chain":
+        # ONE proof over several GPUs, task-parallel (kg_groth16_prove_sharded: the G2 query | the three G1 queries | transforms
+        # and h's MSM on contexts 0, 1, 2): rank 0 drives contexts on the first min(3, N) devices while the other ranks wait.
+        # (KG_BENCH_SELFTEST: every context on cuda:0 -- control flow only.)
+        sync()
+        if env["rank"] == 0:
+            from kogarashi_amd.api import ShardedProver
+            n_ctx = min(3, world)
+            selftest = os.environ.get("KG_BENCH_SELFTEST") == "1"
+            ctxs = [K.Context(0 if selftest else i) for i in range(n_ctx)]
+            for c_ in ctxs:
+                c_.set_inputs_complete(True)
+            params = {name: P[name] for name in ("h", "l", "a", "b_g1", "b_g2")}
+            params.update({name + "_inf": P[name + "_inf"] for name in ("h", "l", "a", "b_g1", "b_g2")})
+            params["vk_g1"], params["vk_g2"] = vk_g1, vk_g2
+            sp = ShardedProver(params, m, l, m_l_1, ctxs)
+            ptr, keep = sp.upload_inputs(a_ev, b_ev, c_ev, x, w)
+            for _ in range(3):
+                proof_s = sp.prove_resident(ptr, r, s_)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                proof_s = sp.prove_resident(ptr, r, s_)
+            dt_s = (time.perf_counter() - t0) / steps
+            out["sharded"] = {"contexts": n_ctx, "devices": [0 if selftest else i for i in range(n_ctx)], "ms_per_proof": dt_s * 1e3,
+                              "matches_single_context": bool(all((proof_s[i] == proof[i]).all() for i in range(4))),
+                              "note": "blocking kg_groth16_prove_sharded, inputs and CRS resident per context; unmeasured on multi-GPU hardware until the driver has an 8-GPU node"}
+            del sp, keep
+            for c_ in ctxs:
+                c_.close()
+        sync()
     return out
 
 

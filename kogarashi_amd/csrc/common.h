@@ -241,7 +241,9 @@ template <class F> struct RefIO<Fp2<F>> {
 struct MsmSorted {
   size_t n = 0;
   int c = 0, W = 0, B = 0;
-  uint32_t T = 0, T2 = 16;
+  uint32_t T = 0, T2 = 16, T_top = 0, nhot = 0;   // T_top: task length of the unsigned top window (window top_w of this object, -1: none); nhot: hot buckets
+  int top_w = -1;
+  uint32_t* hot_list = nullptr;                   // buckets with more than GATHER_SUM_MAX tasks (index w * B + b)
   size_t npts = 0, part_cap = 0;
   uint32_t ntasks = 0, max_cnt = 0;
   uint32_t *sorted = nullptr, *bsize = nullptr, *bstart = nullptr, *lcnt = nullptr, *lrel = nullptr, *lbase = nullptr;
@@ -283,13 +285,13 @@ struct MsmSortPlan {
   size_t n = 0, chunk_len = 0, nv = 0;
   int c = 0, W = 0, B = 0, Wb = 0, G = 0, nch = 0, maxseg = 0, mshift = 0, set = 0, ngroups = 1, info_base = 0;
   bool merged = false, two_pass = false;
-  uint32_t T = 0;
+  uint32_t T = 0, T_top = 0;
   int gw0[kg_ctx::MAX_GROUPS] = {}, gW[kg_ctx::MAX_GROUPS] = {};
   char* ws = nullptr;
   size_t o_kt = 0, o_cnt = 0, o_bsize = 0, o_bstart = 0, o_tmp = 0, o_gsize = 0, o_gstart = 0, o_segbase = 0, o_segcnt = 0, o_segoff = 0, o_sorted = 0,
          o_lcnt = 0, o_lrel = 0, o_rowtot = 0, o_bpart = 0, o_woff = 0, o_gsize_m = 0, o_gstart_m = 0, o_segbase_m = 0;
   size_t o_lbase[kg_ctx::MAX_GROUPS] = {}, o_misc[kg_ctx::MAX_GROUPS] = {}, o_lenh[kg_ctx::MAX_GROUPS] = {}, o_tbkt[kg_ctx::MAX_GROUPS] = {},
-         o_tid[kg_ctx::MAX_GROUPS] = {}, part_cap[kg_ctx::MAX_GROUPS] = {};
+         o_tid[kg_ctx::MAX_GROUPS] = {}, o_hot[kg_ctx::MAX_GROUPS] = {}, part_cap[kg_ctx::MAX_GROUPS] = {};
 };
 int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, size_t n, MsmSortPlan* P, bool ordered, int merged_c, int lane_mult,
                    int ngroups = 1, const int* gw = nullptr, bool on_main = false);

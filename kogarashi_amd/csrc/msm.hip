@@ -893,17 +893,24 @@ struct PointAoS<Fp2S<G>> {
 // key = min(length, 255); bins are laid out in DESCENDING key order.  One lane per bucket: a bucket contributes
 // ntask-1 full tasks (length T) and one remainder.
 constexpr int LEN_BINS = 256;
+// a bucket may reach the gather with up to GATHER_SUM_MAX partial sums (k_gather_sum adds them lane by lane); a bucket with
+// more is "hot" (a 0/1-heavy witness piles half of window 0 into one bucket): the sort lists such buckets and k_hot_sum folds each
+// one's partial sums with a workgroup-wide tree before the gather
+constexpr uint32_t GATHER_SUM_MAX = 32;
+constexpr uint32_t HOT_MAX = 4096;                   // hot buckets one k_hot_sum launch takes (more: the lane-by-lane rounds)
+__device__ __forceinline__ uint32_t task_len(uint32_t T, uint32_t T_top, int w, int top_w) { return w == top_w ? T_top : T; }
 __device__ __forceinline__ uint32_t len_key(uint32_t len) { return len > 255u ? 255u : len; }
 
 __global__ void __launch_bounds__(1024) k_len_scatter(const uint32_t* __restrict__ bsize, const uint32_t* __restrict__ ntask,
                                                       const uint32_t* __restrict__ rel, const uint32_t* __restrict__ base, size_t total, int B,
-                                                      uint32_t T, uint32_t* __restrict__ cursor, uint32_t* __restrict__ task_bkt,
-                                                      uint32_t* __restrict__ task_id) {
+                                                      uint32_t T0, uint32_t* __restrict__ cursor, uint32_t* __restrict__ task_bkt,
+                                                      uint32_t* __restrict__ task_id, uint32_t T_top, int top_w) {
   KG_SERVICE_PRIO();
   __shared__ uint32_t h[LEN_BINS], start[LEN_BINS], fill[LEN_BINS];
   if (threadIdx.x < LEN_BINS) { h[threadIdx.x] = 0; fill[threadIdx.x] = 0; }
   __syncthreads();
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t T = task_len(T0, T_top, (int)(t / B), top_w);
   uint32_t nt = 0, rem = 0;
   if (t < total) {
     nt = ntask[t];
@@ -935,12 +942,14 @@ __global__ void __launch_bounds__(1024) k_len_scatter(const uint32_t* __restrict
 // the window's task total, the largest bucket, and the histogram of task lengths -- everything the task decomposition
 // needs from one read of the sizes.
 constexpr int BR_NT = 256;
-__global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restrict__ bsize, int B, uint32_t T, uint32_t* __restrict__ bstart,
+__global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restrict__ bsize, int B, uint32_t T0, uint32_t* __restrict__ bstart,
                                                       uint32_t* __restrict__ ntask, uint32_t* __restrict__ rel, uint32_t* __restrict__ row_total,
-                                                      uint32_t* __restrict__ maxv, uint32_t* __restrict__ ghist) {
+                                                      uint32_t* __restrict__ maxv, uint32_t* __restrict__ ghist, uint32_t T_top, int top_w,
+                                                      uint32_t* __restrict__ hot_list, uint32_t hot_cap) {
   KG_SERVICE_PRIO();
   __shared__ uint32_t sh[40], h[LEN_BINS], red[16];
   const int w = blockIdx.x;
+  const uint32_t T = task_len(T0, T_top, w, top_w);
   if (threadIdx.x < LEN_BINS) h[threadIdx.x] = 0;
   __syncthreads();
   const int per = (B + BR_NT - 1) / BR_NT;
@@ -988,6 +997,9 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restric
       run_s += v; run_t += nt;
     }
   }
+  if (mx > GATHER_SUM_MAX * T)                          // rare: list this lane's hot buckets (maxv + 1 counts them)
+    for (int b = lo; b < hi; ++b)
+      if (src[b] > GATHER_SUM_MAX * T) { const uint32_t pos = atomicAdd(maxv + 1, 1u); if (pos < hot_cap) hot_list[pos] = (uint32_t)(w * B + b); }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
@@ -1004,11 +1016,13 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restric
 // `nsplit` parts of B / nsplit buckets with a workgroup each: k_bucket_part sums a part (entries, tasks, largest bucket,
 // length histogram), k_bucket_fill adds the parts in front of its own and writes starts / task counts / task prefixes.
 // One workgroup per row took 80 us for 65536 buckets; sixteen parts take two launches of ~10 us.
-__global__ void __launch_bounds__(BR_NT) k_bucket_part(const uint32_t* __restrict__ bsize, int B, uint32_t T, int nsplit, uint32_t* __restrict__ part,
-                                                      uint32_t* __restrict__ maxv, uint32_t* __restrict__ ghist) {
+__global__ void __launch_bounds__(BR_NT) k_bucket_part(const uint32_t* __restrict__ bsize, int B, uint32_t T0, int nsplit, uint32_t* __restrict__ part,
+                                                      uint32_t* __restrict__ maxv, uint32_t* __restrict__ ghist, uint32_t T_top, int top_w,
+                                                      uint32_t* __restrict__ hot_list, uint32_t hot_cap) {
   KG_SERVICE_PRIO();
   __shared__ uint32_t sh[40], h[LEN_BINS], red[16];
   const int w = blockIdx.x, k = blockIdx.y, len = B / nsplit;
+  const uint32_t T = task_len(T0, T_top, w, top_w);
   if (threadIdx.x < LEN_BINS) h[threadIdx.x] = 0;
   __syncthreads();
   const int per = len / BR_NT;                           // len is a multiple of 4 * BR_NT (B >= 8192, nsplit <= B / 4096)
@@ -1023,6 +1037,12 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_part(const uint32_t* __restric
     }
   };
   for (int b = 0; b < per; b += 4) { const uint4 q = *reinterpret_cast<const uint4*>(src + b); tally(q.x); tally(q.y); tally(q.z); tally(q.w); }
+  if (mx > GATHER_SUM_MAX * T)                          // rare: list this lane's hot buckets (maxv + 1 counts them)
+    for (int b = 0; b < per; ++b)
+      if (src[b] > GATHER_SUM_MAX * T) {
+        const uint32_t pos = atomicAdd(maxv + 1, 1u);
+        if (pos < hot_cap) hot_list[pos] = (uint32_t)((size_t)w * B + (size_t)k * len + (size_t)threadIdx.x * per + b);
+      }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { full += __shfl_xor(full, d); const uint32_t o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
   if ((threadIdx.x & 63) == 0) { if (full) atomicAdd(&h[len_key(T)], full); red[threadIdx.x >> 6] = mx; }
@@ -1038,12 +1058,13 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_part(const uint32_t* __restric
   }
   if (threadIdx.x < LEN_BINS && h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
 }
-__global__ void __launch_bounds__(BR_NT) k_bucket_fill(const uint32_t* __restrict__ bsize, int B, uint32_t T, int nsplit, const uint32_t* __restrict__ part,
+__global__ void __launch_bounds__(BR_NT) k_bucket_fill(const uint32_t* __restrict__ bsize, int B, uint32_t T0, int nsplit, const uint32_t* __restrict__ part,
                                                       uint32_t* __restrict__ bstart, uint32_t* __restrict__ ntask, uint32_t* __restrict__ rel,
-                                                      uint32_t* __restrict__ row_total) {
+                                                      uint32_t* __restrict__ row_total, uint32_t T_top, int top_w) {
   KG_SERVICE_PRIO();
   __shared__ uint32_t sh[40];
   const int w = blockIdx.x, k = blockIdx.y, len = B / nsplit;
+  const uint32_t T = task_len(T0, T_top, w, top_w);
   uint32_t base_s = 0, base_t = 0;
   for (int j = 0; j < k; ++j) { base_s += part[((size_t)w * nsplit + j) * 2]; base_t += part[((size_t)w * nsplit + j) * 2 + 1]; }
   const int per = len / BR_NT;
@@ -1082,11 +1103,12 @@ __global__ void __launch_bounds__(64) k_task_bases(const uint32_t* __restrict__ 
     uint32_t run = 0;
     for (int w = 0; w < W; ++w) { base[w] = run; run += row_total[w]; }
     base[W] = run;
-    const uint32_t mx = *maxv;
+    const uint32_t mx = *maxv, hot = maxv[1];        // largest bucket; buckets with more than GATHER_SUM_MAX tasks
     info[0] = run;
     info[1] = mx;
     host_info[0] = run;
     host_info[1] = mx;
+    host_info[2] = hot;
   }
   static_assert(LEN_BINS == 256, "four bins per lane");
   const uint32_t h0 = ghist[4 * lane], h1 = ghist[4 * lane + 1], h2 = ghist[4 * lane + 2], h3 = ghist[4 * lane + 3];
@@ -1151,7 +1173,7 @@ template <class F>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::MIN))) k_acc_tasks(AccSets A, const uint32_t* __restrict__ sorted,
                                                   const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bsize, Level L,
                                                   const uint32_t* __restrict__ task_bkt, const uint32_t* __restrict__ task_id,
-                                                  size_t n, int W, int B, uint32_t T, size_t pstride, int mshift) {
+                                                  size_t n, int W, int B, uint32_t T0, size_t pstride, int mshift, uint32_t T_top, int top_w) {
   const int set = A.nsets > 1 ? (int)(blockIdx.x % (unsigned)A.nsets) : 0;
   const uint32_t p = ((A.nsets > 1 ? blockIdx.x / (unsigned)A.nsets : blockIdx.x) * blockDim.x + threadIdx.x) / Lanes<F>::N;   // Fq2: a lane pair per task
   if (p >= L.base[W]) return;
@@ -1165,6 +1187,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
   const size_t bi = task_bkt[p];
   const uint32_t t = task_id[p];
   const int w = (int)(bi / B);
+  const uint32_t T = task_len(T0, T_top, w, top_w);
   const uint32_t seg = t - L.base[w] - L.rel[bi];
   const uint32_t len_all = bsize[bi];
   const uint32_t lo = seg * T, hi = lo + T < len_all ? lo + T : len_all;
@@ -1204,7 +1227,6 @@ __global__ void __launch_bounds__(256) k_gather_buckets(const uint32_t* __restri
 // from the partial sums, a lane (lane pair for G2) per bucket adding its <= GATHER_SUM_MAX partial sums -- instead of a
 // partial-sum round (task count, row scan, bases, k_sum_tasks) followed by the gather: six launches and ~130 us less on the
 // reduction queue per MSM.  KF = F, or the lane-pair form of Fq2 reading the one-lane layout k_acc_tasks<Fq2> wrote.
-constexpr uint32_t GATHER_SUM_MAX = 32;
 template <class F, class KF> struct PartialIO {
   static __device__ __forceinline__ XYZZ<KF> load(const uint32_t* base, size_t i) { return PointAoS<F>::load(base, i); }
 };
@@ -1367,7 +1389,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HalveWa
   const uint32_t total = (uint32_t)W * (uint32_t)B;
   if (t >= total) return;
   const uint32_t w = t / (uint32_t)B;
-  const uint32_t cnt = L.cnt[t];
+  uint32_t cnt = L.cnt[t];
+  if (cnt > GATHER_SUM_MAX) cnt = 1;                   // a hot bucket: k_hot_sum left its sum in the first partial's place
   const BufRsrc rin = soa_rsrc(pin), rout = soa_rsrc(buckets);
   const uint32_t first = cnt ? L.base[w] + L.rel[t] : 0u;
   SoaDst<KF> dst{rout, total * 4u, t * 4u};
@@ -1539,6 +1562,44 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveW
   }
 }
 
+// Hot buckets (more than GATHER_SUM_MAX partial sums: the sort lists them): one workgroup per bucket folds ALL its partial sums --
+// every task-lane sums a strided share into an LDS slot, then a tree over the slots -- and leaves the total where the bucket's
+// first partial sum was.  The lane-by-lane rounds this replaces (k_task_count / k_scan_rows / k_row_bases / k_sum_tasks, sixteen
+// partial sums per lane and round) took two rounds of four launches, 0.5-0.8 ms of latency per MSM of a 0/1-heavy witness.
+template <class KF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveWaves<KF>::MIN))) k_hot_sum(uint32_t* part, Level L, int B, const uint32_t* __restrict__ hot_list) {
+  KG_REDUCE_PRIO();
+  extern __shared__ uint32_t lds[];                   // 36 words x 256 lane-items
+  constexpr uint32_t LPT = Lanes<KF>::N, NT = 256 / LPT, NWB = (uint32_t)PointIO<KF>::NW * 4u;
+  const uint32_t t = hot_list[blockIdx.x];
+  const uint32_t w = t / (uint32_t)B, cnt = L.cnt[t], first = L.base[w] + L.rel[t];
+  const uint32_t task = threadIdx.x / LPT, half = threadIdx.x % LPT;
+  const BufRsrc rp = soa_rsrc(part);
+  const LdsPt<KF> mine{lds, 256u, threadIdx.x};
+  if (task < cnt) {
+    copy_xyzz_stream<KF>(AosSrc<KF>{rp, (first + task) * NWB, true}, mine);
+    for (uint32_t j = task + NT; j < cnt; j += NT) {
+      KG_STREAM_FENCE();
+      add_xyzz_stream<KF>(mine, AosSrc<KF>{rp, (first + j) * NWB, true}, mine);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 36; ++k) lds[(uint32_t)k * 256u + threadIdx.x] = 0u;      // the identity
+  }
+  __syncthreads();
+  for (uint32_t h = NT / 2; h >= 1; h >>= 1) {
+    if (task < h) {
+      const LdsPt<KF> other{lds, 256u, (task + h) * LPT + half};
+      add_xyzz_stream<KF>(mine, other, mine);
+    }
+    __syncthreads();
+  }
+  if (task == 0) {
+    const AosDst<KF> dst{rp, first * NWB};
+    copy_xyzz_stream<KF>(mine, dst);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
@@ -1692,10 +1753,16 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
   if (nch > 64) nch = 64;                         // (window, chunk) workgroups of the first sort pass: 1024 of them at 2^20
   if (nch < 1) nch = 1;
   size_t chunk_len = (n + nch - 1) / nch;
-  // one task per bucket for uniform scalars: the unsigned top window of c = 15/16 holds twice the average load
-  uint32_t T = (uint32_t)(4 * (n / B) + 32);
-  if (T < 64) T = 64;
-  if (T > 4096) T = 4096;
+  // Task length.  A task is one lane's sequential chain of additions, so the accumulation can never be shorter than T
+  // additions' latency (14 us each at four waves per SIMD, ~23 us for G2) however little work there is -- a 0/1-heavy witness
+  // (a third of a uniform input's additions) took LONGER than a uniform one with T = 4 n / B + 32: 1.47 against 1.04 ms for the
+  // prover's G2 query.  T = 2 n / B + 16 still leaves a uniform input one task per bucket (a bucket holds n / B entries on
+  // average, Poisson: 2 n / B + 16 is 8 sigma out at n / B = 16 and 8.5 at 32); the unsigned top window holds twice the load per
+  // bucket and gets twice the length (T_top).  Hot buckets pay for the shorter tasks with more partial sums: k_hot_sum.
+  uint32_t T = (uint32_t)(2 * (n / B) + 16);
+  if (const char* e = getenv("KG_MSM_T")) { const int v = atoi(e); if (v >= 4 && v <= 4096) T = (uint32_t)v; }      // experiments
+  if (T < 32) T = 32;
+  if (T > 2048) T = 2048;
   if (merged) {
     // a bucket holds ~W n / B entries (60 at 2^18, 240 at 2^20): cut so that the accumulation has about one resident round of
     // lanes (4096 waves); every task beyond the first of a bucket costs one partial-sum addition afterwards
@@ -1741,6 +1808,7 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
     Q.o_lbase[g] = cv.take((size_t)(Q.gW[g] + 1) * 4);
     Q.o_misc[g] = cv.take(64); Q.o_lenh[g] = cv.take(2 * LEN_BINS * 4);             // adjacent: one zero fill covers both
     Q.o_tbkt[g] = cv.take(Q.part_cap[g] * 4); Q.o_tid[g] = cv.take(Q.part_cap[g] * 4);
+    Q.o_hot[g] = cv.take((size_t)HOT_MAX * 4);
   }
   // The scalar side runs on a queue of its own and alternates between two spaces: while MSM i accumulates (main queue,
   // reading set i & 1), MSM i+1 is sorted into the other set.  Ordering: the scalar queue waits for `after` (the producer
@@ -1762,6 +1830,7 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
   ctx->ws_idle_n[set] = 0;
   Q.n = n; Q.chunk_len = chunk_len; Q.nv = nv; Q.c = c; Q.W = W; Q.B = B; Q.Wb = Wb; Q.G = G; Q.nch = nch; Q.maxseg = maxseg; Q.mshift = mshift;
   Q.set = set; Q.ngroups = ngroups; Q.merged = merged; Q.two_pass = two_pass; Q.T = T; Q.ws = ws;
+  Q.T_top = merged ? T : 2 * T;
   uint32_t* kt = (uint32_t*)(ws + Q.o_kt);
   uint32_t* cnt = (uint32_t*)(ws + Q.o_cnt);
 
@@ -1821,6 +1890,11 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
   S->bstart = (uint32_t*)(ws + Q.o_bstart) + (size_t)w0 * B;
   S->lcnt = (uint32_t*)(ws + Q.o_lcnt) + (size_t)w0 * B; S->lrel = (uint32_t*)(ws + Q.o_lrel) + (size_t)w0 * B; S->lbase = (uint32_t*)(ws + Q.o_lbase[g]);
   S->task_bkt = (uint32_t*)(ws + Q.o_tbkt[g]); S->task_id = (uint32_t*)(ws + Q.o_tid[g]);
+  S->hot_list = (uint32_t*)(ws + Q.o_hot[g]);
+  S->T_top = Q.T_top;
+  S->top_w = (!merged && w0 + Wg == W) ? Wg - 1 : -1;       // the unsigned top window, if this group holds it
+  const uint32_t T_top = S->T_top;
+  const int top_w = S->top_w;
   {
     PhaseScope ph(ctx, "sort", st);
     const size_t lds = (size_t)(two_pass ? G : B) * 4;
@@ -1860,13 +1934,13 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
     if (B >= 8192) {
       const int nsplit = B / 4096;                    // <= 16 parts per row
       uint32_t* bpart = (uint32_t*)(ws + Q.o_bpart) + (size_t)w0 * nsplit * 2;
-      hipLaunchKernelGGL(k_bucket_part, dim3(Wg, nsplit), dim3(BR_NT), 0, st, S->bsize, B, T, nsplit, bpart, misc, lenh);
-      hipLaunchKernelGGL(k_bucket_fill, dim3(Wg, nsplit), dim3(BR_NT), 0, st, S->bsize, B, T, nsplit, bpart, S->bstart, S->lcnt, S->lrel, rowtot);
+      hipLaunchKernelGGL(k_bucket_part, dim3(Wg, nsplit), dim3(BR_NT), 0, st, S->bsize, B, T, nsplit, bpart, misc, lenh, T_top, top_w, S->hot_list, HOT_MAX);
+      hipLaunchKernelGGL(k_bucket_fill, dim3(Wg, nsplit), dim3(BR_NT), 0, st, S->bsize, B, T, nsplit, bpart, S->bstart, S->lcnt, S->lrel, rowtot, T_top, top_w);
     } else
-      hipLaunchKernelGGL(k_bucket_rows, dim3(Wg), dim3(BR_NT), 0, st, S->bsize, B, T, S->bstart, S->lcnt, S->lrel, rowtot, misc, lenh);
+      hipLaunchKernelGGL(k_bucket_rows, dim3(Wg), dim3(BR_NT), 0, st, S->bsize, B, T, S->bstart, S->lcnt, S->lrel, rowtot, misc, lenh, T_top, top_w, S->hot_list, HOT_MAX);
     hipLaunchKernelGGL(k_task_bases, dim3(1), dim3(64), 0, st, rowtot, Wg, S->lbase, misc, misc + 4, lenh, lenh + LEN_BINS, (uint32_t*)ctx->h_pinned_dev + 4 * gi);
     KG_HIP(ctx, hipEventRecord(ctx->ev_info[gi], st));
-    hipLaunchKernelGGL(k_len_scatter, dim3(g1024), dim3(1024), 0, st, S->bsize, S->lcnt, S->lrel, S->lbase, npts, B, T, lenh + LEN_BINS, S->task_bkt, S->task_id);
+    hipLaunchKernelGGL(k_len_scatter, dim3(g1024), dim3(1024), 0, st, S->bsize, S->lcnt, S->lrel, S->lbase, npts, B, T, lenh + LEN_BINS, S->task_bkt, S->task_id, T_top, top_w);
     if (two_pass)
       hipLaunchKernelGGL(k_fine_scatter, dim3(Wg, maxseg < FS_ROWS ? maxseg : FS_ROWS), dim3(512), 0, st, f_tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bstart, segcnt, segoff, S->sorted);
     else
@@ -1896,7 +1970,8 @@ int msm_sort_wait(kg_ctx* ctx, MsmSorted* S) {
   host_trace("sort: info back");
   const uint32_t* h_info = (const uint32_t*)ctx->h_pinned + 4 * S->group;
   S->ntasks = h_info[0];
-  S->max_cnt = (h_info[1] + S->T - 1) / S->T;          // most tasks any bucket has
+  S->max_cnt = (h_info[1] + S->T - 1) / S->T;          // most tasks any bucket has (an upper bound when the largest bucket is in the top window)
+  S->nhot = h_info[2];                                 // buckets with more than GATHER_SUM_MAX tasks (listed up to HOT_MAX)
   if (S->ntasks > S->part_cap) return set_err(ctx, KG_ERR_HIP, "task count exceeds its bound");
   return KG_OK;
 }
@@ -2009,10 +2084,10 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
     static const bool pair_acc = [] { const char* e = getenv("KG_G2_PAIR_ACC"); return e && atoi(e) != 0; }();
     if (LPT > 1 && pair_acc)          // experiment: G2 accumulation on lane pairs, ~150 VGPRs instead of 256
       hipLaunchKernelGGL(k_acc_tasks<KF>, dim3((unsigned)(((size_t)S.ntasks * LPT + 63) / 64) * (unsigned)njobs), dim3(64), 0, st, A, S.sorted, S.bstart, S.bsize, L0,
-                         S.task_bkt, S.task_id, S.n, W, B, S.T, part_cap, S.merged_shift);
+                         S.task_bkt, S.task_id, S.n, W, B, S.T, part_cap, S.merged_shift, S.T_top, S.top_w);
     else
     hipLaunchKernelGGL(k_acc_tasks<F>, dim3(((S.ntasks + 63) / 64) * (unsigned)njobs), dim3(64), 0, st, A, S.sorted, S.bstart, S.bsize, L0, S.task_bkt, S.task_id,
-                       S.n, W, B, S.T, part_cap, S.merged_shift);
+                       S.n, W, B, S.T, part_cap, S.merged_shift, S.T_top, S.top_w);
     ph.end();
   }
   for (int k = 0; k < njobs; ++k) {
@@ -2044,8 +2119,17 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       uint32_t max_cnt = S.max_cnt;
       int lv = -1;                                     // -1: level arrays of S; 0/1: local ping-pong
       const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
+      static const bool hot_ok = !(getenv("KG_HOT_SUM") && atoi(getenv("KG_HOT_SUM")) == 0);
+      if (max_cnt > GATHER_SUM_MAX && hot_ok && S.nhot >= 1 && S.nhot <= HOT_MAX && (size_t)part_cap * NW * 4 < ((size_t)1 << 32)) {
+        // the few buckets with more partial sums than the gather takes: one workgroup-wide tree each
+        PhaseScope ph2(ctx, "hot_sum", side);
+        hipLaunchKernelGGL(k_hot_sum<KF>, dim3(S.nhot), dim3(256), 36 * 256 * 4, side, part[pcur], L, B, S.hot_list);
+        ph2.end();
+        max_cnt = GATHER_SUM_MAX;
+      }
       while (max_cnt > GATHER_SUM_MAX) {               // (at most GATHER_SUM_MAX partial sums per bucket are left to the gather below)
         const int nx = lv < 0 ? 0 : (lv ^ 1);
+        PhaseScope pr(ctx, "partial_round", side);         // one per extra round: its count is what a skewed input costs (bench.py msm_skewed)
         uint32_t* ncnt = (uint32_t*)(ws + o_lc[nx]);
         uint32_t* nrel = (uint32_t*)(ws + o_lr[nx]);
         uint32_t* nbase = (uint32_t*)(ws + o_lb[nx]);
@@ -2057,6 +2141,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
         // the task count of this round is bounded by the previous one; threads beyond base[W] exit
         const uint32_t bound = lv < 0 ? S.ntasks : (uint32_t)part_cap;
         hipLaunchKernelGGL(k_sum_tasks<KF>, dim3((unsigned)(((size_t)bound * LPT + 63) / 64)), dim3(64), 0, side, part[pcur], L, Lout, W, B, S.T2, part[pcur ^ 1]);
+        pr.end();
         pcur ^= 1;
         L = Lout;
         lv = nx;

@@ -59,6 +59,56 @@ class ChainCircuit:
         self.c = (np.arange(m + 1, dtype=np.uint64), wire[1:].copy(), ones)
 
 
+def witness_like(scal: np.ndarray, seed: int) -> np.ndarray:
+    """Scalars distributed like a Groth16 aux vector (groth16/src/prover.rs:53-65 meets bit decompositions and selectors): half
+    ones, a fifth zeros, a tenth -1, a tenth the small value 5, a tenth left as they are (uniform).  In place on an (n, 4) array
+    of Montgomery limbs; the same distribution as tests/test_gpu_large.py::_witness_like."""
+    n = len(scal)
+    kind = np.random.default_rng(seed).integers(0, 10, n)
+    scal[kind < 5] = np.array(mont(1), dtype=np.uint64)
+    scal[(kind >= 5) & (kind < 7)] = 0
+    scal[kind == 7] = np.array(mont(R_MOD - 1), dtype=np.uint64)
+    scal[kind == 8] = np.array(mont(5), dtype=np.uint64)
+    return scal
+
+
+class BooleanHeavyCircuit:
+    """A circuit whose witness looks like a real one: mc chain constraints t_{i+1} = t_i (t_i + 1) (uniform wires) followed by
+    mb booleanity constraints b (b - 1) = 0 on wires that are 1 (5 of 7) or 0 (2 of 7) -- z = x || w is then half ones, a fifth
+    zeros, three tenths uniform.  Same interface as ChainCircuit; x = [1, t_0], w = [t_1 .. t_mc, b_1 .. b_mb]."""
+
+    def __init__(self, m: int, t0: int = 0x123456789ABCDEF0123456789ABCDEF, seed: int = 7):
+        mc = (3 * m) // 10
+        mb = m - mc
+        self.m, self.l, self.m_l_1 = m, 2, m
+        t = [t0 % R_MOD]
+        for _ in range(mc):
+            t.append(t[-1] * (t[-1] + 1) % R_MOD)
+        bits = (np.random.default_rng(seed).integers(0, 7, mb) < 5).astype(np.int64)
+        one = np.array(mont(1), dtype=np.uint64)
+        zero = np.zeros(4, dtype=np.uint64)
+        minus_one = np.array(mont(R_MOD - 1), dtype=np.uint64)
+        tm = mont_vec(t)
+        bm = np.where(bits[:, None] == 1, one[None, :], zero[None, :]).astype(np.uint64)
+        self.a_eval = np.concatenate([tm[:mc], bm])                                          # A z: t_i | b_j
+        self.b_eval = np.concatenate([mont_vec([(v + 1) % R_MOD for v in t[:mc]]),           # B z: t_i + 1 | b_j - 1
+                                      np.where(bits[:, None] == 1, zero[None, :], minus_one[None, :]).astype(np.uint64)])
+        self.c_eval = np.concatenate([tm[1:], np.zeros((mb, 4), dtype=np.uint64)])           # C z: t_{i+1} | 0
+        self.x = np.stack([one, tm[0]])
+        self.w = np.concatenate([tm[1:], bm])
+        wire_t = np.concatenate([[1], 2 + np.arange(mc, dtype=np.uint64)]).astype(np.uint64)    # t_0: instance wire 1; t_i: witness i-1
+        wire_b = (2 + mc + np.arange(mb, dtype=np.uint64)).astype(np.uint64)
+        self.a = (np.arange(m + 1, dtype=np.uint64), np.concatenate([wire_t[:mc], wire_b]), np.tile(one, (m, 1)))
+        b_col = np.empty(2 * m, dtype=np.uint64)
+        b_col[0::2] = np.concatenate([wire_t[:mc], wire_b])
+        b_col[1::2] = 0
+        b_val = np.tile(one, (2 * m, 1))
+        b_val[2 * mc + 1::2] = minus_one                                                     # (b_j) + (-1) * 1
+        self.b = (np.arange(0, 2 * m + 1, 2, dtype=np.uint64), b_col, b_val)
+        c_ptr = np.concatenate([np.arange(mc + 1, dtype=np.uint64), np.full(mb, mc, dtype=np.uint64)])
+        self.c = (c_ptr, wire_t[1:].copy(), np.tile(one, (mc, 1)))
+
+
 def fixed_toxic() -> np.ndarray:
     """alpha, beta, gamma, delta, tau (the reference draws them from its rng, groth16/src/zksnark.rs:28-32)"""
     return mont_vec([(0xA11CE + 0x9E3779B97F4A7C15 * (j + 1)) ** 3 % R_MOD for j in range(5)])

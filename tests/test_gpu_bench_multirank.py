@@ -1,0 +1,42 @@
+"""The N > 1 path of bench.py as the driver starts it (`python bench.py --gpus N`: launch_ranks spawns the ranks before anything
+touches the GPU), on the one-GPU box: KG_BENCH_SELFTEST=1 puts every rank on cuda:0 and exchanges over gloo -- the control flow of
+the sharded MSM, the strong-scaled Nova commitment and the sharded Groth16 proof, not a measurement.  Checked against the
+one-rank run of the same command: the combined commitments must be the same points (nova/src/pedersen.rs:15-20)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench(gpus: int) -> dict:
+    env = dict(os.environ, KG_BENCH_SELFTEST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--prewarm", "2", "--log-n", "16",
+           "--nova-log-n", "16", "--groth16-log-m", "12", "--no-cpu-baseline", "--no-ntt", "--no-skew"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_two_ranks_run_the_whole_line_and_combine_to_the_one_rank_points():
+    one = _bench(1)
+    two = _bench(2)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["sharding"] == "index range" and two["scaling"] == "weak"
+    nc1, nc2 = one["nova_commit"], two["nova_commit"]
+    assert nc1["ranks"] == 1 and nc2["ranks"] == 2 and nc2["pairs_per_rank"] * 2 == nc2["pairs_total"] == nc1["pairs_total"]
+    for leg in ("g1_fr", "grumpkin_fq"):             # one commitment cut over the ranks = the same point
+        assert nc1[leg]["point"] == nc2[leg]["point"], leg
+        assert not nc2[leg]["point"]["is_identity"]
+    g = two["groth16"]
+    assert g["replicas"] == 2 and g["pipelined_matches_blocking"]
+    assert g["sharded"]["contexts"] == 2 and g["sharded"]["matches_single_context"]
+    assert "sharded" not in one["groth16"]

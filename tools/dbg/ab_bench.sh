@@ -5,7 +5,7 @@ O=${1:-gpurun_out/ab}; mkdir -p $O
 for rep in $(seq 1 ${2:-3}); do
   for so in build/exp/libkg_*.so; do
     n=${so##*/libkg_}; n=${n%.so}
-    KG_LIB_PATH=$PWD/$so timeout -s KILL 300 python3 bench.py --no-cpu-baseline --no-nova --no-ntt > $O/${n}_$rep.json 2> $O/${n}_$rep.err
+    KG_LIB_PATH=$PWD/$so timeout -s KILL 300 python3 bench.py --no-cpu-baseline --no-nova --no-ntt --no-skew > $O/${n}_$rep.json 2> $O/${n}_$rep.err
   done
 done
 python3 - "$O" <<'PY'

@@ -35,5 +35,6 @@ else:
             ctx.profile_summary(); ctx.profile_enable(False)
         return out
     ctx.groth16_prove = wrapped
-o = bench.bench_groth16(ctx, torch, dev, K, bench.single_rank_env(torch, dev), int(sys.argv[1]) if len(sys.argv) > 1 else 18, steps=4, cpu=False)
+o = bench.bench_groth16(ctx, torch, dev, K, bench.single_rank_env(torch, dev), int(sys.argv[1]) if len(sys.argv) > 1 else 18, steps=4, cpu=False,
+                        circuit=os.environ.get("KG_TL_CIRCUIT", "chain"), from_witness=False)
 print(o["ms_per_proof"], o["ms_per_proof_blocking"])
