@@ -45,38 +45,58 @@ impl ResidentMatrix {
     }
 }
 
-/// 128-bit content hash of (a, b, c): every row boundary, column index and coefficient word goes in, so two constraint
-/// systems share resident matrices only if they are the same matrices.  One pass over the entries
-/// (`SparseMatrix::for_each_entry`, patches/zkstd_matrix_csr.diff), no allocation: this is what a proof pays instead of
-/// rebuilding and re-uploading the CSR.
-pub(crate) fn content_hash<F: PrimeField + 'static>(mats: [&SparseMatrix<F>; 3], l: usize) -> Option<[u64; 2]> {
+/// 128-bit content hash of (a, b, c) -- every row boundary, column index and coefficient word goes in -- plus the exact
+/// invariants that are cheap to keep (entries per matrix): two constraint systems share resident matrices only if they are
+/// the same matrices.  One pass over the entries (`SparseMatrix::for_each_entry`, patches/zkstd_matrix_csr.diff), no
+/// allocation.  NOT a cryptographic hash (FNV-1a and a second multiplicative mixer): it guards against a stale cache, not
+/// against an adversary who builds colliding circuits.  Structure words (matrix number, row boundary, row count) go through a
+/// different mixing step than data words (column, coefficient), so a data word can never stand in for a boundary.
+/// Callers pay this pass on FIRST SIGHT of a shape only (groth16.rs binds the shape to the cached `Parameters` entry; nova.rs
+/// to the folding shape) -- or on every call under `debug_assertions` / `KOGARASHI_AMD_VERIFY_SHAPE`.
+pub(crate) fn content_hash<F: PrimeField + 'static>(mats: [&SparseMatrix<F>; 3], l: usize) -> Option<Fingerprint> {
     scalar_words::<F>(&[])?;                                   // a field the backend serves: 4 x u64 per element
     let (mut h1, mut h2) = (0xcbf2_9ce4_8422_2325u64, 0x9e37_79b9_7f4a_7c15u64);
-    let mut mix = |w: u64| {
-        h1 = (h1 ^ w).wrapping_mul(0x0000_0100_0000_01b3);                                       // FNV-1a over 64-bit words
-        h2 = (h2.rotate_left(23) ^ w).wrapping_mul(0xff51_afd7_ed55_8ccd).wrapping_add(0x2545_f491_4f6c_dd1d);
-    };
+    let mut nnz = [0u64; 3];
     for (k, mat) in mats.iter().enumerate() {
-        mix(0xa5a5_0000_0000_0000 | k as u64);
+        let data = |w: u64, h1: &mut u64, h2: &mut u64| {
+            *h1 = (*h1 ^ w).wrapping_mul(0x0000_0100_0000_01b3);                                 // FNV-1a over 64-bit words
+            *h2 = (h2.rotate_left(23) ^ w).wrapping_mul(0xff51_afd7_ed55_8ccd).wrapping_add(0x2545_f491_4f6c_dd1d);
+        };
+        let structure = |w: u64, h1: &mut u64, h2: &mut u64| {
+            *h1 = (h1.rotate_left(29) ^ w ^ 0xa5a5_a5a5_a5a5_a5a5).wrapping_mul(0x9fb2_1c65_1e98_df25);
+            *h2 = (*h2 ^ w.rotate_left(32)).wrapping_mul(0xc2b2_ae3d_27d4_eb4f).wrapping_add(0x1656_67b1_9e37_79f9);
+        };
+        structure(k as u64, &mut h1, &mut h2);
         let mut last_row = usize::MAX;
+        let mut count = 0u64;
         mat.for_each_entry(l, |row, col, coeff| {
             if row != last_row {
-                mix(0x5a5a_0000_0000_0000 ^ row as u64);       // row boundary (empty rows shift every later row index)
+                structure(row as u64, &mut h1, &mut h2);       // row boundary (empty rows shift every later row index)
                 last_row = row;
             }
-            mix(col);
+            data(col, &mut h1, &mut h2);
             let w = unsafe { &*(coeff as *const F as *const [u64; 4]) };
-            w.iter().for_each(|&x| mix(x));
+            w.iter().for_each(|&x| data(x, &mut h1, &mut h2));
+            count += 1;
         });
-        mix(mat.rows() as u64);
+        structure(mat.rows() as u64, &mut h1, &mut h2);
+        nnz[k] = count;
     }
-    Some([h1, h2])
+    Some(Fingerprint { hash: [h1, h2], nnz, l: l as u64 })
+}
+
+/// what identifies the resident copy of a shape: the content hash and the exact counts it was taken over
+#[derive(Clone, Copy, PartialEq, Eq, Debug)]
+pub(crate) struct Fingerprint {
+    pub hash: [u64; 2],
+    pub nnz: [u64; 3],
+    pub l: u64,
 }
 
 /// Three matrices of one constraint system, resident; `fingerprint` = `content_hash` of the three.
 pub(crate) struct ResidentShape {
     pub m: [ResidentMatrix; 3],
-    pub fingerprint: [u64; 2],
+    pub fingerprint: Fingerprint,
     /// rows of each matrix and the largest column index any of them holds: what a call's (m, z) must cover
     pub rows: usize,
     pub max_col: u64,
@@ -86,8 +106,11 @@ unsafe impl Send for ResidentShape {}
 impl ResidentShape {
     /// Builds the host CSR of (a, b, c) and uploads it: only when no resident copy carries this fingerprint.
     pub fn build<F: PrimeField + 'static>(ctx: &Context, a: &SparseMatrix<F>, b: &SparseMatrix<F>, c: &SparseMatrix<F>, l: usize,
-                                           fingerprint: [u64; 2]) -> Option<Self> {
+                                           fingerprint: Fingerprint) -> Option<Self> {
         let host = [HostCsr::of(a, l)?, HostCsr::of(b, l)?, HostCsr::of(c, l)?];
+        if (0..3).any(|k| host[k].col.len() as u64 != fingerprint.nnz[k]) {
+            return None;                                       // the fingerprint was not taken over these matrices
+        }
         let rows = host[0].row_ptr.len() - 1;
         if host.iter().any(|h| h.row_ptr.len() != rows + 1) {
             return None;                                       // the three matrices of a shape have one row per constraint

@@ -25,7 +25,8 @@ pub fn transform<F: FftField + 'static>(k: usize, data: &mut Vec<F>, what: Trans
     data.resize(n, F::zero());
     cast_slice::<F, Fr>(data)?;
     let ctxs = contexts()?;
-    let ctx = &ctxs[0];
+    let ctx = ctxs.lock_any()?;                                // a transform brings its data along: any GPU that is free
+    let ctx = &*ctx;
     let words = unsafe { core::slice::from_raw_parts(data.as_ptr() as *const u64, 4 * n) };
     let d = DeviceBuf::from_words(ctx, words).ok()?;
     let rc = unsafe {

@@ -17,6 +17,8 @@
 use core::any::TypeId;
 use core::ffi::c_void;
 use core::ptr;
+use std::collections::HashMap;
+use std::sync::Mutex;
 
 use bn_254::{Fq, Fq2, Fr, G1Affine, G1Projective, G2Affine, G2Projective};
 use grumpkin::{Affine as GkAffine, Projective as GkProjective};
@@ -108,18 +110,56 @@ impl Drop for DeviceBuf {
 
 mod global {
     use super::*;
-    use std::sync::{Mutex, MutexGuard};
+    use std::sync::{Arc, MutexGuard};
+
+    /// One GPU's context behind its OWN lock: threads that work on different GPUs (or wait for different calls) do not
+    /// serialise on a process-wide guard -- the reference's callers fan out on the rayon pool ("callable from any
+    /// thread, re-entrant").  Calls on one context are serialised, as the ABI asks.
+    pub struct CtxSlot(Mutex<Context>);
 
     // `Mutex::new` is const on the reference's pinned toolchain (nightly-2022-11-14); `OnceLock` is not stable there.
-    // None: not probed yet; Some(vec): probed -- an empty vec means "no device", and is never probed again.
-    static CTXS: Mutex<Option<Vec<Context>>> = Mutex::new(None);
+    // None: not probed yet; Some(vec): probed -- an empty vec means "no device", and is never probed again.  This lock is held
+    // only while the list is created or its `Arc` is cloned, never across a backend call.
+    static CTXS: Mutex<Option<Arc<Vec<CtxSlot>>>> = Mutex::new(None);
+    // round-robin cursor of `lock_any`
+    static NEXT: Mutex<Option<usize>> = Mutex::new(None);
 
-    /// The contexts of the visible GPUs (one each), created on first use, behind the process-wide lock.
-    pub struct Contexts(MutexGuard<'static, Option<Vec<Context>>>);
-    impl core::ops::Deref for Contexts {
-        type Target = Vec<Context>;
-        fn deref(&self) -> &Vec<Context> {
-            self.0.as_ref().unwrap()
+    /// The contexts of the visible GPUs (one each).  Cheap to obtain and to hold: a reference-counted list, no lock.
+    #[derive(Clone)]
+    pub struct Contexts(Arc<Vec<CtxSlot>>);
+    impl Contexts {
+        pub fn len(&self) -> usize {
+            self.0.len()
+        }
+        /// context i, for calls tied to state resident on that GPU (a CRS, a shape)
+        pub fn lock(&self, i: usize) -> Option<MutexGuard<'_, Context>> {
+            self.0.get(i)?.0.lock().ok()
+        }
+        /// any context, for calls that bring their inputs along (a transform, an MSM over host slices): the first one that is
+        /// free, starting at a round-robin cursor; the cursor's own context if all are busy
+        pub fn lock_any(&self) -> Option<MutexGuard<'_, Context>> {
+            let n = self.0.len();
+            let start = {
+                let mut c = NEXT.lock().ok()?;
+                let v = c.unwrap_or(0);
+                *c = Some((v + 1) % n.max(1));
+                v % n.max(1)
+            };
+            for k in 0..n {
+                if let Ok(g) = self.0[(start + k) % n].0.try_lock() {
+                    return Some(g);
+                }
+            }
+            self.0.get(start)?.0.lock().ok()
+        }
+        /// every context, in index order (one order everywhere: no deadlock), for the calls that span the node
+        /// (`kg_sharded_key_*`, `kg_groth16_prove_sharded`)
+        pub fn lock_all(&self) -> Option<Vec<MutexGuard<'_, Context>>> {
+            let mut v = Vec::with_capacity(self.0.len());
+            for s in self.0.iter() {
+                v.push(s.0.lock().ok()?);
+            }
+            Some(v)
         }
     }
 
@@ -130,27 +170,28 @@ mod global {
             let mut v = Vec::new();
             // one hardware queue per library queue; a no-op when the host exported GPU_MAX_HW_QUEUES or initialised HIP itself.
             // The glue's first backend call is the host's opt-in (`gpu` feature): call `kogarashi_amd::contexts()` from the
-            // start-up path if other threads may be reading the environment later.
+            // single-threaded start-up path if other threads may be reading the environment later (kg_init calls setenv).
             unsafe { sys::kg_init() };
             let n = Context::device_count();
             for d in 0..n.max(0) {
                 match Context::new(d) {
-                    Ok(c) => v.push(c),
+                    Ok(c) => v.push(CtxSlot(Mutex::new(c))),
                     Err(_) => {
                         v.clear();
                         break;
                     }
                 }
             }
-            *guard = Some(v);
+            *guard = Some(Arc::new(v));
         }
-        if guard.as_ref().map(|v| v.is_empty()).unwrap_or(true) {
+        let list = guard.as_ref()?.clone();
+        if list.is_empty() {
             return None;
         }
-        Some(Contexts(guard))
+        Some(Contexts(list))
     }
 }
-pub use global::contexts;
+pub use global::{contexts, Contexts};
 
 // ---- TypeId casts (same type on both sides, so these are identity conversions) ------------------------------------
 pub(crate) fn same<A: 'static, B: 'static>() -> bool {
@@ -272,11 +313,84 @@ pub(crate) fn marshal<C: GpuCurve>(pts: &[C]) -> (Vec<u64>, Vec<u8>) {
     (xy, inf)
 }
 
+/// Bases an MSM has met before, resident on GPU 0 in the MSM's internal form (`kg_bases_register`): keyed by the slice's address
+/// and length and guarded by a three-point probe (first, middle, last point) against a freed and re-used allocation -- an
+/// address-keyed cache, like `pedersen.rs`; a slice whose interior is rewritten in place between calls while its ends and its
+/// middle stay is NOT noticed (the reference's callers pass CRS vectors and commitment keys, which are immutable).  Marshalling
+/// 2^20 `repr(Rust)` points through `get_x() / get_y()` costs tens of milliseconds and the upload 1.3 ms (64 MB over PCIe) around a
+/// 1.8 ms device MSM: both are paid once per slice, a call then uploads its scalars (32 MB, 0.7 ms) and runs `kg_msm`.
+struct ResidentBases {
+    xy: DeviceBuf,
+    inf: Option<DeviceBuf>,
+    scalars: DeviceBuf,
+    probe: [u64; 6],
+    stamp: u64,
+}
+unsafe impl Send for ResidentBases {}
+const MSM_CACHE_SLOTS: usize = 8;
+static MSM_BASES: Mutex<Option<(u64, HashMap<(usize, usize, i32), ResidentBases>)>> = Mutex::new(None);
+
+fn probe3<C: GpuCurve>(pts: &[C]) -> [u64; 6] {
+    let n = pts.len();
+    let three = [pts[0], pts[n / 2], pts[n - 1]];
+    let (xy, _) = marshal(&three);
+    let at = |i: usize| (xy[i * C::WORDS], xy[i * C::WORDS + C::WORDS / 2]);
+    let (a, b, c) = (at(0), at(1), at(2));
+    [a.0, a.1, b.0, b.1, c.0, c.1]
+}
+
 fn msm_typed<C: GpuCurve>(bases: &[C], coeffs: *const u64, n: usize) -> Option<C::Extended> {
+    if n == 0 {
+        return None;                                           // the CPU body returns the identity at once
+    }
     let ctxs = contexts()?;
-    let (xy, inf) = marshal(&bases[..n]);
+    let bases = &bases[..n];
+    if n < (1 << 14) {
+        // small calls (the prover's `inputs` MSMs of length l): one host-array call, nothing worth keeping resident
+        let ctx = ctxs.lock_any()?;
+        let (xy, inf) = marshal(bases);
+        let mut out = [0u64; 24];
+        let rc = unsafe { sys::kg_msm_host(ctx.raw(), C::CURVE, xy.as_ptr(), inf.as_ptr(), coeffs, n, out.as_mut_ptr()) };
+        return if rc == sys::KG_OK { Some(C::extended_from(&out)) } else { None };
+    }
+    let ctx = ctxs.lock(0)?;                                   // the cache lives on GPU 0
+    let mut lock = MSM_BASES.lock().ok()?;
+    let (clock, cache) = lock.get_or_insert_with(|| (0, HashMap::new()));
+    *clock += 1;
+    let id = (bases.as_ptr() as usize, n, C::CURVE);
+    let probe = probe3(bases);
+    if cache.get(&id).map(|r| r.probe != probe).unwrap_or(false) {
+        if let Some(r) = cache.remove(&id) {
+            unsafe { sys::kg_bases_unregister(ctx.raw(), r.xy.as_u64() as *const u64) };
+        }
+    }
+    if !cache.contains_key(&id) {
+        if cache.len() >= MSM_CACHE_SLOTS {                    // evict the least recently used slice
+            let oldest = cache.iter().min_by_key(|(_, r)| r.stamp).map(|(k, _)| *k)?;
+            if let Some(r) = cache.remove(&oldest) {
+                unsafe { sys::kg_bases_unregister(ctx.raw(), r.xy.as_u64() as *const u64) };
+            }
+        }
+        let (xy, inf) = marshal(bases);
+        let d_xy = DeviceBuf::from_words(&ctx, &xy).ok()?;
+        let d_inf = if inf.iter().any(|&f| f != 0) { Some(DeviceBuf::from_bytes(&ctx, &inf).ok()?) } else { None };
+        let pi = d_inf.as_ref().map(|d| d.as_u8() as *const u8).unwrap_or(ptr::null());
+        let rc = unsafe { sys::kg_bases_register(ctx.raw(), C::CURVE, d_xy.as_u64() as *const u64, pi, n) };
+        if rc != sys::KG_OK {
+            return None;
+        }
+        let scalars = DeviceBuf::new(&ctx, 32 * n).ok()?;
+        cache.insert(id, ResidentBases { xy: d_xy, inf: d_inf, scalars, probe, stamp: 0 });
+    }
+    let r = cache.get_mut(&id)?;
+    r.stamp = *clock;
+    let rc = unsafe { sys::kg_memcpy_h2d(ctx.raw(), r.scalars.as_u8() as *mut c_void, coeffs as *const c_void, 32 * n) };
+    if rc != sys::KG_OK {
+        return None;
+    }
+    let pi = r.inf.as_ref().map(|d| d.as_u8() as *const u8).unwrap_or(ptr::null());
     let mut out = [0u64; 24];
-    let rc = unsafe { sys::kg_msm_host(ctxs[0].raw(), C::CURVE, xy.as_ptr(), inf.as_ptr(), coeffs, n, out.as_mut_ptr()) };
+    let rc = unsafe { sys::kg_msm(ctx.raw(), C::CURVE, r.xy.as_u64() as *const u64, pi, r.scalars.as_u64() as *const u64, n, out.as_mut_ptr()) };
     if rc != sys::KG_OK {
         return None;
     }

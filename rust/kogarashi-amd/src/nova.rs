@@ -28,7 +28,12 @@ pub fn cross_term<F: PrimeField + 'static>(a: &SparseMatrix<F>, b: &SparseMatrix
         return None;
     }
     let ctxs = contexts()?;
-    let ctx = &ctxs[0];
+    let ctx = ctxs.lock(0)?;                                   // the shapes are resident on GPU 0
+    let ctx = &*ctx;
+    // `R1csShape::matrices()` hands every call fresh clones (nova/src/prover.rs:63), so neither an address nor a cached
+    // `Parameters`-like entry identifies the shape here: one hashing pass per folding step (128 bits over every row boundary,
+    // column and coefficient plus the exact entry counts) -- O(nnz) host work, the same order as the clone the reference's own
+    // call site has just made -- decides whether the resident copy is still the shape's
     let print = content_hash([a, b, c], l)?;
     let mut guard = SHAPES.lock().ok()?;
     let shapes = guard.get_or_insert_with(HashMap::new);

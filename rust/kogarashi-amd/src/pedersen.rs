@@ -21,7 +21,9 @@ unsafe impl Send for Resident {}
 
 /// keys by (address of g, length): `PedersenCommitment` derives Clone / Encode / Decode / PartialEq, so the device handle
 /// lives here instead of in the struct; the fingerprint (first, middle and last generator) guards against a freed and
-/// re-used allocation.
+/// re-used allocation.  This is an ADDRESS-keyed cache with a three-point probe, not a content hash: a key whose interior
+/// generators are overwritten in place while those three stay is not noticed -- `PedersenCommitment { g }` is immutable in the
+/// reference (`nova/src/pedersen.rs:6-13`: built by `new`, only read afterwards), which is what makes the probe sufficient.
 static KEYS: Mutex<Option<HashMap<(usize, usize, i32), Resident>>> = Mutex::new(None);     // const `Mutex::new`: no `OnceLock` on the pinned nightly
 
 fn fingerprint(xy: &[u64], words: usize, n: usize) -> [u64; 6] {
@@ -35,6 +37,7 @@ fn commit_typed<C: GpuCurve>(g: &[C], m: *const u64, m_len: usize) -> Option<C> 
         return None;
     }
     let ctxs = contexts()?;
+    let all = ctxs.lock_all()?;                                // the key is spread over every GPU of the node: the call holds them all
     let mut keys_guard = KEYS.lock().ok()?;
     let keys = keys_guard.get_or_insert_with(HashMap::new);
     let id = (g.as_ptr() as usize, g.len(), C::CURVE);
@@ -52,7 +55,7 @@ fn commit_typed<C: GpuCurve>(g: &[C], m: *const u64, m_len: usize) -> Option<C> 
     }
     if !keys.contains_key(&id) {
         let (xy, inf) = marshal(g);
-        let raws: Vec<*mut sys::KgCtx> = ctxs.iter().map(|c| c.raw()).collect();
+        let raws: Vec<*mut sys::KgCtx> = all.iter().map(|c| c.raw()).collect();
         let mut key = core::ptr::null_mut();
         let rc = unsafe {
             sys::kg_sharded_key_create(raws.as_ptr(), raws.len() as i32, C::CURVE, xy.as_ptr(), inf.as_ptr(), g.len(), &mut key)

@@ -51,8 +51,9 @@ def test_glue_calls_match_the_header():
                 assert name in arity, (f, name)
                 assert n_args == arity[name], (f, name, n_args, arity[name])
                 seen.add(name)
-    for needed in ("kg_msm_host", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_sharded_key_create", "kg_sharded_key_commit",
-                   "kg_groth16_prove_bn254", "kg_bases_register", "kg_bases_precompute", "kg_nova_cross_term"):
+    for needed in ("kg_msm_host", "kg_msm", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_sharded_key_create", "kg_sharded_key_commit",
+                   "kg_groth16_prove_bn254", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_sharded", "kg_r1cs_evaluate", "kg_bases_register",
+                   "kg_bases_unregister", "kg_bases_precompute", "kg_nova_cross_term"):
         assert needed in seen, needed
 
 
@@ -93,7 +94,10 @@ def test_patches_apply_to_the_reference(tmp_path):
     # the call sites the patches name exist afterwards
     assert "kogarashi_amd::msm(bases, coeffs)" in (tmp_path / "groth16/src/msm.rs").read_text()
     assert "kogarashi_amd::pedersen::commit" in (tmp_path / "nova/src/pedersen.rs").read_text()
-    assert "kogarashi_amd::groth16::resident" in (tmp_path / "groth16/src/prover.rs").read_text()
+    prover = (tmp_path / "groth16/src/prover.rs").read_text()
+    assert "kogarashi_amd::groth16::resident" in prover
+    # the matrices are handed over as a closure: cs.matrices() (three O(nnz) clones) runs for the first proof against a CRS only
+    assert "crs.prove_cs_with(|| cs.matrices()," in prover and "let (a, b, c) = cs.matrices();" not in prover.split("let fft = Fft")[0]
     assert (tmp_path / "groth16/src/fft.rs").read_text().count("gpu::transform") == 5
     assert "kogarashi_amd::nova::cross_term" in (tmp_path / "nova/src/prover.rs").read_text()
     assert "pub fn to_csr" in (tmp_path / "zkstd/src/matrix.rs").read_text()
@@ -139,9 +143,57 @@ def test_resident_matrices_are_keyed_by_a_hash_of_all_their_content():
     csr = open(os.path.join(RUST, "kogarashi-amd", "src", "csr.rs")).read()
     assert "pub(crate) fn content_hash" in csr and "for_each_entry" in csr and ".take(8)" not in csr
     assert "pub fn covers" in csr
-    for f, needle in (("nova.rs", "content_hash([a, b, c], l)"), ("groth16.rs", "content_hash([a, b, c], x.len())")):
+    for f, needle in (("nova.rs", "content_hash([a, b, c], l)"), ("groth16.rs", "content_hash([&a, &b, &c], l)")):
         src = open(os.path.join(RUST, "kogarashi-amd", "src", f)).read()
         assert needle in src and ".covers(" in src, f
         assert "ResidentShape::host" not in src          # no host CSR rebuild on the per-call path
+    # exact invariants travel with the hash, and structure words do not share the data words' mixing step
+    assert "pub nnz: [u64; 3]" in csr and "let structure = |" in csr and "let data = |" in csr
+
+
+def _glue(name):
+    return open(os.path.join(RUST, "kogarashi-amd", "src", name)).read()
+
+
+def test_groth16_shape_is_bound_to_the_cached_parameters_entry():
+    """a proof against a resident CRS does not hash (or clone) the constraint matrices: first sight, debug builds and
+    KOGARASHI_AMD_VERIFY_SHAPE only"""
+    src = _glue("groth16.rs")
+    body = src.split("fn shape_for")[1].split("\n    }\n")[0]
+    assert "if shape.is_none() || verify_shape_every_proof()" in body
+    assert body.index("mats()") > body.index("if shape.is_none()")          # the closure is called inside the branch only
+    assert "cfg!(debug_assertions)" in src and "KOGARASHI_AMD_VERIFY_SHAPE" in src
+    assert "pub fn prove_cs_with(" in src
+
+
+def test_contexts_are_locked_one_by_one():
+    """no process-wide guard is held across a backend call: contexts() hands out a reference-counted list, every use locks the
+    context it needs (lock / lock_any / lock_all in index order)"""
+    lib = _glue("lib.rs")
+    assert "pub struct Contexts(Arc<Vec<CtxSlot>>)" in lib and "pub struct CtxSlot(Mutex<Context>)" in lib
+    for fn in ("pub fn lock(&self, i: usize)", "pub fn lock_any(&self)", "pub fn lock_all(&self)"):
+        assert fn in lib, fn
+    assert "MutexGuard<'static" not in lib
+    for f in os.listdir(os.path.join(RUST, "kogarashi-amd", "src")):
+        src = _glue(f)
+        assert not re.search(r"\bctxs\[\d+\]", src), f             # no direct indexing: a context is reached through its lock
+        if "contexts()" in src and f != "lib.rs":
+            assert re.search(r"ctxs\.lock(_any|_all)?\(", src), f
+
+
+def test_msm_bases_are_marshalled_once_per_slice():
+    lib = _glue("lib.rs")
+    body = lib.split("fn msm_typed")[1].split("\n}\n")[0]
+    assert "MSM_BASES" in body and "probe3(bases)" in body and "kg_bases_register" in body and "sys::kg_msm(" in body
+    assert body.index("if !cache.contains_key(&id)") < body.index("marshal(bases)", body.index("if !cache.contains_key(&id)"))
+    assert "MSM_CACHE_SLOTS" in lib and "min_by_key" in body           # bounded: least recently used slice is dropped
+
+
+def test_sharded_proof_is_wrapped():
+    src = _glue("groth16.rs")
+    assert "sys::kg_groth16_prove_sharded(" in src and "fn owners(n_ctx: usize) -> [usize; 3]" in src
+    assert "[0, 1 % n_ctx, 2 % n_ctx]" in src                          # the split kg_groth16_prove_sharded itself uses (groth16.hip)
+    hip = open(os.path.join(ROOT, "kogarashi_amd", "csrc", "groth16.hip")).read()
+    assert "const int owner[3] = {0, 1 % n_ctx, 2 % n_ctx};" in hip
     patch = open(os.path.join(RUST, "patches", "zkstd_matrix_csr.diff")).read()
     assert "pub fn for_each_entry" in patch and "pub fn rows" in patch
