@@ -75,6 +75,11 @@ KG_HD void static_for(Fn&& f) {
 // ---------------------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(KG_NO_ASM_MAC)
 #define KG_ASM_MAC 1
+// the chains assume wave64: the carry-out operand of v_mad_u64_u32 is an SGPR PAIR ("=&s" of a 64-bit variable); and the gfx9
+// constant-bus rule (one SGPR operand per VALU instruction: the "s" constants of macs_k)
+#if defined(__AMDGCN_WAVEFRONT_SIZE)
+static_assert(__AMDGCN_WAVEFRONT_SIZE == 64, "fp29.h multiply-accumulate chains are written for wave64 (gfx950)");
+#endif
 #endif
 // operands of a chain statement: %0 the 64-bit sum, %1 the carry-out pair, then (x[j], y[j]) as %(2 + 2j), %(3 + 2j)
 #define KG_MAD(op, a, b) op " %0, %1, %" #a ", %" #b ", %0\n\t"

@@ -13,9 +13,21 @@
 #pragma once
 #include "fp29.h"
 
+#if defined(KG_HOST_TEST) && !defined(__HIP_DEVICE_COMPILE__)
+#include <cstdio>
+#include <cstdlib>
+// host builds of the tests (tests/host/, -DKG_HOST_TEST): the bounds the comments below claim are asserted on every call -- the
+// 64-bit accumulators of lincomb, the limb ranges after each round, |f|, |g| <= 2^29, the lifted result below 2^261.  (The
+// bound-tracking FpChecked type routes inv_fast to the Fermat ladder: this is the binary GCD's own bound discipline.)
+#define KG_INV_CHECK(cond) do { if (!(cond)) { std::fprintf(stderr, "fp_inv.h bound violated: %s (line %d)\n", #cond, __LINE__); std::abort(); } } while (0)
+#else
+#define KG_INV_CHECK(cond) ((void)0)
+#endif
+
 namespace kg {
 
 namespace invd {
+KG_HD bool acc_ok(int64_t acc) { return acc < ((int64_t)1 << 62) && acc > -((int64_t)1 << 62); }
 // x * f + y * g (+ t * p) over nine signed-top limbs, divided by 2^29 (the low limb of the sum is zero by construction)
 template <class P, bool MOD>
 KG_HD void lincomb(const int32_t* x, const int32_t* y, int32_t f, int32_t g, int32_t* out) {
@@ -25,14 +37,17 @@ KG_HD void lincomb(const int32_t* x, const int32_t* y, int32_t f, int32_t g, int
     t = (((uint32_t)acc & M29) * P::INV) & M29;
     acc += (int64_t)((uint64_t)t * P::P[0]);
   }
+  KG_INV_CHECK(acc_ok(acc) && ((uint32_t)acc & M29) == 0);          // the low limb of the sum is zero by construction
   acc >>= 29;
 #pragma unroll
   for (int i = 1; i < 9; ++i) {
     acc += (int64_t)x[i] * f + (int64_t)y[i] * g;
     if (MOD) acc += (int64_t)((uint64_t)t * P::P[i]);
+    KG_INV_CHECK(acc_ok(acc));
     out[i - 1] = (int32_t)((uint32_t)acc & M29);
     acc >>= 29;
   }
+  KG_INV_CHECK(acc < ((int64_t)1 << 30) && acc >= -((int64_t)1 << 30));      // the signed top limb fits 32 bits with room for the next round's factors
   out[8] = (int32_t)acc;
 }
 // x <- -x where neg (all-ones mask) says so; limbs 0..7 stay in [0, 2^29), the top limb carries the sign
@@ -95,6 +110,8 @@ KG_HD Fp<P> inv_bingcd(const Fp<P>& x) {
       xa >>= 1;
       f1 <<= 1; g1 <<= 1;
     }
+    KG_INV_CHECK(f0 <= (1 << 29) && f0 >= -(1 << 29) && g0 <= (1 << 29) && g0 >= -(1 << 29) && f1 <= (1 << 29) && f1 >= -(1 << 29) &&
+                 g1 <= (1 << 29) && g1 >= -(1 << 29));
     int32_t an[9], bn[9], un[9], vn[9];
     invd::lincomb<P, false>(a, b, f0, g0, an);
     invd::lincomb<P, false>(a, b, f1, g1, bn);
@@ -107,6 +124,11 @@ KG_HD Fp<P> inv_bingcd(const Fp<P>& x) {
     invd::lincomb<P, true>(u, v, f1, g1, vn);
 #pragma unroll
     for (int i = 0; i < 9; ++i) { a[i] = an[i]; b[i] = bn[i]; u[i] = un[i]; v[i] = vn[i]; }
+#if defined(KG_HOST_TEST) && !defined(__HIP_DEVICE_COMPILE__)
+    for (int i = 0; i < 8; ++i) KG_INV_CHECK(a[i] >= 0 && a[i] < (1 << 29) && b[i] >= 0 && b[i] < (1 << 29) && u[i] >= 0 && u[i] < (1 << 29) && v[i] >= 0 && v[i] < (1 << 29));
+    KG_INV_CHECK(a[8] >= 0 && b[8] >= 0);                          // (a, b) stay non-negative after the conditional negation
+    KG_INV_CHECK(u[8] > -(1 << 27) && u[8] < (1 << 27) && v[8] > -(1 << 27) && v[8] < (1 << 27));      // |u|, |v| < 19 p: top limb |.| < 19 * 2^22 < 2^27
+#endif
   }
   // b = gcd = 1 (or p when a was 0, with v = 0); v = A^-1 mod p as a signed value in (-19p, 19p): lift by 32p and move to the
   // internal form of the inverse: mont(A^-1, 2^783) = A^-1 * 2^522 = a^-1 * 2^261
@@ -119,6 +141,7 @@ KG_HD Fp<P> inv_bingcd(const Fp<P>& x) {
     c = t >> 29;
   }
   r.l[8] = (uint32_t)(v[8] + (int32_t)P::P32[8] + (int32_t)c);
+  KG_INV_CHECK(v[8] + (int32_t)P::P32[8] + (int32_t)c >= 0 && r.l[8] < (1u << 29));      // 0 <= v + 32 p < 51 p < 2^261: a loose value mul() accepts
   return mul(r, Fp<P>::from_const(P::C_R3));
 }
 

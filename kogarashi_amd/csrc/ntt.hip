@@ -171,11 +171,17 @@ int get_tables(kg_ctx* ctx, uint32_t log_n, int inverse, kg_tw_cache** out) {
   const size_t cnt_b = nsteps == 3 ? (size_t)1 << (d[1].log_m + d[2].log_m) : 0;
   auto alloc = [&](uint32_t** p, size_t entries) { return entries == 0 || hipMalloc((void**)p, entries * 36) == hipSuccess; };
   if (!alloc(&t->small, 2u << (NTT_TW_LOG - 1)) || !alloc(&t->lo, n_lo) || !alloc(&t->hi, n_hi) || !alloc(&t->cos_lo, n_lo) ||
-      !alloc(&t->cos_hi, n_hi) || !alloc(&t->zinv, 1) || !alloc(&t->direct[0], cnt_a) || !alloc(&t->direct[1], cnt_b)) {
+      !alloc(&t->cos_hi, n_hi) || !alloc(&t->zinv, 1)) {
     (void)hipGetLastError();
     free_tables(t);                                    // releases whatever was allocated before the failure
     return set_err(ctx, KG_ERR_OOM, "twiddle table allocation");
   }
+  // The direct inter-step tables are an optimisation (36 B per entry: 151 MB per direction at 2^22, kept for the life of the
+  // context -- twice that for a forward + inverse pair, per context): when one cannot be allocated the step composes its twiddle
+  // from the lo / hi tables instead (one more product per element), it does not fail the transform.
+  size_t cnt_a_eff = cnt_a, cnt_b_eff = cnt_b;
+  if (!alloc(&t->direct[0], cnt_a)) { (void)hipGetLastError(); t->direct[0] = nullptr; cnt_a_eff = 0; }
+  if (!alloc(&t->direct[1], cnt_b)) { (void)hipGetLastError(); t->direct[1] = nullptr; cnt_b_eff = 0; }
   hipStream_t st = ctx->stream;
   hipLaunchKernelGGL(k_build_table, dim3((1u << (NTT_TW_LOG - 1)) / 64), dim3(64), 0, st, 0, log_n, inverse, t->lo_bits, 1u << (NTT_TW_LOG - 1), t->small);
   hipLaunchKernelGGL(k_build_table, dim3((n_lo + 63) / 64), dim3(64), 0, st, 1, log_n, inverse, t->lo_bits, n_lo, t->lo);
@@ -183,9 +189,9 @@ int get_tables(kg_ctx* ctx, uint32_t log_n, int inverse, kg_tw_cache** out) {
   hipLaunchKernelGGL(k_build_table, dim3((n_lo + 63) / 64), dim3(64), 0, st, 3, log_n, inverse, t->lo_bits, n_lo, t->cos_lo);
   hipLaunchKernelGGL(k_build_table, dim3((n_hi + 63) / 64), dim3(64), 0, st, 4, log_n, inverse, t->lo_bits, n_hi, t->cos_hi);
   hipLaunchKernelGGL(k_build_zinv, dim3(1), dim3(64), 0, st, log_n, t->zinv);
-  if (cnt_a)
+  if (cnt_a_eff)
     hipLaunchKernelGGL(k_build_direct, dim3((unsigned)((cnt_a + 63) / 64)), dim3(64), 0, st, log_n, inverse, (uint32_t)d[0].log_m, log_n - d[0].log_m, (uint64_t)1, t->direct[0]);
-  if (cnt_b)
+  if (cnt_b_eff)
     hipLaunchKernelGGL(k_build_direct, dim3((unsigned)((cnt_b + 63) / 64)), dim3(64), 0, st, log_n, inverse, (uint32_t)d[1].log_m, (uint32_t)d[2].log_m, (uint64_t)1 << d[0].log_m, t->direct[1]);
   const hipError_t le = hipGetLastError();
   if (le != hipSuccess) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the artefacts profiles/ holds for a round, on the GPU box:
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
-# then, back in the container:  python tools/install_profiles.py r02
+# then, back in the container:  python tools/install_profiles.py r04
 # Every leg is bounded by its own timeout; PMC passes run alone (never with a trace domain).
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"

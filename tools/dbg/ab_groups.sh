@@ -1,3 +1,4 @@
+#!/bin/bash
 mkdir -p gpurun_out/r4m
 for r in 1 2 3; do
   KG_MSM_GROUPS=0 python tools/dbg/groups.py 20 0 2>&1 | grep -v amdgpu | head -1

@@ -1,3 +1,4 @@
+#!/bin/bash
 mkdir -p gpurun_out/r4ab
 for r in 1 2 3; do for pl in 0 1; do
 KG_QUEUE_PLACEMENT=$pl python bench.py --no-cpu-baseline --no-nova --no-ntt --no-skew --no-groth16 > gpurun_out/r4ab/pl${pl}_$r.json 2>/dev/null

@@ -1,5 +1,5 @@
 import os, subprocess, sys
-here = "tools/dbg"
+here = os.path.dirname(os.path.abspath(__file__))
 for rep in range(2):
     for tile in ("10", "11", "12"):
         env = dict(os.environ, KG_NTT_STEPS="3", KG_NTT_TILE=tile)

@@ -1,3 +1,4 @@
+#!/bin/bash
 set -u
 export TMPDIR=/tmp
 O=gpurun_out/ab1; rm -rf $O; mkdir -p $O

@@ -1,3 +1,4 @@
+#!/bin/bash
 # blocking / pipelined Groth16 and MSM against the placement of the library's queues: bash tools/dbg/pad_sweep.sh out_dir [placement]
 #   KG_STREAM_PAD puts never-used streams in front of the context's queues; KG_QUEUE_PLACEMENT=0 switches the placement probe off
 O=${1:-gpurun_out/pad}; mkdir -p $O
