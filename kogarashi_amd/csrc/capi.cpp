@@ -407,7 +407,7 @@ int kg_memcpy_d2d(kg_ctx* c, void* dst, const void* src, size_t bytes) {
   return KG_OK;
 }
 int kg_msm_set_window(kg_ctx* c, int w) {
-  if (!c || w < 0 || w > 18) return KG_ERR_BAD_ARG;   // 17, 18 need the two-pass sort (2^16 <= n <= 2^24)
+  if (!c || w < 0 || w > 20) return KG_ERR_BAD_ARG;   // 17 .. 20 need the two-pass sort (2^16 <= n <= 2^24)
   c->msm_window = w;
   return KG_OK;
 }

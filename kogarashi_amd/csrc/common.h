@@ -283,7 +283,7 @@ int msm_sort_wait(kg_ctx* ctx, MsmSorted* S);
 // result words back.
 struct MsmSortPlan {
   size_t n = 0, chunk_len = 0, nv = 0;
-  int c = 0, W = 0, B = 0, Wb = 0, G = 0, nch = 0, maxseg = 0, mshift = 0, set = 0, ngroups = 1, info_base = 0;
+  int c = 0, W = 0, B = 0, Wb = 0, G = 0, nch = 0, maxseg = 0, mshift = 0, set = 0, ngroups = 1, info_base = 0, fb = 7;
   bool merged = false, two_pass = false;
   uint32_t T = 0, T_top = 0;
   int gw0[kg_ctx::MAX_GROUPS] = {}, gW[kg_ctx::MAX_GROUPS] = {};

@@ -471,7 +471,29 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint32_t* __restrict__ k
 // segment's place inside each bucket (atomicAdd on the bucket size returns it); k_fine_scatter sorts the segment in
 // LDS and copies it out run by run, so consecutive lanes write consecutive addresses.
 // ---------------------------------------------------------------------------------------------------
-constexpr int FINE_BITS = 7, FINE = 1 << FINE_BITS, SEG = 8192;
+constexpr int FINE_BITS = 7, SEG = 8192;
+// Entries between the two passes: the point index (24 bits; the window rides above it in a merged sort), the bucket's low FB bits
+// and the sign.  FB = 7 fits four bytes and serves windows up to c = 18 (2^17 buckets = 1024 groups of 128); wider windows
+// (c = 19, 20: the 2^23..2^24-pair commitments) take FB = 9 -- 1024 groups of 512 buckets -- in eight-byte entries.
+template <int FB> struct Ent;
+template <> struct Ent<7> {
+  using T = uint32_t;
+  static __device__ __forceinline__ T make(uint32_t idx_tag, uint32_t fine, bool neg) { return idx_tag | (fine << 24) | (neg ? 0x80000000u : 0u); }
+  static __device__ __forceinline__ uint32_t fine(T e) { return (e >> 24) & 127u; }
+  static __device__ __forceinline__ uint32_t out(T e) { return e & 0x80ffffffu; }
+};
+template <> struct Ent<9> {
+  using T = uint64_t;
+  static __device__ __forceinline__ T make(uint32_t idx_tag, uint32_t fine, bool neg) { return ((uint64_t)fine << 32) | idx_tag | (neg ? 0x80000000u : 0u); }
+  static __device__ __forceinline__ uint32_t fine(T e) { return (uint32_t)(e >> 32); }
+  static __device__ __forceinline__ uint32_t out(T e) { return (uint32_t)e; }
+};
+static inline int fine_bits_for(int c) { return c >= 19 ? 9 : FINE_BITS; }
+// Segment length of the second pass.  A group of a uniform input holds n / G entries (G <= 1024 groups per window): 4096 at 2^22
+// with FB = 7, but 16384 at 2^24 with FB = 9 -- the wide windows' segments are 20480 entries (80 KiB of LDS), so that their groups
+// stay single segments too (the one-read, no-atomics path of k_fine_local).
+template <int FB> struct SegLen { static constexpr uint32_t V = FB == 9 ? 20480u : (uint32_t)SEG; };
+static inline uint32_t seg_len_for(int fb) { return fb == 9 ? SegLen<9>::V : SegLen<7>::V; }
 constexpr uint32_t MULTI_SEG = 0x80000000u;          // flag in a window's segment total (segbase[G]): a group of several segments exists
 
 // First pass of the two-pass sort, staged through LDS: a workgroup walks its (scalar chunk, window) pair in tiles of
@@ -481,12 +503,15 @@ constexpr uint32_t MULTI_SEG = 0x80000000u;          // flag in a window's segme
 // 256 threads and at most 64 VGPRs: one wave per SIMD that fits in the registers a resident accumulation leaves free, so the
 // sort of the next MSM runs beside it (see KG_SERVICE_PRIO).
 constexpr int GS_NT = 256, GS_TILE = 1024, GS_MAXG = 1024;
+template <int FB>
 __global__ void __launch_bounds__(GS_NT) k_group_scatter(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len, int G,
                                                          const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ gstart,
-                                                         uint32_t* __restrict__ tmp, const uint32_t* __restrict__ woff, int mshift, int w0) {
+                                                         typename Ent<FB>::T* __restrict__ tmp, const uint32_t* __restrict__ woff, int mshift, int w0) {
   KG_SERVICE_PRIO();
+  using E = typename Ent<FB>::T;
+  constexpr uint32_t FINE = 1u << FB;
   __shared__ uint32_t cursor[GS_MAXG], hist[GS_MAXG], lstart[GS_MAXG], sh[40];    // hist doubles as the tile's address delta
-  __shared__ uint32_t stage[GS_TILE];
+  __shared__ E stage[GS_TILE];
   __shared__ uint16_t sg[GS_TILE];
   const int w = (int)blockIdx.x + w0, ch = blockIdx.y, nch = gridDim.y, tid = threadIdx.x;   // w0: first window of the group being sorted (all tables are indexed by the absolute window)
   const int per = (G + GS_NT - 1) / GS_NT;            // groups a lane owns in the scans (consecutive; <= 4)
@@ -495,12 +520,13 @@ __global__ void __launch_bounds__(GS_NT) k_group_scatter(const uint32_t* __restr
   if (woff) for (int g = tid; g < G; g += GS_NT) cursor[g] = cnt[((size_t)w * nch + ch) * G + g] + woff[(size_t)w * G + g] + gstart[g];
   else for (int g = tid; g < G; g += GS_NT) cursor[g] = cnt[((size_t)w * nch + ch) * G + g] + gstart[(size_t)w * G + g];
   const size_t lo = (size_t)ch * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
-  uint32_t* dst = woff ? tmp : tmp + (size_t)w * n;
+  E* dst = woff ? tmp : tmp + (size_t)w * n;
   const uint32_t wtag = woff ? (uint32_t)w << mshift : 0u;
   for (size_t tile = lo; tile < hi; tile += GS_TILE) {
     for (int g = tid; g < G; g += GS_NT) hist[g] = 0;
     __syncthreads();
-    uint32_t rec[GS_TILE / GS_NT], key[GS_TILE / GS_NT];        // key = group << 16 | rank inside the group (tile-local; < 2048)
+    E rec[GS_TILE / GS_NT];
+    uint32_t key[GS_TILE / GS_NT];                              // key = group << 16 | rank inside the group (tile-local; < 2048)
 #pragma unroll
     for (int r = 0; r < GS_TILE / GS_NT; ++r) {
       const size_t i = tile + (size_t)r * GS_NT + tid;
@@ -509,8 +535,8 @@ __global__ void __launch_bounds__(GS_NT) k_group_scatter(const uint32_t* __restr
         bool neg;
         const uint32_t m = window_digit(kt, n, i, w, c, W, neg);
         if (m) {
-          const uint32_t g = (m - 1) >> FINE_BITS;
-          rec[r] = ((uint32_t)i | wtag) | (((m - 1) & (FINE - 1)) << 24) | (neg ? 0x80000000u : 0u);
+          const uint32_t g = (m - 1) >> FB;
+          rec[r] = Ent<FB>::make((uint32_t)i | wtag, (m - 1) & (FINE - 1), neg);
           key[r] = (g << 16) | atomicAdd(&hist[g], 1u);
         }
       }
@@ -551,7 +577,7 @@ __global__ void __launch_bounds__(GS_NT) k_group_scatter(const uint32_t* __restr
 // (workgroup 0 also clears the `zwords` words at `zero`: the task decomposition's counters and length histogram)
 __global__ void __launch_bounds__(GS_NT) k_group_scan(uint32_t* __restrict__ cnt, int nch, int G, int B, uint32_t* __restrict__ gsize,
                                                        uint32_t* __restrict__ gstart, uint32_t* __restrict__ segbase, uint32_t* __restrict__ bsize,
-                                                       uint32_t* __restrict__ zero, int zwords) {
+                                                       uint32_t* __restrict__ zero, int zwords, uint32_t seg) {
   KG_SERVICE_PRIO();
   __shared__ uint32_t sh[40];
   const int w = blockIdx.x, tid = threadIdx.x;
@@ -571,7 +597,7 @@ __global__ void __launch_bounds__(GS_NT) k_group_scan(uint32_t* __restrict__ cnt
       }
       gsize[(size_t)w * G + g] = run[j];
     }
-    ns[j] = (run[j] + SEG - 1) / SEG;
+    ns[j] = (run[j] + seg - 1) / seg;
     rsum += run[j]; nsum += ns[j];
   }
   uint32_t total;
@@ -636,14 +662,14 @@ __global__ void __launch_bounds__(GS_NT) k_merge_groups(const uint32_t* __restri
 struct SegRange { int g; uint32_t lo, hi; };
 // which group / entry range does segment s of window w cover?  (sb: the window's segbase row in LDS)
 __device__ __forceinline__ bool seg_locate(const uint32_t* sb, int G, uint32_t s, const uint32_t* __restrict__ gstart,
-                                           const uint32_t* __restrict__ gsize, int w, SegRange& r) {
+                                           const uint32_t* __restrict__ gsize, int w, SegRange& r, uint32_t seg = SEG) {
   if (s >= (sb[G] & ~MULTI_SEG)) return false;
   int lo = 0, hi = G;                                // largest g with sb[g] <= s (empty groups repeat the value: take the last)
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sb[mid] <= s) lo = mid; else hi = mid; }
   r.g = lo;
   const uint32_t st = gstart[(size_t)w * G + lo], sz = gsize[(size_t)w * G + lo];
-  r.lo = st + (s - sb[lo]) * SEG;
-  r.hi = r.lo + SEG < st + sz ? r.lo + SEG : st + sz;
+  r.lo = st + (s - sb[lo]) * seg;
+  r.hi = r.lo + seg < st + sz ? r.lo + seg : st + sz;
   return true;
 }
 
@@ -653,26 +679,44 @@ __device__ __forceinline__ bool seg_locate(const uint32_t* sb, int G, uint32_t s
 // global prefix: bstart = gstart + the local exclusive prefix (what k_bucket_rows computes from the sizes written here), no
 // atomics on the bucket sizes, and the copy out is one coalesced stream.  Groups of several segments (skewed witnesses, every
 // group of a merged sort) are only counted here (place reserved per segment and bucket); k_fine_scatter places them.
-__global__ void __launch_bounds__(512) k_fine_local(const uint32_t* __restrict__ tmp, size_t n, int G, int B, int maxseg, const uint32_t* __restrict__ gstart,
+// exclusive prefix of FINE (<= 512) counters, one per thread of a 512-thread workgroup (threads >= FINE pass 0)
+__device__ __forceinline__ uint32_t fine_exclusive(uint32_t v, uint32_t* wsum8) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { uint32_t o2 = __shfl_up(inc, d); if (lane >= d) inc += o2; }
+  if (lane == 63) wsum8[wv] = inc;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int k = 0; k < wv; ++k) before += wsum8[k];
+  return inc - v + before;
+}
+template <int FB>
+__global__ void __launch_bounds__(512) k_fine_local(const typename Ent<FB>::T* __restrict__ tmp, size_t n, int G, int B, int maxseg, const uint32_t* __restrict__ gstart,
                                                     const uint32_t* __restrict__ gsize, const uint32_t* __restrict__ segbase,
                                                     uint32_t* __restrict__ bsize, uint32_t* __restrict__ segcnt, uint32_t* __restrict__ segoff,
                                                     uint32_t* __restrict__ sorted) {
   KG_SERVICE_PRIO();
-  __shared__ uint32_t sb[1025];
-  __shared__ uint32_t hist[FINE], cursor[FINE], wsum;
-  __shared__ uint32_t stage[SEG];
+  using E = typename Ent<FB>::T;
+  constexpr uint32_t FINE = 1u << FB, SEGN = SegLen<FB>::V;
+  extern __shared__ uint32_t fl_lds[];                 // sb[1025 (+3)] | hist[FINE] | cursor[FINE] | wsum8[8] | stage[SEGN]
+  uint32_t* const sb = fl_lds;
+  uint32_t* const hist = sb + 1028;
+  uint32_t* const cursor = hist + FINE;
+  uint32_t* const wsum8 = cursor + FINE;
+  uint32_t* const stage = wsum8 + 8;
   const int w = blockIdx.x;
   const uint32_t s = blockIdx.y;
   for (int g = threadIdx.x; g <= G; g += blockDim.x) sb[g] = segbase[(size_t)w * (G + 1) + g];
   if (threadIdx.x < FINE) hist[threadIdx.x] = 0;
   __syncthreads();
   SegRange r;
-  if (!seg_locate(sb, G, s, gstart, gsize, w, r)) return;
-  const uint32_t* src = tmp + (size_t)w * n;
-  if (gsize[(size_t)w * G + r.g] > (uint32_t)SEG) {
+  if (!seg_locate(sb, G, s, gstart, gsize, w, r, SEGN)) return;
+  const E* src = tmp + (size_t)w * n;
+  if (gsize[(size_t)w * G + r.g] > SEGN) {
     // a segment of a larger group: histogram it and reserve its place inside each bucket (the atomicAdd on the bucket size returns
     // the segment's offset there); k_fine_scatter places the entries once the bucket starts are known
-    for (uint32_t i = r.lo + threadIdx.x; i < r.hi; i += blockDim.x) atomicAdd(&hist[(src[i] >> 24) & (FINE - 1)], 1u);
+    for (uint32_t i = r.lo + threadIdx.x; i < r.hi; i += blockDim.x) atomicAdd(&hist[Ent<FB>::fine(src[i])], 1u);
     __syncthreads();
     if (threadIdx.x < FINE) {
       const uint32_t cnt = hist[threadIdx.x];
@@ -682,49 +726,64 @@ __global__ void __launch_bounds__(512) k_fine_local(const uint32_t* __restrict__
     }
     return;
   }
-  constexpr int PER = SEG / 512;                                 // entries a lane keeps in registers between the two phases
-  uint32_t rec[PER];
+  // FB = 7: the segment's entries stay in registers between the histogram and the placement (16 per lane).  FB = 9: 40 eight-byte
+  // entries per lane would not (the kernel has to fit beside an accumulation): the segment is read twice, the second time out of
+  // the cache the first read filled (160 KiB per workgroup).
+  constexpr int PER = (int)(SEGN / 512);
+  constexpr bool KEEP = FB == 7;
+  E rec[KEEP ? PER : 1];
   const uint32_t len = r.hi - r.lo;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const uint32_t i = threadIdx.x + (uint32_t)k * 512u;
-    rec[k] = i < len ? src[r.lo + i] : 0u;
-    if (i < len) atomicAdd(&hist[(rec[k] >> 24) & (FINE - 1)], 1u);
+    if (i < len) {
+      const E e = src[r.lo + i];
+      if (KEEP) rec[KEEP ? k : 0] = e;
+      atomicAdd(&hist[Ent<FB>::fine(e)], 1u);
+    }
   }
   __syncthreads();
-  uint32_t cnt = 0, inc = 0;
-  if (threadIdx.x < FINE) {                                      // exclusive prefix of the FINE counters (two waves), sizes out
+  uint32_t cnt = 0;
+  if (threadIdx.x < FINE) {                                      // sizes out
     cnt = hist[threadIdx.x];
     bsize[(size_t)w * B + (size_t)r.g * FINE + threadIdx.x] = cnt;
-    inc = cnt;
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t o2 = __shfl_up(inc, d); if (lane >= d) inc += o2; }
-    if (threadIdx.x == 63) wsum = inc;
   }
-  __syncthreads();
-  if (threadIdx.x < FINE) cursor[threadIdx.x] = inc - cnt + (threadIdx.x >= 64 ? wsum : 0u);
+  const uint32_t ex = fine_exclusive(cnt, wsum8);               // exclusive prefix of the FINE counters
+  if (threadIdx.x < FINE) cursor[threadIdx.x] = ex;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const uint32_t i = threadIdx.x + (uint32_t)k * 512u;
-    if (i < len) stage[atomicAdd(&cursor[(rec[k] >> 24) & (FINE - 1)], 1u)] = rec[k] & 0x80ffffffu;
+    if (i < len) {
+      const E e = KEEP ? rec[KEEP ? k : 0] : src[r.lo + i];
+      stage[atomicAdd(&cursor[Ent<FB>::fine(e)], 1u)] = Ent<FB>::out(e);
+    }
   }
   __syncthreads();
   uint32_t* dst = sorted + (size_t)w * n + r.lo;                 // r.lo = the group's start: its only segment
   for (uint32_t p = threadIdx.x; p < len; p += blockDim.x) dst[p] = stage[p];
 }
+template <int FB> static constexpr size_t fine_local_lds() { return (size_t)(1028 + 2 * (1u << FB) + 8 + SegLen<FB>::V) * 4; }
 
+template <int FB> static constexpr size_t fine_scatter_lds() { return (size_t)(1028 + 3 * (1u << FB) + 8 + SegLen<FB>::V) * 4 + (size_t)SegLen<FB>::V * 2; }
 constexpr int FS_ROWS = 64;                          // workgroups per window: a workgroup walks the window's segments in steps of gridDim.y
-__global__ void __launch_bounds__(512) k_fine_scatter(const uint32_t* __restrict__ tmp, size_t n, int G, int B, int maxseg,
+template <int FB>
+__global__ void __launch_bounds__(512) k_fine_scatter(const typename Ent<FB>::T* __restrict__ tmp, size_t n, int G, int B, int maxseg,
                                                       const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gsize,
                                                       const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ bstart,
                                                       const uint32_t* __restrict__ segcnt, const uint32_t* __restrict__ segoff,
                                                       uint32_t* __restrict__ sorted) {
   KG_SERVICE_PRIO();
-  __shared__ uint32_t sb[1025];
-  __shared__ uint32_t lstart[FINE], cursor[FINE], gbase[FINE], wsum;
-  __shared__ uint32_t stage[SEG];
+  using E = typename Ent<FB>::T;
+  constexpr uint32_t FINE = 1u << FB, SEGN = SegLen<FB>::V;
+  extern __shared__ uint32_t fs_lds[];                 // sb[1028] | lstart | cursor | gbase [FINE each] | wsum8[8] | stage[SEGN] | sfine[SEGN] (16 bit)
+  uint32_t* const sb = fs_lds;
+  uint32_t* const lstart = sb + 1028;
+  uint32_t* const cursor = lstart + FINE;
+  uint32_t* const gbase = cursor + FINE;
+  uint32_t* const wsum8 = gbase + FINE;
+  uint32_t* const stage = wsum8 + 8;
+  uint16_t* const sfine = reinterpret_cast<uint16_t*>(stage + SEGN);
   const int w = blockIdx.x;
   // every group of this window is one segment (any uniform input): k_fine_local did it all.  (A launch of one workgroup per
   // segment that only returned cost 36 us per 2^20-pair sort: hence the few rows and the loop.)
@@ -734,38 +793,34 @@ __global__ void __launch_bounds__(512) k_fine_scatter(const uint32_t* __restrict
   const uint32_t nseg = sb[G] & ~MULTI_SEG;
   for (uint32_t s = blockIdx.y; s < nseg; s += gridDim.y) {
     SegRange r;
-    seg_locate(sb, G, s, gstart, gsize, w, r);
-    if (gsize[(size_t)w * G + r.g] <= (uint32_t)SEG) continue;     // done by k_fine_local (uniform over the workgroup)
+    seg_locate(sb, G, s, gstart, gsize, w, r, SEGN);
+    if (gsize[(size_t)w * G + r.g] <= SEGN) continue;              // done by k_fine_local (uniform over the workgroup)
     __syncthreads();                                 // the previous segment's stage / tables are no longer read
-    uint32_t cnt = 0, inc = 0;
-    if (threadIdx.x < FINE) {                          // exclusive prefix of the segment's FINE counters (two waves)
+    uint32_t cnt = 0;
+    if (threadIdx.x < FINE) {
       const size_t o = ((size_t)w * maxseg + s) * FINE + threadIdx.x;
       cnt = segcnt[o];
       gbase[threadIdx.x] = bstart[(size_t)w * B + (size_t)r.g * FINE + threadIdx.x] + segoff[o];
-      inc = cnt;
-      const int lane = threadIdx.x & 63;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { uint32_t o2 = __shfl_up(inc, d); if (lane >= d) inc += o2; }
-      if (threadIdx.x == 63) wsum = inc;
     }
-    __syncthreads();
+    const uint32_t ex = fine_exclusive(cnt, wsum8);   // exclusive prefix of the segment's FINE counters
     if (threadIdx.x < FINE) {
-      const uint32_t ex = inc - cnt + (threadIdx.x >= 64 ? wsum : 0u);
       lstart[threadIdx.x] = ex;
       cursor[threadIdx.x] = ex;
     }
     __syncthreads();
-    const uint32_t* src = tmp + (size_t)w * n;
+    const E* src = tmp + (size_t)w * n;
     for (uint32_t i = r.lo + threadIdx.x; i < r.hi; i += blockDim.x) {
-      const uint32_t rec = src[i];
-      stage[atomicAdd(&cursor[(rec >> 24) & (FINE - 1)], 1u)] = rec;
+      const E rec = src[i];
+      const uint32_t f = Ent<FB>::fine(rec), pos = atomicAdd(&cursor[f], 1u);
+      stage[pos] = Ent<FB>::out(rec);
+      sfine[pos] = (uint16_t)f;
     }
     __syncthreads();
     uint32_t* dst = sorted + (size_t)w * n;
     const uint32_t len = r.hi - r.lo;
     for (uint32_t p = threadIdx.x; p < len; p += blockDim.x) {
-      const uint32_t rec = stage[p], f = (rec >> 24) & (FINE - 1);
-      dst[gbase[f] + (p - lstart[f])] = rec & 0x80ffffffu;
+      const uint32_t f = sfine[p];
+      dst[gbase[f] + (p - lstart[f])] = stage[p];
     }
   }
 }
@@ -1619,6 +1674,16 @@ int pick_window(size_t n, int forced) {
   // signed windows use), while c = 12..14 would leave 2..7 bits, i.e. a handful of buckets holding ~n points each.
   // c = 17 (W = 15, a 16-bit top window) needs the two-pass sort, i.e. n <= 2^24; measured faster from 2^21 up
   // (2^22: 6.6 vs 7.0 ms, 2^24: 25.8 vs 35.2 ms), slower at 2^20 where its bucket reduction doubles
+  // c = 20 (13 windows, 2^19 buckets each, 32 entries per bucket at 2^24 -- the density of the 2^20 / c = 16 optimum), UNSLICED and
+  // pipelined by window groups (kg_msm): 13 instead of 15 additions per pair and one bucket reduction; needs the nine-bit fine field
+  // of the two-pass sort (eight-byte intermediate entries, 20480-entry segments).  Built, bit-identical, and NOT the default:
+  // measured at 2^24 (MI355X, registered key) 21.3 ms in groups of 3,3,3,4 windows against 21.1 ms for c = 17 in four index
+  // slices -- the accumulation does drop (16.0 against 19.3 ms of launch time) but beside it each group's sort runs 2.5-5x slower
+  // than alone (k_group_scatter 2.3-2.9 against 1.13 ms, k_fine_local 1.4-1.8 against 0.34 ms per three windows: latency-bound
+  // kernels at one wave per SIMD in a memory system full of 64-byte gathers from a 1 GiB key), 4.3-4.6 ms per group against the
+  // 3.8-4.0 ms of its accumulation, so the groups serialise on their sorts.  KG_WIDE_WINDOW=24 (or kg_msm_set_window(20)) selects it.
+  static const int wide_from = [] { const char* e = getenv("KG_WIDE_WINDOW"); return e ? atoi(e) : 0; }();
+  if (wide_from > 0 && lg >= wide_from && n <= ((size_t)1 << 24)) return 20;
   if (lg >= 21 && n <= ((size_t)1 << 24)) return 17;
   if (lg >= 19) return 16;
   if (lg >= 14) return 15;
@@ -1709,6 +1774,7 @@ int msm_group_plan(const kg_ctx* ctx, size_t n, int* gw) {
   // 2^20 1.87 -> 1.79, 2^21 3.16 -> 3.01, 2^22 6.14 -> 5.97; three or four groups pay more launches and more sort beside the
   // accumulations than their shorter reduction tail returns (2^20: 1.98 / 2.03 ms)
   int NG = n >= ((size_t)1 << 17) ? 2 : 0;
+  if (c >= 19) NG = 4;                                 // the unsliced 2^23..2^24-pair commitments: the sort of 13-14 windows is 4 ms, hidden group by group
   static const char* env = getenv("KG_MSM_GROUPS");
   if (env) {
     if (strchr(env, ',')) {
@@ -1750,7 +1816,8 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
   const int Wb = merged ? 1 : W;                    // windows of the BUCKET space: the merged form keeps one set for all digits
   const size_t nv = merged ? (size_t)W * n : n;     // entries that can meet one bucket window
   int nch = (int)((n + 16383) / 16384);
-  if (nch > 64) nch = 64;                         // (window, chunk) workgroups of the first sort pass: 1024 of them at 2^20
+  static const int nch_cap = [] { const char* e = getenv("KG_SORT_NCH"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 1024 ? v : 64; }();
+  if (nch > nch_cap) nch = nch_cap;               // (window, chunk) workgroups of the first sort pass: 1024 of them at 2^20
   if (nch < 1) nch = 1;
   size_t chunk_len = (n + nch - 1) / nch;
   // Task length.  A task is one lane's sequential chain of additions, so the accumulation can never be shorter than T
@@ -1775,8 +1842,12 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
   // two passes (bucket group, then bucket inside the group) once the sorted lists outgrow the L2; entries carry the
   // bucket's low FINE_BITS between the passes, which leaves 24 bits for the index
   const bool two_pass = merged || (c - 1 >= FINE_BITS + 4 && n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24));
-  const int G = two_pass ? B >> FINE_BITS : 0;      // bucket groups per window (<= 1024)
-  const int maxseg = two_pass ? G + (int)((nv + SEG - 1) / SEG) : 0;
+  if (c >= 19 && (!two_pass || merged)) return set_err(ctx, KG_ERR_BAD_ARG, "windows of 19 and 20 bits need the two-pass sort (2^16 .. 2^24 scalars)");
+  const int fb = fine_bits_for(c);                  // low bucket bits an entry carries between the passes
+  const uint32_t FINE = 1u << fb;
+  const int G = two_pass ? B >> fb : 0;             // bucket groups per window (<= 1024)
+  const uint32_t seg = seg_len_for(fb);
+  const int maxseg = two_pass ? G + (int)((nv + seg - 1) / seg) : 0;
   if (two_pass) chunk_len = (chunk_len + PREP_CH - 1) / PREP_CH * PREP_CH;   // k_prep_scalars_count: one chunk per workgroup
   // window groups: gw[0] windows from the top, then gw[1], ... (the host's double-and-add chain consumes them in that order)
   if (ngroups < 1 || ngroups > kg_ctx::MAX_GROUPS) return set_err(ctx, KG_ERR_BAD_ARG, "bad number of window groups");
@@ -1796,13 +1867,13 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
   Carver cv;
   Q.o_kt = cv.take(n * 32); Q.o_cnt = cv.take((size_t)W * nch * (two_pass ? G : B) * 4); Q.o_bsize = cv.take((size_t)W * B * 4);
   Q.o_bstart = cv.take((size_t)Wb * B * 4);
-  Q.o_tmp = cv.take(two_pass ? (size_t)W * n * 4 : 0); Q.o_gsize = cv.take((size_t)W * G * 4); Q.o_gstart = cv.take((size_t)W * G * 4);
+  Q.o_tmp = cv.take(two_pass ? (size_t)W * n * (fb == 9 ? 8 : 4) : 0); Q.o_gsize = cv.take((size_t)W * G * 4); Q.o_gstart = cv.take((size_t)W * G * 4);
   Q.o_segbase = cv.take((size_t)W * (G + 1) * 4); Q.o_segcnt = cv.take((size_t)Wb * maxseg * FINE * 4); Q.o_segoff = cv.take((size_t)Wb * maxseg * FINE * 4);
   Q.o_sorted = cv.take((size_t)W * n * 4); Q.o_lcnt = cv.take((size_t)Wb * B * 4); Q.o_lrel = cv.take((size_t)Wb * B * 4);
   Q.o_rowtot = cv.take((size_t)W * 4);
   Q.o_woff = cv.take(merged ? (size_t)W * G * 4 : 0); Q.o_gsize_m = cv.take(merged ? (size_t)G * 4 : 0); Q.o_gstart_m = cv.take(merged ? (size_t)G * 4 : 0);
   Q.o_segbase_m = cv.take(merged ? (size_t)(G + 1) * 4 : 0);
-  Q.o_bpart = cv.take((size_t)W * 32 * 2 * 4);           // k_bucket_part: (entries, tasks) of each part of each row
+  Q.o_bpart = cv.take((size_t)W * (B / 4096 + 32) * 2 * 4);      // k_bucket_part: (entries, tasks) of each part of each row
   for (int g = 0; g < ngroups; ++g) {                     // what the task decomposition keeps per group
     Q.part_cap[g] = (size_t)Q.gW[g] * ((nv + T - 1) / T) + (size_t)Q.gW[g] * B;     // upper bound on round-1 tasks
     Q.o_lbase[g] = cv.take((size_t)(Q.gW[g] + 1) * 4);
@@ -1831,6 +1902,7 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
   Q.n = n; Q.chunk_len = chunk_len; Q.nv = nv; Q.c = c; Q.W = W; Q.B = B; Q.Wb = Wb; Q.G = G; Q.nch = nch; Q.maxseg = maxseg; Q.mshift = mshift;
   Q.set = set; Q.ngroups = ngroups; Q.merged = merged; Q.two_pass = two_pass; Q.T = T; Q.ws = ws;
   Q.T_top = merged ? T : 2 * T;
+  Q.fb = fb;
   uint32_t* kt = (uint32_t*)(ws + Q.o_kt);
   uint32_t* cnt = (uint32_t*)(ws + Q.o_cnt);
 
@@ -1848,10 +1920,10 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
       const dim3 grid((unsigned)((n + PREP_CH - 1) / PREP_CH));
       if (scalar_field == KG_FR) {
         if (hl > 48 * 1024) KG_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_scalars_count<FrParams>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
-        hipLaunchKernelGGL(k_prep_scalars_count<FrParams>, grid, dim3(PREP_NT), hl, st, d_scalars, n, H, kt, c, W, FINE_BITS, G, nch, chunk_len, cnt);
+        hipLaunchKernelGGL(k_prep_scalars_count<FrParams>, grid, dim3(PREP_NT), hl, st, d_scalars, n, H, kt, c, W, fb, G, nch, chunk_len, cnt);
       } else {
         if (hl > 48 * 1024) KG_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_scalars_count<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
-        hipLaunchKernelGGL(k_prep_scalars_count<FqParams>, grid, dim3(PREP_NT), hl, st, d_scalars, n, H, kt, c, W, FINE_BITS, G, nch, chunk_len, cnt);
+        hipLaunchKernelGGL(k_prep_scalars_count<FqParams>, grid, dim3(PREP_NT), hl, st, d_scalars, n, H, kt, c, W, fb, G, nch, chunk_len, cnt);
       }
     } else if (scalar_field == KG_FR) hipLaunchKernelGGL(k_prep_scalars<FrParams>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
     else hipLaunchKernelGGL(k_prep_scalars<FqParams>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
@@ -1902,7 +1974,10 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
       KG_HIP(ctx, hipFuncSetAttribute((const void*)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       KG_HIP(ctx, hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    uint32_t* tmp = (uint32_t*)(ws + Q.o_tmp);
+    const int fb = Q.fb;
+    const uint32_t FINE = 1u << fb;
+    uint32_t* tmp = (uint32_t*)(ws + Q.o_tmp);                // uint32_t entries (FB = 7) or uint64_t (FB = 9)
+    uint64_t* tmp8 = (uint64_t*)(ws + Q.o_tmp);
     uint32_t* gsize = (uint32_t*)(ws + Q.o_gsize);
     uint32_t* gstart = (uint32_t*)(ws + Q.o_gstart);
     uint32_t* segbase = (uint32_t*)(ws + Q.o_segbase);
@@ -1916,14 +1991,21 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
     const uint32_t* f_gsize = merged ? (uint32_t*)(ws + Q.o_gsize_m) : gsize + (size_t)w0 * G;
     const uint32_t* f_segbase = merged ? (uint32_t*)(ws + Q.o_segbase_m) : segbase + (size_t)w0 * (G + 1);
     const uint32_t* f_tmp = merged ? tmp : tmp + (size_t)w0 * n;
+    const uint64_t* f_tmp8 = tmp8 + (size_t)w0 * n;
     if (two_pass) {
       hipLaunchKernelGGL(k_group_scan, dim3(sWg), dim3(GS_NT), 0, st, cnt + (size_t)sw0 * nch * G, nch, G, B, gsize + (size_t)sw0 * G, gstart + (size_t)sw0 * G,
-                         segbase + (size_t)sw0 * (G + 1), (uint32_t*)(ws + Q.o_bsize) + (size_t)sw0 * B, misc, (int)(zbytes / 4));
+                         segbase + (size_t)sw0 * (G + 1), (uint32_t*)(ws + Q.o_bsize) + (size_t)sw0 * B, misc, (int)(zbytes / 4), seg_len_for(fb));
       if (merged)
         hipLaunchKernelGGL(k_merge_groups, dim3(1), dim3(GS_NT), 0, st, gsize, W, G, woff, (uint32_t*)(ws + Q.o_gsize_m), (uint32_t*)(ws + Q.o_gstart_m),
                            (uint32_t*)(ws + Q.o_segbase_m));
-      hipLaunchKernelGGL(k_group_scatter, dim3(sWg, nch), dim3(GS_NT), 0, st, kt, n, c, W, Q.chunk_len, G, cnt, merged ? f_gstart : gstart, tmp, woff, Q.mshift, sw0);
-      hipLaunchKernelGGL(k_fine_local, dim3(Wg, maxseg), dim3(512), 0, st, f_tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bsize, segcnt, segoff, S->sorted);
+      if (fb == 9) {
+        hipLaunchKernelGGL(k_group_scatter<9>, dim3(sWg, nch), dim3(GS_NT), 0, st, kt, n, c, W, Q.chunk_len, G, cnt, gstart, tmp8, woff, Q.mshift, sw0);
+        KG_HIP(ctx, hipFuncSetAttribute((const void*)k_fine_local<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fine_local_lds<9>()));
+        hipLaunchKernelGGL(k_fine_local<9>, dim3(Wg, maxseg), dim3(512), fine_local_lds<9>(), st, f_tmp8, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bsize, segcnt, segoff, S->sorted);
+      } else {
+        hipLaunchKernelGGL(k_group_scatter<7>, dim3(sWg, nch), dim3(GS_NT), 0, st, kt, n, c, W, Q.chunk_len, G, cnt, merged ? f_gstart : gstart, tmp, woff, Q.mshift, sw0);
+        hipLaunchKernelGGL(k_fine_local<7>, dim3(Wg, maxseg), dim3(512), fine_local_lds<7>(), st, f_tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bsize, segcnt, segoff, S->sorted);
+      }
     } else {
       hipLaunchKernelGGL(k_count, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, Q.chunk_len, 0, cnt);
       hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, cnt, W, nch, B, S->bsize);
@@ -1941,9 +2023,13 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
     hipLaunchKernelGGL(k_task_bases, dim3(1), dim3(64), 0, st, rowtot, Wg, S->lbase, misc, misc + 4, lenh, lenh + LEN_BINS, (uint32_t*)ctx->h_pinned_dev + 4 * gi);
     KG_HIP(ctx, hipEventRecord(ctx->ev_info[gi], st));
     hipLaunchKernelGGL(k_len_scatter, dim3(g1024), dim3(1024), 0, st, S->bsize, S->lcnt, S->lrel, S->lbase, npts, B, T, lenh + LEN_BINS, S->task_bkt, S->task_id, T_top, top_w);
-    if (two_pass)
-      hipLaunchKernelGGL(k_fine_scatter, dim3(Wg, maxseg < FS_ROWS ? maxseg : FS_ROWS), dim3(512), 0, st, f_tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bstart, segcnt, segoff, S->sorted);
-    else
+    if (two_pass && fb == 9) {
+      KG_HIP(ctx, hipFuncSetAttribute((const void*)k_fine_scatter<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fine_scatter_lds<9>()));
+      hipLaunchKernelGGL(k_fine_scatter<9>, dim3(Wg, maxseg < FS_ROWS ? maxseg : FS_ROWS), dim3(512), fine_scatter_lds<9>(), st, f_tmp8, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bstart, segcnt, segoff, S->sorted);
+    } else if (two_pass) {
+      KG_HIP(ctx, hipFuncSetAttribute((const void*)k_fine_scatter<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fine_scatter_lds<7>()));
+      hipLaunchKernelGGL(k_fine_scatter<7>, dim3(Wg, maxseg < FS_ROWS ? maxseg : FS_ROWS), dim3(512), fine_scatter_lds<7>(), st, f_tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bstart, segcnt, segoff, S->sorted);
+    } else
       hipLaunchKernelGGL(k_scatter, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, Q.chunk_len, 0, cnt, S->bstart, S->sorted);
     ph.end();
     KG_HIP(ctx, hipGetLastError());
@@ -2456,7 +2542,7 @@ int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf
   if (!ctx || !out_xyz || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
   static const bool sliced_ok = !(getenv("KG_MSM_SLICED") && atoi(getenv("KG_MSM_SLICED")) == 0);     // experiments: window groups instead of index slices
-  if (n >= ((size_t)1 << 23) && sliced_ok) return msm_sliced(ctx, curve, d_bases, d_inf, d_scalars, n, out_xyz);   // measured: 2^24 25.8 -> 23.0 ms, 2^23 13.1 -> 12.1; below that the slices' own tails cost more than the hidden sort
+  if (n >= ((size_t)1 << 23) && sliced_ok && pick_window(n, ctx->msm_window) < 19) return msm_sliced(ctx, curve, d_bases, d_inf, d_scalars, n, out_xyz);   // measured: 2^24 25.8 -> 23.0 ms, 2^23 13.1 -> 12.1; below that the slices' own tails cost more than the hidden sort
   kg::MsmSorted S;
   const int mc = kg::has_window_table(ctx, curve, d_bases, d_inf, n, n) ? kg::merged_window(ctx, n) : 0;
   if (!mc) {

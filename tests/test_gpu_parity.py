@@ -315,6 +315,9 @@ def test_registered_bases_give_identical_results(ctx, oracle, cv, curve, sfd):
     ("g1", 0, 0, 1 << 16, 0, False), ("g1", 0, 0, 70001, 12, False), ("gk", 1, 1, 100000, 16, False),
     ("g1", 0, 0, 1 << 17, 0, True), ("g1", 0, 0, 150000, 13, True), ("gk", 1, 1, 90000, 16, True),
     ("g2", 2, 0, 66000, 0, False), ("g2", 2, 0, 70001, 13, True),
+    # windows of 19 and 20 bits: nine-bit fine field, eight-byte intermediate entries (the 2^24-pair commitment's sort)
+    ("g1", 0, 0, 70001, 19, False), ("g1", 0, 0, 1 << 17, 20, False), ("gk", 1, 1, 90000, 20, True), ("g1", 0, 0, 150000, 19, True),
+    ("g2", 2, 0, 66000, 20, False),
 ])
 def test_msm_two_pass_sort_sizes(ctx, oracle, cv, curve, sfd, n, c, skew):
     """n >= 2^16 with c >= 12 takes the two-pass bucket sort (bucket group, then bucket inside the group; groups cut
@@ -344,6 +347,9 @@ def test_msm_two_pass_sort_sizes(ctx, oracle, cv, curve, sfd, n, c, skew):
     ctx.set_msm_window(c)
     try:
         assert gpu_aff(ctx.msm_host(curve, bases, inf, scal, n), 8 if curve == 2 else 4) == want
+        if c >= 19:                                 # and the blocking device call (window groups: four for these widths)
+            db, di, ds = ctx.upload(bases), ctx.upload(inf), ctx.upload(scal)
+            assert gpu_aff(ctx.msm(curve, db.ptr, di.ptr, ds.ptr, n), 8 if curve == 2 else 4) == want
     finally:
         ctx.set_msm_window(0)
 
