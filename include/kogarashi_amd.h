@@ -160,7 +160,8 @@ int kg_bases_precompute(kg_ctx* ctx, const uint64_t* d_bases, size_t msm_len);
 /* Window width c of the tables kg_bases_precompute builds for MSMs of msm_len scalars, 0 where none are offered: a table holds
  * ceil(255 / c) rows of the array (64 B per G1 / Grumpkin point, 128 B per G2 point).  Pure function: no device, no context. */
 int kg_msm_table_window(size_t msm_len);
-/* Tuning knob: window width c (0 = automatic). */
+/* Tuning knob: window width c, 0 (automatic) .. 20; KG_ERR_BAD_ARG otherwise.  Widths above 16 need the two-pass sort (2^16 .. 2^24
+ * scalars; shorter or longer MSMs fall back to 16); 19 and 20 are the wide windows of the 2^23 .. 2^24-pair commitments. */
 int kg_msm_set_window(kg_ctx* ctx, int c);
 /* The automatic rule: window width c for n pairs (W = ceil(255 / c) signed windows of 2^(c-1) buckets; the reference's
  * rule is groth16/src/msm.rs:7-14).  Pure function: needs no device and no context. */

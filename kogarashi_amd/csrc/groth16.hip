@@ -341,8 +341,8 @@ static bool g16_h_first() {                               // KG_G16_H_EARLY=2: h
   static const bool on = getenv("KG_G16_H_EARLY") && atoi(getenv("KG_G16_H_EARLY")) == 2;
   return on;
 }
-static bool g16_h_early_pipelined() {                     // KG_G16_H_EARLY_PIPE=1: the same order for proofs in flight (experiments)
-  static const bool on = getenv("KG_G16_H_EARLY_PIPE") && atoi(getenv("KG_G16_H_EARLY_PIPE")) != 0;
+static bool g16_h_early_pipelined() {                     // KG_G16_H_EARLY_PIPE=0: proofs in flight keep h's chain last (the order up to round 3)
+  static const bool on = !(getenv("KG_G16_H_EARLY_PIPE") && atoi(getenv("KG_G16_H_EARLY_PIPE")) == 0);
   return on;
 }
 int assemble_proof(const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t* ss, int rc0, ProofJob* j_g2, ProofJob* j_g1w, ProofJob* j_h,
@@ -458,12 +458,12 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // result slots: consecutive MSMs alternate between the two reduction queues (slot parity), each with run space of
   // its own (slot mod 8); measured against giving G2's long reduction a queue of its own: 3.67 vs 3.84 ms per proof
   const int SL[5] = {slot_base + 1, slot_base + 2, slot_base + 3, slot_base + 4, slot_base + 5};
-  // Order of the main queue.  Two proofs in flight (h_early = false): G2, the fused G1 accumulation, then h's chain -- the
-  // point-wise step, coset_idft, h's sort and MSM go LAST, so that the transforms (queued behind the previous proof's
-  // reductions) never hold up an accumulation.  ONE blocking proof (h_early): nothing else is in flight, the three chains are
-  // done before the witness sort is, and in the old order 1.4 ms of h's chain ran serially after the G1 accumulation on an
-  // otherwise idle chip; so h's point-wise step and coset_idft follow the G2 accumulation at once (G2's long reduction
-  // gets the chip meanwhile), h's sort runs beside the G1 accumulation and h's accumulation follows it directly.
+  // Order of the main queue (h_early, the default since round 4): G2 accumulation, h's point-wise step and coset_idft, the fused G1
+  // accumulation with h's sort beside it, h's accumulation directly behind.  Up to round 3 h's whole chain went LAST (the point-wise
+  // step, coset_idft, h's sort, h's MSM: ~1.4 ms in a row behind the G1 accumulation, on a chip that only the reductions used)
+  // because a service queue that happened to share the main queue's compute pipe started its work ~0.7 ms late and the reductions
+  // did not fit beside an accumulation; with the queues placed (capi.cpp place_queues) and the reduction kernels at <= 96 VGPRs
+  // neither holds.  Measured: blocking proof 3.34 -> 3.18 ms, two in flight 2.91 -> 2.86 ms (same box, alternating runs).
   MsmSorted Sq;
   bool h_sorted = false;
   auto h_front = [&]() {                                  // h = (a o b - c) / Z on the coset, back to coefficients (prover.rs:43-47)

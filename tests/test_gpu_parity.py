@@ -483,7 +483,7 @@ def test_bad_arguments_are_status_codes_not_crashes(ctx):
     assert L.kg_ntt_bn254_fr(h, None, 4, 0, 0) == BAD
     assert L.kg_field_vec_op(h, 9, 0, vp(s.ptr), vp(s.ptr), vp(s.ptr), C.c_size_t(n)) == BAD  # unknown field
     assert L.kg_field_vec_op(h, 0, 0, vp(s.ptr), None, vp(s.ptr), C.c_size_t(n)) == BAD       # binary op without b
-    assert L.kg_msm_set_window(h, 19) == BAD
+    assert L.kg_msm_set_window(h, 21) == BAD                                            # 0 (automatic) .. 20
     assert L.kg_bases_register(h, 5, vp(d.ptr), None, C.c_size_t(n)) == BAD
     assert L.kg_groth16_prove_end(h, 0, out, None) == BAD                                     # null flags
     assert L.kg_groth16_prove_end(h, 1, out, (C.c_uint8 * 3)()) == BAD                        # nothing begun on ticket 1
