@@ -47,7 +47,7 @@ enum { KG_G1 = 0, KG_GRUMPKIN = 1, KG_G2 = 2 };      /* curve ids */
 
 typedef struct kg_ctx kg_ctx;
 
-int kg_version(void);                    /* 3: the last extension added kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
+int kg_version(void);                    /* 4: the last extension added kg_msm_set_groups; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
 /* Optional process-level setup; call it (or export the variable yourself) BEFORE anything in the process initialises the
  * HIP runtime -- before the first kg_device_count / kg_ctx_create and before any other HIP user -- and before the host
  * starts threads (it calls setenv).  Sets GPU_MAX_HW_QUEUES=16 unless the variable is already set, so that each of a
@@ -163,6 +163,12 @@ int kg_msm_table_window(size_t msm_len);
 /* Tuning knob: window width c, 0 (automatic) .. 20; KG_ERR_BAD_ARG otherwise.  Widths above 16 need the two-pass sort (2^16 .. 2^24
  * scalars; shorter or longer MSMs fall back to 16); 19 and 20 are the wide windows of the 2^23 .. 2^24-pair commitments. */
 int kg_msm_set_window(kg_ctx* ctx, int c);
+/* Tuning knob: window groups of a blocking kg_msm / kg_commit (groth16/src/msm.rs:6-48 and nova/src/pedersen.rs:15-20 are blocking
+ * calls).  A blocking MSM of 2^17 .. 2^23 pairs pipelines against itself: the scalars are converted once, then the windows are sorted,
+ * accumulated and reduced in groups, top windows first, the next group's sort under this group's accumulation, this group's reduction
+ * under the next one's accumulation, and the host's double-and-add chain starts on the top group's sums.  groups: 0 = automatic (two),
+ * 1 = none (one accumulation launch per MSM), 2 .. 4.  Results are bit-identical for every setting. */
+int kg_msm_set_groups(kg_ctx* ctx, int groups);
 /* The automatic rule: window width c for n pairs (W = ceil(255 / c) signed windows of 2^(c-1) buckets; the reference's
  * rule is groth16/src/msm.rs:7-14).  Pure function: needs no device and no context. */
 int kg_msm_pick_window(size_t n);

@@ -262,7 +262,7 @@ int kg_hw_queue_setting(void) {
   const char* e = getenv("GPU_MAX_HW_QUEUES");
   return e ? atoi(e) : 0;
 }
-int kg_version(void) { return 3; }      // the round the ABI was last extended in (3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded)
+int kg_version(void) { return 4; }      // the round the ABI was last extended in (4: kg_msm_set_groups; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded)
 
 int kg_device_count(void) {
   int n = 0;
@@ -409,6 +409,11 @@ int kg_memcpy_d2d(kg_ctx* c, void* dst, const void* src, size_t bytes) {
 int kg_msm_set_window(kg_ctx* c, int w) {
   if (!c || w < 0 || w > 20) return KG_ERR_BAD_ARG;   // 17 .. 20 need the two-pass sort (2^16 <= n <= 2^24)
   c->msm_window = w;
+  return KG_OK;
+}
+int kg_msm_set_groups(kg_ctx* c, int groups) {
+  if (!c || groups < 0 || groups > kg_ctx::MAX_GROUPS) return KG_ERR_BAD_ARG;
+  c->msm_groups = groups;
   return KG_OK;
 }
 int kg_profile_enable(kg_ctx* c, int on) {

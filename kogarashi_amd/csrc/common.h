@@ -19,6 +19,7 @@ struct kg_ctx {
   hipStream_t stream = nullptr;          // stream every launch goes to
   std::string last_error;
   int msm_window = 0;                    // 0 = auto
+  int msm_groups = 0;                    // window groups of a blocking MSM: 0 = auto, 1 = none, 2..MAX_GROUPS (kg_msm_set_groups)
   // grow-only scratch
   // MSM scalar-side space (sorted digit lists, task tables), two sets used in turn: the sort of MSM i+1 runs on the scalar
   // queue while the accumulation of MSM i still reads the other set

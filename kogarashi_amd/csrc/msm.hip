@@ -1011,11 +1011,11 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restric
   const int lo = threadIdx.x * per, hi = lo + per < B ? lo + per : B;
   const uint32_t* src = bsize + (size_t)w * B;
   const bool vec = (per & 3) == 0 && hi - lo == per;       // every lane owns whole 16-byte groups
-  uint32_t ssum = 0, tsum = 0, mx = 0, full = 0;     // full: tasks of the full length T (one shared bin: counted per lane, added once)
+  uint32_t ssum = 0, tsum = 0, mx = 0, full = 0, mt = 0;     // full: tasks of the full length T (one shared bin: counted per lane, added once); mt: most tasks of a bucket
   auto tally = [&](uint32_t v) {
     if (v) {
       const uint32_t nt = (v + T - 1) / T;
-      ssum += v; tsum += nt; mx = v > mx ? v : mx;
+      ssum += v; tsum += nt; mx = v > mx ? v : mx; mt = nt > mt ? nt : mt;
       atomicAdd(&h[len_key(v - (nt - 1) * T)], 1u);
       full += nt - 1;
     }
@@ -1056,8 +1056,8 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restric
     for (int b = lo; b < hi; ++b)
       if (src[b] > GATHER_SUM_MAX * T) { const uint32_t pos = atomicAdd(maxv + 1, 1u); if (pos < hot_cap) hot_list[pos] = (uint32_t)(w * B + b); }
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mx, d); mx = o > mx ? o : mx; o = __shfl_xor(mt, d); mt = o > mt ? o : mt; }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mx; if (mt) atomicMax(maxv + 2, mt); }      // maxv[2]: most tasks any bucket has
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t m = 0;
@@ -1082,11 +1082,11 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_part(const uint32_t* __restric
   __syncthreads();
   const int per = len / BR_NT;                           // len is a multiple of 4 * BR_NT (B >= 8192, nsplit <= B / 4096)
   const uint32_t* src = bsize + (size_t)w * B + (size_t)k * len + (size_t)threadIdx.x * per;
-  uint32_t ssum = 0, tsum = 0, mx = 0, full = 0;
+  uint32_t ssum = 0, tsum = 0, mx = 0, full = 0, mt = 0;
   auto tally = [&](uint32_t v) {
     if (v) {
       const uint32_t nt = (v + T - 1) / T;
-      ssum += v; tsum += nt; mx = v > mx ? v : mx;
+      ssum += v; tsum += nt; mx = v > mx ? v : mx; mt = nt > mt ? nt : mt;
       atomicAdd(&h[len_key(v - (nt - 1) * T)], 1u);
       full += nt - 1;
     }
@@ -1099,8 +1099,8 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_part(const uint32_t* __restric
         if (pos < hot_cap) hot_list[pos] = (uint32_t)((size_t)w * B + (size_t)k * len + (size_t)threadIdx.x * per + b);
       }
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { full += __shfl_xor(full, d); const uint32_t o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
-  if ((threadIdx.x & 63) == 0) { if (full) atomicAdd(&h[len_key(T)], full); red[threadIdx.x >> 6] = mx; }
+  for (int d = 32; d >= 1; d >>= 1) { full += __shfl_xor(full, d); uint32_t o = __shfl_xor(mx, d); mx = o > mx ? o : mx; o = __shfl_xor(mt, d); mt = o > mt ? o : mt; }
+  if ((threadIdx.x & 63) == 0) { if (full) atomicAdd(&h[len_key(T)], full); red[threadIdx.x >> 6] = mx; if (mt) atomicMax(maxv + 2, mt); }
   uint32_t total_s, total_t;
   block_exclusive_scan_1024(ssum, sh, total_s);
   block_exclusive_scan_1024(tsum, sh, total_t);
@@ -1164,6 +1164,7 @@ __global__ void __launch_bounds__(64) k_task_bases(const uint32_t* __restrict__ 
     host_info[0] = run;
     host_info[1] = mx;
     host_info[2] = hot;
+    host_info[3] = maxv[2];                          // most tasks any bucket has (exact: the top window's tasks are longer)
   }
   static_assert(LEN_BINS == 256, "four bins per lane");
   const uint32_t h0 = ghist[4 * lane], h1 = ghist[4 * lane + 1], h2 = ghist[4 * lane + 2], h3 = ghist[4 * lane + 3];
@@ -1617,23 +1618,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveW
   }
 }
 
-// Hot buckets (more than GATHER_SUM_MAX partial sums: the sort lists them): one workgroup per bucket folds ALL its partial sums --
-// every task-lane sums a strided share into an LDS slot, then a tree over the slots -- and leaves the total where the bucket's
-// first partial sum was.  The lane-by-lane rounds this replaces (k_task_count / k_scan_rows / k_row_bases / k_sum_tasks, sixteen
-// partial sums per lane and round) took two rounds of four launches, 0.5-0.8 ms of latency per MSM of a 0/1-heavy witness.
+// Hot buckets (more than GATHER_SUM_MAX partial sums: the sort lists them).  Stage 1: HOT_SPLIT workgroups per bucket each fold a
+// contiguous share of its partial sums -- every task-lane sums a strided part into an LDS slot, then a tree over the slots -- into a
+// scratch point; stage 2: one wave per bucket folds the HOT_SPLIT scratch points and leaves the total where the bucket's first partial
+// sum was.  A 0/1-heavy witness against window tables puts 8 192 partial sums into one bucket: 4 + 7 + 4 additions deep instead of the
+// 64 + 7 of a single workgroup (1.3 ms of G2 additions); the lane-by-lane rounds this replaced (k_task_count / k_scan_rows / k_row_bases /
+// k_sum_tasks, sixteen partial sums per lane and round) took two rounds of four launches, 0.5-0.8 ms per MSM.
+constexpr uint32_t HOT_SPLIT = 16;
 template <class KF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveWaves<KF>::MIN))) k_hot_sum(uint32_t* part, Level L, int B, const uint32_t* __restrict__ hot_list) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveWaves<KF>::MIN))) k_hot_sum(const uint32_t* part, Level L, int B, const uint32_t* __restrict__ hot_list,
+                                                                                                     uint32_t* scratch) {
   KG_REDUCE_PRIO();
   extern __shared__ uint32_t lds[];                   // 36 words x 256 lane-items
   constexpr uint32_t LPT = Lanes<KF>::N, NT = 256 / LPT, NWB = (uint32_t)PointIO<KF>::NW * 4u;
   const uint32_t t = hot_list[blockIdx.x];
   const uint32_t w = t / (uint32_t)B, cnt = L.cnt[t], first = L.base[w] + L.rel[t];
+  const uint32_t share = (cnt + HOT_SPLIT - 1) / HOT_SPLIT;
+  const uint32_t lo = blockIdx.y * share, hi = lo + share < cnt ? lo + share : cnt;       // this workgroup's partial sums
   const uint32_t task = threadIdx.x / LPT, half = threadIdx.x % LPT;
-  const BufRsrc rp = soa_rsrc(part);
+  const BufRsrc rp = soa_rsrc(part), rs = soa_rsrc(scratch);
   const LdsPt<KF> mine{lds, 256u, threadIdx.x};
-  if (task < cnt) {
-    copy_xyzz_stream<KF>(AosSrc<KF>{rp, (first + task) * NWB, true}, mine);
-    for (uint32_t j = task + NT; j < cnt; j += NT) {
+  if (lo + task < hi) {
+    copy_xyzz_stream<KF>(AosSrc<KF>{rp, (first + lo + task) * NWB, true}, mine);
+    for (uint32_t j = lo + task + NT; j < hi; j += NT) {
       KG_STREAM_FENCE();
       add_xyzz_stream<KF>(mine, AosSrc<KF>{rp, (first + j) * NWB, true}, mine);
     }
@@ -1645,6 +1652,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveW
   for (uint32_t h = NT / 2; h >= 1; h >>= 1) {
     if (task < h) {
       const LdsPt<KF> other{lds, 256u, (task + h) * LPT + half};
+      add_xyzz_stream<KF>(mine, other, mine);
+    }
+    __syncthreads();
+  }
+  if (task == 0) {
+    const AosDst<KF> dst{rs, (blockIdx.x * HOT_SPLIT + blockIdx.y) * NWB};
+    copy_xyzz_stream<KF>(mine, dst);
+  }
+}
+template <class KF>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HalveWaves<KF>::MIN))) k_hot_fold(uint32_t* part, Level L, int B, const uint32_t* __restrict__ hot_list,
+                                                                                                     const uint32_t* scratch) {
+  KG_REDUCE_PRIO();
+  __shared__ uint32_t lds[36 * 64];
+  constexpr uint32_t LPT = Lanes<KF>::N, NT = 64 / LPT, NWB = (uint32_t)PointIO<KF>::NW * 4u;
+  static_assert(HOT_SPLIT <= 32, "one wave folds the shares (lane pairs for G2)");
+  const uint32_t t = hot_list[blockIdx.x];
+  const uint32_t w = t / (uint32_t)B, first = L.base[w] + L.rel[t];
+  const uint32_t task = threadIdx.x / LPT, half = threadIdx.x % LPT;
+  const BufRsrc rp = soa_rsrc(part), rs = soa_rsrc(scratch);
+  const LdsPt<KF> mine{lds, 64u, threadIdx.x};
+  if (task < HOT_SPLIT) copy_xyzz_stream<KF>(AosSrc<KF>{rs, (blockIdx.x * HOT_SPLIT + task) * NWB, true}, mine);
+  else {
+#pragma unroll
+    for (int k = 0; k < 36; ++k) lds[(uint32_t)k * 64u + threadIdx.x] = 0u;
+  }
+  __syncthreads();
+  for (uint32_t h = NT / 2; h >= 1; h >>= 1) {
+    if (task < h) {
+      const LdsPt<KF> other{lds, 64u, (task + h) * LPT + half};
       add_xyzz_stream<KF>(mine, other, mine);
     }
     __syncthreads();
@@ -1775,6 +1812,7 @@ int msm_group_plan(const kg_ctx* ctx, size_t n, int* gw) {
   // accumulations than their shorter reduction tail returns (2^20: 1.98 / 2.03 ms)
   int NG = n >= ((size_t)1 << 17) ? 2 : 0;
   if (c >= 19) NG = 4;                                 // the unsliced 2^23..2^24-pair commitments: the sort of 13-14 windows is 4 ms, hidden group by group
+  if (ctx && ctx->msm_groups) NG = ctx->msm_groups;   // kg_msm_set_groups
   static const char* env = getenv("KG_MSM_GROUPS");
   if (env) {
     if (strchr(env, ',')) {
@@ -2056,7 +2094,7 @@ int msm_sort_wait(kg_ctx* ctx, MsmSorted* S) {
   host_trace("sort: info back");
   const uint32_t* h_info = (const uint32_t*)ctx->h_pinned + 4 * S->group;
   S->ntasks = h_info[0];
-  S->max_cnt = (h_info[1] + S->T - 1) / S->T;          // most tasks any bucket has (an upper bound when the largest bucket is in the top window)
+  S->max_cnt = h_info[3];                              // most tasks any bucket has
   S->nhot = h_info[2];                                 // buckets with more than GATHER_SUM_MAX tasks (listed up to HOT_MAX)
   if (S->ntasks > S->part_cap) return set_err(ctx, KG_ERR_HIP, "task count exceeds its bound");
   return KG_OK;
@@ -2086,7 +2124,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
     KG_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
     KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_order, 0));
   }
-  struct Lay { size_t o_pb, o_lc[2], o_lr[2], o_lb[2], o_part[2], o_pbuf[2], o_rowtot, o_misc; char* ws; const uint32_t* pb; int set; };
+  struct Lay { size_t o_pb, o_lc[2], o_lr[2], o_lb[2], o_part[2], o_pbuf[2], o_rowtot, o_misc, o_hot; char* ws; const uint32_t* pb; int set; };
   Lay lay[MAX_FUSED];
   AccSets A;
   A.nsets = njobs;
@@ -2129,6 +2167,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       Y.o_part[i] = cv.take(part_cap * NW * 4); Y.o_pbuf[i] = cv.take(npts * NW * 4);
     }
     Y.o_rowtot = cv.take((size_t)W * 4); Y.o_misc = cv.take(64);
+    Y.o_hot = cv.take(S.nhot ? (size_t)(S.nhot < HOT_MAX ? S.nhot : HOT_MAX) * HOT_SPLIT * NW * 4 : 0);      // k_hot_sum's shares
     Y.set = J.slot % kg_ctx::RUN_SETS;              // run space per set: the reductions of the previous MSMs may still read the other sets
     for (int k2 = 0; k2 < k; ++k2)
       if (lay[k2].set == Y.set) return set_err(ctx, KG_ERR_BAD_ARG, "fused MSMs need result slots in different run-space sets");
@@ -2209,7 +2248,9 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       if (max_cnt > GATHER_SUM_MAX && hot_ok && S.nhot >= 1 && S.nhot <= HOT_MAX && (size_t)part_cap * NW * 4 < ((size_t)1 << 32)) {
         // the few buckets with more partial sums than the gather takes: one workgroup-wide tree each
         PhaseScope ph2(ctx, "hot_sum", side);
-        hipLaunchKernelGGL(k_hot_sum<KF>, dim3(S.nhot), dim3(256), 36 * 256 * 4, side, part[pcur], L, B, S.hot_list);
+        uint32_t* hot_scratch = (uint32_t*)(ws + Y.o_hot);
+        hipLaunchKernelGGL(k_hot_sum<KF>, dim3(S.nhot, HOT_SPLIT), dim3(256), 36 * 256 * 4, side, part[pcur], L, B, S.hot_list, hot_scratch);
+        hipLaunchKernelGGL(k_hot_fold<KF>, dim3(S.nhot), dim3(64), 0, side, part[pcur], L, B, S.hot_list, hot_scratch);
         ph2.end();
         max_cnt = GATHER_SUM_MAX;
       }

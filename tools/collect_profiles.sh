@@ -13,10 +13,10 @@ timeout -s KILL 400 python3 bench.py > "$O/bench.json" 2> "$O/bench.err"
 # 2. the same command under the kernel trace (kernel averages must agree with the line's HIP-event figures)
 timeout -s KILL 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_bench" -- python3 bench.py --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/kt_bench.err"
 # 3. MSM legs only (the kernels of the headline metric without NTT / Groth16 launches in the averages)
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_msm" -- python3 bench.py --no-cpu-baseline --no-ntt --no-groth16 --no-nova > "$O/msm_under_rocprof.json" 2> "$O/kt_msm.err"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_msm" -- python3 bench.py --no-cpu-baseline --no-ntt --no-groth16 --no-nova --no-skew > "$O/msm_under_rocprof.json" 2> "$O/kt_msm.err"
 # 4. HBM traffic: one counter per pass
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d "$O/pmc_$c" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-groth16 --no-nova > "$O/pmc_$c.json" 2> "$O/pmc_$c.err"
+  timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d "$O/pmc_$c" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-groth16 --no-nova --no-skew > "$O/pmc_$c.json" 2> "$O/pmc_$c.err"
 done
 # 5. the transform alone (2^22 forward NTT: the two k_ntt_tile kernels without the prover's 2^18 launches in the averages)
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_ntt" -- python3 bench.py --ntt-only --steps 300 > "$O/ntt_under_rocprof.json" 2> "$O/kt_ntt.err"
@@ -25,12 +25,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # 6. SQ issue / wait counters of the same leg
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$O/pmcntt_SQ" -- python3 bench.py --ntt-only --steps 10 > "$O/pmcntt_SQ.json" 2> "$O/pmcntt_SQ.err"
-timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$O/pmc_SQ" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ntt --no-groth16 --no-nova > "$O/pmc_SQ.json" 2> "$O/pmc_SQ.err"
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$O/pmc_SQ" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ntt --no-groth16 --no-nova --no-skew > "$O/pmc_SQ.json" 2> "$O/pmc_SQ.err"
 # 7. the multiplier and the transform's register pass alone (tools/ubench; built in-tree before the call)
 if [ -x tools/ubench/mul_rate ]; then
   ( cd tools/ubench; echo "== fp29.h as shipped (one multiply-accumulate chain per column)"; timeout -s KILL 120 ./mul_rate | grep -E "SIMD=(1|2|4|8) "
     if [ -x ./mul_rate_c ]; then echo "== -DKG_NO_ASM_MAC (the columns left to the compiler)"; timeout -s KILL 120 ./mul_rate_c | grep -E "SIMD=(1|2|4|8) "; fi ) > "$O/mul_rate.txt" 2>&1
 fi
+if [ -x tools/ubench/mfma_const_mul ]; then ( cd tools/ubench; timeout -s KILL 120 ./mfma_const_mul ) > "$O/mfma_const_mul.txt" 2>&1; fi
 if [ -x tools/ubench/ntt_pass_rate ]; then ( cd tools/ubench; timeout -s KILL 120 ./ntt_pass_rate ) > "$O/ntt_pass_rate.txt" 2>&1; fi
 ls -R "$O" | head -80
 tail -c 600 "$O/bench.json"
