@@ -503,8 +503,51 @@ constexpr uint32_t MULTI_SEG = 0x80000000u;          // flag in a window's segme
 // 256 threads and at most 64 VGPRs: one wave per SIMD that fits in the registers a resident accumulation leaves free, so the
 // sort of the next MSM runs beside it (see KG_SERVICE_PRIO).
 constexpr int GS_NT = 256, GS_TILE = 1024, GS_MAXG = 1024;
+// buffer addressing (descriptor + scalar plane offset + one 32-bit lane offset) instead of 64-bit flat addresses: the digit planes
+// and the intermediate runs stay far below the 4 GiB a descriptor spans (two-pass sort: n <= 2^24)
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ BufRsrc soa_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffffu, 0x00020000);
+}
+// window_digit through a descriptor of kt: i4 = 4 * scalar index, n4 = 4 * n (bytes per word plane); w is uniform over the workgroup
+__device__ __forceinline__ uint32_t window_digit_buf(BufRsrc kt, uint32_t n4, uint32_t i4, int w, int c, int W, bool& negative) {
+  const int o = w * c;
+  const int j = o >> 5, sh = o & 31;
+  uint64_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(kt, i4, (uint32_t)j * n4, 0);
+  if (j + 1 < 8 && sh + (w == W - 1 ? 17 : c) > 32) v |= (uint64_t)(uint32_t)__builtin_amdgcn_raw_buffer_load_b32(kt, i4, (uint32_t)(j + 1) * n4, 0) << 32;
+  uint32_t e = (uint32_t)(v >> sh);
+  if (w == W - 1) {            // top window: unsigned remainder (no bias term was added for it)
+    negative = false;
+    return e & 0x1ffffu;
+  }
+  e &= (1u << c) - 1u;
+  const int32_t d = (int32_t)e - (int32_t)(1u << (c - 1));
+  negative = d < 0;
+  return (uint32_t)(d < 0 ? -d : d);
+}
+template <int FB> struct EntLoad;
+template <> struct EntLoad<7> { static __device__ __forceinline__ uint32_t ld(BufRsrc r, uint32_t idx) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, idx * 4u, 0, 0); } };
+template <> struct EntLoad<9> {
+  static __device__ __forceinline__ uint64_t ld(BufRsrc r, uint32_t idx) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, idx * 8u, 0, 0);
+    return ((uint64_t)v.y << 32) | v.x;
+  }
+};
+template <int FB> struct EntStore;
+template <> struct EntStore<7> { static __device__ __forceinline__ void st(BufRsrc r, uint32_t idx, uint32_t e) { __builtin_amdgcn_raw_buffer_store_b32(e, r, idx * 4u, 0, 0); } };
+template <> struct EntStore<9> {
+  static __device__ __forceinline__ void st(BufRsrc r, uint32_t idx, uint64_t e) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    u2 v; v.x = (uint32_t)e; v.y = (uint32_t)(e >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, idx * 8u, 0, 0);
+  }
+};
+#ifndef KG_GS_ATTR
+#define KG_GS_ATTR
+#endif
 template <int FB>
-__global__ void __launch_bounds__(GS_NT) k_group_scatter(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len, int G,
+__global__ void __launch_bounds__(GS_NT) KG_GS_ATTR k_group_scatter(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len, int G,
                                                          const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ gstart,
                                                          typename Ent<FB>::T* __restrict__ tmp, const uint32_t* __restrict__ woff, int mshift, int w0) {
   KG_SERVICE_PRIO();
@@ -517,26 +560,34 @@ __global__ void __launch_bounds__(GS_NT) k_group_scatter(const uint32_t* __restr
   const int per = (G + GS_NT - 1) / GS_NT;            // groups a lane owns in the scans (consecutive; <= 4)
   // merged sort (woff != nullptr): all windows share one run per group -- gstart is the merged table, woff[w][g] the entries
   // of the windows in front of w inside the group's run, and the window number rides in the entry above the scalar index
-  if (woff) for (int g = tid; g < G; g += GS_NT) cursor[g] = cnt[((size_t)w * nch + ch) * G + g] + woff[(size_t)w * G + g] + gstart[g];
-  else for (int g = tid; g < G; g += GS_NT) cursor[g] = cnt[((size_t)w * nch + ch) * G + g] + gstart[(size_t)w * G + g];
-  const size_t lo = (size_t)ch * chunk_len, hi = lo + chunk_len < n ? lo + chunk_len : n;
-  E* dst = woff ? tmp : tmp + (size_t)w * n;
+  // (not unrolled: four iterations' worth of 64-bit addresses in flight made this prologue, not the tile loop, set the kernel's
+  // register count -- 64, one wave per SIMD beside an accumulation; at <= 48 two workgroups per CU fit there)
+  if (woff) {
+#pragma unroll 1
+    for (int g = tid; g < G; g += GS_NT) cursor[g] = cnt[((size_t)w * nch + ch) * G + g] + woff[(size_t)w * G + g] + gstart[g];
+  } else {
+#pragma unroll 1
+    for (int g = tid; g < G; g += GS_NT) cursor[g] = cnt[((size_t)w * nch + ch) * G + g] + gstart[(size_t)w * G + g];
+  }
+  const uint32_t lo = (uint32_t)((size_t)ch * chunk_len), hi = (size_t)lo + chunk_len < n ? lo + (uint32_t)chunk_len : (uint32_t)n;     // n < 2^31
+  const BufRsrc rkt = soa_rsrc(kt), rdst = soa_rsrc(woff ? tmp : tmp + (size_t)w * n);
+  const uint32_t n4 = (uint32_t)n * 4u;
   const uint32_t wtag = woff ? (uint32_t)w << mshift : 0u;
-  for (size_t tile = lo; tile < hi; tile += GS_TILE) {
+  for (uint32_t tile = lo; tile < hi; tile += GS_TILE) {
     for (int g = tid; g < G; g += GS_NT) hist[g] = 0;
     __syncthreads();
     E rec[GS_TILE / GS_NT];
     uint32_t key[GS_TILE / GS_NT];                              // key = group << 16 | rank inside the group (tile-local; < 2048)
 #pragma unroll
     for (int r = 0; r < GS_TILE / GS_NT; ++r) {
-      const size_t i = tile + (size_t)r * GS_NT + tid;
+      const uint32_t i = tile + (uint32_t)r * GS_NT + (uint32_t)tid;
       key[r] = 0xffffffffu;
       if (i < hi) {
         bool neg;
-        const uint32_t m = window_digit(kt, n, i, w, c, W, neg);
+        const uint32_t m = window_digit_buf(rkt, n4, i * 4u, w, c, W, neg);
         if (m) {
           const uint32_t g = (m - 1) >> FB;
-          rec[r] = Ent<FB>::make((uint32_t)i | wtag, (m - 1) & (FINE - 1), neg);
+          rec[r] = Ent<FB>::make(i | wtag, (m - 1) & (FINE - 1), neg);
           key[r] = (g << 16) | atomicAdd(&hist[g], 1u);
         }
       }
@@ -567,7 +618,7 @@ __global__ void __launch_bounds__(GS_NT) k_group_scatter(const uint32_t* __restr
       }
     }
     __syncthreads();
-    for (uint32_t p = tid; p < total; p += GS_NT) dst[p + hist[sg[p]]] = stage[p];
+    for (uint32_t p = tid; p < total; p += GS_NT) EntStore<FB>::st(rdst, p + hist[sg[p]], stage[p]);
     __syncthreads();
   }
 }
@@ -728,19 +779,29 @@ __global__ void __launch_bounds__(512) k_fine_local(const typename Ent<FB>::T* _
   }
   // FB = 7: the segment's entries stay in registers between the histogram and the placement (16 per lane).  FB = 9: 40 eight-byte
   // entries per lane would not (the kernel has to fit beside an accumulation): the segment is read twice, the second time out of
-  // the cache the first read filled (160 KiB per workgroup).
+  // the cache the first read filled (160 KiB per workgroup).  Buffer addressing (one 32-bit offset per access) and loops that are not
+  // unrolled further than they must keep the kernel at two workgroups per CU beside an accumulation.
   constexpr int PER = (int)(SEGN / 512);
+#ifdef KG_FINE_KEEP
   constexpr bool KEEP = FB == 7;
-  E rec[KEEP ? PER : 1];
+#else
+  constexpr bool KEEP = false;      // measured: see EXPERIMENTS.md (round 4, sort kernels beside an accumulation)
+#endif
+  const BufRsrc rsrc = soa_rsrc(src + r.lo), rdst = soa_rsrc(sorted + (size_t)w * n + r.lo);      // r.lo = the group's start: its only segment
   const uint32_t len = r.hi - r.lo;
+  E rec[KEEP ? PER : 1];
+  if constexpr (KEEP) {
 #pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const uint32_t i = threadIdx.x + (uint32_t)k * 512u;
-    if (i < len) {
-      const E e = src[r.lo + i];
-      if (KEEP) rec[KEEP ? k : 0] = e;
-      atomicAdd(&hist[Ent<FB>::fine(e)], 1u);
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t i = threadIdx.x + (uint32_t)k * 512u;
+      if (i < len) {
+        rec[k] = EntLoad<FB>::ld(rsrc, i);
+        atomicAdd(&hist[Ent<FB>::fine(rec[k])], 1u);
+      }
     }
+  } else {
+#pragma unroll 2
+    for (uint32_t i = threadIdx.x; i < len; i += 512u) atomicAdd(&hist[Ent<FB>::fine(EntLoad<FB>::ld(rsrc, i))], 1u);
   }
   __syncthreads();
   uint32_t cnt = 0;
@@ -751,17 +812,22 @@ __global__ void __launch_bounds__(512) k_fine_local(const typename Ent<FB>::T* _
   const uint32_t ex = fine_exclusive(cnt, wsum8);               // exclusive prefix of the FINE counters
   if (threadIdx.x < FINE) cursor[threadIdx.x] = ex;
   __syncthreads();
+  if constexpr (KEEP) {
 #pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const uint32_t i = threadIdx.x + (uint32_t)k * 512u;
-    if (i < len) {
-      const E e = KEEP ? rec[KEEP ? k : 0] : src[r.lo + i];
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t i = threadIdx.x + (uint32_t)k * 512u;
+      if (i < len) stage[atomicAdd(&cursor[Ent<FB>::fine(rec[k])], 1u)] = Ent<FB>::out(rec[k]);
+    }
+  } else {
+#pragma unroll 2
+    for (uint32_t i = threadIdx.x; i < len; i += 512u) {
+      const E e = EntLoad<FB>::ld(rsrc, i);
       stage[atomicAdd(&cursor[Ent<FB>::fine(e)], 1u)] = Ent<FB>::out(e);
     }
   }
   __syncthreads();
-  uint32_t* dst = sorted + (size_t)w * n + r.lo;                 // r.lo = the group's start: its only segment
-  for (uint32_t p = threadIdx.x; p < len; p += blockDim.x) dst[p] = stage[p];
+#pragma unroll 2
+  for (uint32_t p = threadIdx.x; p < len; p += blockDim.x) __builtin_amdgcn_raw_buffer_store_b32(stage[p], rdst, p * 4u, 0, 0);
 }
 template <int FB> static constexpr size_t fine_local_lds() { return (size_t)(1028 + 2 * (1u << FB) + 8 + SegLen<FB>::V) * 4; }
 
@@ -1306,10 +1372,6 @@ template <class G> struct PartialIO<Fp2<G>, Fp2S<G>> {      // PointAoS<Fp2<G>>:
 // addressing: the descriptor and the limb plane's offset are wave-uniform (SGPRs), the item's byte offset is ONE 32-bit VGPR
 // per point -- flat loads cost a 64-bit address pair per limb plane (72 planes: the compiler kept ~70 VGPRs of addresses
 // live).  The buffers stay far below the 4 GiB a descriptor spans (72 planes x 15 x 2^17 items x 4 B = 566 MB for G2, c = 18).
-using BufRsrc = __amdgpu_buffer_rsrc_t;
-__device__ __forceinline__ BufRsrc soa_rsrc(const uint32_t* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(base), 0, 0xffffffffu, 0x00020000);
-}
 template <class F> struct SoaLimbs;
 template <class P> struct SoaLimbs<Fp<P>> {
   static __device__ __forceinline__ Fp<P> load(BufRsrc rs, uint32_t plane, uint32_t stride4, uint32_t off) {     // stride4: bytes per plane
@@ -1713,13 +1775,13 @@ int pick_window(size_t n, int forced) {
   // (2^22: 6.6 vs 7.0 ms, 2^24: 25.8 vs 35.2 ms), slower at 2^20 where its bucket reduction doubles
   // c = 20 (13 windows, 2^19 buckets each, 32 entries per bucket at 2^24 -- the density of the 2^20 / c = 16 optimum), UNSLICED and
   // pipelined by window groups (kg_msm): 13 instead of 15 additions per pair and one bucket reduction; needs the nine-bit fine field
-  // of the two-pass sort (eight-byte intermediate entries, 20480-entry segments).  Built, bit-identical, and NOT the default:
-  // measured at 2^24 (MI355X, registered key) 21.3 ms in groups of 3,3,3,4 windows against 21.1 ms for c = 17 in four index
-  // slices -- the accumulation does drop (16.0 against 19.3 ms of launch time) but beside it each group's sort runs 2.5-5x slower
-  // than alone (k_group_scatter 2.3-2.9 against 1.13 ms, k_fine_local 1.4-1.8 against 0.34 ms per three windows: latency-bound
-  // kernels at one wave per SIMD in a memory system full of 64-byte gathers from a 1 GiB key), 4.3-4.6 ms per group against the
-  // 3.8-4.0 ms of its accumulation, so the groups serialise on their sorts.  KG_WIDE_WINDOW=24 (or kg_msm_set_window(20)) selects it.
-  static const int wide_from = [] { const char* e = getenv("KG_WIDE_WINDOW"); return e ? atoi(e) : 0; }();
+  // of the two-pass sort (eight-byte intermediate entries, 20480-entry segments).  Measured at 2^24 (MI355X, alternating runs on one
+  // box): 21.35 ms in groups of 3,3,3,4 windows against 22.0 ms for c = 17 in four index slices (four equal groups: 21.8); at 2^23 the
+  // slices win (11.3 against 11.75 ms).  The accumulation drops from 19.3 to 16.0 ms of launch time, but each group's sort still runs
+  // 2-4x slower beside an accumulation than alone (latency-bound kernels at one or two waves per SIMD) and bounds the pipeline -- before
+  // the sort kernels were slimmed to two workgroups per CU beside an accumulation the wide window lost (21.3 against 21.1).
+  // KG_WIDE_WINDOW=0 keeps the slices, =23 widens from 2^23.
+  static const int wide_from = [] { const char* e = getenv("KG_WIDE_WINDOW"); return e ? atoi(e) : 24; }();
   if (wide_from > 0 && lg >= wide_from && n <= ((size_t)1 << 24)) return 20;
   if (lg >= 21 && n <= ((size_t)1 << 24)) return 17;
   if (lg >= 19) return 16;
@@ -1831,7 +1893,9 @@ int msm_group_plan(const kg_ctx* ctx, size_t n, int* gw) {
   if (NG > kg_ctx::MAX_GROUPS) NG = kg_ctx::MAX_GROUPS;
   if (NG > W) NG = W;
   if (NG < 2) return 0;
-  for (int g = 0; g < NG; ++g) gw[g] = W / NG + (g < W % NG ? 1 : 0);
+  // equal groups, the remainder to the top ones -- except the wide windows, where the LAST group takes it (3,3,3,4 of 13: the top
+  // group's sort is the only one nothing hides; 21.35 against 21.8 ms at 2^24)
+  for (int g = 0; g < NG; ++g) gw[g] = W / NG + (c >= 19 ? (g >= NG - W % NG ? 1 : 0) : (g < W % NG ? 1 : 0));
   return NG;
 }
 
