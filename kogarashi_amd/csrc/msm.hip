@@ -1872,7 +1872,7 @@ int msm_group_plan(const kg_ctx* ctx, size_t n, int* gw) {
   // measured (MI355X, blocking kg_msm, two accumulation queues): two groups give 2^17 0.70 -> 0.68 ms, 2^18 0.88 -> 0.82, 2^19 1.195 -> 1.116,
   // 2^20 1.87 -> 1.79, 2^21 3.16 -> 3.01, 2^22 6.14 -> 5.97; three or four groups pay more launches and more sort beside the
   // accumulations than their shorter reduction tail returns (2^20: 1.98 / 2.03 ms)
-  int NG = n >= ((size_t)1 << 17) ? 2 : 0;
+  int NG = n >= ((size_t)1 << 22) ? 3 : (n >= ((size_t)1 << 17) ? 2 : 0);       // 2^22 (round 4, slimmed sort kernels): 5.97 / 5.79 / 5.83 ms in 2 / 3 / 4 groups
   if (c >= 19) NG = 4;                                 // the unsliced 2^23..2^24-pair commitments: the sort of 13-14 windows is 4 ms, hidden group by group
   if (ctx && ctx->msm_groups) NG = ctx->msm_groups;   // kg_msm_set_groups
   static const char* env = getenv("KG_MSM_GROUPS");
