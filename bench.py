@@ -279,6 +279,8 @@ def main():
         "config": {"workload": f"bn254 G1 MSM, 2^{args.log_n} uniform Fr scalars x uniform G1 bases per GPU, inputs resident in HBM",
                    "pairs_per_gpu": n, "sharding": "index range" if world > 1 else "none"},
         "blocking_ms": blocking_ms,            # wall time of one isolated kg_msm call (nothing in flight), host finish included
+        "queues": {"placement": ctx.queue_placement() if hasattr(ctx, "queue_placement") else None,
+                   "note": "1 + j: the service queues were probed and placed on the three compute pipes the main queue does not use; -1: no clear picture, creation order"},
         "roofline": {"bound": "hbm", "kernel": "k_acc_tasks (bucket accumulation, one launch per MSM)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic["corrected"] if traffic else None, "kernel_ms": acc_avg_ms, "algorithmic_bytes_per_launch": G1_BYTES_PER_PAIR * n,

@@ -47,7 +47,7 @@ enum { KG_G1 = 0, KG_GRUMPKIN = 1, KG_G2 = 2 };      /* curve ids */
 
 typedef struct kg_ctx kg_ctx;
 
-int kg_version(void);                    /* 4: the last extension added kg_msm_set_groups; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
+int kg_version(void);                    /* 4: the last extension added kg_msm_set_groups, kg_ctx_queue_placement; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
 /* Optional process-level setup; call it (or export the variable yourself) BEFORE anything in the process initialises the
  * HIP runtime -- before the first kg_device_count / kg_ctx_create and before any other HIP user -- and before the host
  * starts threads (it calls setenv).  Sets GPU_MAX_HW_QUEUES=16 unless the variable is already set, so that each of a
@@ -74,6 +74,14 @@ int kg_ctx_sync(kg_ctx* ctx);
  * COMPLETE when the call is made (uploaded with kg_memcpy_h2d, or the caller synchronised): the scalar side of MSM i+1 then
  * runs on its own queue UNDER the accumulation of MSM i instead of behind it. */
 int kg_ctx_set_inputs_complete(kg_ctx* ctx, int on);
+/* Diagnostics: how the context's service queues were placed over the GPU's compute pipes.  The runtime deals a process's streams over
+ * hardware queues in creation order and hardware queue k is served by pipe k mod 4; a queue that shares the main queue's pipe starts its
+ * work only when an accumulation's last round of workgroups is placed (~0.7 ms late), so the context creates eight candidate streams on
+ * first use, probes which of them share the main queue's pipe, and puts the scalar queue and the two reduction queues on the three
+ * other pipes.  Returns 1 + j when the probe gave the expected picture (candidates j and j + 4 share the main queue's pipe), -1 when it
+ * did not (the queues are then taken in creation order, as up to version 3), 0 when the probe is switched off (KG_QUEUE_PLACEMENT=0);
+ * creates the queues if they do not exist yet. */
+int kg_ctx_queue_placement(kg_ctx* ctx);
 
 /* device memory plumbing so that non-HIP hosts (Rust shim, ctypes) never link the HIP runtime */
 int kg_malloc(kg_ctx* ctx, size_t bytes, void** d_ptr);

@@ -120,7 +120,7 @@ static int place_queues(kg_ctx* c) {
     for (int j = 0; j < NC && ok; ++j) ok = shares[j] == ((j - j0) % 4 == 0);
     if (ok) for (int j = 0; j < NC; ++j) cls[j] = ((j - j0) % 4 + 4) % 4;      // 0: the main queue's pipe
     c->placement = ok ? 1 + j0 : -1;
-  }
+  } else c->placement = 0;
   auto take = [&](int want) -> hipStream_t {                // first unused candidate of the class (any class when the probe gave no picture)
     for (int j = 0; j < NC; ++j)
       if (cand[j] && (cls[j] == want || !ok)) { hipStream_t t = cand[j]; cand[j] = nullptr; return t; }
@@ -365,6 +365,12 @@ int kg_ctx_sync(kg_ctx* c) {
   for (hipStream_t s : c->acc_stream)
     if (s) KG_HIP(c, hipStreamSynchronize(s));
   return KG_OK;
+}
+int kg_ctx_queue_placement(kg_ctx* c) {
+  if (!c) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipSetDevice(c->device));
+  KG_TRY(make_sort_stream(c));
+  return c->placement;
 }
 int kg_ctx_set_inputs_complete(kg_ctx* c, int on) {
   if (!c) return KG_ERR_BAD_ARG;

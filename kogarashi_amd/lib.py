@@ -21,7 +21,7 @@ EXPORTS = [
     "kg_version", "kg_init", "kg_hw_queue_setting", "kg_device_count", "kg_strerror", "kg_ctx_create", "kg_ctx_destroy", "kg_last_error", "kg_ctx_set_stream",
     "kg_ctx_sync", "kg_malloc", "kg_free", "kg_memcpy_h2d", "kg_memcpy_d2h", "kg_memcpy_d2d", "kg_field_vec_op",
     "kg_field_vec_scale", "kg_ntt_bn254_fr", "kg_fr_divide_by_z_on_coset", "kg_msm", "kg_msm_host", "kg_commit",
-    "kg_points_sum_affine", "kg_msm_set_window", "kg_msm_set_groups", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
+    "kg_points_sum_affine", "kg_msm_set_window", "kg_msm_set_groups", "kg_ctx_queue_placement", "kg_gen_scalars", "kg_gen_bases", "kg_profile_enable", "kg_profile_last",
     "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
     "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_r1cs_begin", "kg_groth16_prove_sharded", "kg_ntt_plan",
@@ -260,6 +260,10 @@ class Context:
 
     def set_msm_window(self, c: int):
         self._chk(self._lib.kg_msm_set_window(self._h, int(c)), "kg_msm_set_window")
+
+    def queue_placement(self) -> int:
+        """how the service queues were dealt over the compute pipes (kg_ctx_queue_placement): 1 + j probed, -1 creation order, 0 off"""
+        return int(self._lib.kg_ctx_queue_placement(self._h))
 
     def set_msm_groups(self, groups: int):
         """window groups of a blocking MSM: 0 automatic, 1 none, 2..4 (kg_msm_set_groups)"""

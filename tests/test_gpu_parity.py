@@ -605,3 +605,71 @@ print("ok")
 """ % root
     r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, KG_G2_PAIR_ACC="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("cv,curve,sfd,n", [("g1", 0, 0, (1 << 17) + 5), ("gk", 1, 1, 140001)])
+def test_blocking_msm_in_window_groups_is_the_same_point(ctx, oracle, cv, curve, sfd, n):
+    """kg_msm pipelines a blocking call against itself by window groups (kg_msm_set_groups; groth16/src/msm.rs:6-48 is a blocking
+    call): the windows are sorted, accumulated and reduced group by group, top windows first, and the host's double-and-add chain runs
+    through the groups in that order.  Every plan -- none, two, three, four groups, per-call bases and a registered array -- must give
+    the oracle's point on an edge mix (identity bases, zero / one / minus-one scalars, repeated points)."""
+    O = oracle
+    bases, scal, inf = edge_mix(O, cv, curve, sfd, n, SEED + 700 + n)
+    want = aff(O, cv, O.msm(cv, bases, scal, inf, threads=8))
+    db, di, ds = ctx.upload(bases), ctx.upload(inf), ctx.upload(scal)
+    try:
+        for g in (1, 2, 3, 4, 0):
+            ctx.set_msm_groups(g)
+            assert gpu_aff(ctx.msm(curve, db.ptr, di.ptr, ds.ptr, n), 4) == want, g
+        ctx.bases_register(curve, db.ptr, di.ptr, n)
+        for g in (2, 4):
+            ctx.set_msm_groups(g)
+            assert gpu_aff(ctx.msm(curve, db.ptr, di.ptr, ds.ptr, n), 4) == want, ("registered", g)
+        # a prefix of the registered array (zip semantics of msm_curve_addition), still in groups
+        m = n - 1234
+        want_m = aff(O, cv, O.msm(cv, bases[:m], scal[:m], inf[:m], threads=8))
+        assert gpu_aff(ctx.msm(curve, db.ptr, di.ptr, ds.ptr, m), 4) == want_m
+    finally:
+        ctx.set_msm_groups(0)
+        ctx.bases_unregister(db.ptr)
+    import ctypes as C
+    assert ctx._lib.kg_msm_set_groups(ctx._h, 5) == -2 and ctx._lib.kg_msm_set_groups(ctx._h, -1) == -2
+
+
+def test_hot_bucket_tree_matches_the_lane_by_lane_rounds(oracle):
+    """A 0/1-heavy scalar vector puts tens of thousands of entries into one bucket: its partial sums go through k_hot_sum / k_hot_fold
+    (sixteen workgroup-wide trees per hot bucket, then one wave).  The older path -- rounds of sixteen partial sums per lane -- is still in
+    the library (KG_HOT_SUM=0) for hot-bucket counts beyond one launch: both must give the oracle's point, pipelined and blocking."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import kogarashi_amd as K
+from kogarashi_amd import synthetic as syn
+from oracle import oracle as O
+ctx = K.Context(0)
+n = (1 << 18) + 77
+bases = O.gen_bases(0, 4242, 0, n)
+scal = O.gen_scalars(0, 4243, 0, n)
+syn.witness_like(scal, 5)
+want_xy, want_inf = O.to_affine("g1", O.msm("g1", bases, scal, None, threads=8))
+db, ds = ctx.upload(bases), ctx.upload(scal)
+for _ in range(2):
+    got = ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n)
+    assert not want_inf and (got[:8] == want_xy).all()
+ctx.msm_begin(K.KG_G1, db.ptr, 0, ds.ptr, n, 0); ctx.msm_begin(K.KG_G1, db.ptr, 0, ds.ptr, n, 1)
+assert (ctx.msm_end(K.KG_G1, 0)[:8] == want_xy).all() and (ctx.msm_end(K.KG_G1, 1)[:8] == want_xy).all()
+print("ok")
+""" % root
+    for hot in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, KG_HOT_SUM=hot), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (hot, r.stderr[-2000:])
+
+
+def test_service_queues_are_placed_off_the_main_queues_pipe(ctx):
+    """capi.cpp place_queues: the probe finds exactly the candidates j and j + 4 on the main queue's compute pipe (1 <= result <= 4),
+    whatever streams the process created before (here: none but the runtime's own)"""
+    p = ctx.queue_placement()
+    assert 1 <= p <= 4, p
