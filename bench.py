@@ -62,7 +62,7 @@ def single_rank_env(torch, dev):
 def window_adds(n):
     """bucket additions of one MSM: one per (window, scalar) pair with a non-zero digit ~ W * n"""
     lg = n.bit_length() - 1
-    c = 17 if 21 <= lg <= 24 and n <= (1 << 24) else (16 if lg >= 19 else (15 if lg >= 14 else min(max(lg - 3, 2), 10)))   # pick_window, msm.hip
+    c = 20 if n == (1 << 24) else (17 if 21 <= lg <= 24 and n <= (1 << 24) else (16 if lg >= 19 else (15 if lg >= 14 else min(max(lg - 3, 2), 10))))   # pick_window, msm.hip
     return ((255 + c - 1) // c) * n
 
 

@@ -19,12 +19,14 @@ def test_window_rule_is_total():
     for n in list(range(1, 70)) + [2 ** k + d for k in range(6, 31) for d in (-1, 0, 1)]:
         c = pick(n)
         w = (255 + c - 1) // c
-        assert w * c >= 255 and 2 <= c <= 17
+        assert w * c >= 255 and 2 <= c <= 20
         top_bits = 254 - (w - 1) * c
         assert top_bits <= c - 1, (n, c)    # top digit (+1 carry of the bias) stays within the 2^(c-1) buckets
-        if c == 17:
+        if c >= 17:
             assert (1 << 16) <= n <= (1 << 24)        # needs the two-pass sort (msm_sort)
-    assert pick(1 << 20) == 16 and pick(1 << 18) == 15 and pick(1 << 22) == 17 and pick(1 << 24) == 17 and pick(1 << 10) == 7
+        if c >= 19:
+            assert n == (1 << 24)                     # the wide window (nine-bit fine field): the 2^24-pair commitment only
+    assert pick(1 << 20) == 16 and pick(1 << 18) == 15 and pick(1 << 22) == 17 and pick(1 << 23) == 17 and pick(1 << 24) == 20 and pick(1 << 10) == 7
     # bench.py's addition count uses the same rule
     import bench
     for lg in (10, 18, 20, 22, 24):
