@@ -2745,6 +2745,11 @@ int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t*
   kg::MsmSorted S;
   const int mc = kg::has_window_table(ctx, curve, d_bases, d_inf, n, n) ? kg::merged_window(ctx, n) : 0;
   KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S, false, mc));
+  // KG_PIPE_ACCQ=2 (experiment, round 4): MSMs in flight alternate between two accumulation queues on the same compute pipe, so that the
+  // next launch's first waves fill the tail in which this one drains.  Measured level to slightly worse (1.347 -> 1.358 ms per step,
+  // three alternating runs): a two-round launch with longest-first tasks has little tail to fill.  Off.
+  static const int pipe_accq = getenv("KG_PIPE_ACCQ") ? atoi(getenv("KG_PIPE_ACCQ")) : 1;
+  if (pipe_accq > 1 && (ticket & 1) && ctx->acc_stream[1]) S.acc_stream = ctx->acc_stream[1];
   if (ctx->ticket_fut[ticket].valid()) ctx->ticket_fut[ticket].wait();      // a ticket begun twice without its end: drop the older result
   KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 1 + ticket));      // slots 1..4 (slot 0: kg_msm; 6..15: the prover's two jobs)
   uint64_t* out = ctx->ticket_out[ticket];
