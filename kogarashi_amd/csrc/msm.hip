@@ -623,6 +623,112 @@ __global__ void __launch_bounds__(GS_NT) KG_GS_ATTR k_group_scatter(const uint32
   }
 }
 
+// The same pass on tiles of TILE > GS_TILE entries.  With G groups a tile of GS_TILE entries leaves GS_TILE / G entries per run and
+// tile -- ONE eight-byte entry at c = 20 (1024 groups), four four-byte ones at c = 16 -- so every store instruction touches its own
+// sector, and a workgroup pays the load and the store latency once per 1024 entries.  Here a tile is TILE / G entries per run
+// (64 bytes at TILE = 8192, c = 20) and TILE / GS_NT loads per lane are in flight at once; a lane cannot hold that many entries
+// in registers, so the tile is walked twice -- count, then place (the digit planes of a tile are a few KiB: the second read is an
+// L2 hit) -- and an entry's slot inside its run is handed out by the second walk's LDS atomic (the order inside a run is free: the
+// fine pass re-sorts it).  stage / sg are dynamic LDS (gs_big_lds).
+template <int FB, int TILE> constexpr size_t gs_big_lds() { return (size_t)TILE * (sizeof(typename Ent<FB>::T) + 2); }
+template <int FB, int TILE, int NT>
+__global__ void __launch_bounds__(NT) k_group_scatter_big(const uint32_t* __restrict__ kt, size_t n, int c, int W, size_t chunk_len, int G,
+                                                             const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ gstart,
+                                                             typename Ent<FB>::T* __restrict__ tmp, const uint32_t* __restrict__ woff, int mshift, int w0) {
+  KG_SERVICE_PRIO();
+  using E = typename Ent<FB>::T;
+  constexpr uint32_t FINE = 1u << FB;
+  constexpr int R = TILE / NT;
+  __shared__ uint32_t cursor[GS_MAXG], delta[GS_MAXG], fill[GS_MAXG], sh[40];
+  extern __shared__ __align__(8) unsigned char gs_dyn[];
+  E* stage = reinterpret_cast<E*>(gs_dyn);
+  uint16_t* sg = reinterpret_cast<uint16_t*>(gs_dyn + sizeof(E) * TILE);
+  const int w = (int)blockIdx.x + w0, ch = blockIdx.y, nch = gridDim.y, tid = threadIdx.x;
+  const int per = (G + NT - 1) / NT;
+  if (woff) {
+#pragma unroll 1
+    for (int g = tid; g < G; g += NT) cursor[g] = cnt[((size_t)w * nch + ch) * G + g] + woff[(size_t)w * G + g] + gstart[g];
+  } else {
+#pragma unroll 1
+    for (int g = tid; g < G; g += NT) cursor[g] = cnt[((size_t)w * nch + ch) * G + g] + gstart[(size_t)w * G + g];
+  }
+  const uint32_t lo = (uint32_t)((size_t)ch * chunk_len), hi = (size_t)lo + chunk_len < n ? lo + (uint32_t)chunk_len : (uint32_t)n;
+  const BufRsrc rkt = soa_rsrc(kt), rdst = soa_rsrc(woff ? tmp : tmp + (size_t)w * n);
+  const uint32_t n4 = (uint32_t)n * 4u;
+  const uint32_t wtag = woff ? (uint32_t)w << mshift : 0u;
+  for (uint32_t tile = lo; tile < hi; tile += TILE) {
+    for (int g = tid; g < G; g += NT) fill[g] = 0;
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < R; ++r) {
+      const uint32_t i = tile + (uint32_t)r * NT + (uint32_t)tid;
+      if (i < hi) {
+        bool neg;
+        const uint32_t m = window_digit_buf(rkt, n4, i * 4u, w, c, W, neg);
+        if (m) atomicAdd(&fill[(m - 1) >> FB], 1u);
+      }
+    }
+    __syncthreads();
+    uint32_t v[4], vsum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int g = tid * per + j; v[j] = (j < per && g < G) ? fill[g] : 0u; vsum += v[j]; }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan_1024(vsum, sh, total);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = tid * per + j;
+      if (j < per && g < G) {
+        fill[g] = ex;                                 // the run's first slot in the tile: the second walk's cursor
+        delta[g] = cursor[g] - ex;                    // destination = slot in the tile + this
+        cursor[g] += v[j];
+        ex += v[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < R; ++r) {
+      const uint32_t i = tile + (uint32_t)r * NT + (uint32_t)tid;
+      if (i < hi) {
+        bool neg;
+        const uint32_t m = window_digit_buf(rkt, n4, i * 4u, w, c, W, neg);
+        if (m) {
+          const uint32_t g = (m - 1) >> FB;
+          const uint32_t p = atomicAdd(&fill[g], 1u);
+          stage[p] = Ent<FB>::make(i | wtag, (m - 1) & (FINE - 1), neg);
+          sg[p] = (uint16_t)g;
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < total; p += NT) EntStore<FB>::st(rdst, p + delta[sg[p]], stage[p]);
+    // no barrier here: the next tile's first walk touches only fill[], and its barriers order everything else
+  }
+}
+
+template <int FB, int TILE, int NT>
+static hipError_t launch_gs_big(dim3 grid, hipStream_t st, const uint32_t* kt, size_t n, int c, int W, size_t chunk_len, int G, const uint32_t* cnt,
+                                const uint32_t* gstart, typename Ent<FB>::T* tmp, const uint32_t* woff, int mshift, int w0) {
+  constexpr size_t lds = gs_big_lds<FB, TILE>();
+  auto* kern = &k_group_scatter_big<FB, TILE, NT>;
+  if (lds + 4 * (3 * GS_MAXG + 40) > 48 * 1024) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, kt, n, c, W, chunk_len, G, cnt, gstart, tmp, woff, mshift, w0);
+  return hipSuccess;
+}
+
+template <int FB>
+static hipError_t launch_gs_big_any(int tile, int nt, dim3 grid, hipStream_t st, const uint32_t* kt, size_t n, int c, int W, size_t chunk_len, int G,
+                                    const uint32_t* cnt, const uint32_t* gstart, typename Ent<FB>::T* tmp, const uint32_t* woff, int mshift, int w0) {
+#define KG_GS_CASE(TILE, NT) \
+  if (tile == TILE && nt == NT) return launch_gs_big<FB, TILE, NT>(grid, st, kt, n, c, W, chunk_len, G, cnt, gstart, tmp, woff, mshift, w0);
+  KG_GS_CASE(4096, 256) KG_GS_CASE(4096, 512) KG_GS_CASE(4096, 1024)
+  KG_GS_CASE(8192, 256) KG_GS_CASE(8192, 512) KG_GS_CASE(8192, 1024)
+#undef KG_GS_CASE
+  return hipErrorInvalidValue;
+}
+
 // One workgroup per window, one lane per bucket group: exclusive prefix of the group's counters over the chunks (in
 // place), group sizes and starts, the segment table, and the window's bucket sizes zeroed for k_fine_local.
 // (workgroup 0 also clears the `zwords` words at `zero`: the task decomposition's counters and length histogram)
@@ -2094,6 +2200,15 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
     const uint32_t* f_segbase = merged ? (uint32_t*)(ws + Q.o_segbase_m) : segbase + (size_t)w0 * (G + 1);
     const uint32_t* f_tmp = merged ? tmp : tmp + (size_t)w0 * n;
     const uint64_t* f_tmp8 = tmp8 + (size_t)w0 * n;
+    // first pass on big tiles (k_group_scatter_big): 8192 entries with the wide windows' 1024 groups, 4096 otherwise; 1024 threads
+    // where nothing else runs (the first window group of a blocking MSM), 256 beside an accumulation.  Measured (MI355X, round 4):
+    // 2^24-pair commitment 20.32 -> 19.00 ms, blocking 2^20 1.746 -> 1.685 ms, the four-deep 2^20 step 1.32 -> 1.295 ms; 512 threads
+    // beside the accumulation shorten the sorts (12.9 -> 9.8 ms summed at 2^24) and lengthen the accumulations by as much.
+    static const int gs_tile_env = getenv("KG_GS_TILE") ? atoi(getenv("KG_GS_TILE")) : -1;     // experiments: 0 = the 1024-entry tiles of k_group_scatter
+    static const int gs_nt_env = getenv("KG_GS_NT") ? atoi(getenv("KG_GS_NT")) : 256;
+    static const int gs_nt0_env = getenv("KG_GS_NT0") ? atoi(getenv("KG_GS_NT0")) : 1024;
+    const int gs_tile = gs_tile_env >= 0 ? gs_tile_env : (fb == 9 ? 8192 : 4096);
+    const int gs_nt = (Q.ngroups > 1 && g == 0) ? gs_nt0_env : gs_nt_env;
     if (two_pass) {
       hipLaunchKernelGGL(k_group_scan, dim3(sWg), dim3(GS_NT), 0, st, cnt + (size_t)sw0 * nch * G, nch, G, B, gsize + (size_t)sw0 * G, gstart + (size_t)sw0 * G,
                          segbase + (size_t)sw0 * (G + 1), (uint32_t*)(ws + Q.o_bsize) + (size_t)sw0 * B, misc, (int)(zbytes / 4), seg_len_for(fb));
@@ -2101,11 +2216,15 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
         hipLaunchKernelGGL(k_merge_groups, dim3(1), dim3(GS_NT), 0, st, gsize, W, G, woff, (uint32_t*)(ws + Q.o_gsize_m), (uint32_t*)(ws + Q.o_gstart_m),
                            (uint32_t*)(ws + Q.o_segbase_m));
       if (fb == 9) {
-        hipLaunchKernelGGL(k_group_scatter<9>, dim3(sWg, nch), dim3(GS_NT), 0, st, kt, n, c, W, Q.chunk_len, G, cnt, gstart, tmp8, woff, Q.mshift, sw0);
+        if (gs_tile) KG_HIP(ctx, launch_gs_big_any<9>(gs_tile, gs_nt, dim3(sWg, nch), st, kt, n, c, W, Q.chunk_len, G, cnt, gstart, tmp8, woff, Q.mshift, sw0));
+        else
+          hipLaunchKernelGGL(k_group_scatter<9>, dim3(sWg, nch), dim3(GS_NT), 0, st, kt, n, c, W, Q.chunk_len, G, cnt, gstart, tmp8, woff, Q.mshift, sw0);
         KG_HIP(ctx, hipFuncSetAttribute((const void*)k_fine_local<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fine_local_lds<9>()));
         hipLaunchKernelGGL(k_fine_local<9>, dim3(Wg, maxseg), dim3(512), fine_local_lds<9>(), st, f_tmp8, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bsize, segcnt, segoff, S->sorted);
       } else {
-        hipLaunchKernelGGL(k_group_scatter<7>, dim3(sWg, nch), dim3(GS_NT), 0, st, kt, n, c, W, Q.chunk_len, G, cnt, merged ? f_gstart : gstart, tmp, woff, Q.mshift, sw0);
+        if (gs_tile) KG_HIP(ctx, launch_gs_big_any<7>(gs_tile, gs_nt, dim3(sWg, nch), st, kt, n, c, W, Q.chunk_len, G, cnt, merged ? f_gstart : gstart, tmp, woff, Q.mshift, sw0));
+        else
+          hipLaunchKernelGGL(k_group_scatter<7>, dim3(sWg, nch), dim3(GS_NT), 0, st, kt, n, c, W, Q.chunk_len, G, cnt, merged ? f_gstart : gstart, tmp, woff, Q.mshift, sw0);
         hipLaunchKernelGGL(k_fine_local<7>, dim3(Wg, maxseg), dim3(512), fine_local_lds<7>(), st, f_tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bsize, segcnt, segoff, S->sorted);
       }
     } else {

@@ -1,5 +1,7 @@
-"""Accumulate-phase rate (G mixed additions/s) against n for a forced window width: python tools/dbg/acc_rate.py c lg1 lg2 ..."""
+"""Accumulate-phase rate (G mixed additions/s) against n for a forced window width, the accumulation running alone (one window
+group, no index slices):  python tools/dbg/acc_rate.py c lg1 lg2 ..."""
 import os, sys
+os.environ.setdefault("KG_MSM_SLICED", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import kogarashi_amd as K
@@ -7,6 +9,7 @@ K.init()          # one hardware queue per library queue (kg_init), before anyth
 SEED = 0x4B6F676172617368
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 ctx = K.Context(0)
+ctx.set_msm_groups(1)
 c = int(sys.argv[1])
 for lg in [int(a) for a in sys.argv[2:]]:
     n = 1 << lg
