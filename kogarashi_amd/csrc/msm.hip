@@ -65,14 +65,14 @@ constexpr int PREP_CH = 4096;
 constexpr int PREP_NT = 256;      // one wave per SIMD at <= 64 VGPRs: fits beside a resident accumulation (4 x 112 VGPRs per SIMD)
 template <class SP>
 __global__ void __launch_bounds__(PREP_NT) k_prep_scalars_count(const uint64_t* __restrict__ scalars, size_t n, Words8 H, uint32_t* __restrict__ kt,
-                                                             int c, int W, int shift, int G, int nch, size_t chunk_len, uint32_t* __restrict__ cnt) {
+                                                             int c, int W, int shift, int G, int nch, size_t chunk_len, uint32_t* __restrict__ cnt, int per_wg) {
   KG_SERVICE_PRIO();
   extern __shared__ uint32_t hist[];                 // [W][G]
   for (int t = threadIdx.x; t < W * G; t += blockDim.x) hist[t] = 0;
   __syncthreads();
-  const size_t lo = (size_t)blockIdx.x * PREP_CH;
+  const size_t lo = (size_t)blockIdx.x * per_wg;      // per_wg divides PREP_CH, which divides chunk_len: a workgroup stays inside one chunk
   const uint32_t cmask = (1u << c) - 1u, half = 1u << (c - 1);
-  for (int r = 0; r < PREP_CH / PREP_NT; ++r) {
+  for (int r = 0; r < per_wg / PREP_NT; ++r) {
     const size_t i = lo + (size_t)r * PREP_NT + threadIdx.x;
     if (i >= n) break;
     uint32_t w[8], k[8];
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(PREP_NT) k_prep_scalars_count(const uint64_t* 
     }
   }
   __syncthreads();
-  const int ch = (int)(lo / chunk_len);               // chunk_len is a multiple of PREP_CH: one chunk per workgroup
+  const int ch = (int)(lo / chunk_len);
   for (int t = threadIdx.x; t < W * G; t += blockDim.x) {
     const uint32_t v = hist[t];
     if (v) atomicAdd(&cnt[((size_t)(t / G) * nch + ch) * G + (t % G)], v);
@@ -746,8 +746,19 @@ __global__ void __launch_bounds__(GS_NT) k_group_scan(uint32_t* __restrict__ cnt
     const int g = tid * per + j;
     run[j] = 0;
     if (j < per && g < G) {
-      for (int ch = 0; ch < nch; ++ch) {
-        uint32_t* p = cnt + ((size_t)w * nch + ch) * G + g;
+      // eight chunks' counters are requested before the first running sum goes back (one load, one dependent store per chunk
+      // was 26 us of pure latency at 256 chunks)
+      uint32_t* col = cnt + (size_t)w * nch * G + g;
+      int ch = 0;
+      for (; ch + 8 <= nch; ch += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = col[(size_t)(ch + k) * G];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { col[(size_t)(ch + k) * G] = run[j]; run[j] += v[k]; }
+      }
+      for (; ch < nch; ++ch) {
+        uint32_t* p = col + (size_t)ch * G;
         const uint32_t v = *p;
         *p = run[j];
         run[j] += v;
@@ -944,7 +955,7 @@ __global__ void __launch_bounds__(512) k_fine_scatter(const typename Ent<FB>::T*
                                                       const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gsize,
                                                       const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ bstart,
                                                       const uint32_t* __restrict__ segcnt, const uint32_t* __restrict__ segoff,
-                                                      uint32_t* __restrict__ sorted) {
+                                                      uint32_t* __restrict__ sorted, int Wg, int extra_w) {
   KG_SERVICE_PRIO();
   using E = typename Ent<FB>::T;
   constexpr uint32_t FINE = 1u << FB, SEGN = SegLen<FB>::V;
@@ -956,14 +967,18 @@ __global__ void __launch_bounds__(512) k_fine_scatter(const typename Ent<FB>::T*
   uint32_t* const wsum8 = gbase + FINE;
   uint32_t* const stage = wsum8 + 8;
   uint16_t* const sfine = reinterpret_cast<uint16_t*>(stage + SEGN);
-  const int w = blockIdx.x;
+  // columns >= Wg of the grid are further rows of window `extra_w` (the unsigned top window: its ~2^12 digit values fill a tenth of
+  // the groups, every one of them several segments even on uniform scalars -- 64 workgroups walked them at 2^20 in 36 us, at 2^24 in 340)
+  const int w = (int)blockIdx.x < Wg ? (int)blockIdx.x : extra_w;
+  const uint32_t row0 = (int)blockIdx.x < Wg ? blockIdx.y : ((uint32_t)blockIdx.x - (uint32_t)Wg + 1u) * gridDim.y + blockIdx.y;
+  const uint32_t rows = (extra_w >= 0 && w == extra_w) ? ((uint32_t)gridDim.x - (uint32_t)Wg + 1u) * gridDim.y : gridDim.y;
   // every group of this window is one segment (any uniform input): k_fine_local did it all.  (A launch of one workgroup per
   // segment that only returned cost 36 us per 2^20-pair sort: hence the few rows and the loop.)
   if (!(segbase[(size_t)w * (G + 1) + G] & MULTI_SEG)) return;
   for (int g = threadIdx.x; g <= G; g += blockDim.x) sb[g] = segbase[(size_t)w * (G + 1) + g];
   __syncthreads();
   const uint32_t nseg = sb[G] & ~MULTI_SEG;
-  for (uint32_t s = blockIdx.y; s < nseg; s += gridDim.y) {
+  for (uint32_t s = row0; s < nseg; s += rows) {
     SegRange r;
     seg_locate(sb, G, s, gstart, gsize, w, r, SEGN);
     if (gsize[(size_t)w * G + r.g] <= SEGN) continue;              // done by k_fine_local (uniform over the workgroup)
@@ -2125,13 +2140,17 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
     if (two_pass) {
       const size_t hl = (size_t)W * G * 4;
       zero_fill(st, cnt, (size_t)W * nch * G * 4);
-      const dim3 grid((unsigned)((n + PREP_CH - 1) / PREP_CH));
+      // PREP_CH scalars per workgroup is 256 workgroups at 2^20 -- one wave per SIMD, which is all that fits beside an accumulation
+      // anyway; the first conversion of a blocking MSM has the chip to itself and takes a quarter of that per workgroup (four times
+      // the flushes of the [W][G] counters: only where those are few, i.e. not the wide windows)
+      const int per_wg = (ngroups > 1 && n < ((size_t)1 << 22) && fb == FINE_BITS) ? PREP_CH / 4 : PREP_CH;
+      const dim3 grid((unsigned)((n + per_wg - 1) / per_wg));
       if (scalar_field == KG_FR) {
         if (hl > 48 * 1024) KG_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_scalars_count<FrParams>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
-        hipLaunchKernelGGL(k_prep_scalars_count<FrParams>, grid, dim3(PREP_NT), hl, st, d_scalars, n, H, kt, c, W, fb, G, nch, chunk_len, cnt);
+        hipLaunchKernelGGL(k_prep_scalars_count<FrParams>, grid, dim3(PREP_NT), hl, st, d_scalars, n, H, kt, c, W, fb, G, nch, chunk_len, cnt, per_wg);
       } else {
         if (hl > 48 * 1024) KG_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_scalars_count<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
-        hipLaunchKernelGGL(k_prep_scalars_count<FqParams>, grid, dim3(PREP_NT), hl, st, d_scalars, n, H, kt, c, W, fb, G, nch, chunk_len, cnt);
+        hipLaunchKernelGGL(k_prep_scalars_count<FqParams>, grid, dim3(PREP_NT), hl, st, d_scalars, n, H, kt, c, W, fb, G, nch, chunk_len, cnt, per_wg);
       }
     } else if (scalar_field == KG_FR) hipLaunchKernelGGL(k_prep_scalars<FrParams>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
     else hipLaunchKernelGGL(k_prep_scalars<FqParams>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, H, kt);
@@ -2244,12 +2263,15 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
     hipLaunchKernelGGL(k_task_bases, dim3(1), dim3(64), 0, st, rowtot, Wg, S->lbase, misc, misc + 4, lenh, lenh + LEN_BINS, (uint32_t*)ctx->h_pinned_dev + 4 * gi);
     KG_HIP(ctx, hipEventRecord(ctx->ev_info[gi], st));
     hipLaunchKernelGGL(k_len_scatter, dim3(g1024), dim3(1024), 0, st, S->bsize, S->lcnt, S->lrel, S->lbase, npts, B, T, lenh + LEN_BINS, S->task_bkt, S->task_id, T_top, top_w);
+    // rows of segment walkers per window; the top window (top_w >= 0: this group holds it, the sort is not merged) gets three more sets
+    const int fs_rows = maxseg < FS_ROWS ? maxseg : FS_ROWS;
+    const int fs_extra = top_w >= 0 ? 3 : 0;
     if (two_pass && fb == 9) {
       KG_HIP(ctx, hipFuncSetAttribute((const void*)k_fine_scatter<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fine_scatter_lds<9>()));
-      hipLaunchKernelGGL(k_fine_scatter<9>, dim3(Wg, maxseg < FS_ROWS ? maxseg : FS_ROWS), dim3(512), fine_scatter_lds<9>(), st, f_tmp8, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bstart, segcnt, segoff, S->sorted);
+      hipLaunchKernelGGL(k_fine_scatter<9>, dim3(Wg + fs_extra, fs_rows), dim3(512), fine_scatter_lds<9>(), st, f_tmp8, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bstart, segcnt, segoff, S->sorted, Wg, fs_extra ? top_w : -1);
     } else if (two_pass) {
       KG_HIP(ctx, hipFuncSetAttribute((const void*)k_fine_scatter<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fine_scatter_lds<7>()));
-      hipLaunchKernelGGL(k_fine_scatter<7>, dim3(Wg, maxseg < FS_ROWS ? maxseg : FS_ROWS), dim3(512), fine_scatter_lds<7>(), st, f_tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bstart, segcnt, segoff, S->sorted);
+      hipLaunchKernelGGL(k_fine_scatter<7>, dim3(Wg + fs_extra, fs_rows), dim3(512), fine_scatter_lds<7>(), st, f_tmp, n, G, B, maxseg, f_gstart, f_gsize, f_segbase, S->bstart, segcnt, segoff, S->sorted, Wg, fs_extra ? top_w : -1);
     } else
       hipLaunchKernelGGL(k_scatter, dim3(W, nch), dim3(1024), lds, st, kt, n, c, W, Q.chunk_len, 0, cnt, S->bstart, S->sorted);
     ph.end();
@@ -2695,7 +2717,7 @@ static int msm_grouped(kg_ctx* ctx, int curve, const uint64_t* d_bases, const ui
   // scalar queue (2^20, same box, alternating runs; unsplit 1.85-1.90)
   static const int main_first = getenv("KG_GROUP_MAIN_FIRST") ? atoi(getenv("KG_GROUP_MAIN_FIRST")) : 0;
   KG_TRY(kg::msm_sort_begin(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &Q, false, 0, 1, NG, gw, main_first != 0));
-  if (main_first) {                                        // the scalar queue (the later groups' sorts) follows the conversion
+  if (main_first == 1) {                                   // the scalar queue (the later groups' sorts) follows the conversion
     KG_HIP(ctx, hipEventRecord(ctx->ev_prep, ctx->stream));
     KG_HIP(ctx, hipStreamWaitEvent(ctx->sort_stream, ctx->ev_prep, 0));
   }
@@ -2736,6 +2758,10 @@ static int msm_grouped(kg_ctx* ctx, int curve, const uint64_t* d_bases, const ui
   kg::MsmSorted S[kg_ctx::MAX_GROUPS];
   int slots[kg_ctx::MAX_GROUPS];
   int rc = kg::msm_sort_group(ctx, Q, 0, &S[0], main_first != 0);
+  // KG_GROUP_MAIN_FIRST=2: as 1, but the scalar queue waits for the first group's SORT -- the sorts still run in turn, and the
+  // cross-queue hand-over (20-60 us) sits in front of the second sort, which has the whole first accumulation to hide in, instead of
+  // in front of the first accumulation
+  if (rc == KG_OK && main_first == 2) KG_HIP(ctx, hipStreamWaitEvent(ctx->sort_stream, S[0].ready, 0));
   if (rc == KG_OK && NG > 1) rc = kg::msm_sort_group(ctx, Q, 1, &S[1]);
   int launched = 0;
   for (int g = 0; g < NG && rc == KG_OK; ++g) {
