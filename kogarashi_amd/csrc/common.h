@@ -19,6 +19,7 @@ struct kg_ctx {
   hipStream_t stream = nullptr;          // stream every launch goes to
   std::string last_error;
   int msm_window = 0;                    // 0 = auto
+  bool sort_alone = false;               // hint for the next msm_sort / msm_sort_begin: nothing else is on the device (a blocking call's first sort) -- set and cleared by the caller
   int msm_groups = 0;                    // window groups of a blocking MSM: 0 = auto, 1 = none, 2..MAX_GROUPS (kg_msm_set_groups)
   // grow-only scratch
   // MSM scalar-side space (sorted digit lists, task tables), two sets used in turn: the sort of MSM i+1 runs on the scalar
@@ -285,6 +286,7 @@ int msm_sort_wait(kg_ctx* ctx, MsmSorted* S);
 struct MsmSortPlan {
   size_t n = 0, chunk_len = 0, nv = 0;
   int c = 0, W = 0, B = 0, Wb = 0, G = 0, nch = 0, maxseg = 0, mshift = 0, set = 0, ngroups = 1, info_base = 0, fb = 7;
+  bool alone = false;                    // the first group's sort has the chip to itself (kg_ctx::sort_alone, or a call split into window groups)
   bool merged = false, two_pass = false;
   uint32_t T = 0, T_top = 0;
   int gw0[kg_ctx::MAX_GROUPS] = {}, gW[kg_ctx::MAX_GROUPS] = {};

@@ -350,7 +350,7 @@ int assemble_proof(const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t*
 int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
                   const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
                   const uint64_t* s, ProofJob* job, int slot_base, const kg_csr* const* mats = nullptr, int roles = ROLE_ALL,
-                  bool defer_assembly = false, bool h_early = false) {
+                  bool defer_assembly = false, bool h_early = false, bool alone_front = false) {
   if (!ctx || !crs || !r || !s) return KG_ERR_BAD_ARG;
   const bool do_g2 = (roles & ROLE_G2) != 0, do_g1w = (roles & ROLE_G1W) != 0, do_h = (roles & ROLE_H) != 0;
   const bool need_z = do_g2 || do_g1w || mats != nullptr;      // z = x || w feeds the witness MSMs and cs.evaluate()
@@ -422,7 +422,12 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   const bool tz = (!do_g2 || has_window_table(ctx, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, nz)) &&
                   (!do_g1w || (has_window_table(ctx, KG_G1, crs->d_a, crs->d_a_inf, nz, nz) && has_window_table(ctx, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, nz, nz) &&
                                (!m_l_1 || has_window_table(ctx, KG_G1, crs->d_l, crs->d_l_inf, m_l_1, nz))));
-  if (do_g2 || do_g1w) KG_TRY(msm_sort(ctx, KG_FR, Z, nz, &Sz, true, tz ? merged_window(ctx, nz) : 0, 2, false));
+  if (do_g2 || do_g1w) {
+    ctx->sort_alone = alone_front;                        // a blocking proof: the witness sort has the chip (the transforms beside it are few workgroups)
+    const int rs = msm_sort(ctx, KG_FR, Z, nz, &Sz, true, tz ? merged_window(ctx, nz) : 0, 2, false);
+    ctx->sort_alone = false;
+    KG_TRY(rs);
+  }
   int rc = KG_OK;
   auto hip_rc = [&](hipError_t e, const char* what) {
     if (e != hipSuccess && rc == KG_OK) rc = set_err(ctx, e == hipErrorOutOfMemory ? KG_ERR_OOM : KG_ERR_HIP, what, e);
@@ -467,7 +472,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   MsmSorted Sq;
   bool h_sorted = false;
   auto h_front = [&]() {                                  // h = (a o b - c) / Z on the coset, back to coefficients (prover.rs:43-47)
-    for (int v = 0; v < 3; ++v) hip_rc(hipStreamWaitEvent(st, ctx->ev_join[v], 0), "hipStreamWaitEvent(join)");
+    for (int v = 1; v < 3; ++v) hip_rc(hipStreamWaitEvent(st, ctx->ev_join[v], 0), "hipStreamWaitEvent(join)");   // chain 0 shares chain 2's queue, in front of it
     HostFr seven = HostFr::one();                         // (7^n - 1)^-1 on the host: n = 2^k squarings of 7
     {
       HostFr one = HostFr::one(), acc = HostFr::zero();
@@ -605,7 +610,7 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   if (!ctx || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
   ProofJob* job = job_of(ctx, 0);
   if (job->active) return KG_ERR_BAD_ARG;                // a proof begun with ticket 0 has not been collected
-  KG_TRY(prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job, 5, nullptr, ROLE_ALL, false, g16_h_early()));
+  KG_TRY(prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job, 5, nullptr, ROLE_ALL, false, g16_h_early(), true));
   return prove_collect(ctx, job, proof_out, proof_inf);
 }
 
@@ -626,7 +631,7 @@ int kg_groth16_prove_r1cs_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const kg
   ProofJob* job = job_of(ctx, 0);
   if (job->active) return KG_ERR_BAD_ARG;
   const kg_csr* mats[3] = {a, b, c};
-  KG_TRY(prove_enqueue(ctx, crs, nullptr, nullptr, nullptr, d_x, d_w, r, s, job, 5, mats, ROLE_ALL, false, g16_h_early()));
+  KG_TRY(prove_enqueue(ctx, crs, nullptr, nullptr, nullptr, d_x, d_w, r, s, job, 5, mats, ROLE_ALL, false, g16_h_early(), true));
   return prove_collect(ctx, job, proof_out, proof_inf);
 }
 int kg_groth16_prove_r1cs_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const kg_csr* a, const kg_csr* b, const kg_csr* c,

@@ -2065,6 +2065,8 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
   // two passes (bucket group, then bucket inside the group) once the sorted lists outgrow the L2; entries carry the
   // bucket's low FINE_BITS between the passes, which leaves 24 bits for the index
   const bool two_pass = merged || (c - 1 >= FINE_BITS + 4 && n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24));
+  static const bool alone_ok = !(getenv("KG_SORT_ALONE") && atoi(getenv("KG_SORT_ALONE")) == 0);   // experiments: every sort shaped for a busy device
+  const bool alone = alone_ok && (ctx->sort_alone || ngroups > 1);      // the (first group's) sort runs on an otherwise idle device
   if (c >= 19 && (!two_pass || merged)) return set_err(ctx, KG_ERR_BAD_ARG, "windows of 19 and 20 bits need the two-pass sort (2^16 .. 2^24 scalars)");
   const int fb = fine_bits_for(c);                  // low bucket bits an entry carries between the passes
   const uint32_t FINE = 1u << fb;
@@ -2124,6 +2126,7 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
   ctx->ws_idle_n[set] = 0;
   Q.n = n; Q.chunk_len = chunk_len; Q.nv = nv; Q.c = c; Q.W = W; Q.B = B; Q.Wb = Wb; Q.G = G; Q.nch = nch; Q.maxseg = maxseg; Q.mshift = mshift;
   Q.set = set; Q.ngroups = ngroups; Q.merged = merged; Q.two_pass = two_pass; Q.T = T; Q.ws = ws;
+  Q.alone = alone;
   Q.T_top = merged ? T : 2 * T;
   Q.fb = fb;
   uint32_t* kt = (uint32_t*)(ws + Q.o_kt);
@@ -2143,7 +2146,7 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
       // PREP_CH scalars per workgroup is 256 workgroups at 2^20 -- one wave per SIMD, which is all that fits beside an accumulation
       // anyway; the first conversion of a blocking MSM has the chip to itself and takes a quarter of that per workgroup (four times
       // the flushes of the [W][G] counters: only where those are few, i.e. not the wide windows)
-      const int per_wg = (ngroups > 1 && n < ((size_t)1 << 22) && fb == FINE_BITS) ? PREP_CH / 4 : PREP_CH;
+      const int per_wg = (alone && n < ((size_t)1 << 22) && fb == FINE_BITS) ? PREP_CH / 4 : PREP_CH;
       const dim3 grid((unsigned)((n + per_wg - 1) / per_wg));
       if (scalar_field == KG_FR) {
         if (hl > 48 * 1024) KG_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_scalars_count<FrParams>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
@@ -2227,7 +2230,7 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
     static const int gs_nt_env = getenv("KG_GS_NT") ? atoi(getenv("KG_GS_NT")) : 256;
     static const int gs_nt0_env = getenv("KG_GS_NT0") ? atoi(getenv("KG_GS_NT0")) : 1024;
     const int gs_tile = gs_tile_env >= 0 ? gs_tile_env : (fb == 9 ? 8192 : 4096);
-    const int gs_nt = (Q.ngroups > 1 && g == 0) ? gs_nt0_env : gs_nt_env;
+    const int gs_nt = (Q.alone && g == 0) ? gs_nt0_env : gs_nt_env;
     if (two_pass) {
       hipLaunchKernelGGL(k_group_scan, dim3(sWg), dim3(GS_NT), 0, st, cnt + (size_t)sw0 * nch * G, nch, G, B, gsize + (size_t)sw0 * G, gstart + (size_t)sw0 * G,
                          segbase + (size_t)sw0 * (G + 1), (uint32_t*)(ws + Q.o_bsize) + (size_t)sw0 * B, misc, (int)(zbytes / 4), seg_len_for(fb));
@@ -2800,7 +2803,10 @@ int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf
     const int NG = kg::msm_group_plan(ctx, n, gw);
     if (NG > 1) return msm_grouped(ctx, curve, d_bases, d_inf, d_scalars, n, gw, NG, out_xyz);
   }
-  KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S, false, mc));
+  ctx->sort_alone = true;                                 // a blocking call: its sort is all the device has to do
+  const int rs = kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S, false, mc);
+  ctx->sort_alone = false;
+  KG_TRY(rs);
   KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 0));
   return kg::msm_finish(ctx, curve, 0, out_xyz);
 }
