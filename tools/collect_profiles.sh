@@ -32,6 +32,7 @@ if [ -x tools/ubench/mul_rate ]; then
     if [ -x ./mul_rate_c ]; then echo "== -DKG_NO_ASM_MAC (the columns left to the compiler)"; timeout -s KILL 120 ./mul_rate_c | grep -E "SIMD=(1|2|4|8) "; fi ) > "$O/mul_rate.txt" 2>&1
 fi
 if [ -x tools/ubench/mfma_const_mul ]; then ( cd tools/ubench; timeout -s KILL 120 ./mfma_const_mul ) > "$O/mfma_const_mul.txt" 2>&1; fi
+if [ -x tools/ubench/group_scatter ]; then ( cd tools/ubench; timeout -s KILL 120 ./group_scatter 24 20; timeout -s KILL 120 ./group_scatter 20 16 ) > "$O/group_scatter.txt" 2>&1; fi
 if [ -x tools/ubench/ntt_pass_rate ]; then ( cd tools/ubench; timeout -s KILL 120 ./ntt_pass_rate ) > "$O/ntt_pass_rate.txt" 2>&1; fi
 ls -R "$O" | head -80
 tail -c 600 "$O/bench.json"

@@ -61,7 +61,7 @@ if os.path.isdir(os.path.join(src, "kt_ntt")):
     sq_counters(os.path.join(src, "pmcntt_SQ"), os.path.join(dst, f"{rnd}_ntt_sq_counters.json"), only="k_ntt_tile")
 if os.path.isdir(os.path.join(src, "pmc_SQ")):
     sq_counters(os.path.join(src, "pmc_SQ"), os.path.join(dst, f"{rnd}_msm_sq_counters.json"))
-for name in ("mul_rate.txt", "ntt_pass_rate.txt"):
+for name in ("mul_rate.txt", "ntt_pass_rate.txt", "mfma_const_mul.txt", "group_scatter.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
 print("installed into", dst)
