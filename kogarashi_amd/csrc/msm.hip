@@ -859,6 +859,9 @@ __device__ __forceinline__ uint32_t fine_exclusive(uint32_t v, uint32_t* wsum8) 
   for (int k = 0; k < wv; ++k) before += wsum8[k];
   return inc - v + before;
 }
+#ifndef KG_FL_UNROLL
+#define KG_FL_UNROLL 4      // entries a lane requests before it touches LDS (1 / 4 / 8: 2^24 commitment 19.18 / 19.00 / 19.00 ms, blocking 2^20 1.634 / 1.597 / 1.594)
+#endif
 template <int FB>
 __global__ void __launch_bounds__(512) k_fine_local(const typename Ent<FB>::T* __restrict__ tmp, size_t n, int G, int B, int maxseg, const uint32_t* __restrict__ gstart,
                                                     const uint32_t* __restrict__ gsize, const uint32_t* __restrict__ segbase,
@@ -884,7 +887,15 @@ __global__ void __launch_bounds__(512) k_fine_local(const typename Ent<FB>::T* _
   if (gsize[(size_t)w * G + r.g] > SEGN) {
     // a segment of a larger group: histogram it and reserve its place inside each bucket (the atomicAdd on the bucket size returns
     // the segment's offset there); k_fine_scatter places the entries once the bucket starts are known
-    for (uint32_t i = r.lo + threadIdx.x; i < r.hi; i += blockDim.x) atomicAdd(&hist[Ent<FB>::fine(src[i])], 1u);
+    uint32_t i = r.lo + threadIdx.x;
+    for (; i + 3u * blockDim.x < r.hi; i += 4u * blockDim.x) {
+      E e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = src[i + (uint32_t)k * blockDim.x];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(&hist[Ent<FB>::fine(e[k])], 1u);
+    }
+    for (; i < r.hi; i += blockDim.x) atomicAdd(&hist[Ent<FB>::fine(src[i])], 1u);
     __syncthreads();
     if (threadIdx.x < FINE) {
       const uint32_t cnt = hist[threadIdx.x];
@@ -917,8 +928,16 @@ __global__ void __launch_bounds__(512) k_fine_local(const typename Ent<FB>::T* _
       }
     }
   } else {
-#pragma unroll 2
-    for (uint32_t i = threadIdx.x; i < len; i += 512u) atomicAdd(&hist[Ent<FB>::fine(EntLoad<FB>::ld(rsrc, i))], 1u);
+    // KG_FL_UNROLL entries requested before the first LDS atomic (left to the compiler the loads stay one at a time: 14 VGPRs)
+    uint32_t i = threadIdx.x;
+    for (; i + (KG_FL_UNROLL - 1) * 512u < len; i += KG_FL_UNROLL * 512u) {
+      E e[KG_FL_UNROLL];
+#pragma unroll
+      for (int k = 0; k < KG_FL_UNROLL; ++k) e[k] = EntLoad<FB>::ld(rsrc, i + (uint32_t)k * 512u);
+#pragma unroll
+      for (int k = 0; k < KG_FL_UNROLL; ++k) atomicAdd(&hist[Ent<FB>::fine(e[k])], 1u);
+    }
+    for (; i < len; i += 512u) atomicAdd(&hist[Ent<FB>::fine(EntLoad<FB>::ld(rsrc, i))], 1u);
   }
   __syncthreads();
   uint32_t cnt = 0;
@@ -936,14 +955,21 @@ __global__ void __launch_bounds__(512) k_fine_local(const typename Ent<FB>::T* _
       if (i < len) stage[atomicAdd(&cursor[Ent<FB>::fine(rec[k])], 1u)] = Ent<FB>::out(rec[k]);
     }
   } else {
-#pragma unroll 2
-    for (uint32_t i = threadIdx.x; i < len; i += 512u) {
+    uint32_t i = threadIdx.x;
+    for (; i + (KG_FL_UNROLL - 1) * 512u < len; i += KG_FL_UNROLL * 512u) {
+      E e[KG_FL_UNROLL];
+#pragma unroll
+      for (int k = 0; k < KG_FL_UNROLL; ++k) e[k] = EntLoad<FB>::ld(rsrc, i + (uint32_t)k * 512u);
+#pragma unroll
+      for (int k = 0; k < KG_FL_UNROLL; ++k) stage[atomicAdd(&cursor[Ent<FB>::fine(e[k])], 1u)] = Ent<FB>::out(e[k]);
+    }
+    for (; i < len; i += 512u) {
       const E e = EntLoad<FB>::ld(rsrc, i);
       stage[atomicAdd(&cursor[Ent<FB>::fine(e)], 1u)] = Ent<FB>::out(e);
     }
   }
   __syncthreads();
-#pragma unroll 2
+#pragma unroll 4
   for (uint32_t p = threadIdx.x; p < len; p += blockDim.x) __builtin_amdgcn_raw_buffer_store_b32(stage[p], rdst, p * 4u, 0, 0);
 }
 template <int FB> static constexpr size_t fine_local_lds() { return (size_t)(1028 + 2 * (1u << FB) + 8 + SegLen<FB>::V) * 4; }
@@ -996,7 +1022,19 @@ __global__ void __launch_bounds__(512) k_fine_scatter(const typename Ent<FB>::T*
     }
     __syncthreads();
     const E* src = tmp + (size_t)w * n;
-    for (uint32_t i = r.lo + threadIdx.x; i < r.hi; i += blockDim.x) {
+    uint32_t i = r.lo + threadIdx.x;
+    for (; i + 3u * blockDim.x < r.hi; i += 4u * blockDim.x) {      // four entries in flight per lane (see KG_FL_UNROLL)
+      E rec[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rec[k] = src[i + (uint32_t)k * blockDim.x];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t f = Ent<FB>::fine(rec[k]), pos = atomicAdd(&cursor[f], 1u);
+        stage[pos] = Ent<FB>::out(rec[k]);
+        sfine[pos] = (uint16_t)f;
+      }
+    }
+    for (; i < r.hi; i += blockDim.x) {
       const E rec = src[i];
       const uint32_t f = Ent<FB>::fine(rec), pos = atomicAdd(&cursor[f], 1u);
       stage[pos] = Ent<FB>::out(rec);

@@ -668,6 +668,39 @@ print("ok")
         assert r.returncode == 0 and "ok" in r.stdout, (hot, r.stderr[-2000:])
 
 
+def test_first_sort_pass_variants_give_the_oracles_point(oracle):
+    """The first pass of the two-pass sort exists in two kernels and several shapes -- k_group_scatter (1024-entry tiles, entries held in
+    registers: KG_GS_TILE=0) and k_group_scatter_big (a tile walked twice; 4096 / 8192 entries, 256 / 512 / 1024 threads; 1024 threads
+    and quarter-size conversion workgroups where a blocking call's sort runs alone, KG_SORT_ALONE=0 turns that off).  Every one of them
+    must sort the same lists: blocking (window groups), pipelined and witness-like scalars against the oracle."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import kogarashi_amd as K
+from kogarashi_amd import synthetic as syn
+from oracle import oracle as O
+ctx = K.Context(0)
+for n, skew in (((1 << 17) + 4099, False), ((1 << 16) + 1, True)):
+    bases = O.gen_bases(0, 777, 0, n)
+    scal = O.gen_scalars(0, 778, 0, n)
+    if skew: syn.witness_like(scal, 9)
+    want_xy, want_inf = O.to_affine("g1", O.msm("g1", bases, scal, None, threads=8))
+    db, ds = ctx.upload(bases), ctx.upload(scal)
+    got = ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n)
+    assert not want_inf and (got[:8] == want_xy).all(), (n, "blocking")
+    ctx.msm_begin(K.KG_G1, db.ptr, 0, ds.ptr, n, 0); ctx.msm_begin(K.KG_G1, db.ptr, 0, ds.ptr, n, 1)
+    assert (ctx.msm_end(K.KG_G1, 0)[:8] == want_xy).all() and (ctx.msm_end(K.KG_G1, 1)[:8] == want_xy).all(), (n, "pipelined")
+print("ok")
+""" % root
+    for knobs in ({"KG_GS_TILE": "0"}, {"KG_GS_TILE": "8192", "KG_GS_NT": "512", "KG_GS_NT0": "256"}, {"KG_GS_TILE": "4096", "KG_GS_NT": "1024"},
+                  {"KG_SORT_ALONE": "0"}):
+        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **knobs), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (knobs, r.stderr[-2000:])
+
+
 def test_service_queues_are_placed_off_the_main_queues_pipe(ctx):
     """capi.cpp place_queues: the probe finds exactly the candidates j and j + 4 on the main queue's compute pipe (1 <= result <= 4),
     whatever streams the process created before (here: none but the runtime's own)"""
