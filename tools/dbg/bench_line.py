@@ -1,7 +1,8 @@
 """One-line summary of a bench.py JSON line (stdin or a file):  python3 bench.py ... | python3 tools/dbg/bench_line.py"""
 import json, sys
 txt = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
-d = json.loads(txt.strip().splitlines()[-1])
+try: d = json.loads(txt)
+except ValueError: d = json.loads(txt.strip().splitlines()[-1])
 out = ["step", round(d["ms_per_step"], 3), "blocking", round(d.get("blocking_ms", 0), 3)]
 g = d.get("groth16")
 if g:
