@@ -502,6 +502,8 @@ constexpr uint32_t MULTI_SEG = 0x80000000u;          // flag in a window's segme
 // lane to a random line is what bounds the unstaged k_scatter: tools/ubench/scatter_rate.hip).
 // 256 threads and at most 64 VGPRs: one wave per SIMD that fits in the registers a resident accumulation leaves free, so the
 // sort of the next MSM runs beside it (see KG_SERVICE_PRIO).
+// (Since round 4 the default is k_group_scatter_big below; this kernel -- entries held in registers across the tile's barriers -- stays
+// reachable with KG_GS_TILE=0 and is parity-tested: tests/test_gpu_parity.py::test_first_sort_pass_variants_give_the_oracles_point.)
 constexpr int GS_NT = 256, GS_TILE = 1024, GS_MAXG = 1024;
 // buffer addressing (descriptor + scalar plane offset + one 32-bit lane offset) instead of 64-bit flat addresses: the digit planes
 // and the intermediate runs stay far below the 4 GiB a descriptor spans (two-pass sort: n <= 2^24)
