@@ -146,6 +146,13 @@ template <class P> struct BaseIO<Fp<P>> {
     x = limbs_from_words<P>(w); y = limbs_from_words<P>(w + 8);
     return inf;
   }
+  // the same from the sixteen words themselves (k_acc_tasks_q reads them out of LDS)
+  static __device__ __forceinline__ bool point64_from_words(uint32_t (&w)[16], Fp<P>& x, Fp<P>& y) {
+    const bool inf = (w[7] & INF_BIT) != 0;
+    w[7] &= ~INF_BIT;
+    x = limbs_from_words<P>(w); y = limbs_from_words<P>(w + 8);
+    return inf;
+  }
   // whole point (x | y, 18 words at an 8-byte aligned address); returns the identity flag
   static __device__ __forceinline__ bool load_point(const uint32_t* src, Fp<P>& x, Fp<P>& y) {
     uint32_t w[18];
@@ -1484,12 +1491,114 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
     if (mshift) { row = (size_t)(idx >> mshift) * tab_n; idx &= (1u << mshift) - 1u; }
     if (idx < idx_off) continue;                         // scalars in front of this base array (shared sort, z = x || w)
     Affine<F> a;
+#ifdef KG_EXP_ACC_CACHED      // timing experiment (wrong sums): every base comes out of a 4 MiB region -- what the accumulation would run at if its gathers never left the cache
+    const size_t at = (row + (idx - idx_off)) & 0xffffu;
+#else
     const size_t at = row + (idx - idx_off);
+#endif
     if (fmt64 ? BaseIO<F>::load_point64(pbases + at * (2 * BaseIO<F>::PK), a.x, a.y) : BaseIO<F>::load_point(pbases + at * PW, a.x, a.y))
       continue;                                          // identity base (msm.rs:58-64 adds it as a no-op)
     acc = add_mixed_signed(acc, a, (e & 0x80000000u) != 0);
   }
   AccStore<F>::store(partial, t, acc);
+}
+
+// Experiment (KG_ACC_PREFETCH=1; off by default -- measured level, see EXPERIMENTS.md Part I section 10): the accumulation with the
+// NEXT base on its way while the current addition runs, without a register for it.  gfx950's global_load_lds_dwordx4 writes 16 bytes
+// per lane straight into LDS (address = M0 base + 16 x lane); request k of lane L fetches piece L & 3 of the point of lane
+// 16 k + (L >> 2), so a quad covers one 64-byte point with one contiguous request (16 lines per instruction instead of 64, every line
+// requested once instead of by four instructions) and the point of lane l lands contiguously at LDS slot 64 (l >> 4) + 4 (l & 15).
+// Per entry: read the point out of LDS, request the next one (its list entry was requested an iteration earlier), add.  The loop is
+// wave-uniform (every lane fetches for its quad's owners until the longest task of the wave is done); a lane adds while its own task
+// lasts.  Base-field curves in the 64-byte resident form only.  Why it was tried: a 2^24-pair array is 1 GiB of bases -- no cache holds
+// it -- and with every gather forced into a 4 MiB region (-DKG_EXP_ACC_CACHED) the 2^24 accumulation takes 13.97 instead of 15.16 ms.
+template <class F>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::MIN))) k_acc_tasks_q(AccSets A, const uint32_t* __restrict__ sorted,
+                                                  const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bsize, Level L,
+                                                  const uint32_t* __restrict__ task_bkt, const uint32_t* __restrict__ task_id,
+                                                  size_t n, int W, int B, uint32_t T0, size_t pstride, int mshift, uint32_t T_top, int top_w) {
+  __shared__ uint4 pf[4 * 64];
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr uint32_t NONE = 0xffffffffu;
+  const int lane = threadIdx.x;
+  const int set = A.nsets > 1 ? (int)(blockIdx.x % (unsigned)A.nsets) : 0;
+  const uint32_t p = (A.nsets > 1 ? blockIdx.x / (unsigned)A.nsets : blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool live = p < L.base[W];
+  const uint32_t* __restrict__ pbases = A.pb[0];
+  uint32_t idx_off = A.idx_off[0], tab_n = A.tab_n[0];
+  uint32_t* __restrict__ partial = A.partial[0];
+#pragma unroll
+  for (int k = 1; k < MAX_FUSED; ++k)
+    if (set == k) { pbases = A.pb[k]; idx_off = A.idx_off[k]; partial = A.partial[k]; tab_n = A.tab_n[k]; }
+  uint32_t t = 0, len = 0;
+  const uint32_t* list = sorted;
+  if (live) {
+    const size_t bi = task_bkt[p];
+    t = task_id[p];
+    const int w = (int)(bi / B);
+    const uint32_t T = task_len(T0, T_top, w, top_w);
+    const uint32_t seg = t - L.base[w] - L.rel[bi];
+    const uint32_t len_all = bsize[bi];
+    const uint32_t lo = seg * T, hi = lo + T < len_all ? lo + T : len_all;
+    list = sorted + (size_t)w * n + bstart[bi] + lo;
+    len = hi - lo;
+  }
+  uint32_t mx = len;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d); mx = o > mx ? o : mx; }
+  // entry -> 32-bit point index in the array (window-table row included); NONE: no entry, or a scalar in front of this array
+  auto locate = [&](uint32_t e) -> uint32_t {
+    if (e == NONE) return NONE;
+    uint32_t idx = e & 0x7fffffffu, row = 0;
+    if (mshift) { row = (idx >> mshift) * tab_n; idx &= (1u << mshift) - 1u; }
+    return idx >= idx_off ? row + (idx - idx_off) : NONE;
+  };
+  auto request = [&](uint32_t e) {                       // all 64 lanes, each for the owners of its quad's points
+    const uint32_t at = locate(e);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t ak = (uint32_t)__shfl((int)at, 16 * k + (lane >> 2));
+      if (ak != NONE) {
+        const uint4* src = reinterpret_cast<const uint4*>(pbases + (size_t)ak * (2 * BaseIO<F>::PK)) + (lane & 3);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(pf + k * 64), 16, 0, 0);
+      }
+    }
+  };
+  XYZZ<F> acc = XYZZ<F>::identity();
+  uint32_t e1 = len > 0 ? list[0] : NONE, e2 = len > 1 ? list[1] : NONE;
+  request(e1);
+  const int slot = 64 * (lane >> 4) + 4 * (lane & 15);
+  for (uint32_t j = 0; j < mx; ++j) {
+    uint32_t wd[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint4 v = pf[slot + k]; wd[4 * k] = v.x; wd[4 * k + 1] = v.y; wd[4 * k + 2] = v.z; wd[4 * k + 3] = v.w; }
+    const uint32_t e = e1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads above are done before the next requests overwrite the buffer
+    e1 = e2;
+    request(e1);
+    e2 = j + 2 < len ? list[j + 2] : NONE;
+    if (locate(e) == NONE) continue;
+    Affine<F> a;
+    if (BaseIO<F>::point64_from_words(wd, a.x, a.y)) continue;        // identity base
+    acc = add_mixed_signed(acc, a, (e & 0x80000000u) != 0);
+  }
+  if (live) AccStore<F>::store(partial, t, acc);
+}
+
+// which launches take k_acc_tasks_q (KG_ACC_PREFETCH=1): base-field arrays in the 64-byte form with at least 2^KG_ACC_PREFETCH_LOG
+// bases; 0 (default): none
+template <class F> struct PfField { using T = Fq; static constexpr bool ok = false; };      // Fq2: never launched (the alias only keeps the launch expression well-formed)
+template <class P> struct PfField<Fp<P>> { using T = Fp<P>; static constexpr bool ok = true; };
+template <class F>
+static int acc_prefetch(const AccSets& A, int njobs, size_t nbases) {
+  if (!PfField<F>::ok) return 0;
+  static const int mode = getenv("KG_ACC_PREFETCH") ? atoi(getenv("KG_ACC_PREFETCH")) : 0;
+  static const int from_log = getenv("KG_ACC_PREFETCH_LOG") ? atoi(getenv("KG_ACC_PREFETCH_LOG")) : 0;
+  if (mode == 0 || nbases < ((size_t)1 << from_log)) return 0;
+  for (int k = 0; k < njobs; ++k)
+    if (!A.fmt64[k]) return 0;
+  return mode;
 }
 
 // final: dense bucket array for the halving reduction
@@ -2458,6 +2567,9 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
     if (LPT > 1 && pair_acc)          // experiment: G2 accumulation on lane pairs, ~150 VGPRs instead of 256
       hipLaunchKernelGGL(k_acc_tasks<KF>, dim3((unsigned)(((size_t)S.ntasks * LPT + 63) / 64) * (unsigned)njobs), dim3(64), 0, st, A, S.sorted, S.bstart, S.bsize, L0,
                          S.task_bkt, S.task_id, S.n, W, B, S.T, part_cap, S.merged_shift, S.T_top, S.top_w);
+    else if (acc_prefetch<F>(A, njobs, jobs[0].nbases))
+      hipLaunchKernelGGL(k_acc_tasks_q<typename PfField<F>::T>, dim3(((S.ntasks + 63) / 64) * (unsigned)njobs), dim3(64), 0, st, A, S.sorted, S.bstart, S.bsize, L0, S.task_bkt,
+                         S.task_id, S.n, W, B, S.T, part_cap, S.merged_shift, S.T_top, S.top_w);
     else
     hipLaunchKernelGGL(k_acc_tasks<F>, dim3(((S.ntasks + 63) / 64) * (unsigned)njobs), dim3(64), 0, st, A, S.sorted, S.bstart, S.bsize, L0, S.task_bkt, S.task_id,
                        S.n, W, B, S.T, part_cap, S.merged_shift, S.T_top, S.top_w);

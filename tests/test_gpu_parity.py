@@ -672,7 +672,8 @@ def test_first_sort_pass_variants_give_the_oracles_point(oracle):
     """The first pass of the two-pass sort exists in two kernels and several shapes -- k_group_scatter (1024-entry tiles, entries held in
     registers: KG_GS_TILE=0) and k_group_scatter_big (a tile walked twice; 4096 / 8192 entries, 256 / 512 / 1024 threads; 1024 threads
     and quarter-size conversion workgroups where a blocking call's sort runs alone, KG_SORT_ALONE=0 turns that off).  Every one of them
-    must sort the same lists: blocking (window groups), pipelined and witness-like scalars against the oracle."""
+    must sort the same lists: blocking (window groups), pipelined and witness-like scalars against the oracle.  The accumulation's
+    experiment kernel (KG_ACC_PREFETCH=1) rides along: same inputs, same point."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = r"""
@@ -696,7 +697,7 @@ for n, skew in (((1 << 17) + 4099, False), ((1 << 16) + 1, True)):
 print("ok")
 """ % root
     for knobs in ({"KG_GS_TILE": "0"}, {"KG_GS_TILE": "8192", "KG_GS_NT": "512", "KG_GS_NT0": "256"}, {"KG_GS_TILE": "4096", "KG_GS_NT": "1024"},
-                  {"KG_SORT_ALONE": "0"}):
+                  {"KG_SORT_ALONE": "0"}, {"KG_ACC_PREFETCH": "1"}):      # the last: k_acc_tasks_q (bases through LDS, gathers shared by lane quads)
         r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **knobs), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (knobs, r.stderr[-2000:])
 
