@@ -96,9 +96,12 @@ __global__ void __launch_bounds__(64) k_build_direct(uint32_t log_n, int inverse
   st_tw(tab, e, pow_u64(root_of(log_n, inverse), r * c * mult));
 }
 
+#ifndef KG_NTT_WAVES
+#define KG_NTT_WAVES 4
+#endif
 // One tile per workgroup; see ntt_tile.h.  NT = tile / 4 threads (one radix-4 group per lane and pass).
 template <int LOG_M, int LOG_TC, bool ROW>
-__global__ void __launch_bounds__((NttTile<Fr, LOG_M, LOG_TC, ROW>::NT)) __attribute__((amdgpu_waves_per_eu(4))) k_ntt_tile(NttStepArgs A) {   // <= 128 VGPRs: LDS admits four waves per SIMD
+__global__ void __launch_bounds__((NttTile<Fr, LOG_M, LOG_TC, ROW>::NT)) __attribute__((amdgpu_waves_per_eu(KG_NTT_WAVES))) k_ntt_tile(NttStepArgs A) {   // <= 128 VGPRs: LDS admits four waves per SIMD
   KG_SERVICE_PRIO();
   using T = NttTile<Fr, LOG_M, LOG_TC, ROW>;
   extern __shared__ uint32_t lds[];
