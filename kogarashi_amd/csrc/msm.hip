@@ -1189,6 +1189,19 @@ constexpr uint32_t GATHER_SUM_MAX = 32;
 constexpr uint32_t HOT_MAX = 4096;                   // hot buckets one k_hot_sum launch takes (more: the lane-by-lane rounds)
 __device__ __forceinline__ uint32_t task_len(uint32_t T, uint32_t T_top, int w, int top_w) { return w == top_w ? T_top : T; }
 __device__ __forceinline__ uint32_t len_key(uint32_t len) { return len > 255u ? 255u : len; }
+// Task length of ONE bucket: a hot bucket (more than GATHER_SUM_MAX tasks of the window's length T) is cut four times finer.  Its
+// partial sums meet in k_hot_sum's trees whatever their number, and its tasks are what a launch waits for: on a 0/1-heavy witness the
+// hot buckets' T = 80-entry chains (80 x 14 us) were the whole accumulation of a window group whose other buckets hold three entries.
+// Every kernel that derives tasks from a bucket size uses bucket_task_len / bucket_tasks (T >= 32: kg::msm_sort_begin clamps it).
+// The task length the kernels receive carries the cut in its top two bits (hot_shift: T >> shift for hot buckets; 0 = none, the merged
+// sort of window tables -- one launch of 15 n entries hides its hot chains, and four times the partial sums cost it 5-8 %).
+constexpr uint32_t T_MASK = 0x3fffffffu;
+__device__ __forceinline__ uint32_t t_plain(uint32_t T) { return T & T_MASK; }
+__device__ __forceinline__ uint32_t bucket_task_len(uint32_t T, uint32_t v) {
+  const uint32_t t = T & T_MASK, sh = T >> 30;
+  return v > GATHER_SUM_MAX * t ? t >> sh : t;
+}
+__device__ __forceinline__ uint32_t bucket_tasks(uint32_t T, uint32_t v) { const uint32_t Tb = bucket_task_len(T, v); return (v + Tb - 1) / Tb; }
 
 __global__ void __launch_bounds__(1024) k_len_scatter(const uint32_t* __restrict__ bsize, const uint32_t* __restrict__ ntask,
                                                       const uint32_t* __restrict__ rel, const uint32_t* __restrict__ base, size_t total, int B,
@@ -1196,34 +1209,56 @@ __global__ void __launch_bounds__(1024) k_len_scatter(const uint32_t* __restrict
                                                       uint32_t* __restrict__ task_id, uint32_t T_top, int top_w) {
   KG_SERVICE_PRIO();
   __shared__ uint32_t h[LEN_BINS], start[LEN_BINS], fill[LEN_BINS];
+  __shared__ uint32_t big_n, big_t[64], big_first[64], big_cnt[64], big_pos[64];
   if (threadIdx.x < LEN_BINS) { h[threadIdx.x] = 0; fill[threadIdx.x] = 0; }
+  if (threadIdx.x == 0) big_n = 0;
   __syncthreads();
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t T = task_len(T0, T_top, (int)(t / B), top_w);
-  uint32_t nt = 0, rem = 0;
+  uint32_t nt = 0, rem = 0, Tb = t_plain(T);
   if (t < total) {
     nt = ntask[t];
     if (nt) {
-      rem = bsize[t] - (nt - 1) * T;
+      Tb = bucket_task_len(T, bsize[t]);
+      rem = bsize[t] - (nt - 1) * Tb;
       atomicAdd(&h[len_key(rem)], 1u);
-      if (nt > 1) atomicAdd(&h[len_key(T)], nt - 1);
+      if (nt > 1) atomicAdd(&h[len_key(Tb)], nt - 1);
     }
   }
   __syncthreads();
   if (threadIdx.x < LEN_BINS && h[threadIdx.x]) start[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
   __syncthreads();
+  // a bucket cut into many tasks (0/1-heavy scalars: one bucket of a 2^24-pair witness holds 8 M entries = 10^5 tasks) hands its
+  // full-length tasks to the whole workgroup -- written by its own lane they were 5.4 ms of a 20 ms commitment
+  constexpr uint32_t BIG = 16, BIG_CAP = 64;
   if (nt) {
     const uint32_t first = base[t / B] + rel[t];
-    const uint32_t kf = len_key(T);
-    for (uint32_t sgm = 0; sgm + 1 < nt; ++sgm) {
-      const uint32_t pos = start[kf] + atomicAdd(&fill[kf], 1u);
-      task_bkt[pos] = (uint32_t)t;
-      task_id[pos] = first + sgm;
+    const uint32_t kf = len_key(Tb);
+    uint32_t slot = BIG_CAP;
+    if (nt - 1 > BIG) slot = atomicAdd(&big_n, 1u);
+    if (slot < BIG_CAP) {
+      big_t[slot] = (uint32_t)t; big_first[slot] = first; big_cnt[slot] = nt - 1;
+      big_pos[slot] = start[kf] + atomicAdd(&fill[kf], nt - 1);
+    } else {
+      for (uint32_t sgm = 0; sgm + 1 < nt; ++sgm) {
+        const uint32_t pos = start[kf] + atomicAdd(&fill[kf], 1u);
+        task_bkt[pos] = (uint32_t)t;
+        task_id[pos] = first + sgm;
+      }
     }
     const uint32_t kr = len_key(rem);
     const uint32_t pos = start[kr] + atomicAdd(&fill[kr], 1u);
     task_bkt[pos] = (uint32_t)t;
     task_id[pos] = first + nt - 1;
+  }
+  __syncthreads();
+  const uint32_t nb = big_n < BIG_CAP ? big_n : BIG_CAP;
+  for (uint32_t b = 0; b < nb; ++b) {
+    const uint32_t bt = big_t[b], bf = big_first[b], bc = big_cnt[b], bp = big_pos[b];
+    for (uint32_t i = threadIdx.x; i < bc; i += blockDim.x) {
+      task_bkt[bp + i] = bt;
+      task_id[bp + i] = bf + i;
+    }
   }
 }
 
@@ -1248,10 +1283,11 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restric
   uint32_t ssum = 0, tsum = 0, mx = 0, full = 0, mt = 0;     // full: tasks of the full length T (one shared bin: counted per lane, added once); mt: most tasks of a bucket
   auto tally = [&](uint32_t v) {
     if (v) {
-      const uint32_t nt = (v + T - 1) / T;
+      const uint32_t Tb = bucket_task_len(T, v), nt = (v + Tb - 1) / Tb;
       ssum += v; tsum += nt; mx = v > mx ? v : mx; mt = nt > mt ? nt : mt;
-      atomicAdd(&h[len_key(v - (nt - 1) * T)], 1u);
-      full += nt - 1;
+      atomicAdd(&h[len_key(v - (nt - 1) * Tb)], 1u);
+      if (Tb == t_plain(T)) full += nt - 1;
+      else atomicAdd(&h[len_key(Tb)], nt - 1);           // a hot bucket's finer tasks: a bin of their own
     }
   };
   if (vec) {
@@ -1261,7 +1297,7 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restric
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) full += __shfl_xor(full, d);
-  if ((threadIdx.x & 63) == 0 && full) atomicAdd(&h[len_key(T)], full);
+  if ((threadIdx.x & 63) == 0 && full) atomicAdd(&h[len_key(t_plain(T))], full);
   uint32_t total_s, total_t;
   uint32_t run_s = block_exclusive_scan_1024(ssum, sh, total_s);
   uint32_t run_t = block_exclusive_scan_1024(tsum, sh, total_t);
@@ -1272,7 +1308,7 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restric
     for (int b = lo; b < hi; b += 4) {
       const uint4 q = *reinterpret_cast<const uint4*>(src + b);
       uint4 st, nt, rl;
-      nt.x = (q.x + T - 1) / T; nt.y = (q.y + T - 1) / T; nt.z = (q.z + T - 1) / T; nt.w = (q.w + T - 1) / T;
+      nt.x = bucket_tasks(T, q.x); nt.y = bucket_tasks(T, q.y); nt.z = bucket_tasks(T, q.z); nt.w = bucket_tasks(T, q.w);
       st.x = run_s; st.y = st.x + q.x; st.z = st.y + q.y; st.w = st.z + q.z; run_s = st.w + q.w;
       rl.x = run_t; rl.y = rl.x + nt.x; rl.z = rl.y + nt.y; rl.w = rl.z + nt.z; run_t = rl.w + nt.w;
       *reinterpret_cast<uint4*>(o_start + b) = st;
@@ -1281,14 +1317,14 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_rows(const uint32_t* __restric
     }
   } else {
     for (int b = lo; b < hi; ++b) {
-      const uint32_t v = src[b], nt = (v + T - 1) / T;
+      const uint32_t v = src[b], nt = bucket_tasks(T, v);
       o_start[b] = run_s; o_nt[b] = nt; o_rel[b] = run_t;
       run_s += v; run_t += nt;
     }
   }
-  if (mx > GATHER_SUM_MAX * T)                          // rare: list this lane's hot buckets (maxv + 1 counts them)
+  if (mx > GATHER_SUM_MAX * t_plain(T))                 // rare: list this lane's hot buckets (maxv + 1 counts them)
     for (int b = lo; b < hi; ++b)
-      if (src[b] > GATHER_SUM_MAX * T) { const uint32_t pos = atomicAdd(maxv + 1, 1u); if (pos < hot_cap) hot_list[pos] = (uint32_t)(w * B + b); }
+      if (src[b] > GATHER_SUM_MAX * t_plain(T)) { const uint32_t pos = atomicAdd(maxv + 1, 1u); if (pos < hot_cap) hot_list[pos] = (uint32_t)(w * B + b); }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mx, d); mx = o > mx ? o : mx; o = __shfl_xor(mt, d); mt = o > mt ? o : mt; }
   if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mx; if (mt) atomicMax(maxv + 2, mt); }      // maxv[2]: most tasks any bucket has
@@ -1319,22 +1355,23 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_part(const uint32_t* __restric
   uint32_t ssum = 0, tsum = 0, mx = 0, full = 0, mt = 0;
   auto tally = [&](uint32_t v) {
     if (v) {
-      const uint32_t nt = (v + T - 1) / T;
+      const uint32_t Tb = bucket_task_len(T, v), nt = (v + Tb - 1) / Tb;
       ssum += v; tsum += nt; mx = v > mx ? v : mx; mt = nt > mt ? nt : mt;
-      atomicAdd(&h[len_key(v - (nt - 1) * T)], 1u);
-      full += nt - 1;
+      atomicAdd(&h[len_key(v - (nt - 1) * Tb)], 1u);
+      if (Tb == t_plain(T)) full += nt - 1;
+      else atomicAdd(&h[len_key(Tb)], nt - 1);           // a hot bucket's finer tasks: a bin of their own
     }
   };
   for (int b = 0; b < per; b += 4) { const uint4 q = *reinterpret_cast<const uint4*>(src + b); tally(q.x); tally(q.y); tally(q.z); tally(q.w); }
-  if (mx > GATHER_SUM_MAX * T)                          // rare: list this lane's hot buckets (maxv + 1 counts them)
+  if (mx > GATHER_SUM_MAX * t_plain(T))                 // rare: list this lane's hot buckets (maxv + 1 counts them)
     for (int b = 0; b < per; ++b)
-      if (src[b] > GATHER_SUM_MAX * T) {
+      if (src[b] > GATHER_SUM_MAX * t_plain(T)) {
         const uint32_t pos = atomicAdd(maxv + 1, 1u);
         if (pos < hot_cap) hot_list[pos] = (uint32_t)((size_t)w * B + (size_t)k * len + (size_t)threadIdx.x * per + b);
       }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { full += __shfl_xor(full, d); uint32_t o = __shfl_xor(mx, d); mx = o > mx ? o : mx; o = __shfl_xor(mt, d); mt = o > mt ? o : mt; }
-  if ((threadIdx.x & 63) == 0) { if (full) atomicAdd(&h[len_key(T)], full); red[threadIdx.x >> 6] = mx; if (mt) atomicMax(maxv + 2, mt); }
+  if ((threadIdx.x & 63) == 0) { if (full) atomicAdd(&h[len_key(t_plain(T))], full); red[threadIdx.x >> 6] = mx; if (mt) atomicMax(maxv + 2, mt); }
   uint32_t total_s, total_t;
   block_exclusive_scan_1024(ssum, sh, total_s);
   block_exclusive_scan_1024(tsum, sh, total_t);
@@ -1363,7 +1400,7 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_fill(const uint32_t* __restric
   for (int b = 0; b < per; b += 4) {
     const uint4 q = *reinterpret_cast<const uint4*>(src + b);
     ssum += q.x + q.y + q.z + q.w;
-    tsum += (q.x + T - 1) / T + (q.y + T - 1) / T + (q.z + T - 1) / T + (q.w + T - 1) / T;
+    tsum += bucket_tasks(T, q.x) + bucket_tasks(T, q.y) + bucket_tasks(T, q.z) + bucket_tasks(T, q.w);
   }
   uint32_t total_s, total_t;
   uint32_t run_s = base_s + block_exclusive_scan_1024(ssum, sh, total_s);
@@ -1371,7 +1408,7 @@ __global__ void __launch_bounds__(BR_NT) k_bucket_fill(const uint32_t* __restric
   for (int b = 0; b < per; b += 4) {
     const uint4 q = *reinterpret_cast<const uint4*>(src + b);
     uint4 st, nt, rl;
-    nt.x = (q.x + T - 1) / T; nt.y = (q.y + T - 1) / T; nt.z = (q.z + T - 1) / T; nt.w = (q.w + T - 1) / T;
+    nt.x = bucket_tasks(T, q.x); nt.y = bucket_tasks(T, q.y); nt.z = bucket_tasks(T, q.z); nt.w = bucket_tasks(T, q.w);
     st.x = run_s; st.y = st.x + q.x; st.z = st.y + q.y; st.w = st.z + q.z; run_s = st.w + q.w;
     rl.x = run_t; rl.y = rl.x + nt.x; rl.z = rl.y + nt.y; rl.w = rl.z + nt.z; run_t = rl.w + nt.w;
     *reinterpret_cast<uint4*>(bstart + off + b) = st;
@@ -1477,9 +1514,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
   const size_t bi = task_bkt[p];
   const uint32_t t = task_id[p];
   const int w = (int)(bi / B);
-  const uint32_t T = task_len(T0, T_top, w, top_w);
   const uint32_t seg = t - L.base[w] - L.rel[bi];
   const uint32_t len_all = bsize[bi];
+  const uint32_t T = bucket_task_len(task_len(T0, T_top, w, top_w), len_all);
   const uint32_t lo = seg * T, hi = lo + T < len_all ? lo + T : len_all;
   const uint32_t* list = sorted + (size_t)w * n + bstart[bi];
   constexpr int PW = 2 * BaseIO<F>::PE;
@@ -1537,9 +1574,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
     const size_t bi = task_bkt[p];
     t = task_id[p];
     const int w = (int)(bi / B);
-    const uint32_t T = task_len(T0, T_top, w, top_w);
     const uint32_t seg = t - L.base[w] - L.rel[bi];
     const uint32_t len_all = bsize[bi];
+    const uint32_t T = bucket_task_len(task_len(T0, T_top, w, top_w), len_all);
     const uint32_t lo = seg * T, hi = lo + T < len_all ? lo + T : len_all;
     list = sorted + (size_t)w * n + bstart[bi] + lo;
     len = hi - lo;
@@ -1956,10 +1993,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveW
 // sum was.  A 0/1-heavy witness against window tables puts 8 192 partial sums into one bucket: 4 + 7 + 4 additions deep instead of the
 // 64 + 7 of a single workgroup (1.3 ms of G2 additions); the lane-by-lane rounds this replaced (k_task_count / k_scan_rows / k_row_bases /
 // k_sum_tasks, sixteen partial sums per lane and round) took two rounds of four launches, 0.5-0.8 ms per MSM.
-constexpr uint32_t HOT_SPLIT = 16;
+// The number of shares follows the fullest bucket (hot_split: ~512 partial sums per share, 16 .. one per task-lane of the folding
+// workgroup): the 4 x 10^5 partial sums of a 2^24-pair witness' bucket of ones were 100 additions per lane in sixteen shares (0.97 ms).
+constexpr uint32_t HOT_SPLIT = 16;                   // the fewest shares
+template <class KF> constexpr uint32_t hot_split_max() { return 256u / Lanes<KF>::N; }
+template <class KF>
+static uint32_t hot_split(uint32_t max_tasks) {
+  uint32_t sp = (max_tasks + 511u) / 512u;
+  if (sp < HOT_SPLIT) sp = HOT_SPLIT;
+  if (sp > hot_split_max<KF>()) sp = hot_split_max<KF>();
+  return sp;
+}
 template <class KF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveWaves<KF>::MIN))) k_hot_sum(const uint32_t* part, Level L, int B, const uint32_t* __restrict__ hot_list,
-                                                                                                     uint32_t* scratch) {
+                                                                                                     uint32_t* scratch, uint32_t HOT_SPLIT) {
   KG_REDUCE_PRIO();
   extern __shared__ uint32_t lds[];                   // 36 words x 256 lane-items
   constexpr uint32_t LPT = Lanes<KF>::N, NT = 256 / LPT, NWB = (uint32_t)PointIO<KF>::NW * 4u;
@@ -1994,26 +2041,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveW
   }
 }
 template <class KF>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HalveWaves<KF>::MIN))) k_hot_fold(uint32_t* part, Level L, int B, const uint32_t* __restrict__ hot_list,
-                                                                                                     const uint32_t* scratch) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveWaves<KF>::MIN))) k_hot_fold(uint32_t* part, Level L, int B, const uint32_t* __restrict__ hot_list,
+                                                                                                      const uint32_t* scratch, uint32_t HOT_SPLIT) {
   KG_REDUCE_PRIO();
-  __shared__ uint32_t lds[36 * 64];
-  constexpr uint32_t LPT = Lanes<KF>::N, NT = 64 / LPT, NWB = (uint32_t)PointIO<KF>::NW * 4u;
-  static_assert(HOT_SPLIT <= 32, "one wave folds the shares (lane pairs for G2)");
+  extern __shared__ uint32_t lds[];                   // 36 words x 256 lane-items
+  constexpr uint32_t LPT = Lanes<KF>::N, NT = 256 / LPT, NWB = (uint32_t)PointIO<KF>::NW * 4u;
   const uint32_t t = hot_list[blockIdx.x];
   const uint32_t w = t / (uint32_t)B, first = L.base[w] + L.rel[t];
   const uint32_t task = threadIdx.x / LPT, half = threadIdx.x % LPT;
   const BufRsrc rp = soa_rsrc(part), rs = soa_rsrc(scratch);
-  const LdsPt<KF> mine{lds, 64u, threadIdx.x};
+  const LdsPt<KF> mine{lds, 256u, threadIdx.x};
   if (task < HOT_SPLIT) copy_xyzz_stream<KF>(AosSrc<KF>{rs, (blockIdx.x * HOT_SPLIT + task) * NWB, true}, mine);
   else {
 #pragma unroll
-    for (int k = 0; k < 36; ++k) lds[(uint32_t)k * 64u + threadIdx.x] = 0u;
+    for (int k = 0; k < 36; ++k) lds[(uint32_t)k * 256u + threadIdx.x] = 0u;
   }
   __syncthreads();
-  for (uint32_t h = NT / 2; h >= 1; h >>= 1) {
+  uint32_t top = NT / 2;
+  while (top >= HOT_SPLIT && top > 1) top >>= 1;       // the first level that has a partner with data: skip the levels of identities
+  for (uint32_t h = top; h >= 1; h >>= 1) {
     if (task < h) {
-      const LdsPt<KF> other{lds, 64u, (task + h) * LPT + half};
+      const LdsPt<KF> other{lds, 256u, (task + h) * LPT + half};
       add_xyzz_stream<KF>(mine, other, mine);
     }
     __syncthreads();
@@ -2249,7 +2297,7 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
   Q.o_segbase_m = cv.take(merged ? (size_t)(G + 1) * 4 : 0);
   Q.o_bpart = cv.take((size_t)W * (B / 4096 + 32) * 2 * 4);      // k_bucket_part: (entries, tasks) of each part of each row
   for (int g = 0; g < ngroups; ++g) {                     // what the task decomposition keeps per group
-    Q.part_cap[g] = (size_t)Q.gW[g] * ((nv + T - 1) / T) + (size_t)Q.gW[g] * B;     // upper bound on round-1 tasks
+    Q.part_cap[g] = (size_t)Q.gW[g] * (4 * ((nv + T - 1) / T)) + (size_t)Q.gW[g] * B;     // upper bound on round-1 tasks (hot buckets: tasks of T / 4, bucket_task_len)
     Q.o_lbase[g] = cv.take((size_t)(Q.gW[g] + 1) * 4);
     Q.o_misc[g] = cv.take(64); Q.o_lenh[g] = cv.take(2 * LEN_BINS * 4);             // adjacent: one zero fill covers both
     Q.o_tbkt[g] = cv.take(Q.part_cap[g] * 4); Q.o_tid[g] = cv.take(Q.part_cap[g] * 4);
@@ -2323,7 +2371,12 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
   const bool merged = Q.merged, two_pass = Q.two_pass;
   const int w0 = Q.gw0[g], Wg = Q.gW[g];              // bucket-space windows of the group (merged: the single set)
   const int sw0 = merged ? 0 : w0, sWg = merged ? W : Wg;      // scalar windows the group's first pass covers
-  const uint32_t T = Q.T;
+  // hot buckets are cut 2^shift times finer (bucket_task_len; the shift travels in the top bits of the task length): 2 by default, 0 for
+  // a merged sort.  KG_HOT_SHIFT: experiments.  Measured with shift 2 (MI355X): witness-like 2^20 MSM 1.17 -> 0.67 ms per step, proof from a
+  // 0/1-heavy witness 2.48 -> 2.16 ms; with window tables (merged) 1.87 -> 2.03, hence 0 there.
+  static const int hot_shift_env = getenv("KG_HOT_SHIFT") ? atoi(getenv("KG_HOT_SHIFT")) : -1;
+  const uint32_t hot_shift = hot_shift_env >= 0 && hot_shift_env <= 2 ? (uint32_t)hot_shift_env : (Q.merged ? 0u : 2u);
+  const uint32_t T = Q.T | (hot_shift << 30);
   char* ws = Q.ws;
   hipStream_t st = on_main ? ctx->stream : ctx->sort_stream;
   const size_t npts = (size_t)Wg * B;
@@ -2342,7 +2395,7 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
   S->lcnt = (uint32_t*)(ws + Q.o_lcnt) + (size_t)w0 * B; S->lrel = (uint32_t*)(ws + Q.o_lrel) + (size_t)w0 * B; S->lbase = (uint32_t*)(ws + Q.o_lbase[g]);
   S->task_bkt = (uint32_t*)(ws + Q.o_tbkt[g]); S->task_id = (uint32_t*)(ws + Q.o_tid[g]);
   S->hot_list = (uint32_t*)(ws + Q.o_hot[g]);
-  S->T_top = Q.T_top;
+  S->T_top = Q.T_top | (hot_shift << 30);
   S->top_w = (!merged && w0 + Wg == W) ? Wg - 1 : -1;       // the unsigned top window, if this group holds it
   const uint32_t T_top = S->T_top;
   const int top_w = S->top_w;
@@ -2524,7 +2577,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       Y.o_part[i] = cv.take(part_cap * NW * 4); Y.o_pbuf[i] = cv.take(npts * NW * 4);
     }
     Y.o_rowtot = cv.take((size_t)W * 4); Y.o_misc = cv.take(64);
-    Y.o_hot = cv.take(S.nhot ? (size_t)(S.nhot < HOT_MAX ? S.nhot : HOT_MAX) * HOT_SPLIT * NW * 4 : 0);      // k_hot_sum's shares
+    Y.o_hot = cv.take(S.nhot ? (size_t)(S.nhot < HOT_MAX ? S.nhot : HOT_MAX) * hot_split<KF>(S.max_cnt) * NW * 4 : 0);      // k_hot_sum's shares
     Y.set = J.slot % kg_ctx::RUN_SETS;              // run space per set: the reductions of the previous MSMs may still read the other sets
     for (int k2 = 0; k2 < k; ++k2)
       if (lay[k2].set == Y.set) return set_err(ctx, KG_ERR_BAD_ARG, "fused MSMs need result slots in different run-space sets");
@@ -2609,8 +2662,9 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
         // the few buckets with more partial sums than the gather takes: one workgroup-wide tree each
         PhaseScope ph2(ctx, "hot_sum", side);
         uint32_t* hot_scratch = (uint32_t*)(ws + Y.o_hot);
-        hipLaunchKernelGGL(k_hot_sum<KF>, dim3(S.nhot, HOT_SPLIT), dim3(256), 36 * 256 * 4, side, part[pcur], L, B, S.hot_list, hot_scratch);
-        hipLaunchKernelGGL(k_hot_fold<KF>, dim3(S.nhot), dim3(64), 0, side, part[pcur], L, B, S.hot_list, hot_scratch);
+        const uint32_t split = hot_split<KF>(S.max_cnt);
+        hipLaunchKernelGGL(k_hot_sum<KF>, dim3(S.nhot, split), dim3(256), 36 * 256 * 4, side, part[pcur], L, B, S.hot_list, hot_scratch, split);
+        hipLaunchKernelGGL(k_hot_fold<KF>, dim3(S.nhot), dim3(256), 36 * 256 * 4, side, part[pcur], L, B, S.hot_list, hot_scratch, split);
         ph2.end();
         max_cnt = GATHER_SUM_MAX;
       }

@@ -697,7 +697,8 @@ for n, skew in (((1 << 17) + 4099, False), ((1 << 16) + 1, True)):
 print("ok")
 """ % root
     for knobs in ({"KG_GS_TILE": "0"}, {"KG_GS_TILE": "8192", "KG_GS_NT": "512", "KG_GS_NT0": "256"}, {"KG_GS_TILE": "4096", "KG_GS_NT": "1024"},
-                  {"KG_SORT_ALONE": "0"}, {"KG_ACC_PREFETCH": "1"}):      # the last: k_acc_tasks_q (bases through LDS, gathers shared by lane quads)
+                  {"KG_SORT_ALONE": "0"}, {"KG_ACC_PREFETCH": "1"},        # k_acc_tasks_q (bases through LDS, gathers shared by lane quads)
+                  {"KG_HOT_SHIFT": "0"}, {"KG_HOT_SHIFT": "1"}):          # hot buckets cut no finer / twice finer than the others (default: four times)
         r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **knobs), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (knobs, r.stderr[-2000:])
 

@@ -24,6 +24,17 @@ for curve, fld, name in ((K.KG_G1, K.KG_FR, "g1"), (K.KG_GRUMPKIN, K.KG_FQ, "gru
         xy, inf = ctx.points_sum_affine(curve, np.stack([a[:8], b[:8]]), np.array([not a[8:].any(), not b[8:].any()], dtype=np.uint8))
         ok = (xy == full[:8]).all() and (full == full2).all()
         print(f"{name} msm 2^{lg}: gen {tg:.2f}s first {t1*1e3:.1f} ms second {t2*1e3:.1f} ms -> {n/t2/1e6:.1f} Mpairs/s split-sum ok={ok}", flush=True)
+        if lg == 24 and curve == K.KG_G1:                # the same with witness-like scalars (half ones, a fifth zeros): hot buckets under the wide windows
+            from kogarashi_amd import synthetic as syn
+            hs = scal.cpu().numpy().view(np.uint64).reshape(n, 4)
+            syn.witness_like(hs, 11)
+            scal.copy_(torch.from_numpy(hs.view(np.int64).reshape(-1)))
+            full = ctx.msm(curve, bases.data_ptr(), 0, scal.data_ptr(), n)
+            a = ctx.msm(curve, bases.data_ptr(), 0, scal.data_ptr(), h)
+            b = ctx.msm(curve, bases.data_ptr() + h * 64, 0, scal.data_ptr() + h * 32, n - h)
+            xy, inf = ctx.points_sum_affine(curve, np.stack([a[:8], b[:8]]), np.array([not a[8:].any(), not b[8:].any()], dtype=np.uint8))
+            t = time.time(); full2 = ctx.msm(curve, bases.data_ptr(), 0, scal.data_ptr(), n); t2 = time.time() - t
+            print(f"{name} msm 2^{lg}, witness-like scalars: {t2*1e3:.1f} ms split-sum ok={(xy == full[:8]).all() and (full == full2).all()}", flush=True)
         del bases, scal
 for lg in (24, 26):
     n = 1 << lg
