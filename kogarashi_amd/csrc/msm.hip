@@ -2429,7 +2429,10 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
     // 2^24-pair commitment 20.32 -> 19.00 ms, blocking 2^20 1.746 -> 1.685 ms, the four-deep 2^20 step 1.32 -> 1.295 ms; 512 threads
     // beside the accumulation shorten the sorts (12.9 -> 9.8 ms summed at 2^24) and lengthen the accumulations by as much.
     static const int gs_tile_env = getenv("KG_GS_TILE") ? atoi(getenv("KG_GS_TILE")) : -1;     // experiments: 0 = the 1024-entry tiles of k_group_scatter
-    static const int gs_nt_env = getenv("KG_GS_NT") ? atoi(getenv("KG_GS_NT")) : 256;
+    static const int gs_nt_set = getenv("KG_GS_NT") ? atoi(getenv("KG_GS_NT")) : 0;
+    // wide windows: 512 -- level on uniform scalars (2^24: 19.05 / 19.0 ms), and a witness-like 2^24-pair vector, whose accumulations are
+    // short and whose sorts therefore run mostly alone, 10.65 -> 8.9 ms; below, 512 costs the four-deep 2^20 step 1 %
+    const int gs_nt_env = gs_nt_set ? gs_nt_set : (fb == 9 ? 512 : 256);
     static const int gs_nt0_env = getenv("KG_GS_NT0") ? atoi(getenv("KG_GS_NT0")) : 1024;
     const int gs_tile = gs_tile_env >= 0 ? gs_tile_env : (fb == 9 ? 8192 : 4096);
     const int gs_nt = (Q.alone && g == 0) ? gs_nt0_env : gs_nt_env;
