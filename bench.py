@@ -342,7 +342,7 @@ def main():
     if not args.no_ntt:
         line["ntt"] = bench_ntt(ctx, torch, dev, K, env)
     if not args.no_nova:
-        line["nova_commit"] = bench_nova_commit(ctx, torch, dev, K, env, args.nova_log_n, cpu=cpu)
+        line["nova_commit"] = bench_nova_commit(ctx, torch, dev, K, env, args.nova_log_n, cpu=cpu, skew=not args.no_skew)
     if not args.no_groth16:
         line["groth16"] = bench_groth16(ctx, torch, dev, K, env, args.groth16_log_m, cpu=cpu)
         if not args.no_skew:
@@ -418,7 +418,7 @@ def bench_ntt(ctx, torch, dev, K, env, log_n=22, steps=10, warmup=100):
     return out
 
 
-def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5):
+def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, skew=False):
     """BASELINE.json configs[4]: Nova's Pedersen commitment (nova/src/pedersen.rs:15-20) over 2^24 generators, on both
     curves of the cycle (bn254 G1 with Fr scalars, Grumpkin with Fq scalars; nova/src/driver.rs:9-42).  ONE commitment of
     2^log_n pairs is cut over the N ranks by kg_shard_range; every rank commits its slice (kg_commit) and the N affine
@@ -460,6 +460,26 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5):
                "point": {"xy_hex": "".join(f"{int(v_):016x}" for v_ in got[0]), "is_identity": bool(got[1])},     # the commitment itself: equal for every N
                "roofline": {"bound": "hbm", "achieved": 96 * total / dt / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                             "frac": 96 * total / dt / 1e9 / (HBM_PEAK_GBS * world)}}
+        if skew and name == "g1_fr" and world == 1:
+            # the same commitment of a witness-like vector (half ones, a fifth zeros: what a folded R1CS witness looks like,
+            # nova/src/relaxed_r1cs/witness.rs:56-70) -- sort-bound instead of accumulation-bound; checked by committing the halves
+            from kogarashi_amd import synthetic as syn
+            hw = m.cpu().numpy().view(np.uint64).reshape(nl, 4)
+            syn.witness_like(hw, 23)
+            mw = torch.from_numpy(hw.view(np.int64).reshape(-1)).to(dev)
+            del hw
+            ctx.commit(curve, g.data_ptr(), 0, mw.data_ptr(), nl)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                wxy, winf = ctx.commit(curve, g.data_ptr(), 0, mw.data_ptr(), nl)
+            wdt = (time.perf_counter() - t0) / 3
+            h = nl // 2
+            a = ctx.commit(curve, g.data_ptr(), 0, mw.data_ptr(), h)
+            b = ctx.commit(curve, g.data_ptr() + h * 64, 0, mw.data_ptr() + h * 32, nl - h)
+            sxy, sinf = ctx.points_sum_affine(curve, np.stack([a[0], b[0]]), np.array([a[1], b[1]], dtype=np.uint8))
+            leg["witness_like"] = {"ms_per_commit": wdt * 1e3, "ratio_to_uniform": wdt / dt,
+                                   "halves_add_up": bool(bool(sinf) == bool(winf) and (bool(winf) or (np.asarray(sxy) == np.asarray(wxy)).all()))}
+            del mw
         if cpu:
             from oracle import oracle as O
             hg = g.cpu().numpy().view(np.uint64).reshape(nl, 8)
