@@ -110,6 +110,28 @@ def test_commit_2_24_matches_the_oracles_pippenger(ctx, oracle, curve, sfd, cv):
     assert reg_inf == 0 and (reg_xy == want_xy).all()
 
 
+def test_commit_2_24_of_a_witness_like_vector_matches_the_oracles_pippenger(ctx, oracle):
+    """The same commitment of a vector distributed like a folded R1CS witness (half ones, a fifth zeros, a tenth -1: nova/src/relaxed_r1cs/
+    witness.rs:56-70 meets bit decompositions): the wide windows (c = 20, nine-bit fine field) with hot buckets -- 8 M entries in one bucket, its
+    tasks written by the whole workgroup (k_len_scatter), cut finer (bucket_task_len) and folded by up to 256 shares (k_hot_sum / k_hot_fold)."""
+    import kogarashi_amd as K
+    from kogarashi_amd import synthetic as syn
+    n = 1 << 24
+    g, m = ctx.empty((n, 8)), ctx.empty((n, 4))
+    ctx.gen_bases(K.KG_G1, SEED + 40, 0, n, g.ptr)
+    ctx.gen_scalars(K.KG_FR, SEED + 43, 0, n, m.ptr)
+    hm = m.numpy()
+    syn.witness_like(hm, 29)
+    m = ctx.upload(hm)
+    want_xy, want_inf = oracle.to_affine("g1", oracle.msm("g1", g.numpy(), hm, None, threads=14))
+    got_xy, got_inf = ctx.commit(K.KG_G1, g.ptr, 0, m.ptr, n)
+    assert got_inf == want_inf == 0 and (got_xy == want_xy).all()
+    ctx.bases_register(K.KG_G1, g.ptr, 0, n)
+    reg_xy, reg_inf = ctx.commit(K.KG_G1, g.ptr, 0, m.ptr, n)
+    ctx.bases_unregister(g.ptr)
+    assert reg_inf == 0 and (reg_xy == want_xy).all()
+
+
 def test_ntt_2_22_all_variants_match_oracle(ctx, oracle):
     """BASELINE.json configs[2] against the oracle's restatement of Fft<Fr> (fft.rs:92-127), all four transforms."""
     import kogarashi_amd as K
