@@ -524,6 +524,10 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   if (rc == KG_OK && hn && do_h) {
     if (!h_sorted) h_sort(true);
     else { const int rw = msm_sort_wait(ctx, &Sq); if (rc == KG_OK) rc = rw; }
+    // a blocking proof: h's reduction follows its accumulation on the main queue (nothing else is coming there) -- the two reduction
+    // queues may still hold the witness MSMs' reductions (a 0/1-heavy witness: hot-bucket trees; h's reduction waited 0.7 ms for a queue)
+    static const bool h_inline = !(getenv("KG_G16_H_INLINE") && atoi(getenv("KG_G16_H_INLINE")) == 0);
+    if (alone_front && h_inline) Sq.reduce_inline = true;
     if (rc == KG_OK) rc = msm_run(ctx, Sq, KG_G1, crs->d_h, crs->d_h_inf, hn, 0, SL[4]);
     if (rc == KG_OK) f_q = finish_async(KG_G1, SL[4], q_p);
   } else msm_identity(KG_G1, q_p);
