@@ -449,7 +449,7 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, ske
             if world > 1:
                 xy, inf = kdist.combine_partials(ctx, curve, xy, inf, device=xdev)
             return xy, inf
-        one()
+        one(); one()          # twice: consecutive calls alternate between the library's two sort spaces, and each is sized on first use
         env["barrier"]()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -468,7 +468,8 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, ske
             syn.witness_like(hw, 23)
             mw = torch.from_numpy(hw.view(np.int64).reshape(-1)).to(dev)
             del hw
-            ctx.commit(curve, g.data_ptr(), 0, mw.data_ptr(), nl)
+            for _ in range(2):
+                ctx.commit(curve, g.data_ptr(), 0, mw.data_ptr(), nl)
             t0 = time.perf_counter()
             for _ in range(3):
                 wxy, winf = ctx.commit(curve, g.data_ptr(), 0, mw.data_ptr(), nl)
