@@ -741,14 +741,15 @@ static hipError_t launch_gs_big_any(int tile, int nt, dim3 grid, hipStream_t st,
 // One workgroup per window, one lane per bucket group: exclusive prefix of the group's counters over the chunks (in
 // place), group sizes and starts, the segment table, and the window's bucket sizes zeroed for k_fine_local.
 // (workgroup 0 also clears the `zwords` words at `zero`: the task decomposition's counters and length histogram)
-__global__ void __launch_bounds__(GS_NT) k_group_scan(uint32_t* __restrict__ cnt, int nch, int G, int B, uint32_t* __restrict__ gsize,
+__global__ void __launch_bounds__(1024) k_group_scan(uint32_t* __restrict__ cnt, int nch, int G, int B, uint32_t* __restrict__ gsize,
                                                        uint32_t* __restrict__ gstart, uint32_t* __restrict__ segbase, uint32_t* __restrict__ bsize,
                                                        uint32_t* __restrict__ zero, int zwords, uint32_t seg) {
   KG_SERVICE_PRIO();
   __shared__ uint32_t sh[40];
   const int w = blockIdx.x, tid = threadIdx.x;
-  if (w == 0) for (int t = tid; t < zwords; t += GS_NT) zero[t] = 0;
-  const int per = (G + GS_NT - 1) / GS_NT;            // consecutive groups per lane (<= 4)
+  const int NT = (int)blockDim.x;                     // 256, or 512 from 512 groups on (wide windows: 1024 groups and 2 MiB of bucket sizes to clear per window; 512 threads of 48 VGPRs still fit beside an accumulation)
+  if (w == 0) for (int t = tid; t < zwords; t += NT) zero[t] = 0;
+  const int per = (G + NT - 1) / NT;                  // consecutive groups per lane (<= 4)
   uint32_t run[4], ns[4], rsum = 0, nsum = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -2437,7 +2438,7 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
     const int gs_tile = gs_tile_env >= 0 ? gs_tile_env : (fb == 9 ? 8192 : 4096);
     const int gs_nt = (Q.alone && g == 0) ? gs_nt0_env : gs_nt_env;
     if (two_pass) {
-      hipLaunchKernelGGL(k_group_scan, dim3(sWg), dim3(GS_NT), 0, st, cnt + (size_t)sw0 * nch * G, nch, G, B, gsize + (size_t)sw0 * G, gstart + (size_t)sw0 * G,
+      hipLaunchKernelGGL(k_group_scan, dim3(sWg), dim3(G > 256 ? 512 : GS_NT), 0, st, cnt + (size_t)sw0 * nch * G, nch, G, B, gsize + (size_t)sw0 * G, gstart + (size_t)sw0 * G,
                          segbase + (size_t)sw0 * (G + 1), (uint32_t*)(ws + Q.o_bsize) + (size_t)sw0 * B, misc, (int)(zbytes / 4), seg_len_for(fb));
       if (merged)
         hipLaunchKernelGGL(k_merge_groups, dim3(1), dim3(GS_NT), 0, st, gsize, W, G, woff, (uint32_t*)(ws + Q.o_gsize_m), (uint32_t*)(ws + Q.o_gstart_m),
