@@ -15,7 +15,8 @@ names = {0: "g1", 1: "gk", 2: "g2"}
 bad = 0
 for it in range(rounds):
     curve = int(rng.choice([0, 0, 0, 1, 2]))
-    lg = int(rng.integers(12, 19 if curve != 2 else 17))
+    lo_lg, hi_lg = [int(v) for v in os.environ.get("KG_STRESS_LG", "12,19").split(",")]       # sizes 2^lo .. 2^hi - 1 (G2: two fewer)
+    lg = int(rng.integers(lo_lg, hi_lg if curve != 2 else max(lo_lg + 1, hi_lg - 2)))
     n = (1 << lg) + int(rng.integers(-50, 50))
     fld = 1 if curve == 1 else 0
     bases = O.gen_bases(curve, 1000 + it, 0, n) if curve != 2 else None
