@@ -703,6 +703,17 @@ print("ok")
         assert r.returncode == 0 and "ok" in r.stdout, (knobs, r.stderr[-2000:])
 
 
+def test_skewed_scalar_vectors_over_the_three_curves():
+    """tools/dbg/stress_skew.py as a test: sixteen seeded configurations -- all scalars equal, one dominant value, a handful of values,
+    witness-like, half zeros -- at ragged sizes 2^12..2^18 over G1 / Grumpkin / G2, blocking and pipelined, against the oracle.  The hot-bucket
+    machinery (tasks written by the workgroup, the finer cut, the shares that follow the fullest bucket) meets every one of them."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg", "stress_skew.py"), "16"], env=dict(os.environ, KG_STRESS_SEED="21"),
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "failures: 0" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
 def test_service_queues_are_placed_off_the_main_queues_pipe(ctx):
     """capi.cpp place_queues: the probe finds exactly the candidates j and j + 4 on the main queue's compute pipe (1 <= result <= 4),
     whatever streams the process created before (here: none but the runtime's own)"""
