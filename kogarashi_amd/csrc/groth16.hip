@@ -673,6 +673,12 @@ int kg_groth16_prove_sharded(kg_ctx* const* ctxs, int n_ctx, const kg_groth16_cr
     if (job_of(ctxs[i], 0)->active) return set_err(ctxs[i], KG_ERR_BAD_ARG, "a proof is in flight on this context");
     if ((roles[i] & ROLE_H) && (!d_a_eval || !d_b_eval || !d_c_eval || !d_a_eval[i] || !d_b_eval[i] || !d_c_eval[i])) return KG_ERR_BAD_ARG;
   }
+  // one context per device (the multi-GPU case): each has its device to itself for this blocking call -- its first sort is shaped for an
+  // idle device and h's reduction follows h's accumulation, as in kg_groth16_prove_bn254; contexts that share a device do not
+  bool own_device = true;
+  for (int i = 0; i < n_ctx; ++i)
+    for (int j = 0; j < i; ++j)
+      if (roles[i] && roles[j] && ctxs[i]->device == ctxs[j]->device) own_device = false;
   std::vector<std::future<int>> enq;
   std::vector<int> who;
   for (int i = 0; i < n_ctx; ++i) {
@@ -680,7 +686,7 @@ int kg_groth16_prove_sharded(kg_ctx* const* ctxs, int n_ctx, const kg_groth16_cr
     who.push_back(i);
     enq.push_back(std::async(std::launch::async, [=]() -> int {
       return prove_enqueue(ctxs[i], crs[i], d_a_eval ? d_a_eval[i] : nullptr, d_b_eval ? d_b_eval[i] : nullptr, d_c_eval ? d_c_eval[i] : nullptr,
-                           d_x[i], d_w[i], r, s, job_of(ctxs[i], 0), 5, nullptr, roles[i], true);
+                           d_x[i], d_w[i], r, s, job_of(ctxs[i], 0), 5, nullptr, roles[i], true, false, own_device);
     }));
   }
   int rc = KG_OK;
