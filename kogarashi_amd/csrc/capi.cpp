@@ -38,7 +38,7 @@ int ensure_ws_sort(kg_ctx* c, int set, size_t bytes) {
 // KG_STREAM_PAD=n0,n1,...: experiment -- n_i never-used streams are created in front of the context's i-th queue (creation
 // order: main, scalar, reduction 1, reduction 2, ...), which shifts the queues over the hardware queues / pipes
 static int stream_pad(int idx) {
-  const char* e = getenv("KG_STREAM_PAD");
+  const char* e = tuning().stream_pad.empty() ? nullptr : tuning().stream_pad.c_str();
   if (!e) return 0;
   for (int i = 0; i < idx && e; ++i) { e = strchr(e, ','); if (e) ++e; }
   return e ? atoi(e) : 0;
@@ -82,7 +82,7 @@ static int place_queues(kg_ctx* c) {
   if (e != hipSuccess) return set_err(c, KG_ERR_HIP, "queue creation", e);
   int cls[NC];
   for (int j = 0; j < NC; ++j) cls[j] = -1;
-  static const bool enabled = !(getenv("KG_QUEUE_PLACEMENT") && atoi(getenv("KG_QUEUE_PLACEMENT")) == 0);
+  const bool enabled = c->tune.queue_placement != 0;
   bool ok = enabled;
   if (ok) {
     hipEvent_t ev_s = nullptr, ev_a = nullptr, ev_b[NC] = {};
@@ -292,6 +292,7 @@ int kg_ctx_create(int device, kg_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return KG_ERR_NO_DEVICE;
   kg_ctx* c = new kg_ctx();
   c->device = device;
+  c->tune = tuning();
   if (create_stream(c, &c->own_stream, false) != hipSuccess) { delete c; return KG_ERR_HIP; }
   c->stream = c->own_stream;
   *out = c;
@@ -437,7 +438,7 @@ int kg_profile_summary(kg_ctx* c, const char** names, float* total_ms, int* coun
   if (!c) return KG_ERR_BAD_ARG;
   hipSetDevice(c->device);
   sync_all(c);
-  if (getenv("KG_PROFILE_TIMELINE") && !c->phases.empty()) {     // debugging aid: phase start / end relative to the first phase
+  if (c->tune.profile_timeline && !c->phases.empty()) {     // debugging aid: phase start / end relative to the first phase
     for (auto& p : c->phases) {
       float a = 0, b = 0;
       if (hipEventElapsedTime(&a, c->phases[0].e0, p.e0) == hipSuccess && hipEventElapsedTime(&b, c->phases[0].e0, p.e1) == hipSuccess)

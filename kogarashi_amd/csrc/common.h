@@ -10,6 +10,7 @@
 #include <vector>
 #include "../../include/kogarashi_amd.h"
 #include "curve.h"
+#include "tuning.h"
 
 struct kg_tw_cache;   // ntt.hip
 
@@ -18,6 +19,7 @@ struct kg_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;          // stream every launch goes to
   std::string last_error;
+  kg_tuning tune;                        // the knob table (tuning.h): the process-wide values at creation
   int msm_window = 0;                    // 0 = auto
   bool sort_alone = false;               // hint for the next msm_sort / msm_sort_begin: nothing else is on the device (a blocking call's first sort) -- set and cleared by the caller
   int msm_groups = 0;                    // window groups of a blocking MSM: 0 = auto, 1 = none, 2..MAX_GROUPS (kg_msm_set_groups)

@@ -334,16 +334,13 @@ ProofJob* job_of(kg_ctx* ctx, int i) {
 // start the assembly -- the sharded entry assembles from several jobs.
 enum { ROLE_G2 = 1, ROLE_G1W = 2, ROLE_H = 4, ROLE_ALL = 7 };
 static bool g16_h_early() {                               // KG_G16_H_EARLY=0: the blocking proof in the order of the pipelined ones (experiments)
-  static const bool on = !(getenv("KG_G16_H_EARLY") && atoi(getenv("KG_G16_H_EARLY")) == 0);
-  return on;
+  return tuning().g16_h_early != 0;
 }
 static bool g16_h_first() {                               // KG_G16_H_EARLY=2: h's point-wise step and coset_idft in front of the G2 accumulation (experiments)
-  static const bool on = getenv("KG_G16_H_EARLY") && atoi(getenv("KG_G16_H_EARLY")) == 2;
-  return on;
+  return tuning().g16_h_early == 2;
 }
 static bool g16_h_early_pipelined() {                     // KG_G16_H_EARLY_PIPE=0: proofs in flight keep h's chain last (the order up to round 3)
-  static const bool on = !(getenv("KG_G16_H_EARLY_PIPE") && atoi(getenv("KG_G16_H_EARLY_PIPE")) == 0);
-  return on;
+  return tuning().g16_h_early_pipe != 0;
 }
 int assemble_proof(const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t* ss, int rc0, ProofJob* j_g2, ProofJob* j_g1w, ProofJob* j_h,
                    uint64_t* proof, uint8_t* inf);
@@ -526,7 +523,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
     else { const int rw = msm_sort_wait(ctx, &Sq); if (rc == KG_OK) rc = rw; }
     // a blocking proof: h's reduction follows its accumulation on the main queue (nothing else is coming there) -- the two reduction
     // queues may still hold the witness MSMs' reductions (a 0/1-heavy witness: hot-bucket trees; h's reduction waited 0.7 ms for a queue)
-    static const bool h_inline = !(getenv("KG_G16_H_INLINE") && atoi(getenv("KG_G16_H_INLINE")) == 0);
+    const bool h_inline = ctx->tune.g16_h_inline != 0;
     if (alone_front && h_inline) Sq.reduce_inline = true;
     if (rc == KG_OK) rc = msm_run(ctx, Sq, KG_G1, crs->d_h, crs->d_h_inf, hn, 0, SL[4]);
     if (rc == KG_OK) f_q = finish_async(KG_G1, SL[4], q_p);

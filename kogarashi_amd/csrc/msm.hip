@@ -20,6 +20,7 @@
 #include "common.h"
 #include "host_fp.h"
 #include "fp2s.h"
+#include "msm_internal.h"
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -321,6 +322,22 @@ __global__ void __launch_bounds__(64) k_table_next(const uint32_t* __restrict__ 
   if (inf) buf[8] |= INF_BIT;
   store_resident<F>(next, i, buf, fmt64);
 }
+
+}  // namespace
+namespace kg {
+void prep_bases_enqueue(int curve, hipStream_t st, const uint64_t* d_bases, const uint8_t* d_inf, size_t n, uint32_t* out, bool fmt64) {
+  if (curve == KG_G1) launch_prep_bases<Fq>(st, d_bases, d_inf, n, out, fmt64);
+  else if (curve == KG_GRUMPKIN) launch_prep_bases<Fr>(st, d_bases, d_inf, n, out, fmt64);
+  else launch_prep_bases<Fq2>(st, d_bases, d_inf, n, out, fmt64);
+}
+void table_next_enqueue(int curve, hipStream_t st, const uint32_t* prev, size_t n, int c, uint32_t* next, bool fmt64) {
+  const dim3 grid((unsigned)((n + 63) / 64));
+  if (curve == KG_G1) hipLaunchKernelGGL(k_table_next<Fq>, grid, dim3(64), 0, st, prev, n, c, next, fmt64 ? 1 : 0);
+  else if (curve == KG_GRUMPKIN) hipLaunchKernelGGL(k_table_next<Fr>, grid, dim3(64), 0, st, prev, n, c, next, fmt64 ? 1 : 0);
+  else hipLaunchKernelGGL(k_table_next<Fq2>, grid, dim3(64), 0, st, prev, n, c, next, fmt64 ? 1 : 0);
+}
+}  // namespace kg
+namespace {
 
 // ---------------------------------------------------------------------------------------------------
 // signed window digit of the biased scalar: returns bucket id + 1 (0 = skip) and the sign
@@ -1631,8 +1648,7 @@ template <class P> struct PfField<Fp<P>> { using T = Fp<P>; static constexpr boo
 template <class F>
 static int acc_prefetch(const AccSets& A, int njobs, size_t nbases) {
   if (!PfField<F>::ok) return 0;
-  static const int mode = getenv("KG_ACC_PREFETCH") ? atoi(getenv("KG_ACC_PREFETCH")) : 0;
-  static const int from_log = getenv("KG_ACC_PREFETCH_LOG") ? atoi(getenv("KG_ACC_PREFETCH_LOG")) : 0;
+  const int mode = tuning().acc_prefetch, from_log = tuning().acc_prefetch_log;
   if (mode == 0 || nbases < ((size_t)1 << from_log)) return 0;
   for (int k = 0; k < njobs; ++k)
     if (!A.fmt64[k]) return 0;
@@ -2077,14 +2093,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveW
 // host side
 // ---------------------------------------------------------------------------------------------------
 // debugging aid (KG_TRACE_HOST=1): host-side timestamps of the pipeline's calls
-static void host_trace(const char* what) {
-  static const bool on = getenv("KG_TRACE_HOST") != nullptr;
-  if (!on) return;
+}  // namespace
+namespace kg {
+void host_trace(const char* what) {
+  if (!tuning().trace_host) return;
   static const auto t0 = std::chrono::steady_clock::now();
   fprintf(stderr, "[host] %-18s %10.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
 }
 
 int pick_window(size_t n, int forced) {
+  const int wide_from = tuning().wide_window;
   if (forced) return forced;
   int lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) ++lg;      // floor(log2 n)
@@ -2100,7 +2118,6 @@ int pick_window(size_t n, int forced) {
   // 2-4x slower beside an accumulation than alone (latency-bound kernels at one or two waves per SIMD) and bounds the pipeline -- before
   // the sort kernels were slimmed to two workgroups per CU beside an accumulation the wide window lost (21.3 against 21.1).
   // KG_WIDE_WINDOW=0 keeps the slices, =23 widens from 2^23.
-  static const int wide_from = [] { const char* e = getenv("KG_WIDE_WINDOW"); return e ? atoi(e) : 24; }();
   if (wide_from > 0 && lg >= wide_from && n <= ((size_t)1 << 24)) return 20;
   if (lg >= 21 && n <= ((size_t)1 << 24)) return 17;
   if (lg >= 19) return 16;
@@ -2111,52 +2128,15 @@ int pick_window(size_t n, int forced) {
   return c;
 }
 
-template <class HF> struct HostIO;
-template <class P> struct HostIO<HostFp<P>> {
-  static HostFp<P> load(const uint64_t* w) { return HostFp<P>::from_words(w); }
-  static void store(const HostFp<P>& a, uint64_t* w) { a.to_words(w); }
-};
-template <class F> struct HostIO<Fp2<F>> {
-  static Fp2<F> load(const uint64_t* w) { return {HostIO<F>::load(w), HostIO<F>::load(w + 4)}; }
-  static void store(const Fp2<F>& a, uint64_t* w) { HostIO<F>::store(a.c0, w); HostIO<F>::store(a.c1, w + 4); }
-};
-
-template <class Cfg>
-XYZZ<typename Cfg::HF> host_load_point(const uint64_t* p) {
-  using HF = typename Cfg::HF;
-  constexpr int E = Cfg::E64;
-  return {HostIO<HF>::load(p), HostIO<HF>::load(p + E), HostIO<HF>::load(p + 2 * E), HostIO<HF>::load(p + 3 * E)};
-}
-
-template <class Cfg>
-void store_projective(const XYZZ<typename Cfg::HF>& p, uint64_t* out_xyz) {
-  using HF = typename Cfg::HF;
-  constexpr int E = Cfg::E64;
-  Affine<HF> a;
-  if (!to_affine(p, a)) {                        // (0, 1, 0): macros/curve/weierstrass/group.rs:106-110
-    HostIO<HF>::store(HF::zero(), out_xyz);
-    HostIO<HF>::store(HF::one(), out_xyz + E);
-    HostIO<HF>::store(HF::zero(), out_xyz + 2 * E);
-    return;
-  }
-  HostIO<HF>::store(a.x, out_xyz);
-  HostIO<HF>::store(a.y, out_xyz + E);
-  HostIO<HF>::store(HF::one(), out_xyz + 2 * E);
-}
-
 // Which resident form an array of n bases gets.  The 64-byte point is the default at every size: its ~50 re-spreading
 // instructions per addition cost 1-2 % of the accumulation when it runs alone, but in the pipeline -- where the next sort and
 // the previous reductions compete for the memory system -- halving the sectors per gather wins (2^20: 1.452 -> 1.421 ms per
 // step; 2^22 blocking 6.40 -> 6.19 ms; the PMC traffic of a launch halves).  KG_FMT64_MIN_LOG=30 brings the 72-byte form back
 // (experiments, and the cross-format test).
-static bool resident_fmt64(size_t n) {
-  static const int min_log = getenv("KG_FMT64_MIN_LOG") ? atoi(getenv("KG_FMT64_MIN_LOG")) : 0;
-  return n >= ((size_t)1 << min_log);
-}
-static bool table_fmt64() {
-  static const int on = getenv("KG_TABLE64") ? atoi(getenv("KG_TABLE64")) : 1;      // tables never fit the cache: 2^20 1.36 -> 1.30 ms per step, Groth16 2.94 -> 2.87
-  return on != 0;
-}
+bool resident_fmt64(size_t n) { return n >= ((size_t)1 << tuning().fmt64_min_log); }
+bool table_fmt64() { return tuning().table64 != 0; }      // tables never fit the cache: 2^20 1.36 -> 1.30 ms per step, Groth16 2.94 -> 2.87
+}  // namespace kg
+namespace {
 
 struct Carver {
   size_t off = 0;
@@ -2194,11 +2174,11 @@ int msm_group_plan(const kg_ctx* ctx, size_t n, int* gw) {
   int NG = n >= ((size_t)1 << 22) ? 3 : (n >= ((size_t)1 << 17) ? 2 : 0);       // 2^22 (round 4, slimmed sort kernels): 5.97 / 5.79 / 5.83 ms in 2 / 3 / 4 groups
   if (c >= 19) NG = 4;                                 // the unsliced 2^23..2^24-pair commitments: the sort of 13-14 windows is 4 ms, hidden group by group
   if (ctx && ctx->msm_groups) NG = ctx->msm_groups;   // kg_msm_set_groups
-  static const char* env = getenv("KG_MSM_GROUPS");
-  if (env) {
-    if (strchr(env, ',')) {
+  const kg_tuning& tn = ctx ? ctx->tune : tuning();
+  if (!tn.msm_groups_list.empty() || tn.msm_groups >= 0) {
+    if (!tn.msm_groups_list.empty()) {
       int k = 0, sum = 0;
-      const char* p = env;
+      const char* p = tn.msm_groups_list.c_str();
       while (*p && k < kg_ctx::MAX_GROUPS) {
         const int v = atoi(p);
         if (v < 1) return 0;
@@ -2207,7 +2187,7 @@ int msm_group_plan(const kg_ctx* ctx, size_t n, int* gw) {
         if (*p == ',') ++p;
       }
       if (sum == W && !*p) return k;                 // a list that does not fit this window count falls through to the default
-    } else NG = atoi(env);
+    } else NG = tn.msm_groups;
   }
   if (NG > kg_ctx::MAX_GROUPS) NG = kg_ctx::MAX_GROUPS;
   if (NG > W) NG = W;
@@ -2237,7 +2217,7 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
   const int Wb = merged ? 1 : W;                    // windows of the BUCKET space: the merged form keeps one set for all digits
   const size_t nv = merged ? (size_t)W * n : n;     // entries that can meet one bucket window
   int nch = (int)((n + 16383) / 16384);
-  static const int nch_cap = [] { const char* e = getenv("KG_SORT_NCH"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 1024 ? v : 64; }();
+  const int nch_cap = ctx->tune.sort_nch >= 1 && ctx->tune.sort_nch <= 1024 ? ctx->tune.sort_nch : 64;
   if (nch > nch_cap) nch = nch_cap;               // (window, chunk) workgroups of the first sort pass: 1024 of them at 2^20
   if (nch < 1) nch = 1;
   size_t chunk_len = (n + nch - 1) / nch;
@@ -2248,7 +2228,7 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
   // average, Poisson: 2 n / B + 16 is 8 sigma out at n / B = 16 and 8.5 at 32); the unsigned top window holds twice the load per
   // bucket and gets twice the length (T_top).  Hot buckets pay for the shorter tasks with more partial sums: k_hot_sum.
   uint32_t T = (uint32_t)(2 * (n / B) + 16);
-  if (const char* e = getenv("KG_MSM_T")) { const int v = atoi(e); if (v >= 4 && v <= 4096) T = (uint32_t)v; }      // experiments
+  if (ctx->tune.msm_t >= 4 && ctx->tune.msm_t <= 4096) T = (uint32_t)ctx->tune.msm_t;      // experiments
   if (T < 32) T = 32;
   if (T > 2048) T = 2048;
   if (merged) {
@@ -2258,12 +2238,12 @@ int msm_sort_begin(kg_ctx* ctx, int scalar_field, const uint64_t* d_scalars, siz
     size_t t = nv * lanes / ((size_t)4096 * 64);
     T = 16;
     while (T < 128 && 2 * (size_t)T <= t) T *= 2;
-    if (const char* e = getenv("KG_MERGED_T")) { const int v = atoi(e); if (v >= 4 && v <= 4096) T = (uint32_t)v; }
+    if (ctx->tune.merged_t >= 4 && ctx->tune.merged_t <= 4096) T = (uint32_t)ctx->tune.merged_t;
   }
   // two passes (bucket group, then bucket inside the group) once the sorted lists outgrow the L2; entries carry the
   // bucket's low FINE_BITS between the passes, which leaves 24 bits for the index
   const bool two_pass = merged || (c - 1 >= FINE_BITS + 4 && n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24));
-  static const bool alone_ok = !(getenv("KG_SORT_ALONE") && atoi(getenv("KG_SORT_ALONE")) == 0);   // experiments: every sort shaped for a busy device
+  const bool alone_ok = ctx->tune.sort_alone != 0;   // 0 (experiments): every sort shaped for a busy device
   const bool alone = alone_ok && (ctx->sort_alone || ngroups > 1);      // the (first group's) sort runs on an otherwise idle device
   if (c >= 19 && (!two_pass || merged)) return set_err(ctx, KG_ERR_BAD_ARG, "windows of 19 and 20 bits need the two-pass sort (2^16 .. 2^24 scalars)");
   const int fb = fine_bits_for(c);                  // low bucket bits an entry carries between the passes
@@ -2375,7 +2355,7 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
   // hot buckets are cut 2^shift times finer (bucket_task_len; the shift travels in the top bits of the task length): 2 by default, 0 for
   // a merged sort.  KG_HOT_SHIFT: experiments.  Measured with shift 2 (MI355X): witness-like 2^20 MSM 1.17 -> 0.67 ms per step, proof from a
   // 0/1-heavy witness 2.48 -> 2.16 ms; with window tables (merged) 1.87 -> 2.03, hence 0 there.
-  static const int hot_shift_env = getenv("KG_HOT_SHIFT") ? atoi(getenv("KG_HOT_SHIFT")) : -1;
+  const int hot_shift_env = ctx->tune.hot_shift;
   const uint32_t hot_shift = hot_shift_env >= 0 && hot_shift_env <= 2 ? (uint32_t)hot_shift_env : (Q.merged ? 0u : 2u);
   const uint32_t T = Q.T | (hot_shift << 30);
   char* ws = Q.ws;
@@ -2429,12 +2409,12 @@ int msm_sort_group(kg_ctx* ctx, const MsmSortPlan& Q, int g, MsmSorted* S, bool 
     // where nothing else runs (the first window group of a blocking MSM), 256 beside an accumulation.  Measured (MI355X, round 4):
     // 2^24-pair commitment 20.32 -> 19.00 ms, blocking 2^20 1.746 -> 1.685 ms, the four-deep 2^20 step 1.32 -> 1.295 ms; 512 threads
     // beside the accumulation shorten the sorts (12.9 -> 9.8 ms summed at 2^24) and lengthen the accumulations by as much.
-    static const int gs_tile_env = getenv("KG_GS_TILE") ? atoi(getenv("KG_GS_TILE")) : -1;     // experiments: 0 = the 1024-entry tiles of k_group_scatter
-    static const int gs_nt_set = getenv("KG_GS_NT") ? atoi(getenv("KG_GS_NT")) : 0;
+    const int gs_tile_env = ctx->tune.gs_tile;     // experiments: 0 = the 1024-entry tiles of k_group_scatter
+    const int gs_nt_set = ctx->tune.gs_nt;
     // wide windows: 512 -- level on uniform scalars (2^24: 19.05 / 19.0 ms), and a witness-like 2^24-pair vector, whose accumulations are
     // short and whose sorts therefore run mostly alone, 10.65 -> 8.9 ms; below, 512 costs the four-deep 2^20 step 1 %
     const int gs_nt_env = gs_nt_set ? gs_nt_set : (fb == 9 ? 512 : 256);
-    static const int gs_nt0_env = getenv("KG_GS_NT0") ? atoi(getenv("KG_GS_NT0")) : 1024;
+    const int gs_nt0_env = ctx->tune.gs_nt0;
     const int gs_tile = gs_tile_env >= 0 ? gs_tile_env : (fb == 9 ? 8192 : 4096);
     const int gs_nt = (Q.alone && g == 0) ? gs_nt0_env : gs_nt_env;
     if (two_pass) {
@@ -2620,7 +2600,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
   if (shared_pb) KG_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_pb, 0));     // the caller's conversion of the bases
   if (S.ntasks) {
     PhaseScope ph(ctx, "accumulate", st);
-    static const bool pair_acc = [] { const char* e = getenv("KG_G2_PAIR_ACC"); return e && atoi(e) != 0; }();
+    const bool pair_acc = ctx->tune.g2_pair_acc != 0;
     if (LPT > 1 && pair_acc)          // experiment: G2 accumulation on lane pairs, ~150 VGPRs instead of 256
       hipLaunchKernelGGL(k_acc_tasks<KF>, dim3((unsigned)(((size_t)S.ntasks * LPT + 63) / 64) * (unsigned)njobs), dim3(64), 0, st, A, S.sorted, S.bstart, S.bsize, L0,
                          S.task_bkt, S.task_id, S.n, W, B, S.T, part_cap, S.merged_shift, S.T_top, S.top_w);
@@ -2661,7 +2641,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       uint32_t max_cnt = S.max_cnt;
       int lv = -1;                                     // -1: level arrays of S; 0/1: local ping-pong
       const unsigned g1024 = (unsigned)((npts + 1023) / 1024);
-      static const bool hot_ok = !(getenv("KG_HOT_SUM") && atoi(getenv("KG_HOT_SUM")) == 0);
+      const bool hot_ok = ctx->tune.hot_sum != 0;
       if (max_cnt > GATHER_SUM_MAX && hot_ok && S.nhot >= 1 && S.nhot <= HOT_MAX && (size_t)part_cap * NW * 4 < ((size_t)1 << 32)) {
         // the few buckets with more partial sums than the gather takes: one workgroup-wide tree each
         PhaseScope ph2(ctx, "hot_sum", side);
@@ -2694,7 +2674,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       }
       ph.end();
       PhaseScope pg(ctx, "gather", side);
-      static const bool fuse_ok = !(getenv("KG_GATHER_FUSE") && atoi(getenv("KG_GATHER_FUSE")) == 0);
+      const bool fuse_ok = ctx->tune.gather_fuse != 0;
       fused_first = fuse_ok && max_cnt <= 1 && (uint32_t)B > (uint32_t)TailCfg<KF>::L && (size_t)part_cap * NW * 4 < ((size_t)1 << 32);
       if (max_cnt > 1)
         hipLaunchKernelGGL((k_gather_sum<F, KF>), dim3((unsigned)((npts * LPT + 63) / 64)), dim3(64), 0, side, part[pcur], L, W, B, pbuf[0]);
@@ -2747,43 +2727,6 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
   return KG_OK;
 }
 
-// Host half: wait for the slot's copy, then the 255-step double-and-add over the c*W bit-plane sums.
-// Window w contributes 2^(w*c) * (A_w + sum_l 2^l T_{w,l}); array 0 = A, array 1 + l = T_l.
-// An MSM cut into window groups holds one slot per group, top windows first: the chain runs through the groups in that
-// order and waits for a slot only when it reaches the slot's windows, so the top of the chain is computed while the lower
-// groups are still on the device.
-template <class Cfg>
-int msm_finish_t(kg_ctx* ctx, const int* slots, int nslots, uint64_t* out_xyz) {
-  using HF = typename Cfg::HF;
-  hipSetDevice(ctx->device);
-  host_trace("finish: enter");
-  constexpr int PE = 4 * Cfg::E64;
-  XYZZ<HF> acc = XYZZ<HF>::identity();
-  long long busy_us = 0;
-  for (int s = 0; s < nslots; ++s) {
-    kg_ctx::Slot& sl = ctx->slots[slots[s]];
-    if (hipEventSynchronize(sl.done) != hipSuccess) return KG_ERR_HIP;
-    host_trace("finish: slot ready");
-    const auto t0 = std::chrono::steady_clock::now();
-    const uint64_t* hp = (const uint64_t*)sl.host;
-    const int W = sl.W, c = sl.c, w0 = sl.w0;
-    for (int bit = (w0 + W) * c - 1; bit >= w0 * c; --bit) {
-      acc = double_xyzz(acc);
-      const int w = bit / c - w0, l = bit % c;
-      if (c > 1 && l < c - 1) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c + 1 + l) * PE));
-      if (l == 0) acc = add_xyzz(acc, host_load_point<Cfg>(hp + ((size_t)w * c) * PE));
-    }
-    if (s == nslots - 1) store_projective<Cfg>(acc, out_xyz);
-    busy_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
-  }
-  host_trace("finish: done");
-  if (ctx->prof) {
-    ctx->host_finish_us += busy_us;
-    ctx->host_finish_calls += 1;
-  }
-  return KG_OK;
-}
-
 bool has_window_table(const kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, size_t msm_len) {
   const int c = merged_window(ctx, msm_len);
   if (!c) return false;
@@ -2814,434 +2757,7 @@ int msm_run(kg_ctx* ctx, const MsmSorted& S, int curve, const uint64_t* d_bases,
   const MsmRunJob j{d_bases, d_inf, nbases, idx_off, slot, false, nullptr, false};
   return msm_run_multi(ctx, S, curve, &j, 1);
 }
-int msm_finish_groups(kg_ctx* ctx, int curve, const int* slots, int nslots, uint64_t* out_xyz) {
-  if (nslots < 1) return KG_ERR_BAD_ARG;
-  switch (curve) {
-    case KG_G1: return msm_finish_t<G1Cfg>(ctx, slots, nslots, out_xyz);
-    case KG_GRUMPKIN: return msm_finish_t<GkCfg>(ctx, slots, nslots, out_xyz);
-    case KG_G2: return msm_finish_t<G2Cfg>(ctx, slots, nslots, out_xyz);
-    default: return KG_ERR_BAD_ARG;
-  }
-}
-int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz) { return msm_finish_groups(ctx, curve, &slot, 1, out_xyz); }
-void msm_identity(int curve, uint64_t* out_xyz) {
-  if (curve == KG_G2) store_projective<G2Cfg>(XYZZ<HostFq2>::identity(), out_xyz);
-  else if (curve == KG_GRUMPKIN) store_projective<GkCfg>(XYZZ<HostFr>::identity(), out_xyz);
-  else store_projective<G1Cfg>(XYZZ<HostFq>::identity(), out_xyz);
-}
 
 }  // namespace kg
 
-namespace {
 
-template <class Cfg>
-int sum_affine_impl(const uint64_t* pts, const uint8_t* inf, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
-  using HF = typename Cfg::HF;
-  constexpr int E = Cfg::E64;
-  XYZZ<HF> acc = XYZZ<HF>::identity();
-  for (size_t i = 0; i < count; ++i) {
-    if (inf && inf[i]) continue;
-    Affine<HF> a{HostIO<HF>::load(pts + i * 2 * E), HostIO<HF>::load(pts + i * 2 * E + E)};
-    acc = add_mixed(acc, a);
-  }
-  uint64_t xyz[3 * 8];
-  store_projective<Cfg>(acc, xyz);
-  std::memcpy(out_xy, xyz, 2 * E * 8);
-  *out_inf = is_identity(acc) ? 1 : 0;
-  return KG_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-// Sum of the slices' results (projective (x, y, 1) / (0, 1, 0) each) -> the same form
-static int sum_slices(kg_ctx* ctx, int curve, const uint64_t (*part)[24], int K, uint64_t* out_xyz) {
-  const int E = curve == KG_G2 ? 8 : 4;
-  if (K == 1) { std::memcpy(out_xyz, part[0], (size_t)3 * E * 8); return KG_OK; }
-  uint64_t pts[kg_ctx::UP_SLICES * 16];
-  uint8_t pinf[kg_ctx::UP_SLICES];
-  for (int j = 0; j < K; ++j) {
-    bool z0 = true;
-    for (int k = 0; k < E; ++k) z0 = z0 && part[j][2 * E + k] == 0;
-    pinf[j] = z0 ? 1 : 0;
-    std::memcpy(pts + (size_t)j * 2 * E, part[j], (size_t)2 * E * 8);
-  }
-  uint64_t xy[16];
-  uint8_t inf = 0;
-  KG_TRY(kg_points_sum_affine(ctx, curve, pts, pinf, (size_t)K, xy, &inf));
-  kg::msm_identity(curve, out_xyz);                        // (0, 1, 0); y doubles as the field's one
-  if (!inf) {
-    for (int k = 0; k < E; ++k) out_xyz[2 * E + k] = out_xyz[E + k];
-    std::memcpy(out_xyz, xy, (size_t)2 * E * 8);
-  }
-  return KG_OK;
-}
-
-// A large blocking MSM as a pipeline over index slices: slice j+1 is sorted (scalar queue) while slice j accumulates, and
-// the slices' reductions and host finishes run under the later accumulations; the slices' sums are added on the host.
-// Unsliced, the sort (4.0 ms of 25.8 at 2^24) sits in front of the accumulation.  The slices keep the
-// window width of the whole (c = 17), so the number of additions does not change; the extra bucket reductions are hidden.
-static int msm_sliced(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
-  constexpr int K = kg_ctx::UP_SLICES;
-  const size_t pw = curve == KG_G2 ? 16 : 8;               // u64 words per base
-  size_t lo[K + 1];
-  for (int j = 0; j <= K; ++j) lo[j] = n / K * j + (j == K ? n % K : 0);
-  const int saved_window = ctx->msm_window;
-  if (!saved_window) { const int cw = pick_window(n, 0), cs = pick_window(n / K, 0); ctx->msm_window = cw > cs ? cw : cs; }
-  std::future<int> fin[K];
-  uint64_t part[K][24];
-  int rc = KG_OK;
-  const int sfield = curve == KG_GRUMPKIN ? KG_FQ : KG_FR;
-  for (int j = 0; j < K && rc == KG_OK; ++j) {
-    const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
-    kg::MsmSorted S;
-    rc = kg::msm_sort(ctx, sfield, d_scalars + 4 * a, cnt, &S, j > 0);      // slice 0 orders the scalar queue behind the inputs' producer
-    if (rc != KG_OK) break;
-    rc = kg::msm_run(ctx, S, curve, d_bases + a * pw, d_inf ? d_inf + a : nullptr, cnt, 0, 16 + j);
-    if (rc != KG_OK) break;
-    uint64_t* out = part[j];
-    fin[j] = std::async(std::launch::async, [ctx, curve, j, out] { return kg::msm_finish(ctx, curve, 16 + j, out); });
-  }
-  ctx->msm_window = saved_window;
-  for (int j = 0; j < K; ++j)
-    if (fin[j].valid()) { const int r2 = fin[j].get(); if (rc == KG_OK) rc = r2; }
-  if (rc != KG_OK) { kg_ctx_sync(ctx); return rc; }
-  return sum_slices(ctx, curve, part, K, out_xyz);
-}
-
-// A blocking MSM pipelined against itself by window groups (kg_ctx::MAX_GROUPS): the windows of one MSM are independent
-// until the host's double-and-add, so after ONE conversion of the scalars (k_prep_scalars_count peels all digits) the top
-// group is sorted, then accumulated while the next group is sorted, reduced while the next group accumulates, and its sums
-// feed the top of the host chain while the lower groups are still on the device.  Exactly the work of the unsplit call
-// (an index slice would add a bucket reduction and a host chain per slice); the groups' accumulations go to queues of
-// their own so that a group's tail and the next group's head share the chip.
-static int msm_grouped(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, const int* gw, int NG,
-                       uint64_t* out_xyz) {
-  KG_HIP(ctx, hipSetDevice(ctx->device));
-  if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
-  KG_TRY(make_sort_stream(ctx));
-  for (int g = 1; g < NG; ++g)
-    if (!ctx->acc_stream[g]) KG_HIP(ctx, create_stream(ctx, &ctx->acc_stream[g], false));
-  kg::MsmSortPlan Q;
-  // KG_GROUP_MAIN_FIRST=1 (experiment): conversion and the first group's sort on the main queue, in front of its accumulation -- no
-  // cross-queue hand-over there, but the second group's sort then runs BESIDE the first one's, the two accumulations start 50 us
-  // apart, share the chip from the start and neither finishes early: 1.93-2.04 ms against 1.77-1.85 with both sorts in turn on the
-  // scalar queue (2^20, same box, alternating runs; unsplit 1.85-1.90)
-  static const int main_first = getenv("KG_GROUP_MAIN_FIRST") ? atoi(getenv("KG_GROUP_MAIN_FIRST")) : 0;
-  KG_TRY(kg::msm_sort_begin(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &Q, false, 0, 1, NG, gw, main_first != 0));
-  if (main_first == 1) {                                   // the scalar queue (the later groups' sorts) follows the conversion
-    KG_HIP(ctx, hipEventRecord(ctx->ev_prep, ctx->stream));
-    KG_HIP(ctx, hipStreamWaitEvent(ctx->sort_stream, ctx->ev_prep, 0));
-  }
-  // the bases: a registered array is resident already; otherwise ONE conversion for all groups, on a reduction queue (idle
-  // at this point) beside the scalar conversion
-  const size_t pw64 = curve == KG_G2 ? 16 : 8;             // u64 words per ABI point
-  bool resident = false;
-  for (const auto& r : ctx->registered) {
-    if (r.curve != curve || d_bases < r.base) continue;
-    const size_t off64 = (size_t)(d_bases - r.base);
-    if (off64 % pw64 != 0 || off64 / pw64 + n > r.n) continue;
-    if (d_inf != (r.inf ? r.inf + off64 / pw64 : nullptr)) continue;
-    resident = true;
-    break;
-  }
-  const bool f64 = resident_fmt64(n);
-  if (!resident) {
-    const size_t bytes = n * (f64 ? (curve == KG_G2 ? 128 : 64) : (curve == KG_G2 ? 144 : 72));
-    if (bytes > ctx->ws_pb_bytes) {
-      if (ctx->ws_pb) { sync_all(ctx); hipFree(ctx->ws_pb); ctx->ws_pb = nullptr; ctx->ws_pb_bytes = 0; }
-      const hipError_t e = hipMalloc(&ctx->ws_pb, bytes + bytes / 8);
-      if (e != hipSuccess) return set_err(ctx, KG_ERR_OOM, "resident-bases allocation", e);
-      ctx->ws_pb_bytes = bytes + bytes / 8;
-    }
-    hipStream_t cq = ctx->side_stream;
-    if (!ctx->inputs_complete) {                          // stream semantics: the bases may still be in flight on the main queue
-      KG_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
-      KG_HIP(ctx, hipStreamWaitEvent(cq, ctx->ev_order, 0));
-    }
-    PhaseScope ph(ctx, "prep_bases", cq);
-    if (curve == KG_G1) launch_prep_bases<Fq>(cq, d_bases, d_inf, n, (uint32_t*)ctx->ws_pb, f64);
-    else if (curve == KG_GRUMPKIN) launch_prep_bases<Fr>(cq, d_bases, d_inf, n, (uint32_t*)ctx->ws_pb, f64);
-    else launch_prep_bases<Fq2>(cq, d_bases, d_inf, n, (uint32_t*)ctx->ws_pb, f64);
-    ph.end();
-    KG_HIP(ctx, hipGetLastError());
-    KG_HIP(ctx, hipEventRecord(ctx->ev_pb, cq));
-  }
-  kg::MsmSorted S[kg_ctx::MAX_GROUPS];
-  int slots[kg_ctx::MAX_GROUPS];
-  int rc = kg::msm_sort_group(ctx, Q, 0, &S[0], main_first != 0);
-  // KG_GROUP_MAIN_FIRST=2: as 1, but the scalar queue waits for the first group's SORT -- the sorts still run in turn, and the
-  // cross-queue hand-over (20-60 us) sits in front of the second sort, which has the whole first accumulation to hide in, instead of
-  // in front of the first accumulation
-  if (rc == KG_OK && main_first == 2) KG_HIP(ctx, hipStreamWaitEvent(ctx->sort_stream, S[0].ready, 0));
-  if (rc == KG_OK && NG > 1) rc = kg::msm_sort_group(ctx, Q, 1, &S[1]);
-  int launched = 0;
-  for (int g = 0; g < NG && rc == KG_OK; ++g) {
-    rc = kg::msm_sort_wait(ctx, &S[g]);
-    if (rc != KG_OK) break;
-    // accumulation queues the groups rotate over: 2 (the main queue and one more).  On ONE queue a group's launch waits for the
-    // previous group's last wave -- and the top window's tasks are twice as long as the others (unsigned digits: half the buckets),
-    // so the chip idles behind them: 2^20 in two groups 2.09 ms on one queue, 1.80 on two; a queue per group (four) is no better
-    // than two, and more than ~4 busy hardware queues start to delay each other's hand-overs
-    static const int accq = getenv("KG_GROUP_ACCQ") ? atoi(getenv("KG_GROUP_ACCQ")) : 2;
-    S[g].acc_stream = (accq > 1 && g % accq) ? ctx->acc_stream[g % accq] : nullptr;
-    static const int rinl = getenv("KG_GROUP_REDUCE_INLINE") ? atoi(getenv("KG_GROUP_REDUCE_INLINE")) : 1;
-    S[g].reduce_inline = rinl && g == NG - 1;
-    static const int one_side = getenv("KG_GROUP_ONE_SIDE") ? atoi(getenv("KG_GROUP_ONE_SIDE")) : 0;
-    slots[g] = one_side ? 16 + 2 * g : 16 + g;
-    kg::MsmRunJob job{d_bases, d_inf, n, 0u, slots[g], false, resident ? nullptr : (const uint32_t*)ctx->ws_pb, f64};
-    rc = kg::msm_run_multi(ctx, S[g], curve, &job, 1);
-    if (rc != KG_OK) break;
-    ++launched;
-    if (g + 2 < NG) rc = kg::msm_sort_group(ctx, Q, g + 2, &S[g + 2]);
-  }
-  if (rc != KG_OK) { sync_all(ctx); return rc; }
-  (void)launched;
-  return kg::msm_finish_groups(ctx, curve, slots, NG, out_xyz);
-}
-
-int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
-  if (!ctx || !out_xyz || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
-  if (n == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
-  static const bool sliced_ok = !(getenv("KG_MSM_SLICED") && atoi(getenv("KG_MSM_SLICED")) == 0);     // experiments: window groups instead of index slices
-  if (n >= ((size_t)1 << 23) && sliced_ok && pick_window(n, ctx->msm_window) < 19) return msm_sliced(ctx, curve, d_bases, d_inf, d_scalars, n, out_xyz);   // measured: 2^24 25.8 -> 23.0 ms, 2^23 13.1 -> 12.1; below that the slices' own tails cost more than the hidden sort
-  kg::MsmSorted S;
-  const int mc = kg::has_window_table(ctx, curve, d_bases, d_inf, n, n) ? kg::merged_window(ctx, n) : 0;
-  if (!mc) {
-    int gw[kg_ctx::MAX_GROUPS];
-    const int NG = kg::msm_group_plan(ctx, n, gw);
-    if (NG > 1) return msm_grouped(ctx, curve, d_bases, d_inf, d_scalars, n, gw, NG, out_xyz);
-  }
-  ctx->sort_alone = true;                                 // a blocking call: its sort is all the device has to do
-  const int rs = kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S, false, mc);
-  ctx->sort_alone = false;
-  KG_TRY(rs);
-  KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 0));
-  return kg::msm_finish(ctx, curve, 0, out_xyz);
-}
-
-int kg_msm_pick_window(size_t n) { return pick_window(n ? n : 1, 0); }
-int kg_msm_table_window(size_t msm_len) { return kg::merged_window(nullptr, msm_len); }
-
-int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t n) {
-  if (!ctx || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
-  if (n == 0) return KG_OK;                         // nothing to convert (e.g. an empty CRS vector)
-  if (!d_bases) return KG_ERR_BAD_ARG;
-  KG_HIP(ctx, hipSetDevice(ctx->device));
-  kg_bases_unregister(ctx, d_bases);
-  const bool fmt64 = resident_fmt64(n);
-  const size_t pw = fmt64 ? (curve == KG_G2 ? 32 : 16) : (curve == KG_G2 ? 36 : 18);
-  uint32_t* packed = nullptr;
-  KG_HIP(ctx, hipMalloc((void**)&packed, n * pw * 4));
-  if (curve == KG_G1) launch_prep_bases<Fq>(ctx->stream, d_bases, d_inf, n, packed, fmt64);
-  else if (curve == KG_GRUMPKIN) launch_prep_bases<Fr>(ctx->stream, d_bases, d_inf, n, packed, fmt64);
-  else launch_prep_bases<Fq2>(ctx->stream, d_bases, d_inf, n, packed, fmt64);
-  if (hipError_t e = hipGetLastError(); e != hipSuccess) {
-    hipFree(packed);
-    return set_err(ctx, KG_ERR_HIP, "k_prep_bases launch", e);
-  }
-  kg_ctx::Registered reg{d_bases, d_inf, n, curve, packed};
-  reg.fmt64 = fmt64;
-  ctx->registered.push_back(reg);
-  return KG_OK;
-}
-
-int kg_bases_unregister(kg_ctx* ctx, const uint64_t* d_bases) {
-  if (!ctx) return KG_ERR_BAD_ARG;
-  for (size_t i = 0; i < ctx->registered.size(); ++i) {
-    if (ctx->registered[i].base == d_bases) {
-      kg_ctx_sync(ctx);
-      hipFree(ctx->registered[i].packed);
-      if (ctx->registered[i].table) hipFree(ctx->registered[i].table);
-      ctx->registered.erase(ctx->registered.begin() + i);
-      return KG_OK;
-    }
-  }
-  return KG_OK;
-}
-
-int kg_bases_precompute(kg_ctx* ctx, const uint64_t* d_bases, size_t msm_len) {
-  if (!ctx || !d_bases) return KG_ERR_BAD_ARG;
-  KG_HIP(ctx, hipSetDevice(ctx->device));
-  kg_ctx::Registered* r = nullptr;
-  for (auto& e : ctx->registered) if (e.base == d_bases) r = &e;
-  if (!r) return set_err(ctx, KG_ERR_BAD_ARG, "kg_bases_precompute: the array is not registered");
-  if (msm_len == 0) msm_len = r->n;
-  if (msm_len < r->n) return set_err(ctx, KG_ERR_BAD_ARG, "kg_bases_precompute: msm_len is shorter than the array");
-  const int c = kg::merged_window(ctx, msm_len);
-  if (!c) return set_err(ctx, KG_ERR_BAD_ARG, "kg_bases_precompute: window tables are offered for MSMs of 2^16 .. 2^20 scalars");
-  if (r->table && r->table_c == c) return KG_OK;
-  if (r->table) { kg_ctx_sync(ctx); hipFree(r->table); r->table = nullptr; r->table_c = r->table_W = 0; }
-  const int W = (255 + c - 1) / c;
-  const bool t64 = table_fmt64();
-  const size_t pw = t64 ? (r->curve == KG_G2 ? 32 : 16) : (r->curve == KG_G2 ? 36 : 18), row = r->n * pw;
-  uint32_t* table = nullptr;
-  if (hipError_t e = hipMalloc((void**)&table, (size_t)W * row * 4); e != hipSuccess) {
-    (void)hipGetLastError();
-    return set_err(ctx, KG_ERR_OOM, "window table allocation", e);
-  }
-  hipStream_t st = ctx->stream;
-  // row 0 from the caller's array (the resident copy may be in the other form), then one launch per further window
-  if (r->curve == KG_G1) launch_prep_bases<Fq>(st, r->base, r->inf, r->n, table, t64);
-  else if (r->curve == KG_GRUMPKIN) launch_prep_bases<Fr>(st, r->base, r->inf, r->n, table, t64);
-  else launch_prep_bases<Fq2>(st, r->base, r->inf, r->n, table, t64);
-  hipError_t e = hipGetLastError();
-  const dim3 grid((unsigned)((r->n + 63) / 64));
-  for (int w = 1; w < W && e == hipSuccess; ++w) {
-    if (r->curve == KG_G1) hipLaunchKernelGGL(k_table_next<Fq>, grid, dim3(64), 0, st, table + (size_t)(w - 1) * row, r->n, c, table + (size_t)w * row, t64 ? 1 : 0);
-    else if (r->curve == KG_GRUMPKIN) hipLaunchKernelGGL(k_table_next<Fr>, grid, dim3(64), 0, st, table + (size_t)(w - 1) * row, r->n, c, table + (size_t)w * row, t64 ? 1 : 0);
-    else hipLaunchKernelGGL(k_table_next<Fq2>, grid, dim3(64), 0, st, table + (size_t)(w - 1) * row, r->n, c, table + (size_t)w * row, t64 ? 1 : 0);
-    e = hipGetLastError();
-  }
-  if (e != hipSuccess) { hipFree(table); return set_err(ctx, KG_ERR_HIP, "window table build", e); }
-  r->table = table; r->table_c = c; r->table_W = W; r->table64 = t64;
-  return KG_OK;
-}
-
-int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, int ticket) {
-  if (!ctx || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2 || ticket < 0 || ticket > 3) return KG_ERR_BAD_ARG;
-  ctx->ticket_n[ticket] = n;
-  if (n == 0) return KG_OK;
-  kg::MsmSorted S;
-  const int mc = kg::has_window_table(ctx, curve, d_bases, d_inf, n, n) ? kg::merged_window(ctx, n) : 0;
-  KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S, false, mc));
-  // KG_PIPE_ACCQ=2 (experiment, round 4): MSMs in flight alternate between two accumulation queues on the same compute pipe, so that the
-  // next launch's first waves fill the tail in which this one drains.  Measured level to slightly worse (1.347 -> 1.358 ms per step,
-  // three alternating runs): a two-round launch with longest-first tasks has little tail to fill.  Off.
-  static const int pipe_accq = getenv("KG_PIPE_ACCQ") ? atoi(getenv("KG_PIPE_ACCQ")) : 1;
-  if (pipe_accq > 1 && (ticket & 1) && ctx->acc_stream[1]) S.acc_stream = ctx->acc_stream[1];
-  if (ctx->ticket_fut[ticket].valid()) ctx->ticket_fut[ticket].wait();      // a ticket begun twice without its end: drop the older result
-  KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 1 + ticket));      // slots 1..4 (slot 0: kg_msm; 6..15: the prover's two jobs)
-  uint64_t* out = ctx->ticket_out[ticket];
-  ctx->ticket_fut[ticket] = std::async(std::launch::async, [ctx, curve, ticket, out] { return kg::msm_finish(ctx, curve, 1 + ticket, out); });
-  return KG_OK;
-}
-
-int kg_msm_end(kg_ctx* ctx, int curve, int ticket, uint64_t* out_xyz) {
-  if (!ctx || !out_xyz || curve < 0 || curve > KG_G2 || ticket < 0 || ticket > 3) return KG_ERR_BAD_ARG;
-  if (ctx->ticket_n[ticket] == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
-  if (!ctx->ticket_fut[ticket].valid()) return kg::set_err(ctx, KG_ERR_BAD_ARG, "kg_msm_end without a matching kg_msm_begin");
-  const int rc = ctx->ticket_fut[ticket].get();
-  if (rc != KG_OK) return rc;
-  std::memcpy(out_xyz, ctx->ticket_out[ticket], (curve == KG_G2 ? 24 : 12) * 8);
-  return KG_OK;
-}
-
-// Host arrays in, one point out: the call shape of the reference's slices (msm_curve_addition(&[C], &[C::Scalar])).
-// The index range is cut into up to four slices that travel through a pipeline: an uploader thread copies slice j's
-// scalars, then its bases, into cached device buffers (upload queue); the scalar queue sorts slice j as soon as its scalars
-// have landed, converts its bases when they have, and the main queue accumulates it while slice j+1 is still on the bus.
-// The slices' partial sums are added on the host.  PCIe (96 B per G1 pair) is the floor: 1.8 ms per 2^20 pairs.
-static int grow_device(kg_ctx* ctx, int which, size_t bytes) {
-  if (bytes <= ctx->up_bytes[which]) return KG_OK;
-  if (ctx->up_buf[which]) { sync_all(ctx); hipFree(ctx->up_buf[which]); ctx->up_buf[which] = nullptr; ctx->up_bytes[which] = 0; }
-  const hipError_t e = hipMalloc(&ctx->up_buf[which], bytes + bytes / 8);
-  if (e != hipSuccess) return set_err(ctx, KG_ERR_OOM, "upload buffer allocation", e);
-  ctx->up_bytes[which] = bytes + bytes / 8;
-  return KG_OK;
-}
-
-int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars, size_t n, uint64_t* out_xyz) {
-  if (!ctx || !out_xyz || (n && (!h_bases || !h_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
-  if (n == 0) return kg_msm(ctx, curve, nullptr, nullptr, nullptr, 0, out_xyz);
-  KG_HIP(ctx, hipSetDevice(ctx->device));
-  host_trace("host: enter");
-  const size_t pb = curve == KG_G2 ? 128 : 64;             // bytes per base
-  KG_TRY(grow_device(ctx, 0, n * pb));
-  KG_TRY(grow_device(ctx, 1, n * 32));
-  if (h_inf) KG_TRY(grow_device(ctx, 2, n));
-  if (!ctx->ev_up_s[0]) {
-    KG_TRY(make_sort_stream(ctx));                         // places the context's queues, the upload queue among them
-    if (!ctx->up_stream) KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
-    for (int i = 0; i < kg_ctx::UP_SLICES; ++i) {
-      KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_up_s[i], hipEventDisableTiming));
-      KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_up_b[i], hipEventDisableTiming));
-    }
-  }
-  hipStream_t sq;
-  KG_TRY(kg::scalar_queue(ctx, &sq));
-  char* d_b = (char*)ctx->up_buf[0];
-  uint64_t* d_s = (uint64_t*)ctx->up_buf[1];
-  uint8_t* d_i = h_inf ? (uint8_t*)ctx->up_buf[2] : nullptr;
-  const int K = n >= ((size_t)1 << 19) ? 4 : (n >= ((size_t)1 << 16) ? 2 : 1);
-  size_t lo[kg_ctx::UP_SLICES + 1];
-  for (int j = 0; j <= K; ++j) lo[j] = n / K * j + (j == K ? n % K : 0);
-  // the previous call's readers of the cached buffers are done (every call joins its slices before it returns)
-  std::atomic<int> up_s{0}, up_b{0}, up_rc{(int)hipSuccess};
-  auto upload_all = [&] {
-    hipSetDevice(ctx->device);
-    for (int j = 0; j < K; ++j) {
-      const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
-      hipError_t e = hipMemcpyAsync(d_s + 4 * a, h_scalars + 4 * a, cnt * 32, hipMemcpyHostToDevice, ctx->up_stream);
-      if (e == hipSuccess) e = hipEventRecord(ctx->ev_up_s[j], ctx->up_stream);
-      if (e != hipSuccess) up_rc = (int)e;
-      up_s = j + 1;
-      host_trace("upload: scalars");
-      e = hipMemcpyAsync(d_b + a * pb, (const char*)h_bases + a * pb, cnt * pb, hipMemcpyHostToDevice, ctx->up_stream);
-      if (e == hipSuccess && h_inf) e = hipMemcpyAsync(d_i + a, h_inf + a, cnt, hipMemcpyHostToDevice, ctx->up_stream);
-      if (e == hipSuccess) e = hipEventRecord(ctx->ev_up_b[j], ctx->up_stream);
-      if (e != hipSuccess) up_rc = (int)e;
-      up_b = j + 1;
-      host_trace("upload: bases");
-    }
-  };
-  // one slice: nothing to overlap, the calling thread uploads; otherwise an uploader thread feeds the pipeline (a copy from
-  // pageable memory occupies its thread for the duration of the copy)
-  std::thread uploader;
-  if (K == 1) upload_all(); else uploader = std::thread(upload_all);
-  std::future<int> fin[kg_ctx::UP_SLICES];
-  uint64_t part[kg_ctx::UP_SLICES][24];
-  int rc = KG_OK;
-  const int sfield = curve == KG_GRUMPKIN ? KG_FQ : KG_FR;
-  for (int j = 0; j < K && rc == KG_OK; ++j) {
-    const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
-    while (up_s.load() <= j) std::this_thread::yield();
-    if (up_rc != (int)hipSuccess) { rc = set_err(ctx, KG_ERR_HIP, "host-to-device upload", (hipError_t)up_rc.load()); break; }
-    if (hipStreamWaitEvent(sq, ctx->ev_up_s[j], 0) != hipSuccess) { rc = KG_ERR_HIP; break; }
-    kg::MsmSorted S;
-    rc = kg::msm_sort(ctx, sfield, d_s + 4 * a, cnt, &S, true);
-    if (rc != KG_OK) break;
-    while (up_b.load() <= j) std::this_thread::yield();
-    if (up_rc != (int)hipSuccess) { rc = set_err(ctx, KG_ERR_HIP, "host-to-device upload", (hipError_t)up_rc.load()); break; }
-    const kg::MsmRunJob job{(const uint64_t*)(d_b + a * pb), d_i ? d_i + a : nullptr, cnt, 0u, 16 + j, true};
-    if (hipStreamWaitEvent(sq, ctx->ev_up_b[j], 0) != hipSuccess) { rc = KG_ERR_HIP; break; }
-    rc = kg::msm_run_multi(ctx, S, curve, &job, 1);
-    if (rc != KG_OK) break;
-    uint64_t* out = part[j];
-    fin[j] = std::async(std::launch::async, [ctx, curve, j, out] { return kg::msm_finish(ctx, curve, 16 + j, out); });
-  }
-  if (uploader.joinable()) uploader.join();
-  hipStreamSynchronize(ctx->up_stream);
-  host_trace("host: uploads synced");
-  for (int j = 0; j < K; ++j)
-    if (fin[j].valid()) { const int r2 = fin[j].get(); if (rc == KG_OK) rc = r2; }
-  if (rc != KG_OK) { kg_ctx_sync(ctx); return rc; }
-  return sum_slices(ctx, curve, part, K, out_xyz);
-}
-
-int kg_commit(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,
-              uint64_t* out_xy, uint8_t* out_inf) {
-  if (!ctx || !out_xy || !out_inf || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
-  uint64_t xyz[24];
-  KG_TRY(kg_msm(ctx, curve, d_bases, d_inf, d_scalars, n, xyz));
-  const int E = curve == KG_G2 ? 8 : 4;
-  std::memcpy(out_xy, xyz, 2 * E * 8);
-  bool z0 = true;
-  for (int i = 0; i < E; ++i) z0 = z0 && xyz[2 * E + i] == 0;
-  *out_inf = z0 ? 1 : 0;
-  return KG_OK;
-}
-
-int kg_points_sum_affine(kg_ctx* ctx, int curve, const uint64_t* pts, const uint8_t* inf, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
-  (void)ctx;
-  if (!out_xy || !out_inf || (count && !pts)) return KG_ERR_BAD_ARG;
-  switch (curve) {
-    case KG_G1: return sum_affine_impl<G1Cfg>(pts, inf, count, out_xy, out_inf);
-    case KG_GRUMPKIN: return sum_affine_impl<GkCfg>(pts, inf, count, out_xy, out_inf);
-    case KG_G2: return sum_affine_impl<G2Cfg>(pts, inf, count, out_xy, out_inf);
-    default: return KG_ERR_BAD_ARG;
-  }
-}
-
-}  // extern "C"

@@ -44,12 +44,8 @@ namespace {
 // one box, level on another -- the table stays the default there for those 1-2 %.
 // KG_NTT_DIRECT_MAX_LOG lowers it for hosts that would rather keep the memory (0 = never).
 uint32_t direct_a_max_log() {
-  static const uint32_t v = [] {
-    const char* e = getenv("KG_NTT_DIRECT_MAX_LOG");
-    const long x = e ? atol(e) : 22;
-    return (uint32_t)(x < 0 ? 0 : (x > 22 ? 22 : x));
-  }();
-  return v;
+  const int x = tuning().ntt_direct_max_log;
+  return (uint32_t)(x < 0 ? 0 : (x > 22 ? 22 : x));
 }
 
 __device__ __forceinline__ Fr ld_tw(const uint32_t* __restrict__ tab, size_t e) { return NttIO<Fr>::table(tab, e); }
@@ -145,12 +141,10 @@ __global__ void k_build_zinv(uint32_t log_n, uint32_t* __restrict__ out) {
 }
 
 int plan_tile_env() {        // KG_NTT_TILE=10..12: log2 of the tile size (experiments)
-  static const int v = [] { const char* e = getenv("KG_NTT_TILE"); return e ? atoi(e) : 0; }();
-  return v;
+  return tuning().ntt_tile;
 }
 int plan_steps_env() {       // KG_NTT_STEPS=3: three-step plans from 2^18 up; 2: two steps up to 2^22 (experiments; default: ntt_plan's automatic rule)
-  static const int v = [] { const char* e = getenv("KG_NTT_STEPS"); return e ? atoi(e) : 0; }();
-  return v;
+  return tuning().ntt_steps;
 }
 
 void free_tables(kg_tw_cache* t) {

@@ -1,0 +1,69 @@
+// tuning.h -- every environment knob of the library, in ONE table, parsed ONCE.
+//
+// The knobs are experiment switches and scheduling parameters (results are bit-identical for every setting: tests/ run the
+// parity suite over the ones that change a code path).  The process-wide values are read from the environment the first time
+// kg::tuning() is called; every kg_ctx takes a copy at creation (kg_ctx::tune), which is what the code consults where it has a
+// context.  kg_tuning_describe (C ABI) walks the table: README.md's knob table is generated from it
+// (tools/gen_knob_table.py), so the documentation cannot drift from the code.
+//
+// -1 means "automatic" wherever the default column says so.
+#pragma once
+#include <string>
+
+// X(field, "ENV_NAME", default, "what it does")
+#define KG_TUNING_TABLE(X)                                                                                                                   \
+  /* ---- MSM: windows, groups, slices ------------------------------------------------------------------------------------------------ */ \
+  X(wide_window, "KG_WIDE_WINDOW", 24, "log2 of the length from which a blocking MSM takes the 20-bit window (13 windows, unsliced, window groups); 0 = never (index slices with c = 17)") \
+  X(msm_groups, "KG_MSM_GROUPS", -1, "window groups of a blocking MSM: -1 automatic, 0/1 none, k = k equal groups; a list \"a,b,c\" names the groups' window counts from the top window down") \
+  X(msm_sliced, "KG_MSM_SLICED", 1, "0 = a blocking MSM of 2^23 pairs or more runs in window groups instead of four index slices") \
+  X(msm_t, "KG_MSM_T", -1, "task length of the accumulation (entries per lane): -1 = 2 n / B + 16") \
+  X(merged_t, "KG_MERGED_T", -1, "task length of a merged (window-table) accumulation: -1 = one resident round of lanes") \
+  X(hot_shift, "KG_HOT_SHIFT", -1, "hot buckets are cut 2^shift times finer: -1 = 2 (0 for a merged sort)") \
+  X(hot_sum, "KG_HOT_SUM", 1, "0 = hot buckets go through the generic partial-sum rounds instead of the workgroup-wide trees") \
+  X(gather_fuse, "KG_GATHER_FUSE", 1, "0 = the bucket gather writes the dense bucket array instead of fusing the first halving level") \
+  X(fmt64_min_log, "KG_FMT64_MIN_LOG", 0, "log2 of the array length from which resident bases take the 64-byte point form (30 = always the 72-byte limb form)") \
+  X(table64, "KG_TABLE64", 1, "0 = window tables in the 72-byte limb form") \
+  X(pipe_accq, "KG_PIPE_ACCQ", 1, "2 = MSM tickets alternate between two accumulation queues (measured level; off)") \
+  /* ---- MSM: sort shaping ----------------------------------------------------------------------------------------------------------- */ \
+  X(sort_nch, "KG_SORT_NCH", 64, "cap on the scalar chunks (workgroups per window) of the first sort pass, 1..1024") \
+  X(sort_alone, "KG_SORT_ALONE", 1, "0 = every sort is shaped for a busy device (a blocking call's first sort normally takes the whole chip)") \
+  X(gs_tile, "KG_GS_TILE", -1, "entries per tile of the first sort pass: -1 = 4096 (8192 for the wide windows), 0 = the 1024-entry kernel (needs -DKG_EXPERIMENTS)") \
+  X(gs_nt, "KG_GS_NT", 0, "threads per workgroup of the first sort pass beside an accumulation: 0 = 256 (512 for the wide windows)") \
+  X(gs_nt0, "KG_GS_NT0", 1024, "threads per workgroup of the first sort pass on an idle device") \
+  /* ---- MSM: window groups of a blocking call --------------------------------------------------------------------------------------- */ \
+  X(group_main_first, "KG_GROUP_MAIN_FIRST", 0, "1 / 2 = conversion and first group's sort on the main queue (measured slower; off)") \
+  X(group_accq, "KG_GROUP_ACCQ", 2, "accumulation queues the window groups rotate over") \
+  X(group_reduce_inline, "KG_GROUP_REDUCE_INLINE", 1, "the last group's bucket reduction follows its accumulation on the same queue") \
+  X(group_one_side, "KG_GROUP_ONE_SIDE", 0, "1 = all groups reduce on one side queue") \
+  /* ---- host-scalar entries (kg_msm_host_scalars, kg_sharded_key_commit) ------------------------------------------------------------ */ \
+  X(host_slices, "KG_HOST_SLICES", 0, "index slices a host-scalar MSM is uploaded and run in: 0 = automatic (by length), 1..8") \
+  X(host_first_div, "KG_HOST_FIRST_DIV", 0, "the first slice (whose upload nothing hides) is 1/div of an equal share: 0 = automatic") \
+  X(host_pinned, "KG_HOST_PINNED", -1, "upload path of host scalars: -1 automatic, 0 = hipMemcpyAsync straight from the caller's pages, 1 = through the context's pinned staging ring") \
+  /* ---- experiments compiled only with -DKG_EXPERIMENTS ----------------------------------------------------------------------------- */ \
+  X(acc_prefetch, "KG_ACC_PREFETCH", 0, "experiment: 1 = accumulation with the next base prefetched into LDS (k_acc_tasks_q; measured level)") \
+  X(acc_prefetch_log, "KG_ACC_PREFETCH_LOG", 0, "experiment: log2 of the array length from which KG_ACC_PREFETCH applies") \
+  X(g2_pair_acc, "KG_G2_PAIR_ACC", 0, "experiment: 1 = G2 accumulation on lane pairs (~150 VGPRs instead of 250; measured level)") \
+  /* ---- Groth16 prover -------------------------------------------------------------------------------------------------------------- */ \
+  X(g16_h_early, "KG_G16_H_EARLY", 1, "order of h's transform chain in a proof: 1 = before the fused G1 accumulation, 0 = last (the order up to round 3), 2 = in front of the G2 accumulation") \
+  X(g16_h_early_pipe, "KG_G16_H_EARLY_PIPE", 1, "0 = the early-h order only for blocking proofs") \
+  X(g16_h_inline, "KG_G16_H_INLINE", 1, "a blocking proof runs h's reduction behind h's accumulation on the main queue") \
+  /* ---- NTT ------------------------------------------------------------------------------------------------------------------------- */ \
+  X(ntt_direct_max_log, "KG_NTT_DIRECT_MAX_LOG", 22, "largest log2 of a direct inter-step twiddle table, 0..22 (beyond it, and when the allocation fails: composed twiddles)") \
+  X(ntt_steps, "KG_NTT_STEPS", 0, "force the number of steps (HBM round trips) of a transform, 1..3; 0 = by size") \
+  X(ntt_tile, "KG_NTT_TILE", 0, "force log2 of the elements a workgroup holds in LDS; 0 = by size") \
+  /* ---- queues, diagnostics --------------------------------------------------------------------------------------------------------- */ \
+  X(queue_placement, "KG_QUEUE_PLACEMENT", 1, "0 = the context's queues in creation order instead of probed over the compute pipes") \
+  X(trace_host, "KG_TRACE_HOST", 0, "1 = host-side timestamps of the MSM pipeline's calls on stderr") \
+  X(profile_timeline, "KG_PROFILE_TIMELINE", 0, "1 = kg_profile_summary prints every phase's start / end on stderr")
+
+struct kg_tuning {
+#define KG_X(field, env, def, doc) int field = def;
+  KG_TUNING_TABLE(KG_X)
+#undef KG_X
+  std::string msm_groups_list;      // KG_MSM_GROUPS given as "a,b,c"
+  std::string stream_pad;           // KG_STREAM_PAD=n0,n1,...: never-used streams in front of the context's i-th queue (experiment)
+};
+
+namespace kg {
+const kg_tuning& tuning();          // the process-wide values: the table's defaults overridden by the environment, read once
+}
