@@ -60,9 +60,9 @@ def single_rank_env(torch, dev):
 
 
 def window_adds(n):
-    """bucket additions of one MSM: one per (window, scalar) pair with a non-zero digit ~ W * n"""
-    lg = n.bit_length() - 1
-    c = 20 if n == (1 << 24) else (17 if 21 <= lg <= 24 and n <= (1 << 24) else (16 if lg >= 19 else (15 if lg >= 14 else min(max(lg - 3, 2), 10))))   # pick_window, msm.hip
+    """bucket additions of one MSM: one per (window, scalar) pair with a non-zero digit ~ W * n; c from the library's own rule"""
+    from kogarashi_amd.lib import msm_pick_window
+    c = msm_pick_window(n)                  # kg_msm_pick_window (no device needed)
     return ((255 + c - 1) // c) * n
 
 
@@ -298,8 +298,8 @@ def main():
                           "routine_relative": {"unit": "G point additions/s", "achieved": adds / (iso_ms * 1e-3) / 1e9, "peak": MADD_PEAK_G,
                                                "frac": adds / (iso_ms * 1e-3) / 1e9 / MADD_PEAK_G},
                           "note": "isolated launches; the remaining ~30 % of issue slots go to the shifts / masks / carries of the 29-bit limbs, "
-                                  "the lazy-reduction bookkeeping and the gathers; rocprofv3 SQ counters (profiles/r03_msm_sq_counters.json): VALU issue "
-                                  "busy 89 % of the SIMD cycles of a launch"},
+                                  "the lazy-reduction bookkeeping and the gathers; rocprofv3 SQ counters (profiles/r04_msm_sq_counters.json): VALU issue "
+                                  "busy 88 % of the SIMD cycles of a launch"},
         "phases_ms_per_step": phase_avg, "pipelining": f"{depth} MSM steps in flight (kg_msm_begin / kg_msm_end), inputs declared complete",
     }
 
@@ -330,6 +330,35 @@ def main():
             line["registered_bases"]["window_tables"] = {"ms_per_step": (time.perf_counter() - t0) / args.steps * 1e3, "build_ms": build_ms,
                                                          "table_bytes": (15 if n >= (1 << 17) else 16) * 64 * n,
                                                          "matches_unregistered": bool((res_tab[0] == res[0]).all() and res_tab[1] == res[1])}
+        # The call the reference's call sites make (groth16/src/msm.rs:6: fixed bases, a fresh `coeffs` slice per call): bases registered
+        # once, the 2^log_n scalars in pageable HOST memory, uploaded inside the call in index slices under the accumulations
+        # (kg_msm_host_scalars).  PCIe-inclusive: reported beside blocking_ms, never as `value`.
+        hs = scalars.cpu().numpy().view(np.uint64).reshape(n, 4)
+        for _ in range(3):
+            hres = ctx.msm_host_scalars(K.KG_G1, bases.data_ptr(), 0, hs, n)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            hres = ctx.msm_host_scalars(K.KG_G1, bases.data_ptr(), 0, hs, n)
+        host_ms = (time.perf_counter() - t0) / 10 * 1e3
+        for _ in range(2):
+            ctx.msm(K.KG_G1, bases.data_ptr(), 0, scalars.data_ptr(), n)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            rres = ctx.msm(K.KG_G1, bases.data_ptr(), 0, scalars.data_ptr(), n)
+        res_ms = (time.perf_counter() - t0) / 10 * 1e3
+        stage = torch.empty(n * 4, dtype=torch.int64, device=dev)
+        ctx.write(stage.data_ptr(), hs)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ctx.write(stage.data_ptr(), hs)                # one synchronous kg_memcpy_h2d of the whole slice: what the call replaced
+        up_ms = (time.perf_counter() - t0) / 5 * 1e3
+        del stage
+        line["msm_host_scalars"] = {"ms_per_msm": host_ms, "resident_blocking_ms": res_ms, "over_resident_ms": host_ms - res_ms,
+                                    "plain_upload_ms": up_ms, "upload_gb_per_s": 32 * n / (up_ms * 1e-3) / 1e9,
+                                    "matches_resident": bool((hres == rres).all()),
+                                    "note": "kg_msm_host_scalars: registered bases, pageable host scalars (32 B per pair over PCIe inside the call), "
+                                            "blocking, host finish included; resident_blocking_ms = kg_msm on the same registered bases, same loop"}
+        del hs
         ctx.bases_unregister(bases.data_ptr())
     cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     if rank == 0 and world == 1 and not args.no_skew:
@@ -460,6 +489,25 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, ske
                "point": {"xy_hex": "".join(f"{int(v_):016x}" for v_ in got[0]), "is_identity": bool(got[1])},     # the commitment itself: equal for every N
                "roofline": {"bound": "hbm", "achieved": 96 * total / dt / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                             "frac": 96 * total / dt / 1e9 / (HBM_PEAK_GBS * world)}}
+        if world == 1:
+            # As nova/src/pedersen.rs:15-20 is called: the key resident (kg_sharded_key over this one context), m a pageable HOST vector --
+            # kg_sharded_key_commit uploads it in index slices under the accumulations.  PCIe-inclusive; beside ms_per_commit, never `value`.
+            from kogarashi_amd.lib import ShardedKey
+            hm = m.cpu().numpy().view(np.uint64).reshape(nl, 4)
+            hg = g.cpu().numpy().view(np.uint64).reshape(nl, 8)
+            key = ShardedKey([ctx], curve, hg)
+            del hg
+            for _ in range(2):
+                hxy, hinf = key.commit(hm)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                hxy, hinf = key.commit(hm)
+            hdt = (time.perf_counter() - t0) / steps
+            key.close()
+            leg["from_host"] = {"ms_per_commit": hdt * 1e3, "ratio_to_resident": hdt / dt, "scalar_bytes": 32 * nl,
+                                "bus_gb_per_s_if_serial": 32 * nl / max(hdt - dt, 1e-9) / 1e9,
+                                "matches_resident": bool(bool(hinf) == bool(got[1]) and (bool(hinf) or (np.asarray(hxy) == np.asarray(got[0])).all()))}
+            del hm
         if skew and name == "g1_fr" and world == 1:
             # the same commitment of a witness-like vector (half ones, a fifth zeros: what a folded R1CS witness looks like,
             # nova/src/relaxed_r1cs/witness.rs:56-70) -- sort-bound instead of accumulation-bound; checked by committing the halves
@@ -531,11 +579,22 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, ske
             for _ in range(10):
                 ctx.commit(K.KG_G1, g.data_ptr(), 0, m.data_ptr(), nn)
             unit[lg] = (time.perf_counter() - t0) / 10 * 1e3
+            if lg == log_n - 3:
+                hm = m.cpu().numpy().view(np.uint64).reshape(nn, 4)
+                for _ in range(3):
+                    ctx.commit_host_scalars(K.KG_G1, g.data_ptr(), 0, hm, nn)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    ctx.commit_host_scalars(K.KG_G1, g.data_ptr(), 0, hm, nn)
+                unit["host"] = (time.perf_counter() - t0) / 10 * 1e3
+                del hm
             ctx.bases_unregister(g.data_ptr())
             del g, m
         a, b = unit[log_n - 3], unit[log_n - 2]
         out["rank_unit"] = {"log_n": log_n - 3, "blocking_ms_per_commit": a, "half_of_twice_the_size_ms": b / 2, "ratio": a / (b / 2),
-                            "note": "blocking kg_commit, registered key, bn254 G1: the slice one rank of the 8-GPU configuration commits"}
+                            "from_host_ms_per_commit": unit["host"],
+                            "note": "blocking kg_commit, registered key, bn254 G1: the slice one rank of the 8-GPU configuration commits; "
+                                    "from_host = the same slice with its scalars in pageable host memory (kg_commit_host_scalars, PCIe-inclusive)"}
     return out
 
 

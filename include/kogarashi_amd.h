@@ -47,7 +47,7 @@ enum { KG_G1 = 0, KG_GRUMPKIN = 1, KG_G2 = 2 };      /* curve ids */
 
 typedef struct kg_ctx kg_ctx;
 
-int kg_version(void);                    /* 4: the last extension added kg_msm_set_groups, kg_ctx_queue_placement; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
+int kg_version(void);                    /* 5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe, kg_mem_info; 4: kg_msm_set_groups, kg_ctx_queue_placement; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
 /* Optional process-level setup; call it (or export the variable yourself) BEFORE anything in the process initialises the
  * HIP runtime -- before the first kg_device_count / kg_ctx_create and before any other HIP user -- and before the host
  * starts threads (it calls setenv).  Sets GPU_MAX_HW_QUEUES=16 unless the variable is already set, so that each of a
@@ -86,6 +86,10 @@ int kg_ctx_queue_placement(kg_ctx* ctx);
 /* device memory plumbing so that non-HIP hosts (Rust shim, ctypes) never link the HIP runtime */
 int kg_malloc(kg_ctx* ctx, size_t bytes, void** d_ptr);
 int kg_free(kg_ctx* ctx, void* d_ptr);
+/* Free and total memory of the context's device (hipMemGetInfo): a host sizes its resident CRS / keys with it.  Work spaces the
+ * library keeps are grow-only and counted as used; an allocation the device refuses makes the call return KG_ERR_OOM with the
+ * context intact (the call can be repeated once memory has been released). */
+int kg_mem_info(kg_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 int kg_memcpy_h2d(kg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int kg_memcpy_d2h(kg_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 int kg_memcpy_d2d(kg_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
@@ -138,10 +142,22 @@ int kg_msm_end(kg_ctx* ctx, int curve, int ticket, uint64_t* out_xyz);
  * slice j + 1 is still on the bus -- and the slices' sums are added on the host. */
 int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars,
                 size_t n, uint64_t* out_xyz);
+/* The call shape of the reference's call sites: the bases are FIXED per circuit / per commitment key (a CRS vector of
+ * groth16/src/params.rs:6-28, the generators of nova/src/pedersen.rs:6-13) and live on the device -- register them once with
+ * kg_bases_register -- while the scalars are a fresh HOST slice per call (groth16/src/msm.rs:6 `coeffs`, pedersen.rs:15 `m`).
+ * d_bases / d_inf: device (any whole-point offset into a registered array is served from its resident copy); h_scalars: HOST,
+ * pageable or pinned.  The scalars are uploaded in index slices, each sorted and accumulated while the next one is still on the
+ * bus; only the first, short slice's upload is exposed.  Result identical to kg_msm on the uploaded scalars. */
+int kg_msm_host_scalars(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* h_scalars,
+                        size_t n, uint64_t* out_xyz);
 /* nova/src/pedersen.rs:15-20 PedersenCommitment::commit: affine(sum_i m[i] * g[i]).
  * out_xy: HOST, 8 or 16 uint64; *out_inf = 1 for the identity (then out_xy = (0, 1)). */
 int kg_commit(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars,
               size_t n, uint64_t* out_xy, uint8_t* out_inf);
+/* kg_commit with the scalars in HOST memory (see kg_msm_host_scalars): what nova/src/pedersen.rs:15-20 does per call against
+ * a resident key. */
+int kg_commit_host_scalars(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* h_scalars,
+                           size_t n, uint64_t* out_xy, uint8_t* out_inf);
 /* Per-GPU partial for the sharded commit: the un-normalised device result (raw window sums) is reduced on
  * the host to ONE affine partial; ranks exchange these (RCCL all_gather of 17/33 words) and add them with
  * kg_points_sum_affine.  See DESIGN.md "Multi-GPU". */
@@ -291,6 +307,13 @@ int kg_groth16_prove_r1cs_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const kg
 /* ---- deterministic synthetic inputs (identical streams in oracle/) -------------------- */
 int kg_gen_scalars(kg_ctx* ctx, int field, uint64_t seed, size_t start, size_t n, uint64_t* d_out);
 int kg_gen_bases(kg_ctx* ctx, int curve, uint64_t seed, size_t start, size_t n, uint64_t* d_out); /* G1, Grumpkin */
+
+/* ---- tuning knobs ---------------------------------------------------------------------------------------------------
+ * Every environment variable the library reads (experiment switches, scheduling parameters; results are bit-identical for every
+ * setting) lives in ONE table (kogarashi_amd/csrc/tuning.h), parsed once per process.  kg_tuning_describe(-1, ...) returns the
+ * number of rows; for 0 <= index < rows it writes the variable's name, its description, the default and the value this process
+ * runs with (any out-pointer may be NULL).  README.md's table is generated from it (tools/gen_knob_table.py). */
+int kg_tuning_describe(int index, const char** env, const char** doc, int* dflt, int* value);
 
 /* ---- timing: when enabled, the library brackets its device phases with HIP events on its stream ------ */
 int kg_profile_enable(kg_ctx* ctx, int on);       /* (re)starts the accumulation */

@@ -179,10 +179,11 @@ class PedersenCommitment {
   ~PedersenCommitment() { kg_bases_unregister(c_.raw(), g_->as<uint64_t>()); }
   G1Affine commit(const std::vector<Fe>& m) const {
     const size_t n = m.size() < n_ ? m.size() : n_;
-    DeviceBuffer d(c_, m.data(), n * 32);
     uint64_t xy[8];
     uint8_t inf = 0;
-    c_.check(kg_commit(c_.raw(), curve_, g_->as<uint64_t>(), inf_ ? inf_->as<uint8_t>() : nullptr, d.as<uint64_t>(), n, xy, &inf), "kg_commit");
+    // the key is resident, m is the caller's slice: uploaded in index slices under the accumulations (no whole-vector copy in front)
+    c_.check(kg_commit_host_scalars(c_.raw(), curve_, g_->as<uint64_t>(), inf_ ? inf_->as<uint8_t>() : nullptr,
+                                    reinterpret_cast<const uint64_t*>(m.data()), n, xy, &inf), "kg_commit_host_scalars");
     return detail::g1_from(xy, inf != 0);
   }
 

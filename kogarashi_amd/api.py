@@ -107,8 +107,8 @@ class PedersenCommitment:
     def commit(self, m):
         m = np.ascontiguousarray(m, dtype=np.uint64).reshape(-1, 4)
         n = min(len(m), self.len)
-        d = self.ctx.upload(m[:n])
-        return self.ctx.commit(self.cid, self._g.ptr, self._inf.ptr if self._inf else 0, d.ptr, n)
+        # the key is resident, m is a host slice: uploaded in index slices under the accumulations (kg_commit_host_scalars)
+        return self.ctx.commit_host_scalars(self.cid, self._g.ptr, self._inf.ptr if self._inf else 0, m[:n], n)
 
 
 class Prover:

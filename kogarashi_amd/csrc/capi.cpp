@@ -262,7 +262,7 @@ int kg_hw_queue_setting(void) {
   const char* e = getenv("GPU_MAX_HW_QUEUES");
   return e ? atoi(e) : 0;
 }
-int kg_version(void) { return 4; }      // the round the ABI was last extended in (4: kg_msm_set_groups; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded)
+int kg_version(void) { return 5; }      // the round the ABI was last extended in (5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe; 4: kg_msm_set_groups; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded)
 
 int kg_device_count(void) {
   int n = 0;
@@ -382,6 +382,15 @@ int kg_malloc(kg_ctx* c, size_t bytes, void** p) {
   if (!c || !p) return KG_ERR_BAD_ARG;
   KG_HIP(c, hipSetDevice(c->device));
   KG_HIP(c, hipMalloc(p, bytes ? bytes : 1));
+  return KG_OK;
+}
+int kg_mem_info(kg_ctx* c, size_t* free_bytes, size_t* total_bytes) {
+  if (!c) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipSetDevice(c->device));
+  size_t f = 0, t = 0;
+  KG_HIP(c, hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
   return KG_OK;
 }
 int kg_free(kg_ctx* c, void* p) {

@@ -66,7 +66,7 @@ struct kg_ctx {
   hipEvent_t ev_acc[RUN_SETS] = {};
   hipEvent_t ev_info[MAX_GROUPS] = {};   // marks the task-count read-back of msm_sort (per window group)
   struct Slot { void* host = nullptr; void* host_dev = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0, w0 = 0; bool busy = false; };   // w0: first window of the group the slot holds
-  static constexpr int NSLOTS = 24;      // 0 kg_msm, 1..4 kg_msm_begin tickets, 6..10 prover job 0, 11..15 prover job 1, 16..19 slices of kg_msm_host / window groups of kg_msm (disjoint: calls may interleave)
+  static constexpr int NSLOTS = 24;      // 0 kg_msm, 1..4 kg_msm_begin tickets, 6..10 prover job 0, 11..15 prover job 1, 16..23 slices of kg_msm_host / kg_msm_host_scalars, 16..19 window groups / index slices of kg_msm (blocking calls: never at the same time)
   Slot slots[NSLOTS];
   std::shared_ptr<void> prover_jobs;     // groth16.hip: proofs in flight (kg_groth16_prove_begin / _end)
   size_t ticket_n[4] = {0, 0, 0, 0};
@@ -82,7 +82,7 @@ struct kg_ctx {
   void* up_buf[3] = {nullptr, nullptr, nullptr};     // bases, scalars, identity flags
   size_t up_bytes[3] = {0, 0, 0};
   hipStream_t up_stream = nullptr;
-  static constexpr int UP_SLICES = 4;
+  static constexpr int UP_SLICES = 8;    // index slices of a host-array MSM (kg_msm_host, kg_msm_host_scalars): result slots 16 .. 23
   hipEvent_t ev_up_s[UP_SLICES] = {}, ev_up_b[UP_SLICES] = {};
   void* fb_tmp = nullptr;                // XYZZ results between the two passes of kg_fixed_base_mul (grow-only)
   size_t fb_tmp_bytes = 0;
@@ -109,6 +109,7 @@ inline int set_err(kg_ctx* c, int code, const char* what, hipError_t e = hipSucc
     c->last_error = what;
     if (e != hipSuccess) { c->last_error += ": "; c->last_error += hipGetErrorString(e); }
   }
+  if (e != hipSuccess) (void)hipGetLastError();     // the runtime's sticky copy: a later launch check must not report this failure again
   return code;
 }
 #define KG_HIP(ctx, call)                                                        \

@@ -163,7 +163,7 @@ static int sum_slices(kg_ctx* ctx, int curve, const uint64_t (*part)[24], int K,
 // Unsliced, the sort (4.0 ms of 25.8 at 2^24) sits in front of the accumulation.  The slices keep the
 // window width of the whole (c = 17), so the number of additions does not change; the extra bucket reductions are hidden.
 static int msm_sliced(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
-  constexpr int K = kg_ctx::UP_SLICES;
+  constexpr int K = 4;
   const size_t pw = curve == KG_G2 ? 16 : 8;               // u64 words per base
   size_t lo[K + 1];
   for (int j = 0; j <= K; ++j) lo[j] = n / K * j + (j == K ? n % K : 0);
@@ -400,28 +400,68 @@ int kg_msm_end(kg_ctx* ctx, int curve, int ticket, uint64_t* out_xyz) {
 }
 
 // Host arrays in, one point out: the call shape of the reference's slices (msm_curve_addition(&[C], &[C::Scalar])).
-// The index range is cut into up to four slices that travel through a pipeline: an uploader thread copies slice j's
-// scalars, then its bases, into cached device buffers (upload queue); the scalar queue sorts slice j as soon as its scalars
+// The index range is cut into slices that travel through a pipeline: an uploader thread copies slice j's scalars (then, for
+// kg_msm_host, its bases) into cached device buffers (upload queue); the scalar queue sorts slice j as soon as its scalars
 // have landed, converts its bases when they have, and the main queue accumulates it while slice j+1 is still on the bus.
-// The slices' partial sums are added on the host.  PCIe (96 B per G1 pair) is the floor: 1.8 ms per 2^20 pairs.
+// The slices' partial sums are added on the host.
+//   kg_msm_host          both arrays from host memory: PCIe (96 B per G1 pair) is the floor, 1.8 ms per 2^20 pairs.
+//   kg_msm_host_scalars  the bases are a device array (a CRS vector, a commitment key: registered, so nothing is converted per
+//                        call) and only the scalars travel -- 32 B per pair.  This is what the Rust call sites do per call:
+//                        the bases of groth16/src/msm.rs:6 / nova/src/pedersen.rs:15-20 are fixed, the scalars are new.
+// Only the FIRST slice's upload is exposed (everything downstream needs its scalars), so it is the short one:
+// msm_host_plan cuts the range into one half-share and K - 1 full shares.
 static int grow_device(kg_ctx* ctx, int which, size_t bytes) {
   if (bytes <= ctx->up_bytes[which]) return KG_OK;
   if (ctx->up_buf[which]) { sync_all(ctx); hipFree(ctx->up_buf[which]); ctx->up_buf[which] = nullptr; ctx->up_bytes[which] = 0; }
   const hipError_t e = hipMalloc(&ctx->up_buf[which], bytes + bytes / 8);
-  if (e != hipSuccess) return set_err(ctx, KG_ERR_OOM, "upload buffer allocation", e);
+  if (e != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, KG_ERR_OOM, "upload buffer allocation", e); }
   ctx->up_bytes[which] = bytes + bytes / 8;
   return KG_OK;
 }
 
-int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars, size_t n, uint64_t* out_xyz) {
-  if (!ctx || !out_xyz || (n && (!h_bases || !h_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
-  if (n == 0) return kg_msm(ctx, curve, nullptr, nullptr, nullptr, 0, out_xyz);
+// Slice boundaries lo[0 .. K] of an n-pair host-array MSM; returns K.  scalars_only: the bases are resident.
+//   both arrays : 4 equal slices from 2^19 pairs, 2 from 2^16 (the bus is the floor; round 2's measured optimum)
+//   scalars only: the first slice is 1 / first_div of an equal share (its upload is the one nothing hides), the others equal;
+//                 K grows with n so that a slice stays a well-filled MSM (>= 2^17 pairs) and the exposed upload stays short
+static int msm_host_plan(const kg_ctx* ctx, size_t n, bool scalars_only, size_t* lo) {
+  int K = n >= ((size_t)1 << 19) ? 4 : (n >= ((size_t)1 << 16) ? 2 : 1);
+  int first_div = 1;
+  if (scalars_only) {
+    // measured (MI355X, registered G1 bases, pageable scalars, ms over the resident blocking kg_msm; tools/dbg/host_scalars.py):
+    //   2^20: K = 2 +0.13, 3 +0.23, 4 +0.32      2^21: K = 2 +0.67, 3 +0.63, 4 +0.71      2^22: K = 2 +1.23, 3 +0.93, 4 +0.92
+    //   2^23: K = 6 +0.92, 8 +1.13               2^24: K = 4 +3.65, 6 +2.86, 8 +2.82 (1.15x: the slices run c = 17, 15 windows against 13)
+    // first_div 2 beats 1, 3 and 4 at every size (2^20, K = 2: +0.13 / +0.14 / +0.18 / +0.12 within noise of each other above 1)
+    int lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) ++lg;
+    K = lg >= 24 ? 8 : (lg == 23 ? 6 : (lg == 22 ? 4 : (lg == 21 ? 3 : (lg >= 17 ? 2 : 1))));
+    first_div = K > 1 ? 2 : 1;
+  }
+  if (ctx->tune.host_slices >= 1 && ctx->tune.host_slices <= kg_ctx::UP_SLICES) K = ctx->tune.host_slices;
+  if (ctx->tune.host_first_div >= 1 && ctx->tune.host_first_div <= 16) first_div = ctx->tune.host_first_div;
+  if ((size_t)K > n) K = (int)n;
+  if (K <= 1) { lo[0] = 0; lo[1] = n; return 1; }
+  // shares: 1 for the first slice, first_div for each of the others
+  const size_t units = 1 + (size_t)(K - 1) * first_div;
+  size_t first = n / units;
+  if (first < 1) first = 1;
+  first &= ~(size_t)255;                                   // keeps the later slices' device addresses 8 KiB-aligned
+  if (first == 0) first = n / units ? n / units : 1;
+  lo[0] = 0; lo[1] = first;
+  const size_t rest = n - first;
+  for (int j = 2; j <= K; ++j) lo[j] = first + rest / (K - 1) * (j - 1) + (j == K ? rest % (K - 1) : 0);
+  return K;
+}
+
+static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const uint8_t* inf, bool bases_on_device, const uint64_t* h_scalars, size_t n,
+                         uint64_t* out_xyz) {
   KG_HIP(ctx, hipSetDevice(ctx->device));
   host_trace("host: enter");
   const size_t pb = curve == KG_G2 ? 128 : 64;             // bytes per base
-  KG_TRY(grow_device(ctx, 0, n * pb));
+  if (!bases_on_device) {
+    KG_TRY(grow_device(ctx, 0, n * pb));
+    if (inf) KG_TRY(grow_device(ctx, 2, n));
+  }
   KG_TRY(grow_device(ctx, 1, n * 32));
-  if (h_inf) KG_TRY(grow_device(ctx, 2, n));
   if (!ctx->ev_up_s[0]) {
     KG_TRY(make_sort_stream(ctx));                         // places the context's queues, the upload queue among them
     if (!ctx->up_stream) KG_HIP(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
@@ -432,12 +472,15 @@ int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* 
   }
   hipStream_t sq;
   KG_TRY(kg::scalar_queue(ctx, &sq));
-  char* d_b = (char*)ctx->up_buf[0];
+  if (bases_on_device && !ctx->inputs_complete) {          // stream semantics: a device array may still be in flight on the main queue
+    KG_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
+    KG_HIP(ctx, hipStreamWaitEvent(sq, ctx->ev_order, 0));
+  }
+  const char* d_b = bases_on_device ? (const char*)bases : (const char*)ctx->up_buf[0];
   uint64_t* d_s = (uint64_t*)ctx->up_buf[1];
-  uint8_t* d_i = h_inf ? (uint8_t*)ctx->up_buf[2] : nullptr;
-  const int K = n >= ((size_t)1 << 19) ? 4 : (n >= ((size_t)1 << 16) ? 2 : 1);
+  const uint8_t* d_i = bases_on_device ? inf : (inf ? (const uint8_t*)ctx->up_buf[2] : nullptr);
   size_t lo[kg_ctx::UP_SLICES + 1];
-  for (int j = 0; j <= K; ++j) lo[j] = n / K * j + (j == K ? n % K : 0);
+  const int K = msm_host_plan(ctx, n, bases_on_device, lo);
   // the previous call's readers of the cached buffers are done (every call joins its slices before it returns)
   std::atomic<int> up_s{0}, up_b{0}, up_rc{(int)hipSuccess};
   auto upload_all = [&] {
@@ -449,12 +492,14 @@ int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* 
       if (e != hipSuccess) up_rc = (int)e;
       up_s = j + 1;
       host_trace("upload: scalars");
-      e = hipMemcpyAsync(d_b + a * pb, (const char*)h_bases + a * pb, cnt * pb, hipMemcpyHostToDevice, ctx->up_stream);
-      if (e == hipSuccess && h_inf) e = hipMemcpyAsync(d_i + a, h_inf + a, cnt, hipMemcpyHostToDevice, ctx->up_stream);
-      if (e == hipSuccess) e = hipEventRecord(ctx->ev_up_b[j], ctx->up_stream);
-      if (e != hipSuccess) up_rc = (int)e;
+      if (!bases_on_device) {
+        e = hipMemcpyAsync((char*)ctx->up_buf[0] + a * pb, (const char*)bases + a * pb, cnt * pb, hipMemcpyHostToDevice, ctx->up_stream);
+        if (e == hipSuccess && inf) e = hipMemcpyAsync((uint8_t*)ctx->up_buf[2] + a, inf + a, cnt, hipMemcpyHostToDevice, ctx->up_stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_up_b[j], ctx->up_stream);
+        if (e != hipSuccess) up_rc = (int)e;
+        host_trace("upload: bases");
+      }
       up_b = j + 1;
-      host_trace("upload: bases");
     }
   };
   // one slice: nothing to overlap, the calling thread uploads; otherwise an uploader thread feeds the pipeline (a copy from
@@ -465,18 +510,23 @@ int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* 
   uint64_t part[kg_ctx::UP_SLICES][24];
   int rc = KG_OK;
   const int sfield = curve == KG_GRUMPKIN ? KG_FQ : KG_FR;
+  const bool was_alone = ctx->sort_alone;
   for (int j = 0; j < K && rc == KG_OK; ++j) {
     const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
     while (up_s.load() <= j) std::this_thread::yield();
     if (up_rc != (int)hipSuccess) { rc = set_err(ctx, KG_ERR_HIP, "host-to-device upload", (hipError_t)up_rc.load()); break; }
     if (hipStreamWaitEvent(sq, ctx->ev_up_s[j], 0) != hipSuccess) { rc = KG_ERR_HIP; break; }
     kg::MsmSorted S;
+    ctx->sort_alone = j == 0;                              // the first slice's sort has the device to itself
     rc = kg::msm_sort(ctx, sfield, d_s + 4 * a, cnt, &S, true);
+    ctx->sort_alone = was_alone;
     if (rc != KG_OK) break;
-    while (up_b.load() <= j) std::this_thread::yield();
-    if (up_rc != (int)hipSuccess) { rc = set_err(ctx, KG_ERR_HIP, "host-to-device upload", (hipError_t)up_rc.load()); break; }
+    if (!bases_on_device) {
+      while (up_b.load() <= j) std::this_thread::yield();
+      if (up_rc != (int)hipSuccess) { rc = set_err(ctx, KG_ERR_HIP, "host-to-device upload", (hipError_t)up_rc.load()); break; }
+      if (hipStreamWaitEvent(sq, ctx->ev_up_b[j], 0) != hipSuccess) { rc = KG_ERR_HIP; break; }
+    }
     const kg::MsmRunJob job{(const uint64_t*)(d_b + a * pb), d_i ? d_i + a : nullptr, cnt, 0u, 16 + j, true};
-    if (hipStreamWaitEvent(sq, ctx->ev_up_b[j], 0) != hipSuccess) { rc = KG_ERR_HIP; break; }
     rc = kg::msm_run_multi(ctx, S, curve, &job, 1);
     if (rc != KG_OK) break;
     uint64_t* out = part[j];
@@ -491,16 +541,41 @@ int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* 
   return sum_slices(ctx, curve, part, K, out_xyz);
 }
 
-int kg_commit(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,
-              uint64_t* out_xy, uint8_t* out_inf) {
-  if (!ctx || !out_xy || !out_inf || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
-  uint64_t xyz[24];
-  KG_TRY(kg_msm(ctx, curve, d_bases, d_inf, d_scalars, n, xyz));
+int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars, size_t n, uint64_t* out_xyz) {
+  if (!ctx || !out_xyz || (n && (!h_bases || !h_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
+  if (n == 0) return kg_msm(ctx, curve, nullptr, nullptr, nullptr, 0, out_xyz);
+  return msm_host_impl(ctx, curve, h_bases, h_inf, false, h_scalars, n, out_xyz);
+}
+
+int kg_msm_host_scalars(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* h_scalars, size_t n, uint64_t* out_xyz) {
+  if (!ctx || !out_xyz || (n && (!d_bases || !h_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
+  if (n == 0) return kg_msm(ctx, curve, nullptr, nullptr, nullptr, 0, out_xyz);
+  return msm_host_impl(ctx, curve, d_bases, d_inf, true, h_scalars, n, out_xyz);
+}
+
+static void xyz_to_commit(int curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf) {
   const int E = curve == KG_G2 ? 8 : 4;
   std::memcpy(out_xy, xyz, 2 * E * 8);
   bool z0 = true;
   for (int i = 0; i < E; ++i) z0 = z0 && xyz[2 * E + i] == 0;
   *out_inf = z0 ? 1 : 0;
+}
+
+int kg_commit_host_scalars(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* h_scalars, size_t n,
+                           uint64_t* out_xy, uint8_t* out_inf) {
+  if (!ctx || !out_xy || !out_inf || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
+  uint64_t xyz[24];
+  KG_TRY(kg_msm_host_scalars(ctx, curve, d_bases, d_inf, h_scalars, n, xyz));
+  xyz_to_commit(curve, xyz, out_xy, out_inf);
+  return KG_OK;
+}
+
+int kg_commit(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,
+              uint64_t* out_xy, uint8_t* out_inf) {
+  if (!ctx || !out_xy || !out_inf || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
+  uint64_t xyz[24];
+  KG_TRY(kg_msm(ctx, curve, d_bases, d_inf, d_scalars, n, xyz));
+  xyz_to_commit(curve, xyz, out_xy, out_inf);
   return KG_OK;
 }
 

@@ -64,8 +64,6 @@ struct kg_sharded_key {
   std::vector<size_t> lo, hi;
   std::vector<uint64_t*> d_bases;
   std::vector<uint8_t*> d_inf;
-  std::vector<uint64_t*> d_scalars;      // per-device scalar staging, grown on demand
-  std::vector<size_t> scalars_cap;
 };
 
 extern "C" {
@@ -117,7 +115,6 @@ int kg_sharded_key_create(kg_ctx* const* ctxs, int n_ctx, int curve, const uint6
   K->curve = curve; K->n = n;
   K->lo.resize((size_t)n_ctx); K->hi.resize((size_t)n_ctx);
   K->d_bases.assign((size_t)n_ctx, nullptr); K->d_inf.assign((size_t)n_ctx, nullptr);
-  K->d_scalars.assign((size_t)n_ctx, nullptr); K->scalars_cap.assign((size_t)n_ctx, 0);
   const size_t wb = (size_t)words_of(curve) * 8;
   const int rc = for_each_ctx(n_ctx, [&](int i) {
     size_t lo, hi;
@@ -145,7 +142,6 @@ void kg_sharded_key_destroy(kg_sharded_key* K) {
     kg_ctx* c = K->ctxs[i];
     if (K->d_bases[i]) kg_free(c, K->d_bases[i]);        // kg_free drops the registration with the array
     if (K->d_inf[i]) kg_free(c, K->d_inf[i]);
-    if (K->d_scalars[i]) kg_free(c, K->d_scalars[i]);
   }
   delete K;
 }
@@ -164,13 +160,9 @@ int kg_sharded_key_commit(kg_sharded_key* K, const uint64_t* h_scalars, size_t n
     kg_ctx* c = K->ctxs[(size_t)i];
     uint64_t* part = xyz.data() + (size_t)i * 3 * E;
     if (!cnt) { msm_identity(K->curve, part); return (int)KG_OK; }
-    if (K->scalars_cap[(size_t)i] < cnt) {
-      if (K->d_scalars[(size_t)i]) { KG_TRY(kg_free(c, K->d_scalars[(size_t)i])); K->d_scalars[(size_t)i] = nullptr; K->scalars_cap[(size_t)i] = 0; }
-      KG_TRY(kg_malloc(c, cnt * 32, (void**)&K->d_scalars[(size_t)i]));
-      K->scalars_cap[(size_t)i] = cnt;
-    }
-    KG_TRY(kg_memcpy_h2d(c, K->d_scalars[(size_t)i], h_scalars + 4 * lo, cnt * 32));
-    return kg_msm(c, K->curve, K->d_bases[(size_t)i], K->d_inf[(size_t)i], K->d_scalars[(size_t)i], cnt, part);
+    // the slice's scalars travel in index sub-slices, each sorted and accumulated while the next one is on the bus (msm_host.cpp):
+    // one synchronous copy in front of a blocking MSM would add the whole upload (10 ms per 2^24 scalars) to every commit
+    return kg_msm_host_scalars(c, K->curve, K->d_bases[(size_t)i], K->d_inf[(size_t)i], h_scalars + 4 * lo, cnt, part);
   });
   if (rc != KG_OK) return rc;
   return combine(K->ctxs[0], K->curve, xyz, n_ctx, out_xy, out_inf);

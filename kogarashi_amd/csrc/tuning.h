@@ -38,7 +38,6 @@
   /* ---- host-scalar entries (kg_msm_host_scalars, kg_sharded_key_commit) ------------------------------------------------------------ */ \
   X(host_slices, "KG_HOST_SLICES", 0, "index slices a host-scalar MSM is uploaded and run in: 0 = automatic (by length), 1..8") \
   X(host_first_div, "KG_HOST_FIRST_DIV", 0, "the first slice (whose upload nothing hides) is 1/div of an equal share: 0 = automatic") \
-  X(host_pinned, "KG_HOST_PINNED", -1, "upload path of host scalars: -1 automatic, 0 = hipMemcpyAsync straight from the caller's pages, 1 = through the context's pinned staging ring") \
   /* ---- experiments compiled only with -DKG_EXPERIMENTS ----------------------------------------------------------------------------- */ \
   X(acc_prefetch, "KG_ACC_PREFETCH", 0, "experiment: 1 = accumulation with the next base prefetched into LDS (k_acc_tasks_q; measured level)") \
   X(acc_prefetch_log, "KG_ACC_PREFETCH_LOG", 0, "experiment: log2 of the array length from which KG_ACC_PREFETCH applies") \

@@ -25,6 +25,7 @@ EXPORTS = [
     "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
     "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_r1cs_begin", "kg_groth16_prove_sharded", "kg_ntt_plan",
+    "kg_msm_host_scalars", "kg_commit_host_scalars", "kg_tuning_describe", "kg_mem_info",
 ]
 
 
@@ -103,6 +104,18 @@ def ntt_plan(log_n: int) -> list[tuple[int, int]]:
     return [(int(m[i]), int(t[i])) for i in range(s)]
 
 
+def tuning_table() -> list[dict]:
+    """kg_tuning_describe: every environment knob of the library -- name, description, default, value in this process"""
+    lib = load()
+    rows = []
+    for i in range(int(lib.kg_tuning_describe(-1, None, None, None, None))):
+        env, doc, d, v = C.c_char_p(), C.c_char_p(), C.c_int(), C.c_int()
+        if lib.kg_tuning_describe(i, C.byref(env), C.byref(doc), C.byref(d), C.byref(v)) != 0:
+            raise KogarashiError("kg_tuning_describe")
+        rows.append({"env": env.value.decode(), "doc": doc.value.decode(), "default": d.value, "value": v.value})
+    return rows
+
+
 def msm_pick_window(n: int) -> int:
     """kg_msm_pick_window: the automatic window width for n pairs (no device needed)"""
     return int(load().kg_msm_pick_window(C.c_size_t(n)))
@@ -154,6 +167,12 @@ class Context:
         p = C.c_void_p()
         self._chk(self._lib.kg_malloc(self._h, C.c_size_t(nbytes), C.byref(p)), "kg_malloc")
         return p.value
+
+    def mem_info(self) -> tuple[int, int]:
+        """(free, total) bytes of the context's device (kg_mem_info)"""
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        self._chk(self._lib.kg_mem_info(self._h, C.byref(f), C.byref(t)), "kg_mem_info")
+        return int(f.value), int(t.value)
 
     def free(self, dptr: int):
         self._chk(self._lib.kg_free(self._h, _vp(dptr)), "kg_free")
@@ -242,6 +261,22 @@ class Context:
         self._chk(self._lib.kg_msm_host(self._h, curve, bases.ctypes.data_as(C.c_void_p), ip, scalars.ctypes.data_as(C.c_void_p),
                                         C.c_size_t(n), out.ctypes.data_as(C.c_void_p)), "kg_msm_host")
         return out
+
+    def msm_host_scalars(self, curve: int, bases: int, inf: int, scalars: np.ndarray, n: int) -> np.ndarray:
+        """kg_msm_host_scalars: device bases (registered or not), HOST scalars -- the per-call shape of the reference's call sites"""
+        out = np.zeros(24 if curve == KG_G2 else 12, dtype=np.uint64)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        self._chk(self._lib.kg_msm_host_scalars(self._h, curve, _vp(bases), _vp(inf), scalars.ctypes.data_as(C.c_void_p), C.c_size_t(n),
+                                                out.ctypes.data_as(C.c_void_p)), "kg_msm_host_scalars")
+        return out
+
+    def commit_host_scalars(self, curve: int, bases: int, inf: int, scalars: np.ndarray, n: int):
+        xy = np.zeros(16 if curve == KG_G2 else 8, dtype=np.uint64)
+        oi = C.c_uint8(0)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        self._chk(self._lib.kg_commit_host_scalars(self._h, curve, _vp(bases), _vp(inf), scalars.ctypes.data_as(C.c_void_p), C.c_size_t(n),
+                                                   xy.ctypes.data_as(C.c_void_p), C.byref(oi)), "kg_commit_host_scalars")
+        return xy, int(oi.value)
 
     def commit(self, curve: int, bases: int, inf: int, scalars: int, n: int):
         xy = np.zeros(16 if curve == KG_G2 else 8, dtype=np.uint64)

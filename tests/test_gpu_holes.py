@@ -1,0 +1,195 @@
+"""Round-5 test holes: MSMs longer than 2^24 (groth16/src/msm.rs:6-48 takes any length), the caller-stream
+contract of kg_ctx_set_stream, and allocation failures (the library never aborts -- KG_ERR_OOM, context intact)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = 0x4B6F676172617368
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import kogarashi_amd as K
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+# ---- MSMs beyond 2^24 pairs ------------------------------------------------------------------------------------------------------
+def test_msm_2_25_matches_the_oracles_pippenger(ctx, oracle):
+    """2^25 pairs: past the two-pass sort's index field, kg_msm runs four index slices of 2^23 (c = 17 each) and adds their sums.
+    Against the oracle's restatement of msm_curve_addition at full size (window rule c = 19, one thread per window)."""
+    import kogarashi_amd as K
+    n = 1 << 25
+    g, m = ctx.empty((n, 8)), ctx.empty((n, 4))
+    ctx.gen_bases(K.KG_G1, SEED + 60, 0, n, g.ptr)
+    ctx.gen_scalars(K.KG_FR, SEED + 61, 0, n, m.ptr)
+    got = ctx.msm(K.KG_G1, g.ptr, 0, m.ptr, n)
+    want_xy, want_inf = oracle.to_affine("g1", oracle.msm("g1", g.numpy(), m.numpy(), None, threads=14))
+    assert not want_inf and (got[:8] == want_xy).all() and (got[8:] == oracle.f_consts(1)["r"]).all()
+    # the same pairs with the scalars in host memory (eight slices of 2^22 under the uploads)
+    assert (ctx.msm_host_scalars(K.KG_G1, g.ptr, 0, m.numpy(), n) == got).all()
+
+
+def test_msm_2_26_plus_ragged_equals_the_sum_of_its_parts(ctx):
+    """2^26 + 12345 pairs: slices longer than 2^24 fall back to c = 16 with the ONE-pass sort (whole-window histogram in LDS, 32-bit
+    entries).  Size-independent property: MSM(whole) = sum of MSM(part) over a ragged cut into parts the tested paths cover
+    (<= 2^24: two-pass sort, window groups / wide windows), added with kg_points_sum_affine."""
+    import kogarashi_amd as K
+    n = (1 << 26) + 12345
+    g, m = ctx.empty((n, 8)), ctx.empty((n, 4))
+    ctx.gen_bases(K.KG_G1, SEED + 62, 0, n, g.ptr)
+    ctx.gen_scalars(K.KG_FR, SEED + 63, 0, n, m.ptr)
+    whole = ctx.msm(K.KG_G1, g.ptr, 0, m.ptr, n)
+    cuts = [0, (1 << 24), (1 << 24) + (1 << 23) + 77, 3 * (1 << 24) - 5, (1 << 26) - 1, n]
+    parts, infs = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        xy, inf = ctx.commit(K.KG_G1, g.ptr + lo * 64, 0, m.ptr + lo * 32, hi - lo)
+        parts.append(xy); infs.append(inf)
+    xy, inf = ctx.points_sum_affine(K.KG_G1, np.stack(parts), np.array(infs, dtype=np.uint8))
+    assert not inf and (whole[:8] == xy).all()
+    # and a length just past the two-pass limit, unsliced (kg_msm_begin never slices): one pass, c = 16
+    n1 = (1 << 24) + 3
+    ctx.msm_begin(K.KG_G1, g.ptr, 0, m.ptr, n1, 0)
+    one_pass = ctx.msm_end(K.KG_G1, 0)
+    a = ctx.commit(K.KG_G1, g.ptr, 0, m.ptr, 1 << 24)
+    b = ctx.commit(K.KG_G1, g.ptr + (1 << 24) * 64, 0, m.ptr + (1 << 24) * 32, 3)
+    xy, inf = ctx.points_sum_affine(K.KG_G1, np.stack([a[0], b[0]]), np.array([a[1], b[1]], dtype=np.uint8))
+    assert not inf and (one_pass[:8] == xy).all()
+
+
+# ---- kg_ctx_set_stream -----------------------------------------------------------------------------------------------------------
+def test_caller_stream_orders_producers_before_the_msm_and_the_ntt(oracle):
+    """A torch host hands the library its current stream (kg_ctx_set_stream) and enqueues, WITHOUT synchronising: a long torch kernel
+    chain, a device copy that produces the inputs, kg_field_vec_op (the producer kernel on the caller's stream), then kg_msm and
+    kg_ntt on its output.  The MSM's scalar side runs on the library's own queues: it must be ordered behind everything the caller's
+    stream holds (stream semantics, include/kogarashi_amd.h kg_ctx_set_inputs_complete) -- a missing hand-over would read the
+    zero-filled buffers.  Then back to the context's own stream."""
+    import torch
+    import kogarashi_amd as K
+    O, n, k = oracle, (1 << 17) + 11, 14
+    ctx = K.Context(0)
+    dev = torch.device("cuda", 0)
+    bases = O.gen_bases(0, SEED + 70, 0, n)
+    a, b = O.gen_scalars(0, SEED + 71, 0, n), O.gen_scalars(0, SEED + 72, 0, n)
+    want_s = O.f_vec_mul(0, a, b)
+    want_xy, want_inf = O.to_affine("g1", O.msm("g1", bases, want_s, None, threads=8))
+    want_ntt = O.Fft(k).coset_dft(want_s[: 1 << k])
+    t_bases = torch.from_numpy(bases.view(np.int64).reshape(-1)).to(dev)
+    src_a = torch.from_numpy(a.view(np.int64).reshape(-1)).to(dev)
+    src_b = torch.from_numpy(b.view(np.int64).reshape(-1)).to(dev)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream(device=dev)
+    for rep in range(3):
+        t_a, t_b = torch.zeros_like(src_a), torch.zeros_like(src_b)
+        t_s = torch.zeros_like(src_a)
+        t_v = torch.zeros(4 << k, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        ctx.set_stream(s.cuda_stream)
+        with torch.cuda.stream(s):
+            x = torch.randn(4096, 4096, device=dev)
+            for _ in range(40):                      # ~10 ms of matrix products in front of the producers
+                x = (x @ x).clamp_(-1, 1)
+            t_a.copy_(src_a, non_blocking=True)
+            t_b.copy_(src_b, non_blocking=True)
+            ctx.field_vec_op(K.KG_FR, "mul", t_a.data_ptr(), t_b.data_ptr(), t_s.data_ptr(), n)
+            got = ctx.msm(K.KG_G1, t_bases.data_ptr(), 0, t_s.data_ptr(), n)              # blocking: window groups, scalar queue
+            ctx.msm_begin(K.KG_G1, t_bases.data_ptr(), 0, t_s.data_ptr(), n, 1)           # ticketed: scalar queue behind the main queue
+            t_v.copy_(t_s[: 4 << k], non_blocking=True)                                     # torch op behind the library's producer
+            ctx.ntt(t_v.data_ptr(), k, False, True)
+            got_t = ctx.msm_end(K.KG_G1, 1)
+            s.synchronize()
+        assert not want_inf and (got[:8] == want_xy).all() and (got_t == got).all(), rep
+        assert (t_v.cpu().numpy().view(np.uint64).reshape(-1, 4) == want_ntt).all(), rep
+        ctx.set_stream(0)                            # the context's own stream again (drains the caller's)
+        d = ctx.upload(want_s)
+        assert (ctx.msm(K.KG_G1, t_bases.data_ptr(), 0, d.ptr, n) == got).all()
+    ctx.close()
+
+
+# ---- allocation failures ---------------------------------------------------------------------------------------------------------
+def _hog(ctx, leave):
+    """device allocations until at most `leave` bytes are free; returns them"""
+    held = []
+    for chunk in (64 << 30, 8 << 30, 1 << 30, 128 << 20, 16 << 20):
+        while True:
+            free, _ = ctx.mem_info()
+            if free <= leave + chunk:
+                break
+            try:
+                held.append(ctx.malloc(chunk))
+            except Exception:
+                break
+    return held
+
+
+def test_absurd_allocation_is_a_status_code_and_the_context_survives(ctx, oracle):
+    import kogarashi_amd as K
+    with pytest.raises(K.KogarashiError, match="out of device memory"):
+        ctx.malloc(1 << 50)
+    free, total = ctx.mem_info()
+    assert 0 < free <= total and total > (200 << 30)                # an MI355X: 288 GB
+    n = 3000
+    b, s = oracle.gen_bases(0, SEED + 80, 0, n), oracle.gen_scalars(0, SEED + 81, 0, n)
+    want_xy, _ = oracle.to_affine("g1", oracle.msm("g1", b, s, None, threads=4))
+    assert (ctx.msm_host(K.KG_G1, b, None, s, n)[:8] == want_xy).all()
+
+
+def test_work_space_refused_is_oom_and_the_call_succeeds_once_memory_is_back(oracle):
+    """The device is filled up to 48 MiB: a 2^20-pair MSM's work space (hundreds of MiB), the host-scalar entry's upload buffer and
+    a Groth16-size NTT buffer are refused -> KG_ERR_OOM each, nothing aborts; after the memory is released the same calls succeed
+    and give the oracle's results."""
+    import kogarashi_amd as K
+    O, n, k = oracle, 1 << 20, 20
+    ctx = K.Context(0)
+    g, m = ctx.empty((n, 8)), ctx.empty((n, 4))
+    ctx.gen_bases(K.KG_G1, SEED + 82, 0, n, g.ptr)
+    ctx.gen_scalars(K.KG_FR, SEED + 83, 0, n, m.ptr)
+    hm = m.numpy()
+    v = ctx.empty((1 << 22, 4))                                    # a 2^22 transform needs a 128 MiB ping-pong buffer
+    ctx.bases_register(K.KG_G1, g.ptr, 0, n)                       # (the resident copy exists before the device fills up)
+    small = ctx.msm(K.KG_G1, g.ptr, 0, m.ptr, 1000)                # queues, events, small work spaces exist
+    held = _hog(ctx, 48 << 20)
+    assert ctx.mem_info()[0] <= (48 << 20) + (16 << 20)
+    for call in (lambda: ctx.msm(K.KG_G1, g.ptr, 0, m.ptr, n),
+                 lambda: ctx.msm_host_scalars(K.KG_G1, g.ptr, 0, hm, n),
+                 lambda: ctx.msm_begin(K.KG_G1, g.ptr, 0, m.ptr, n, 0),
+                 lambda: ctx.ntt(v.ptr, 22, False, False),
+                 lambda: ctx.bases_precompute(g.ptr)):              # 15 windows x 64 MiB
+        with pytest.raises(K.KogarashiError, match="out of device memory"):
+            call()
+    assert (ctx.msm(K.KG_G1, g.ptr, 0, m.ptr, 1000) == small).all()           # what fits still runs
+    for p in held:
+        ctx.free(p)
+    got = ctx.msm(K.KG_G1, g.ptr, 0, m.ptr, n)
+    want_xy, want_inf = O.to_affine("g1", O.msm("g1", g.numpy(), hm, None, threads=14))
+    assert not want_inf and (got[:8] == want_xy).all()
+    assert (ctx.msm_host_scalars(K.KG_G1, g.ptr, 0, hm, n) == got).all()
+    ctx.msm_begin(K.KG_G1, g.ptr, 0, m.ptr, n, 0)
+    assert (ctx.msm_end(K.KG_G1, 0) == got).all()
+    ctx.ntt(m.ptr, k, False, False)
+    assert (m.numpy() == O.Fft(k).dft(hm)).all()
+    ctx.close()
+
+
+def test_ntt_direct_tables_refused_fall_back_to_composed_twiddles(oracle):
+    """2^22 transform with the device filled so that the 151 MB direct inter-step table cannot be allocated while the small tables
+    can: the step composes its twiddles instead (ntt.hip get_tables) -- the transform succeeds and equals the oracle's."""
+    import kogarashi_amd as K
+    O, k = oracle, 22
+    n = 1 << k
+    ctx = K.Context(0)
+    v = ctx.empty((n, 4))
+    ctx.gen_scalars(K.KG_FR, SEED + 84, 0, n, v.ptr)
+    hv = v.numpy()
+    ctx.ntt(v.ptr, k, False, False)                                  # forward: ping-pong buffer and forward tables (direct) exist now
+    fwd = v.numpy()
+    assert (fwd == O.Fft(k).dft(hv)).all()
+    held = _hog(ctx, 100 << 20)                                      # < 151 MB: the inverse's direct table is refused, its small tables fit
+    ctx.ntt(v.ptr, k, True, False)
+    for p in held:
+        ctx.free(p)
+    assert (v.numpy() == hv).all()                                   # idft(dft(v)) = v, through composed twiddles
+    ctx.ntt(v.ptr, k, False, True)                                   # and the same context keeps working: coset_dft with the fwd tables
+    assert (v.numpy() == O.Fft(k).coset_dft(hv)).all()
+    ctx.close()

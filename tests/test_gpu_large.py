@@ -106,8 +106,11 @@ def test_commit_2_24_matches_the_oracles_pippenger(ctx, oracle, curve, sfd, cv):
     # and with the key resident (kg_bases_register), as PedersenCommitment { g } is
     ctx.bases_register(curve, g.ptr, 0, n)
     reg_xy, reg_inf = ctx.commit(curve, g.ptr, 0, m.ptr, n)
+    # and as pedersen.rs:15-20 is called: the key resident, the 2^24 scalars a host slice (eight index slices, uploads under the accumulations)
+    host_xy, host_inf = ctx.commit_host_scalars(curve, g.ptr, 0, m.numpy(), n)
     ctx.bases_unregister(g.ptr)
     assert reg_inf == 0 and (reg_xy == want_xy).all()
+    assert host_inf == 0 and (host_xy == want_xy).all()
 
 
 def test_commit_2_24_of_a_witness_like_vector_matches_the_oracles_pippenger(ctx, oracle):
