@@ -38,7 +38,8 @@ typedef enum {
   KG_ERR_OOM = -3,         /* device allocation failed */
   KG_ERR_HIP = -4,         /* a HIP call or kernel launch failed (see kg_last_error) */
   KG_ERR_UNSUPPORTED = -5,
-  KG_ERR_CRS = -6          /* delta is the identity: Error::ProverSubVersionCrsAttack (groth16/src/prover.rs:67-69) */
+  KG_ERR_CRS = -6,         /* delta is the identity: Error::ProverSubVersionCrsAttack (groth16/src/prover.rs:67-69) */
+  KG_ERR_INVERSION = -7    /* a toxic scalar has no inverse: Error::ProverInversionFailed (groth16/src/zksnark.rs:37-38) */
 } kg_status;
 
 /* field / curve selectors */
@@ -47,7 +48,7 @@ enum { KG_G1 = 0, KG_GRUMPKIN = 1, KG_G2 = 2 };      /* curve ids */
 
 typedef struct kg_ctx kg_ctx;
 
-int kg_version(void);                    /* 5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe, kg_mem_info; 4: kg_msm_set_groups, kg_ctx_queue_placement; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
+int kg_version(void);                    /* 5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe, kg_mem_info, kg_groth16_setup_bn254; 4: kg_msm_set_groups, kg_ctx_queue_placement; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
 /* Optional process-level setup; call it (or export the variable yourself) BEFORE anything in the process initialises the
  * HIP runtime -- before the first kg_device_count / kg_ctx_create and before any other HIP user -- and before the host
  * starts threads (it calls setenv).  Sets GPU_MAX_HW_QUEUES=16 unless the variable is already set, so that each of a
@@ -273,6 +274,27 @@ int kg_groth16_prove_sharded(kg_ctx* const* ctxs, int n_ctx, const kg_groth16_cr
                              const uint64_t* const* d_b_eval, const uint64_t* const* d_c_eval, const uint64_t* const* d_x,
                              const uint64_t* const* d_w, const uint64_t* r, const uint64_t* s, uint64_t* proof_out, uint8_t* proof_inf);
 
+/* a sparse matrix in CSR form: row_ptr (rows + 1 entries), col and val (4 words per entry); all device pointers */
+typedef struct { const uint64_t* d_row_ptr; const uint64_t* d_col; const uint64_t* d_val; } kg_csr;
+
+/* ---- Groth16 setup ---------------------------------------------------------------------------------
+ * groth16/src/zksnark.rs:17-127 ZkSnark::setup after circuit synthesis: the CRS of a circuit from the five toxic scalars.
+ * a, b, c: the constraint matrices as CSR over z = x || w (m rows; the same arrays kg_groth16_prove_r1cs_bn254 takes; all device
+ * pointers).  h_toxic: HOST, 5 x 4 words alpha | beta | gamma | delta | tau (the reference draws them from its rng in that order,
+ * zksnark.rs:28-32 -- the shim draws them the same way and passes them in).
+ * crs: on entry its d_* pointers name caller-allocated DEVICE arrays (kg_malloc) of the lengths the struct documents -- h: m - 1,
+ * l: m_l_1, a / b_g1 / b_g2: l + m_l_1 points, one flag byte per point; on return they hold Parameters { h, l, a, b_g1, b_g2 }
+ * (groth16/src/params.rs:6-28), and m, l, m_l_1, alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2 and the two delta flags are
+ * filled in: the struct is ready for kg_groth16_prove_bn254 (register its arrays to keep them in the MSM's internal form).
+ * d_ic / d_ic_inf: DEVICE, l points -- vk.ic; out_gamma_g2: HOST, 16 words; out_vk_inf: HOST, 6 flags in the order alpha_g1,
+ * beta_g1, delta_g1, beta_g2, gamma_g2, delta_g2 (a zero toxic scalar gives an identity).
+ * The powers of tau, the idft, the matrices' transposition (zkstd/src/matrix.rs:17-29 x_and_w), the three transposed products
+ * (eval_at_tau, zksnark.rs:190-194), the linear combinations and every generator multiple run on the device; the host computes
+ * two inversions and tau^n.  KG_ERR_INVERSION when gamma or delta is zero.  Blocking: all outputs are complete on return. */
+int kg_groth16_setup_bn254(kg_ctx* ctx, const kg_csr* a, const kg_csr* b, const kg_csr* c, size_t m, size_t l, size_t m_l_1,
+                           const uint64_t* h_toxic, kg_groth16_crs* crs, uint64_t* d_ic, uint8_t* d_ic_inf, uint64_t* out_gamma_g2,
+                           uint8_t* out_vk_inf);
+
 /* ---- R1CS evaluation -------------------------------------------------------------------------------
  * zkstd/src/matrix.rs:31-33 SparseMatrix::evaluate_with_z (row.rs:43-51): out[i] = sum_e val[e] * z[col[e]] over the
  * entries row_ptr[i] <= e < row_ptr[i+1] of a CSR matrix with m rows; z = x || w (instance wires first).  The step
@@ -291,7 +313,6 @@ int kg_r1cs_prod(kg_ctx* ctx, int field, const uint64_t* d_row_ptr, const uint64
  * matrices as CSR over z = (u | x | w); d_z1 / d_z2: the two z vectors (relaxed instance-witness pair and the fresh one);
  * h_u1, h_u2: HOST, one element each (the reference passes instance1.u and one).  One fused kernel: each matrix row is
  * read once, the six products stay in registers. */
-typedef struct { const uint64_t* d_row_ptr; const uint64_t* d_col; const uint64_t* d_val; } kg_csr;
 int kg_nova_cross_term(kg_ctx* ctx, int field, const kg_csr* a, const kg_csr* b, const kg_csr* c, size_t m, const uint64_t* d_z1,
                        const uint64_t* d_z2, const uint64_t* h_u1, const uint64_t* h_u2, uint64_t* d_out);
 /* create_proof with cs.evaluate() (zkstd/src/r1cs.rs:137-142, prover.rs:33) on the device as well: the constraint matrices

@@ -408,80 +408,36 @@ class NovaProver:
         return t.numpy(), (xy, inf)
 
 
-def _csr_transpose(row_ptr, col, val, m, nvars):
-    """index-only transposition of a CSR matrix (m rows) -> CSR of its transpose (nvars rows, column = constraint);
-    the reference's SparseMatrix::x_and_w (zkstd/src/matrix.rs:17-29)."""
-    row_ptr = np.asarray(row_ptr, dtype=np.int64)
-    col = np.asarray(col, dtype=np.int64)
-    rows = np.repeat(np.arange(m, dtype=np.int64), np.diff(row_ptr))
-    order = np.argsort(col, kind="stable")
-    t_ptr = np.zeros(nvars + 1, dtype=np.uint64)
-    np.add.at(t_ptr, col + 1, 1)
-    t_ptr = np.cumsum(t_ptr).astype(np.uint64)
-    return t_ptr, rows[order].astype(np.uint64), np.ascontiguousarray(np.asarray(val, dtype=np.uint64).reshape(-1, 4)[order])
-
-
-def groth16_setup(a, b, c, m: int, l: int, m_l_1: int, toxic, field_ops, ctx: Context | None = None) -> dict:
-    """ZkSnark::setup (groth16/src/zksnark.rs:17-127) on the device, with the toxic waste injected
+def groth16_setup(a, b, c, m: int, l: int, m_l_1: int, toxic, field_ops=None, ctx: Context | None = None) -> dict:
+    """ZkSnark::setup (groth16/src/zksnark.rs:17-127) on the device through kg_groth16_setup_bn254, with the toxic waste injected
     (alpha, beta, gamma, delta, tau as rows of `toxic`; the reference draws them from its rng, :28-32).
 
-    a, b, c: CSR triples (row_ptr, col, val) over z = x || w.  field_ops: a tiny host-side scalar helper with
-    `inv(x)`, `mul(x, y)`, `sub(x, y)`, `pow2k(x, k)` on single Fr elements (Montgomery limbs) -- only five scalars are
-    touched on the host.  Returns the Parameters dict `Prover` takes (device-computed, downloaded)."""
+    a, b, c: CSR triples (row_ptr, col, val) over z = x || w, host arrays.  Returns the Parameters dict `Prover` takes
+    (device-computed, downloaded).  `field_ops` is accepted for callers of the round-3 signature and ignored: the five host-side
+    scalars are computed behind the boundary now."""
     ctx = ctx or default_context()
     toxic = np.ascontiguousarray(toxic, dtype=np.uint64).reshape(5, 4)
-    alpha, beta, gamma, delta, tau = toxic
-    n, k = 1, 0
-    while n < m:
-        n, k = n << 1, k + 1
-    if k < 1:
-        n, k = 2, 1
-    one = field_ops.one()
-    gamma_inv, delta_inv = field_ops.inv(gamma), field_ops.inv(delta)
-    coeff = field_ops.mul(field_ops.sub(field_ops.pow2k(tau, k), one), delta_inv)     # (tau^n - 1) / delta, zksnark.rs:51-53
     nv = l + m_l_1
-    pw = ctx.empty((n, 4))
-    ctx.field_powers(KG_FR, one, tau, pw.ptr, m)                                      # zksnark.rs:44-49
-    if n > m:
-        ctx.write(pw.ptr + 32 * m, np.zeros((n - m, 4), dtype=np.uint64))
-    h_s = ctx.empty((max(m - 1, 1), 4))
-    if m > 1:
-        ctx.field_vec_scale(KG_FR, pw.ptr, coeff, h_s.ptr, m - 1)                     # zksnark.rs:56-58
-    ctx.ntt(pw.ptr, k, True, False)                                                   # Lagrange coefficients, zksnark.rs:61
-    evals = []
-    for rp, col, val in (a, b, c):                                                    # eval_at_tau over x_and_w, zksnark.rs:190-194
-        t_ptr, t_col, t_val = _csr_transpose(rp, col, val, m, nv)
-        d = [ctx.upload(t_ptr), ctx.upload(t_col if len(t_col) else np.zeros(1, dtype=np.uint64)),
-             ctx.upload(t_val if len(t_val) else np.zeros((1, 4), dtype=np.uint64))]
-        out = ctx.empty((nv, 4))
-        ctx.r1cs_evaluate(d[0].ptr, d[1].ptr, d[2].ptr, nv, pw.ptr, out.ptr)
-        evals.append(out)
-    at, bt, ct = evals
-    ext = ctx.empty((nv, 4))                                                          # (beta*at + alpha*bt + ct) * inv, zksnark.rs:180-187
-    ctx.field_vec_axpy(KG_FR, ct.ptr, beta, at.ptr, ext.ptr, nv)
-    ctx.field_vec_axpy(KG_FR, ext.ptr, alpha, bt.ptr, ext.ptr, nv)
-    ic_s, l_s = ctx.empty((l, 4)), ctx.empty((max(m_l_1, 1), 4))
-    ctx.field_vec_scale(KG_FR, ext.ptr, gamma_inv, ic_s.ptr, l)
-    if m_l_1:
-        ctx.field_vec_scale(KG_FR, ext.ptr + 32 * l, delta_inv, l_s.ptr, m_l_1)
-
-    def points(curve, d_k, cnt, w):
-        xy, inf = ctx.empty((max(cnt, 1), w)), ctx.empty((max(cnt, 1),), dtype=np.uint8)
-        if cnt:
-            ctx.fixed_base_mul(curve, d_k, cnt, xy.ptr, inf.ptr)
-        return xy.numpy()[:cnt], inf.numpy()[:cnt]
-
+    keep, mats = [], []
+    for rp, col, val in (a, b, c):
+        col = np.ascontiguousarray(col, dtype=np.uint64)
+        val = np.ascontiguousarray(val, dtype=np.uint64).reshape(-1, 4)
+        d = [ctx.upload(np.ascontiguousarray(rp, dtype=np.uint64)), ctx.upload(col if len(col) else np.zeros(1, dtype=np.uint64)),
+             ctx.upload(val if len(val) else np.zeros((1, 4), dtype=np.uint64))]
+        keep.append(d)
+        mats.append((d[0].ptr, d[1].ptr, d[2].ptr))
+    lens = {"h": (max(m - 1, 0), 8), "l": (m_l_1, 8), "a": (nv, 8), "b_g1": (nv, 8), "b_g2": (nv, 16), "ic": (l, 8)}
+    dev = {k: (ctx.empty((max(cnt, 1), w)), ctx.empty((max(cnt, 1),), dtype=np.uint8)) for k, (cnt, w) in lens.items()}
+    crs = Groth16Crs()
+    for k in ("h", "l", "a", "b_g1", "b_g2"):
+        setattr(crs, "d_" + k, dev[k][0].ptr)
+        setattr(crs, "d_" + k + "_inf", dev[k][1].ptr)
+    gamma_g2, vk_inf = ctx.groth16_setup(mats[0], mats[1], mats[2], m, l, m_l_1, toxic, crs, dev["ic"][0].ptr, dev["ic"][1].ptr)
     P = {}
-    P["h"], P["h_inf"] = points(KG_G1, h_s.ptr, m - 1, 8)
-    P["l"], P["l_inf"] = points(KG_G1, l_s.ptr, m_l_1, 8)
-    P["a"], P["a_inf"] = points(KG_G1, at.ptr, nv, 8)
-    P["b_g1"], P["b_g1_inf"] = points(KG_G1, bt.ptr, nv, 8)
-    P["b_g2"], P["b_g2_inf"] = points(KG_G2, bt.ptr, nv, 16)
-    P["ic"], P["ic_inf"] = points(KG_G1, ic_s.ptr, l, 8)
-    vk1 = ctx.upload(np.stack([alpha, beta, delta]))
-    vk2 = ctx.upload(np.stack([beta, delta, gamma]))
-    P["vk_g1"], _ = points(KG_G1, vk1.ptr, 3, 8)                                       # zksnark.rs:104-112
-    g2, g2inf = points(KG_G2, vk2.ptr, 3, 16)
-    P["vk_g2"], P["gamma_g2"] = g2[:2], g2[2]
-    P["delta_g1_inf"], P["delta_g2_inf"] = 0, int(g2inf[1])
+    for k, (cnt, w) in lens.items():
+        P[k], P[k + "_inf"] = dev[k][0].numpy()[:cnt], dev[k][1].numpy()[:cnt]
+    P["vk_g1"] = np.stack([np.array(crs.alpha_g1, dtype=np.uint64), np.array(crs.beta_g1, dtype=np.uint64), np.array(crs.delta_g1, dtype=np.uint64)])
+    P["vk_g2"] = np.stack([np.array(crs.beta_g2, dtype=np.uint64), np.array(crs.delta_g2, dtype=np.uint64)])
+    P["gamma_g2"] = gamma_g2
+    P["delta_g1_inf"], P["delta_g2_inf"] = int(crs.delta_g1_inf), int(crs.delta_g2_inf)
     return P

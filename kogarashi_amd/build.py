@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkogarashi_amd.so")
-SOURCES = ["capi.cpp", "tuning.cpp", "sharded.cpp", "msm_host.cpp", "vec.hip", "msm.hip", "ntt.hip", "groth16.hip"]
+SOURCES = ["capi.cpp", "tuning.cpp", "sharded.cpp", "msm_host.cpp", "vec.hip", "msm.hip", "ntt.hip", "groth16.hip", "setup.hip"]
 EXTRA_DEPS = ["../../include/kogarashi_amd.h"]     # plus every header under csrc/ (see _compile)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
          "-ffp-contract=off", "-Xarch_host", "-march=x86-64-v3"]

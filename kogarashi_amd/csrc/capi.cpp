@@ -279,6 +279,7 @@ const char* kg_strerror(int s) {
     case KG_ERR_HIP: return "HIP runtime error";
     case KG_ERR_UNSUPPORTED: return "unsupported";
     case KG_ERR_CRS: return "CRS delta is the identity (ProverSubVersionCrsAttack)";
+    case KG_ERR_INVERSION: return "a toxic scalar has no inverse (ProverInversionFailed)";
     default: return "unknown status";
   }
 }

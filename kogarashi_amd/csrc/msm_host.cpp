@@ -7,6 +7,7 @@
 #include "common.h"
 #include "host_fp.h"
 #include "msm_internal.h"
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -511,6 +512,7 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
   int rc = KG_OK;
   const int sfield = curve == KG_GRUMPKIN ? KG_FQ : KG_FR;
   const bool was_alone = ctx->sort_alone;
+  if (K > 1 && !ctx->acc_stream[1]) { if (create_stream(ctx, &ctx->acc_stream[1], false) != hipSuccess) return set_err(ctx, KG_ERR_HIP, "queue creation"); }
   for (int j = 0; j < K && rc == KG_OK; ++j) {
     const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
     while (up_s.load() <= j) std::this_thread::yield();
@@ -521,6 +523,12 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
     rc = kg::msm_sort(ctx, sfield, d_s + 4 * a, cnt, &S, true);
     ctx->sort_alone = was_alone;
     if (rc != KG_OK) break;
+    if (bases_on_device) {
+      // consecutive slices accumulate on two queues (like the window groups of a blocking kg_msm): the next launch's first waves fill the
+      // chip while this one's last waves drain; the last slice's reduction follows its accumulation on the same queue
+      if (ctx->tune.host_accq > 1 && (j & 1)) S.acc_stream = ctx->acc_stream[1];
+      S.reduce_inline = ctx->tune.group_reduce_inline && K > 1 && j == K - 1;
+    }
     if (!bases_on_device) {
       while (up_b.load() <= j) std::this_thread::yield();
       if (up_rc != (int)hipSuccess) { rc = set_err(ctx, KG_ERR_HIP, "host-to-device upload", (hipError_t)up_rc.load()); break; }

@@ -25,7 +25,7 @@ EXPORTS = [
     "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
     "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_r1cs_begin", "kg_groth16_prove_sharded", "kg_ntt_plan",
-    "kg_msm_host_scalars", "kg_commit_host_scalars", "kg_tuning_describe", "kg_mem_info",
+    "kg_msm_host_scalars", "kg_commit_host_scalars", "kg_tuning_describe", "kg_mem_info", "kg_groth16_setup_bn254",
 ]
 
 
@@ -47,6 +47,10 @@ class Csr(C.Structure):
 
 class KogarashiError(RuntimeError):
     pass
+
+
+class ProverInversionFailed(KogarashiError):
+    """groth16::Error::ProverInversionFailed (groth16/src/zksnark.rs:37-38): gamma or delta is zero"""
 
 
 class ProverSubVersionCrsAttack(KogarashiError):
@@ -382,6 +386,22 @@ class Context:
             raise ProverSubVersionCrsAttack("delta is the identity")
         self._chk(rc, "kg_groth16_prove_end")
         return out[:8].copy(), out[8:24].copy(), out[24:].copy(), inf
+
+    def groth16_setup(self, a, b, c, m: int, l: int, m_l_1: int, toxic: np.ndarray, crs: "Groth16Crs", ic: int, ic_inf: int):
+        """kg_groth16_setup_bn254: a, b, c = (row_ptr, col, val) device pointers; crs carries the output arrays' device pointers and
+        comes back ready for groth16_prove; returns (gamma_g2, vk_inf[6])"""
+        mk = lambda t: Csr(_vp(t[0]), _vp(t[1]), _vp(t[2]))
+        ca, cb, cc = mk(a), mk(b), mk(c)
+        toxic = np.ascontiguousarray(toxic, dtype=np.uint64).reshape(5, 4)
+        gamma_g2 = np.zeros(16, dtype=np.uint64)
+        vk_inf = np.zeros(6, dtype=np.uint8)
+        rc = self._lib.kg_groth16_setup_bn254(self._h, C.byref(ca), C.byref(cb), C.byref(cc), C.c_size_t(m), C.c_size_t(l), C.c_size_t(m_l_1),
+                                              toxic.ctypes.data_as(C.c_void_p), C.byref(crs), _vp(ic), _vp(ic_inf),
+                                              gamma_g2.ctypes.data_as(C.c_void_p), vk_inf.ctypes.data_as(C.c_void_p))
+        if rc == -7:
+            raise ProverInversionFailed("gamma or delta is zero")
+        self._chk(rc, "kg_groth16_setup_bn254")
+        return gamma_g2, vk_inf
 
     def profile_enable(self, on: bool = True):
         self._chk(self._lib.kg_profile_enable(self._h, int(on)), "kg_profile_enable")

@@ -66,6 +66,8 @@ pub const KG_ERR_HIP: i32 = -4;
 pub const KG_ERR_UNSUPPORTED: i32 = -5;
 /// delta is the identity: `Error::ProverSubVersionCrsAttack` (`groth16/src/prover.rs:67-69`)
 pub const KG_ERR_CRS: i32 = -6;
+/// a toxic scalar has no inverse: `Error::ProverInversionFailed` (`groth16/src/zksnark.rs:37-38`)
+pub const KG_ERR_INVERSION: i32 = -7;
 
 // field / curve selectors
 pub const KG_FR: i32 = 0;

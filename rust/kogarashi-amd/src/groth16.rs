@@ -4,10 +4,13 @@
 //! five MSMs (the reference's eight, merged) and the host assembly inside `kg_groth16_prove_r1cs_bn254`, and returns the
 //! three affine points.  (`prove` takes host-side evaluation vectors instead.)
 //!
-//! Several GPUs: the proof is split by task (`kg_groth16_prove_sharded`, SURVEY.md 8e -- the MSMs of prover.rs:51-65 are
-//! independent until the assembly and the G2 query is the long pole): GPU 0 holds `b_g2` and runs that query, GPU 1 % n holds
-//! `a`, `b_g1`, `l` (the three G1 queries against z = x || w), GPU 2 % n holds `h` and runs the transforms and h's MSM; each CRS
-//! vector is uploaded only where it is used.
+//! One GPU per proof is the default: a node's GPUs then serve as many provers (threads) as there are devices, and a proof takes
+//! one context's lock.  `KOGARASHI_AMD_SHARD_GPUS=n` (2 or 3) OPTS IN to splitting ONE proof by task over n GPUs
+//! (`kg_groth16_prove_sharded`, SURVEY.md 8e -- the MSMs of prover.rs:51-65 are independent until the assembly and the G2 query is
+//! the long pole): GPU 0 holds `b_g2` and runs that query, GPU 1 % n holds `a`, `b_g1`, `l` (the three G1 queries against
+//! z = x || w), GPU 2 % n holds `h` and runs the transforms and h's MSM; each CRS vector is uploaded only where it is used, and a
+//! proof locks exactly those n contexts (`Contexts::lock_set`), never the rest of the node.  The sharded path is unmeasured on
+//! multi-GPU hardware -- hence opt-in.
 //!
 //! Host cost per proof (INTEGRATION.md has the table): the constraint matrices are bound to the cached `Parameters` entry -- a
 //! CRS is made for ONE circuit, so a proof against a resident CRS reuses the resident matrices without looking at them; the
@@ -74,6 +77,14 @@ fn words16(p: &G2Affine) -> [u64; 16] {
     v.try_into().unwrap()
 }
 
+/// contexts ONE proof is split over: `KOGARASHI_AMD_SHARD_GPUS` = 2 or 3 opts in, anything else (and unset) is 1
+fn shard_gpus() -> usize {
+    match std::env::var("KOGARASHI_AMD_SHARD_GPUS").ok().and_then(|v| v.parse::<usize>().ok()) {
+        Some(n) if (2..=3).contains(&n) => n,
+        _ => 1,
+    }
+}
+
 fn verify_shape_every_proof() -> bool {
     cfg!(debug_assertions) || std::env::var_os("KOGARASHI_AMD_VERIFY_SHAPE").is_some()
 }
@@ -86,10 +97,10 @@ impl ResidentCrs {
                beta_g1: &G1Affine, delta_g1: &G1Affine, beta_g2: &G2Affine, delta_g2: &G2Affine, m: usize, n_inputs: usize,
                n_aux: usize) -> Result<Self, Status> {
         let ctxs = contexts().ok_or(Status(sys::KG_ERR_NO_DEVICE))?;
-        // KOGARASHI_AMD_ONE_GPU=1 keeps a proof on GPU 0 (then several provers can share the node, one per thread and GPU)
-        let n_ctx = if std::env::var_os("KOGARASHI_AMD_ONE_GPU").is_some() { 1 } else { ctxs.len().min(3) };
+        // one GPU per proof unless the host opts in to the task split (see the module comment)
+        let n_ctx = shard_gpus().min(ctxs.len()).max(1);
         let own = owners(n_ctx);
-        let guards = ctxs.lock_all().ok_or(Status(sys::KG_ERR_BAD_ARG))?;
+        let (_, guards) = ctxs.lock_set(&own).ok_or(Status(sys::KG_ERR_BAD_ARG))?;      // contexts 0 .. n_ctx, in index order
         let mut bufs = Vec::new();
         let mut registered = Vec::new();
         let null8 = core::ptr::null::<u64>();
@@ -186,7 +197,7 @@ impl ResidentCrs {
         // several GPUs: the context that runs the transforms evaluates the three matrix-vector products (kg_r1cs_evaluate on
         // the resident CSR), then the task-parallel proof takes the evaluation vectors
         let own = owners(self.n_ctx);
-        let guards = ctxs.lock_all().ok_or(Status(sys::KG_ERR_BAD_ARG))?;
+        let (_, guards) = ctxs.lock_set(&own).ok_or(Status(sys::KG_ERR_BAD_ARG))?;      // exactly the contexts the proof uses
         let hc = &*guards[own[2]];
         let shape = self.shape_for(hc, &mut matrices, x.len(), x.len() + w.len())?;
         let m3 = &shape.as_ref().unwrap().m;
@@ -253,7 +264,7 @@ impl ResidentCrs {
         let ctxs = contexts().ok_or(Status(sys::KG_ERR_NO_DEVICE))?;
         let words = |v: &[Fr]| unsafe { core::slice::from_raw_parts(v.as_ptr() as *const u64, 4 * v.len()) };
         if self.n_ctx > 1 {
-            let guards = ctxs.lock_all().ok_or(Status(sys::KG_ERR_BAD_ARG))?;
+            let (_, guards) = ctxs.lock_set(&owners(self.n_ctx)).ok_or(Status(sys::KG_ERR_BAD_ARG))?;
             let hc = &*guards[owners(self.n_ctx)[2]];
             let (da, db, dc) = (DeviceBuf::from_words(hc, words(a))?, DeviceBuf::from_words(hc, words(b))?, DeviceBuf::from_words(hc, words(c))?);
             return self.prove_sharded(&guards, [da.as_u64(), db.as_u64(), dc.as_u64()], x, w, r, s);
@@ -309,6 +320,86 @@ pub fn resident(h: &[G1Affine], l: &[G1Affine], a: &[G1Affine], b_g1: &[G1Affine
     let crs = ResidentCrs::new(h, l, a, b_g1, b_g2, alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, m, n_inputs, n_aux).ok().map(Arc::new);
     cache.insert(key, (crs.clone(), guard, m));
     crs
+}
+
+/// What `ZkSnark::setup` assembles into `Parameters` / `VerifyingKey` (groth16/src/zksnark.rs:104-124).
+pub struct SetupOutput {
+    pub h: Vec<G1Affine>,
+    pub l: Vec<G1Affine>,
+    pub a: Vec<G1Affine>,
+    pub b_g1: Vec<G1Affine>,
+    pub b_g2: Vec<G2Affine>,
+    pub ic: Vec<G1Affine>,
+    pub alpha_g1: G1Affine,
+    pub beta_g1: G1Affine,
+    pub beta_g2: G2Affine,
+    pub gamma_g2: G2Affine,
+    pub delta_g1: G1Affine,
+    pub delta_g2: G2Affine,
+}
+
+fn download<C: GpuCurve>(xy: &DeviceBuf, inf: &DeviceBuf, n: usize) -> Result<Vec<C>, Status> {
+    let mut w = vec![0u64; n * C::WORDS];
+    let mut f = vec![0u64; (n + 7) / 8];
+    xy.read_words(&mut w)?;
+    inf.read_words(&mut f)?;
+    let flags = unsafe { core::slice::from_raw_parts(f.as_ptr() as *const u8, n) };
+    Ok((0..n).map(|i| C::affine_from(&w[i * C::WORDS..(i + 1) * C::WORDS], flags[i] != 0)).collect())
+}
+
+/// `ZkSnark::setup` after circuit synthesis and after the toxic waste has been drawn (zksnark.rs:28-38): the CRS of the
+/// circuit (a, b, c) = cs.matrices() from toxic = [alpha, beta, gamma, delta, tau], computed by `kg_groth16_setup_bn254` on GPU 0
+/// -- powers of tau, idft, transposition (x_and_w), the transposed products (eval_at_tau), the linear combinations and every
+/// generator multiple.  `None` (no device, any non-zero status -- a zero gamma / delta never reaches this call: the
+/// reference has returned `ProverInversionFailed` before) lets the CPU body run.
+pub fn setup(a: &SparseMatrix<Fr>, b: &SparseMatrix<Fr>, c: &SparseMatrix<Fr>, m: usize, n_inputs: usize, n_aux: usize, toxic: &[Fr; 5])
+             -> Option<SetupOutput> {
+    if m == 0 {
+        return None;
+    }
+    let ctxs = contexts()?;
+    let ctx = ctxs.lock(0)?;
+    let ctx = &*ctx;
+    let print = content_hash([a, b, c], n_inputs)?;
+    let shape = ResidentShape::build(ctx, a, b, c, n_inputs, print)?;
+    let nv = n_inputs + n_aux;
+    if !shape.covers(m, nv) {
+        return None;
+    }
+    let buf = |points: usize, words: usize| -> Option<(DeviceBuf, DeviceBuf)> {
+        Some((DeviceBuf::new(ctx, points.max(1) * words * 8).ok()?, DeviceBuf::new(ctx, (points.max(1) + 7) / 8 * 8).ok()?))
+    };
+    let (h, l, qa, qb1, qb2, ic) = (buf(m - 1, 8)?, buf(n_aux, 8)?, buf(nv, 8)?, buf(nv, 8)?, buf(nv, 16)?, buf(n_inputs, 8)?);
+    let mut crs = sys::KgGroth16Crs {
+        m, l: n_inputs, m_l_1: n_aux,
+        d_h: h.0.as_u64(), d_h_inf: h.1.as_u8(), d_l: l.0.as_u64(), d_l_inf: l.1.as_u8(), d_a: qa.0.as_u64(), d_a_inf: qa.1.as_u8(),
+        d_b_g1: qb1.0.as_u64(), d_b_g1_inf: qb1.1.as_u8(), d_b_g2: qb2.0.as_u64(), d_b_g2_inf: qb2.1.as_u8(),
+        alpha_g1: [0; 8], beta_g1: [0; 8], delta_g1: [0; 8], beta_g2: [0; 16], delta_g2: [0; 16], delta_g1_inf: 0, delta_g2_inf: 0,
+    };
+    let (ca, cb, cc) = (shape.m[0].csr(), shape.m[1].csr(), shape.m[2].csr());
+    let mut gamma_g2 = [0u64; 16];
+    let mut vk_inf = [0u8; 6];
+    let rc = unsafe {
+        sys::kg_groth16_setup_bn254(ctx.raw(), &ca, &cb, &cc, m, n_inputs, n_aux, toxic.as_ptr() as *const u64, &mut crs, ic.0.as_u64(),
+                                    ic.1.as_u8(), gamma_g2.as_mut_ptr(), vk_inf.as_mut_ptr())
+    };
+    if rc != sys::KG_OK {
+        return None;
+    }
+    Some(SetupOutput {
+        h: download(&h.0, &h.1, m - 1).ok()?,
+        l: download(&l.0, &l.1, n_aux).ok()?,
+        a: download(&qa.0, &qa.1, nv).ok()?,
+        b_g1: download(&qb1.0, &qb1.1, nv).ok()?,
+        b_g2: download(&qb2.0, &qb2.1, nv).ok()?,
+        ic: download(&ic.0, &ic.1, n_inputs).ok()?,
+        alpha_g1: G1Affine::affine_from(&crs.alpha_g1, vk_inf[0] != 0),
+        beta_g1: G1Affine::affine_from(&crs.beta_g1, vk_inf[1] != 0),
+        delta_g1: G1Affine::affine_from(&crs.delta_g1, vk_inf[2] != 0),
+        beta_g2: G2Affine::affine_from(&crs.beta_g2, vk_inf[3] != 0),
+        gamma_g2: G2Affine::affine_from(&gamma_g2, vk_inf[4] != 0),
+        delta_g2: G2Affine::affine_from(&crs.delta_g2, vk_inf[5] != 0),
+    })
 }
 
 impl Drop for ResidentCrs {

@@ -152,6 +152,19 @@ mod global {
             }
             self.0.get(start)?.0.lock().ok()
         }
+        /// the contexts `idx` names (duplicates allowed), locked in ascending index order (one order everywhere: no deadlock);
+        /// the result holds one guard per DISTINCT index, sorted -- `position(i)` finds a context's guard.  For calls that
+        /// span a few GPUs (`kg_groth16_prove_sharded` over three) without stopping the node's other callers.
+        pub fn lock_set(&self, idx: &[usize]) -> Option<(Vec<usize>, Vec<MutexGuard<'_, Context>>)> {
+            let mut order: Vec<usize> = idx.to_vec();
+            order.sort_unstable();
+            order.dedup();
+            let mut v = Vec::with_capacity(order.len());
+            for &i in order.iter() {
+                v.push(self.0.get(i)?.0.lock().ok()?);
+            }
+            Some((order, v))
+        }
         /// every context, in index order (one order everywhere: no deadlock), for the calls that span the node
         /// (`kg_sharded_key_*`, `kg_groth16_prove_sharded`)
         pub fn lock_all(&self) -> Option<Vec<MutexGuard<'_, Context>>> {
@@ -313,31 +326,139 @@ pub(crate) fn marshal<C: GpuCurve>(pts: &[C]) -> (Vec<u64>, Vec<u8>) {
     (xy, inf)
 }
 
-/// Bases an MSM has met before, resident on GPU 0 in the MSM's internal form (`kg_bases_register`): keyed by the slice's address
-/// and length and guarded by a three-point probe (first, middle, last point) against a freed and re-used allocation -- an
-/// address-keyed cache, like `pedersen.rs`; a slice whose interior is rewritten in place between calls while its ends and its
-/// middle stay is NOT noticed (the reference's callers pass CRS vectors and commitment keys, which are immutable).  Marshalling
-/// 2^20 `repr(Rust)` points through `get_x() / get_y()` costs tens of milliseconds and the upload 1.3 ms (64 MB over PCIe) around a
-/// 1.8 ms device MSM: both are paid once per slice, a call then uploads its scalars (32 MB, 0.7 ms) and runs `kg_msm`.
-struct ResidentBases {
+/// How `msm` treats the base slice of a call (`KOGARASHI_AMD_MSM_RESIDENT`, read once):
+///   unset / `probe`  keep the slice resident on GPU 0 in the MSM's internal form (`kg_bases_register`), keyed by address, length and
+///                    curve, and re-validate it on EVERY call with a sampled content digest: up to 256 evenly spaced points, every
+///                    coordinate word and the identity flag of each.  The reference's callers pass CRS vectors and commitment keys,
+///                    which are immutable (`groth16/src/params.rs:6-28`, `nova/src/pedersen.rs:6-13`); a caller that rewrites a base
+///                    slice IN PLACE between calls, at an index the sample happens to miss, must use `hash` or `0`.
+///   `hash`           the same cache, validated with a digest of EVERY point on every call: O(n) host work (a few ms per 2^20 points)
+///                    in front of a 1.6 ms MSM -- exact, for hosts that mutate base slices.
+///   `0`              nothing is kept: every call marshals and uploads its bases (`kg_msm_host`).
+/// `register_bases` / `ResidentMsmBases::msm` is the explicit alternative: the caller owns the handle and the promise.
+#[derive(Clone, Copy, PartialEq, Eq)]
+enum ResidencyMode {
+    Off,
+    Probe,
+    Hash,
+}
+fn residency_mode() -> ResidencyMode {
+    static MODE: Mutex<Option<ResidencyMode>> = Mutex::new(None);
+    let mut m = match MODE.lock() {
+        Ok(m) => m,
+        Err(_) => return ResidencyMode::Off,
+    };
+    *m.get_or_insert_with(|| match std::env::var("KOGARASHI_AMD_MSM_RESIDENT").ok().as_deref() {
+        Some("0") | Some("off") => ResidencyMode::Off,
+        Some("hash") => ResidencyMode::Hash,
+        _ => ResidencyMode::Probe,
+    })
+}
+
+/// 128-bit digest of the points at `step`-spaced indices (always including the last one): every coordinate word and the flag.
+/// `step` = 1 is the full content hash.  Not cryptographic: it guards a cache against stale content, not against an adversary.
+fn digest<C: GpuCurve>(pts: &[C], step: usize) -> [u64; 2] {
+    let (mut h1, mut h2) = (0xcbf2_9ce4_8422_2325u64, 0x9e37_79b9_7f4a_7c15u64);
+    let mut words = Vec::with_capacity(C::WORDS);
+    let mut take = |i: usize, h1: &mut u64, h2: &mut u64| {
+        words.clear();
+        pts[i].put_xy(&mut words);
+        let flag = pts[i].is_identity() as u64;
+        for &w in words.iter().chain(core::iter::once(&(flag ^ (i as u64).rotate_left(17)))) {
+            *h1 = (*h1 ^ w).wrapping_mul(0x0000_0100_0000_01b3);
+            *h2 = (h2.rotate_left(23) ^ w).wrapping_mul(0xff51_afd7_ed55_8ccd).wrapping_add(0x2545_f491_4f6c_dd1d);
+        }
+    };
+    let n = pts.len();
+    let mut i = 0;
+    while i < n {
+        take(i, &mut h1, &mut h2);
+        i += step.max(1);
+    }
+    if n > 0 {
+        take(n - 1, &mut h1, &mut h2);
+    }
+    [h1, h2 ^ n as u64]
+}
+const PROBE_POINTS: usize = 256;
+fn digest_for<C: GpuCurve>(pts: &[C], mode: ResidencyMode) -> [u64; 2] {
+    let step = if mode == ResidencyMode::Hash { 1 } else { (pts.len() / PROBE_POINTS).max(1) };
+    digest(pts, step)
+}
+
+/// A base slice resident on GPU 0 in the MSM's internal form (`kg_bases_register`).  Dropping its buffers releases the
+/// registration too (`kg_free` unregisters the array it frees); whoever drops it holds GPU 0's lock.
+struct Resident {
     xy: DeviceBuf,
     inf: Option<DeviceBuf>,
-    scalars: DeviceBuf,
-    probe: [u64; 6],
+    n: usize,
+    curve: i32,
+    digest: [u64; 2],
     stamp: u64,
 }
-unsafe impl Send for ResidentBases {}
-const MSM_CACHE_SLOTS: usize = 8;
-static MSM_BASES: Mutex<Option<(u64, HashMap<(usize, usize, i32), ResidentBases>)>> = Mutex::new(None);
-
-fn probe3<C: GpuCurve>(pts: &[C]) -> [u64; 6] {
-    let n = pts.len();
-    let three = [pts[0], pts[n / 2], pts[n - 1]];
-    let (xy, _) = marshal(&three);
-    let at = |i: usize| (xy[i * C::WORDS], xy[i * C::WORDS + C::WORDS / 2]);
-    let (a, b, c) = (at(0), at(1), at(2));
-    [a.0, a.1, b.0, b.1, c.0, c.1]
+unsafe impl Send for Resident {}
+impl Resident {
+    fn upload<C: GpuCurve>(ctx: &Context, bases: &[C], digest: [u64; 2]) -> Option<Self> {
+        let (xy, inf) = marshal(bases);
+        let d_xy = DeviceBuf::from_words(ctx, &xy).ok()?;
+        let d_inf = if inf.iter().any(|&f| f != 0) { Some(DeviceBuf::from_bytes(ctx, &inf).ok()?) } else { None };
+        let pi = d_inf.as_ref().map(|d| d.as_u8() as *const u8).unwrap_or(ptr::null());
+        let rc = unsafe { sys::kg_bases_register(ctx.raw(), C::CURVE, d_xy.as_u64() as *const u64, pi, bases.len()) };
+        if rc != sys::KG_OK {
+            return None;
+        }
+        Some(Self { xy: d_xy, inf: d_inf, n: bases.len(), curve: C::CURVE, digest, stamp: 0 })
+    }
+    /// sum_i coeffs[i] * bases[i] over `n <= len` pairs: the scalars go up in index slices under the accumulations
+    /// (`kg_msm_host_scalars`), nothing else crosses the bus
+    fn run(&self, ctx: &Context, coeffs: *const u64, n: usize) -> Option<[u64; 24]> {
+        let pi = self.inf.as_ref().map(|d| d.as_u8() as *const u8).unwrap_or(ptr::null());
+        let mut out = [0u64; 24];
+        let rc = unsafe { sys::kg_msm_host_scalars(ctx.raw(), self.curve, self.xy.as_u64() as *const u64, pi, coeffs, n.min(self.n), out.as_mut_ptr()) };
+        if rc == sys::KG_OK { Some(out) } else { None }
+    }
 }
+
+/// Explicit residency: the handle `register_bases` returns.  The caller keeps the slice's content unchanged while the handle
+/// lives (the handle does not look at the slice again); dropping it releases the device copy.
+pub struct ResidentMsmBases(Option<Resident>);
+impl ResidentMsmBases {
+    /// `msm_curve_addition(bases, coeffs)` against the registered slice (zip semantics, msm.rs:25)
+    pub fn msm<C: GpuCurve>(&self, coeffs: &[C::Scalar]) -> Option<C::Extended>
+    where
+        C::Scalar: 'static,
+    {
+        let r = self.0.as_ref()?;
+        if C::CURVE != r.curve {
+            return None;
+        }
+        let (sw, _) = scalar_words(coeffs)?;
+        let ctxs = contexts()?;
+        let ctx = ctxs.lock(0)?;
+        Some(C::extended_from(&r.run(&ctx, sw, coeffs.len())?))
+    }
+}
+impl Drop for ResidentMsmBases {
+    fn drop(&mut self) {
+        // the buffers are freed (and the registration dropped) under GPU 0's lock: calls on one context are serialised
+        let ctxs = contexts();
+        let _held = ctxs.as_ref().and_then(|c| c.lock(0));
+        self.0.take();
+    }
+}
+
+/// Upload and convert `bases` once; the handle's `msm` then moves only scalars.
+pub fn register_bases<C: GpuCurve>(bases: &[C]) -> Option<ResidentMsmBases> {
+    if bases.is_empty() {
+        return None;
+    }
+    let ctxs = contexts()?;
+    let ctx = ctxs.lock(0)?;
+    Some(ResidentMsmBases(Some(Resident::upload(&ctx, bases, digest(bases, 1))?)))
+}
+
+const MSM_CACHE_SLOTS: usize = 8;
+static MSM_BASES: Mutex<Option<(u64, HashMap<(usize, usize, i32), Resident>)>> = Mutex::new(None);
 
 fn msm_typed<C: GpuCurve>(bases: &[C], coeffs: *const u64, n: usize) -> Option<C::Extended> {
     if n == 0 {
@@ -345,56 +466,37 @@ fn msm_typed<C: GpuCurve>(bases: &[C], coeffs: *const u64, n: usize) -> Option<C
     }
     let ctxs = contexts()?;
     let bases = &bases[..n];
-    if n < (1 << 14) {
-        // small calls (the prover's `inputs` MSMs of length l): one host-array call, nothing worth keeping resident
+    let mode = residency_mode();
+    if n < (1 << 14) || mode == ResidencyMode::Off {
+        // small calls (the prover's `inputs` MSMs of length l), or a host that keeps nothing resident: one host-array call
         let ctx = ctxs.lock_any()?;
         let (xy, inf) = marshal(bases);
         let mut out = [0u64; 24];
         let rc = unsafe { sys::kg_msm_host(ctx.raw(), C::CURVE, xy.as_ptr(), inf.as_ptr(), coeffs, n, out.as_mut_ptr()) };
         return if rc == sys::KG_OK { Some(C::extended_from(&out)) } else { None };
     }
+    // Marshalling 2^20 `repr(Rust)` points through `get_x() / get_y()` costs tens of milliseconds and the upload 1.3 ms (64 MB over
+    // PCIe) around a 1.6 ms device MSM: both are paid once per slice.  A call then validates the slice (sampled digest: ~10 us; full
+    // digest under KOGARASHI_AMD_MSM_RESIDENT=hash: a few ms) and uploads its scalars inside `kg_msm_host_scalars`.
+    let print = digest_for(bases, mode);
     let ctx = ctxs.lock(0)?;                                   // the cache lives on GPU 0
     let mut lock = MSM_BASES.lock().ok()?;
     let (clock, cache) = lock.get_or_insert_with(|| (0, HashMap::new()));
     *clock += 1;
     let id = (bases.as_ptr() as usize, n, C::CURVE);
-    let probe = probe3(bases);
-    if cache.get(&id).map(|r| r.probe != probe).unwrap_or(false) {
-        if let Some(r) = cache.remove(&id) {
-            unsafe { sys::kg_bases_unregister(ctx.raw(), r.xy.as_u64() as *const u64) };
-        }
+    if cache.get(&id).map(|r| r.digest != print).unwrap_or(false) {
+        cache.remove(&id);                                     // stale: freed (and unregistered) here, under GPU 0's lock
     }
     if !cache.contains_key(&id) {
         if cache.len() >= MSM_CACHE_SLOTS {                    // evict the least recently used slice
             let oldest = cache.iter().min_by_key(|(_, r)| r.stamp).map(|(k, _)| *k)?;
-            if let Some(r) = cache.remove(&oldest) {
-                unsafe { sys::kg_bases_unregister(ctx.raw(), r.xy.as_u64() as *const u64) };
-            }
+            cache.remove(&oldest);
         }
-        let (xy, inf) = marshal(bases);
-        let d_xy = DeviceBuf::from_words(&ctx, &xy).ok()?;
-        let d_inf = if inf.iter().any(|&f| f != 0) { Some(DeviceBuf::from_bytes(&ctx, &inf).ok()?) } else { None };
-        let pi = d_inf.as_ref().map(|d| d.as_u8() as *const u8).unwrap_or(ptr::null());
-        let rc = unsafe { sys::kg_bases_register(ctx.raw(), C::CURVE, d_xy.as_u64() as *const u64, pi, n) };
-        if rc != sys::KG_OK {
-            return None;
-        }
-        let scalars = DeviceBuf::new(&ctx, 32 * n).ok()?;
-        cache.insert(id, ResidentBases { xy: d_xy, inf: d_inf, scalars, probe, stamp: 0 });
+        cache.insert(id, Resident::upload(&ctx, bases, print)?);
     }
     let r = cache.get_mut(&id)?;
     r.stamp = *clock;
-    let rc = unsafe { sys::kg_memcpy_h2d(ctx.raw(), r.scalars.as_u8() as *mut c_void, coeffs as *const c_void, 32 * n) };
-    if rc != sys::KG_OK {
-        return None;
-    }
-    let pi = r.inf.as_ref().map(|d| d.as_u8() as *const u8).unwrap_or(ptr::null());
-    let mut out = [0u64; 24];
-    let rc = unsafe { sys::kg_msm(ctx.raw(), C::CURVE, r.xy.as_u64() as *const u64, pi, r.scalars.as_u64() as *const u64, n, out.as_mut_ptr()) };
-    if rc != sys::KG_OK {
-        return None;
-    }
-    Some(C::extended_from(&out))
+    Some(C::extended_from(&r.run(&ctx, coeffs, n)?))
 }
 
 /// `groth16::msm::msm_curve_addition` on the device: sum over `min(len)` pairs (the reference zips, msm.rs:25).

@@ -60,3 +60,38 @@ pub fn cross_term<F: PrimeField + 'static>(a: &SparseMatrix<F>, b: &SparseMatrix
     out.read_words(unsafe { core::slice::from_raw_parts_mut(t.as_mut_ptr() as *mut u64, 4 * t.len()) }).ok()?;
     Some(t)
 }
+
+/// shortest vector whose fold goes to the device: below this the two PCIe trips cost more than the host's multiply-adds
+const AXPY_MIN_LEN: usize = 1 << 14;
+
+/// out[i] = a[i] + s * b[i] over min(len) elements: the vector folds of NIFS -- `RelaxedR1csWitness::fold`
+/// (nova/src/relaxed_r1cs/witness.rs:56-70: W = W1 + r W2, E = E1 + r T) and `RelaxedR1csInstance::fold`'s x (instance.rs:81-101)
+/// -- as one `kg_field_vec_axpy` on the scalar field of either curve of the cycle.
+///
+/// The vectors cross the bus -- two up, one down: 96 B per element at ~50 GB/s is ~2 ns per element against ~25 ns for the host's
+/// Montgomery product and addition, so the transfer-inclusive device path takes about a tenth of the host's time from 2^14
+/// elements up (arithmetic from the measured bus rate, not a measurement of the Rust path: no toolchain in the build image).
+/// They cannot STAY on the device between folding steps without changing the reference's own types: `RelaxedR1csWitness { w, e }`
+/// holds host `DenseVectors` that the IVC driver clones, encodes and compares (`#[derive(Clone, Encode, Decode, PartialEq)]`), so the
+/// folded W and E are returned to the host here, and the next step's cross term uploads them again as part of z1 (INTEGRATION.md,
+/// "Nova folds").  `None` (no device, short vectors, an unserved field, any status) lets the CPU body run.
+pub fn axpy<F: PrimeField + 'static>(a: &[F], s: &F, b: &[F]) -> Option<Vec<F>> {
+    let n = a.len().min(b.len());
+    if n < AXPY_MIN_LEN || a.len() != b.len() {
+        return None;                                           // DenseVectors' own `+` asserts equal lengths: let it
+    }
+    let (_, field) = scalar_words(a)?;
+    let ctxs = contexts()?;
+    let ctx = ctxs.lock_any()?;                                // nothing resident is involved: any free GPU
+    let ctx = &*ctx;
+    let words = |v: &[F]| unsafe { core::slice::from_raw_parts(v.as_ptr() as *const u64, 4 * v.len()) };
+    let (da, db) = (DeviceBuf::from_words(ctx, words(a)).ok()?, DeviceBuf::from_words(ctx, words(b)).ok()?);
+    // out aliases a (`kg_field_vec_axpy`: "out may alias an input"): no third buffer
+    let rc = unsafe { sys::kg_field_vec_axpy(ctx.raw(), field, da.as_u64(), s as *const F as *const u64, db.as_u64(), da.as_u64(), n) };
+    if rc != sys::KG_OK {
+        return None;
+    }
+    let mut out = vec![F::zero(); n];
+    da.read_words(unsafe { core::slice::from_raw_parts_mut(out.as_mut_ptr() as *mut u64, 4 * n) }).ok()?;
+    Some(out)
+}

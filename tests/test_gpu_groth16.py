@@ -115,10 +115,11 @@ class _FrOps:
         return x
 
 
-@pytest.mark.parametrize("m", [6, 64, 1000])
+@pytest.mark.parametrize("m", [1, 2, 6, 64, 1000, 1 << 14])
 def test_device_setup_matches_oracle_and_proves(ctx, oracle, m):
-    """ZkSnark::setup composed from the device primitives (powers, idft, transposed SpMV, axpy/scale, generator
-    multiples) equals the oracle's restatement of zksnark.rs element for element; the proof made with it matches too."""
+    """ZkSnark::setup behind the C ABI (kg_groth16_setup_bn254: powers, idft, device-side transposition, transposed products,
+    axpy / scale, generator multiples) equals the oracle's restatement of zksnark.rs element for element; the proof made with it
+    matches too.  m = 1, 2: the smallest circuits (n = 2); 2^14: the windowed generator tables, long transposed rows."""
     import kogarashi_amd as K
     from kogarashi_amd.api import groth16_setup
     O = oracle
@@ -130,11 +131,37 @@ def test_device_setup_matches_oracle_and_proves(ctx, oracle, m):
         assert (got[name] == want[name]).all(), name
         assert (got[name + "_inf"] == want[name + "_inf"]).all(), name
     assert (got["vk_g1"] == want["vk_g1"]).all() and (got["vk_g2"] == want["vk_g2"][:2]).all()
+    assert (got["gamma_g2"] == want["vk_g2"][2]).all()
     r, s = O.gen_scalars(0, SEED + 602, 0, 2)
     a, b, c = cs.evaluate()
     proof = K.Prover(got, cs.m, cs.l, cs.m_l_1, ctx=ctx).create_proof(a, b, c, cs.x, cs.w, r, s)
     ref = O.groth16_prove(cs, want, r, s, evals=(a, b, c))
     assert all((g == w_).all() for g, w_ in zip(proof[:3], ref[:3]))
+
+
+def test_setup_status_codes(ctx, oracle):
+    """gamma = 0 or delta = 0 -> Error::ProverInversionFailed (zksnark.rs:37-38); alpha = 0 is legal (alpha_g1 is the identity, flagged);
+    missing output arrays and m = 0 are KG_ERR_BAD_ARG; nothing aborts and the context keeps working"""
+    import kogarashi_amd as K
+    from kogarashi_amd.api import groth16_setup
+    from kogarashi_amd.lib import ProverInversionFailed, Groth16Crs, KogarashiError
+    O = oracle
+    cs = O.chain_r1cs(6, O.gen_scalars(0, SEED + 610, 0, 1)[0])
+    toxic = O.gen_scalars(0, SEED + 611, 0, 5)
+    for z in (2, 3):
+        bad = toxic.copy(); bad[z] = 0
+        with pytest.raises(ProverInversionFailed):
+            groth16_setup(cs.a, cs.b, cs.c, cs.m, cs.l, cs.m_l_1, bad, ctx=ctx)
+    za = toxic.copy(); za[0] = 0
+    got, want = groth16_setup(cs.a, cs.b, cs.c, cs.m, cs.l, cs.m_l_1, za, ctx=ctx), O.groth16_params(cs, za, threads=2)
+    for name in ("h", "l", "a", "b_g1", "b_g2", "ic"):
+        assert (got[name] == want[name]).all() and (got[name + "_inf"] == want[name + "_inf"]).all(), name
+    d = [ctx.upload(np.ascontiguousarray(x, dtype=np.uint64)) for x in cs.a]
+    mat = (d[0].ptr, d[1].ptr, d[2].ptr)
+    with pytest.raises(KogarashiError, match="bad argument"):
+        ctx.groth16_setup(mat, mat, mat, cs.m, cs.l, cs.m_l_1, toxic, Groth16Crs(), 0, 0)       # no output arrays
+    with pytest.raises(KogarashiError, match="bad argument"):
+        groth16_setup(cs.a, cs.b, cs.c, 0, cs.l, cs.m_l_1, toxic, ctx=ctx)
 
 
 def test_groth16_two_proofs_in_flight_match_blocking_calls(ctx, oracle):
