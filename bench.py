@@ -56,7 +56,45 @@ def ntt_cost(K, log_n):
 
 def single_rank_env(torch, dev):
     """the rank environment of the legs for one process without a process group (--ntt-only, tools/dbg)"""
-    return {"world": 1, "rank": 0, "barrier": torch.cuda.synchronize, "max_over_ranks": lambda x: x, "xdev": dev, "kdist": None}
+    return {"world": 1, "rank": 0, "barrier": torch.cuda.synchronize, "host_barrier": torch.cuda.synchronize, "max_over_ranks": lambda x: x, "xdev": dev,
+            "kdist": None}
+
+
+def bench_msm_strong(ctx, torch, dev, K, env, log_n, steps):
+    """ONE G1 MSM of 2^log_n pairs (the headline's pairs: same seeds, global index range) cut over the N ranks by kg_shard_range: every
+    rank runs a BLOCKING kg_msm on its contiguous slice (2^log_n / N pairs: latency-bound below ~2^18) and the N affine partial sums
+    meet in one all_gather of 9 words per rank (kogarashi_amd/dist.py) -- strong scaling of a fixed job, beside the weak-scaled headline.
+    Unmeasured on multi-GPU hardware until the driver has an 8-GPU node; the point is the same for every N (tests/test_gpu_bench_multirank.py)."""
+    from kogarashi_amd.lib import shard_range
+    world, rank, kdist, xdev = env["world"], env["rank"], env["kdist"], env["xdev"]
+    total = 1 << log_n
+    lo, hi = shard_range(total, rank, world)
+    nl = hi - lo
+    b = torch.empty(max(nl, 1) * 8, dtype=torch.int64, device=dev)
+    sc = torch.empty(max(nl, 1) * 4, dtype=torch.int64, device=dev)
+    if nl:
+        ctx.gen_bases(K.KG_G1, SEED + 1, lo, nl, b.data_ptr())
+        ctx.gen_scalars(K.KG_FR, SEED + 2, lo, nl, sc.data_ptr())
+    ctx.sync()
+
+    def one():
+        out = ctx.msm(K.KG_G1, b.data_ptr(), 0, sc.data_ptr(), nl)
+        xy, inf = out[:8], int(not out[8:].any())
+        if world > 1:
+            xy, inf = kdist.combine_partials(ctx, K.KG_G1, xy, inf, device=xdev)
+        return xy, inf
+    for _ in range(3):
+        got = one()
+    env["barrier"]()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        got = one()
+    env["barrier"]()
+    dt = env["max_over_ranks"](time.perf_counter() - t0) / steps
+    return {"metric": "bn254_g1_msm_pairs_per_sec (one MSM over all ranks)", "log_n": log_n, "pairs_total": total, "pairs_per_rank": nl, "ranks": world,
+            "scaling": "strong", "ms_per_msm": dt * 1e3, "value": total / dt, "unit": "pairs/s",
+            "exchange": "one all_gather of 9 x 64-bit words per rank (RCCL), partial sums added on every rank" if world > 1 else "none",
+            "point": {"xy_hex": "".join(f"{int(v_):016x}" for v_ in got[0]), "is_identity": bool(got[1])}}
 
 
 def window_adds(n):
@@ -148,6 +186,7 @@ def main():
     # exchange goes over gloo with host tensors (RCCL refuses two ranks on one device).  Never a measurement.
     selftest = world > 1 and os.environ.get("KG_BENCH_SELFTEST") == "1"
     dist = None
+    host_group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -159,8 +198,12 @@ def main():
         torch.cuda.set_device(local_rank)
         if selftest:
             dist.init_process_group("gloo")
+            host_group = None                                # the default group is gloo already
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # a second, host-only group: ranks that merely WAIT for rank 0 (the sharded proof drives GPUs 0..2 from one process) park on
+            # a gloo barrier -- a barrier of the nccl group is an RCCL kernel spinning on the very GPUs rank 0 is timing
+            host_group = dist.new_group(backend="gloo")
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     else:
         torch.cuda.set_device(0)
@@ -221,6 +264,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def host_barrier():
+        """all ranks meet WITHOUT touching a GPU (gloo): for waits during which another rank is timing work on this rank's device"""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(group=host_group)
+
     def max_over_ranks(x):
         if world == 1:
             return x
@@ -280,7 +329,7 @@ def main():
                    "pairs_per_gpu": n, "sharding": "index range" if world > 1 else "none"},
         "blocking_ms": blocking_ms,            # wall time of one isolated kg_msm call (nothing in flight), host finish included
         "queues": {"placement": ctx.queue_placement() if hasattr(ctx, "queue_placement") else None,
-                   "note": "1 + j: the service queues were probed and placed on the three compute pipes the main queue does not use; -1: no clear picture, creation order"},
+                   "note": "2 + j: the service queues were probed and placed on the three compute pipes the main queue does not use; 1: no clear picture, creation order; 0: probe off"},
         "roofline": {"bound": "hbm", "kernel": "k_acc_tasks (bucket accumulation, one launch per MSM)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic["corrected"] if traffic else None, "kernel_ms": acc_avg_ms, "algorithmic_bytes_per_launch": G1_BYTES_PER_PAIR * n,
@@ -367,7 +416,10 @@ def main():
         line["cpu_baseline"] = cpu_baseline(ctx, K, bases, scalars, n, res)
         line["cpu_plumbing_2_10"] = cpu_plumbing(ctx, K)
     del bases, scalars
-    env = {"world": world, "rank": rank, "barrier": barrier, "max_over_ranks": max_over_ranks, "xdev": xdev, "kdist": kdist}
+    env = {"world": world, "rank": rank, "barrier": barrier, "host_barrier": host_barrier, "max_over_ranks": max_over_ranks, "xdev": xdev, "kdist": kdist}
+    # the strong-scaled counterpart of the headline: ONE 2^log_n MSM cut over the ranks (north_star: "splitting the scalar/base array
+    # across the 8 GPUs"); at N = 1 it is the blocking kg_msm of the whole range
+    line["msm_strong"] = bench_msm_strong(ctx, torch, dev, K, env, args.log_n, args.steps)
     if not args.no_ntt:
         line["ntt"] = bench_ntt(ctx, torch, dev, K, env)
     if not args.no_nova:
@@ -831,8 +883,9 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
     if world > 1 and circuit == "chain":
         # ONE proof over several GPUs, task-parallel (kg_groth16_prove_sharded: the G2 query | the three G1 queries | transforms
         # and h's MSM on contexts 0, 1, 2): rank 0 drives contexts on the first min(3, N) devices while the other ranks wait.
-        # (KG_BENCH_SELFTEST: every context on cuda:0 -- control flow only.)
-        sync()
+        # (KG_BENCH_SELFTEST: every context on cuda:0 -- control flow only.)  The waiting ranks park on a HOST barrier (gloo): an RCCL
+        # barrier kernel would spin on the GPUs whose proof is being timed.
+        env["host_barrier"]()
         if env["rank"] == 0:
             from kogarashi_amd.api import ShardedProver
             n_ctx = min(3, world)
@@ -857,7 +910,7 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
             del sp, keep
             for c_ in ctxs:
                 c_.close()
-        sync()
+        env["host_barrier"]()
     return out
 
 

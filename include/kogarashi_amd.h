@@ -79,10 +79,11 @@ int kg_ctx_set_inputs_complete(kg_ctx* ctx, int on);
  * hardware queues in creation order and hardware queue k is served by pipe k mod 4; a queue that shares the main queue's pipe starts its
  * work only when an accumulation's last round of workgroups is placed (~0.7 ms late), so the context creates eight candidate streams on
  * first use, probes which of them share the main queue's pipe, and puts the scalar queue and the two reduction queues on the three
- * other pipes.  Returns 1 + j when the probe gave the expected picture (candidates j and j + 4 share the main queue's pipe), -1 when it
- * did not (the queues are then taken in creation order, as up to version 3), 0 when the probe is switched off (KG_QUEUE_PLACEMENT=0);
- * creates the queues if they do not exist yet. */
-int kg_ctx_queue_placement(kg_ctx* ctx);
+ * other pipes.  *out_placement: 0 = the probe is switched off (KG_QUEUE_PLACEMENT=0), 1 = the probe gave no clear picture (the queues
+ * are then taken in creation order, as up to version 3), 2 + j = probed, candidates j and j + 4 share the main queue's pipe.  Returns
+ * KG_OK or a negative kg_status like every other entry (up to version 4 the placement itself was the return value, and "no clear
+ * picture" collided with KG_ERR_NO_DEVICE); creates the queues if they do not exist yet. */
+int kg_ctx_queue_placement(kg_ctx* ctx, int* out_placement);
 
 /* device memory plumbing so that non-HIP hosts (Rust shim, ctypes) never link the HIP runtime */
 int kg_malloc(kg_ctx* ctx, size_t bytes, void** d_ptr);
@@ -189,9 +190,9 @@ int kg_msm_table_window(size_t msm_len);
  * scalars; shorter or longer MSMs fall back to 16); 19 and 20 are the wide windows of the 2^23 .. 2^24-pair commitments. */
 int kg_msm_set_window(kg_ctx* ctx, int c);
 /* Tuning knob: window groups of a blocking kg_msm / kg_commit (groth16/src/msm.rs:6-48 and nova/src/pedersen.rs:15-20 are blocking
- * calls).  A blocking MSM of 2^17 .. 2^23 pairs pipelines against itself: the scalars are converted once, then the windows are sorted,
+ * calls).  A blocking MSM of 2^17 .. 2^24 pairs pipelines against itself (2^23: in index slices instead): the scalars are converted once, then the windows are sorted,
  * accumulated and reduced in groups, top windows first, the next group's sort under this group's accumulation, this group's reduction
- * under the next one's accumulation, and the host's double-and-add chain starts on the top group's sums.  groups: 0 = automatic (two),
+ * under the next one's accumulation, and the host's double-and-add chain starts on the top group's sums.  groups: 0 = automatic (two for 2^17 .. 2^21 pairs, three from 2^22, four for the 19- and 20-bit windows of 2^23 .. 2^24 pairs),
  * 1 = none (one accumulation launch per MSM), 2 .. 4.  Results are bit-identical for every setting. */
 int kg_msm_set_groups(kg_ctx* ctx, int groups);
 /* The automatic rule: window width c for n pairs (W = ceil(255 / c) signed windows of 2^(c-1) buckets; the reference's

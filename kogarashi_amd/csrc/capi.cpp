@@ -74,12 +74,14 @@ __global__ void __launch_bounds__(64) k_probe_nop(uint32_t* p) { if (p) *p = 1; 
 
 static int place_queues(kg_ctx* c) {
   if (c->queues_placed) return KG_OK;
-  c->queues_placed = true;
   constexpr int NC = 8;
   hipStream_t cand[NC] = {};
   hipError_t e = hipSuccess;
   for (int j = 0; j < NC && e == hipSuccess; ++j) e = create_stream(c, &cand[j], true);
-  if (e != hipSuccess) return set_err(c, KG_ERR_HIP, "queue creation", e);
+  if (e != hipSuccess) {                                // nothing is kept: the candidates made so far are released, a later call tries again
+    for (int j = 0; j < NC; ++j) if (cand[j]) hipStreamDestroy(cand[j]);
+    return set_err(c, KG_ERR_HIP, "queue creation", e);
+  }
   int cls[NC];
   for (int j = 0; j < NC; ++j) cls[j] = -1;
   const bool enabled = c->tune.queue_placement != 0;
@@ -133,6 +135,7 @@ static int place_queues(kg_ctx* c) {
   c->acc_stream[1] = take(0);
   c->up_stream = take(3);                                 // kg_msm_host's upload queue: copies only
   for (int j = 0; j < NC; ++j) if (cand[j]) hipStreamDestroy(cand[j]);
+  c->queues_placed = true;                                // only now: every queue the context uses exists
   return KG_OK;
 }
 int make_sort_stream(kg_ctx* c) {
@@ -368,11 +371,13 @@ int kg_ctx_sync(kg_ctx* c) {
     if (s) KG_HIP(c, hipStreamSynchronize(s));
   return KG_OK;
 }
-int kg_ctx_queue_placement(kg_ctx* c) {
-  if (!c) return KG_ERR_BAD_ARG;
+int kg_ctx_queue_placement(kg_ctx* c, int* out_placement) {
+  if (!c || !out_placement) return KG_ERR_BAD_ARG;
   KG_HIP(c, hipSetDevice(c->device));
   KG_TRY(make_sort_stream(c));
-  return c->placement;
+  // kg_ctx::placement: 0 probe off, -1 no clear picture, 1 + j probed -> the ABI's non-negative codes
+  *out_placement = c->placement == 0 ? 0 : (c->placement < 0 ? 1 : 1 + c->placement);
+  return KG_OK;
 }
 int kg_ctx_set_inputs_complete(kg_ctx* c, int on) {
   if (!c) return KG_ERR_BAD_ARG;

@@ -145,7 +145,11 @@ KG_HD XYZZ<F> add_xyzz(const XYZZ<F>& p, const XYZZ<F>& q_) {
 // element) and the result written the same way (x(v), ...): the operations of add_xyzz / double_xyzz in an order that keeps at
 // most six field elements live, so that a kernel built on it fits the registers a resident accumulation leaves free
 // (k_halve: 96 VGPRs instead of 160, no scratch).  A coordinate that is needed twice is read twice -- the second read comes out of
-// the cache.  The output must not alias the inputs.
+// the cache.  ALIASING CONTRACT: `out` may be the same point as the FIRST operand p (the running sum living in its output slot:
+// k_gather_sum, k_sum_tasks, k_hot_sum, k_hot_fold) and must not alias q.  It holds because every coordinate of p is read before
+// the same coordinate of out is written -- the write order is zz, zzz, x, y, and y of p is read last, inside the expression that
+// writes y; a reordering of these bodies must keep that (tests/host/hosttest.cpp mode 9 / 10 run both formulas in place, every
+// branch, with the bound checker on).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define KG_STREAM_FENCE() __asm__ volatile("" ::: "memory")     // keeps a later read of a coordinate from being merged with an earlier one
 #else

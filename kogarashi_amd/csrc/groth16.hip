@@ -378,10 +378,11 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // latency-bound launches (2^18 points = 128..512 workgroups): the witness sort goes out first (it gates the accumulations),
   // the three idft -> coset_dft chains (prover.rs:36-41) run on the two reduction queues beside it and in front of the witness MSMs
   // of the main queue, and h's MSM -- the only consumer of the transforms -- goes last.
-  // (Measured and dropped: h's point-wise step and coset_idft IN FRONT of the accumulations with h's sort beside the G1
-  // accumulations, so that h's accumulation follows them at once -- the gap in front of h's accumulation closes (0.54 ->
-  // 0.03 ms), but the reductions of a, b_g1 and l, which used that gap (they do not fit beside an accumulation), then queue up
-  // behind h's: 3.28 -> 3.40 ms blocking, 2.97 -> 3.17 ms with two proofs in flight.)
+  // The order since round 4 (KG_G16_H_EARLY = 1, the default): h's point-wise step and coset_idft run BETWEEN the G2 accumulation and
+  // the fused G1 accumulation, h's sort beside the latter, h's accumulation right behind it.  (Round 2 measured the same idea with the
+  // 160-VGPR reductions of the time and dropped it: the reductions of a, b_g1 and l lost the gap they ran in, 3.28 -> 3.40 ms
+  // blocking; with reductions that fit beside an accumulation it wins -- EXPERIMENTS.md Part I section 11.  KG_G16_H_EARLY = 0 is the old
+  // order, = 2 puts h's chain in front of the G2 accumulation.)
   if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
   if (!ctx->ev_fork) {
     KG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));

@@ -202,7 +202,7 @@ static int msm_grouped(kg_ctx* ctx, int curve, const uint64_t* d_bases, const ui
   KG_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->side_stream) KG_TRY(make_side_stream(ctx));
   KG_TRY(make_sort_stream(ctx));
-  for (int g = 1; g < NG; ++g)
+  for (int g = 1; g < NG && g < ctx->tune.group_accq; ++g)      // only the queues the groups rotate over (two: acc_stream[1] comes placed from place_queues)
     if (!ctx->acc_stream[g]) KG_HIP(ctx, create_stream(ctx, &ctx->acc_stream[g], false));
   kg::MsmSortPlan Q;
   // KG_GROUP_MAIN_FIRST=1 (experiment): conversion and the first group's sort on the main queue, in front of its accumulation -- no

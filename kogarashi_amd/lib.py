@@ -301,8 +301,11 @@ class Context:
         self._chk(self._lib.kg_msm_set_window(self._h, int(c)), "kg_msm_set_window")
 
     def queue_placement(self) -> int:
-        """how the service queues were dealt over the compute pipes (kg_ctx_queue_placement): 1 + j probed, -1 creation order, 0 off"""
-        return int(self._lib.kg_ctx_queue_placement(self._h))
+        """how the service queues were dealt over the compute pipes (kg_ctx_queue_placement): 0 probe off, 1 creation order (no clear picture),
+        2 + j probed"""
+        p = C.c_int(0)
+        self._chk(self._lib.kg_ctx_queue_placement(self._h, C.byref(p)), "kg_ctx_queue_placement")
+        return int(p.value)
 
     def set_msm_groups(self, groups: int):
         """window groups of a blocking MSM: 0 automatic, 1 none, 2..4 (kg_msm_set_groups)"""

@@ -82,11 +82,24 @@ static int st_aff(const XYZZ<F>& p, uint32_t* xy) {
   Conv<F>::out(a.x, xy); Conv<F>::out(a.y, xy + Conv<F>::W);
   return 0;
 }
+// a point in memory read and written coordinate by coordinate: the device's SoaSrc / SoaDst / AosSrc accessors over one slot
+template <class F> struct MemPt {
+  XYZZ<F>* s;
+  F x() const { return s->x; }
+  F y() const { return s->y; }
+  F zz() const { return s->zz; }
+  F zzz() const { return s->zzz; }
+  void x(const F& v) const { s->x = v; }
+  void y(const F& v) const { s->y = v; }
+  void zz(const F& v) const { s->zz = v; }
+  void zzz(const F& v) const { s->zzz = v; }
+};
 // mode 0: left fold with add_mixed; 1: pairwise tree with add_xyzz; 2: fold of add_xyzz(from_affine);
 // 3: sum_i 2*P_i via double_affine + add_xyzz; 4: double_xyzz applied `n` times to point 0; 5: fold, negated;
 // 7: fold of add_mixed_signed(acc, -P_i, negate = true), i.e. the sign folded back: equals mode 0;
 // 8: the device pipeline's shape -- chunks of three folded with add_mixed_signed (their X is not value-reduced), the
 //    partial sums combined by an add_xyzz tree
+// 9: fold of add_xyzz_stream with the running sum as first operand AND output (in place); 10: double_xyzz_stream in place, n times
 template <class F>
 static int curve_sum(int mode, const uint32_t* pts, const uint8_t* inf, size_t n, uint32_t* out_xy) {
   const int W2 = 2 * Conv<F>::W;
@@ -134,6 +147,17 @@ static int curve_sum(int mode, const uint32_t* pts, const uint8_t* inf, size_t n
   } else if (mode == 4) {
     acc = from_affine(ld_aff<F>(pts));
     for (size_t i = 0; i < n; ++i) acc = double_xyzz(acc);
+  } else if (mode == 9) {
+    // the streaming formulas IN PLACE on their first operand, as the device runs them (k_gather_sum, k_hot_sum, k_hot_fold: the
+    // running sum lives in its output slot): out aliases p, every coordinate of p is read before the same coordinate is written
+    for (size_t i = 0; i < n; ++i) if (!inf || !inf[i]) {
+      XYZZ<F> q = from_affine(ld_aff<F>(pts + W2 * i));
+      MemPt<F> P{&acc}, Q{&q}, O{&acc};
+      add_xyzz_stream<F>(P, Q, O);
+    }
+  } else if (mode == 10) {                                  // and the doubling on its own, in place
+    acc = from_affine(ld_aff<F>(pts));
+    for (size_t i = 0; i < n; ++i) { MemPt<F> P{&acc}, O{&acc}; double_xyzz_stream<F>(P, O); }
   }
   return st_aff(acc, out_xy);
 }

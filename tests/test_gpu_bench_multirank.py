@@ -40,3 +40,12 @@ def test_two_ranks_run_the_whole_line_and_combine_to_the_one_rank_points():
     assert g["replicas"] == 2 and g["pipelined_matches_blocking"]
     assert g["sharded"]["contexts"] == 2 and g["sharded"]["matches_single_context"]
     assert "sharded" not in one["groth16"]
+    # the strong-scaled MSM: ONE 2^16-pair MSM cut over the ranks is the point the one-rank run computes on the whole range
+    s1, s2 = one["msm_strong"], two["msm_strong"]
+    assert s1["ranks"] == 1 and s2["ranks"] == 2 and s2["scaling"] == "strong" and s2["pairs_per_rank"] * 2 == s2["pairs_total"] == s1["pairs_total"]
+    assert s1["point"] == s2["point"] and not s2["point"]["is_identity"] and s2["ms_per_msm"] > 0
+    # the waiting ranks of the sharded proof park on a host-side (gloo) barrier, never on an RCCL kernel of the GPUs being timed
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src.split("if world > 1 and circuit == \"chain\":")[1].split("return out")[0]
+    assert body.count('env["host_barrier"]()') == 2 and "sync()" not in body
+    assert 'dist.new_group(backend="gloo")' in src

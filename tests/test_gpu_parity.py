@@ -715,7 +715,18 @@ def test_skewed_scalar_vectors_over_the_three_curves():
 
 
 def test_service_queues_are_placed_off_the_main_queues_pipe(ctx):
-    """capi.cpp place_queues: the probe finds exactly the candidates j and j + 4 on the main queue's compute pipe (1 <= result <= 4),
-    whatever streams the process created before (here: none but the runtime's own)"""
-    p = ctx.queue_placement()
-    assert 1 <= p <= 4, p
+    """capi.cpp place_queues: in a fresh process (none but the runtime's own streams, GPU_MAX_HW_QUEUES as the suite sets it) the probe
+    finds exactly the candidates j and j + 4 on the main queue's compute pipe (2 <= code <= 5), also with never-used streams created
+    first; in THIS process -- hundreds of streams and contexts behind it -- any answer is a status-clean code 0..5 (1 = no clear
+    picture: creation order, which only costs speed)."""
+    import os, subprocess, sys
+    assert 0 <= ctx.queue_placement() <= 5
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = "import sys; sys.path.insert(0, %r)\nimport kogarashi_amd as K\nc = K.Context(0); print('placement', c.queue_placement()); c.close()" % root
+    for env in ({}, {"KG_STREAM_PAD": "1,2"}):
+        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        p = int(r.stdout.split("placement")[1].split()[0])
+        assert 2 <= p <= 5, (env, p)
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, KG_QUEUE_PLACEMENT="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and int(r.stdout.split("placement")[1].split()[0]) == 0

@@ -117,12 +117,13 @@ def _check_point_formulas(hostlib, pyoracle, name):
                 if not f:
                     exp = cur.add(exp, pt)
             for chk in (0, 1):
-                for mode in (0, 1, 2, 7, 8):
+                for mode in (0, 1, 2, 7, 8, 9):         # 9: the streaming formulas in place on their first operand
                     assert curve_sum(hostlib, cid, cur, chk, mode, pts, inf) == exp, (name, ci, some_inf, chk, mode)
                 assert curve_sum(hostlib, cid, cur, chk, 5, pts, inf) == cur.neg(exp)
                 assert curve_sum(hostlib, cid, cur, chk, 3, pts, inf) == cur.add(exp, exp), (name, ci, "dbl")
     for chk in (0, 1):
         assert curve_sum(hostlib, cid, cur, chk, 4, [A] * 5, [0] * 5) == cur.mul(A, 32)
+        assert curve_sum(hostlib, cid, cur, chk, 10, [A] * 5, [0] * 5) == cur.mul(A, 32)       # double_xyzz_stream in place
 
 
 def test_ntt_butterfly_network_bounds_and_values(hostlib, oracle):
