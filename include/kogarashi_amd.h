@@ -48,7 +48,7 @@ enum { KG_G1 = 0, KG_GRUMPKIN = 1, KG_G2 = 2 };      /* curve ids */
 
 typedef struct kg_ctx kg_ctx;
 
-int kg_version(void);                    /* 5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe, kg_mem_info, kg_groth16_setup_bn254; 4: kg_msm_set_groups, kg_ctx_queue_placement; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
+int kg_version(void);                    /* 5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe, kg_mem_info, kg_groth16_setup_bn254, kg_experiments_built; 4: kg_msm_set_groups, kg_ctx_queue_placement; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
 /* Optional process-level setup; call it (or export the variable yourself) BEFORE anything in the process initialises the
  * HIP runtime -- before the first kg_device_count / kg_ctx_create and before any other HIP user -- and before the host
  * starts threads (it calls setenv).  Sets GPU_MAX_HW_QUEUES=16 unless the variable is already set, so that each of a
@@ -59,6 +59,11 @@ int kg_version(void);                    /* 5: kg_msm_host_scalars, kg_commit_ho
 int kg_init(void);
 /* The process's GPU_MAX_HW_QUEUES as an integer, 0 when unset (the runtime default of 4 applies). */
 int kg_hw_queue_setting(void);
+/* 1 when the library was compiled with -DKG_EXPERIMENTS (`python -m kogarashi_amd.build --experiments`: libkogarashi_amd_exp.so), which
+ * adds three kernels that lost their A/B runs -- the round-3 first sort pass (KG_GS_TILE=0), the LDS-prefetching accumulation
+ * (KG_ACC_PREFETCH=1) and the lane-pair G2 accumulation (KG_G2_PAIR_ACC=1) -- for further measurements; 0 for the product build, where
+ * those knobs are ignored. */
+int kg_experiments_built(void);
 int kg_device_count(void);
 const char* kg_strerror(int status);
 

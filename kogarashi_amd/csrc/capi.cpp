@@ -267,6 +267,14 @@ int kg_hw_queue_setting(void) {
 }
 int kg_version(void) { return 5; }      // the round the ABI was last extended in (5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe; 4: kg_msm_set_groups; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded)
 
+int kg_experiments_built(void) {
+#ifdef KG_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 int kg_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -25,7 +25,7 @@ EXPORTS = [
     "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
     "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_r1cs_begin", "kg_groth16_prove_sharded", "kg_ntt_plan",
-    "kg_msm_host_scalars", "kg_commit_host_scalars", "kg_tuning_describe", "kg_mem_info", "kg_groth16_setup_bn254",
+    "kg_msm_host_scalars", "kg_commit_host_scalars", "kg_tuning_describe", "kg_mem_info", "kg_groth16_setup_bn254", "kg_experiments_built",
 ]
 
 
@@ -118,6 +118,11 @@ def tuning_table() -> list[dict]:
             raise KogarashiError("kg_tuning_describe")
         rows.append({"env": env.value.decode(), "doc": doc.value.decode(), "default": d.value, "value": v.value})
     return rows
+
+
+def experiments_built() -> bool:
+    """kg_experiments_built: does the loaded library carry the -DKG_EXPERIMENTS kernels?"""
+    return bool(load().kg_experiments_built())
 
 
 def msm_pick_window(n: int) -> int:

@@ -572,6 +572,16 @@ def test_msm_host_slices_match_device_call(ctx, oracle, cv, curve, sfd, n):
     assert gpu_aff(want, nb) == aff(O, cv, O.msm(cv, bases, scal, inf, threads=8))
 
 
+def _experiments_lib():
+    """libkogarashi_amd_exp.so: the product's sources with -DKG_EXPERIMENTS (python -m kogarashi_amd.build --experiments; built by
+    __graft_entry__.build()) -- the three kernels that lost their A/B runs exist there only, and so do their parity tests"""
+    import os
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kogarashi_amd", "libkogarashi_amd_exp.so")
+    if not os.path.exists(so):
+        pytest.skip("libkogarashi_amd_exp.so is not built (python -m kogarashi_amd.build --experiments)")
+    return so
+
+
 def test_g2_accumulation_on_lane_pairs_gives_the_same_sum(oracle):
     """KG_G2_PAIR_ACC=1 (read once per process): k_acc_tasks<Fp2S> -- a lane pair per task, c0 on the even lane, c1 on the odd
     one, partial sums written in the one-lane layout -- against the oracle, in a child process; identity bases and zero
@@ -603,7 +613,8 @@ got = ctx.msm(K.KG_G2, dxy.ptr, dinf.ptr, ds.ptr, n)
 assert (got[:16] == want[0]).all()
 print("ok")
 """ % root
-    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, KG_G2_PAIR_ACC="1"), capture_output=True, text=True, timeout=600)
+    exp = _experiments_lib()
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, KG_G2_PAIR_ACC="1", KG_LIB_PATH=exp), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
@@ -699,7 +710,13 @@ print("ok")
     for knobs in ({"KG_GS_TILE": "0"}, {"KG_GS_TILE": "8192", "KG_GS_NT": "512", "KG_GS_NT0": "256"}, {"KG_GS_TILE": "4096", "KG_GS_NT": "1024"},
                   {"KG_SORT_ALONE": "0"}, {"KG_ACC_PREFETCH": "1"},        # k_acc_tasks_q (bases through LDS, gathers shared by lane quads)
                   {"KG_HOT_SHIFT": "0"}, {"KG_HOT_SHIFT": "1"}):          # hot buckets cut no finer / twice finer than the others (default: four times)
-        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **knobs), capture_output=True, text=True, timeout=600)
+        env = dict(os.environ, **knobs)
+        if knobs.get("KG_GS_TILE") == "0" or "KG_ACC_PREFETCH" in knobs:      # kernels of the -DKG_EXPERIMENTS build only
+            env["KG_LIB_PATH"] = _experiments_lib()
+            script_k = script.replace('print("ok")', 'from kogarashi_amd.lib import experiments_built\nassert experiments_built()\nprint("ok")')
+        else:
+            script_k = script
+        r = subprocess.run([sys.executable, "-c", script_k], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (knobs, r.stderr[-2000:])
 
 
