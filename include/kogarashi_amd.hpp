@@ -18,6 +18,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 #include "kogarashi_amd.h"
 
@@ -125,6 +126,51 @@ inline G1Projective msm_curve_addition(const Context& c, const std::vector<G1Aff
   return r;
 }
 
+// The same call against bases that stay on the device: what a Rust host does behind `msm_curve_addition` for a CRS vector or any
+// other slice it meets again (rust/kogarashi-amd/src/lib.rs: register_bases / the address-keyed cache) -- marshal, upload and
+// kg_bases_register ONCE, then every call moves only its scalars (kg_msm_host_scalars: index slices uploaded under the accumulations).
+class ResidentBases {
+ public:
+  ResidentBases(const Context& c, const std::vector<G1Affine>& bases, int curve = KG_G1) : c_(c), curve_(curve), n_(bases.size()) {
+    std::vector<uint64_t> xy;
+    std::vector<uint8_t> inf;
+    detail::marshal(bases, n_, xy, inf);
+    bool any = false;
+    for (uint8_t f : inf) any = any || f;
+    g_.reset(new DeviceBuffer(c, xy.data(), xy.size() * 8));
+    if (any) inf_.reset(new DeviceBuffer(c, inf.data(), inf.size()));
+    if (n_) c.check(kg_bases_register(c.raw(), curve, g_->as<uint64_t>(), any ? inf_->as<uint8_t>() : nullptr, n_), "kg_bases_register");
+  }
+  ~ResidentBases() { if (n_) kg_bases_unregister(c_.raw(), g_->as<uint64_t>()); }
+  size_t size() const { return n_; }
+  G1Projective msm(const std::vector<Fe>& coeffs) const {
+    const size_t n = coeffs.size() < n_ ? coeffs.size() : n_;
+    uint64_t out[12];
+    c_.check(kg_msm_host_scalars(c_.raw(), curve_, g_->as<uint64_t>(), inf_ ? inf_->as<uint8_t>() : nullptr,
+                                 reinterpret_cast<const uint64_t*>(coeffs.data()), n, out), "kg_msm_host_scalars");
+    G1Projective r;
+    for (int k = 0; k < 4; ++k) { r.x[k] = out[k]; r.y[k] = out[4 + k]; r.z[k] = out[8 + k]; }
+    return r;
+  }
+
+ private:
+  const Context& c_;
+  int curve_;
+  size_t n_;
+  std::unique_ptr<DeviceBuffer> g_, inf_;
+};
+
+// nova/src/relaxed_r1cs/witness.rs:56-70 (W = W1 + r W2, E = E1 + r T) and instance.rs:81-101 (x = x1 + r x2): a[i] + s * b[i] on the
+// scalar field of either curve (field: KG_FR / KG_FQ); two vectors up, one down
+inline std::vector<Fe> fold(const Context& c, const std::vector<Fe>& a, const Fe& s, const std::vector<Fe>& b, int field = KG_FR) {
+  if (a.size() != b.size()) throw std::invalid_argument("fold: DenseVectors of different lengths");
+  DeviceBuffer da(c, a.data(), a.size() * 32), db(c, b.data(), b.size() * 32);
+  c.check(kg_field_vec_axpy(c.raw(), field, da.as<uint64_t>(), s.data(), db.as<uint64_t>(), da.as<uint64_t>(), a.size()), "kg_field_vec_axpy");
+  std::vector<Fe> out(a.size());
+  da.download(out.data());
+  return out;
+}
+
 // groth16/src/fft.rs:27-154 Fft<Fr>: 2^k-point transforms, natural order; shorter inputs are zero padded (prepare_fft :157-162)
 class Fft {
  public:
@@ -136,6 +182,15 @@ class Fft {
   std::vector<Fe> idft(const std::vector<Fe>& v) const { return run(v, 1, 0); }
   std::vector<Fe> coset_dft(const std::vector<Fe>& v) const { return run(v, 0, 1); }
   std::vector<Fe> coset_idft(const std::vector<Fe>& v) const { return run(v, 1, 1); }
+  // the same transforms in place on a vector of exactly 2^k elements -- the shape of the reference's own methods (they consume and
+  // return the vector, fft.rs:92-127) and of the Rust glue's fft::transform: no padded copy, no result vector, the host cost is the
+  // two bus trips
+  void transform_in_place(std::vector<Fe>& v, int inverse, int coset) const {
+    if (v.size() != n_) throw std::invalid_argument("Fft::transform_in_place: the vector must hold 2^k elements");
+    DeviceBuffer d(c_, v.data(), n_ * 32);
+    c_.check(kg_ntt_bn254_fr(c_.raw(), d.as<uint64_t>(), k_, inverse, coset), "kg_ntt_bn254_fr");
+    d.download(v.data());
+  }
   std::vector<Fe> divide_by_z_on_coset(const std::vector<Fe>& v) const {
     std::vector<Fe> buf = padded(v);
     DeviceBuffer d(c_, buf.data(), n_ * 32);
@@ -202,6 +257,25 @@ struct Parameters {
   G2Affine beta_g2, delta_g2;
 };
 struct Proof { G1Affine a; G2Affine b; G1Affine c; };
+
+// groth16/src/verifier.rs:20-46 VerifyingKey, as ZkSnark::setup fills it
+struct VerifyingKey {
+  G1Affine alpha_g1, beta_g1, delta_g1;
+  G2Affine beta_g2, gamma_g2, delta_g2;
+  std::vector<G1Affine> ic;
+};
+// groth16::Error::ProverInversionFailed (zksnark.rs:37-38): gamma or delta has no inverse
+struct ProverInversionFailed : Error {
+  ProverInversionFailed() : Error(KG_ERR_INVERSION, "setup") {}
+};
+
+// groth16/src/zksnark.rs:17-127 ZkSnark::setup after circuit synthesis: (Parameters, VerifyingKey) of the circuit whose constraint
+// matrices a, b, c are given as CSR over z = x || w (SparseMatrix below), from the five toxic scalars alpha, beta, gamma, delta, tau --
+// the reference draws them from its rng in that order (zksnark.rs:28-32) and so does the caller here.  One call:
+// kg_groth16_setup_bn254 computes everything on the device.
+struct SparseMatrix;
+inline std::pair<struct Parameters, VerifyingKey> setup(const Context& c, const SparseMatrix& a, const SparseMatrix& b, const SparseMatrix& cm, size_t l,
+                                                        size_t m_l_1, const std::array<Fe, 5>& toxic);
 
 // groth16/src/prover.rs:14-99 Prover { params }: the CRS is uploaded and registered once; create_proof takes the synthesised
 // constraint system's evaluations (cs.evaluate()), x = cs.x(), w = cs.w() and the blinding scalars the reference draws from its
@@ -270,6 +344,62 @@ struct SparseMatrix {
   std::vector<Fe> val;
   size_t rows() const { return row_ptr.empty() ? 0 : row_ptr.size() - 1; }
 };
+
+inline std::pair<Parameters, VerifyingKey> setup(const Context& c, const SparseMatrix& a, const SparseMatrix& b, const SparseMatrix& cm, size_t l, size_t m_l_1,
+                                                 const std::array<Fe, 5>& toxic) {
+  const size_t m = a.rows(), nv = l + m_l_1;
+  if (m == 0 || b.rows() != m || cm.rows() != m) throw std::invalid_argument("setup: three matrices with one row per constraint");
+  const SparseMatrix* mats[3] = {&a, &b, &cm};
+  std::unique_ptr<DeviceBuffer> buf[9];
+  kg_csr csr[3];
+  const uint64_t pad64 = 0;
+  const Fe padfe{0, 0, 0, 0};
+  for (int k = 0; k < 3; ++k) {
+    const SparseMatrix& M = *mats[k];
+    if (M.col.size() != M.val.size() || M.row_ptr.size() != m + 1 || M.row_ptr.back() != M.col.size()) throw std::invalid_argument("setup: malformed CSR");
+    for (uint64_t cidx : M.col) if (cidx >= nv) throw std::out_of_range("setup: a column index past z = x || w");
+    buf[3 * k].reset(new DeviceBuffer(c, M.row_ptr.data(), M.row_ptr.size() * 8));
+    buf[3 * k + 1].reset(new DeviceBuffer(c, M.col.empty() ? &pad64 : M.col.data(), (M.col.empty() ? 1 : M.col.size()) * 8));
+    buf[3 * k + 2].reset(new DeviceBuffer(c, M.val.empty() ? &padfe : M.val.data(), (M.val.empty() ? 1 : M.val.size()) * 32));
+    csr[k] = kg_csr{buf[3 * k]->as<uint64_t>(), buf[3 * k + 1]->as<uint64_t>(), buf[3 * k + 2]->as<uint64_t>()};
+  }
+  auto pts = [&](size_t n, size_t words) { return std::unique_ptr<DeviceBuffer>(new DeviceBuffer(c, (n ? n : 1) * words * 8)); };
+  auto flg = [&](size_t n) { return std::unique_ptr<DeviceBuffer>(new DeviceBuffer(c, n ? n : 1)); };
+  auto h = pts(m - 1, 8), lq = pts(m_l_1, 8), qa = pts(nv, 8), qb1 = pts(nv, 8), qb2 = pts(nv, 16), ic = pts(l, 8);
+  auto hi = flg(m - 1), li = flg(m_l_1), ai = flg(nv), b1i = flg(nv), b2i = flg(nv), ici = flg(l);
+  kg_groth16_crs crs{};
+  crs.d_h = h->as<uint64_t>(); crs.d_h_inf = hi->as<uint8_t>(); crs.d_l = lq->as<uint64_t>(); crs.d_l_inf = li->as<uint8_t>();
+  crs.d_a = qa->as<uint64_t>(); crs.d_a_inf = ai->as<uint8_t>(); crs.d_b_g1 = qb1->as<uint64_t>(); crs.d_b_g1_inf = b1i->as<uint8_t>();
+  crs.d_b_g2 = qb2->as<uint64_t>(); crs.d_b_g2_inf = b2i->as<uint8_t>();
+  uint64_t gamma_g2[16];
+  uint8_t vinf[6];
+  const int rc = kg_groth16_setup_bn254(c.raw(), &csr[0], &csr[1], &csr[2], m, l, m_l_1, reinterpret_cast<const uint64_t*>(toxic.data()), &crs,
+                                        ic->as<uint64_t>(), ici->as<uint8_t>(), gamma_g2, vinf);
+  if (rc == KG_ERR_INVERSION) throw ProverInversionFailed();
+  c.check(rc, "kg_groth16_setup_bn254");
+  auto g1s = [&](const DeviceBuffer& xy, const DeviceBuffer& inf, size_t n) {
+    std::vector<uint64_t> w((n ? n : 1) * 8);
+    std::vector<uint8_t> f(n ? n : 1);
+    xy.download(w.data()); inf.download(f.data());
+    std::vector<G1Affine> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = detail::g1_from(&w[8 * i], f[i] != 0);
+    return v;
+  };
+  Parameters P;
+  P.h = g1s(*h, *hi, m - 1); P.l = g1s(*lq, *li, m_l_1); P.a = g1s(*qa, *ai, nv); P.b_g1 = g1s(*qb1, *b1i, nv);
+  {
+    std::vector<uint64_t> w((nv ? nv : 1) * 16);
+    std::vector<uint8_t> f(nv ? nv : 1);
+    qb2->download(w.data()); b2i->download(f.data());
+    P.b_g2.resize(nv);
+    for (size_t i = 0; i < nv; ++i) P.b_g2[i] = detail::g2_from(&w[16 * i], f[i] != 0);
+  }
+  P.alpha_g1 = detail::g1_from(crs.alpha_g1, vinf[0] != 0); P.beta_g1 = detail::g1_from(crs.beta_g1, vinf[1] != 0);
+  P.delta_g1 = detail::g1_from(crs.delta_g1, vinf[2] != 0);
+  P.beta_g2 = detail::g2_from(crs.beta_g2, vinf[3] != 0); P.delta_g2 = detail::g2_from(crs.delta_g2, vinf[5] != 0);
+  VerifyingKey vk{P.alpha_g1, P.beta_g1, P.delta_g1, P.beta_g2, detail::g2_from(gamma_g2, vinf[4] != 0), P.delta_g2, g1s(*ic, *ici, l)};
+  return {std::move(P), std::move(vk)};
+}
 
 // nova::R1csShape's three matrices, resident on the device: prod (SparseMatrix::prod) and Prover::compute_cross_term
 // (nova/src/prover.rs:53-90: T = AZ1 o BZ2 + AZ2 o BZ1 - u1 CZ2 - u2 CZ1, one fused kernel).  field: KG_FR for the bn254 driver,

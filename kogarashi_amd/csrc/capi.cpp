@@ -17,11 +17,32 @@ void sync_all(kg_ctx* c) {
   for (hipStream_t s : c->acc_stream)
     if (s) hipStreamSynchronize(s);
 }
+// ---- the block pool behind kg_malloc / kg_free ---------------------------------------------------------------------------------
+static size_t pool_class(size_t bytes) {
+  if (bytes <= 4096) return 4096;
+  if (bytes <= ((size_t)1 << 20)) { size_t c = 8192; while (c < bytes) c <<= 1; return c; }      // powers of two up to 1 MiB
+  return (bytes + (((size_t)1 << 20) - 1)) & ~(((size_t)1 << 20) - 1);                          // whole MiB above
+}
+void pool_trim(kg_ctx* c) {
+  for (auto& kv : c->pool_free) hipFree(kv.second);
+  c->pool_free.clear();
+  c->pool_cached = 0;
+}
+hipError_t dev_alloc(kg_ctx* c, void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess && c->pool_cached) {
+    (void)hipGetLastError();
+    sync_all(c);
+    pool_trim(c);
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
 int ensure_ws_sort(kg_ctx* c, int set, size_t bytes) {
   if (bytes <= c->ws_sort_bytes[set]) return KG_OK;
   if (c->ws_sort[set]) { sync_all(c); hipFree(c->ws_sort[set]); c->ws_sort[set] = nullptr; c->ws_sort_bytes[set] = 0; }
   size_t want = bytes + bytes / 8;
-  hipError_t e = hipMalloc(&c->ws_sort[set], want);
+  hipError_t e = dev_alloc(c, &c->ws_sort[set], want);
   if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "workspace allocation", e);
   c->ws_sort_bytes[set] = want;
   return KG_OK;
@@ -161,7 +182,7 @@ int make_sort_stream(kg_ctx* c) {
 int ensure_ws_vec(kg_ctx* c, size_t bytes) {
   if (bytes <= c->ws_vec_bytes) return KG_OK;
   if (c->ws_vec) { sync_all(c); hipFree(c->ws_vec); c->ws_vec = nullptr; c->ws_vec_bytes = 0; }
-  hipError_t e = hipMalloc(&c->ws_vec, bytes);
+  hipError_t e = dev_alloc(c, &c->ws_vec, bytes);
   if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "workspace allocation", e);
   c->ws_vec_bytes = bytes;
   return KG_OK;
@@ -169,7 +190,7 @@ int ensure_ws_vec(kg_ctx* c, size_t bytes) {
 int ensure_ws2(kg_ctx* c, size_t bytes) {
   if (bytes <= c->ws2_bytes) return KG_OK;
   if (c->ws2) { sync_all(c); hipFree(c->ws2); c->ws2 = nullptr; c->ws2_bytes = 0; }
-  hipError_t e = hipMalloc(&c->ws2, bytes);
+  hipError_t e = dev_alloc(c, &c->ws2, bytes);
   if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "ntt buffer allocation", e);
   c->ws2_bytes = bytes;
   return KG_OK;
@@ -177,7 +198,7 @@ int ensure_ws2(kg_ctx* c, size_t bytes) {
 int ensure_ws3(kg_ctx* c, int which, size_t bytes) {
   if (bytes <= c->ws3_bytes[which]) return KG_OK;
   if (c->ws3[which]) { sync_all(c); hipFree(c->ws3[which]); c->ws3[which] = nullptr; c->ws3_bytes[which] = 0; }
-  hipError_t e = hipMalloc(&c->ws3[which], bytes);
+  hipError_t e = dev_alloc(c, &c->ws3[which], bytes);
   if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "prover buffer allocation", e);
   c->ws3_bytes[which] = bytes;
   return KG_OK;
@@ -190,7 +211,7 @@ int ensure_ws_run(kg_ctx* c, int which, size_t bytes) {
     c->ws_run[which] = nullptr; c->ws_run_bytes[which] = 0;
   }
   size_t want = bytes + bytes / 8;
-  hipError_t e = hipMalloc(&c->ws_run[which], want);
+  hipError_t e = dev_alloc(c, &c->ws_run[which], want);
   if (e != hipSuccess) return set_err(c, KG_ERR_OOM, "msm run-space allocation", e);
   c->ws_run_bytes[which] = want;
   return KG_OK;
@@ -341,6 +362,8 @@ void kg_ctx_destroy(kg_ctx* c) {
   }
   if (c->ev_pb) hipEventDestroy(c->ev_pb);
   if (c->ev_prep) hipEventDestroy(c->ev_prep);
+  pool_trim(c);
+  for (auto& kv : c->pool_live) hipFree(kv.first);       // blocks the host never freed go with the context
   if (c->ws_pb) hipFree(c->ws_pb);
   for (auto& sl : c->slots) { if (sl.host) hipHostFree(sl.host); if (sl.done) hipEventDestroy(sl.done); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -395,7 +418,18 @@ int kg_ctx_set_inputs_complete(kg_ctx* c, int on) {
 int kg_malloc(kg_ctx* c, size_t bytes, void** p) {
   if (!c || !p) return KG_ERR_BAD_ARG;
   KG_HIP(c, hipSetDevice(c->device));
-  KG_HIP(c, hipMalloc(p, bytes ? bytes : 1));
+  const size_t cls = pool_class(bytes ? bytes : 1);
+  if (cls < bytes) return set_err(c, KG_ERR_OOM, "kg_malloc: size overflow");
+  auto it = c->pool_free.find(cls);
+  if (it != c->pool_free.end()) {                          // a block of this class that has been used before: its pages are mapped
+    *p = it->second;
+    c->pool_free.erase(it);
+    c->pool_cached -= cls;
+  } else {
+    const hipError_t e = dev_alloc(c, p, cls);
+    if (e != hipSuccess) { *p = nullptr; return set_err(c, e == hipErrorOutOfMemory ? KG_ERR_OOM : KG_ERR_HIP, "kg_malloc", e); }
+  }
+  c->pool_live[*p] = cls;
   return KG_OK;
 }
 int kg_mem_info(kg_ctx* c, size_t* free_bytes, size_t* total_bytes) {
@@ -403,17 +437,28 @@ int kg_mem_info(kg_ctx* c, size_t* free_bytes, size_t* total_bytes) {
   KG_HIP(c, hipSetDevice(c->device));
   size_t f = 0, t = 0;
   KG_HIP(c, hipMemGetInfo(&f, &t));
-  if (free_bytes) *free_bytes = f;
+  if (free_bytes) *free_bytes = f + c->pool_cached;        // kept blocks are released on demand: they count as free
   if (total_bytes) *total_bytes = t;
   return KG_OK;
 }
 int kg_free(kg_ctx* c, void* p) {
   if (!c) return KG_ERR_BAD_ARG;
-  if (p) {
-    KG_HIP(c, hipSetDevice(c->device));
-    kg_bases_unregister(c, (const uint64_t*)p);     // a freed array must never be served from its registration
-    KG_HIP(c, hipFree(p));
+  if (!p) return KG_OK;
+  KG_HIP(c, hipSetDevice(c->device));
+  kg_bases_unregister(c, (const uint64_t*)p);     // a freed array must never be served from its registration
+  auto it = c->pool_live.find(p);
+  if (it == c->pool_live.end()) { KG_HIP(c, hipFree(p)); return KG_OK; }       // not from kg_malloc (a foreign HIP allocation): released as before
+  const size_t cls = it->second;
+  c->pool_live.erase(it);
+  const size_t cap = (size_t)(c->tune.pool_mb > 0 ? c->tune.pool_mb : 0) << 20;
+  if (c->pool_cached + cls <= cap) {
+    // hipFree waits for the device; a kept block must be just as safe to hand out again: nothing of this context may still use it
+    sync_all(c);
+    c->pool_free.emplace(cls, p);
+    c->pool_cached += cls;
+    return KG_OK;
   }
+  KG_HIP(c, hipFree(p));
   return KG_OK;
 }
 int kg_memcpy_h2d(kg_ctx* c, void* d, const void* h, size_t bytes) {

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <string>
 #include <memory>
+#include <map>
+#include <unordered_map>
 #include <vector>
 #include "../../include/kogarashi_amd.h"
 #include "curve.h"
@@ -51,6 +53,13 @@ struct kg_ctx {
   hipEvent_t ev_order = nullptr;         // stream-order hand-over main -> scalar queue
   bool inputs_complete = false;          // kg_ctx_set_inputs_complete: MSM inputs are complete when the call is made
 
+  // kg_malloc / kg_free keep released blocks for the next request of the same size class (capi.cpp): the first DMA into a FRESH
+  // hipMalloc allocation runs at 1-5 GB/s (its pages are mapped on first touch: 15-28 ms per 32 MiB, measured), a copy into a block
+  // that has been used before at 56 GB/s -- and every host of the boundary allocates per call (DeviceBuf::new in the Rust glue,
+  // DeviceBuffer in the C++ mirror, Context.upload in Python)
+  std::multimap<size_t, void*> pool_free;            // size class -> released blocks
+  std::unordered_map<void*, size_t> pool_live;       // every block kg_malloc handed out -> its size class
+  size_t pool_cached = 0;                            // bytes sitting in pool_free
   void* ws_vec = nullptr;                // kg_r1cs_prod: work list of long rows (grow-only)
   size_t ws_vec_bytes = 0;
   void* ws2 = nullptr;                   // NTT ping-pong buffer
@@ -123,6 +132,10 @@ inline int set_err(kg_ctx* c, int code, const char* what, hipError_t e = hipSucc
     if (s__ != KG_OK) return s__; \
   } while (0)
 
+// hipMalloc for the library's own work spaces: when the device refuses, the blocks kg_free has kept are released and the request is
+// repeated once (the pool must never be what makes a call fail)
+hipError_t dev_alloc(kg_ctx* c, void** p, size_t bytes);
+void pool_trim(kg_ctx* c);               // releases every kept block
 int ensure_ws_sort(kg_ctx* c, int set, size_t bytes);
 int make_sort_stream(kg_ctx* c);
 hipError_t create_stream(kg_ctx* c, hipStream_t* out, bool service);

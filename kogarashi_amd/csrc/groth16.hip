@@ -260,10 +260,10 @@ int fixed_base_t(kg_ctx* ctx, int curve, const uint64_t* d_k, size_t n, uint64_t
       hipFree(d_tk); hipFree(d_txy); hipFree(d_tinf);
       if (!keep_table) hipFree(table);
     };
-    hipError_t e = hipMalloc((void**)&d_tk, tn * 32);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_txy, tn * 2 * E64 * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_tinf, tn);
-    if (e == hipSuccess) e = hipMalloc((void**)&table, tn * PW * 4);
+    hipError_t e = dev_alloc(ctx, (void**)&d_tk, tn * 32);
+    if (e == hipSuccess) e = dev_alloc(ctx, (void**)&d_txy, tn * 2 * E64 * 8);
+    if (e == hipSuccess) e = dev_alloc(ctx, (void**)&d_tinf, tn);
+    if (e == hipSuccess) e = dev_alloc(ctx, (void**)&table, tn * PW * 4);
     if (e != hipSuccess) { release(false); return set_err(ctx, KG_ERR_OOM, "fixed-base table allocation", e); }
     e = hipMemcpyAsync(d_tk, hk.data(), tn * 32, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -281,7 +281,7 @@ int fixed_base_t(kg_ctx* ctx, int curve, const uint64_t* d_k, size_t n, uint64_t
   constexpr int NW = PointIO<F>::NW;
   if (n * NW * 4 > ctx->fb_tmp_bytes) {
     if (ctx->fb_tmp) { sync_all(ctx); hipFree(ctx->fb_tmp); ctx->fb_tmp = nullptr; ctx->fb_tmp_bytes = 0; }
-    KG_HIP(ctx, hipMalloc(&ctx->fb_tmp, n * NW * 4));
+    KG_HIP(ctx, dev_alloc(ctx, &ctx->fb_tmp, n * NW * 4));
     ctx->fb_tmp_bytes = n * NW * 4;
   }
   uint32_t* tmp = (uint32_t*)ctx->fb_tmp;

@@ -232,7 +232,7 @@ static int msm_grouped(kg_ctx* ctx, int curve, const uint64_t* d_bases, const ui
     const size_t bytes = n * (f64 ? (curve == KG_G2 ? 128 : 64) : (curve == KG_G2 ? 144 : 72));
     if (bytes > ctx->ws_pb_bytes) {
       if (ctx->ws_pb) { sync_all(ctx); hipFree(ctx->ws_pb); ctx->ws_pb = nullptr; ctx->ws_pb_bytes = 0; }
-      const hipError_t e = hipMalloc(&ctx->ws_pb, bytes + bytes / 8);
+      const hipError_t e = dev_alloc(ctx, &ctx->ws_pb, bytes + bytes / 8);
       if (e != hipSuccess) return set_err(ctx, KG_ERR_OOM, "resident-bases allocation", e);
       ctx->ws_pb_bytes = bytes + bytes / 8;
     }
@@ -312,7 +312,7 @@ int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uin
   const bool fmt64 = resident_fmt64(n);
   const size_t pw = fmt64 ? (curve == KG_G2 ? 32 : 16) : (curve == KG_G2 ? 36 : 18);
   uint32_t* packed = nullptr;
-  KG_HIP(ctx, hipMalloc((void**)&packed, n * pw * 4));
+  KG_HIP(ctx, dev_alloc(ctx, (void**)&packed, n * pw * 4));
   prep_bases_enqueue(curve, ctx->stream, d_bases, d_inf, n, packed, fmt64);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) {
     hipFree(packed);
@@ -354,7 +354,7 @@ int kg_bases_precompute(kg_ctx* ctx, const uint64_t* d_bases, size_t msm_len) {
   const bool t64 = table_fmt64();
   const size_t pw = t64 ? (r->curve == KG_G2 ? 32 : 16) : (r->curve == KG_G2 ? 36 : 18), row = r->n * pw;
   uint32_t* table = nullptr;
-  if (hipError_t e = hipMalloc((void**)&table, (size_t)W * row * 4); e != hipSuccess) {
+  if (hipError_t e = dev_alloc(ctx, (void**)&table, (size_t)W * row * 4); e != hipSuccess) {
     (void)hipGetLastError();
     return set_err(ctx, KG_ERR_OOM, "window table allocation", e);
   }
@@ -414,7 +414,7 @@ int kg_msm_end(kg_ctx* ctx, int curve, int ticket, uint64_t* out_xyz) {
 static int grow_device(kg_ctx* ctx, int which, size_t bytes) {
   if (bytes <= ctx->up_bytes[which]) return KG_OK;
   if (ctx->up_buf[which]) { sync_all(ctx); hipFree(ctx->up_buf[which]); ctx->up_buf[which] = nullptr; ctx->up_bytes[which] = 0; }
-  const hipError_t e = hipMalloc(&ctx->up_buf[which], bytes + bytes / 8);
+  const hipError_t e = dev_alloc(ctx, &ctx->up_buf[which], bytes + bytes / 8);
   if (e != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, KG_ERR_OOM, "upload buffer allocation", e); }
   ctx->up_bytes[which] = bytes + bytes / 8;
   return KG_OK;

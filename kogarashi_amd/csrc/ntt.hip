@@ -166,7 +166,7 @@ int get_tables(kg_ctx* ctx, uint32_t log_n, int inverse, kg_tw_cache** out) {
   // 151 MB at 2^22), step B of a three-step plan w_n^(n1 * i2 * j3) (n2 * n3 entries)
   const size_t cnt_a = (nsteps >= 2 && log_n <= direct_a_max_log()) ? (size_t)1 << log_n : 0;
   const size_t cnt_b = nsteps == 3 ? (size_t)1 << (d[1].log_m + d[2].log_m) : 0;
-  auto alloc = [&](uint32_t** p, size_t entries) { return entries == 0 || hipMalloc((void**)p, entries * 36) == hipSuccess; };
+  auto alloc = [&](uint32_t** p, size_t entries) { return entries == 0 || dev_alloc(ctx, (void**)p, entries * 36) == hipSuccess; };
   if (!alloc(&t->small, 2u << (NTT_TW_LOG - 1)) || !alloc(&t->lo, n_lo) || !alloc(&t->hi, n_hi) || !alloc(&t->cos_lo, n_lo) ||
       !alloc(&t->cos_hi, n_hi) || !alloc(&t->zinv, 1)) {
     (void)hipGetLastError();

@@ -136,7 +136,7 @@ int kg_groth16_setup_bn254(kg_ctx* ctx, const kg_csr* a, const kg_csr* b, const 
                o_tptr = cv.take((nv + 2) * 8), o_tcol = cv.take((nnz_max + 1) * 8), o_tval = cv.take((nnz_max + 1) * 32),
                o_vks = cv.take(6 * 32), o_vk1 = cv.take(3 * 64), o_vk2 = cv.take(3 * 128), o_vki = cv.take(64);
   char* ws = nullptr;
-  if (hipError_t e = hipMalloc((void**)&ws, cv.off); e != hipSuccess) return set_err(ctx, KG_ERR_OOM, "setup scratch allocation", e);
+  if (hipError_t e = dev_alloc(ctx, (void**)&ws, cv.off); e != hipSuccess) return set_err(ctx, KG_ERR_OOM, "setup scratch allocation", e);
   struct Free { kg_ctx* c; char* p; ~Free() { kg_ctx_sync(c); hipFree(p); } } guard{ctx, ws};
   KG_TRY(ensure_ws_vec(ctx, 3 * (nv + 16) * 4));
   hipStream_t st = ctx->stream;

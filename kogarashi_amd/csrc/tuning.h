@@ -51,6 +51,8 @@
   X(ntt_direct_max_log, "KG_NTT_DIRECT_MAX_LOG", 22, "largest log2 of a direct inter-step twiddle table, 0..22 (beyond it, and when the allocation fails: composed twiddles)") \
   X(ntt_steps, "KG_NTT_STEPS", 0, "force the number of steps (HBM round trips) of a transform, 1..3; 0 = by size") \
   X(ntt_tile, "KG_NTT_TILE", 0, "force log2 of the elements a workgroup holds in LDS; 0 = by size") \
+  /* ---- device memory ---------------------------------------------------------------------------------------------------------------- */ \
+  X(pool_mb, "KG_POOL_MB", 8192, "MiB of released kg_malloc blocks a context keeps for the next request of the same size (0 = none: every kg_free is a hipFree); kept blocks are given back when the device runs out") \
   /* ---- queues, diagnostics --------------------------------------------------------------------------------------------------------- */ \
   X(queue_placement, "KG_QUEUE_PLACEMENT", 1, "0 = the context's queues in creation order instead of probed over the compute pipes") \
   X(trace_host, "KG_TRACE_HOST", 0, "1 = host-side timestamps of the MSM pipeline's calls on stderr") \

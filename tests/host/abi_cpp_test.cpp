@@ -86,6 +86,12 @@ static void test_msm(const Context& ctx, int curve) {
   const G1Projective id = msm_curve_addition(ctx, {}, {}, curve);
   const Fe zero{0, 0, 0, 0};
   CHECK(id.x == zero && id.z == zero && !std::memcmp(id.y.data(), consts + 5, 32), "msm_curve_addition of nothing");
+  // the same bases resident (marshalled and registered once), the scalars a host vector per call
+  const ResidentBases rb(ctx, points(xy.data(), inf.data(), n), curve);
+  for (int rep = 0; rep < 2; ++rep) {
+    const G1Projective r2 = rb.msm(k);
+    CHECK(r2.x == got.x && r2.y == got.y && r2.z == got.z, "ResidentBases::msm");
+  }
 }
 
 static void test_fft(const Context& ctx, int k) {
@@ -194,6 +200,36 @@ static void test_prover(const Context& ctx) {
           !std::memcmp(pr.b.y1.data(), want + 20, 32), "proof.b");
     CHECK(!std::memcmp(pr.c.x.data(), want + 24, 32) && !std::memcmp(pr.c.y.data(), want + 28, 32), "proof.c");
   }
+  {
+    // ZkSnark::setup behind the boundary: the same Parameters and VerifyingKey from the matrices and the five toxic scalars
+    SparseMatrix A{a_rp, a_col, a_val}, B{b_rp, b_col, b_val}, C{c_rp, c_col, c_val};
+    const auto made = setup(ctx, A, B, C, l, m_l_1, std::array<Fe, 5>{toxic[0], toxic[1], toxic[2], toxic[3], toxic[4]});
+    const Parameters& Q = made.first;
+    auto same1 = [](const std::vector<G1Affine>& u, const std::vector<G1Affine>& v) {
+      if (u.size() != v.size()) return false;
+      for (size_t i = 0; i < u.size(); ++i) if (u[i].x != v[i].x || u[i].y != v[i].y || u[i].is_infinity != v[i].is_infinity) return false;
+      return true;
+    };
+    CHECK(same1(Q.h, P.h) && same1(Q.l, P.l) && same1(Q.a, P.a) && same1(Q.b_g1, P.b_g1), "setup: G1 vectors of Parameters");
+    bool g2ok = Q.b_g2.size() == P.b_g2.size();
+    for (size_t i = 0; g2ok && i < nv; ++i)
+      g2ok = Q.b_g2[i].x0 == P.b_g2[i].x0 && Q.b_g2[i].x1 == P.b_g2[i].x1 && Q.b_g2[i].y0 == P.b_g2[i].y0 && Q.b_g2[i].y1 == P.b_g2[i].y1 &&
+             Q.b_g2[i].is_infinity == P.b_g2[i].is_infinity;
+    CHECK(g2ok, "setup: b_g2");
+    CHECK(Q.alpha_g1.x == P.alpha_g1.x && Q.beta_g1.y == P.beta_g1.y && Q.delta_g1.x == P.delta_g1.x && Q.beta_g2.x1 == P.beta_g2.x1 &&
+          Q.delta_g2.y0 == P.delta_g2.y0, "setup: vk points of Parameters");
+    const G2Affine gamma = g2at(2);
+    CHECK(made.second.gamma_g2.x0 == gamma.x0 && made.second.gamma_g2.y1 == gamma.y1, "setup: gamma_g2");
+    std::vector<u64> ic_xy;
+    std::vector<unsigned char> ic_inf;
+    g1(ics, ic_xy, ic_inf);
+    CHECK(same1(made.second.ic, points(ic_xy.data(), ic_inf.data(), l)), "setup: vk.ic");
+    bool inv_threw = false;
+    try {
+      setup(ctx, A, B, C, l, m_l_1, std::array<Fe, 5>{toxic[0], toxic[1], Fe{0, 0, 0, 0}, toxic[3], toxic[4]});
+    } catch (const ProverInversionFailed&) { inv_threw = true; }
+    CHECK(inv_threw, "Error::ProverInversionFailed");
+  }
   P.delta_g1.is_infinity = true;                       // prover.rs:67-69
   bool threw = false;
   try {
@@ -231,6 +267,14 @@ static void test_nova(const Context& ctx, int field) {
   bool threw = false;
   try { shape.prod(0, std::vector<Fe>(nz - 200)); } catch (const std::out_of_range&) { threw = true; }
   CHECK(threw, "short z is refused");
+  // RelaxedR1csWitness::fold (witness.rs:56-70): W1 + r W2 element by element
+  std::vector<Fe> folded(nz);
+  for (size_t i = 0; i < nz; ++i) {
+    Fe t;
+    kgo_f_mul(field, us[0].data(), z2[i].data(), t.data());
+    kgo_f_add(field, z1[i].data(), t.data(), folded[i].data());
+  }
+  CHECK(fold(ctx, z1, us[0], z2, field) == folded, "RelaxedR1csWitness::fold");
 }
 
 // the commitment key over two contexts (sharing device 0 on a one-GPU box) against the single-context commitment

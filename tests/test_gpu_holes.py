@@ -135,6 +135,39 @@ def test_absurd_allocation_is_a_status_code_and_the_context_survives(ctx, oracle
     assert (ctx.msm_host(K.KG_G1, b, None, s, n)[:8] == want_xy).all()
 
 
+def test_released_blocks_are_kept_for_the_next_request_and_given_back_under_pressure():
+    """kg_malloc / kg_free keep released blocks per size class (capi.cpp: the first copy into a FRESH allocation runs at 1-5 GB/s, into a used
+    block at 56 GB/s): the same request gets the same block back, kept blocks count as free memory, KG_POOL_MB bounds what is kept, and a
+    work-space request the device refuses releases them instead of failing."""
+    import kogarashi_amd as K
+    ctx = K.Context(0)
+    free0, _ = ctx.mem_info()
+    a = ctx.malloc(33 << 20)
+    ctx.free(a)
+    assert ctx.mem_info()[0] >= free0 - (1 << 20)                   # the kept 33 MiB count as free
+    b = ctx.malloc((33 << 20) - 4096)                               # same size class (whole MiB above 1 MiB)
+    assert b == a
+    c = ctx.malloc(33 << 20)                                        # a second block of the class: a new allocation
+    assert c != b
+    ctx.free(b); ctx.free(c)
+    big = [ctx.malloc(3 << 30) for _ in range(4)]                   # 12 GiB released with an 8 GiB pool: two blocks are kept, two go back
+    for p in big:
+        ctx.free(p)
+    # pressure: filling the device takes the kept blocks' memory too -- a request the device refuses releases them and is repeated
+    held = _hog(ctx, 64 << 20)
+    assert ctx.mem_info()[0] <= (64 << 20) + (16 << 20)             # nothing is left, kept or free
+    with pytest.raises(K.KogarashiError, match="out of device memory"):
+        ctx.malloc(1 << 30)
+    for p in held:
+        ctx.free(p)
+    n = 1 << 18
+    g, m = ctx.empty((n, 8)), ctx.empty((n, 4))
+    ctx.gen_bases(K.KG_G1, SEED + 90, 0, n, g.ptr)
+    ctx.gen_scalars(K.KG_FR, SEED + 91, 0, n, m.ptr)
+    assert ctx.msm(K.KG_G1, g.ptr, 0, m.ptr, n)[8:].any()
+    ctx.close()
+
+
 def test_work_space_refused_is_oom_and_the_call_succeeds_once_memory_is_back(oracle):
     """The device is filled up to 48 MiB: a 2^20-pair MSM's work space (hundreds of MiB), the host-scalar entry's upload buffer and
     a Groth16-size NTT buffer are refused -> KG_ERR_OOM each, nothing aborts; after the memory is released the same calls succeed
