@@ -450,7 +450,7 @@ def pmc_traffic(log_n):
     WRITE_SIZE are collected in separate runs of this same command.  MI355X_MICROARCH.md prescribes doubling FETCH_SIZE on
     gfx950 for wide coalesced streams; this kernel's reads are scattered 8-byte-per-lane gathers, for which the correction is
     uncalibrated -- both figures are reported.  Only valid for the configuration it was measured on (2^20 pairs); null otherwise."""
-    for name in ("r04_pmc_hbm.json", "r03_pmc_hbm.json", "r02_pmc_hbm.json", "r01_m_pmc_hbm.json"):
+    for name in ("r05_pmc_hbm.json", "r04_pmc_hbm.json", "r03_pmc_hbm.json", "r02_pmc_hbm.json", "r01_m_pmc_hbm.json"):
         path = os.environ.get("KG_BENCH_PMC") or os.path.join(ROOT, "profiles", name)
         if log_n == LOG_N and os.path.exists(path):
             with open(path) as f:

@@ -124,3 +124,23 @@ def test_host_point_sums_without_a_device(lib):
             else:
                 wxy, winf = O.to_affine(cv, want)
                 assert got_inf == winf and (winf or (got_xy == wxy).all()), (cv, len(arr))
+
+
+def test_knob_table_is_one_table_and_the_readme_quotes_it(lib):
+    """every KG_* variable the library reads lives in kogarashi_amd/csrc/tuning.h (no getenv anywhere else), kg_tuning_describe walks it,
+    and README.md's table is the generated one (tools/gen_knob_table.py)"""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "kogarashi_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".h", ".hip", ".cpp")) and f not in ("tuning.cpp",):
+            txt = open(os.path.join(csrc, f)).read()
+            for m in re.finditer(r'getenv\("([A-Z0-9_]+)"\)', txt):
+                assert m.group(1) == "GPU_MAX_HW_QUEUES", (f, m.group(1))        # kg_init / kg_hw_queue_setting: the runtime's variable, not a knob
+    from kogarashi_amd.lib import tuning_table
+    rows = tuning_table()
+    assert len(rows) >= 30 and len({r["env"] for r in rows}) == len(rows)
+    assert all(r["env"].startswith("KG_") and r["doc"] for r in rows)
+    if not any(k.startswith("KG_") and k not in ("KG_LIB_PATH", "KG_BENCH_SELFTEST", "KG_BENCH_PMC") for k in os.environ):
+        assert all(r["value"] == r["default"] for r in rows)
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_knob_table.py"), "--check"]).returncode == 0, "run python tools/gen_knob_table.py"

@@ -9,9 +9,9 @@ export TMPDIR=/tmp
 O=gpurun_out/collect
 rm -rf "$O"; mkdir -p "$O"
 # 1. the bench line itself (default flags: what the driver runs)
-timeout -s KILL 400 python3 bench.py > "$O/bench.json" 2> "$O/bench.err"
+timeout -s KILL 700 python3 bench.py > "$O/bench.json" 2> "$O/bench.err"
 # 2. the same command under the kernel trace (kernel averages must agree with the line's HIP-event figures)
-timeout -s KILL 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_bench" -- python3 bench.py --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/kt_bench.err"
+timeout -s KILL 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_bench" -- python3 bench.py --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/kt_bench.err"
 # 3. MSM legs only (the kernels of the headline metric without NTT / Groth16 launches in the averages)
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_msm" -- python3 bench.py --no-cpu-baseline --no-ntt --no-groth16 --no-nova --no-skew > "$O/msm_under_rocprof.json" 2> "$O/kt_msm.err"
 # 4. HBM traffic: one counter per pass

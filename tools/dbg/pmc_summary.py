@@ -9,7 +9,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+        name = re.sub(r"(kg::)?(msm::)?\(anonymous namespace\)::|kg::msm::|kg::", "", r["Kernel_Name"])
         name = re.sub(r"^void ", "", name)
         m = re.match(r"([A-Za-z_0-9]+)(<[^(]*>)?\(", name)
         key = m.group(1) + (m.group(2) if m and m.group(2) and ("Fp2" in m.group(2)) else "") if m else name[:40]

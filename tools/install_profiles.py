@@ -35,7 +35,7 @@ def sq_counters(pass_dir, out_path, only=None):
         if "k_ntt_tile" in name:
             key = re.search(r"k_ntt_tile<[^>]*>", name).group(0).replace(" ", "") + "/grid" + r["Grid_Size"]
         else:
-            key = re.sub(r"\(anonymous namespace\)::", "", name); key = re.sub(r"^void ", "", key); key = re.sub(r"\(.*", "", key)
+            key = re.sub(r"(kg::)?(msm::)?\(anonymous namespace\)::|kg::msm::|kg::", "", name); key = re.sub(r"^void ", "", key); key = re.sub(r"\(.*", "", key)
         acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[key] += r["Counter_Name"] == "SQ_WAVE_CYCLES"
     out = {k: {"dispatches": cnt[k], **{c: v / max(cnt[k], 1) for c, v in d.items()}} for k, d in acc.items()}
