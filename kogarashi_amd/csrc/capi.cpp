@@ -362,8 +362,7 @@ void kg_ctx_destroy(kg_ctx* c) {
   }
   if (c->ev_pb) hipEventDestroy(c->ev_pb);
   if (c->ev_prep) hipEventDestroy(c->ev_prep);
-  pool_trim(c);
-  for (auto& kv : c->pool_live) hipFree(kv.first);       // blocks the host never freed go with the context
+  pool_trim(c);                                          // (blocks the host still holds stay allocated, as before the pool: they are the host's)
   if (c->ws_pb) hipFree(c->ws_pb);
   for (auto& sl : c->slots) { if (sl.host) hipHostFree(sl.host); if (sl.done) hipEventDestroy(sl.done); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
