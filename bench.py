@@ -864,6 +864,21 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
         sync()
         dt_w = mx(time.perf_counter() - t0) / k_pipe
         out["window_tables"].update({"ms_per_proof_from_witness": dt_w * 1e3, "from_witness_matches": bool(all((proof_w[i] == proof[i]).all() for i in range(4)))})
+        # and as the patched Prover::create_proof calls it (rust/kogarashi-amd/src/groth16.rs prove_cs_with): BLOCKING, x = cs.x() and w = cs.w()
+        # in host memory, uploaded into kg_malloc buffers per proof (the pool hands the same blocks back) -- PCIe-inclusive, never `value`
+        hx, hw = np.ascontiguousarray(x), np.ascontiguousarray(w)
+
+        def host_proof():
+            dx, dw = ctx.upload(hx), ctx.upload(hw)
+            return ctx.groth16_prove_r1cs(crs, csr_ptr[0], csr_ptr[1], csr_ptr[2], dx.ptr, dw.ptr, r, s_)
+        for _ in range(3):
+            proof_h = host_proof()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            proof_h = host_proof()
+        dt_h = (time.perf_counter() - t0) / steps
+        out["window_tables"].update({"ms_per_proof_blocking_host_witness": dt_h * 1e3, "witness_bytes": int(hx.nbytes + hw.nbytes),
+                                     "host_witness_matches": bool(all((proof_h[i] == proof[i]).all() for i in range(4)))})
     # the CPU leg LAST: a second of 32 busy host threads in front of a timed GPU leg costs it 3-5 % (clocks, host threads)
     if cpu:
         from oracle import oracle as O

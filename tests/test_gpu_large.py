@@ -211,6 +211,16 @@ def test_groth16_2_18_matches_oracle(ctx, oracle):
     m = 1 << 18
     cc = syn.ChainCircuit(m)
     P = groth16_setup(cc.a, cc.b, cc.c, m, cc.l, cc.m_l_1, syn.fixed_toxic(), syn.FrOps, ctx=ctx)
+    # the CRS itself at full size: the oracle's restatement of zksnark.rs gives every SCALAR of the 2^18-constraint setup in seconds; its
+    # generator multiples (the slow part on a CPU) are checked on 96 sampled entries per vector, the edges and the instance wires included
+    sc = O.groth16_setup_scalars(O.R1cs(cc.a, cc.b, cc.c, cc.x, cc.w), syn.fixed_toxic())
+    rng = np.random.default_rng(18)
+    for name, key, curve in (("h", "h", 0), ("l", "l", 0), ("a", "a", 0), ("b_g1", "b", 0), ("b_g2", "b", 2), ("ic", "ic", 0)):
+        k = sc[key]
+        assert len(P[name]) == len(k), name
+        idx = np.unique(np.concatenate([[0, 1, 2, len(k) - 1], rng.integers(0, len(k), 92)])) if len(k) > 4 else np.arange(len(k))
+        xy, inf = O.fixed_base_mul(curve, k[idx], threads=8)
+        assert (P[name][idx] == xy).all() and (P[name + "_inf"][idx] == inf).all(), name
     r, s = syn.fixed_rs()
     prover = K.Prover(P, m, cc.l, cc.m_l_1, ctx=ctx)
     got = prover.create_proof(cc.a_eval, cc.b_eval, cc.c_eval, cc.x, cc.w, r, s)
