@@ -243,7 +243,10 @@ int fixed_base_t(kg_ctx* ctx, int curve, const uint64_t* d_k, size_t n, uint64_t
   hipStream_t st = ctx->stream;
   constexpr int PW = FbIO<F>::PW;
   const size_t tn = (size_t)FB_WIN * FB_ENT;
-  if (n < 512) {                                      // few scalars (vk elements, tests): plain double-and-add; also builds the table
+  if (n < 512 && !ctx->fb_table[curve]) {             // few scalars and no table yet (vk elements of a host that never makes a CRS, tests): plain
+                                                      // double-and-add, a 255-step chain per lane (2 ms in G1, 5.5 ms in G2 whatever n is); also builds the
+                                                      // table.  Once the table exists (kg_groth16_setup_bn254 has made its long vectors first) the few go
+                                                      // through it as well: 32 additions and an inversion, ~0.5 ms
     hipLaunchKernelGGL((k_fixed_base_mul<F, SP, E64>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_k, n, d_out_xy, d_out_inf);
     KG_HIP(ctx, hipGetLastError());
     return KG_OK;

@@ -25,11 +25,33 @@ using namespace kg;
 
 namespace {
 
+// counter[key] += 1 for every active lane, ONE atomic per distinct key of the wave; returns the lane's own slot (the counter's value
+// before the wave's addition + the lane's rank among its peers).  Constraint systems have wires that nearly every row uses (the constant
+// one: every second entry of B in the chain circuit) -- 2^18 atomics on one address took 3 ms per matrix, the aggregated form 0.1.
+__device__ __forceinline__ uint32_t wave_add_by_key(uint32_t* counters, uint32_t key, bool active) {
+  const int lane = (int)(threadIdx.x & 63);
+  unsigned long long todo = __ballot(active);
+  uint32_t pos = 0;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t k = (uint32_t)__shfl((int)key, leader);
+    const bool mine = active && key == k;
+    const unsigned long long peers = __ballot(mine);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&counters[k], (uint32_t)__popcll(peers));
+    base = (uint32_t)__shfl((int)base, leader);
+    if (mine) pos = base + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+    todo &= ~peers;
+  }
+  return pos;
+}
+
 // entries per column (+1: the scan below turns them into row pointers of the transpose)
 __global__ void __launch_bounds__(256) k_col_count(const uint64_t* __restrict__ col, size_t nnz, uint32_t* __restrict__ cnt) {
   KG_SERVICE_PRIO();
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < nnz) atomicAdd(&cnt[col[e] + 1], 1u);
+  const bool active = e < nnz;
+  wave_add_by_key(cnt, active ? (uint32_t)col[e] + 1u : 0u, active);
 }
 
 // exclusive scan of cnt[0 .. len) by ONE workgroup (len = variables + 1: a few hundred thousand; setup is not a hot path):
@@ -66,13 +88,14 @@ __global__ void __launch_bounds__(256) k_transpose_fill(const uint64_t* __restri
                                                         size_t m, size_t nnz, uint32_t* __restrict__ cursor, uint64_t* __restrict__ t_col, uint64_t* __restrict__ t_val) {
   KG_SERVICE_PRIO();
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nnz) return;
+  const bool active = e < nnz;                            // (no early return: the wave's lanes meet in wave_add_by_key)
   size_t lo = 0, hi = m;                                  // the row of entry e: largest r with row_ptr[r] <= e
-  while (hi - lo > 1) {
+  while (active && hi - lo > 1) {
     const size_t mid = (lo + hi) >> 1;
     if (row_ptr[mid] <= e) lo = mid; else hi = mid;
   }
-  const uint32_t pos = atomicAdd(&cursor[col[e]], 1u);
+  const uint32_t pos = wave_add_by_key(cursor, active ? (uint32_t)col[e] : 0u, active);
+  if (!active) return;
   t_col[pos] = lo;
   const uint4* src = reinterpret_cast<const uint4*>(val) + 2 * e;
   uint4* dst = reinterpret_cast<uint4*>(t_val) + 2 * (size_t)pos;

@@ -147,23 +147,47 @@ __global__ void __launch_bounds__(256) k_r1cs_rows_short(const uint64_t* __restr
   words_from_limbs(reduce_2p(mul(sum[0], Fp<P>::from_const(P::C_FROM_REF))), wo);        // raw product domain -> the ABI's
   store_words(out, row, wo);
 }
+// A long row per WORKGROUP (1024 lanes stride over its entries; wave sums by shuffles, the sixteen wave sums through LDS).  Up to round 4
+// a wave took a long row: the transposed systems of the setup have a row per wire, and the constant-one wire's row holds an entry per
+// constraint -- 2^18 entries on 64 lanes took 4.8 ms of a 29 ms setup.
+constexpr int LONG_NT = 1024;
 template <class P>
-__global__ void __launch_bounds__(256) k_r1cs_rows_long(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
-                                                        const uint64_t* __restrict__ val, const uint64_t* __restrict__ z, uint64_t* __restrict__ out,
-                                                        const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ long_count) {
+__global__ void __launch_bounds__(LONG_NT) k_r1cs_rows_long(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
+                                                            const uint64_t* __restrict__ val, const uint64_t* __restrict__ z, uint64_t* __restrict__ out,
+                                                            const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ long_count) {
   KG_SERVICE_PRIO();
-  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6), wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
+  __shared__ uint32_t part[LONG_NT / 64][9];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t total = *long_count;
-  for (uint32_t i = wave; i < total; i += nwaves) {      // wave-uniform trip count: the shuffles inside row_dot see full waves
+  for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {      // workgroup-uniform trip count
     const size_t row = long_rows[i];
-    Fp<P> sum[1];
-    row_dot<P, 64, 1>(row_ptr, col, val, row, lane, z, z, sum);
+    Fp<P> sum = Fp<P>::zero();
+    for (uint64_t e = row_ptr[row] + threadIdx.x; e < row_ptr[row + 1]; e += LONG_NT) {
+      uint32_t wv[8], wz[8];
+      load_words(val, e, wv);
+      load_words(z, col[e], wz);
+      sum = dot_step(sum, limbs_from_words<P>(wz), limbs_from_words<P>(wv));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum = dot_merge(sum, shfl_xor_f(sum, d));
     if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) part[wave][k] = sum.l[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      Fp<P> tot = sum;                                          // wave 0's own sum
+      for (int w = 1; w < LONG_NT / 64; ++w) {
+        Fp<P> o;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o.l[k] = part[w][k];
+        tot = dot_merge(tot, o);
+      }
       uint32_t wo[8];
-      words_from_limbs(reduce_2p(mul(sum[0], Fp<P>::from_const(P::C_FROM_REF))), wo);
+      words_from_limbs(reduce_2p(mul(tot, Fp<P>::from_const(P::C_FROM_REF))), wo);
       store_words(out, row, wo);
     }
+    __syncthreads();
   }
 }
 
@@ -366,10 +390,10 @@ int r1cs_prod_enqueue(kg_ctx* c, hipStream_t st, int field, const uint64_t* row_
   const dim3 grid((unsigned)((m + 255) / 256));
   if (field == KG_FR) {
     hipLaunchKernelGGL(k_r1cs_rows_short<FrParams>, grid, dim3(256), 0, st, row_ptr, col, val, m, z, out, list, count);
-    hipLaunchKernelGGL(k_r1cs_rows_long<FrParams>, dim3(256), dim3(256), 0, st, row_ptr, col, val, z, out, list, count);
+    hipLaunchKernelGGL(k_r1cs_rows_long<FrParams>, dim3(256), dim3(LONG_NT), 0, st, row_ptr, col, val, z, out, list, count);
   } else {
     hipLaunchKernelGGL(k_r1cs_rows_short<FqParams>, grid, dim3(256), 0, st, row_ptr, col, val, m, z, out, list, count);
-    hipLaunchKernelGGL(k_r1cs_rows_long<FqParams>, dim3(256), dim3(256), 0, st, row_ptr, col, val, z, out, list, count);
+    hipLaunchKernelGGL(k_r1cs_rows_long<FqParams>, dim3(256), dim3(LONG_NT), 0, st, row_ptr, col, val, z, out, list, count);
   }
   KG_HIP(c, hipGetLastError());
   return KG_OK;
