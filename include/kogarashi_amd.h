@@ -48,7 +48,7 @@ enum { KG_G1 = 0, KG_GRUMPKIN = 1, KG_G2 = 2 };      /* curve ids */
 
 typedef struct kg_ctx kg_ctx;
 
-int kg_version(void);                    /* 5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe, kg_mem_info, kg_groth16_setup_bn254, kg_experiments_built; 4: kg_msm_set_groups, kg_ctx_queue_placement; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
+int kg_version(void);                    /* 5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe, kg_mem_info, kg_groth16_setup_bn254, kg_experiments_built, kg_msm_host_slices; 4: kg_msm_set_groups, kg_ctx_queue_placement; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
 /* Optional process-level setup; call it (or export the variable yourself) BEFORE anything in the process initialises the
  * HIP runtime -- before the first kg_device_count / kg_ctx_create and before any other HIP user -- and before the host
  * starts threads (it calls setenv).  Sets GPU_MAX_HW_QUEUES=16 unless the variable is already set, so that each of a
@@ -157,6 +157,11 @@ int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* 
  * bus; only the first, short slice's upload is exposed.  Result identical to kg_msm on the uploaded scalars. */
 int kg_msm_host_scalars(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* h_scalars,
                         size_t n, uint64_t* out_xyz);
+/* How a host-array MSM of n pairs is cut into index slices (no device needed; reporting and tests): lo[0 .. K] are the slice boundaries
+ * (lo[0] = 0, lo[K] = n, 9 entries at most), K is returned (0 for n = 0).  scalars_only = 1: kg_msm_host_scalars / kg_commit_host_scalars
+ * (K = 1 below 2^17 pairs, 2 up to 2^20, 3 / 4 / 6 / 8 at 2^21 / 22 / 23 / 24; the first slice is half a share: its upload is the one
+ * nothing hides), 0: kg_msm_host (1 / 2 / 4 equal slices).  KG_HOST_SLICES / KG_HOST_FIRST_DIV apply. */
+int kg_msm_host_slices(size_t n, int scalars_only, size_t* lo);
 /* nova/src/pedersen.rs:15-20 PedersenCommitment::commit: affine(sum_i m[i] * g[i]).
  * out_xy: HOST, 8 or 16 uint64; *out_inf = 1 for the identity (then out_xy = (0, 1)). */
 int kg_commit(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars,

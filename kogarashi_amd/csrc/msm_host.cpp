@@ -424,7 +424,7 @@ static int grow_device(kg_ctx* ctx, int which, size_t bytes) {
 //   both arrays : 4 equal slices from 2^19 pairs, 2 from 2^16 (the bus is the floor; round 2's measured optimum)
 //   scalars only: the first slice is 1 / first_div of an equal share (its upload is the one nothing hides), the others equal;
 //                 K grows with n so that a slice stays a well-filled MSM (>= 2^17 pairs) and the exposed upload stays short
-static int msm_host_plan(const kg_ctx* ctx, size_t n, bool scalars_only, size_t* lo) {
+static int msm_host_plan(const kg_tuning& tune, size_t n, bool scalars_only, size_t* lo) {
   int K = n >= ((size_t)1 << 19) ? 4 : (n >= ((size_t)1 << 16) ? 2 : 1);
   int first_div = 1;
   if (scalars_only) {
@@ -437,8 +437,8 @@ static int msm_host_plan(const kg_ctx* ctx, size_t n, bool scalars_only, size_t*
     K = lg >= 24 ? 8 : (lg == 23 ? 6 : (lg == 22 ? 4 : (lg == 21 ? 3 : (lg >= 17 ? 2 : 1))));
     first_div = K > 1 ? 2 : 1;
   }
-  if (ctx->tune.host_slices >= 1 && ctx->tune.host_slices <= kg_ctx::UP_SLICES) K = ctx->tune.host_slices;
-  if (ctx->tune.host_first_div >= 1 && ctx->tune.host_first_div <= 16) first_div = ctx->tune.host_first_div;
+  if (tune.host_slices >= 1 && tune.host_slices <= kg_ctx::UP_SLICES) K = tune.host_slices;
+  if (tune.host_first_div >= 1 && tune.host_first_div <= 16) first_div = tune.host_first_div;
   if ((size_t)K > n) K = (int)n;
   if (K <= 1) { lo[0] = 0; lo[1] = n; return 1; }
   // shares: 1 for the first slice, first_div for each of the others
@@ -481,7 +481,7 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
   uint64_t* d_s = (uint64_t*)ctx->up_buf[1];
   const uint8_t* d_i = bases_on_device ? inf : (inf ? (const uint8_t*)ctx->up_buf[2] : nullptr);
   size_t lo[kg_ctx::UP_SLICES + 1];
-  const int K = msm_host_plan(ctx, n, bases_on_device, lo);
+  const int K = msm_host_plan(ctx->tune, n, bases_on_device, lo);
   // the previous call's readers of the cached buffers are done (every call joins its slices before it returns)
   std::atomic<int> up_s{0}, up_b{0}, up_rc{(int)hipSuccess};
   auto upload_all = [&] {
@@ -547,6 +547,12 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
     if (fin[j].valid()) { const int r2 = fin[j].get(); if (rc == KG_OK) rc = r2; }
   if (rc != KG_OK) { kg_ctx_sync(ctx); return rc; }
   return sum_slices(ctx, curve, part, K, out_xyz);
+}
+
+int kg_msm_host_slices(size_t n, int scalars_only, size_t* lo) {
+  if (!lo) return KG_ERR_BAD_ARG;
+  if (n == 0) { lo[0] = 0; return 0; }
+  return msm_host_plan(tuning(), n, scalars_only != 0, lo);
 }
 
 int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars, size_t n, uint64_t* out_xyz) {

@@ -25,7 +25,7 @@ EXPORTS = [
     "kg_fixed_base_mul", "kg_groth16_prove_bn254", "kg_r1cs_evaluate", "kg_field_vec_axpy", "kg_field_powers", "kg_msm_begin", "kg_msm_end", "kg_profile_summary", "kg_bases_register", "kg_bases_unregister", "kg_groth16_prove_begin", "kg_groth16_prove_end",
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
     "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_r1cs_begin", "kg_groth16_prove_sharded", "kg_ntt_plan",
-    "kg_msm_host_scalars", "kg_commit_host_scalars", "kg_tuning_describe", "kg_mem_info", "kg_groth16_setup_bn254", "kg_experiments_built",
+    "kg_msm_host_scalars", "kg_commit_host_scalars", "kg_tuning_describe", "kg_mem_info", "kg_groth16_setup_bn254", "kg_experiments_built", "kg_msm_host_slices",
 ]
 
 
@@ -118,6 +118,15 @@ def tuning_table() -> list[dict]:
             raise KogarashiError("kg_tuning_describe")
         rows.append({"env": env.value.decode(), "doc": doc.value.decode(), "default": d.value, "value": v.value})
     return rows
+
+
+def msm_host_slices(n: int, scalars_only: bool = True) -> list[int]:
+    """kg_msm_host_slices: boundaries lo[0..K] of the index slices a host-array MSM of n pairs runs in (no device needed)"""
+    lo = (C.c_size_t * 9)()
+    k = int(load().kg_msm_host_slices(C.c_size_t(n), int(bool(scalars_only)), lo))
+    if k < 0:
+        raise KogarashiError("kg_msm_host_slices")
+    return [int(lo[i]) for i in range(k + 1)] if k else [0]
 
 
 def experiments_built() -> bool:

@@ -68,3 +68,31 @@ def test_table_window_rule():
         s = (n - 1).bit_length()
         assert (w << s) <= (1 << 24), (n, c)
     assert tw(1 << 18) == 17 and tw(1 << 16) == 16
+
+
+def test_host_slice_plan_covers_the_range_at_every_length():
+    """kg_msm_host_slices (no device): the index slices of kg_msm_host_scalars / kg_msm_host are contiguous, cover [0, n), are never empty, follow the
+    documented counts, and the first slice of a host-scalar call is the short one (its upload is the one nothing hides)"""
+    import os
+    import random
+    from kogarashi_amd.lib import msm_host_slices
+    if any(k in os.environ for k in ("KG_HOST_SLICES", "KG_HOST_FIRST_DIV")):
+        import pytest
+        pytest.skip("slice knobs set in the environment")
+    assert msm_host_slices(0) == [0]
+    rnd = random.Random(5)
+    sizes = [1, 2, 255, 256, 257, 1000, (1 << 17) - 1, 1 << 17, (1 << 17) + 1] + [1 << k for k in range(18, 27)] + [rnd.randrange(1, 1 << 25) for _ in range(200)]
+    for n in sizes:
+        for only in (True, False):
+            lo = msm_host_slices(n, only)
+            assert lo[0] == 0 and lo[-1] == n and all(a < b for a, b in zip(lo, lo[1:])), (n, only, lo)
+            k = len(lo) - 1
+            lg = n.bit_length() - 1
+            if only:
+                want = 8 if lg >= 24 else 6 if lg == 23 else 4 if lg == 22 else 3 if lg == 21 else 2 if lg >= 17 else 1
+                assert k == want, (n, k)
+                if k > 1:
+                    rest = [b - a for a, b in zip(lo[1:], lo[2:])]
+                    assert lo[1] <= min(rest) and 2 * (lo[1] + 256) >= min(rest), (n, lo)      # half a share, rounded down to 256 pairs
+            else:
+                assert k == (4 if n >= (1 << 19) else 2 if n >= (1 << 16) else 1), (n, k)
