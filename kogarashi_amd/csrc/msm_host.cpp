@@ -484,29 +484,36 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
   const int K = msm_host_plan(ctx->tune, n, bases_on_device, lo);
   // the previous call's readers of the cached buffers are done (every call joins its slices before it returns)
   std::atomic<int> up_s{0}, up_b{0}, up_rc{(int)hipSuccess};
-  auto upload_all = [&] {
-    hipSetDevice(ctx->device);
-    for (int j = 0; j < K; ++j) {
-      const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
-      hipError_t e = hipMemcpyAsync(d_s + 4 * a, h_scalars + 4 * a, cnt * 32, hipMemcpyHostToDevice, ctx->up_stream);
-      if (e == hipSuccess) e = hipEventRecord(ctx->ev_up_s[j], ctx->up_stream);
-      if (e != hipSuccess) up_rc = (int)e;
-      up_s = j + 1;
-      host_trace("upload: scalars");
-      if (!bases_on_device) {
-        e = hipMemcpyAsync((char*)ctx->up_buf[0] + a * pb, (const char*)bases + a * pb, cnt * pb, hipMemcpyHostToDevice, ctx->up_stream);
-        if (e == hipSuccess && inf) e = hipMemcpyAsync((uint8_t*)ctx->up_buf[2] + a, inf + a, cnt, hipMemcpyHostToDevice, ctx->up_stream);
-        if (e == hipSuccess) e = hipEventRecord(ctx->ev_up_b[j], ctx->up_stream);
-        if (e != hipSuccess) up_rc = (int)e;
-        host_trace("upload: bases");
-      }
-      up_b = j + 1;
-    }
+  auto upload_scalars = [&](int j) {
+    const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
+    hipError_t e = hipMemcpyAsync(d_s + 4 * a, h_scalars + 4 * a, cnt * 32, hipMemcpyHostToDevice, ctx->up_stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_up_s[j], ctx->up_stream);
+    if (e != hipSuccess) up_rc = (int)e;
+    up_s = j + 1;
+    host_trace("upload: scalars");
   };
-  // one slice: nothing to overlap, the calling thread uploads; otherwise an uploader thread feeds the pipeline (a copy from
-  // pageable memory occupies its thread for the duration of the copy)
+  auto upload_bases = [&](int j) {
+    if (!bases_on_device) {
+      const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
+      hipError_t e = hipMemcpyAsync((char*)ctx->up_buf[0] + a * pb, (const char*)bases + a * pb, cnt * pb, hipMemcpyHostToDevice, ctx->up_stream);
+      if (e == hipSuccess && inf) e = hipMemcpyAsync((uint8_t*)ctx->up_buf[2] + a, inf + a, cnt, hipMemcpyHostToDevice, ctx->up_stream);
+      if (e == hipSuccess) e = hipEventRecord(ctx->ev_up_b[j], ctx->up_stream);
+      if (e != hipSuccess) up_rc = (int)e;
+      host_trace("upload: bases");
+    }
+    up_b = j + 1;
+  };
+  // The first slice's scalars go up from the calling thread (nothing can start before them: a thread start in front of that copy is
+  // 30-40 us on the critical path); everything else from an uploader thread that feeds the pipeline while this thread enqueues
+  // sorts and accumulations (a copy from pageable memory occupies its thread for the duration of the copy).
+  upload_scalars(0);
   std::thread uploader;
-  if (K == 1) upload_all(); else uploader = std::thread(upload_all);
+  if (K > 1 || !bases_on_device) uploader = std::thread([&] {
+    hipSetDevice(ctx->device);
+    upload_bases(0);
+    for (int j = 1; j < K; ++j) { upload_scalars(j); upload_bases(j); }
+  });
+  else upload_bases(0);
   std::future<int> fin[kg_ctx::UP_SLICES];
   uint64_t part[kg_ctx::UP_SLICES][24];
   int rc = KG_OK;
