@@ -9,7 +9,9 @@
  * by reference vectors.  This restatement is pinned (tests/test_oracle_*.py) against (1) every
  * constant the reference holds (moduli, R, R2, R3, INV, ROOT_OF_UNITY, generators, curve b),
  * (2) the reference's own algebraic test properties, (3) an independent big-integer implementation
- * (oracle/pyoracle.py) on committed golden vectors (tests/golden/).
+ * (oracle/pyoracle.py) on committed golden vectors (tests/golden/), (4) public known answers of the
+ * same curve -- the reference's bn254 is Ethereum's alt_bn128: 2 G of EIP-196 and the G2 generator of
+ * EIP-197 (tests/test_oracle_pinning.py::test_public_alt_bn128_known_answers).
  *
  * Every function cites the reference file:line it follows (paths relative to the reference root).
  * Limbs are 4 x u64 little-endian, Montgomery form with R = 2^256, fully reduced -- exactly the

@@ -255,3 +255,40 @@ def test_big_golden_groth16_tiny(oracle, pyoracle):
     assert np_to_pt(P.G1, A, 0) == gpt(P.G1, c["proof"]["a"])
     assert np_to_pt(P.G2, B, 0) == gpt(P.G2, c["proof"]["b"])
     assert np_to_pt(P.G1, C, 0) == gpt(P.G1, c["proof"]["c"])
+
+
+# Public known answers of the SAME curve, independent of the reference and of this repository: the reference's bn254 is Ethereum's
+# alt_bn128 (G1 generator (1, 2) on y^2 = x^3 + 3, bn254/src/params.rs:8-13; the G2 generator of params.rs:15-42 is EIP-197's), so the
+# test vectors of the EIP-196 / EIP-197 precompiles apply to it.
+EIP196_2G = (1368015179489954701390400359078579693043519447331113978918064868415326638035,
+             9918110051302171585080402603319702774565515993150576347155970296011118125764)        # ecMul((1, 2), 2) = ecAdd((1, 2), (1, 2))
+EIP197_G2 = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,       # x: real, imaginary
+              11559732032986387107991004021392285783925812861821192530917403151452391805634),
+             (8495653923123431417604973247489272438418190587263600148770280649306958101930,        # y: real, imaginary
+              4082367875863433681332203403145435568316851327593401208105741076214120093531))
+
+
+def test_public_alt_bn128_known_answers(oracle, pyoracle):
+    O, P = oracle, pyoracle
+    q, r = P.Q_MOD, P.R_MOD
+    # the reference's G2 generator limbs (bn254/src/params.rs:15-42, canonical integers given to to_mont_form) ARE EIP-197's
+    ref_g2 = ((0x1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed, 0x198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2),
+              (0x12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa, 0x090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b))
+    assert ref_g2 == EIP197_G2
+    mont = lambda v: O.f_to_mont(0, L(v))
+    k = np.stack([mont(1), mont(2), mont(r - 1), mont(0)])
+    # the oracle's generator multiples (restatement of `g * scalar`, zksnark.rs:57): 1 G, 2 G, (r - 1) G = -G, 0 G
+    xy, inf = O.fixed_base_mul(0, k, threads=1)
+    pts = [np_to_pt(CURVES["g1"][1], xy[i], inf[i]) for i in range(4)]
+    assert pts[0] == (1, 2) and pts[1] == EIP196_2G and pts[2] == (1, q - 2) and pts[3] is None
+    xy2, inf2 = O.fixed_base_mul(2, k[:1], threads=1)
+    g2 = np_to_pt(CURVES["g2"][1], xy2[0], inf2[0])
+    assert ((g2[0].a, g2[0].b), (g2[1].a, g2[1].b)) == EIP197_G2
+    # the same through the restatement of msm_curve_addition (groth16/src/msm.rs:6-48) and through the independent big-integer curve
+    g = pt_to_np(CURVES["g1"][1], (1, 2)).reshape(1, 8)
+    got = O.to_affine("g1", O.msm("g1", np.repeat(g, 3, axis=0), np.stack([mont(1), mont(1), mont(r - 1)]), None, threads=1))
+    assert np_to_pt(CURVES["g1"][1], got[0], got[1]) == (1, 2)                       # G + G - G
+    got = O.to_affine("g1", O.msm("g1", g, np.stack([mont(2)]), None, threads=1))
+    assert np_to_pt(CURVES["g1"][1], got[0], got[1]) == EIP196_2G
+    cur = CURVES["g1"][1]
+    assert cur.add((1, 2), (1, 2)) == EIP196_2G and cur.mul((1, 2), 2) == EIP196_2G and cur.mul((1, 2), r) is None
