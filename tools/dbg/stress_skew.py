@@ -48,6 +48,13 @@ for it in range(rounds):
         got = ctx.msm(curve, d_b.ptr, 0, d_s.ptr, n)
         ctx.msm_begin(curve, d_b.ptr, 0, d_s.ptr, n, 0); got2 = ctx.msm_end(curve, 0)
         if not (got2 == got).all(): bad += 1; print("PIPELINED != BLOCKING", it, cv, n, pat)
+    # the same pairs with the scalars in host memory (index slices under the uploads), bases plain and registered
+    inf_ptr = d_i.ptr if curve == 2 else 0
+    got3 = ctx.msm_host_scalars(curve, d_b.ptr, inf_ptr, scal, n)
+    ctx.bases_register(curve, d_b.ptr, inf_ptr, n)
+    got4 = ctx.msm_host_scalars(curve, d_b.ptr, inf_ptr, scal, n)
+    ctx.bases_unregister(d_b.ptr)
+    if not ((got3 == got).all() and (got4 == got).all()): bad += 1; print("HOST SCALARS != BLOCKING", it, cv, n, pat)
     w = 8 if curve != 2 else 16
     ok = (want[1] and not got[w:].any()) or ((not want[1]) and (got[:w] == want[0]).all())
     print(f"{it:3d} {cv} n={n} pattern {pat}: {'ok' if ok else 'MISMATCH'}", flush=True)
