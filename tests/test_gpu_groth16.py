@@ -139,6 +139,48 @@ def test_device_setup_matches_oracle_and_proves(ctx, oracle, m):
     assert all((g == w_).all() for g, w_ in zip(proof[:3], ref[:3]))
 
 
+@pytest.mark.parametrize("m,l,m_l_1,seed", [(37, 3, 50, 1), (500, 2, 300, 2), (1, 1, 0, 3), (260, 5, 700, 4)])
+def test_device_setup_on_random_sparse_systems(ctx, oracle, m, l, m_l_1, seed):
+    """The setup's transposition and transposed products on matrices that are NOT the chain circuit: random rows of 0..6 entries (empty rows,
+    columns nobody uses, the same column twice in a row), one wire that most rows use (a heavy column: the wave-aggregated atomics), one
+    row that names every wire (a long row), more wires than constraints and the other way round -- every CRS element against the
+    oracle's restatement of zksnark.rs:131-194 (eval / eval_at_tau fold the entries in storage order; the device in any order)."""
+    from kogarashi_amd.api import groth16_setup
+    O = oracle
+    rng = np.random.default_rng(seed)
+    nv = l + m_l_1
+
+    def matrix(k):
+        rp, col = [0], []
+        for i in range(m):
+            cnt = int(rng.integers(0, 7))
+            if nv and i == m // 2 and k == 1:
+                cols = list(range(nv))                                 # the long row
+            elif nv:
+                cols = [int(c) for c in rng.integers(0, nv, cnt)]
+                if cnt >= 2 and rng.random() < 0.3:
+                    cols[1] = cols[0]                                  # a duplicate entry
+                if rng.random() < 0.7 and k != 2:
+                    cols.append(0)                                     # the heavy column
+            else:
+                cols = []
+            col += cols
+            rp.append(len(col))
+        val = O.gen_scalars(0, SEED + 700 + 10 * seed + k, 0, max(len(col), 1))[: len(col)]
+        return (np.array(rp, dtype=np.uint64), np.array(col, dtype=np.uint64), np.ascontiguousarray(val).reshape(-1, 4))
+    a, b, c = matrix(0), matrix(1), matrix(2)
+    x = O.gen_scalars(0, SEED + 790 + seed, 0, max(l, 1))[:l]
+    w = O.gen_scalars(0, SEED + 795 + seed, 0, max(m_l_1, 1))[:m_l_1]
+    cs = O.R1cs(a, b, c, x, w)
+    toxic = O.gen_scalars(0, SEED + 799 + seed, 0, 5)
+    want = O.groth16_params(cs, toxic, threads=8)
+    got = groth16_setup(a, b, c, m, l, m_l_1, toxic, ctx=ctx)
+    for name in ("h", "l", "a", "b_g1", "b_g2", "ic"):
+        assert got[name].shape == want[name].shape and (got[name] == want[name]).all(), name
+        assert (got[name + "_inf"] == want[name + "_inf"]).all(), name
+    assert (got["vk_g1"] == want["vk_g1"]).all() and (got["vk_g2"] == want["vk_g2"][:2]).all() and (got["gamma_g2"] == want["vk_g2"][2]).all()
+
+
 def test_setup_status_codes(ctx, oracle):
     """gamma = 0 or delta = 0 -> Error::ProverInversionFailed (zksnark.rs:37-38); alpha = 0 is legal (alpha_g1 is the identity, flagged);
     missing output arrays and m = 0 are KG_ERR_BAD_ARG; nothing aborts and the context keeps working"""
