@@ -130,6 +130,7 @@ __device__ __forceinline__ void row_dot(const uint64_t* __restrict__ row_ptr, co
 // of the setup have one per heavily used wire, the constant-one wire touching every constraint -- is put on a work list
 // instead and summed by a whole wave in the second launch.
 constexpr uint32_t SHORT_ROW = 48;
+constexpr uint32_t HUGE_ROW = 4096;      // beyond: a 1024-lane workgroup per row (the constant-one wire's row of a transposed system: an entry per constraint)
 template <class P>
 __global__ void __launch_bounds__(256) k_r1cs_rows_short(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
                                                          const uint64_t* __restrict__ val, size_t m, const uint64_t* __restrict__ z,
@@ -137,8 +138,10 @@ __global__ void __launch_bounds__(256) k_r1cs_rows_short(const uint64_t* __restr
   KG_SERVICE_PRIO();
   const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= m) return;
-  if (row_ptr[row + 1] - row_ptr[row] > SHORT_ROW) {
-    long_rows[atomicAdd(long_count, 1u)] = (uint32_t)row;
+  const uint64_t len = row_ptr[row + 1] - row_ptr[row];
+  if (len > SHORT_ROW) {      // work lists: long rows from the front of the list (a wave each), huge rows from its back (a workgroup each)
+    if (len > HUGE_ROW) long_rows[m - 1 - atomicAdd(long_count + 1, 1u)] = (uint32_t)row;
+    else long_rows[atomicAdd(long_count, 1u)] = (uint32_t)row;
     return;
   }
   Fp<P> sum[1];
@@ -147,20 +150,41 @@ __global__ void __launch_bounds__(256) k_r1cs_rows_short(const uint64_t* __restr
   words_from_limbs(reduce_2p(mul(sum[0], Fp<P>::from_const(P::C_FROM_REF))), wo);        // raw product domain -> the ABI's
   store_words(out, row, wo);
 }
-// A long row per WORKGROUP (1024 lanes stride over its entries; wave sums by shuffles, the sixteen wave sums through LDS).  Up to round 4
-// a wave took a long row: the transposed systems of the setup have a row per wire, and the constant-one wire's row holds an entry per
-// constraint -- 2^18 entries on 64 lanes took 4.8 ms of a 29 ms setup.
+template <class P>
+__global__ void __launch_bounds__(256) k_r1cs_rows_long(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
+                                                        const uint64_t* __restrict__ val, const uint64_t* __restrict__ z, uint64_t* __restrict__ out,
+                                                        const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ long_count) {
+  KG_SERVICE_PRIO();
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6), wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const uint32_t total = *long_count;
+  for (uint32_t i = wave; i < total; i += nwaves) {      // wave-uniform trip count: the shuffles inside row_dot see full waves
+    const size_t row = long_rows[i];
+    Fp<P> sum[1];
+    row_dot<P, 64, 1>(row_ptr, col, val, row, lane, z, z, sum);
+    if (lane == 0) {
+      uint32_t wo[8];
+      words_from_limbs(reduce_2p(mul(sum[0], Fp<P>::from_const(P::C_FROM_REF))), wo);
+      store_words(out, row, wo);
+    }
+  }
+}
+
+// A HUGE row (more than HUGE_ROW entries) per WORKGROUP: 1024 lanes stride over its entries; wave sums by shuffles, the sixteen wave sums
+// through LDS.  Up to round 4 a wave took every long row: the transposed systems of the setup have a row per wire, and the constant-one wire's
+// row holds an entry per constraint -- 2^18 entries on 64 lanes took 4.8 ms of a 29 ms setup.  Rows of 49 .. 4096 entries (a range check's bit
+// sum: 254) keep a wave each: a circuit may hold tens of thousands of them, and 1024 waves take them in parallel.
 constexpr int LONG_NT = 1024;
 template <class P>
-__global__ void __launch_bounds__(LONG_NT) k_r1cs_rows_long(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
+__global__ void __launch_bounds__(LONG_NT) k_r1cs_rows_huge(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col,
                                                             const uint64_t* __restrict__ val, const uint64_t* __restrict__ z, uint64_t* __restrict__ out,
-                                                            const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ long_count) {
+                                                            const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ long_count, size_t m) {
   KG_SERVICE_PRIO();
   __shared__ uint32_t part[LONG_NT / 64][9];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t total = *long_count;
+  const uint32_t total = long_count[1];
   for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {      // workgroup-uniform trip count
-    const size_t row = long_rows[i];
+    const size_t row = long_rows[m - 1 - i];
     Fp<P> sum = Fp<P>::zero();
     for (uint64_t e = row_ptr[row] + threadIdx.x; e < row_ptr[row + 1]; e += LONG_NT) {
       uint32_t wv[8], wz[8];
@@ -386,14 +410,16 @@ int r1cs_prod_enqueue(kg_ctx* c, hipStream_t st, int field, const uint64_t* row_
                       const uint64_t* z, uint64_t* out, uint32_t* scratch) {
   uint32_t* count = scratch;
   uint32_t* list = scratch + 16;
-  KG_HIP(c, hipMemsetAsync(count, 0, 4, st));
+  KG_HIP(c, hipMemsetAsync(count, 0, 8, st));
   const dim3 grid((unsigned)((m + 255) / 256));
   if (field == KG_FR) {
     hipLaunchKernelGGL(k_r1cs_rows_short<FrParams>, grid, dim3(256), 0, st, row_ptr, col, val, m, z, out, list, count);
-    hipLaunchKernelGGL(k_r1cs_rows_long<FrParams>, dim3(256), dim3(LONG_NT), 0, st, row_ptr, col, val, z, out, list, count);
+    hipLaunchKernelGGL(k_r1cs_rows_long<FrParams>, dim3(256), dim3(256), 0, st, row_ptr, col, val, z, out, list, count);
+    hipLaunchKernelGGL(k_r1cs_rows_huge<FrParams>, dim3(64), dim3(LONG_NT), 0, st, row_ptr, col, val, z, out, list, count, m);
   } else {
     hipLaunchKernelGGL(k_r1cs_rows_short<FqParams>, grid, dim3(256), 0, st, row_ptr, col, val, m, z, out, list, count);
-    hipLaunchKernelGGL(k_r1cs_rows_long<FqParams>, dim3(256), dim3(LONG_NT), 0, st, row_ptr, col, val, z, out, list, count);
+    hipLaunchKernelGGL(k_r1cs_rows_long<FqParams>, dim3(256), dim3(256), 0, st, row_ptr, col, val, z, out, list, count);
+    hipLaunchKernelGGL(k_r1cs_rows_huge<FqParams>, dim3(64), dim3(LONG_NT), 0, st, row_ptr, col, val, z, out, list, count, m);
   }
   KG_HIP(c, hipGetLastError());
   return KG_OK;

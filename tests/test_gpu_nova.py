@@ -181,3 +181,28 @@ def test_folding_step_matches_big_integer_fold(ctx, oracle, pyoracle, fd, curve,
         ctx.field_vec_op(fd, "add", rhs.ptr, de.ptr, rhs.ptr, m)
         assert (lhs.numpy() == rhs.numpy()).all(), step
         i1, w1 = i1_next, w1_next
+
+
+@pytest.mark.parametrize("fd", [0, 1])
+def test_matrix_vector_product_with_every_row_class(ctx, oracle, fd):
+    """kg_r1cs_prod classes its rows: up to 48 entries a lane each, 49 .. 4096 a wave each (a range check's bit sum holds 254: a circuit has
+    many), beyond that a 1024-lane workgroup each (the constant-one wire's row of a transposed system).  One matrix with all three --
+    300 rows of 254 entries, rows of exactly 48 / 49 / 4096 / 4097 entries, two rows of 70 000 -- against the oracle's SparseMatrix::prod."""
+    O = oracle
+    rng = np.random.default_rng(77 + fd)
+    m, nvars = 2000, 5000
+    counts = rng.integers(0, 7, m)
+    counts[100:400] = 254
+    counts[[10, 11, 12, 13]] = [48, 49, 4096, 4097]
+    counts[[500, 1999]] = 70000
+    counts[501] = 0
+    rp = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    col = rng.integers(0, nvars, int(rp[-1])).astype(np.uint64)
+    val = O.gen_scalars(fd, SEED + 950 + fd, 0, int(rp[-1]))
+    z = O.gen_scalars(fd, SEED + 952 + fd, 0, nvars)
+    want = O.matrix_prod(fd, (rp, col, np.ascontiguousarray(val)), z)
+    d = [ctx.upload(rp), ctx.upload(col), ctx.upload(val)]
+    dz, out = ctx.upload(z), ctx.empty((m, 4))
+    for _ in range(2):                                   # twice: the work lists are rebuilt per call
+        ctx.r1cs_prod(fd, d[0].ptr, d[1].ptr, d[2].ptr, m, dz.ptr, out.ptr)
+        assert (out.numpy() == want).all()
