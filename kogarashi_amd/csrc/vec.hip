@@ -225,10 +225,17 @@ struct CsrView { const uint64_t* row_ptr; const uint64_t* col; const uint64_t* v
 struct Limbs9 { uint32_t l[9]; };
 template <class P>
 __global__ void __launch_bounds__(256) k_nova_cross_term(CsrView A, CsrView B, CsrView C, size_t m, const uint64_t* __restrict__ z1,
-                                                         const uint64_t* __restrict__ z2, Limbs9 u1s, Limbs9 u2s, uint64_t* __restrict__ out) {
+                                                         const uint64_t* __restrict__ z2, Limbs9 u1s, Limbs9 u2s, uint64_t* __restrict__ out,
+                                                         uint32_t* __restrict__ long_rows, uint32_t* __restrict__ long_count) {
   KG_SERVICE_PRIO();
   const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= m) return;
+  // a constraint with a long linear combination (a range check's bit sum: 254 terms) would hold its whole wave for ~0.5 us per term and
+  // z vector: such rows go to a work list and get a wave each (k_nova_cross_term_long)
+  if (A.row_ptr[row + 1] - A.row_ptr[row] > SHORT_ROW || B.row_ptr[row + 1] - B.row_ptr[row] > SHORT_ROW || C.row_ptr[row + 1] - C.row_ptr[row] > SHORT_ROW) {
+    long_rows[atomicAdd(long_count, 1u)] = (uint32_t)row;
+    return;
+  }
   Fp<P> az[2], bz[2], cz[2];
   row_dot<P, 1, 2>(A.row_ptr, A.col, A.val, row, 0, z1, z2, az);
   row_dot<P, 1, 2>(B.row_ptr, B.col, B.val, row, 0, z1, z2, bz);
@@ -238,6 +245,30 @@ __global__ void __launch_bounds__(256) k_nova_cross_term(CsrView A, CsrView B, C
   uint32_t wo[8];
   words_from_limbs(reduce_2p(r), wo);
   store_words(out, row, wo);
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) k_nova_cross_term_long(CsrView A, CsrView B, CsrView C, const uint64_t* __restrict__ z1, const uint64_t* __restrict__ z2,
+                                                              Limbs9 u1s, Limbs9 u2s, uint64_t* __restrict__ out, const uint32_t* __restrict__ long_rows,
+                                                              const uint32_t* __restrict__ long_count) {
+  KG_SERVICE_PRIO();
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6), wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const uint32_t total = *long_count;
+  for (uint32_t i = wave; i < total; i += nwaves) {      // wave-uniform trip count: the shuffles inside row_dot see full waves
+    const size_t row = long_rows[i];
+    Fp<P> az[2], bz[2], cz[2];
+    row_dot<P, 64, 2>(A.row_ptr, A.col, A.val, row, lane, z1, z2, az);
+    row_dot<P, 64, 2>(B.row_ptr, B.col, B.val, row, lane, z1, z2, bz);
+    row_dot<P, 64, 2>(C.row_ptr, C.col, C.val, row, lane, z1, z2, cz);
+    if (lane == 0) {
+      const Fp<P> r = cross_term_row(az[0], az[1], bz[0], bz[1], cz[0], cz[1], Fp<P>::from_const(u1s.l), Fp<P>::from_const(u2s.l),
+                                     Fp<P>::from_const(P::C_XT_HAD));
+      uint32_t wo[8];
+      words_from_limbs(reduce_2p(r), wo);
+      store_words(out, row, wo);
+    }
+  }
 }
 
 // ---- splitmix64 streams (oracle/pyoracle.py stream_at, oracle/kg_oracle.c stream_words) ---------------
@@ -464,9 +495,19 @@ int kg_nova_cross_term(kg_ctx* c, int field, const kg_csr* a, const kg_csr* b, c
   };
   const Limbs9 u1 = scaled(h_u1, field == KG_FR), u2 = scaled(h_u2, field == KG_FR);
   const CsrView A{a->d_row_ptr, a->d_col, a->d_val}, B{b->d_row_ptr, b->d_col, b->d_val}, C{cm->d_row_ptr, cm->d_col, cm->d_val};
+  if (m >= ((size_t)1 << 32)) return set_err(c, KG_ERR_BAD_ARG, "more than 2^32 rows");
+  KG_TRY(ensure_ws_vec(c, 3 * (m + 16) * 4));             // the work list of long rows (same space as kg_r1cs_prod's)
+  uint32_t* count = (uint32_t*)c->ws_vec;
+  uint32_t* list = count + 16;
+  KG_HIP(c, hipMemsetAsync(count, 0, 8, c->stream));
   const dim3 grid((unsigned)((m + 255) / 256));
-  if (field == KG_FR) hipLaunchKernelGGL(k_nova_cross_term<FrParams>, grid, dim3(256), 0, c->stream, A, B, C, m, d_z1, d_z2, u1, u2, d_out);
-  else hipLaunchKernelGGL(k_nova_cross_term<FqParams>, grid, dim3(256), 0, c->stream, A, B, C, m, d_z1, d_z2, u1, u2, d_out);
+  if (field == KG_FR) {
+    hipLaunchKernelGGL(k_nova_cross_term<FrParams>, grid, dim3(256), 0, c->stream, A, B, C, m, d_z1, d_z2, u1, u2, d_out, list, count);
+    hipLaunchKernelGGL(k_nova_cross_term_long<FrParams>, dim3(256), dim3(256), 0, c->stream, A, B, C, d_z1, d_z2, u1, u2, d_out, list, count);
+  } else {
+    hipLaunchKernelGGL(k_nova_cross_term<FqParams>, grid, dim3(256), 0, c->stream, A, B, C, m, d_z1, d_z2, u1, u2, d_out, list, count);
+    hipLaunchKernelGGL(k_nova_cross_term_long<FqParams>, dim3(256), dim3(256), 0, c->stream, A, B, C, d_z1, d_z2, u1, u2, d_out, list, count);
+  }
   KG_HIP(c, hipGetLastError());
   return KG_OK;
 }

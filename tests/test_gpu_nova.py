@@ -23,7 +23,10 @@ def random_shape(O, fd, m, nvars, seed, max_row=6):
         counts = rng.integers(0, max_row + 1, m)
         counts[3 % m] = 0
         if m > 10:
-            counts[7] = 200                              # one long row (8 lanes stride over it)
+            counts[7] = 200                              # one long row: past 48 entries a row gets a wave of its own (work list)
+        if m > 100:
+            counts[20 + j:60:7] = 254                    # range-check-like rows, at different constraints in A, B and C
+            counts[61] = 5000 if j == 1 else counts[61]
         rp = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
         col = rng.integers(0, nvars, int(rp[-1])).astype(np.uint64)
         val = O.gen_scalars(fd, seed + 10 + j, 0, max(int(rp[-1]), 1))[: int(rp[-1])]
