@@ -153,13 +153,14 @@ int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* 
  * groth16/src/params.rs:6-28, the generators of nova/src/pedersen.rs:6-13) and live on the device -- register them once with
  * kg_bases_register -- while the scalars are a fresh HOST slice per call (groth16/src/msm.rs:6 `coeffs`, pedersen.rs:15 `m`).
  * d_bases / d_inf: device (any whole-point offset into a registered array is served from its resident copy); h_scalars: HOST,
- * pageable or pinned.  The scalars are uploaded in index slices, each sorted and accumulated while the next one is still on the
- * bus; only the first, short slice's upload is exposed.  Result identical to kg_msm on the uploaded scalars. */
+ * pageable or pinned.  From 2^19 pairs the scalars are uploaded in index slices, each sorted and accumulated while the next one is
+ * still on the bus; only the first, short slice's upload is exposed.  Shorter calls run the blocking kg_msm behind one copy (the
+ * whole upload is shorter than what a second slice costs).  Result identical to kg_msm on the uploaded scalars. */
 int kg_msm_host_scalars(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* h_scalars,
                         size_t n, uint64_t* out_xyz);
 /* How a host-array MSM of n pairs is cut into index slices (no device needed; reporting and tests): lo[0 .. K] are the slice boundaries
  * (lo[0] = 0, lo[K] = n, 9 entries at most), K is returned (0 for n = 0).  scalars_only = 1: kg_msm_host_scalars / kg_commit_host_scalars
- * (K = 1 below 2^17 pairs, 2 up to 2^20, 3 / 4 / 6 / 8 at 2^21 / 22 / 23 / 24; the first slice is half a share: its upload is the one
+ * (K = 1 below 2^19 pairs, 2 up to 2^20, 3 / 4 / 6 / 8 at 2^21 / 22 / 23 / 24; the first slice is half a share: its upload is the one
  * nothing hides), 0: kg_msm_host (1 / 2 / 4 equal slices).  KG_HOST_SLICES / KG_HOST_FIRST_DIV apply. */
 int kg_msm_host_slices(size_t n, int scalars_only, size_t* lo);
 /* nova/src/pedersen.rs:15-20 PedersenCommitment::commit: affine(sum_i m[i] * g[i]).

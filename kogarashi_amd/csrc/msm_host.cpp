@@ -280,13 +280,25 @@ static int msm_grouped(kg_ctx* ctx, int curve, const uint64_t* d_bases, const ui
   return kg::msm_finish_groups(ctx, curve, slots, NG, out_xyz);
 }
 
+static int msm_blocking(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz);
+
 int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
   if (!ctx || !out_xyz || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
+  return msm_blocking(ctx, curve, d_bases, d_inf, d_scalars, n, out_xyz);
+}
+
+// one blocking MSM over device arrays (kg_msm; the unsliced kg_msm_host_scalars behind its upload)
+static int msm_blocking(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
   const bool sliced_ok = ctx->tune.msm_sliced != 0;     // 0 (experiments): window groups instead of index slices
   if (n >= ((size_t)1 << 23) && sliced_ok && pick_window(n, ctx->msm_window) < 19) return msm_sliced(ctx, curve, d_bases, d_inf, d_scalars, n, out_xyz);   // measured: 2^24 25.8 -> 23.0 ms, 2^23 13.1 -> 12.1; below that the slices' own tails cost more than the hidden sort
   kg::MsmSorted S;
-  const int mc = kg::has_window_table(ctx, curve, d_bases, d_inf, n, n) ? kg::merged_window(ctx, n) : 0;
+  // window tables serve a BLOCKING call up to 2^18 pairs only: the merged sort is one piece, so nothing of it hides under an accumulation,
+  // while the plain form runs in window groups (msm_grouped).  Measured (MI355X, registered bases, ms without / with tables): 2^16 0.54 / 0.42,
+  // 2^17 0.63 / 0.50, 2^18 0.73 / 0.67, 2^19 1.00 / 1.05, 2^20 1.54 / 1.73 (profiles/r05_blocking_tables.txt); calls in flight
+  // (kg_msm_begin) keep the tables at every size -- there the next call's sort is hidden either way
+  const bool tables_ok = n <= ((size_t)1 << ctx->tune.blocking_tables_log);
+  const int mc = tables_ok && kg::has_window_table(ctx, curve, d_bases, d_inf, n, n) ? kg::merged_window(ctx, n) : 0;
   if (!mc) {
     int gw[kg_ctx::MAX_GROUPS];
     const int NG = kg::msm_group_plan(ctx, n, gw);
@@ -434,7 +446,8 @@ static int msm_host_plan(const kg_tuning& tune, size_t n, bool scalars_only, siz
     // first_div 2 beats 1, 3 and 4 at every size (2^20, K = 2: +0.13 / +0.14 / +0.18 / +0.12 within noise of each other above 1)
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    K = lg >= 24 ? 8 : (lg == 23 ? 6 : (lg == 22 ? 4 : (lg == 21 ? 3 : (lg >= 17 ? 2 : 1))));
+    //   2^16 .. 2^19, K = 1 / 2 (round 5, profiles/r05_host_small.txt): 0.61 / 0.77, 0.73 / 0.89, 0.97 / 1.06, 1.44 / 1.41
+    K = lg >= 24 ? 8 : (lg == 23 ? 6 : (lg == 22 ? 4 : (lg == 21 ? 3 : (lg >= 19 ? 2 : 1))));
     first_div = K > 1 ? 2 : 1;
   }
   if (tune.host_slices >= 1 && tune.host_slices <= kg_ctx::UP_SLICES) K = tune.host_slices;
@@ -507,6 +520,14 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
   // 30-40 us on the critical path); everything else from an uploader thread that feeds the pipeline while this thread enqueues
   // sorts and accumulations (a copy from pageable memory occupies its thread for the duration of the copy).
   upload_scalars(0);
+  if (K == 1 && bases_on_device) {
+    // unsliced (up to 2^18 pairs the whole upload is shorter than what a second slice costs): the blocking kg_msm behind the copy --
+    // window groups, or the window table of registered bases
+    if (up_rc != (int)hipSuccess) return set_err(ctx, KG_ERR_HIP, "host-to-device upload", (hipError_t)up_rc.load());
+    KG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_up_s[0], 0));
+    KG_HIP(ctx, hipStreamWaitEvent(sq, ctx->ev_up_s[0], 0));
+    return msm_blocking(ctx, curve, bases, inf, d_s, n, out_xyz);
+  }
   std::thread uploader;
   if (K > 1 || !bases_on_device) uploader = std::thread([&] {
     hipSetDevice(ctx->device);

@@ -81,7 +81,7 @@ def test_host_slice_plan_covers_the_range_at_every_length():
         pytest.skip("slice knobs set in the environment")
     assert msm_host_slices(0) == [0]
     rnd = random.Random(5)
-    sizes = [1, 2, 255, 256, 257, 1000, (1 << 17) - 1, 1 << 17, (1 << 17) + 1] + [1 << k for k in range(18, 27)] + [rnd.randrange(1, 1 << 25) for _ in range(200)]
+    sizes = [1, 2, 255, 256, 257, 1000, (1 << 19) - 1, 1 << 19, (1 << 19) + 1] + [1 << k for k in range(17, 27)] + [rnd.randrange(1, 1 << 25) for _ in range(200)]
     for n in sizes:
         for only in (True, False):
             lo = msm_host_slices(n, only)
@@ -89,7 +89,7 @@ def test_host_slice_plan_covers_the_range_at_every_length():
             k = len(lo) - 1
             lg = n.bit_length() - 1
             if only:
-                want = 8 if lg >= 24 else 6 if lg == 23 else 4 if lg == 22 else 3 if lg == 21 else 2 if lg >= 17 else 1
+                want = 8 if lg >= 24 else 6 if lg == 23 else 4 if lg == 22 else 3 if lg == 21 else 2 if lg >= 19 else 1
                 assert k == want, (n, k)
                 if k > 1:
                     rest = [b - a for a, b in zip(lo[1:], lo[2:])]

@@ -125,3 +125,31 @@ print("ok")
                   {"KG_HOST_SLICES": "5", "KG_HOST_FIRST_DIV": "3"}):
         r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **knobs), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (knobs, r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("log_n", [16, 18, 19])
+def test_window_tables_serve_short_blocking_calls_and_host_scalars(ctx, oracle, log_n):
+    """Registered bases with window tables (kg_bases_precompute): a blocking kg_msm / kg_msm_host_scalars of up to 2^18 pairs goes through the
+    tables (merged sort), a longer one runs in window groups against the resident copy -- either way the point of the plain call, and the oracle's."""
+    import kogarashi_amd as K
+    O, n = oracle, 1 << log_n
+    db, ds = ctx.empty((n, 8)), ctx.empty((n, 4))
+    ctx.gen_bases(K.KG_G1, SEED + 40 + log_n, 0, n, db.ptr)
+    ctx.gen_scalars(K.KG_FR, SEED + 41 + log_n, 0, n, ds.ptr)
+    hs = ds.numpy()
+    plain = ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n)
+    ctx.bases_register(K.KG_G1, db.ptr, 0, n)
+    try:
+        ctx.bases_precompute(db.ptr)
+        ctx.sync()
+        for _ in range(2):
+            assert (ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n) == plain).all()
+            assert (ctx.msm_host_scalars(K.KG_G1, db.ptr, 0, hs, n) == plain).all()
+        xy, inf = ctx.commit_host_scalars(K.KG_G1, db.ptr, 0, hs, n)
+        # a shorter call against the same array: no table row set matches its length -- the resident copy serves it
+        m = n - 4097
+        assert (ctx.msm_host_scalars(K.KG_G1, db.ptr, 0, hs[:m], m) == ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, m)).all()
+    finally:
+        ctx.bases_unregister(db.ptr)
+    oxy, oinf = O.to_affine("g1", O.msm("g1", db.numpy(), hs, None, threads=8))
+    assert not oinf and not inf and (xy == oxy).all() and (plain[:8] == oxy).all()
