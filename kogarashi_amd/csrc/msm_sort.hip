@@ -56,11 +56,14 @@ int pick_window(size_t n, int forced) {
   if (wide_from > 0 && lg >= wide_from && n <= ((size_t)1 << 24)) return 20;
   if (lg >= 21 && n <= ((size_t)1 << 24)) return 17;
   if (lg >= 19) return 16;
-  if (lg >= 14) return 15;
-  int c = lg - 3;
-  if (c < 2) c = 2;
-  if (c > 10) c = 10;
-  return c;
+  // Short inputs are latency, not work: what counts is the depth of the chains (a task's additions, log2 B reduction levels), and above all
+  // that the unsigned TOP window is not a handful of buckets holding ~n / 8 points each -- which it is for every width that leaves 255 mod c
+  // small (c = 4, 6, 7, 9, 11, 12, 14).  Measured (MI355X, blocking kg_msm, ms; profiles/r05_small_windows.txt), c = 5 / 8 / 13 / 15 against
+  // the former rule c = lg - 3: 2^6 0.26 / 0.27 / 0.33 / 0.38 (0.32); 2^8 0.38 / 0.31 / 0.38 / 0.41 (0.38); 2^9 0.47 / 0.34 / 0.38 / 0.43 (0.75);
+  // 2^10 0.71 / 0.41 / 0.42 / 0.44 (0.78); 2^11 1.18 / 0.54 / 0.48 / 0.43 (0.54); 2^12 2.13 / 0.77 / 0.62 / 0.43 (0.83); 2^13 3.92 / 1.26 / 0.67 / 0.45 (0.85)
+  // (2^10: level between 8 and 15 when blocking, 0.19 against 0.16 ms per step with four calls in flight; 1536 pairs 0.49 against 0.43)
+  if (lg >= 10) return 15;
+  return lg >= 7 ? 8 : 5;
 }
 
 // Which resident form an array of n bases gets.  The 64-byte point is the default at every size: its ~50 re-spreading
