@@ -146,6 +146,7 @@ int ensure_ws_run(kg_ctx* c, int which, size_t bytes);
 int ensure_slot(kg_ctx* c, int slot, size_t bytes);
 int ensure_pinned(kg_ctx* c, size_t bytes);
 int make_side_stream(kg_ctx* c);
+int slice_table_window(const kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t cnt);
 void sync_all(kg_ctx* c);
 
 // RAII-free phase timer: PhaseScope p(ctx, "name"); ... p.end();

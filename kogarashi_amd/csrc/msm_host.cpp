@@ -548,7 +548,10 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
     if (hipStreamWaitEvent(sq, ctx->ev_up_s[j], 0) != hipSuccess) { rc = KG_ERR_HIP; break; }
     kg::MsmSorted S;
     ctx->sort_alone = j == 0;                              // the first slice's sort has the device to itself
-    rc = kg::msm_sort(ctx, sfield, d_s + 4 * a, cnt, &S, true);
+    // registered bases with window tables: a slice reads the table's rows from its offset (15 additions per pair instead of 16 and one small
+    // bucket set per slice; every slice's sort is one piece anyway)
+    const int mc = (bases_on_device && ctx->tune.host_slice_tables) ? kg::slice_table_window(ctx, curve, (const uint64_t*)(d_b + a * pb), d_i ? d_i + a : nullptr, cnt) : 0;
+    rc = kg::msm_sort(ctx, sfield, d_s + 4 * a, cnt, &S, true, mc);
     ctx->sort_alone = was_alone;
     if (rc != KG_OK) break;
     if (bases_on_device) {

@@ -72,8 +72,9 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       const size_t off = off64 / BaseIO<F>::W;
       if (J.d_inf != (r.inf ? r.inf + off : nullptr)) continue;
       if (S.merged_shift) {                         // merged sort: the whole array through its window table
-        if (off != 0 || J.nbases != r.n || !r.table || r.table_c != c || r.table_W != S.windows) continue;
-        reg_pb = r.table;
+        // (an index slice of the array reads the same rows from its offset: row w of point i is table[w * r.n + i])
+        if (!r.table || r.table_c != c || r.table_W != S.windows) continue;
+        reg_pb = r.table + off * (r.table64 ? 2 * BaseIO<F>::PK : PW);
         A.tab_n[k] = (uint32_t)r.n;
         A.fmt64[k] = r.table64 ? 1 : 0;
       } else {
@@ -264,6 +265,24 @@ bool has_window_table(const kg_ctx* ctx, int curve, const uint64_t* d_bases, con
   for (const auto& r : ctx->registered)
     if (r.base == d_bases && r.curve == curve && r.n == nbases && r.inf == d_inf && r.table && r.table_c == c) return true;
   return false;
+}
+
+// window width of the table that covers [d_bases, d_bases + cnt) inside a registered array, if a merged sort of cnt scalars can use it
+// (an index slice of a host-scalar call); 0: none
+int slice_table_window(const kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t cnt) {
+  const size_t pw64 = curve == KG_G2 ? 16 : 8;
+  if (cnt < ((size_t)1 << 16)) return 0;
+  int s = 0;
+  while (((size_t)1 << s) < cnt) ++s;
+  for (const auto& r : ctx->registered) {
+    if (r.curve != curve || !r.table || d_bases < r.base) continue;
+    const size_t off64 = (size_t)(d_bases - r.base);
+    if (off64 % pw64 != 0 || off64 / pw64 + cnt > r.n) continue;
+    if (d_inf != (r.inf ? r.inf + off64 / pw64 : nullptr)) continue;
+    if (((size_t)r.table_W << s) > ((size_t)1 << 24)) continue;       // (window, index) must fit the entry's 24-bit field
+    return r.table_c;
+  }
+  return 0;
 }
 
 int scalar_queue(kg_ctx* ctx, hipStream_t* out) {

@@ -39,6 +39,7 @@
   X(host_slices, "KG_HOST_SLICES", 0, "index slices a host-scalar MSM is uploaded and run in: 0 = automatic (by length), 1..8") \
   X(host_first_div, "KG_HOST_FIRST_DIV", 0, "the first slice (whose upload nothing hides) is 1/div of an equal share: 0 = automatic") \
   X(blocking_tables_log, "KG_BLOCKING_TABLES_LOG", 18, "longest blocking kg_msm (log2 pairs) that goes through the window tables of registered bases; longer ones run in window groups") \
+  X(host_slice_tables, "KG_HOST_SLICE_TABLES", 1, "index slices of a host-scalar MSM go through the window tables of registered bases when they have them") \
   X(host_accq, "KG_HOST_ACCQ", 2, "accumulation queues the slices of a host-scalar MSM alternate over (1 = the main queue only)") \
   /* ---- experiments compiled only with -DKG_EXPERIMENTS ----------------------------------------------------------------------------- */ \
   X(acc_prefetch, "KG_ACC_PREFETCH", 0, "experiment: 1 = accumulation with the next base prefetched into LDS (k_acc_tasks_q; measured level)") \

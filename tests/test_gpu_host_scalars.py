@@ -137,19 +137,23 @@ def test_window_tables_serve_short_blocking_calls_and_host_scalars(ctx, oracle, 
     ctx.gen_bases(K.KG_G1, SEED + 40 + log_n, 0, n, db.ptr)
     ctx.gen_scalars(K.KG_FR, SEED + 41 + log_n, 0, n, ds.ptr)
     hs = ds.numpy()
-    plain = ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n)
-    ctx.bases_register(K.KG_G1, db.ptr, 0, n)
+    flags = np.zeros(n, dtype=np.uint8)
+    flags[[3, n // 3 - 1, n // 3, n // 3 + 1, n // 2, n - 1]] = 1      # identity bases, some at the seams of the index slices (the table rows carry them)
+    di = ctx.upload(flags)
+    plain = ctx.msm(K.KG_G1, db.ptr, di.ptr, ds.ptr, n)
+    ctx.bases_register(K.KG_G1, db.ptr, di.ptr, n)
     try:
         ctx.bases_precompute(db.ptr)
         ctx.sync()
         for _ in range(2):
-            assert (ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n) == plain).all()
-            assert (ctx.msm_host_scalars(K.KG_G1, db.ptr, 0, hs, n) == plain).all()
-        xy, inf = ctx.commit_host_scalars(K.KG_G1, db.ptr, 0, hs, n)
-        # a shorter call against the same array: no table row set matches its length -- the resident copy serves it
+            assert (ctx.msm(K.KG_G1, db.ptr, di.ptr, ds.ptr, n) == plain).all()
+            assert (ctx.msm_host_scalars(K.KG_G1, db.ptr, di.ptr, hs, n) == plain).all()      # 2^19: two index slices, each through the table's rows at its offset
+        xy, inf = ctx.commit_host_scalars(K.KG_G1, db.ptr, di.ptr, hs, n)
+        # a shorter call against the same array, and one at an offset into it
         m = n - 4097
-        assert (ctx.msm_host_scalars(K.KG_G1, db.ptr, 0, hs[:m], m) == ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, m)).all()
+        assert (ctx.msm_host_scalars(K.KG_G1, db.ptr, di.ptr, hs[:m], m) == ctx.msm(K.KG_G1, db.ptr, di.ptr, ds.ptr, m)).all()
+        assert (ctx.msm_host_scalars(K.KG_G1, db.ptr + 4097 * 64, di.ptr + 4097, hs[:m], m) == ctx.msm(K.KG_G1, db.ptr + 4097 * 64, di.ptr + 4097, ds.ptr, m)).all()
     finally:
         ctx.bases_unregister(db.ptr)
-    oxy, oinf = O.to_affine("g1", O.msm("g1", db.numpy(), hs, None, threads=8))
+    oxy, oinf = O.to_affine("g1", O.msm("g1", db.numpy(), hs, flags, threads=8))
     assert not oinf and not inf and (xy == oxy).all() and (plain[:8] == oxy).all()
