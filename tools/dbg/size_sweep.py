@@ -10,21 +10,30 @@ SEED = 0x4B6F676172617368
 ctx = K.Context(0)
 ctx.set_inputs_complete(True)
 lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (10, 24)
+CV = {"g1": (K.KG_G1, K.KG_FR, 8), "gk": (K.KG_GRUMPKIN, K.KG_FQ, 8), "g2": (K.KG_G2, K.KG_FR, 16)}[sys.argv[3] if len(sys.argv) > 3 else "g1"]
+CURVE = CV[0]
 nmax = 1 << hi
-db = ctx.empty((nmax, 8)); ds = ctx.empty((nmax, 4))
-ctx.gen_bases(K.KG_G1, SEED, 0, nmax, db.ptr); ctx.gen_scalars(K.KG_FR, SEED + 1, 0, nmax, ds.ptr); ctx.sync()
+db = ctx.empty((nmax, CV[2])); ds = ctx.empty((nmax, 4))
+ctx.gen_scalars(CV[1], SEED + 1, 0, nmax, ds.ptr)
+if CURVE == K.KG_G2:                                   # G2 bases: k_i * G2 (no try-and-increment generator for the twist)
+    dinf = ctx.empty((nmax,), dtype=np.uint8)
+    ctx.fixed_base_mul(2, ds.ptr, nmax, db.ptr, dinf.ptr)
+    ctx.gen_scalars(CV[1], SEED + 2, 0, nmax, ds.ptr)
+else:
+    ctx.gen_bases(CURVE, SEED, 0, nmax, db.ptr)
+ctx.sync()
 def piped(n, steps):
     for i in range(steps):
-        ctx.msm_begin(K.KG_G1, db.ptr, 0, ds.ptr, n, i % 4)
-        if i >= 3: ctx.msm_end(K.KG_G1, (i - 3) % 4)
-    for i in range(steps - 3, steps): ctx.msm_end(K.KG_G1, i % 4)
+        ctx.msm_begin(CURVE, db.ptr, 0, ds.ptr, n, i % 4)
+        if i >= 3: ctx.msm_end(CURVE, (i - 3) % 4)
+    for i in range(steps - 3, steps): ctx.msm_end(CURVE, i % 4)
 piped(min(nmax, 1 << 20), 200 if hi >= 20 else 2000)
 for k in range(lo, hi + 1):
     for n in ([1 << k, (1 << k) + 1, 3 << (k - 1)] if k < hi else [1 << k]):
         reps = max(3, min(30, (64 << 20) // n))
-        for _ in range(2): ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n)
+        for _ in range(2): ctx.msm(CURVE, db.ptr, 0, ds.ptr, n)
         t0 = time.perf_counter()
-        for _ in range(reps): ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n)
+        for _ in range(reps): ctx.msm(CURVE, db.ptr, 0, ds.ptr, n)
         b = (time.perf_counter() - t0) / reps * 1e3
         piped(n, 4)
         t0 = time.perf_counter(); piped(n, reps + 3); p = (time.perf_counter() - t0) / (reps + 3) * 1e3
