@@ -23,6 +23,13 @@ for lg in sizes:
         if os.environ.get('TABLES') == '1':
             ctx.bases_precompute(db.ptr); ctx.sync()
         hs = ds.numpy()
+        if os.environ.get('TORCH') == '1':             # the bench's host array: a torch CPU tensor viewed by numpy
+            import torch
+            tt = torch.empty(n * 4, dtype=torch.int64, device="cuda:0")
+            ctx.gen_scalars(field, SEED + 1, 0, n, tt.data_ptr()); ctx.sync()
+            hs = tt.cpu().numpy().view(np.uint64).reshape(n, 4)
+        elif os.environ.get('TORCH') == '2':
+            import torch                                # torch loaded, numpy array as before
         warm = max(4, (200 << 20) // n)
         for i in range(warm):                       # clock ramp: pipelined MSMs as in the bench's timed region
             ctx.msm_begin(curve, db.ptr, 0, ds.ptr, n, i % 4)
