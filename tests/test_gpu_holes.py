@@ -226,3 +226,68 @@ def test_ntt_direct_tables_refused_fall_back_to_composed_twiddles(oracle):
     ctx.ntt(v.ptr, k, False, True)                                   # and the same context keeps working: coset_dft with the fwd tables
     assert (v.numpy() == O.Fft(k).coset_dft(hv)).all()
     ctx.close()
+
+
+def test_contexts_on_one_device_from_concurrent_threads_and_a_context_handed_between_threads(oracle):
+    """SURVEY 8b threading: the reference's call sites run on whatever thread calls them (rayon workers).  Four host threads, each with its
+    own context on device 0, run blocking / in-flight / host-scalar MSMs and transforms at the same time (ctypes drops the GIL inside the
+    calls); then ONE context is used from four threads in turn.  Every result must be the single-threaded one."""
+    import threading
+    import kogarashi_amd as K
+    n = 1 << 16
+    base = K.Context(0)
+    db, ds, dv = base.empty((n, 8)), base.empty((n, 4)), base.empty((1 << 14, 4))
+    base.gen_bases(K.KG_G1, SEED + 70, 0, n, db.ptr)
+    base.gen_scalars(K.KG_FR, SEED + 71, 0, n, ds.ptr)
+    base.gen_scalars(K.KG_FR, SEED + 72, 0, 1 << 14, dv.ptr)
+    base.sync()
+    hb, hs, hv = db.numpy(), ds.numpy(), dv.numpy()
+    sizes = [1, 300, 1 << 10, 5000, 1 << 14, 40000, n]
+    want = {m: base.msm(K.KG_G1, db.ptr, 0, ds.ptr, m).copy() for m in sizes}
+    base.ntt(dv.ptr, 14, False, False)
+    base.sync()
+    want_ntt = dv.numpy().copy()
+    oxy, oinf = oracle.to_affine("g1", oracle.msm("g1", hb[:5000], hs[:5000], None, threads=4))
+    xy, inf = base.commit(K.KG_G1, db.ptr, 0, ds.ptr, 5000)
+    assert not oinf and not inf and (xy == oxy).all()
+    errors = []
+
+    def work(ctx, tid, rounds):
+        try:
+            b, s = ctx.upload(hb), ctx.upload(hs)
+            if tid & 1:
+                ctx.bases_register(K.KG_G1, b.ptr, 0, n)
+            for r in range(rounds):
+                m = sizes[(r + tid) % len(sizes)]
+                assert (ctx.msm(K.KG_G1, b.ptr, 0, s.ptr, m) == want[m]).all(), ("blocking", tid, m)
+                assert (ctx.msm_host_scalars(K.KG_G1, b.ptr, 0, hs[:m], m) == want[m]).all(), ("host", tid, m)
+                for t in range(4):
+                    ctx.msm_begin(K.KG_G1, b.ptr, 0, s.ptr, sizes[(r + t) % len(sizes)], t)
+                for t in range(4):
+                    assert (ctx.msm_end(K.KG_G1, t) == want[sizes[(r + t) % len(sizes)]]).all(), ("ticket", tid, t)
+                v = ctx.upload(hv)
+                ctx.ntt(v.ptr, 14, False, False)
+                ctx.sync()
+                assert (v.numpy() == want_ntt).all(), ("ntt", tid)
+            if tid & 1:
+                ctx.bases_unregister(b.ptr)
+        except BaseException as e:          # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    ctxs = [K.Context(0) for _ in range(4)]
+    ths = [threading.Thread(target=work, args=(ctxs[i], i, 6)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    # one context, four threads in turn (no thread affinity: the creating thread never calls it again)
+    shared = ctxs[0]
+    for i in range(4):
+        t = threading.Thread(target=work, args=(shared, i, 2))
+        t.start()
+        t.join()
+    assert not errors, errors
+    for c in ctxs:
+        c.close()
+    base.close()
