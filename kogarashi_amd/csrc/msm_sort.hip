@@ -52,7 +52,9 @@ int pick_window(size_t n, int forced) {
   // slices win (11.3 against 11.75 ms).  The accumulation drops from 19.3 to 16.0 ms of launch time, but each group's sort still runs
   // 2-4x slower beside an accumulation than alone (latency-bound kernels at one or two waves per SIMD) and bounds the pipeline -- before
   // the sort kernels were slimmed to two workgroups per CU beside an accumulation the wide window lost (21.3 against 21.1).
-  // KG_WIDE_WINDOW=0 keeps the slices, =23 widens from 2^23.
+  // Round 5, after round 4's later sort work (big tiles, 512-thread first pass): 2^23 10.32 ms in four window groups against 10.7 in index
+  // slices (three groups 10.55, c = 19 10.5; profiles/r05_wide23.txt) -- the wide window is the default from 2^23 pairs.  At 2^22 c = 19 loses
+  // (5.9 against 5.4 ms), at 2^24 c = 19 loses to 20 (19.9 against 18.7).  KG_WIDE_WINDOW=0 keeps the slices, =24 widens from 2^24 only.
   if (wide_from > 0 && lg >= wide_from && n <= ((size_t)1 << 24)) return 20;
   if (lg >= 21 && n <= ((size_t)1 << 24)) return 17;
   if (lg >= 19) return 16;

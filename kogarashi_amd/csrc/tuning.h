@@ -13,7 +13,7 @@
 // X(field, "ENV_NAME", default, "what it does")
 #define KG_TUNING_TABLE(X)                                                                                                                   \
   /* ---- MSM: windows, groups, slices ------------------------------------------------------------------------------------------------ */ \
-  X(wide_window, "KG_WIDE_WINDOW", 24, "log2 of the length from which a blocking MSM takes the 20-bit window (13 windows, unsliced, window groups); 0 = never (index slices with c = 17)") \
+  X(wide_window, "KG_WIDE_WINDOW", 23, "log2 of the length from which a blocking MSM takes the 20-bit window (13 windows, unsliced, window groups); 0 = never (index slices with c = 17)") \
   X(msm_groups, "KG_MSM_GROUPS", -1, "window groups of a blocking MSM: -1 automatic, 0/1 none, k = k equal groups; a list \"a,b,c\" names the groups' window counts from the top window down") \
   X(msm_sliced, "KG_MSM_SLICED", 1, "0 = a blocking MSM of 2^23 pairs or more runs in window groups instead of four index slices") \
   X(msm_t, "KG_MSM_T", -1, "task length of the accumulation (entries per lane): -1 = 2 n / B + 16") \

@@ -244,3 +244,27 @@ def test_groth16_2_18_matches_oracle(ctx, oracle):
     assert all((pr[i] == got[i]).all() for i in range(4))
     for pr in tabled.create_proofs(jobs):
         assert all((pr[i] == got[i]).all() for i in range(4))
+
+
+def test_commit_between_2_23_and_2_24_is_the_sum_of_its_parts(ctx, oracle):
+    """The wide window (c = 20, 13 windows, window groups) serves every length from 2^23 to 2^24: a ragged 12 000 001-pair commitment (blocking and
+    through a ticket) against the sum of two parts that take other paths (2^22 + 7: c = 17 in three groups; the rest: index slices of the
+    c = 17 sort or the wide window again), and 2^23 pairs against the oracle's Pippenger."""
+    import kogarashi_amd as K
+    n = 12_000_001
+    g, a = ctx.empty((n, 8)), ctx.empty((n, 4))
+    ctx.gen_bases(K.KG_G1, SEED + 60, 0, n, g.ptr)
+    ctx.gen_scalars(K.KG_FR, SEED + 61, 0, n, a.ptr)
+    whole, iw = ctx.commit(K.KG_G1, g.ptr, 0, a.ptr, n)
+    ctx.msm_begin(K.KG_G1, g.ptr, 0, a.ptr, n, 0)
+    tick = ctx.msm_end(K.KG_G1, 0)
+    h = (1 << 22) + 7
+    c1, i1 = ctx.commit(K.KG_G1, g.ptr, 0, a.ptr, h)
+    c2, i2 = ctx.commit(K.KG_G1, g.ptr + 64 * h, 0, a.ptr + 32 * h, n - h)
+    xy, inf = ctx.points_sum_affine(K.KG_G1, np.stack([c1, c2]), np.array([i1, i2], dtype=np.uint8))
+    assert not iw and inf == 0 and (xy == whole).all()
+    assert (ctx.msm(K.KG_G1, g.ptr, 0, a.ptr, n) == tick).all()
+    m = 1 << 23
+    got, gi = ctx.commit(K.KG_G1, g.ptr, 0, a.ptr, m)
+    oxy, oinf = oracle.to_affine("g1", oracle.msm("g1", g.numpy()[:m], a.numpy()[:m], None, threads=14))
+    assert not gi and not oinf and (got == oxy).all()

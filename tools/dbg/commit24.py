@@ -15,10 +15,11 @@ if len(sys.argv) > 2:
     from kogarashi_amd import synthetic as syn
     hm = m.numpy(); syn.witness_like(hm, 23); ctx.write(m.ptr, hm)
 ctx.bases_register(K.KG_G1, g.ptr, 0, n)
+if os.environ.get('KG_FORCE_C'): ctx.set_msm_window(int(os.environ['KG_FORCE_C']))
 for _ in range(4): r = ctx.commit(K.KG_G1, g.ptr, 0, m.ptr, n)
 ts = []
 for _ in range(3):
     t0 = time.perf_counter()
     for _ in range(5): r = ctx.commit(K.KG_G1, g.ptr, 0, m.ptr, n)
     ts.append((time.perf_counter() - t0) / 5 * 1e3)
-print(f"2^{lg} commit KG_MSM_GROUPS={os.environ.get('KG_MSM_GROUPS', 'auto')}: " + " ".join(f"{t:.2f}" for t in ts) + f" ms  x0={int(r[0][0]):016x}", flush=True)
+print(f"2^{lg} commit KG_MSM_GROUPS={os.environ.get('KG_MSM_GROUPS', 'auto')} KG_WIDE_WINDOW={os.environ.get('KG_WIDE_WINDOW', '-')} c={os.environ.get('KG_FORCE_C', 'auto')}: " + " ".join(f"{t:.2f}" for t in ts) + f" ms  x0={int(r[0][0]):016x}", flush=True)
