@@ -161,7 +161,7 @@ int kg_msm_host_scalars(kg_ctx* ctx, int curve, const uint64_t* d_bases, const u
 /* How a host-array MSM of n pairs is cut into index slices (no device needed; reporting and tests): lo[0 .. K] are the slice boundaries
  * (lo[0] = 0, lo[K] = n, 9 entries at most), K is returned (0 for n = 0).  scalars_only = 1: kg_msm_host_scalars / kg_commit_host_scalars
  * (K = 1 below 2^19 pairs, 2 up to 2^20, 3 / 4 / 6 / 8 at 2^21 / 22 / 23 / 24; the first slice is half a share: its upload is the one
- * nothing hides), 0: kg_msm_host (1 / 2 / 4 equal slices).  KG_HOST_SLICES / KG_HOST_FIRST_DIV apply. */
+ * nothing hides), 0: kg_msm_host (1 / 2 / 4 equal slices: below 2^18, below 2^20, from there).  KG_HOST_SLICES / KG_HOST_FIRST_DIV apply. */
 int kg_msm_host_slices(size_t n, int scalars_only, size_t* lo);
 /* nova/src/pedersen.rs:15-20 PedersenCommitment::commit: affine(sum_i m[i] * g[i]).
  * out_xy: HOST, 8 or 16 uint64; *out_inf = 1 for the identity (then out_xy = (0, 1)). */

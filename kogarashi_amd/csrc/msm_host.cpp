@@ -433,11 +433,12 @@ static int grow_device(kg_ctx* ctx, int which, size_t bytes) {
 }
 
 // Slice boundaries lo[0 .. K] of an n-pair host-array MSM; returns K.  scalars_only: the bases are resident.
-//   both arrays : 4 equal slices from 2^19 pairs, 2 from 2^16 (the bus is the floor; round 2's measured optimum)
+//   both arrays : 4 equal slices from 2^20 pairs, 2 from 2^18 (the bus is the floor).  Measured, K = 1 / 2 / 4 (round 5, ms): 2^16 0.67 / 0.84 / 1.16,
+//                 2^17 0.93 / 1.01 / 1.24, 2^18 1.28 / 1.22 / 1.54, 2^19 1.99 / 1.78 / 1.86, 2^20 3.62 / 2.95 / 2.80
 //   scalars only: the first slice is 1 / first_div of an equal share (its upload is the one nothing hides), the others equal;
 //                 K grows with n so that a slice stays a well-filled MSM (>= 2^17 pairs) and the exposed upload stays short
 static int msm_host_plan(const kg_tuning& tune, size_t n, bool scalars_only, size_t* lo) {
-  int K = n >= ((size_t)1 << 19) ? 4 : (n >= ((size_t)1 << 16) ? 2 : 1);
+  int K = n >= ((size_t)1 << 20) ? 4 : (n >= ((size_t)1 << 18) ? 2 : 1);
   int first_div = 1;
   if (scalars_only) {
     // measured (MI355X, registered G1 bases, pageable scalars, ms over the resident blocking kg_msm; tools/dbg/host_scalars.py):

@@ -96,4 +96,4 @@ def test_host_slice_plan_covers_the_range_at_every_length():
                     rest = [b - a for a, b in zip(lo[1:], lo[2:])]
                     assert lo[1] <= min(rest) and 2 * lo[1] + 1024 >= min(rest), (n, lo)      # half a share, rounded down to 256 pairs
             else:
-                assert k == (4 if n >= (1 << 19) else 2 if n >= (1 << 16) else 1), (n, k)
+                assert k == (4 if n >= (1 << 20) else 2 if n >= (1 << 18) else 1), (n, k)
