@@ -529,19 +529,18 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
     KG_HIP(ctx, hipStreamWaitEvent(sq, ctx->ev_up_s[0], 0));
     return msm_blocking(ctx, curve, bases, inf, d_s, n, out_xyz);
   }
-  std::thread uploader;
-  if (K > 1 || !bases_on_device) uploader = std::thread([&] {
+  // (everything that can fail and return comes before the uploader thread exists)
+  if (K > 1 && !ctx->acc_stream[1]) { if (create_stream(ctx, &ctx->acc_stream[1], false) != hipSuccess) return set_err(ctx, KG_ERR_HIP, "queue creation"); }
+  std::thread uploader([&] {
     hipSetDevice(ctx->device);
     upload_bases(0);
     for (int j = 1; j < K; ++j) { upload_scalars(j); upload_bases(j); }
   });
-  else upload_bases(0);
   std::future<int> fin[kg_ctx::UP_SLICES];
   uint64_t part[kg_ctx::UP_SLICES][24];
   int rc = KG_OK;
   const int sfield = curve == KG_GRUMPKIN ? KG_FQ : KG_FR;
   const bool was_alone = ctx->sort_alone;
-  if (K > 1 && !ctx->acc_stream[1]) { if (create_stream(ctx, &ctx->acc_stream[1], false) != hipSuccess) return set_err(ctx, KG_ERR_HIP, "queue creation"); }
   for (int j = 0; j < K && rc == KG_OK; ++j) {
     const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
     while (up_s.load() <= j) std::this_thread::yield();
