@@ -10,6 +10,8 @@
 #include <map>
 #include <unordered_map>
 #include <vector>
+#include <thread>
+#include <new>
 #include "../../include/kogarashi_amd.h"
 #include "curve.h"
 #include "tuning.h"
@@ -121,6 +123,19 @@ inline int set_err(kg_ctx* c, int code, const char* what, hipError_t e = hipSucc
   if (e != hipSuccess) (void)hipGetLastError();     // the runtime's sticky copy: a later launch check must not report this failure again
   return code;
 }
+// Host-side C++ failures -- std::bad_alloc, a worker thread that cannot be started (std::system_error) -- never cross the C ABI as exceptions
+// (the callers are Rust with panic = "abort", C and ctypes): entry points that allocate host containers or start threads run their body
+// through kg_guarded and report a status.  JoinGuard: a std::thread that is joined when its scope unwinds.
+template <class Fn>
+inline int kg_guarded(kg_ctx* c, Fn&& fn) noexcept {
+  try { return fn(); }
+  catch (const std::bad_alloc&) { return set_err(c, KG_ERR_OOM, "host allocation failed"); }
+  catch (...) { return set_err(c, KG_ERR_HIP, "host runtime failure (a worker thread could not be started?)"); }
+}
+struct JoinGuard {
+  std::thread& t;
+  ~JoinGuard() { if (t.joinable()) t.join(); }
+};
 #define KG_HIP(ctx, call)                                                        \
   do {                                                                           \
     hipError_t e__ = (call);                                                     \

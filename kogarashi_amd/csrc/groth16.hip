@@ -612,11 +612,13 @@ extern "C" {
 int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
                            const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
                            const uint64_t* s, uint64_t* proof_out, uint8_t* proof_inf) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
   ProofJob* job = job_of(ctx, 0);
   if (job->active) return KG_ERR_BAD_ARG;                // a proof begun with ticket 0 has not been collected
   KG_TRY(prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job, 5, nullptr, ROLE_ALL, false, g16_h_early(), true));
   return prove_collect(ctx, job, proof_out, proof_inf);
+  });
 }
 
 // Two proofs in flight (tickets 0 and 1): begin(i + 1) may be called before end(i), so that the next proof's transforms
@@ -625,29 +627,37 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
 int kg_groth16_prove_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
                            const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
                            const uint64_t* s, int ticket) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || ticket < 0 || ticket > 1 || job_of(ctx, ticket)->active) return KG_ERR_BAD_ARG;
   return prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job_of(ctx, ticket), 5 + 5 * ticket, nullptr, ROLE_ALL, false, g16_h_early_pipelined());
+  });
 }
 // The same with cs.evaluate() on the device: the constraint matrices (resident CSR) instead of the evaluation vectors
 int kg_groth16_prove_r1cs_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const kg_csr* a, const kg_csr* b, const kg_csr* c,
                                 const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r, const uint64_t* s, uint64_t* proof_out,
                                 uint8_t* proof_inf) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
   ProofJob* job = job_of(ctx, 0);
   if (job->active) return KG_ERR_BAD_ARG;
   const kg_csr* mats[3] = {a, b, c};
   KG_TRY(prove_enqueue(ctx, crs, nullptr, nullptr, nullptr, d_x, d_w, r, s, job, 5, mats, ROLE_ALL, false, g16_h_early(), true));
   return prove_collect(ctx, job, proof_out, proof_inf);
+  });
 }
 int kg_groth16_prove_r1cs_begin(kg_ctx* ctx, const kg_groth16_crs* crs, const kg_csr* a, const kg_csr* b, const kg_csr* c,
                                 const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r, const uint64_t* s, int ticket) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || ticket < 0 || ticket > 1 || job_of(ctx, ticket)->active) return KG_ERR_BAD_ARG;
   const kg_csr* mats[3] = {a, b, c};
   return prove_enqueue(ctx, crs, nullptr, nullptr, nullptr, d_x, d_w, r, s, job_of(ctx, ticket), 5 + 5 * ticket, mats, ROLE_ALL, false, g16_h_early_pipelined());
+  });
 }
 int kg_groth16_prove_end(kg_ctx* ctx, int ticket, uint64_t* proof_out, uint8_t* proof_inf) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || ticket < 0 || ticket > 1 || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
   return prove_collect(ctx, job_of(ctx, ticket), proof_out, proof_inf);
+  });
 }
 
 
@@ -659,6 +669,7 @@ int kg_groth16_prove_end(kg_ctx* ctx, int ticket, uint64_t* proof_out, uint8_t* 
 int kg_groth16_prove_sharded(kg_ctx* const* ctxs, int n_ctx, const kg_groth16_crs* const* crs, const uint64_t* const* d_a_eval,
                              const uint64_t* const* d_b_eval, const uint64_t* const* d_c_eval, const uint64_t* const* d_x,
                              const uint64_t* const* d_w, const uint64_t* r, const uint64_t* s, uint64_t* proof_out, uint8_t* proof_inf) {
+  return kg::kg_guarded((ctxs && n_ctx > 0 ? ctxs[0] : nullptr), [&]() -> int {
   if (!ctxs || n_ctx < 1 || n_ctx > 8 || !crs || !d_x || !d_w || !r || !s || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;   // d_x, d_w: the arrays; entries of contexts that do not read z may be NULL
   for (int i = 0; i < n_ctx; ++i)
     if (!ctxs[i] || !crs[i]) return KG_ERR_BAD_ARG;
@@ -716,6 +727,7 @@ int kg_groth16_prove_sharded(kg_ctx* const* ctxs, int n_ctx, const kg_groth16_cr
   for (int i = 0; i < 32; ++i) proof_out[i] = proof[i];
   for (int i = 0; i < 3; ++i) proof_inf[i] = inf[i];
   return KG_OK;
+  });
 }
 
 }  // extern "C"

@@ -283,9 +283,11 @@ static int msm_grouped(kg_ctx* ctx, int curve, const uint64_t* d_bases, const ui
 static int msm_blocking(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz);
 
 int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || !out_xyz || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
   return msm_blocking(ctx, curve, d_bases, d_inf, d_scalars, n, out_xyz);
+  });
 }
 
 // one blocking MSM over device arrays (kg_msm; the unsliced kg_msm_host_scalars behind its upload)
@@ -384,6 +386,7 @@ int kg_bases_precompute(kg_ctx* ctx, const uint64_t* d_bases, size_t msm_len) {
 }
 
 int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, int ticket) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2 || ticket < 0 || ticket > 3) return KG_ERR_BAD_ARG;
   ctx->ticket_n[ticket] = n;
   if (n == 0) return KG_OK;
@@ -400,9 +403,11 @@ int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t*
   uint64_t* out = ctx->ticket_out[ticket];
   ctx->ticket_fut[ticket] = std::async(std::launch::async, [ctx, curve, ticket, out] { return kg::msm_finish(ctx, curve, 1 + ticket, out); });
   return KG_OK;
+  });
 }
 
 int kg_msm_end(kg_ctx* ctx, int curve, int ticket, uint64_t* out_xyz) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || !out_xyz || curve < 0 || curve > KG_G2 || ticket < 0 || ticket > 3) return KG_ERR_BAD_ARG;
   if (ctx->ticket_n[ticket] == 0) { kg::msm_identity(curve, out_xyz); return KG_OK; }
   if (!ctx->ticket_fut[ticket].valid()) return kg::set_err(ctx, KG_ERR_BAD_ARG, "kg_msm_end without a matching kg_msm_begin");
@@ -410,6 +415,7 @@ int kg_msm_end(kg_ctx* ctx, int curve, int ticket, uint64_t* out_xyz) {
   if (rc != KG_OK) return rc;
   std::memcpy(out_xyz, ctx->ticket_out[ticket], (curve == KG_G2 ? 24 : 12) * 8);
   return KG_OK;
+  });
 }
 
 // Host arrays in, one point out: the call shape of the reference's slices (msm_curve_addition(&[C], &[C::Scalar])).
@@ -536,6 +542,7 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
     upload_bases(0);
     for (int j = 1; j < K; ++j) { upload_scalars(j); upload_bases(j); }
   });
+  kg::JoinGuard uploader_joined{uploader};                 // also when a worker thread below cannot be started (std::async throws)
   std::future<int> fin[kg_ctx::UP_SLICES];
   uint64_t part[kg_ctx::UP_SLICES][24];
   int rc = KG_OK;
@@ -587,15 +594,19 @@ int kg_msm_host_slices(size_t n, int scalars_only, size_t* lo) {
 }
 
 int kg_msm_host(kg_ctx* ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, const uint64_t* h_scalars, size_t n, uint64_t* out_xyz) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || !out_xyz || (n && (!h_bases || !h_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) return kg_msm(ctx, curve, nullptr, nullptr, nullptr, 0, out_xyz);
   return msm_host_impl(ctx, curve, h_bases, h_inf, false, h_scalars, n, out_xyz);
+  });
 }
 
 int kg_msm_host_scalars(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* h_scalars, size_t n, uint64_t* out_xyz) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || !out_xyz || (n && (!d_bases || !h_scalars)) || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) return kg_msm(ctx, curve, nullptr, nullptr, nullptr, 0, out_xyz);
   return msm_host_impl(ctx, curve, d_bases, d_inf, true, h_scalars, n, out_xyz);
+  });
 }
 
 static void xyz_to_commit(int curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* out_inf) {
@@ -608,11 +619,13 @@ static void xyz_to_commit(int curve, const uint64_t* xyz, uint64_t* out_xy, uint
 
 int kg_commit_host_scalars(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* h_scalars, size_t n,
                            uint64_t* out_xy, uint8_t* out_inf) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || !out_xy || !out_inf || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   uint64_t xyz[24];
   KG_TRY(kg_msm_host_scalars(ctx, curve, d_bases, d_inf, h_scalars, n, xyz));
   xyz_to_commit(curve, xyz, out_xy, out_inf);
   return KG_OK;
+  });
 }
 
 int kg_commit(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,

@@ -32,8 +32,13 @@ int for_each_ctx(int n_ctx, Fn fn) {
   std::vector<int> rc((size_t)n_ctx, KG_OK);
   std::vector<std::thread> th;
   th.reserve((size_t)n_ctx);
-  for (int i = 1; i < n_ctx; ++i) th.emplace_back([&rc, &fn, i] { rc[(size_t)i] = fn(i); });
+  int started = 1;
+  try {
+    for (int i = 1; i < n_ctx; ++i, ++started) th.emplace_back([&rc, &fn, i] { rc[(size_t)i] = fn(i); });
+  } catch (...) {                                        // a thread could not be started: its context and the later ones run here, in turn
+  }
   rc[0] = fn(0);
+  for (int i = started; i < n_ctx; ++i) rc[(size_t)i] = fn(i);
   for (auto& t : th) t.join();
   for (int i = 0; i < n_ctx; ++i)
     if (rc[(size_t)i] != KG_OK) return rc[(size_t)i];
@@ -76,6 +81,7 @@ int kg_shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi) {
 
 int kg_commit_sharded(kg_ctx* const* ctxs, int n_ctx, int curve, const uint64_t* const* d_bases, const uint8_t* const* d_inf,
                       const uint64_t* const* d_scalars, const size_t* n_local, uint64_t* out_xy, uint8_t* out_inf) {
+  return kg::kg_guarded((ctxs && n_ctx > 0 ? ctxs[0] : nullptr), [&]() -> int {
   if (!ctxs || n_ctx < 1 || n_ctx > 64 || curve < 0 || curve > KG_G2 || !d_bases || !d_scalars || !n_local || !out_xy || !out_inf) return KG_ERR_BAD_ARG;
   for (int i = 0; i < n_ctx; ++i)
     if (!ctxs[i] || (n_local[i] && (!d_bases[i] || !d_scalars[i]))) return KG_ERR_BAD_ARG;
@@ -86,10 +92,12 @@ int kg_commit_sharded(kg_ctx* const* ctxs, int n_ctx, int curve, const uint64_t*
   });
   if (rc != KG_OK) return rc;
   return combine(ctxs[0], curve, xyz, n_ctx, out_xy, out_inf);
+  });
 }
 
 int kg_msm_sharded(kg_ctx* const* ctxs, int n_ctx, int curve, const uint64_t* const* d_bases, const uint8_t* const* d_inf,
                    const uint64_t* const* d_scalars, const size_t* n_local, uint64_t* out_xyz) {
+  return kg::kg_guarded((ctxs && n_ctx > 0 ? ctxs[0] : nullptr), [&]() -> int {
   if (!out_xyz || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   uint64_t xy[16];
   uint8_t inf = 0;
@@ -101,10 +109,12 @@ int kg_msm_sharded(kg_ctx* const* ctxs, int n_ctx, int curve, const uint64_t* co
   for (int k = 0; k < 2 * E; ++k) out_xyz[k] = xy[k];
   for (int k = 0; k < E; ++k) out_xyz[2 * E + k] = one[E + k];
   return KG_OK;
+  });
 }
 
 int kg_sharded_key_create(kg_ctx* const* ctxs, int n_ctx, int curve, const uint64_t* h_bases, const uint8_t* h_inf, size_t n,
                           kg_sharded_key** out) {
+  return kg::kg_guarded((ctxs && n_ctx > 0 ? ctxs[0] : nullptr), [&]() -> int {
   if (!out) return KG_ERR_BAD_ARG;
   *out = nullptr;
   if (!ctxs || n_ctx < 1 || n_ctx > 64 || curve < 0 || curve > KG_G2 || (n && !h_bases)) return KG_ERR_BAD_ARG;
@@ -134,6 +144,7 @@ int kg_sharded_key_create(kg_ctx* const* ctxs, int n_ctx, int curve, const uint6
   if (rc != KG_OK) { kg_sharded_key_destroy(K); return rc; }
   *out = K;
   return KG_OK;
+  });
 }
 
 void kg_sharded_key_destroy(kg_sharded_key* K) {
@@ -149,6 +160,7 @@ void kg_sharded_key_destroy(kg_sharded_key* K) {
 size_t kg_sharded_key_len(const kg_sharded_key* K) { return K ? K->n : 0; }
 
 int kg_sharded_key_commit(kg_sharded_key* K, const uint64_t* h_scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
+  return kg::kg_guarded((kg_ctx*)nullptr, [&]() -> int {
   if (!K || !out_xy || !out_inf || (n && !h_scalars)) return KG_ERR_BAD_ARG;
   if (n > K->n) n = K->n;                              // zip semantics of commit (pedersen.rs:16-17)
   const int n_ctx = (int)K->ctxs.size();
@@ -166,6 +178,7 @@ int kg_sharded_key_commit(kg_sharded_key* K, const uint64_t* h_scalars, size_t n
   });
   if (rc != KG_OK) return rc;
   return combine(K->ctxs[0], K->curve, xyz, n_ctx, out_xy, out_inf);
+  });
 }
 
 }  // extern "C"

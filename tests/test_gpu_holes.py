@@ -291,3 +291,49 @@ def test_contexts_on_one_device_from_concurrent_threads_and_a_context_handed_bet
     for c in ctxs:
         c.close()
     base.close()
+
+
+_NPROC_SCRIPT = r"""
+import os, sys, resource
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import kogarashi_amd as K
+K.init()
+ctx = K.Context(0)
+n = 1 << 19
+db, ds = ctx.empty((n, 8)), ctx.empty((n, 4))
+ctx.gen_bases(K.KG_G1, 1, 0, n, db.ptr); ctx.gen_scalars(K.KG_FR, 2, 0, n, ds.ptr); ctx.sync()
+hs = ds.numpy()
+want = ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n)
+assert (ctx.msm_host_scalars(K.KG_G1, db.ptr, 0, hs, n) == want).all()
+soft, hard = resource.getrlimit(resource.RLIMIT_NPROC)
+resource.setrlimit(resource.RLIMIT_NPROC, (1, hard))          # from here on no thread of this user can be started
+out = []
+for f in (lambda: ctx.msm_host_scalars(K.KG_G1, db.ptr, 0, hs, n), lambda: ctx.msm_begin(K.KG_G1, db.ptr, 0, ds.ptr, n, 0)):
+    try:
+        f(); out.append("ok")
+    except K.KogarashiError as e:
+        out.append("status")
+resource.setrlimit(resource.RLIMIT_NPROC, (soft, hard))
+print("OUTCOMES", out, flush=True)
+ctx.sync()
+assert (ctx.msm_host_scalars(K.KG_G1, db.ptr, 0, hs, n) == want).all()
+ctx.msm_begin(K.KG_G1, db.ptr, 0, ds.ptr, n, 0)
+assert (ctx.msm_end(K.KG_G1, 0) == want).all()
+print("USABLE", flush=True)
+"""
+
+
+def test_a_worker_thread_that_cannot_be_started_is_a_status_not_an_abort():
+    """never aborts.  The host side starts threads (the uploader of a host-scalar call, the host finishes of tickets): with
+    RLIMIT_NPROC at 1 std::thread / std::async throw std::system_error -- which must come back through the C ABI as a status (kg_guarded), with
+    the context usable once threads can be started again.  Run in a subprocess (the limit is per process); root is exempt from the limit."""
+    import os
+    import subprocess
+    import sys
+    if os.geteuid() == 0:
+        pytest.skip("RLIMIT_NPROC does not bind root")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _NPROC_SCRIPT], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "OUTCOMES ['status', 'status']" in r.stdout and "USABLE" in r.stdout, r.stdout[-1500:]
