@@ -317,6 +317,7 @@ const char* kg_strerror(int s) {
 }
 
 int kg_ctx_create(int device, kg_ctx** out) {
+  return kg::kg_guarded((kg_ctx*)nullptr, [&]() -> int {
   if (!out) return KG_ERR_BAD_ARG;
   *out = nullptr;
   int n = 0;
@@ -330,6 +331,7 @@ int kg_ctx_create(int device, kg_ctx** out) {
   c->stream = c->own_stream;
   *out = c;
   return KG_OK;
+  });
 }
 
 void kg_ctx_destroy(kg_ctx* c) {
@@ -415,6 +417,7 @@ int kg_ctx_set_inputs_complete(kg_ctx* c, int on) {
   return KG_OK;
 }
 int kg_malloc(kg_ctx* c, size_t bytes, void** p) {
+  return kg::kg_guarded(c, [&]() -> int {
   if (!c || !p) return KG_ERR_BAD_ARG;
   KG_HIP(c, hipSetDevice(c->device));
   const size_t cls = pool_class(bytes ? bytes : 1);
@@ -430,6 +433,7 @@ int kg_malloc(kg_ctx* c, size_t bytes, void** p) {
   }
   c->pool_live[*p] = cls;
   return KG_OK;
+  });
 }
 int kg_mem_info(kg_ctx* c, size_t* free_bytes, size_t* total_bytes) {
   if (!c) return KG_ERR_BAD_ARG;
@@ -441,6 +445,7 @@ int kg_mem_info(kg_ctx* c, size_t* free_bytes, size_t* total_bytes) {
   return KG_OK;
 }
 int kg_free(kg_ctx* c, void* p) {
+  return kg::kg_guarded(c, [&]() -> int {
   if (!c) return KG_ERR_BAD_ARG;
   if (!p) return KG_OK;
   KG_HIP(c, hipSetDevice(c->device));
@@ -459,6 +464,7 @@ int kg_free(kg_ctx* c, void* p) {
   }
   KG_HIP(c, hipFree(p));
   return KG_OK;
+  });
 }
 int kg_memcpy_h2d(kg_ctx* c, void* d, const void* h, size_t bytes) {
   if (!c || (bytes && (!d || !h))) return KG_ERR_BAD_ARG;
@@ -491,17 +497,20 @@ int kg_msm_set_groups(kg_ctx* c, int groups) {
   return KG_OK;
 }
 int kg_profile_enable(kg_ctx* c, int on) {
+  return kg::kg_guarded(c, [&]() -> int {
   if (!c) return KG_ERR_BAD_ARG;
   hipSetDevice(c->device);
   sync_all(c);                   // events still pending on any queue must not be re-recorded by the reset below
   c->prof = on != 0;
   prof_reset(c);                 // phases accumulate from here until the next enable / disable
   return KG_OK;
+  });
 }
 int kg_profile_last(kg_ctx* c, const char** names, float* ms, int cap) {
   return kg_profile_summary(c, names, ms, nullptr, cap);
 }
 int kg_profile_summary(kg_ctx* c, const char** names, float* total_ms, int* counts, int cap) {
+  return kg::kg_guarded(c, [&]() -> int {
   if (!c) return KG_ERR_BAD_ARG;
   hipSetDevice(c->device);
   sync_all(c);
@@ -532,6 +541,7 @@ int kg_profile_summary(kg_ctx* c, const char** names, float* total_ms, int* coun
     if (counts) counts[n] = cnt[k];
   }
   return n;
+  });
 }
 
 }  // extern "C"

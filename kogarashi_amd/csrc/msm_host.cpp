@@ -318,6 +318,7 @@ int kg_msm_pick_window(size_t n) { return pick_window(n ? n : 1, 0); }
 int kg_msm_table_window(size_t msm_len) { return kg::merged_window(nullptr, msm_len); }
 
 int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t n) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) return KG_OK;                         // nothing to convert (e.g. an empty CRS vector)
   if (!d_bases) return KG_ERR_BAD_ARG;
@@ -336,9 +337,11 @@ int kg_bases_register(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uin
   reg.fmt64 = fmt64;
   ctx->registered.push_back(reg);
   return KG_OK;
+  });
 }
 
 int kg_bases_unregister(kg_ctx* ctx, const uint64_t* d_bases) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx) return KG_ERR_BAD_ARG;
   for (size_t i = 0; i < ctx->registered.size(); ++i) {
     if (ctx->registered[i].base == d_bases) {
@@ -350,9 +353,11 @@ int kg_bases_unregister(kg_ctx* ctx, const uint64_t* d_bases) {
     }
   }
   return KG_OK;
+  });
 }
 
 int kg_bases_precompute(kg_ctx* ctx, const uint64_t* d_bases, size_t msm_len) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || !d_bases) return KG_ERR_BAD_ARG;
   KG_HIP(ctx, hipSetDevice(ctx->device));
   kg_ctx::Registered* r = nullptr;
@@ -383,6 +388,7 @@ int kg_bases_precompute(kg_ctx* ctx, const uint64_t* d_bases, size_t msm_len) {
   if (e != hipSuccess) { hipFree(table); return set_err(ctx, KG_ERR_HIP, "window table build", e); }
   r->table = table; r->table_c = c; r->table_W = W; r->table64 = t64;
   return KG_OK;
+  });
 }
 
 int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, int ticket) {

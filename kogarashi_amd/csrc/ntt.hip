@@ -274,6 +274,7 @@ int ntt_enqueue(kg_ctx* ctx, hipStream_t st, uint64_t* tmp, uint64_t* d_data, ui
 extern "C" {
 
 int kg_ntt_bn254_fr(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n, int inverse, int coset) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || !d_data || log_n < 1 || log_n > 28) return KG_ERR_BAD_ARG;
   KG_HIP(ctx, hipSetDevice(ctx->device));
   uint64_t* tmp = nullptr;
@@ -282,6 +283,7 @@ int kg_ntt_bn254_fr(kg_ctx* ctx, uint64_t* d_data, uint32_t log_n, int inverse, 
     tmp = (uint64_t*)ctx->ws2;
   }
   return kg::ntt_enqueue(ctx, ctx->stream, tmp, d_data, log_n, inverse, coset);
+  });
 }
 
 int kg_ntt_plan(uint32_t log_n, uint32_t* log_m, uint32_t* log_tile) {

@@ -114,6 +114,7 @@ extern "C" {
 int kg_groth16_setup_bn254(kg_ctx* ctx, const kg_csr* a, const kg_csr* b, const kg_csr* c, size_t m, size_t l, size_t m_l_1,
                            const uint64_t* h_toxic, kg_groth16_crs* crs, uint64_t* d_ic, uint8_t* d_ic_inf, uint64_t* out_gamma_g2,
                            uint8_t* out_vk_inf) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || !a || !b || !c || !h_toxic || !crs || !out_gamma_g2 || !out_vk_inf) return KG_ERR_BAD_ARG;
   const size_t nv = l + m_l_1;
   if (m < 1 || m >= ((size_t)1 << 28)) return set_err(ctx, KG_ERR_BAD_ARG, "kg_groth16_setup_bn254: 1 <= m < 2^28 constraints (Fr has two-adicity 28)");
@@ -234,6 +235,7 @@ int kg_groth16_setup_bn254(kg_ctx* ctx, const kg_csr* a, const kg_csr* b, const 
   crs->delta_g1_inf = vinf[2]; crs->delta_g2_inf = vinf[5];
   out_vk_inf[0] = vinf[0]; out_vk_inf[1] = vinf[1]; out_vk_inf[2] = vinf[2]; out_vk_inf[3] = vinf[3]; out_vk_inf[4] = vinf[4]; out_vk_inf[5] = vinf[5];
   return KG_OK;
+  });
 }
 
 }  // extern "C"
