@@ -18,7 +18,8 @@
  *
  * Pointers named d_* are DEVICE pointers (from kg_malloc, or any HIP allocation of the same device, e.g. a
  * torch tensor's data_ptr()); pointers named h_* / out_* are host pointers.
- * All functions return KG_OK (0) or a negative kg_status; none aborts.  Calls on one kg_ctx are
+ * All functions return KG_OK (0) or a negative kg_status; none aborts, and no C++ exception leaves the library (a host allocation
+ * that fails is KG_ERR_OOM, a worker thread that cannot be started KG_ERR_HIP; the context stays usable).  Calls on one kg_ctx are
  * serialised by the caller; distinct contexts may be used from distinct threads.
  */
 #ifndef KOGARASHI_AMD_H
