@@ -17,7 +17,7 @@ for it in range(rounds):
     curve = int(rng.choice([0, 0, 0, 1, 2]))
     lo_lg, hi_lg = [int(v) for v in os.environ.get("KG_STRESS_LG", "12,19").split(",")]       # sizes 2^lo .. 2^hi - 1 (G2: two fewer)
     lg = int(rng.integers(lo_lg, hi_lg if curve != 2 else max(lo_lg + 1, hi_lg - 2)))
-    n = (1 << lg) + int(rng.integers(-50, 50))
+    n = max(1, (1 << lg) + int(rng.integers(-50, 50)))
     fld = 1 if curve == 1 else 0
     bases = O.gen_bases(curve, 1000 + it, 0, n) if curve != 2 else None
     if curve == 2:
@@ -28,12 +28,12 @@ for it in range(rounds):
     scal = O.gen_scalars(fld, 2000 + it, 0, n)
     pat = int(rng.integers(0, 7))
     if pat == 0: scal[:] = scal[0]                                   # all equal
-    elif pat == 1: scal[rng.random(n) < 0.9] = scal[1]               # one dominant value among uniform ones
+    elif pat == 1: scal[rng.random(n) < 0.9] = scal[min(1, n - 1)]               # one dominant value among uniform ones
     elif pat == 2:                                                   # few distinct values
-        vals = scal[:5].copy(); scal[:] = vals[rng.integers(0, 5, n)]
+        vals = scal[:5].copy(); scal[:] = vals[rng.integers(0, len(vals), n)]
     elif pat == 3 and fld == 0: syn.witness_like(scal, it)
     elif pat == 4: scal[rng.random(n) < 0.5] = 0                     # half zeros
-    elif pat == 5: scal[rng.random(n) < 0.97] = scal[2]              # 97 % one value
+    elif pat == 5: scal[rng.random(n) < 0.97] = scal[min(2, n - 1)]              # 97 % one value
     # pat 6: uniform
     cv = names[curve]
     if curve == 2:
