@@ -741,7 +741,8 @@ def test_service_queues_are_placed_off_the_main_queues_pipe(ctx):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = "import sys; sys.path.insert(0, %r)\nimport kogarashi_amd as K\nc = K.Context(0); print('placement', c.queue_placement()); c.close()" % root
     for env in ({}, {"KG_STREAM_PAD": "1,2"}):
-        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        # (the probe's own switch is set explicitly: the suite also runs under non-default knob sets, tools/dbg/r5_knob_suites.sh)
+        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, KG_QUEUE_PLACEMENT="1", **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-1500:]
         p = int(r.stdout.split("placement")[1].split()[0])
         assert 2 <= p <= 5, (env, p)
