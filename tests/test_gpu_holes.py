@@ -337,3 +337,39 @@ def test_a_worker_thread_that_cannot_be_started_is_a_status_not_an_abort():
     r = subprocess.run([sys.executable, "-c", _NPROC_SCRIPT], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "OUTCOMES ['status', 'status']" in r.stdout and "USABLE" in r.stdout, r.stdout[-1500:]
+
+
+def test_profiling_entries_report_the_phases_of_the_calls_between_enable_and_summary(ctx):
+    """kg_profile_enable / kg_profile_summary / kg_profile_last / kg_device_count: the library's own HIP-event phase timers (what bench.py's
+    roofline.achieved is computed from).  Between enable and summary one blocking MSM and one transform: their phases appear once each
+    per launch with positive durations that add up to less than the calls' wall time; after disable nothing accumulates."""
+    import ctypes as C
+    import time
+    import kogarashi_amd as K
+    from kogarashi_amd import lib as L
+    assert L.load().kg_device_count() >= 1
+    n = 1 << 18
+    db, ds, dv = ctx.empty((n, 8)), ctx.empty((n, 4)), ctx.empty((1 << 16, 4))
+    ctx.gen_bases(K.KG_G1, SEED + 80, 0, n, db.ptr)
+    ctx.gen_scalars(K.KG_FR, SEED + 81, 0, n, ds.ptr)
+    ctx.gen_scalars(K.KG_FR, SEED + 82, 0, 1 << 16, dv.ptr)
+    ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n)
+    ctx.ntt(dv.ptr, 16, False, False)
+    ctx.sync()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    want = ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n)
+    ctx.ntt(dv.ptr, 16, False, False)
+    ctx.sync()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    s = ctx.profile_summary()
+    for phase in ("prep_scalars", "sort", "accumulate", "reduce", "ntt"):
+        assert phase in s and s[phase][0] > 0 and s[phase][1] >= 1, (phase, s)
+    assert s["ntt"][1] == 1 and s["accumulate"][1] == s["sort"][1] >= 1          # one sort and one accumulation per window group
+    assert max(v[0] for v in s.values()) < wall_ms * 1.5, (s, wall_ms)
+    assert ctx.profile_last() == {k: v[0] for k, v in s.items()}
+    names, ms = (C.c_char_p * 32)(), (C.c_float * 32)()
+    assert L.load().kg_profile_last(ctx._h, names, ms, 32) == len(s)
+    ctx.profile_enable(False)
+    assert (ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n) == want).all()
+    assert ctx.profile_summary() == {} or all(v[1] == 0 for v in ctx.profile_summary().values())
