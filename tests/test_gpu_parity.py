@@ -742,9 +742,13 @@ def test_service_queues_are_placed_off_the_main_queues_pipe(ctx):
     script = "import sys; sys.path.insert(0, %r)\nimport kogarashi_amd as K\nc = K.Context(0); print('placement', c.queue_placement()); c.close()" % root
     for env in ({}, {"KG_STREAM_PAD": "1,2"}):
         # (the probe's own switch is set explicitly: the suite also runs under non-default knob sets, tools/dbg/r5_knob_suites.sh)
-        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, KG_QUEUE_PLACEMENT="1", **env), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-1500:]
-        p = int(r.stdout.split("placement")[1].split()[0])
-        assert 2 <= p <= 5, (env, p)
+        seen = []
+        for attempt in range(3):                    # the probe is a timing measurement on a box whose host cores are shared: it repeats an
+            r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, KG_QUEUE_PLACEMENT="1", **env), capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-1500:]      # inconclusive pass itself (four times), and so does this test (three processes)
+            seen.append(int(r.stdout.split("placement")[1].split()[0]))
+            if 2 <= seen[-1] <= 5:
+                break
+        assert 2 <= seen[-1] <= 5 and all(v == 1 for v in seen[:-1]), (env, seen)
     r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, KG_QUEUE_PLACEMENT="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and int(r.stdout.split("placement")[1].split()[0]) == 0
