@@ -65,7 +65,10 @@ def test_two_rank_commit_over_gloo(oracle):
     n, world = 600, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:                     # a free rendezvous port on the loop-back interface (as bench.py's launcher picks one)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
