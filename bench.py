@@ -7,13 +7,21 @@ N > 1: one rank per GPU.  Under torch.distributed.run (WORLD_SIZE set) this proc
 the N ranks itself as child processes BEFORE anything touches the GPU (launch_ranks) and exits with their status.  Either
 way the process group's world size must equal --gpus.
 
-A step is one full MSM (kg_msm: scalars + bases resident in HBM -> one projective point on the host).  With N > 1
-the index range of an N * 2^20 commitment is sharded: every rank runs the same pipeline on its own 2^20 slice and
-the per-rank affine partial sums (17 words) are all-gathered over RCCL and added (weak scaling).
-Every N also reports `nova_commit` (BASELINE.json configs[4]: ONE 2^24-pair Pedersen commitment cut over the N ranks by
-kg_shard_range, G1 / Fr and Grumpkin / Fq), `ntt` (2^22 forward transforms, one replica per rank: the transform does not
-shard) and `groth16` (2^18-constraint proofs, one prover per rank).  Rank 0 prints ONE JSON line; see DESIGN.md
-"Measurement" for the roofline / cpu_baseline fields."""
+A step is one full MSM (kg_msm: scalars + bases resident in HBM -> one projective point on the host).  The headline is the
+MEDIAN of --rounds (5) timed rounds of K steps each, every round bracketed by a barrier + device synchronisation, max over
+ranks (`rounds_ms` lists them).  With N > 1 the index range of an N * 2^20 commitment is sharded: every rank runs the same
+pipeline on its own 2^20 slice and the per-rank affine partial sums (9 words) are all-gathered over RCCL and added (weak
+scaling).
+
+Rank 0 prints ONE JSON line.  Its first key is `summary`: every leg's headline figure, flat.  The legs: `roofline` /
+`valu_roofline` / `cpu_baseline` of the headline, `blocking_ms`, `msm_host_scalars`, `msm_strong`, `msm_skewed`, `msm_g2`
+(2^18 G2 pairs, 160 B per pair), `small` (short blocking calls: the reference's own test sizes), `ntt` (2^22 forward, and
+`variants`: idft / coset_dft / coset_idft), `groth16` (2^18 constraints), `nova_commit` (2^24 pairs, both curves).  Prose
+notes are left out unless --notes is given (the driver keeps the last 8 KB of stdout: the line must fit); what every field
+means is in DESIGN.md section 8.
+
+Profiling aids (tools/collect_profiles.sh): --headline-only (pre-warm, warm-up and the timed rounds, nothing else: the
+k_acc_tasks average of a kernel trace of this command is roofline.kernel_ms), --ntt-only, --msm-g2-only, --groth16-only."""
 import argparse
 import json
 import os
@@ -29,12 +37,44 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 SEED = 0x4B6F676172617368
 LOG_N = 20
 G1_BYTES_PER_PAIR = 96          # 32 B scalar + 64 B affine base
+G2_BYTES_PER_PAIR = 160         # 32 B scalar + 128 B affine G2 base
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 MADD_PEAK_G = 17.3              # measured: the bucket kernel's addition routine, operands in registers, 4 waves/SIMD (profiles/r03_mul_rate.txt; 16.5 before round 3's column chains)
 MAD_PEAK_T = 33.0               # measured chip-wide v_mad_u64_u32 issue rate, T instructions/s (profiles/r01_valu_rates.txt)
 MADS_PER_ADDITION = 1467        # add_mixed_signed (curve.h): 6 products x 162 + 2 squares x 126 + one double product x 243 multiply-accumulates (fp29.h)
+MADS_PER_G2_ADDITION = 4536     # add_mixed over Fq2 (curve.h, fp29.h Fp2): 6 products x 486 + 2 squares x 324 + one double product x 972
 WARM_PROOFS = 16                # untimed proofs in front of a timed Groth16 section (clock ramp after an idle period)
 MUL_PEAK_G = 175.0              # measured Montgomery products/s, 4 waves/SIMD (profiles/r03_mul_rate.txt)
+NOTES = False                   # --notes
+
+
+def note(d, text):
+    """an explanatory note on a leg -- only with --notes (the default line must fit the 8 KB of stdout the driver keeps)"""
+    if NOTES:
+        d["note"] = text
+    return d
+
+
+def point_digest(xy, inf):
+    """fingerprint of an affine point (equal points <=> equal digests): 16 hex digits of sha256 over its words"""
+    import hashlib
+    import numpy as np
+    return "identity" if inf else hashlib.sha256(np.ascontiguousarray(xy, dtype=np.uint64).tobytes()).hexdigest()[:16]
+
+
+def r3(x):
+    return None if x is None else round(float(x), 4)
+
+
+def compact(x, digits=5):
+    """floats to `digits` significant digits, recursively (the line must fit the 8 KB of stdout the driver keeps)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k_: compact(v_, digits) for k_, v_ in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [compact(v_, digits) for v_ in x]
+    return x
 
 
 def ntt_cost(K, log_n):
@@ -48,16 +88,28 @@ def ntt_cost(K, log_n):
     direct_a = len(plan) >= 2 and log_n <= min(22, int(os.environ.get("KG_NTT_DIRECT_MAX_LOG", "22")))
     composed = len(plan) >= 2 and not direct_a
     mads = sum((m / 2 - 0.75) * 143 for m, _ in plan) + (len(plan) - 1 + (1 if composed else 0)) * 162
-    kern = " + ".join(f"k_ntt_tile<2^{m} points, {1 << t}-element tiles>" for m, t in plan)
-    note = (f"{kern}: {len(plan)} HBM round trip(s), {64 * len(plan)} B of data moved per element"
-            + (" + 36 B of inter-step twiddle table" if direct_a else ""))
-    return mads, note, plan
+    kern = "k_ntt_tile steps " + " x ".join(f"2^{m}" for m, _ in plan) + f", {1 << plan[0][1]}-element tiles"
+    return mads, kern, plan
 
 
 def single_rank_env(torch, dev):
-    """the rank environment of the legs for one process without a process group (--ntt-only, tools/dbg)"""
+    """the rank environment of the legs for one process without a process group (the --*-only modes, tools/dbg)"""
     return {"world": 1, "rank": 0, "barrier": torch.cuda.synchronize, "host_barrier": torch.cuda.synchronize, "max_over_ranks": lambda x: x, "xdev": dev,
             "kdist": None}
+
+
+def timed_rounds(env, fn, steps, rounds):
+    """`rounds` timed rounds of fn(steps), each bracketed by the rank barrier + device synchronisation, max over ranks per round;
+    returns (median seconds per round, [ms per step of every round], the last result)"""
+    out, res = [], None
+    for _ in range(rounds):
+        env["barrier"]()
+        t0 = time.perf_counter()
+        res = fn(steps)
+        env["barrier"]()
+        out.append(env["max_over_ranks"](time.perf_counter() - t0))
+    med = sorted(out)[len(out) // 2]
+    return med, [round(x / steps * 1e3, 4) for x in out], res
 
 
 def bench_msm_strong(ctx, torch, dev, K, env, log_n, steps):
@@ -92,9 +144,9 @@ def bench_msm_strong(ctx, torch, dev, K, env, log_n, steps):
     env["barrier"]()
     dt = env["max_over_ranks"](time.perf_counter() - t0) / steps
     return {"metric": "bn254_g1_msm_pairs_per_sec (one MSM over all ranks)", "log_n": log_n, "pairs_total": total, "pairs_per_rank": nl, "ranks": world,
-            "scaling": "strong", "ms_per_msm": dt * 1e3, "value": total / dt, "unit": "pairs/s",
-            "exchange": "one all_gather of 9 x 64-bit words per rank (RCCL), partial sums added on every rank" if world > 1 else "none",
-            "point": {"xy_hex": "".join(f"{int(v_):016x}" for v_ in got[0]), "is_identity": bool(got[1])}}
+            "scaling": "strong", "ms_per_msm": r3(dt * 1e3), "value": total / dt, "unit": "pairs/s",
+            "exchange": "all_gather of 9 words per rank (RCCL)" if world > 1 else "none",
+            "point": point_digest(got[0], got[1])}
 
 
 def window_adds(n):
@@ -148,19 +200,30 @@ def launch_ranks(args):
 
 
 def main():
+    global NOTES
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rounds", type=int, default=5, help="timed rounds of --steps steps each; the headline is the median round")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-groth16", action="store_true")
     ap.add_argument("--no-nova", action="store_true")
+    ap.add_argument("--no-g2", action="store_true")
+    ap.add_argument("--no-small", action="store_true")
     ap.add_argument("--no-skew", action="store_true", help="skip the skewed-scalar legs (msm_skewed, groth16.skewed_witness)")
-    ap.add_argument("--ntt-only", action="store_true", help="profiling aid: only the NTT leg (tools/collect_profiles.sh); prints {\"ntt\": ...}")
+    ap.add_argument("--headline-only", action="store_true", help="profiling aid: pre-warm, warm-up and the timed rounds of the headline, nothing else")
+    ap.add_argument("--ntt-only", action="store_true", help="profiling aid: only the NTT leg; prints {\"ntt\": ...}")
+    ap.add_argument("--ntt-variant", default="all", help="with --ntt-only: dft | idft | coset_dft | coset_idft | all")
+    ap.add_argument("--msm-g2-only", action="store_true", help="profiling aid: only the G2 MSM leg; prints {\"msm_g2\": ...}")
+    ap.add_argument("--groth16-only", action="store_true", help="profiling aid: only the prover (no tables, no CPU leg); prints {\"groth16\": ...}")
+    ap.add_argument("--small-only", action="store_true", help="only the short blocking calls; prints {\"small\": ...}")
+    ap.add_argument("--notes", action="store_true", help="keep the prose notes in the line")
     ap.add_argument("--nova-log-n", type=int, default=24, help="pairs of the Nova commitment (whole job, cut over the ranks)")
     ap.add_argument("--groth16-log-m", type=int, default=18)
+    ap.add_argument("--g2-log-n", type=int, default=18)
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--depth", type=int, default=4, help="MSM steps in flight (1..4)")
     ap.add_argument("--prewarm", type=int, default=200, help="untimed steps before the W warm-up steps (first touch, clock ramp)")
@@ -168,6 +231,9 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.rounds < 1:
+        ap.error("--rounds must be >= 1")
+    NOTES = args.notes
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
@@ -213,10 +279,19 @@ def main():
     n = 1 << args.log_n
 
     ctx = K.Context(local_rank)
-    if args.ntt_only:
+    if args.ntt_only or args.msm_g2_only or args.groth16_only or args.small_only:
         torch.cuda.synchronize()
         env = single_rank_env(torch, dev)
-        print(json.dumps({"ntt": bench_ntt(ctx, torch, dev, K, env, steps=max(args.steps, 10))}), flush=True)
+        ctx.set_inputs_complete(True)
+        if args.ntt_only:
+            out = {"ntt": bench_ntt(ctx, torch, dev, K, env, steps=max(args.steps, 10), variants=args.ntt_variant)}
+        elif args.msm_g2_only:
+            out = {"msm_g2": bench_msm_g2(ctx, torch, dev, K, env, args.g2_log_n, steps=max(args.steps, 10), rounds=args.rounds, cpu=not args.no_cpu_baseline)}
+        elif args.small_only:
+            out = {"small": bench_small(ctx, torch, dev, K)}
+        else:
+            out = {"groth16": bench_groth16(ctx, torch, dev, K, env, args.groth16_log_m, steps=max(args.steps, 8), cpu=False, tables=False, from_witness=False)}
+        print(json.dumps(compact(out)), flush=True)
         return
     # The library launches on its own queues (main queue: accumulations; scalar-side queue: digit extraction, sort, base
     # conversion; two reduction queues) and brackets its phases with HIP events recorded on those queues; the timed region
@@ -277,23 +352,50 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    env = {"world": world, "rank": rank, "barrier": barrier, "host_barrier": host_barrier, "max_over_ranks": max_over_ranks, "xdev": xdev, "kdist": kdist}
     run(args.prewarm)                         # untimed: first-touch allocations and the clock ramp of a cold GPU (~0.3 s)
     if args.warmup:
         run(args.warmup)
     ctx.profile_enable(True)
-    barrier()
-    t0 = time.perf_counter()
-    res = run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    summary = ctx.profile_summary()           # HIP events recorded on the launch streams during the timed region
+    # the timed region: --rounds rounds of EXACTLY --steps steps, each bracketed by barrier + synchronisation; the median round is the
+    # headline (a 27 ms window moves 2-4 % between runs on a box whose host cores are shared)
+    elapsed, rounds_ms, res = timed_rounds(env, run, args.steps, args.rounds)
+    summary = ctx.profile_summary()           # HIP events recorded on the launch streams during ALL timed rounds
     ctx.profile_enable(False)
     acc_avg_ms = summary["accumulate"][0] / summary["accumulate"][1]
-    phase_avg = {k_: v_[0] / v_[1] for k_, v_ in summary.items()}
-    elapsed = max_over_ranks(elapsed)
+    phase_avg = {k_: r3(v_[0] / v_[1]) for k_, v_ in summary.items()}
 
     value = world * n * args.steps / elapsed
     achieved = G1_BYTES_PER_PAIR * n / (acc_avg_ms * 1e-3) / 1e9
+    traffic = pmc_traffic(args.log_n)
+    rccl = {"backend": dist.get_backend() if world > 1 else None, "ranks": dist.get_world_size() if world > 1 else 1,
+            "hosts": 1, "selftest": bool(selftest)}
+    line = {
+        "metric": "bn254_g1_msm_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 64-bit accumulate)", "data": "synthetic",
+        "config": {"workload": f"bn254 G1 MSM, 2^{args.log_n} uniform Fr scalars x uniform G1 bases per GPU, resident in HBM",
+                   "pairs_per_gpu": n, "sharding": "index range" if world > 1 else "none"},
+        "rounds": args.rounds, "rounds_ms": rounds_ms,
+        "rccl": rccl,
+        "roofline": note({"bound": "hbm", "kernel": "k_acc_tasks<Fq>",
+                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                          "traffic": traffic["corrected"] if traffic else None, "kernel_ms": acc_avg_ms, "launches": summary["accumulate"][1],
+                          "algorithmic_bytes_per_launch": G1_BYTES_PER_PAIR * n,
+                          "traffic_detail": traffic},
+                         "VALU-bound kernel (16 n point additions, see valu_roofline); in the timed region its launches overlap the next step's sort "
+                         "and the previous steps' reductions (service kernels run at wave priority 3 beside it), so kernel_ms there is longer than "
+                         "isolated.kernel_ms while ms_per_step is shorter than their sum; kernel_ms = HIP events over every launch of all timed rounds"),
+        "phases_ms_per_step": phase_avg, "pipelining": f"{depth} in flight",
+    }
+    if args.headline_only:
+        if rank == 0:
+            print(json.dumps(compact({"summary": {"msm_ms_per_step": r3(line["ms_per_step"]), "msm_pairs_per_s": value, "acc_kernel_ms": r3(acc_avg_ms)}, **line})), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     # The same kernel with nothing beside it (a few blocking MSMs after the timed region): in the timed region the
     # accumulation shares the chip with the next step's sort and the previous steps' reductions, which is what makes the
     # step shorter and the kernel's own launch longer.
@@ -313,44 +415,29 @@ def main():
     groups(0)
     for _ in range(2):        # untimed: the blocking call's own queues, work spaces and result slots (window groups) are set up on first use
         ctx.msm(K.KG_G1, bases.data_ptr(), 0, scalars.data_ptr(), n)
-    t0 = time.perf_counter()
+    blk_rounds = []
     for _ in range(5):
-        ctx.msm(K.KG_G1, bases.data_ptr(), 0, scalars.data_ptr(), n)
-    blocking_ms = (time.perf_counter() - t0) / 5 * 1e3
+        t0 = time.perf_counter()
+        for _ in range(4):
+            ctx.msm(K.KG_G1, bases.data_ptr(), 0, scalars.data_ptr(), n)
+        blk_rounds.append((time.perf_counter() - t0) / 4 * 1e3)
+    blocking_ms = sorted(blk_rounds)[2]
     iso_ms = iso["accumulate"][0] / iso["accumulate"][1]
     iso_achieved = G1_BYTES_PER_PAIR * n / (iso_ms * 1e-3) / 1e9
     adds = window_adds(n)
-    traffic = pmc_traffic(args.log_n)
-    line = {
-        "metric": "bn254_g1_msm_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 64-bit accumulate)", "data": "synthetic",
-        "config": {"workload": f"bn254 G1 MSM, 2^{args.log_n} uniform Fr scalars x uniform G1 bases per GPU, inputs resident in HBM",
-                   "pairs_per_gpu": n, "sharding": "index range" if world > 1 else "none"},
-        "blocking_ms": blocking_ms,            # wall time of one isolated kg_msm call (nothing in flight), host finish included
-        "queues": {"placement": ctx.queue_placement() if hasattr(ctx, "queue_placement") else None,
-                   "note": "2 + j: the service queues were probed and placed on the three compute pipes the main queue does not use; 1: no clear picture, creation order; 0: probe off"},
-        "roofline": {"bound": "hbm", "kernel": "k_acc_tasks (bucket accumulation, one launch per MSM)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic["corrected"] if traffic else None, "kernel_ms": acc_avg_ms, "algorithmic_bytes_per_launch": G1_BYTES_PER_PAIR * n,
-                     "traffic_detail": traffic,
-                     "isolated": {"kernel_ms": iso_ms, "achieved": iso_achieved, "frac": iso_achieved / HBM_PEAK_GBS,
-                                  "note": "same kernel, blocking kg_msm calls, nothing else on the chip"},
-                     "note": "VALU-bound kernel (16 n point additions, see valu_roofline); in the timed region its launches overlap the next step's sort "
-                             "and the previous steps' reductions (service kernels run at wave priority 3 beside it), so kernel_ms there is longer than "
-                             "isolated.kernel_ms while ms_per_step is shorter than their sum"},
-        # the bound that actually limits the kernel, against the MACHINE: multiply-accumulate instructions per second vs the
-        # chip's measured v_mad_u64_u32 issue rate; and against the same addition routine with operands in registers
-        "valu_roofline": {"bound": "valu", "unit": "T v_mad_u64_u32/s", "mads_per_addition": MADS_PER_ADDITION, "additions_per_launch": adds,
-                          "achieved": adds * MADS_PER_ADDITION / (iso_ms * 1e-3) / 1e12, "peak": MAD_PEAK_T,
-                          "frac": adds * MADS_PER_ADDITION / (iso_ms * 1e-3) / 1e12 / MAD_PEAK_T,
-                          "routine_relative": {"unit": "G point additions/s", "achieved": adds / (iso_ms * 1e-3) / 1e9, "peak": MADD_PEAK_G,
-                                               "frac": adds / (iso_ms * 1e-3) / 1e9 / MADD_PEAK_G},
-                          "note": "isolated launches; the remaining ~30 % of issue slots go to the shifts / masks / carries of the 29-bit limbs, "
-                                  "the lazy-reduction bookkeeping and the gathers; rocprofv3 SQ counters (profiles/r04_msm_sq_counters.json): VALU issue "
-                                  "busy 88 % of the SIMD cycles of a launch"},
-        "phases_ms_per_step": phase_avg, "pipelining": f"{depth} MSM steps in flight (kg_msm_begin / kg_msm_end), inputs declared complete",
-    }
+    line["blocking_ms"] = blocking_ms          # wall time of one isolated kg_msm call (nothing in flight), host finish included; median of five rounds of four
+    line["queues"] = {"placement": ctx.queue_placement() if hasattr(ctx, "queue_placement") else None}
+    line["roofline"]["isolated"] = {"kernel_ms": iso_ms, "achieved": iso_achieved, "frac": iso_achieved / HBM_PEAK_GBS}
+    # the bound that actually limits the kernel, against the MACHINE: multiply-accumulate instructions per second vs the
+    # chip's measured v_mad_u64_u32 issue rate; and against the same addition routine with operands in registers
+    line["valu_roofline"] = note({"bound": "valu", "unit": "T v_mad_u64_u32/s", "mads_per_addition": MADS_PER_ADDITION, "additions_per_launch": adds,
+                                  "achieved": adds * MADS_PER_ADDITION / (iso_ms * 1e-3) / 1e12, "peak": MAD_PEAK_T,
+                                  "frac": adds * MADS_PER_ADDITION / (iso_ms * 1e-3) / 1e12 / MAD_PEAK_T,
+                                  "routine_relative": {"unit": "G point additions/s", "achieved": adds / (iso_ms * 1e-3) / 1e9, "peak": MADD_PEAK_G,
+                                                       "frac": adds / (iso_ms * 1e-3) / 1e9 / MADD_PEAK_G}},
+                                 "isolated launches; the remaining ~30 % of issue slots go to the shifts / masks / carries of the 29-bit limbs, "
+                                 "the lazy-reduction bookkeeping and the gathers; rocprofv3 SQ counters (profiles/r05_msm_sq_counters.json): VALU issue "
+                                 "busy 88 % of the SIMD cycles of a launch")
 
     if rank == 0 and world == 1:
         # informational: the same steps with the bases registered (kg_bases_register: converted to the internal
@@ -361,7 +448,7 @@ def main():
         t0 = time.perf_counter()
         res_reg = run(args.steps)
         barrier()
-        line["registered_bases"] = {"ms_per_step": (time.perf_counter() - t0) / args.steps * 1e3,
+        line["registered_bases"] = {"ms_per_step": r3((time.perf_counter() - t0) / args.steps * 1e3),
                                     "matches_unregistered": bool((res_reg[0] == res[0]).all() and res_reg[1] == res[1])}
         if (1 << 16) <= n <= (1 << 20):
             # and with window tables on top (kg_bases_precompute: 2^(17 w) * P for the 15 windows, one bucket set for all of them):
@@ -376,8 +463,7 @@ def main():
             t0 = time.perf_counter()
             res_tab = run(args.steps)
             barrier()
-            line["registered_bases"]["window_tables"] = {"ms_per_step": (time.perf_counter() - t0) / args.steps * 1e3, "build_ms": build_ms,
-                                                         "table_bytes": (15 if n >= (1 << 17) else 16) * 64 * n,
+            line["registered_bases"]["window_tables"] = {"ms_per_step": r3((time.perf_counter() - t0) / args.steps * 1e3), "build_ms": r3(build_ms),
                                                          "matches_unregistered": bool((res_tab[0] == res[0]).all() and res_tab[1] == res[1])}
         # The call the reference's call sites make (groth16/src/msm.rs:6: fixed bases, a fresh `coeffs` slice per call): bases registered
         # once, the 2^log_n scalars in pageable HOST memory, uploaded inside the call in index slices under the accumulations
@@ -406,12 +492,12 @@ def main():
             ctx.write(stage.data_ptr(), hs)                # one synchronous kg_memcpy_h2d of the whole slice: what the call replaced
         up_ms = (time.perf_counter() - t0) / 5 * 1e3
         del stage
-        line["msm_host_scalars"] = {"ms_per_msm": host_ms, "resident_blocking_ms": res_ms, "over_resident_ms": host_ms - res_ms,
-                                    "rounds_ms": [round(x, 3) for x in host_rounds], "resident_rounds_ms": [round(x, 3) for x in res_rounds],
-                                    "plain_upload_ms": up_ms, "upload_gb_per_s": 32 * n / (up_ms * 1e-3) / 1e9,
-                                    "matches_resident": bool((hres == rres).all()),
-                                    "note": "kg_msm_host_scalars: registered bases, pageable host scalars (32 B per pair over PCIe inside the call), "
-                                            "blocking, host finish included; resident_blocking_ms = kg_msm on the same registered bases, same loop"}
+        line["msm_host_scalars"] = note({"ms_per_msm": r3(host_ms), "resident_blocking_ms": r3(res_ms), "over_resident_ms": r3(host_ms - res_ms),
+                                         "rounds_ms": [round(x, 3) for x in host_rounds], "resident_rounds_ms": [round(x, 3) for x in res_rounds],
+                                         "plain_upload_ms": r3(up_ms), "upload_gb_per_s": r3(32 * n / (up_ms * 1e-3) / 1e9),
+                                         "matches_resident": bool((hres == rres).all())},
+                                        "kg_msm_host_scalars: registered bases, pageable host scalars (32 B per pair over PCIe inside the call), "
+                                        "blocking, host finish included; resident_blocking_ms = kg_msm on the same registered bases, same loop")
         del hs
         ctx.bases_unregister(bases.data_ptr())
     cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
@@ -421,10 +507,13 @@ def main():
         line["cpu_baseline"] = cpu_baseline(ctx, K, bases, scalars, n, res)
         line["cpu_plumbing_2_10"] = cpu_plumbing(ctx, K)
     del bases, scalars
-    env = {"world": world, "rank": rank, "barrier": barrier, "host_barrier": host_barrier, "max_over_ranks": max_over_ranks, "xdev": xdev, "kdist": kdist}
     # the strong-scaled counterpart of the headline: ONE 2^log_n MSM cut over the ranks (north_star: "splitting the scalar/base array
     # across the 8 GPUs"); at N = 1 it is the blocking kg_msm of the whole range
     line["msm_strong"] = bench_msm_strong(ctx, torch, dev, K, env, args.log_n, args.steps)
+    if not args.no_g2:
+        line["msm_g2"] = bench_msm_g2(ctx, torch, dev, K, env, args.g2_log_n, steps=10, rounds=3, cpu=cpu)
+    if rank == 0 and world == 1 and not args.no_small:
+        line["small"] = bench_small(ctx, torch, dev, K)
     if not args.no_ntt:
         line["ntt"] = bench_ntt(ctx, torch, dev, K, env)
     if not args.no_nova:
@@ -435,18 +524,57 @@ def main():
             # the same proof size on a circuit whose witness is 0/1-heavy (prover.rs:53-65 meets such aux vectors)
             sk = bench_groth16(ctx, torch, dev, K, env, args.groth16_log_m, steps=4, cpu=cpu, circuit="boolean", from_witness=False)
             line["groth16"]["skewed_witness"] = {
-                "circuit": "30 % chain constraints, 70 % booleanity constraints: z = x || w is half ones, a fifth zeros, the rest uniform",
                 "ms_per_proof": sk["ms_per_proof"], "ms_per_proof_blocking": sk["ms_per_proof_blocking"],
-                "ratio_to_uniform": sk["ms_per_proof"] / line["groth16"]["ms_per_proof"],
+                "ratio_to_uniform": r3(sk["ms_per_proof"] / line["groth16"]["ms_per_proof"]),
                 "pipelined_matches_blocking": sk["pipelined_matches_blocking"],
                 "window_tables": {k_: sk["window_tables"][k_] for k_ in ("ms_per_proof", "ms_per_proof_blocking", "proofs_match")} if "window_tables" in sk else None,
-                "window_tables_ratio_to_uniform": (sk["window_tables"]["ms_per_proof"] / line["groth16"]["window_tables"]["ms_per_proof"]) if "window_tables" in sk and "window_tables" in line["groth16"] else None,
                 "cpu_baseline": sk.get("cpu_baseline")}
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        out = {"summary": make_summary(line), **line}
+        text = json.dumps(compact(out), separators=(",", ":"))
+        print(text, flush=True)
+        print(f"bench.py: the line is {len(text)} bytes", file=sys.stderr)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def make_summary(line):
+    """every leg's headline figure, flat, FIRST in the line (ms unless the key says otherwise); `checks` = every parity flag the legs carry"""
+    def g(d, *ks):
+        for k_ in ks:
+            if not isinstance(d, dict) or k_ not in d:
+                return None
+            d = d[k_]
+        return d
+    s = {"msm_ms_per_step": r3(line["ms_per_step"]), "msm_pairs_per_s": line["value"], "acc_kernel_ms": r3(g(line, "roofline", "kernel_ms")),
+         "acc_kernel_isolated_ms": r3(g(line, "roofline", "isolated", "kernel_ms")), "hbm_frac": r3(g(line, "roofline", "frac")),
+         "blocking_ms": r3(line.get("blocking_ms")), "host_scalars_ms": g(line, "msm_host_scalars", "ms_per_msm"),
+         "host_scalars_over_resident_ms": g(line, "msm_host_scalars", "over_resident_ms"), "msm_strong_ms": g(line, "msm_strong", "ms_per_msm"),
+         "msm_skewed_ms": g(line, "msm_skewed", "ms_per_step"),
+         "g2_ms_per_step": g(line, "msm_g2", "ms_per_step"), "g2_blocking_ms": g(line, "msm_g2", "blocking_ms"), "g2_pairs_per_s": g(line, "msm_g2", "value"),
+         "msm_2p10_blocking_ms": g(line, "small", "msm_blocking_ms", "1024"), "msm_32_blocking_ms": g(line, "small", "msm_blocking_ms", "32"),
+         "proof_2p10_blocking_ms": g(line, "small", "proof_2p10_blocking_ms"),
+         "ntt_ms": g(line, "ntt", "ms"), "ntt_idft_ms": g(line, "ntt", "variants", "idft", "ms"), "ntt_coset_dft_ms": g(line, "ntt", "variants", "coset_dft", "ms"),
+         "ntt_coset_idft_ms": g(line, "ntt", "variants", "coset_idft", "ms"),
+         "proof_ms": g(line, "groth16", "ms_per_proof"), "proof_blocking_ms": g(line, "groth16", "ms_per_proof_blocking"),
+         "proof_tables_ms": g(line, "groth16", "window_tables", "ms_per_proof"), "proof_tables_blocking_ms": g(line, "groth16", "window_tables", "ms_per_proof_blocking"),
+         "setup_ms": g(line, "groth16", "setup_ms"),
+         "commit_g1_ms": g(line, "nova_commit", "g1_fr", "ms_per_commit"), "commit_grumpkin_ms": g(line, "nova_commit", "grumpkin_fq", "ms_per_commit"),
+         "commit_g1_from_host_ms": g(line, "nova_commit", "g1_fr", "from_host", "ms_per_commit"),
+         "commit_grumpkin_from_host_ms": g(line, "nova_commit", "grumpkin_fq", "from_host", "ms_per_commit"),
+         "cpu_msm_pairs_per_s": g(line, "cpu_baseline", "value"), "cpu_proofs_per_s": g(line, "groth16", "cpu_baseline", "value")}
+    flags = []
+
+    def walk(d, path):
+        for k_, v_ in d.items():
+            if isinstance(v_, dict):
+                walk(v_, path + [k_])
+            elif isinstance(v_, bool) and ("match" in k_ or "add_up" in k_):
+                flags.append((".".join(path + [k_]), v_))
+    walk(line, [])
+    s["checks"] = {"passed": sum(1 for _, v_ in flags if v_), "failed": [k_ for k_, v_ in flags if not v_]}
+    return {k_: v_ for k_, v_ in s.items() if v_ is not None}
 
 
 def pmc_traffic(log_n):
@@ -454,54 +582,230 @@ def pmc_traffic(log_n):
     Memory-side bytes per k_acc_tasks launch from the committed rocprofv3 --pmc passes (profiles/): FETCH_SIZE and
     WRITE_SIZE are collected in separate runs of this same command.  MI355X_MICROARCH.md prescribes doubling FETCH_SIZE on
     gfx950 for wide coalesced streams; this kernel's reads are scattered 8-byte-per-lane gathers, for which the correction is
-    uncalibrated -- both figures are reported.  Only valid for the configuration it was measured on (2^20 pairs); null otherwise."""
-    for name in ("r05_pmc_hbm.json", "r04_pmc_hbm.json", "r03_pmc_hbm.json", "r02_pmc_hbm.json", "r01_m_pmc_hbm.json"):
+    uncalibrated (an upper estimate) -- both figures are reported.  Only valid for the configuration it was measured on (2^20 pairs); null otherwise."""
+    for name in ("r06_pmc_hbm.json", "r05_pmc_hbm.json", "r04_pmc_hbm.json", "r03_pmc_hbm.json", "r02_pmc_hbm.json", "r01_m_pmc_hbm.json"):
         path = os.environ.get("KG_BENCH_PMC") or os.path.join(ROOT, "profiles", name)
         if log_n == LOG_N and os.path.exists(path):
             with open(path) as f:
                 t = json.load(f)["k_acc_tasks_traffic_bytes_per_launch"]
             return {"uncorrected": t["fetch_reported"] + t["write"], "corrected": t["total_corrected"], "fetch_reported": t["fetch_reported"],
-                    "write": t["write"], "source": os.path.relpath(path, ROOT),
-                    "note": "FETCH_SIZE x2 is calibrated for 16-B-per-lane streams; 8-B gathers out of L2 / Infinity Cache make it an upper estimate"}
+                    "write": t["write"], "source": os.path.relpath(path, ROOT)}
     return None
 
 
-def bench_ntt(ctx, torch, dev, K, env, log_n=22, steps=10, warmup=100):
-    """secondary line: forward Fr NTT at 2^22 (BASELINE.json configs[2]), 64 algorithmic bytes per element.  The transform
-    does not shard (it would need an all-to-all transpose): with N ranks every rank transforms its own vector
-    (replicas) and `value` is the aggregate."""
+def bench_msm_g2(ctx, torch, dev, K, env, log_n=18, steps=10, rounds=3, cpu=False):
+    """BN254 G2 MSM (north_star: "Pippenger bucket MSM over G1/G2"; the prover's b_g2 query, groth16/src/prover.rs:64-65, bn254/src/g2.rs:16-20):
+    2^log_n uniform Fr scalars against G2 bases k_i * G2 (cofactor != 1: generator multiples, made on the device by kg_fixed_base_mul),
+    four in flight and blocking.  160 algorithmic bytes per pair; the dominant kernel is k_acc_tasks<Fq2> (250 VGPRs, two
+    waves per SIMD), timed alone (one launch per MSM) for `roofline.isolated` and `valu_roofline`.  CPU leg: the oracle's Pippenger
+    restatement on the same pairs, which also checks the GPU point."""
+    import numpy as np
+    world, rank = env["world"], env["rank"]
+    n = 1 << log_n
+    k = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    xy = torch.empty(n * 16, dtype=torch.int64, device=dev)
+    inf = torch.zeros(n, dtype=torch.uint8, device=dev)
+    sc = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    ctx.gen_scalars(K.KG_FR, SEED + 60, rank * n, n, k.data_ptr())
+    ctx.fixed_base_mul(K.KG_G2, k.data_ptr(), n, xy.data_ptr(), inf.data_ptr())
+    ctx.gen_scalars(K.KG_FR, SEED + 61, rank * n, n, sc.data_ptr())
+    ctx.sync()
+    args_ = (K.KG_G2, xy.data_ptr(), inf.data_ptr(), sc.data_ptr(), n)
+
+    def run(kk, depth=4):
+        res = None
+        for i in range(kk):
+            ctx.msm_begin(*args_, i % 4)
+            if i >= depth - 1:
+                res = ctx.msm_end(K.KG_G2, (i - depth + 1) % 4)
+        for i in range(max(kk - depth + 1, 0), kk):
+            res = ctx.msm_end(K.KG_G2, i % 4)
+        return res
+    run(24)
+    ctx.profile_enable(True)
+    elapsed, rounds_ms, res = timed_rounds(env, run, steps, rounds)
+    summ = ctx.profile_summary()
+    ctx.profile_enable(False)
+    pipe_kernel_ms = summ["accumulate"][0] / summ["accumulate"][1]
+    ctx.set_msm_groups(1)                      # the kernel alone: ONE accumulation launch per MSM
+    ctx.msm(*args_)
+    ctx.profile_enable(True)
+    for _ in range(5):
+        ctx.msm(*args_)
+    iso = ctx.profile_summary()
+    ctx.profile_enable(False)
+    ctx.set_msm_groups(0)
+    for _ in range(2):
+        blk = ctx.msm(*args_)
+    br = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(4):
+            blk = ctx.msm(*args_)
+        br.append((time.perf_counter() - t0) / 4 * 1e3)
+    iso_ms = iso["accumulate"][0] / iso["accumulate"][1]
+    adds = window_adds(n)
+    gbs = G2_BYTES_PER_PAIR * n / (pipe_kernel_ms * 1e-3) / 1e9
+    iso_gbs = G2_BYTES_PER_PAIR * n / (iso_ms * 1e-3) / 1e9
+    out = {"metric": "bn254_g2_msm_pairs_per_sec", "log_n": log_n, "value": world * n * steps / elapsed, "unit": "pairs/s", "ms_per_step": r3(elapsed / steps * 1e3),
+           "rounds_ms": rounds_ms, "blocking_ms": r3(sorted(br)[2]), "pipelined_matches_blocking": bool((res == blk).all()),
+           "bases": "k_i * G2 (kg_fixed_base_mul)",
+           "roofline": {"bound": "hbm", "kernel": "k_acc_tasks<Fq2>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "kernel_ms": pipe_kernel_ms, "launches": summ["accumulate"][1], "algorithmic_bytes_per_launch": G2_BYTES_PER_PAIR * n, "traffic": None,
+                        "isolated": {"kernel_ms": iso_ms, "achieved": iso_gbs, "frac": iso_gbs / HBM_PEAK_GBS}},
+           "valu_roofline": {"bound": "valu", "unit": "T v_mad_u64_u32/s", "mads_per_addition": MADS_PER_G2_ADDITION, "additions_per_launch": adds,
+                             "achieved": adds * MADS_PER_G2_ADDITION / (iso_ms * 1e-3) / 1e12, "peak": MAD_PEAK_T,
+                             "frac": adds * MADS_PER_G2_ADDITION / (iso_ms * 1e-3) / 1e12 / MAD_PEAK_T}}
+    if cpu:
+        from oracle import oracle as O
+        hb = xy.cpu().numpy().view(np.uint64).reshape(n, 16)
+        hi = inf.cpu().numpy()
+        hs = sc.cpu().numpy().view(np.uint64).reshape(n, 4)
+        lg = n.bit_length()
+        c_ref = (lg * 69 // 100) + 2
+        threads = max(1, min(256 // c_ref + 1, os.cpu_count() or 1))
+        t0 = time.perf_counter()
+        want_xy, want_inf = O.to_affine("g2", O.msm("g2", hb, hs, hi, threads=threads))
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / cdt, "unit": "pairs/s", "cores": threads, "kind": "port",
+                               "sample": f"all {n} pairs, reference window rule (c = {c_ref}), {cdt:.2f} s",
+                               "gpu_matches_cpu_at_full_size": bool(not want_inf and blk[16:].any() and (blk[:16] == want_xy).all())}
+    del k, xy, inf, sc
+    return out
+
+
+def bench_small(ctx, torch, dev, K):
+    """Short BLOCKING calls, the sizes the reference's own tests and BASELINE configs[0] live at (groth16/src/msm.rs:118-135: 32 pairs;
+    bn254/benches: 2^10; groth16/src/lib.rs:29-77: a handful of constraints): latency of kg_msm on resident arrays for n = 16 ... 2^12 on
+    the three curves, and a blocking proof of 2^10 constraints.  Median of five rounds of eight calls."""
+    import numpy as np
+    out = {"msm_blocking_ms": {}, "grumpkin_blocking_ms": {}, "g2_blocking_ms": {}}
+
+    def lat(fn, reps=8):
+        for _ in range(3):
+            fn()
+        rr = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            rr.append((time.perf_counter() - t0) / reps * 1e3)
+        return r3(sorted(rr)[2])
+    nmax = 1 << 12
+    for name, curve, fld in (("msm_blocking_ms", K.KG_G1, K.KG_FR), ("grumpkin_blocking_ms", K.KG_GRUMPKIN, K.KG_FQ)):
+        b = torch.empty(nmax * 8, dtype=torch.int64, device=dev)
+        s = torch.empty(nmax * 4, dtype=torch.int64, device=dev)
+        ctx.gen_bases(curve, SEED + 80, 0, nmax, b.data_ptr())
+        ctx.gen_scalars(fld, SEED + 81, 0, nmax, s.data_ptr())
+        ctx.sync()
+        for nn in ((16, 32, 256, 1024, 4096) if curve == K.KG_G1 else (32, 1024)):
+            out[name][str(nn)] = lat(lambda: ctx.msm(curve, b.data_ptr(), 0, s.data_ptr(), nn))
+        del b, s
+    k = torch.empty(1024 * 4, dtype=torch.int64, device=dev)
+    xy = torch.empty(1024 * 16, dtype=torch.int64, device=dev)
+    inf = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    ctx.gen_scalars(K.KG_FR, SEED + 82, 0, 1024, k.data_ptr())
+    ctx.fixed_base_mul(K.KG_G2, k.data_ptr(), 1024, xy.data_ptr(), inf.data_ptr())
+    ctx.sync()
+    for nn in (32, 1024):
+        out["g2_blocking_ms"][str(nn)] = lat(lambda: ctx.msm(K.KG_G2, xy.data_ptr(), inf.data_ptr(), k.data_ptr(), nn))
+    del k, xy, inf
+    # a blocking proof of 2^10 constraints (chain circuit, real CRS from the device setup)
+    from kogarashi_amd import synthetic as syn
+    from kogarashi_amd.api import groth16_setup
+    from kogarashi_amd.lib import Groth16Crs
+    m = 1 << 10
+    cc = syn.ChainCircuit(m)
+    P = groth16_setup(cc.a, cc.b, cc.c, m, cc.l, cc.m_l_1, syn.fixed_toxic(), syn.FrOps, ctx=ctx)
+    up = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(dev)
+    names = ("h", "l", "a", "b_g1", "b_g2")
+    dev_arr = {nm: up(P[nm]) for nm in names}
+    dev_inf = {nm: (torch.from_numpy(P[nm + "_inf"]).to(dev) if P[nm + "_inf"].any() else None) for nm in names}
+    crs = Groth16Crs()
+    crs.m, crs.l, crs.m_l_1 = m, cc.l, cc.m_l_1
+    for nm in names:
+        setattr(crs, "d_" + nm, dev_arr[nm].data_ptr())
+        if dev_inf[nm] is not None:
+            setattr(crs, "d_" + nm + "_inf", dev_inf[nm].data_ptr())
+        ctx.bases_register(K.KG_G2 if nm == "b_g2" else K.KG_G1, dev_arr[nm].data_ptr(), dev_inf[nm].data_ptr() if dev_inf[nm] is not None else 0,
+                           dev_arr[nm].numel() // (16 if nm == "b_g2" else 8))
+    for i in range(8):
+        crs.alpha_g1[i], crs.beta_g1[i], crs.delta_g1[i] = int(P["vk_g1"][0, i]), int(P["vk_g1"][1, i]), int(P["vk_g1"][2, i])
+    for i in range(16):
+        crs.beta_g2[i], crs.delta_g2[i] = int(P["vk_g2"][0, i]), int(P["vk_g2"][1, i])
+    r, s_ = syn.fixed_rs()
+    d = [up(x_) for x_ in (cc.a_eval, cc.b_eval, cc.c_eval, cc.x, cc.w)]
+    out["proof_2p10_blocking_ms"] = lat(lambda: ctx.groth16_prove(crs, *[t.data_ptr() for t in d], r, s_), reps=4)
+    for nm in names:
+        ctx.bases_unregister(dev_arr[nm].data_ptr())
+    return out
+
+
+def bench_ntt(ctx, torch, dev, K, env, log_n=22, steps=10, warmup=100, variants="all"):
+    """secondary line: forward Fr NTT at 2^22 (BASELINE.json configs[2]), 64 algorithmic bytes per element, and -- `variants` -- the
+    other three transforms of groth16/src/fft.rs:100-127 (idft, coset_dft, coset_idft: the n^-1 scale and the coset shifts are fused
+    into the first load / last store of the same kernels) at the same size.  The transform does not shard (it would need an
+    all-to-all transpose): with N ranks every rank transforms its own vector (replicas) and `value` is the aggregate."""
     world, rank = env["world"], env["rank"]
     n = 1 << log_n
     data = torch.empty(n * 4, dtype=torch.int64, device=dev)
     ctx.gen_scalars(K.KG_FR, SEED + 3, rank * n, n, data.data_ptr())
-    for _ in range(warmup):       # untimed: tables, first touch, and the clock ramp after the CPU legs (the GPU sat idle behind them)
-        ctx.ntt(data.data_ptr(), log_n, False, False)
-    ctx.sync()
-    # the library brackets every transform with HIP events on the queue it launches on ("ntt" phase)
-    ctx.profile_enable(True)
-    env["barrier"]()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ctx.ntt(data.data_ptr(), log_n, False, False)
-    ctx.sync()
-    env["barrier"]()
-    wall_ms = env["max_over_ranks"](time.perf_counter() - t0) / steps * 1e3
-    tot, cnt = ctx.profile_summary()["ntt"]
-    ctx.profile_enable(False)
-    ms = tot / cnt
-    gbs = 64.0 * n / (ms * 1e-3) / 1e9
+
+    def timed(inverse, coset, wu):
+        for _ in range(wu):       # untimed: tables, first touch, and the clock ramp after the CPU legs (the GPU sat idle behind them)
+            ctx.ntt(data.data_ptr(), log_n, inverse, coset)
+        ctx.sync()
+        # the library brackets every transform with HIP events on the queue it launches on ("ntt" phase)
+        ctx.profile_enable(True)
+        env["barrier"]()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.ntt(data.data_ptr(), log_n, inverse, coset)
+        ctx.sync()
+        env["barrier"]()
+        wall_ms = env["max_over_ranks"](time.perf_counter() - t0) / steps * 1e3
+        tot, cnt = ctx.profile_summary()["ntt"]
+        ctx.profile_enable(False)
+        return tot / cnt, wall_ms
     mads, kernel_note, plan = ntt_cost(K, log_n)
-    out = {"metric": "bn254_fr_ntt_elements_per_sec", "log_n": log_n, "value": world * n / (wall_ms * 1e-3), "ms": ms, "wall_ms": wall_ms,
+    table = {"dft": (False, False), "idft": (True, False), "coset_dft": (False, True), "coset_idft": (True, True)}
+    if variants not in ("all", "dft"):            # --ntt-only --ntt-variant X: that transform alone (its kernels' rocprof averages)
+        ms, wall_ms = timed(*table[variants], warmup)
+        return {"log_n": log_n, "variant": variants, "ms": r3(ms), "wall_ms": r3(wall_ms), "value": world * n / (wall_ms * 1e-3), "steps": steps}
+    ms, wall_ms = timed(False, False, warmup)
+    gbs = 64.0 * n / (ms * 1e-3) / 1e9
+    out = {"metric": "bn254_fr_ntt_elements_per_sec", "log_n": log_n, "value": world * n / (wall_ms * 1e-3), "ms": r3(ms), "wall_ms": r3(wall_ms),
            "replicas": world, "steps": steps, "warmup": warmup,
-           "note": "value = replicas x n / wall time per transform (max over ranks); ms = HIP-event duration of one transform on rank 0",
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "algorithmic_bytes": 64 * n, "kernel": kernel_note},
-           "plan": [{"log_m": m, "log_tile": t} for m, t in plan]}
+                        "algorithmic_bytes": 64 * n, "kernel": kernel_note, "traffic": ntt_pmc_traffic(log_n)}}
+    note(out, "value = replicas x n / wall time per transform (max over ranks); ms = HIP-event duration of one transform on rank 0")
     if mads:
         out["valu_roofline"] = {"bound": "valu", "unit": "T v_mad_u64_u32/s", "mads_per_element": mads,
-                                "achieved": mads * n / (ms * 1e-3) / 1e12, "peak": MAD_PEAK_T, "frac": mads * n / (ms * 1e-3) / 1e12 / MAD_PEAK_T,
-                                "note": "multiply-accumulates are ~60 % of the kernels' VALU instructions (DESIGN.md section 4)"}
+                                "achieved": mads * n / (ms * 1e-3) / 1e12, "peak": MAD_PEAK_T, "frac": mads * n / (ms * 1e-3) / 1e12 / MAD_PEAK_T}
+    if variants == "all":
+        out["variants"] = {}
+        for name in ("idft", "coset_dft", "coset_idft"):
+            vms, vwall = timed(*table[name], 20)
+            out["variants"][name] = {"ms": r3(vms), "wall_ms": r3(vwall), "value": world * n / (vwall * 1e-3), "hbm_frac": r3(64.0 * n / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS)}
     return out
+
+
+def ntt_pmc_traffic(log_n):
+    """HBM bytes per 2^22 transform from the committed counter passes (profiles/rNN_ntt_pmc_hbm.json: the transform's launches,
+    FETCH_SIZE x2-corrected + WRITE_SIZE), or null"""
+    if log_n != 22:
+        return None
+    for name in ("r06_ntt_pmc_hbm.json", "r05_ntt_pmc_hbm.json", "r04_ntt_pmc_hbm.json", "r03_ntt_pmc_hbm.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                with open(path) as f:
+                    t = json.load(f)
+                v = t.get("ntt_traffic_bytes_per_transform")
+                return (v["total_corrected"] if isinstance(v, dict) else v) if v is not None else None
+            except (OSError, ValueError, KeyError):
+                return None
+    return None
 
 
 def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, skew=False):
@@ -519,9 +823,7 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, ske
     lo, hi = shard_range(total, rank, world)
     nl = hi - lo
     out = {"metric": "nova_pedersen_commit_pairs_per_sec", "log_n": log_n, "pairs_total": total, "pairs_per_rank": nl, "ranks": world,
-           "scaling": "strong (one 2^%d-pair commitment cut over the ranks by kg_shard_range)" % log_n,
-           "key": "registered (kg_bases_register: the generators are fixed by PedersenCommitment::new)",
-           "algorithmic_bytes_per_commit": 96 * total}
+           "scaling": "strong", "key": "registered", "unit": "pairs/s", "algorithmic_bytes_per_commit": 96 * total}
     for name, curve, fld, cv in (("g1_fr", K.KG_G1, K.KG_FR, "g1"), ("grumpkin_fq", K.KG_GRUMPKIN, K.KG_FQ, "gk")):
         g = torch.empty(nl * 8, dtype=torch.int64, device=dev)
         m = torch.empty(nl * 4, dtype=torch.int64, device=dev)
@@ -542,10 +844,9 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, ske
             got = one()
         env["barrier"]()
         dt = env["max_over_ranks"](time.perf_counter() - t0) / steps
-        leg = {"ms_per_commit": dt * 1e3, "value": total / dt, "unit": "pairs/s",
-               "point": {"xy_hex": "".join(f"{int(v_):016x}" for v_ in got[0]), "is_identity": bool(got[1])},     # the commitment itself: equal for every N
-               "roofline": {"bound": "hbm", "achieved": 96 * total / dt / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                            "frac": 96 * total / dt / 1e9 / (HBM_PEAK_GBS * world)}}
+        leg = {"ms_per_commit": r3(dt * 1e3), "value": total / dt,
+               "point": point_digest(got[0], got[1]),     # the commitment itself: equal for every N
+               "hbm_frac": 96 * total / dt / 1e9 / (HBM_PEAK_GBS * world)}
         if world == 1:
             # As nova/src/pedersen.rs:15-20 is called: the key resident (kg_sharded_key over this one context), m a pageable HOST vector --
             # kg_sharded_key_commit uploads it in index slices under the accumulations.  PCIe-inclusive; beside ms_per_commit, never `value`.
@@ -561,8 +862,7 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, ske
                 hxy, hinf = key.commit(hm)
             hdt = (time.perf_counter() - t0) / steps
             key.close()
-            leg["from_host"] = {"ms_per_commit": hdt * 1e3, "ratio_to_resident": hdt / dt, "scalar_bytes": 32 * nl,
-                                "bus_gb_per_s_if_serial": 32 * nl / max(hdt - dt, 1e-9) / 1e9,
+            leg["from_host"] = {"ms_per_commit": r3(hdt * 1e3), "ratio_to_resident": r3(hdt / dt),
                                 "matches_resident": bool(bool(hinf) == bool(got[1]) and (bool(hinf) or (np.asarray(hxy) == np.asarray(got[0])).all()))}
             del hm
         if skew and name == "g1_fr" and world == 1:
@@ -583,7 +883,7 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, ske
             a = ctx.commit(curve, g.data_ptr(), 0, mw.data_ptr(), h)
             b = ctx.commit(curve, g.data_ptr() + h * 64, 0, mw.data_ptr() + h * 32, nl - h)
             sxy, sinf = ctx.points_sum_affine(curve, np.stack([a[0], b[0]]), np.array([a[1], b[1]], dtype=np.uint8))
-            leg["witness_like"] = {"ms_per_commit": wdt * 1e3, "ratio_to_uniform": wdt / dt,
+            leg["witness_like"] = {"ms_per_commit": r3(wdt * 1e3), "ratio_to_uniform": r3(wdt / dt),
                                    "halves_add_up": bool(bool(sinf) == bool(winf) and (bool(winf) or (np.asarray(sxy) == np.asarray(wxy)).all()))}
             del mw
         if cpu:
@@ -601,8 +901,8 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, ske
                 O.commit_naive(cv, hg[:k], hm[:k])
                 cdt = time.perf_counter() - t0
             leg["cpu_naive_fold"] = {"value": k / cdt, "unit": "pairs/s", "cores": 1, "kind": "port",
-                                     "sample": f"first {k} pairs, {cdt:.2f} s; the fold is sequential in the reference",
-                                     "extrapolated_s_per_commit": cdt * total / k}
+                                     "sample": f"first {k} pairs, {cdt:.2f} s",
+                                     "extrapolated_s_per_commit": r3(cdt * total / k)}
             # (2) like for like at full size: the oracle's restatement of msm_curve_addition, one thread per window
             lg = nl.bit_length()
             c_ref = (lg * 69 // 100) + 2
@@ -611,7 +911,7 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, ske
             want = O.to_affine(cv, O.msm(cv, hg, hm, None, threads=threads))
             cdt = time.perf_counter() - t0
             leg["cpu_pippenger"] = {"value": nl / cdt, "unit": "pairs/s", "cores": threads, "kind": "port",
-                                    "sample": f"all {nl} pairs, reference window rule (c = {c_ref}), {cdt:.2f} s",
+                                    "sample": f"all {nl} pairs, c = {c_ref}, {cdt:.2f} s",
                                     "gpu_matches_cpu_at_full_size": bool(want[1] == got[1] and (want[1] or (want[0] == got[0]).all()))}
             del hg, hm
         ctx.bases_unregister(g.data_ptr())
@@ -648,16 +948,16 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, ske
             ctx.bases_unregister(g.data_ptr())
             del g, m
         a, b = unit[log_n - 3], unit[log_n - 2]
-        out["rank_unit"] = {"log_n": log_n - 3, "blocking_ms_per_commit": a, "half_of_twice_the_size_ms": b / 2, "ratio": a / (b / 2),
-                            "from_host_ms_per_commit": unit["host"],
-                            "note": "blocking kg_commit, registered key, bn254 G1: the slice one rank of the 8-GPU configuration commits; "
-                                    "from_host = the same slice with its scalars in pageable host memory (kg_commit_host_scalars, PCIe-inclusive)"}
+        out["rank_unit"] = note({"log_n": log_n - 3, "blocking_ms_per_commit": r3(a), "half_of_twice_the_size_ms": r3(b / 2), "ratio": r3(a / (b / 2)),
+                                 "from_host_ms_per_commit": r3(unit["host"])},
+                                "blocking kg_commit, registered key, bn254 G1: the slice one rank of the 8-GPU configuration commits; "
+                                "from_host = the same slice with its scalars in pageable host memory (kg_commit_host_scalars, PCIe-inclusive)")
     return out
 
 
 def cpu_plumbing(ctx, K, log_n=10):
-    """BASELINE.json configs[0]: bn254 G1 MSM over 2^10 random pairs on the CPU (the reference's bn254/benches size; no GPU
-    number is claimed at this size -- a blocking kg_msm_host of 2^10 pairs is latency, reported beside it for the record)."""
+    """BASELINE.json configs[0]: bn254 G1 MSM over 2^10 random pairs on the CPU (the reference's bn254/benches size), with the blocking
+    kg_msm_host of the same host arrays beside it (latency: see `small` for the resident calls)."""
     import numpy as np
     from oracle import oracle as O
     n = 1 << log_n
@@ -676,7 +976,7 @@ def cpu_plumbing(ctx, K, log_n=10):
         got = ctx.msm_host(K.KG_G1, hb, inf0, hs, n)
     gdt = (time.perf_counter() - t0) / reps
     return {"value": n / dt, "unit": "pairs/s", "cores": 1, "kind": "port", "sample": f"{reps} x 2^{log_n} pairs, {dt * 1e3:.2f} ms each, one thread",
-            "gpu_host_call_ms": gdt * 1e3, "gpu_matches_cpu": bool(not inf and (got[:8] == xy).all())}
+            "gpu_host_call_ms": r3(gdt * 1e3), "gpu_matches_cpu": bool(not inf and (got[:8] == xy).all())}
 
 
 def bench_msm_skewed(ctx, torch, dev, K, bases, n, run_uniform, barrier, steps, uniform_ms, uniform_blocking_ms, cpu):
@@ -719,11 +1019,10 @@ def bench_msm_skewed(ctx, torch, dev, K, bases, n, run_uniform, barrier, steps, 
     for _ in range(5):
         blk = ctx.msm(K.KG_G1, bases.data_ptr(), 0, sc.data_ptr(), n)
     blocking = (time.perf_counter() - t0) / 5 * 1e3
-    out = {"ms_per_step": ms, "ratio_to_uniform": ms / uniform_ms, "blocking_ms": blocking, "blocking_ratio_to_uniform": blocking / uniform_blocking_ms,
+    out = {"ms_per_step": r3(ms), "ratio_to_uniform": r3(ms / uniform_ms), "blocking_ms": r3(blocking), "blocking_ratio_to_uniform": r3(blocking / uniform_blocking_ms),
            "partial_rounds_per_msm": (summ["partial_round"][1] / steps) if "partial_round" in summ else 0.0,
-           "phases_ms_per_step": {k_: v_[0] / v_[1] for k_, v_ in summ.items() if k_ != "partial_round"},
            "pipelined_matches_blocking": bool((res == blk).all()),
-           "scalars": "witness-like: 50 % ones, 20 % zeros, 10 % -1, 10 % the value 5, 10 % uniform (synthetic.witness_like)"}
+           "scalars": "synthetic.witness_like"}
     if cpu:
         from oracle import oracle as O
         hb = bases.cpu().numpy().view(np.uint64).reshape(n, 8)
@@ -804,16 +1103,14 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
     proof_p = run(k_pipe)
     sync()
     dt = mx(time.perf_counter() - t0) / k_pipe
-    out = {"metric": "groth16_proofs_per_sec", "log_m": log_m, "value": world / dt, "ms_per_proof": dt * 1e3, "replicas": world,
-           "ms_per_proof_blocking": dt_blocking * 1e3, "pipelining": "two proofs in flight (kg_groth16_prove_begin / _end)",
-           "crs": "resident and registered (kg_bases_register: converted to the internal form once, as api.Prover does)",
+    out = {"metric": "groth16_proofs_per_sec", "log_m": log_m, "value": world / dt, "ms_per_proof": r3(dt * 1e3), "replicas": world,
+           "ms_per_proof_blocking": r3(dt_blocking * 1e3), "pipelining": "two in flight", "crs": "registered",
            "pipelined_matches_blocking": bool(all((proof_p[i] == proof[i]).all() for i in range(4))),
            "algorithmic_bytes_per_proof": (7 * 64 + 4 * 32 + 4 * 96 + 160) * m,      # 1120 B per constraint
-           "setup_ms": setup_ms, "setup_first_ms": setup_first_ms,
-           "setup_note": "ZkSnark::setup (zksnark.rs:17-127) through kg_groth16_setup_bn254: matrices uploaded, CRS computed on the device, "
-                         "Parameters downloaded; first = with the one-off generator window tables of the context"}
-    out["roofline"] = {"bound": "hbm", "achieved": out["algorithmic_bytes_per_proof"] / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": out["algorithmic_bytes_per_proof"] / dt / 1e9 / HBM_PEAK_GBS}
+           "setup_ms": r3(setup_ms), "setup_first_ms": r3(setup_first_ms)}
+    note(out, "setup: ZkSnark::setup (zksnark.rs:17-127) through kg_groth16_setup_bn254: matrices uploaded, CRS computed on the device, "
+              "Parameters downloaded; first = with the one-off generator window tables of the context")
+    out["roofline"] = {"bound": "hbm", "achieved": out["algorithmic_bytes_per_proof"] / dt / 1e9, "frac": out["algorithmic_bytes_per_proof"] / dt / 1e9 / HBM_PEAK_GBS}
     # the same proofs with window tables on the five CRS vectors (kg_bases_precompute: 2^(c w) * P for every window, built once
     # per CRS): one bucket set for all windows of an MSM; proofs must be bit-identical
     tables = tables and (1 << 16) <= (l + m_l_1) <= (1 << 20) and (m - 1) >= (1 << 16)      # kg_bases_precompute: MSMs of 2^16 .. 2^20 scalars
@@ -840,10 +1137,7 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
         proof_tp = run(k_pipe)
         sync()
         dt_t = mx(time.perf_counter() - t0) / k_pipe
-        c_t = 17 if nz >= (1 << 17) else 16
-        w_t = (255 + c_t - 1) // c_t
-        out["window_tables"] = {"ms_per_proof": dt_t * 1e3, "ms_per_proof_blocking": dt_tb * 1e3, "value": world / dt_t, "build_ms": build_ms,
-                                "table_bytes": w_t * (64 * (3 * nz + (m - 1)) + 128 * nz),
+        out["window_tables"] = {"ms_per_proof": r3(dt_t * 1e3), "ms_per_proof_blocking": r3(dt_tb * 1e3), "value": world / dt_t, "build_ms": r3(build_ms),
                                 "proofs_match": bool(all((proof_t[i] == proof[i]).all() and (proof_tp[i] == proof[i]).all() for i in range(4)))}
     if tables and from_witness:
         # and from the witness alone: the constraint matrices resident as CSR, cs.evaluate() on the device at the head of the
@@ -868,7 +1162,7 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
         proof_w = run_w(k_pipe)
         sync()
         dt_w = mx(time.perf_counter() - t0) / k_pipe
-        out["window_tables"].update({"ms_per_proof_from_witness": dt_w * 1e3, "from_witness_matches": bool(all((proof_w[i] == proof[i]).all() for i in range(4)))})
+        out["window_tables"].update({"ms_per_proof_from_witness": r3(dt_w * 1e3), "from_witness_matches": bool(all((proof_w[i] == proof[i]).all() for i in range(4)))})
         # and as the patched Prover::create_proof calls it (rust/kogarashi-amd/src/groth16.rs prove_cs_with): BLOCKING, x = cs.x() and w = cs.w()
         # in host memory, uploaded into kg_malloc buffers per proof (the pool hands the same blocks back) -- PCIe-inclusive, never `value`
         hx, hw = np.ascontiguousarray(x), np.ascontiguousarray(w)
@@ -882,7 +1176,7 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
         for _ in range(steps):
             proof_h = host_proof()
         dt_h = (time.perf_counter() - t0) / steps
-        out["window_tables"].update({"ms_per_proof_blocking_host_witness": dt_h * 1e3, "witness_bytes": int(hx.nbytes + hw.nbytes),
+        out["window_tables"].update({"ms_per_proof_blocking_host_witness": r3(dt_h * 1e3),
                                      "host_witness_matches": bool(all((proof_h[i] == proof[i]).all() for i in range(4)))})
     # the CPU leg LAST: a second of 32 busy host threads in front of a timed GPU leg costs it 3-5 % (clocks, host threads)
     if cpu:
@@ -897,7 +1191,7 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
         cdt = time.perf_counter() - t0
         same = all((g == w_).all() for g, w_ in zip(proof[:3], want[:3])) and (proof[3] == want[3]).all()
         out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "proofs/s", "cores": threads, "kind": "port",
-                               "sample": f"one full proof at m = 2^{log_m}, {cdt:.2f} s", "gpu_matches_cpu_at_full_size": bool(same)}
+                               "sample": f"one proof at m = 2^{log_m}, {cdt:.2f} s", "gpu_matches_cpu_at_full_size": bool(same)}
     for name in ("h", "l", "a", "b_g1", "b_g2"):
         ctx.bases_unregister(dev_arr[name].data_ptr())
     if world > 1 and circuit == "chain":
@@ -924,9 +1218,8 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
             for _ in range(steps):
                 proof_s = sp.prove_resident(ptr, r, s_)
             dt_s = (time.perf_counter() - t0) / steps
-            out["sharded"] = {"contexts": n_ctx, "devices": [0 if selftest else i for i in range(n_ctx)], "ms_per_proof": dt_s * 1e3,
-                              "matches_single_context": bool(all((proof_s[i] == proof[i]).all() for i in range(4))),
-                              "note": "blocking kg_groth16_prove_sharded, inputs and CRS resident per context; unmeasured on multi-GPU hardware until the driver has an 8-GPU node"}
+            out["sharded"] = {"contexts": n_ctx, "devices": [0 if selftest else i for i in range(n_ctx)], "ms_per_proof": r3(dt_s * 1e3),
+                              "matches_single_context": bool(all((proof_s[i] == proof[i]).all() for i in range(4)))}
             del sp, keep
             for c_ in ctxs:
                 c_.close()

@@ -61,6 +61,18 @@ if os.path.isdir(os.path.join(src, "kt_ntt")):
     sq_counters(os.path.join(src, "pmcntt_SQ"), os.path.join(dst, f"{rnd}_ntt_sq_counters.json"), only="k_ntt_tile")
 if os.path.isdir(os.path.join(src, "pmc_SQ")):
     sq_counters(os.path.join(src, "pmc_SQ"), os.path.join(dst, f"{rnd}_msm_sq_counters.json"))
+# round 6: the prover alone, the G2 MSM alone, the three other transforms, and the per-launch tables (tools/kernel_table.py)
+for d, out in (("kt_g16", "groth16"), ("kt_g2", "msm_g2"), ("kt_ntt_idft", "ntt_idft"), ("kt_ntt_coset_dft", "ntt_coset_dft"), ("kt_ntt_coset_idft", "ntt_coset_idft")):
+    if os.path.isdir(os.path.join(src, d)):
+        shutil.copy(newest(os.path.join(src, d, "*", "*kernel_stats.csv")), os.path.join(dst, f"{rnd}_{out}_kernel_stats.csv"))
+for name, out in (("g16_under_rocprof.json", "groth16_under_rocprof.json"), ("g2_under_rocprof.json", "msm_g2_under_rocprof.json"),
+                  ("ntt_idft_under_rocprof.json", "ntt_idft_under_rocprof.json"), ("ntt_coset_dft_under_rocprof.json", "ntt_coset_dft_under_rocprof.json"),
+                  ("ntt_coset_idft_under_rocprof.json", "ntt_coset_idft_under_rocprof.json")):
+    if os.path.exists(os.path.join(src, name)):
+        json.dump(last_json_line(os.path.join(src, name)), open(os.path.join(dst, f"{rnd}_{out}"), "w"), indent=1)
+for name, out in (("msm_kernel_table.txt", "msm_kernel_table.txt"), ("g16_phase_table.txt", "groth16_phase_table.txt"), ("g2_kernel_table.txt", "msm_g2_kernel_table.txt")):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{out}"))
 for name in ("mul_rate.txt", "ntt_pass_rate.txt", "mfma_const_mul.txt", "group_scatter.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
