@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkogarashi_amd.so")
 OUT_EXP = os.path.join(HERE, "libkogarashi_amd_exp.so")
-SOURCES = ["capi.cpp", "tuning.cpp", "sharded.cpp", "msm_host.cpp", "vec.hip", "msm_sort.hip", "msm_run.hip", "ntt.hip", "groth16.hip", "setup.hip"]
+SOURCES = ["capi.cpp", "tuning.cpp", "sharded.cpp", "msm_host.cpp", "vec.hip", "msm_sort.hip", "msm_run.hip", "msm_small.hip", "ntt.hip", "groth16.hip", "setup.hip"]
 EXTRA_DEPS = ["../../include/kogarashi_amd.h"]     # plus every header under csrc/ (see _compile)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
          "-ffp-contract=off", "-Xarch_host", "-march=x86-64-v3"]

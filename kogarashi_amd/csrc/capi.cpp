@@ -289,7 +289,7 @@ int kg_hw_queue_setting(void) {
   const char* e = getenv("GPU_MAX_HW_QUEUES");
   return e ? atoi(e) : 0;
 }
-int kg_version(void) { return 5; }      // the round the ABI was last extended in (5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe; 4: kg_msm_set_groups; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded)
+int kg_version(void) { return 6; }      // the round the ABI was last extended in (6: kg_msm_set_small; 5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe; 4: kg_msm_set_groups; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded)
 
 int kg_experiments_built(void) {
 #ifdef KG_EXPERIMENTS
@@ -357,6 +357,7 @@ void kg_ctx_destroy(kg_ctx* c) {
   for (int i = 0; i < 2; ++i) if (c->ws3[i]) hipFree(c->ws3[i]);
   if (c->side_stream) hipStreamSynchronize(c->side_stream);
   for (int i = 0; i < kg_ctx::RUN_SETS; ++i) { if (c->ws_run[i]) hipFree(c->ws_run[i]); if (c->ev_acc[i]) hipEventDestroy(c->ev_acc[i]); }
+  for (int i = 0; i < kg_ctx::NSLOTS; ++i) if (c->ws_small[i]) hipFree(c->ws_small[i]);
   if (c->side_stream) hipStreamDestroy(c->side_stream);
   if (c->side2_stream) { hipStreamSynchronize(c->side2_stream); hipStreamDestroy(c->side2_stream); }
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -497,6 +498,13 @@ int kg_msm_set_window(kg_ctx* c, int w) {
 int kg_msm_set_groups(kg_ctx* c, int groups) {
   if (!c || groups < 0 || groups > kg_ctx::MAX_GROUPS) return KG_ERR_BAD_ARG;
   c->msm_groups = groups;
+  return KG_OK;
+}
+int kg_msm_set_small(kg_ctx* c, int max_pairs, int cw, int r) {
+  if (!c || max_pairs < -2 || max_pairs == -1 || max_pairs > 8192 || cw < 0 || cw == 1 || cw > 10 || r < -1 || r > 7) return KG_ERR_BAD_ARG;
+  if (max_pairs != -2) c->tune.small_max = max_pairs;
+  c->tune.small_c = cw;
+  c->tune.small_r = r;
   return KG_OK;
 }
 int kg_profile_enable(kg_ctx* c, int on) {

@@ -76,9 +76,12 @@ struct kg_ctx {
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_acc[RUN_SETS] = {};
   hipEvent_t ev_info[MAX_GROUPS] = {};   // marks the task-count read-back of msm_sort (per window group)
-  struct Slot { void* host = nullptr; void* host_dev = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0, w0 = 0; bool busy = false; };   // w0: first window of the group the slot holds
+  struct Slot { void* host = nullptr; void* host_dev = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int W = 0, c = 0, w0 = 0; bool busy = false;
+                bool combined = false; };   // w0: first window of the group the slot holds; combined: ONE point per window (the short-input MSM adds a window's bit planes on the device), otherwise c bit-plane sums per window
   static constexpr int NSLOTS = 24;      // 0 kg_msm, 1..4 kg_msm_begin tickets, 6..10 prover job 0, 11..15 prover job 1, 16..23 slices of kg_msm_host / kg_msm_host_scalars, 16..19 window groups / index slices of kg_msm (blocking calls: never at the same time)
   Slot slots[NSLOTS];
+  void* ws_small[NSLOTS] = {};           // short-input MSM (msm_small.hip): plane points of a window split over several workgroups, per result slot (grow-only)
+  size_t ws_small_bytes[NSLOTS] = {};
   std::shared_ptr<void> prover_jobs;     // groth16.hip: proofs in flight (kg_groth16_prove_begin / _end)
   size_t ticket_n[4] = {0, 0, 0, 0};
   // kg_msm_begin starts the ticket's host finish (wait for the reduction, 255-step double-and-add, inversion) on a worker
@@ -346,6 +349,12 @@ struct MsmRunJob { const uint64_t* d_bases; const uint8_t* d_inf; size_t nbases;
 int msm_run_multi(kg_ctx* ctx, const MsmSorted& S, int curve, const MsmRunJob* jobs, int njobs);
 int msm_run(kg_ctx* ctx, const MsmSorted& S, int curve, const uint64_t* d_bases, const uint8_t* d_inf, size_t nbases, uint32_t idx_off, int slot);
 int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz);
+// msm_small.hip: the short-input MSM (one or two launches, no sort, no read-back).  msm_small_plan: does it take an n-pair MSM of this
+// context, and with which window width c and bucket range 2^r per workgroup; msm_small_enqueue: the launches on queue st, the window
+// sums into the slot (msm_finish is the host half, as for the long pipeline)
+bool msm_small_plan(const kg_ctx* ctx, int curve, size_t n, int* c, int* r);
+int msm_small_enqueue(kg_ctx* ctx, hipStream_t st, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, int slot,
+                      int c, int r);
 // the same over the slots of an MSM's window groups, top group first: one double-and-add chain, each slot awaited when the
 // chain reaches its windows
 int msm_finish_groups(kg_ctx* ctx, int curve, const int* slots, int nslots, uint64_t* out_xyz);

@@ -78,6 +78,12 @@ int msm_finish_t(kg_ctx* ctx, const int* slots, int nslots, uint64_t* out_xyz) {
     const auto t0 = std::chrono::steady_clock::now();
     const uint64_t* hp = (const uint64_t*)sl.host;
     const int W = sl.W, c = sl.c, w0 = sl.w0;
+    if (sl.combined) {                                     // one point per window (msm_small.hip): 2^c * acc + S_w
+      for (int w = W - 1; w >= 0; --w) {
+        for (int l = 0; l < c; ++l) acc = double_xyzz(acc);
+        acc = add_xyzz(acc, host_load_point<Cfg>(hp + (size_t)w * PE));
+      }
+    } else
     for (int bit = (w0 + W) * c - 1; bit >= w0 * c; --bit) {
       acc = double_xyzz(acc);
       const int w = bit / c - w0, l = bit % c;
@@ -292,6 +298,11 @@ int kg_msm(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf
 
 // one blocking MSM over device arrays (kg_msm; the unsliced kg_msm_host_scalars behind its upload)
 static int msm_blocking(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t* out_xyz) {
+  int sc = 0, sr = 0;
+  if (kg::msm_small_plan(ctx, curve, n, &sc, &sr)) {      // short inputs: one launch on the main queue (stream-ordered behind the inputs' producer), then the host chain
+    KG_TRY(kg::msm_small_enqueue(ctx, ctx->stream, curve, d_bases, d_inf, d_scalars, n, 0, sc, sr));
+    return kg::msm_finish(ctx, curve, 0, out_xyz);
+  }
   const bool sliced_ok = ctx->tune.msm_sliced != 0;     // 0 (experiments): window groups instead of index slices
   if (n >= ((size_t)1 << 23) && sliced_ok && pick_window(n, ctx->msm_window) < 19) return msm_sliced(ctx, curve, d_bases, d_inf, d_scalars, n, out_xyz);   // measured: 2^24 25.8 -> 23.0 ms, 2^23 13.1 -> 12.1; below that the slices' own tails cost more than the hidden sort
   kg::MsmSorted S;
@@ -396,6 +407,14 @@ int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t*
   if (!ctx || (n && (!d_bases || !d_scalars)) || curve < 0 || curve > KG_G2 || ticket < 0 || ticket > 3) return KG_ERR_BAD_ARG;
   ctx->ticket_n[ticket] = n;
   if (n == 0) return KG_OK;
+  int sc = 0, sr = 0;
+  if (kg::msm_small_plan(ctx, curve, n, &sc, &sr)) {      // short inputs: one launch, the host chain on a worker thread
+    if (ctx->ticket_fut[ticket].valid()) ctx->ticket_fut[ticket].wait();
+    KG_TRY(kg::msm_small_enqueue(ctx, ctx->stream, curve, d_bases, d_inf, d_scalars, n, 1 + ticket, sc, sr));
+    uint64_t* out = ctx->ticket_out[ticket];
+    ctx->ticket_fut[ticket] = std::async(std::launch::async, [ctx, curve, ticket, out] { return kg::msm_finish(ctx, curve, 1 + ticket, out); });
+    return KG_OK;
+  }
   kg::MsmSorted S;
   const int mc = kg::has_window_table(ctx, curve, d_bases, d_inf, n, n) ? kg::merged_window(ctx, n) : 0;
   KG_TRY(kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S, false, mc));
@@ -506,6 +525,17 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
   const char* d_b = bases_on_device ? (const char*)bases : (const char*)ctx->up_buf[0];
   uint64_t* d_s = (uint64_t*)ctx->up_buf[1];
   const uint8_t* d_i = bases_on_device ? inf : (inf ? (const uint8_t*)ctx->up_buf[2] : nullptr);
+  int sc = 0, sr = 0;
+  if (kg::msm_small_plan(ctx, curve, n, &sc, &sr)) {
+    // short inputs: the arrays go up on the main queue (a few KB: the copies are staged and return at once), the one-launch MSM behind them
+    KG_HIP(ctx, hipMemcpyAsync(d_s, h_scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (!bases_on_device) {
+      KG_HIP(ctx, hipMemcpyAsync(ctx->up_buf[0], bases, n * pb, hipMemcpyHostToDevice, ctx->stream));
+      if (inf) KG_HIP(ctx, hipMemcpyAsync(ctx->up_buf[2], inf, n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    KG_TRY(kg::msm_small_enqueue(ctx, ctx->stream, curve, (const uint64_t*)d_b, d_i, d_s, n, 0, sc, sr));
+    return kg::msm_finish(ctx, curve, 0, out_xyz);
+  }
   size_t lo[kg_ctx::UP_SLICES + 1];
   const int K = msm_host_plan(ctx->tune, n, bases_on_device, lo);
   // the previous call's readers of the cached buffers are done (every call joins its slices before it returns)

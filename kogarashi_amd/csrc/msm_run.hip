@@ -253,7 +253,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
     }
     KG_HIP(ctx, hipGetLastError());
     KG_HIP(ctx, hipEventRecord(sl.done, side));
-    sl.W = W; sl.c = c; sl.w0 = S.w0; sl.busy = true;
+    sl.W = W; sl.c = c; sl.w0 = S.w0; sl.busy = true; sl.combined = false;
   }
   host_trace("run: enqueued");
   return KG_OK;

@@ -1,0 +1,93 @@
+// msm_small.hip -- enqueue of the short-input MSM (msm_small_kernels.h): the plan (window width and bucket ranges by length) and the one or
+// two launches that leave the W window sums in the result slot's pinned buffer.  Replaces, for n <= 2^12 pairs, the launch chain of
+// msm_sort.hip + msm_run.hip behind kg_msm / kg_msm_begin / kg_commit / the prover (groth16/src/msm.rs:6-48 at the lengths of its own tests).
+#include "msm_small_kernels.h"
+
+using namespace kg;
+using namespace kg::msm;
+
+namespace kg {
+
+// Does the short-input path take an n-pair MSM, and with which shape?  c: window width; r: log2 of the buckets a workgroup owns
+// (2^(c-1-r) workgroups per window).  A forced window (kg_msm_set_window) keeps the long pipeline: the parity tests walk its widths.
+bool msm_small_plan(const kg_ctx* ctx, int curve, size_t n, int* c_out, int* r_out) {
+  const kg_tuning& tn = ctx ? ctx->tune : tuning();
+  if (tn.small_max <= 0 || n == 0 || n > (size_t)tn.small_max || n > SM_MAX_N) return false;
+  if (ctx && ctx->msm_window) return false;
+  // Measured on MI355X (profiles/r06_small_shapes.txt; blocking kg_msm, ms): the halving and the combine are c - 1 dependent additions /
+  // doublings each, the accumulation n / 2^(c-1) per bucket: short windows for short inputs; from 2^11 pairs a window's buckets are
+  // spread over several workgroups (their CUs are idle otherwise)
+  int c, r;
+  if (n <= 48) { c = 4; r = 3; }
+  else if (n <= 192) { c = 5; r = 4; }
+  else if (n <= 640) { c = 6; r = 5; }
+  else if (n <= 1280) { c = 7; r = 6; }
+  else if (n <= 2560) { c = 8; r = 5; }
+  else { c = 9; r = 5; }
+  if (tn.small_c >= 2 && tn.small_c <= 10) { c = tn.small_c; r = c - 1 < SM_MAX_R ? c - 1 : SM_MAX_R; }
+  if (tn.small_r >= 0 && tn.small_r <= SM_MAX_R) r = tn.small_r;
+  if (r > c - 1) r = c - 1;
+  if (c - 1 - r > 5) r = c - 1 - 5;                  // at most 32 workgroups per window
+  if (r > SM_MAX_R) return false;
+  const size_t lds = curve == KG_G2 ? small_lds_bytes<Fq2>((uint32_t)n, r) : small_lds_bytes<Fq>((uint32_t)n, r);
+  if (lds > 160 * 1024) return false;
+  *c_out = c; *r_out = r;
+  return true;
+}
+
+template <class F, class SP>
+static int small_launch(kg_ctx* ctx, hipStream_t st, const SmallArgs& a, size_t lds, size_t lds2) {
+  static bool attr_set = false;                       // once per process and instance: the kernels may use the whole 160 KiB
+  if (!attr_set) {
+    KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_msm_small<F, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_msm_small_combine<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_msm_small<F, SP>), dim3((unsigned)a.W, (unsigned)a.NB), dim3(SM_NT), lds, st, a);
+  if (a.NB > 1) hipLaunchKernelGGL((k_msm_small_combine<F>), dim3((unsigned)a.W), dim3(SM_NT), lds2, st, a);
+  KG_HIP(ctx, hipGetLastError());
+  return KG_OK;
+}
+
+// The whole MSM on queue `st` (ordered behind whatever produced the inputs there); the W window sums land in the slot's pinned buffer
+// and the slot's event is recorded -- msm_finish(ctx, curve, slot, out) is the host half, as for the long pipeline.
+int msm_small_enqueue(kg_ctx* ctx, hipStream_t st, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, int slot,
+                      int c, int r) {
+  if (slot < 0 || slot >= kg_ctx::NSLOTS) return set_err(ctx, KG_ERR_BAD_ARG, "bad result slot");
+  KG_HIP(ctx, hipSetDevice(ctx->device));
+  const int W = (255 + c - 1) / c, NB = 1 << (c - 1 - r), E64 = curve == KG_G2 ? 8 : 4;
+  const int NW = curve == KG_G2 ? PointIO<Fq2>::NW : PointIO<Fq>::NW;
+  KG_TRY(ensure_slot(ctx, slot, (size_t)W * 4 * E64 * 8));
+  kg_ctx::Slot& sl = ctx->slots[slot];
+  SmallArgs a;
+  a.bases = d_bases; a.inf = d_inf; a.scalars = d_scalars; a.n = (uint32_t)n; a.c = c; a.W = W; a.r = r; a.NB = NB;
+  uint32_t H[8];
+  small_bias(c, W, H);
+  for (int j = 0; j < 8; ++j) a.H.w[j] = H[j];
+  a.out = (uint64_t*)sl.host_dev;
+  a.planes = nullptr;
+  size_t lds2 = 0;
+  if (NB > 1) {
+    const size_t bytes = (size_t)W * NB * (SM_MAX_R + 1) * NW * 4;
+    if (bytes > ctx->ws_small_bytes[slot]) {
+      if (ctx->ws_small[slot]) { sync_all(ctx); (void)hipFree(ctx->ws_small[slot]); ctx->ws_small[slot] = nullptr; ctx->ws_small_bytes[slot] = 0; }
+      const hipError_t e = dev_alloc(ctx, &ctx->ws_small[slot], bytes);
+      if (e != hipSuccess) return set_err(ctx, KG_ERR_OOM, "short-input plane buffer", e);
+      ctx->ws_small_bytes[slot] = bytes;
+    }
+    a.planes = (uint32_t*)ctx->ws_small[slot];
+    lds2 = curve == KG_G2 ? small_combine_lds_bytes<Fq2>(c, NB) : small_combine_lds_bytes<Fq>(c, NB);
+  }
+  PhaseScope ph(ctx, "small_msm", st);
+  int rc;
+  if (curve == KG_G1) rc = small_launch<Fq, FrParams>(ctx, st, a, small_lds_bytes<Fq>(a.n, r), lds2);
+  else if (curve == KG_GRUMPKIN) rc = small_launch<Fr, FqParams>(ctx, st, a, small_lds_bytes<Fr>(a.n, r), lds2);
+  else rc = small_launch<Fq2, FrParams>(ctx, st, a, small_lds_bytes<Fq2>(a.n, r), lds2);
+  ph.end();
+  KG_TRY(rc);
+  KG_HIP(ctx, hipEventRecord(sl.done, st));
+  sl.W = W; sl.c = c; sl.w0 = 0; sl.combined = true; sl.busy = false;
+  return KG_OK;
+}
+
+}  // namespace kg

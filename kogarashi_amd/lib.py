@@ -26,6 +26,7 @@ EXPORTS = [
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
     "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_r1cs_begin", "kg_groth16_prove_sharded", "kg_ntt_plan",
     "kg_msm_host_scalars", "kg_commit_host_scalars", "kg_tuning_describe", "kg_mem_info", "kg_groth16_setup_bn254", "kg_experiments_built", "kg_msm_host_slices",
+    "kg_msm_set_small",
 ]
 
 
@@ -324,6 +325,11 @@ class Context:
     def set_msm_groups(self, groups: int):
         """window groups of a blocking MSM: 0 automatic, 1 none, 2..4 (kg_msm_set_groups)"""
         self._chk(self._lib.kg_msm_set_groups(self._h, int(groups)), "kg_msm_set_groups")
+
+    def set_msm_small(self, max_pairs: int = -2, c: int = 0, r: int = -1):
+        """the short-input MSM (kg_msm_set_small): longest MSM it takes (-2: keep, 0: never), window width (0: by length), log2 of the
+        buckets per workgroup (-1: by length)"""
+        self._chk(self._lib.kg_msm_set_small(self._h, int(max_pairs), int(c), int(r)), "kg_msm_set_small")
 
     def gen_scalars(self, field: int, seed: int, start: int, n: int, out: int):
         self._chk(self._lib.kg_gen_scalars(self._h, field, C.c_uint64(seed), C.c_size_t(start), C.c_size_t(n), _vp(out)), "kg_gen_scalars")

@@ -8,6 +8,7 @@
 #include "../../kogarashi_amd/csrc/curve.h"
 #include "../../kogarashi_amd/csrc/ntt_core.h"
 #include "../../kogarashi_amd/csrc/vecops.h"
+#include "../../kogarashi_amd/csrc/msm_digits.h"
 
 using namespace kg;
 
@@ -155,6 +156,25 @@ static int curve_sum(int mode, const uint32_t* pts, const uint8_t* inf, size_t n
       MemPt<F> P{&acc}, Q{&q}, O{&acc};
       add_xyzz_stream<F>(P, Q, O);
     }
+  } else if (mode == 11) {
+    // the short-input kernel's shape (msm_small_kernels.h): task sums by add_mixed_signed (X not value-reduced), plane i = task sum i
+    // doubled i times as it is (a plane of a two-bucket range is a COPY of a task sum), the planes added by an add_xyzz tree:
+    // sum_i 2^i (P_{2i} - P_{2i+1})
+    std::vector<XYZZ<F>> v;
+    for (size_t i = 0; i + 1 < n; i += 2) {
+      XYZZ<F> part = XYZZ<F>::identity();
+      if (!(inf && inf[i])) part = add_mixed_signed(part, ld_aff<F>(pts + W2 * i), false);
+      if (!(inf && inf[i + 1])) part = add_mixed_signed(part, ld_aff<F>(pts + W2 * (i + 1)), true);
+      for (size_t k = 0; k < i / 2; ++k) part = double_xyzz(part);
+      v.push_back(part);
+    }
+    while (v.size() > 1) {
+      std::vector<XYZZ<F>> w;
+      for (size_t i = 0; i + 1 < v.size(); i += 2) w.push_back(add_xyzz(v[i], v[i + 1]));
+      if (v.size() & 1) w.push_back(v.back());
+      v.swap(w);
+    }
+    if (!v.empty()) acc = v[0];
   } else if (mode == 10) {                                  // and the doubling on its own, in place
     acc = from_affine(ld_aff<F>(pts));
     for (size_t i = 0; i < n; ++i) { MemPt<F> P{&acc}, O{&acc}; double_xyzz_stream<F>(P, O); }
@@ -166,6 +186,24 @@ extern "C" int ht_curve_sum(int curve, int checked, int mode, const uint32_t* pt
   if (curve == 0) return checked ? curve_sum<FqC>(mode, pts, inf, n, out_xy) : curve_sum<Fq>(mode, pts, inf, n, out_xy);
   if (curve == 1) return checked ? curve_sum<FrC>(mode, pts, inf, n, out_xy) : curve_sum<Fr>(mode, pts, inf, n, out_xy);
   return checked ? curve_sum<Fq2C>(mode, pts, inf, n, out_xy) : curve_sum<Fq2>(mode, pts, inf, n, out_xy);
+}
+
+// signed window digits of canonical integers k (msm_digits.h): digits[i * 128 + w], w < W = ceil(255 / c) <= 128; returns W
+extern "C" int ht_small_digits(const uint32_t* k, size_t n, int c, int32_t* digits) {
+  const int W = (255 + c - 1) / c;
+  uint32_t H[8];
+  small_bias(c, W, H);
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t kb[8];
+    uint64_t cy = 0;
+    for (int j = 0; j < 8; ++j) { const uint64_t s_ = (uint64_t)k[8 * i + j] + H[j] + cy; kb[j] = (uint32_t)s_; cy = s_ >> 32; }
+    for (int w = 0; w < W; ++w) {
+      bool neg;
+      const uint32_t m = small_window_digit(kb, w, c, W, neg);
+      digits[i * 128 + w] = neg ? -(int32_t)m : (int32_t)m;
+    }
+  }
+  return W;
 }
 
 // ---- NTT butterfly network (ntt_core.h) ---------------------------------------------------------------

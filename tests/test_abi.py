@@ -23,7 +23,7 @@ def test_header_symbols_are_exported(lib):
     missing = [s for s in declared if not hasattr(so, s)]
     assert not missing, missing
     assert sorted(lib.EXPORTS) == declared
-    assert so.kg_version() == 5
+    assert so.kg_version() == 6
     assert so.kg_strerror(-1) == b"no HIP device"
 
 

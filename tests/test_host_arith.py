@@ -121,6 +121,23 @@ def _check_point_formulas(hostlib, pyoracle, name):
                     assert curve_sum(hostlib, cid, cur, chk, mode, pts, inf) == exp, (name, ci, some_inf, chk, mode)
                 assert curve_sum(hostlib, cid, cur, chk, 5, pts, inf) == cur.neg(exp)
                 assert curve_sum(hostlib, cid, cur, chk, 3, pts, inf) == cur.add(exp, exp), (name, ci, "dbl")
+    # mode 11: the short-input kernel's shape (msm_small_kernels.h) -- task sums by add_mixed_signed whose X is not value-reduced, doubled as
+    # they are (a plane of a two-bucket range is a copy of a task sum), the planes added by a tree: sum_i 2^i (P_2i - P_2i+1)
+    for pts in (base[:2], base[:4], (base + base)[:10], [A, A, B, cur.neg(B)], [A, cur.neg(A), B, B]):
+        for some_inf in (False, True):
+            inf = [0] * len(pts)
+            if some_inf:
+                inf[1] = 1
+            exp = None
+            for i in range(0, len(pts) - 1, 2):
+                t = None
+                if not inf[i]:
+                    t = cur.add(t, pts[i])
+                if not inf[i + 1]:
+                    t = cur.add(t, cur.neg(pts[i + 1]))
+                exp = cur.add(exp, cur.mul(t, 1 << (i // 2)) if t is not None else None)
+            for chk in (0, 1):
+                assert curve_sum(hostlib, cid, cur, chk, 11, pts, inf) == exp, (name, "small", len(pts), some_inf, chk)
     for chk in (0, 1):
         assert curve_sum(hostlib, cid, cur, chk, 4, [A] * 5, [0] * 5) == cur.mul(A, 32)
         assert curve_sum(hostlib, cid, cur, chk, 10, [A] * 5, [0] * 5) == cur.mul(A, 32)       # double_xyzz_stream in place
@@ -182,3 +199,24 @@ def test_cross_term_row_bounds_and_values(hostlib, oracle, fd):
             a32 = lambda x: p32(np.ascontiguousarray(x).view(np.uint32))
             hostlib.ht_cross_term(fd, chk, a32(va), a32(vb), a32(vc), a32(z1), a32(z2), C.c_size_t(cnt), a32(u1), a32(u2), p32(out.view(np.uint32)))
             assert (out == want).all(), (fd, cnt, chk)
+
+
+@pytest.mark.parametrize("c", range(2, 17))
+def test_signed_window_digits_recompose_the_scalar(hostlib, c):
+    """msm_digits.h (the short-input MSM's digit rule, the same as the long pipeline's window_digit): for every width c the signed digits of
+    k + H recompose k, every |digit| is a bucket number <= 2^(c-1), and the top window is unsigned -- on random canonical scalars of both
+    fields and the edge values 0, 1, p - 1, 2^(c-1) boundaries."""
+    rnd = random.Random(100 + c)
+    r_mod = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    q_mod = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+    ks = [0, 1, 2, r_mod - 1, q_mod - 1, (1 << (c - 1)), (1 << (c - 1)) - 1, (1 << c) - 1, (1 << 253) + 12345, (1 << 254) - 1]
+    ks += [rnd.randrange(r_mod) for _ in range(200)] + [rnd.randrange(q_mod) for _ in range(100)]
+    ks += [sum(((1 << (c - 1)) - (j & 1)) << (j * c) for j in range(254 // c)) % q_mod]            # digits at the sign boundary in every window
+    arr = np.array([[(k >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for k in ks], dtype=np.uint32)
+    dig = np.zeros((len(ks), 128), dtype=np.int32)
+    hostlib.ht_small_digits.restype = C.c_int
+    W = hostlib.ht_small_digits(p32(arr), C.c_size_t(len(ks)), c, dig.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert W == (255 + c - 1) // c
+    for k, row in zip(ks, dig):
+        assert sum(int(row[w]) << (w * c) for w in range(W)) == k
+        assert all(abs(int(row[w])) <= 1 << (c - 1) for w in range(W)) and row[W - 1] >= 0
