@@ -2,6 +2,8 @@
 // two launches that leave the W window sums in the result slot's pinned buffer.  Replaces, for n <= 2^12 pairs, the launch chain of
 // msm_sort.hip + msm_run.hip behind kg_msm / kg_msm_begin / kg_commit / the prover (groth16/src/msm.rs:6-48 at the lengths of its own tests).
 #include "msm_small_kernels.h"
+#include <cstdlib>
+#include <cstring>
 
 using namespace kg;
 using namespace kg::msm;
@@ -14,23 +16,30 @@ bool msm_small_plan(const kg_ctx* ctx, int curve, size_t n, int* c_out, int* r_o
   const kg_tuning& tn = ctx ? ctx->tune : tuning();
   if (tn.small_max <= 0 || n == 0 || n > (size_t)tn.small_max || n > SM_MAX_N) return false;
   if (ctx && ctx->msm_window) return false;
-  // Measured on MI355X (profiles/r06_small_shapes.txt; blocking kg_msm, ms): the halving and the combine are c - 1 dependent additions /
-  // doublings each, the accumulation n / 2^(c-1) per bucket: short windows for short inputs; from 2^11 pairs a window's buckets are
-  // spread over several workgroups (their CUs are idle otherwise)
+  // Measured on MI355X (profiles/r06_small_shapes*.txt: blocking kg_msm over every width and range).  With the tree levels run by lane quads
+  // (coop_add.h: ~4.5 us per level) the widths 2 .. 5 are within a few per cent of each other at every length: a narrow window is a short
+  // reduction on the device and more additions on the host (255 doublings + one addition per window).  Up to 1536 pairs the two-bit
+  // window -- 128 workgroups of two buckets, ONE launch; beyond, a window's sixteen buckets go to four or eight workgroups (their CUs
+  // are idle otherwise) and a second launch adds the ranges' planes.  G2 (three times the arithmetic per addition on the device, the
+  // host chain in Fq2): wider windows pay earlier.
   int c, r;
-  if (n <= 48) { c = 4; r = 3; }
-  else if (n <= 192) { c = 5; r = 4; }
-  else if (n <= 640) { c = 6; r = 5; }
-  else if (n <= 1280) { c = 7; r = 6; }
-  else if (n <= 2560) { c = 8; r = 5; }
-  else { c = 9; r = 5; }
+  if (curve == KG_G2) {
+    if (n <= 32) { c = 3; r = 2; }
+    else if (n <= 384) { c = 4; r = 3; }
+    else { c = 5; r = 2; }
+  } else {
+    if (n <= 1536) { c = 2; r = 1; }
+    else if (n <= 3072 || n > 6144) { c = 5; r = 2; }
+    else { c = 5; r = 1; }
+  }
   if (tn.small_c >= 2 && tn.small_c <= 10) { c = tn.small_c; r = c - 1 < SM_MAX_R ? c - 1 : SM_MAX_R; }
   if (tn.small_r >= 0 && tn.small_r <= SM_MAX_R) r = tn.small_r;
   if (r > c - 1) r = c - 1;
   if (c - 1 - r > 5) r = c - 1 - 5;                  // at most 32 workgroups per window
   if (r > SM_MAX_R) return false;
-  const size_t lds = curve == KG_G2 ? small_lds_bytes<Fq2>((uint32_t)n, r) : small_lds_bytes<Fq>((uint32_t)n, r);
-  if (lds > 160 * 1024) return false;
+  auto lds = [&](int rr) { return curve == KG_G2 ? small_lds_bytes<Fq2>((uint32_t)n, rr) : small_lds_bytes<Fq>((uint32_t)n, rr); };
+  while (r > 0 && lds(r) > 160 * 1024) --r;          // G2 points are twice the words: smaller bucket ranges, more workgroups per window
+  if (lds(r) > 160 * 1024 || c - 1 - r > 5) return false;
   *c_out = c; *r_out = r;
   return true;
 }
@@ -66,6 +75,21 @@ int msm_small_enqueue(kg_ctx* ctx, hipStream_t st, int curve, const uint64_t* d_
   for (int j = 0; j < 8; ++j) a.H.w[j] = H[j];
   a.out = (uint64_t*)sl.host_dev;
   a.planes = nullptr;
+#ifdef KG_EXPERIMENTS
+  static uint64_t* stamps = nullptr;                  // KG_SMALL_STAMPS=1: the previous call's phase boundaries (workgroup (0, 0)) on stderr
+  static const bool want_stamps = getenv("KG_SMALL_STAMPS") != nullptr;
+  a.stamps = nullptr;
+  if (want_stamps) {
+    if (!stamps) { if (hipHostMalloc((void**)&stamps, 64 * 8, hipHostMallocDefault) != hipSuccess) stamps = nullptr; else memset(stamps, 0, 64 * 8); }
+    if (stamps && stamps[7]) {
+      fprintf(stderr, "[small] digits %.1f  scan+scatter %.1f  accumulate %.1f  merge %.1f  halve %.1f  (planes) %.1f  combine %.1f  export %.1f us\n",
+              (stamps[1] - stamps[0]) * 0.01, (stamps[2] - stamps[1]) * 0.01, (stamps[3] - stamps[2]) * 0.01, (stamps[4] - stamps[3]) * 0.01,
+              (stamps[5] - stamps[4]) * 0.01, 0.0, (stamps[6] - stamps[5]) * 0.01, (stamps[7] - stamps[6]) * 0.01);
+      memset(stamps, 0, 64 * 8);
+    }
+    a.stamps = stamps;
+  }
+#endif
   size_t lds2 = 0;
   if (NB > 1) {
     const size_t bytes = (size_t)W * NB * (SM_MAX_R + 1) * NW * 4;

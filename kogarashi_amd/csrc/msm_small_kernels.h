@@ -26,6 +26,7 @@
 #pragma once
 #include "msm_acc_kernels.h"
 #include "msm_digits.h"
+#include "coop_add.h"
 
 namespace kg {
 namespace msm {
@@ -46,7 +47,15 @@ struct SmallArgs {
   Words8 H;                   // digit bias (msm_digits.h)
   uint64_t* out;              // NB == 1: W window sums, 4 * E64 words each (x | y | zz | zzz, ABI form) -- the slot's pinned buffer
   uint32_t* planes;           // NB > 1: [W][NB][r + 1] plane points, raw internal form, NW words each
+#ifdef KG_EXPERIMENTS
+  uint64_t* stamps;           // KG_SMALL_STAMPS=1 (A/B builds): wall-clock ticks (10 ns) of workgroup (0, 0) at its phase boundaries
+#endif
 };
+#ifdef KG_EXPERIMENTS
+#define KG_SM_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.stamps[k] = wall_clock64(); } while (0)
+#else
+#define KG_SM_STAMP(k) ((void)0)
+#endif
 
 template <class F> struct SmIO;
 template <class P> struct SmIO<Fp<P>> {
@@ -93,56 +102,59 @@ __device__ __forceinline__ void sm_export(const XYZZ<F>& p, uint64_t* dst) {
   sm_export_el(p.x, dst); sm_export_el(p.y, dst + E); sm_export_el(p.zz, dst + 2 * E); sm_export_el(p.zzz, dst + 3 * E);
 }
 
+// LDS words of the cooperative additions' temporaries and flags (coop_add.h) for a 256-thread workgroup
+template <class F> constexpr uint32_t sm_coop_words() { return COOP_TMP_SLOTS * CoopEl<F>::E * (SM_NT / 4) + SM_NT / 4; }
+constexpr int SM_CLASSES = 9;          // a bucket owns 2^k task slots, k = 0 .. 8
+
 // LDS bytes of k_msm_small for n scalars and 2^r buckets per workgroup
 template <class F>
 static size_t small_lds_bytes(uint32_t n, int r) {
-  const size_t R = (size_t)1 << r, cap = SM_TASKS + R;
+  const size_t R = (size_t)1 << r, cap = SM_TASKS + R + 1;
   const size_t n_pad = (n + 1) & ~(size_t)1;
-  return ((size_t)PointIO<F>::NW * cap + R + 2 * (R + 1) + 48) * 4 + (SM_TASKS + 2 * n_pad) * 2 + 64;
+  return ((size_t)PointIO<F>::NW * cap + sm_coop_words<F>() + 4 * R + 2 + 80) * 4 + (SM_TASKS + 2 * n_pad) * 2 + 64;
 }
 
-// S = P_0 + sum_{l >= 0} 2^l P_{1 + l} over `np` plane points held as items 0 .. np-1 of an LDS image (structure of arrays, stride cap):
-// lane 1 + l doubles its plane l times, then a tree over the np lanes; the sum ends in item 0.  All lanes of the workgroup call it.
+// S = P_0 + sum_{l >= 0} 2^l P_{1 + l} over `np` plane points held as items 0 .. np-1 of an LDS image: quad 1 + l doubles its plane l
+// times (cooperative doubling: three steps each), then a tree of cooperative additions over the planes; the sum ends in item 0.  All
+// threads of the workgroup call it.
 template <class F>
-__device__ __forceinline__ void sm_combine_planes(uint32_t* img, uint32_t cap, uint32_t np) {
-  const uint32_t t = threadIdx.x;
-  if (t >= 2 && t < np) {
-    XYZZ<F> p = PointIO<F>::load(img, cap, t);
-    for (uint32_t k = 1; k < t; ++k) p = double_xyzz(p);
-    PointIO<F>::store(img, cap, t, p);
-  }
+__device__ __forceinline__ void sm_combine_planes(uint32_t* img, uint32_t cap, uint32_t* tmp, uint32_t* flg, uint32_t np) {
+  const uint32_t qd = threadIdx.x >> 2;
+  coop_dbl_level<F>(img, cap, tmp, flg, qd < np ? qd : 0u, (qd >= 2 && qd < np) ? qd - 1 : 0u, np > 2 ? np - 2 : 0u);
   for (uint32_t s = 1; s < np; s <<= 1) {
-    __syncthreads();
-    if ((t & (2 * s - 1)) == 0 && t + s < np) {
-      const XYZZ<F> p = PointIO<F>::load(img, cap, t), q = PointIO<F>::load(img, cap, t + s);
-      PointIO<F>::store(img, cap, t, add_xyzz(p, q));
-    }
+    const uint32_t t = qd * 2 * s;
+    const bool on = t + s < np;
+    coop_add_level<F>(img, cap, tmp, flg, on, on ? t : 0u, on ? t + s : 0u, on ? t : 0u);
   }
-  __syncthreads();
 }
 
 template <class F, class SP>
 __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
   extern __shared__ uint32_t lds[];
   constexpr int NW = PointIO<F>::NW;
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, qd = tid >> 2;
   const int c = a.c, W = a.W, r = a.r;
   const uint32_t R = 1u << r;
   const uint32_t w = blockIdx.x, jb = blockIdx.y, b0 = jb << r;
   const uint32_t n = a.n, n_pad = (n + 1u) & ~1u;
-  const uint32_t CAP = SM_TASKS + R;
-  uint32_t* const pts = lds;                                // NW planes x CAP items: items [0, SM_TASKS) task partial sums / image Y, [SM_TASKS, CAP) image X
-  uint32_t* const hist = pts + (size_t)NW * CAP;            // R: entries per bucket, then the scatter cursors
+  const uint32_t CAP = SM_TASKS + R + 1, IDENT = SM_TASKS + R;      // the last item stays the identity (an empty bucket's sum)
+  uint32_t* const pts = lds;                                // NW planes x CAP items: items [0, SM_TASKS) task sums / image Y, [SM_TASKS, SM_TASKS + R) image X
+  uint32_t* const ctmp = pts + (size_t)NW * CAP;            // temporaries of the cooperative additions
+  uint32_t* const cflg = ctmp + COOP_TMP_SLOTS * CoopEl<F>::E * (SM_NT / 4);
+  uint32_t* const hist = cflg + SM_NT / 4;                  // R: entries per bucket, then the scatter cursors
   uint32_t* const boff = hist + R;                          // R + 1: first list position of each bucket
-  uint32_t* const tfirst = boff + R + 1;                    // R + 1: first task of each bucket
-  uint32_t* const misc = tfirst + R + 1;                    // 48: scan scratch [0, 40), most tasks of a bucket [40]
-  uint16_t* const task_b = reinterpret_cast<uint16_t*>(misc + 48);    // SM_TASKS: bucket of each task
+  uint32_t* const tfirst = boff + R + 1;                    // R: first task slot of each bucket (IDENT for an empty one)
+  uint32_t* const tsize = tfirst + R;                       // R + 1: task slots of each bucket (0 or a power of two)
+  uint32_t* const misc = tsize + R + 1;                     // 80: scan scratch [0, 40), slot classes: count [40, 49), base [50, 60)
+  uint16_t* const task_b = reinterpret_cast<uint16_t*>(misc + 80);    // SM_TASKS: bucket of each task slot
   uint16_t* const dig = task_b + SM_TASKS;                  // n: (bucket - b0) | sign << 15, or SM_SKIP
   uint16_t* const sorted = dig + n_pad;                     // n: (index | sign << 15) ordered by bucket
 
+  KG_SM_STAMP(0);
   // ---- digits of this window; histogram of the workgroup's bucket range
   for (uint32_t t = tid; t < R; t += SM_NT) hist[t] = 0;
-  if (tid == 0) misc[40] = 0;
+  if (tid < 20) misc[40 + tid] = 0;
+  for (uint32_t k = tid; k < (uint32_t)NW; k += SM_NT) pts[(size_t)k * CAP + IDENT] = 0u;
   __syncthreads();
   for (uint32_t i = tid; i < n; i += SM_NT) {
     uint32_t sw[8], k[8];
@@ -166,24 +178,37 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
     dig[i] = (uint16_t)code;
   }
   __syncthreads();
-  // ---- bucket offsets, task length, tasks per bucket
+  KG_SM_STAMP(1);
+  // ---- bucket offsets; task slots.  A bucket of cnt entries is cut into 2^k tasks (the least power of two of ceil(cnt / T)), and the
+  // buckets take their slots in DESCENDING order of k: every bucket's first slot is then a multiple of its size, and the buckets with at
+  // least 2s slots are a prefix [0, P_s) of the slot space -- level s of the merge tree is the regular pair list (t, t + s), t = 0, 2s, 4s ..
+  // below P_s, without a table.  T = 2 total / (slots - R) keeps the slot count within SM_TASKS (2^k < 2 cnt / T for k >= 1).
   const uint32_t cnt = tid < R ? hist[tid] : 0u;
   uint32_t total = 0;
   const uint32_t off = block_exclusive_scan_1024(cnt, misc, total);
-  __syncthreads();                                          // the scan scratch is reused below
-  uint32_t T = (total + (SM_TASKS - R) - 1) / (SM_TASKS - R);
+  uint32_t T = (2 * total + (SM_TASKS - R) - 1) / (SM_TASKS - R);
   if (T < 1) T = 1;
-  const uint32_t tc = (cnt + T - 1) / T;
-  uint32_t ntasks = 0;
-  const uint32_t tf = block_exclusive_scan_1024(tc, misc, ntasks);
+  uint32_t kcls = 0;
+  while (((cnt + T - 1) / T) > (1u << kcls)) ++kcls;        // ceil(cnt / T) <= 2^kcls
+  uint32_t rank = 0;
+  if (tid < R && cnt) rank = atomicAdd(&misc[40 + kcls], 1u);
+  __syncthreads();
+  if (tid == 0) {                                           // class bases: slots of all larger classes; misc[50 + j] = P for level s = 2^j
+    uint32_t run = 0;
+    for (int k = SM_CLASSES - 1; k >= 0; --k) { misc[50 + k] = run; run += misc[40 + k] << k; }
+    misc[59] = run;                                         // slots in use
+  }
+  __syncthreads();
+  const uint32_t nslots = misc[59];
   if (tid < R) {
+    const uint32_t tf = cnt ? misc[50 + kcls] + (rank << kcls) : IDENT;
     boff[tid] = off;
     hist[tid] = off;                                        // scatter cursor
     tfirst[tid] = tf;
-    for (uint32_t k = 0; k < tc; ++k) task_b[tf + k] = (uint16_t)tid;
-    if (tc > 1) atomicMax(&misc[40], tc);
+    tsize[tid] = cnt ? 1u << kcls : 0u;
+    if (cnt) for (uint32_t k = 0; k < (1u << kcls); ++k) task_b[tf + k] = (uint16_t)tid;
   }
-  if (tid == 0) { boff[R] = total; tfirst[R] = ntasks; }
+  if (tid == 0) boff[R] = total;
   __syncthreads();
   // ---- scatter
   for (uint32_t i = tid; i < n; i += SM_NT) {
@@ -194,69 +219,76 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
     }
   }
   __syncthreads();
-  // ---- accumulate: one lane per task
-  if (tid < ntasks) {
+  KG_SM_STAMP(2);
+  // ---- accumulate: one lane per task slot (slot i of a bucket with 2^k slots takes entries [i * per, (i + 1) * per), per = ceil(cnt / 2^k))
+  if (tid < nslots) {
     const uint32_t b = task_b[tid];
-    const uint32_t lo = boff[b] + (tid - tfirst[b]) * T;
-    uint32_t hi = lo + T;
+    const uint32_t cb = boff[b + 1] - boff[b], per = (cb + tsize[b] - 1) / tsize[b];
+    const uint32_t lo = boff[b] + (tid - tfirst[b]) * per;
+    uint32_t hi = lo + per;
     if (hi > boff[b + 1]) hi = boff[b + 1];
     XYZZ<F> acc = XYZZ<F>::identity();
-    uint32_t e = sorted[lo];
-    typename SmIO<F>::Raw raw = SmIO<F>::fetch(a.bases, e & 0x7fffu);
-    for (uint32_t j = lo; j < hi; ++j) {
-      const bool neg = (e & 0x8000u) != 0;
-      const Affine<F> pt = SmIO<F>::convert(raw);
-      if (j + 1 < hi) {                                     // the next base travels while this addition runs
-        e = sorted[j + 1];
-        raw = SmIO<F>::fetch(a.bases, e & 0x7fffu);
+    if (lo < hi) {
+      uint32_t e = sorted[lo];
+      typename SmIO<F>::Raw raw = SmIO<F>::fetch(a.bases, e & 0x7fffu);
+      for (uint32_t j = lo; j < hi; ++j) {
+        const bool neg = (e & 0x8000u) != 0;
+        const Affine<F> pt = SmIO<F>::convert(raw);
+        if (j + 1 < hi) {                                   // the next base travels while this addition runs
+          e = sorted[j + 1];
+          raw = SmIO<F>::fetch(a.bases, e & 0x7fffu);
+        }
+        acc = add_mixed_signed(acc, pt, neg);
       }
-      acc = add_mixed_signed(acc, pt, neg);
     }
     PointIO<F>::store(pts, CAP, tid, acc);
   }
-  // ---- partial sums of one bucket: tree over its tasks (in place: the writer reads a task nobody writes in that step)
-  const uint32_t max_tc = misc[40];
-  for (uint32_t s = 1; s < max_tc; s <<= 1) {
-    __syncthreads();
-    if (tid < ntasks) {
-      const uint32_t b = task_b[tid], rel = tid - tfirst[b], tcb = tfirst[b + 1] - tfirst[b];
-      if ((rel & (2 * s - 1)) == 0 && rel + s < tcb) {
-        const XYZZ<F> p = PointIO<F>::load(pts, CAP, tid), q = PointIO<F>::load(pts, CAP, tid + s);
-        PointIO<F>::store(pts, CAP, tid, add_xyzz(p, q));
-      }
+  __syncthreads();
+  KG_SM_STAMP(3);
+  // ---- partial sums of one bucket: cooperative additions (coop_add.h: a quad of lanes per addition), level s = 2^j over the slot prefix
+  // misc[50 + j], in place on the left slot, 64 quads per round
+  for (int j = 0; j < SM_CLASSES - 1; ++j) {
+    const uint32_t P = misc[50 + j], s = 1u << j;
+    if (P == 0) break;                                      // no bucket has more than 2^j slots (the prefixes shrink with j)
+    const uint32_t pairs = P >> (j + 1);
+    for (uint32_t base = 0; base < pairs; base += SM_NT / 4) {
+      const uint32_t pi = base + qd;
+      const bool on = pi < pairs;
+      const uint32_t t = on ? pi << (j + 1) : 0u;
+      coop_add_level<F>(pts, CAP, ctmp, cflg, on, t, t + (on ? s : 0u), t);
     }
   }
-  __syncthreads();
-  // ---- halving levels over the R bucket sums (bucket i: the first task of bucket i, or the identity).  Step t reads t arrays of
-  // 2 * (R >> t) items and writes t + 1 arrays of R >> t items: array k at item k * (R >> t), the odd items of array 0 become array t.
-  // Images alternate: odd steps write X (items SM_TASKS ..), even steps write Y (items 0 ..: the task sums are dead after step 1).
+  KG_SM_STAMP(4);
+  // ---- halving levels over the R bucket sums (bucket i: its first slot, or the identity item).  Step t reads t arrays of 2 * (R >> t)
+  // items and writes t + 1 arrays of R >> t items: array k at item k * (R >> t), the odd items of array 0 become array t.  Images
+  // alternate: odd steps write X (items SM_TASKS ..), even steps write Y (items 0 ..: the task sums are dead after step 1).  A quad per
+  // pair; t * (R >> t) <= R / 2 <= 64 pairs: one round.
   for (int t = 1; t <= r; ++t) {
     const uint32_t per = R >> t;
     const bool odd_step = (t & 1) != 0;
     const uint32_t obase = odd_step ? SM_TASKS : 0u, ibase = odd_step ? 0u : SM_TASKS;
-    if (tid < (uint32_t)t * per) {
-      const uint32_t k = tid / per, q = tid % per;
-      XYZZ<F> p0, p1;
-      if (t == 1) {
-        const uint32_t i0 = 2 * q, i1 = 2 * q + 1;
-        p0 = tfirst[i0 + 1] > tfirst[i0] ? PointIO<F>::load(pts, CAP, tfirst[i0]) : XYZZ<F>::identity();
-        p1 = tfirst[i1 + 1] > tfirst[i1] ? PointIO<F>::load(pts, CAP, tfirst[i1]) : XYZZ<F>::identity();
-      } else {
-        p0 = PointIO<F>::load(pts, CAP, ibase + k * 2 * per + 2 * q);
-        p1 = PointIO<F>::load(pts, CAP, ibase + k * 2 * per + 2 * q + 1);
+    const bool on = qd < (uint32_t)t * per;
+    uint32_t i0 = 0, i1 = 0, io = 0;
+    if (on) {
+      const uint32_t k = qd / per, q = qd % per;
+      if (t == 1) { i0 = tfirst[2 * q]; i1 = tfirst[2 * q + 1]; }
+      else { i0 = ibase + k * 2 * per + 2 * q; i1 = i0 + 1; }
+      io = obase + k * per + q;
+      if (k == 0) {                                         // the odd item of array 0 spawns array t: lane j of the quad copies coordinate j
+        const CoopQuad<F> cq{pts, CAP, ctmp, SM_NT / 4, qd, cflg, i1, i1, obase + (uint32_t)t * per + q, (int)(tid & 3u)};
+        cq.st(cq.coord(cq.io, (uint32_t)cq.lane), cq.ld(cq.coord(i1, (uint32_t)cq.lane)));
       }
-      PointIO<F>::store(pts, CAP, obase + k * per + q, add_xyzz(p0, p1));       // (a step reads one image and writes the other: one barrier per step)
-      if (k == 0) PointIO<F>::store(pts, CAP, obase + (uint32_t)t * per + q, p1);
     }
-    __syncthreads();
+    coop_add_level<F>(pts, CAP, ctmp, cflg, on, i0, i1, io);
   }
+  KG_SM_STAMP(5);
   // the r + 1 planes: item 0 = A (all buckets), item 1 + l = T_l (buckets whose local index has bit l set)
   const uint32_t fin = (r & 1) ? SM_TASKS : 0u;
   const uint32_t np = (uint32_t)r + 1u;
   uint32_t* const my_planes = a.planes + (size_t)(w * (uint32_t)a.NB + jb) * (SM_MAX_R + 1) * NW;
   if (r == 0) {                                             // one bucket per workgroup: its sum is the only plane
     if (tid == 0) {
-      const XYZZ<F> p = tfirst[1] > tfirst[0] ? PointIO<F>::load(pts, CAP, tfirst[0]) : XYZZ<F>::identity();
+      const XYZZ<F> p = PointIO<F>::load(pts, CAP, tfirst[0]);
       if (a.NB > 1) PointAoS<F>::store(my_planes, 0, p);
       else sm_export(p, a.out + (size_t)w * 4 * SmIO<F>::E64);
     }
@@ -266,21 +298,25 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
     if (tid < np) PointAoS<F>::store(my_planes + (size_t)tid * NW, 0, PointIO<F>::load(pts, CAP, fin + tid));
     return;
   }
-  sm_combine_planes<F>(pts + fin, CAP, np);
+  sm_combine_planes<F>(pts + fin, CAP, ctmp, cflg, np);
+  KG_SM_STAMP(6);
   if (tid == 0) sm_export(PointIO<F>::load(pts, CAP, fin), a.out + (size_t)w * 4 * SmIO<F>::E64);
+  KG_SM_STAMP(7);
 }
 
 // Second launch of a split window (NB > 1 bucket ranges of 2^r buckets): plane l < r is the sum of the ranges' local planes, plane
 // r + h the sum of the totals A_j of the ranges whose index has bit h set (the high bits of the bucket number), the total the sum of
-// all A_j.  LDS: c planes x NB items; a tree along the ranges, then the combine of the fused kernel.
+// all A_j.  LDS: c planes x NB items; a tree of cooperative additions along the ranges, then the combine of the fused kernel.
 template <class F>
 __global__ void __launch_bounds__(SM_NT) k_msm_small_combine(SmallArgs a) {
   extern __shared__ uint32_t lds[];
   constexpr int NW = PointIO<F>::NW;
-  const uint32_t tid = threadIdx.x, w = blockIdx.x;
+  const uint32_t tid = threadIdx.x, w = blockIdx.x, qd = tid >> 2;
   const int c = a.c, r = a.r;
   const uint32_t NB = (uint32_t)a.NB, np = (uint32_t)c;     // planes of the whole window: total, T_0 .. T_{c-2}
   const uint32_t CAP = np * NB;
+  uint32_t* const ctmp = lds + (size_t)NW * (CAP + np);
+  uint32_t* const cflg = ctmp + COOP_TMP_SLOTS * CoopEl<F>::E * (SM_NT / 4);
   // item (p, j) at p * NB + j
   for (uint32_t it = tid; it < CAP; it += SM_NT) {
     const uint32_t p = it / NB, j = it % NB;
@@ -290,26 +326,25 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small_combine(SmallArgs a) {
     else if ((j >> (p - 1 - (uint32_t)r)) & 1u) v = PointAoS<F>::load(src, 0);                  // high bucket bit h = p - 1 - r: the range's total
     PointIO<F>::store(lds, CAP, it, v);
   }
+  __syncthreads();
   for (uint32_t s = 1; s < NB; s <<= 1) {
-    __syncthreads();
-    for (uint32_t it = tid; it < CAP; it += SM_NT) {
-      const uint32_t j = it % NB;
-      if ((j & (2 * s - 1)) == 0 && j + s < NB) {
-        const XYZZ<F> p = PointIO<F>::load(lds, CAP, it), q = PointIO<F>::load(lds, CAP, it + s);
-        PointIO<F>::store(lds, CAP, it, add_xyzz(p, q));
-      }
+    const uint32_t per_plane = NB / (2 * s), pairs = np * per_plane;
+    for (uint32_t base = 0; base < pairs; base += SM_NT / 4) {
+      const uint32_t pi = base + qd;
+      const bool on = pi < pairs;
+      const uint32_t t = on ? (pi / per_plane) * NB + (pi % per_plane) * 2 * s : 0u;
+      coop_add_level<F>(lds, CAP, ctmp, cflg, on, t, t + (on ? s : 0u), t);
     }
   }
-  __syncthreads();
   // gather the planes' sums (item p * NB) into items 0 .. np-1 of a second image behind the first
   uint32_t* const img = lds + (size_t)NW * CAP;
   if (tid < np) PointIO<F>::store(img, np, tid, PointIO<F>::load(lds, CAP, tid * NB));
   __syncthreads();
-  sm_combine_planes<F>(img, np, np);
+  sm_combine_planes<F>(img, np, ctmp, cflg, np);
   if (tid == 0) sm_export(PointIO<F>::load(img, np, 0), a.out + (size_t)w * 4 * SmIO<F>::E64);
 }
 template <class F>
-static size_t small_combine_lds_bytes(int c, int NB) { return (size_t)PointIO<F>::NW * ((size_t)c * NB + c) * 4; }
+static size_t small_combine_lds_bytes(int c, int NB) { return ((size_t)PointIO<F>::NW * ((size_t)c * NB + c) + sm_coop_words<F>()) * 4; }
 
 }  // namespace
 }  // namespace msm

@@ -9,6 +9,7 @@
 #include "../../kogarashi_amd/csrc/ntt_core.h"
 #include "../../kogarashi_amd/csrc/vecops.h"
 #include "../../kogarashi_amd/csrc/msm_digits.h"
+#include "../../kogarashi_amd/csrc/coop_add.h"
 
 using namespace kg;
 
@@ -95,6 +96,50 @@ template <class F> struct MemPt {
   void zz(const F& v) const { s->zz = v; }
   void zzz(const F& v) const { s->zzz = v; }
 };
+// The lane-cooperative addition / doubling of coop_add.h on the host: the step functions run lane by lane, step by step, over an "image"
+// that holds field elements of type F (the device's image holds their limbs; the bound-tracking type keeps its bounds this way).
+template <class F> struct HostQuad {
+  using Field = F;
+  struct Ref { int kind; uint32_t a, b; };           // 0: coordinate b of item a; 1: temporary a
+  std::vector<XYZZ<F>>* img; std::vector<F>* tmp; uint32_t* flg;
+  uint32_t ia, ib, io; int lane;
+  Ref coord(uint32_t item, uint32_t cd) const { return {0, item, cd}; }
+  Ref t(uint32_t s_) const { return {1, s_, 0}; }
+  F ld(const Ref& r) const {
+    if (r.kind == 1) return (*tmp)[r.a];
+    const XYZZ<F>& p = (*img)[r.a];
+    return r.b == 0 ? p.x : (r.b == 1 ? p.y : (r.b == 2 ? p.zz : p.zzz));
+  }
+  void st(const Ref& r, const F& v) const {
+    if (r.kind == 1) { (*tmp)[r.a] = v; return; }
+    XYZZ<F>& p = (*img)[r.a];
+    (r.b == 0 ? p.x : (r.b == 1 ? p.y : (r.b == 2 ? p.zz : p.zzz))) = v;
+  }
+  uint32_t flag() const { return *flg; }
+  void set_flag(uint32_t v) const { *flg = v; }
+  static F pick(bool first, const F& a, const F& b) { return first ? a : b; }
+};
+template <class F>
+static void host_coop_add(std::vector<XYZZ<F>>& img, uint32_t ia, uint32_t ib, uint32_t io) {
+  std::vector<F> tmp(COOP_TMP_SLOTS, F::zero());
+  uint32_t flag = 0;
+  auto quad = [&](int lane) { return HostQuad<F>{&img, &tmp, &flag, ia, ib, io, lane}; };
+  const int mode = coop_add_mode(quad(0));
+  if (mode == COOP_ADD) for (int l = 0; l < 4; ++l) coop_add_s1(quad(l));
+  if (mode == COOP_ADD) for (int l = 3; l >= 0; --l) coop_add_s2(quad(l));       // (lane order inside a step must not matter)
+  for (int l = 0; l < 4; ++l) coop_add_s3(quad(l), mode);
+  for (int l = 3; l >= 0; --l) coop_add_s4(quad(l), mode);
+}
+template <class F>
+static void host_coop_dbl(std::vector<XYZZ<F>>& img, uint32_t it) {
+  std::vector<F> tmp(COOP_TMP_SLOTS, F::zero());
+  uint32_t flag = 0;
+  auto quad = [&](int lane) { return HostQuad<F>{&img, &tmp, &flag, it, it, it, lane}; };
+  if (!coop_dbl_active(quad(0))) return;
+  for (int l = 0; l < 4; ++l) coop_dbl_s1(quad(l));
+  for (int l = 3; l >= 0; --l) coop_dbl_s2(quad(l));
+  for (int l = 0; l < 4; ++l) coop_dbl_s3(quad(l));
+}
 // mode 0: left fold with add_mixed; 1: pairwise tree with add_xyzz; 2: fold of add_xyzz(from_affine);
 // 3: sum_i 2*P_i via double_affine + add_xyzz; 4: double_xyzz applied `n` times to point 0; 5: fold, negated;
 // 7: fold of add_mixed_signed(acc, -P_i, negate = true), i.e. the sign folded back: equals mode 0;
@@ -175,6 +220,26 @@ static int curve_sum(int mode, const uint32_t* pts, const uint8_t* inf, size_t n
       v.swap(w);
     }
     if (!v.empty()) acc = v[0];
+  } else if (mode == 12 || mode == 13) {
+    // coop_add.h: 12 = chunks of three folded with add_mixed_signed (X not value-reduced), then a pairwise tree of COOPERATIVE additions
+    // in place on the left operand (the kernels' merge / halving / combine levels); 13 = the same tree, then the sum doubled twice by the
+    // cooperative doubling: 4 * sum
+    std::vector<XYZZ<F>> v;
+    XYZZ<F> part = XYZZ<F>::identity();
+    size_t cnt = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (!(inf && inf[i])) {
+        Affine<F> a = ld_aff<F>(pts + W2 * i);
+        part = (i & 1) ? add_mixed_signed(part, neg_affine(a), true) : add_mixed_signed(part, a, false);
+      }
+      if (++cnt == 3 || i + 1 == n) { v.push_back(part); part = XYZZ<F>::identity(); cnt = 0; }
+    }
+    for (size_t s_ = 1; s_ < v.size(); s_ <<= 1)
+      for (size_t i = 0; i + s_ < v.size(); i += 2 * s_) host_coop_add(v, (uint32_t)i, (uint32_t)(i + s_), (uint32_t)i);
+    if (!v.empty()) {
+      if (mode == 13) { host_coop_dbl(v, 0); host_coop_dbl(v, 0); }
+      acc = v[0];
+    }
   } else if (mode == 10) {                                  // and the doubling on its own, in place
     acc = from_affine(ld_aff<F>(pts));
     for (size_t i = 0; i < n; ++i) { MemPt<F> P{&acc}, O{&acc}; double_xyzz_stream<F>(P, O); }

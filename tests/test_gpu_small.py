@@ -1,5 +1,5 @@
 """The short-input MSM (csrc/msm_small.hip: one launch up to 2^10 pairs, two above; kg_msm / kg_msm_host / kg_msm_begin / kg_commit take it
-for n <= 4096 by default) against the oracle's restatement of msm_curve_addition (groth16/src/msm.rs:6-48) -- at the lengths the
+for n <= 8192 by default) against the oracle's restatement of msm_curve_addition (groth16/src/msm.rs:6-48) -- at the lengths the
 reference's own tests and bench use (msm.rs:118-135: 32 pairs; bn254/benches: 2^10), every length 1 .. 64, every window width and
 bucket-range shape the knob admits, all three curves, the edge mixes, maximally skewed inputs, and against the long pipeline."""
 import numpy as np
@@ -40,7 +40,7 @@ def test_every_length_up_to_64_matches_the_oracle(ctx, oracle):
 
 
 @pytest.mark.parametrize("cv,curve,sfd,nb", [("g1", 0, 0, 4), ("gk", 1, 1, 4), ("g2", 2, 0, 8)])
-@pytest.mark.parametrize("n", [33, 700, 1024, 2100, 4096])
+@pytest.mark.parametrize("n", [33, 700, 1024, 2100, 4096, 7000])
 def test_three_curves_at_the_plans_lengths(ctx, oracle, cv, curve, sfd, nb, n):
     """every row of the length -> shape table (msm_small_plan), the split windows from 2^11 pairs included, on G1, Grumpkin and G2"""
     O = oracle
@@ -69,28 +69,29 @@ def test_every_shape_gives_the_long_pipelines_point(ctx, oracle):
         try:
             assert gpu_aff(ctx.msm_host(0, bases, inf, scal, n), 4) == want
         finally:
-            ctx.set_msm_small(4096)
+            ctx.set_msm_small(8192)
         for c in range(2, 11):
             for r in sorted({-1, 0, 1, min(c - 1, 3), min(c - 1, 5), min(c - 1, 7)}):
                 ctx.set_msm_small(8192, c, r)
                 try:
                     assert gpu_aff(ctx.msm_host(0, bases, inf, scal, n), 4) == want, (n, c, r)
                 finally:
-                    ctx.set_msm_small(4096, 0, -1)
+                    ctx.set_msm_small(8192, 0, -1)
 
 
 def test_longest_inputs_of_the_short_path(ctx, oracle):
-    """8192 pairs (the entry's 13-bit index field) and the lengths around the default limit"""
+    """8192 pairs (the entry's 13-bit index field: the default limit), the lengths around it and around the rows of the shape table, and
+    a lower limit set through the knob"""
     O = oracle
-    for n in (4095, 4097, 8191, 8192):
+    for n in (1536, 1537, 3072, 3073, 6144, 6145, 8191, 8192, 8193):
         bases, scal, inf = edge_mix(O, "gk", 1, 1, n, SEED + 940 + n)
         want = aff(O, "gk", O.msm("gk", bases, scal, inf, threads=8))
-        ctx.set_msm_small(8192)
+        assert gpu_aff(ctx.msm_host(1, bases, inf, scal, n), 4) == want, n
+        ctx.set_msm_small(4096)
         try:
             assert gpu_aff(ctx.msm_host(1, bases, inf, scal, n), 4) == want, n
         finally:
-            ctx.set_msm_small(4096)
-        assert gpu_aff(ctx.msm_host(1, bases, inf, scal, n), 4) == want, n
+            ctx.set_msm_small(8192)
 
 
 def test_skewed_and_degenerate_inputs(ctx, oracle):
@@ -153,4 +154,4 @@ def test_bad_shapes_are_status_codes(ctx):
     for args in ((9000, 0, -1), (-1, 0, -1), (4096, 1, -1), (4096, 11, -1), (4096, 0, 8), (4096, 0, -2)):
         assert L.kg_msm_set_small(h, *args) == -2, args
     assert L.kg_msm_set_small(None, 4096, 0, -1) == -2
-    assert L.kg_msm_set_small(h, -2, 0, -1) == 0 and L.kg_msm_set_small(h, 4096, 0, -1) == 0
+    assert L.kg_msm_set_small(h, -2, 0, -1) == 0 and L.kg_msm_set_small(h, 8192, 0, -1) == 0
