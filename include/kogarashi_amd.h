@@ -49,7 +49,7 @@ enum { KG_G1 = 0, KG_GRUMPKIN = 1, KG_G2 = 2 };      /* curve ids */
 
 typedef struct kg_ctx kg_ctx;
 
-int kg_version(void);                    /* 6: kg_msm_set_small; 5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe, kg_mem_info, kg_groth16_setup_bn254, kg_experiments_built, kg_msm_host_slices; 4: kg_msm_set_groups, kg_ctx_queue_placement; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
+int kg_version(void);                    /* 6: kg_msm_set_small, kg_ctx_worker_threads; 5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe, kg_mem_info, kg_groth16_setup_bn254, kg_experiments_built, kg_msm_host_slices; 4: kg_msm_set_groups, kg_ctx_queue_placement; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
 /* Optional process-level setup; call it (or export the variable yourself) BEFORE anything in the process initialises the
  * HIP runtime -- before the first kg_device_count / kg_ctx_create and before any other HIP user -- and before the host
  * starts threads (it calls setenv).  Sets GPU_MAX_HW_QUEUES=16 unless the variable is already set, so that each of a
@@ -214,6 +214,10 @@ int kg_msm_set_groups(kg_ctx* ctx, int groups);
  * c: window width, 0 = by length, 2 .. 10; r: log2 of the buckets one workgroup owns, -1 = by length, 0 .. 7.  -2 for max_pairs keeps the
  * current value.  Results are bit-identical for every setting; a forced window (kg_msm_set_window) selects the long pipeline. */
 int kg_msm_set_small(kg_ctx* ctx, int max_pairs, int c, int r);
+/* Host worker threads the context has started so far (host finishes of tickets and slices, proof assemblies, the uploader of a
+ * host-scalar call).  They are started on demand, kept, and reused: after the first calls of a kind the count stays where it is (no
+ * thread creation per call).  KG_POOL_MAX_THREADS caps it (64); a call that would need one more fails with KG_ERR_HIP, never aborts. */
+int kg_ctx_worker_threads(kg_ctx* ctx, int* started);
 /* The automatic rule: window width c for n pairs (W = ceil(255 / c) signed windows of 2^(c-1) buckets; the reference's
  * rule is groth16/src/msm.rs:7-14).  Pure function: needs no device and no context. */
 int kg_msm_pick_window(size_t n);

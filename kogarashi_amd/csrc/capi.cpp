@@ -342,6 +342,7 @@ void kg_ctx_destroy(kg_ctx* c) {
   hipSetDevice(c->device);
   c->prover_jobs.reset();                             // joins the worker threads of proofs still in flight
   for (auto& f : c->ticket_fut) if (f.valid()) f.wait();      // and of MSM tickets begun and never ended
+  c->workers.reset();                                 // the worker threads are idle now: joined here, before what they work on is released
   hipStreamSynchronize(c->stream);
   tw_cache_free(c);
   for (int i = 0; i < 2; ++i) {
@@ -498,6 +499,11 @@ int kg_msm_set_window(kg_ctx* c, int w) {
 int kg_msm_set_groups(kg_ctx* c, int groups) {
   if (!c || groups < 0 || groups > kg_ctx::MAX_GROUPS) return KG_ERR_BAD_ARG;
   c->msm_groups = groups;
+  return KG_OK;
+}
+int kg_ctx_worker_threads(kg_ctx* c, int* started) {
+  if (!c || !started) return KG_ERR_BAD_ARG;
+  *started = c->workers ? c->workers->threads_started() : 0;
   return KG_OK;
 }
 int kg_msm_set_small(kg_ctx* c, int max_pairs, int cw, int r) {

@@ -15,6 +15,7 @@
 #include "../../include/kogarashi_amd.h"
 #include "curve.h"
 #include "tuning.h"
+#include "worker_pool.h"
 
 struct kg_tw_cache;   // ntt.hip
 
@@ -82,6 +83,7 @@ struct kg_ctx {
   Slot slots[NSLOTS];
   void* ws_small[NSLOTS] = {};           // short-input MSM (msm_small.hip): plane points of a window split over several workgroups, per result slot (grow-only)
   size_t ws_small_bytes[NSLOTS] = {};
+  std::unique_ptr<kg::WorkerPool> workers;   // host worker threads (worker_pool.h), started on demand, alive until the context is destroyed
   std::shared_ptr<void> prover_jobs;     // groth16.hip: proofs in flight (kg_groth16_prove_begin / _end)
   size_t ticket_n[4] = {0, 0, 0, 0};
   // kg_msm_begin starts the ticket's host finish (wait for the reduction, 255-step double-and-add, inversion) on a worker
@@ -118,6 +120,11 @@ struct kg_ctx {
 
 namespace kg {
 
+// the context's worker pool (created on first use)
+inline WorkerPool& pool(kg_ctx* c) {
+  if (!c->workers) c->workers.reset(new WorkerPool(c->tune.pool_max_threads));
+  return *c->workers;
+}
 inline int set_err(kg_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
   if (c) {
     c->last_error = what;

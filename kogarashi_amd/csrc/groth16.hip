@@ -300,6 +300,7 @@ int fixed_base_t(kg_ctx* ctx, int curve, const uint64_t* d_k, size_t n, uint64_t
 extern "C" {
 
 int kg_fixed_base_mul(kg_ctx* ctx, int curve, const uint64_t* d_k, size_t n, uint64_t* d_out_xy, uint8_t* d_out_inf) {
+  return kg::kg_guarded(ctx, [&]() -> int {              // (the table construction holds a std::vector)
   if (!ctx || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   if (n == 0) return KG_OK;
   if (!d_k || !d_out_xy || !d_out_inf) return KG_ERR_BAD_ARG;
@@ -307,6 +308,7 @@ int kg_fixed_base_mul(kg_ctx* ctx, int curve, const uint64_t* d_k, size_t n, uin
   if (curve == KG_G1) return fixed_base_t<Fq, FrParams, 4>(ctx, curve, d_k, n, d_out_xy, d_out_inf);
   if (curve == KG_GRUMPKIN) return fixed_base_t<Fr, FqParams, 4>(ctx, curve, d_k, n, d_out_xy, d_out_inf);
   return fixed_base_t<Fq2, FrParams, 8>(ctx, curve, d_k, n, d_out_xy, d_out_inf);
+  });
 }
 
 }  // extern "C"
@@ -321,6 +323,9 @@ struct ProofJob {
   uint64_t rr[4], ss[4];     // the blinding scalars, copied when the proof is enqueued
   int rc0 = 0;               // status of the enqueue, reported by the assembly after it has joined every host finish
   bool active = false;
+  ~ProofJob() {              // a proof still in flight when its context goes: its tasks write into this object
+    for (std::future<int>* f : {&assembly, &f_q, &f_l, &f_a, &f_b1, &f_b2}) if (f->valid()) f->wait();
+  }
 };
 struct ProofJobs { ProofJob j[2]; };   // job 0: kg_groth16_prove_bn254 and ticket 0 (result slots 6..10); job 1: ticket 1 (slots 11..15)
 ProofJob* job_of(kg_ctx* ctx, int i) {
@@ -423,7 +428,13 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   const bool tz = (!do_g2 || has_window_table(ctx, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, nz, nz)) &&
                   (!do_g1w || (has_window_table(ctx, KG_G1, crs->d_a, crs->d_a_inf, nz, nz) && has_window_table(ctx, KG_G1, crs->d_b_g1, crs->d_b_g1_inf, nz, nz) &&
                                (!m_l_1 || has_window_table(ctx, KG_G1, crs->d_l, crs->d_l_inf, m_l_1, nz))));
-  if (do_g2 || do_g1w) {
+  // Short proofs (every MSM within the short-input kernel's reach, msm_small.hip; no window tables at these lengths): no sort, no
+  // read-back -- each of the five MSMs is one launch (two from 1537 pairs) on a queue of its own behind z, h's behind its transform chain
+  int sc2 = 0, sr2 = 0, sc1 = 0, sr1 = 0, scl = 0, srl = 0, sch = 0, srh = 0;
+  const bool small = !tz && (!do_g2 || msm_small_plan(ctx, KG_G2, nz, &sc2, &sr2)) && (!do_g1w || msm_small_plan(ctx, KG_G1, nz, &sc1, &sr1)) &&
+                     (!do_g1w || !m_l_1 || msm_small_plan(ctx, KG_G1, m_l_1, &scl, &srl)) && (!(do_h && hn) || msm_small_plan(ctx, KG_G1, hn, &sch, &srh));
+  if (small && (do_g2 || do_g1w) && !(mats && do_h)) KG_HIP(ctx, hipEventRecord(ctx->ev_order, sq));      // z is complete
+  if ((do_g2 || do_g1w) && !small) {
     ctx->sort_alone = alone_front;                        // a blocking proof: the witness sort has the chip (the transforms beside it are few workgroups)
     const int rs = msm_sort(ctx, KG_FR, Z, nz, &Sz, true, tz ? merged_window(ctx, nz) : 0, 2, false);
     ctx->sort_alone = false;
@@ -459,7 +470,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   uint64_t *q_p = job->q_p, *l_p = job->l_p, *ai = job->ai, *b1i = job->b1i, *b2i = job->b2i;
   std::future<int>&f_q = job->f_q, &f_l = job->f_l, &f_a = job->f_a, &f_b1 = job->f_b1, &f_b2 = job->f_b2;
   auto finish_async = [&](int curve, int slot, uint64_t* out) {
-    return std::async(std::launch::async, [ctx, curve, slot, out] { return msm_finish(ctx, curve, slot, out); });
+    return pool(ctx).submit([ctx, curve, slot, out] { return msm_finish(ctx, curve, slot, out); });
   };
   // result slots: consecutive MSMs alternate between the two reduction queues (slot parity), each with run space of
   // its own (slot mod 8); measured against giving G2's long reduction a queue of its own: 3.67 vs 3.84 ms per proof
@@ -496,7 +507,28 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
     if (rc == KG_OK) rc = msm_sort(ctx, KG_FR, A, hn, &Sq, true, th ? merged_window(ctx, hn) : 0, 1, wait, 1);
     h_sorted = rc == KG_OK;
   };
-  const bool early = h_early && do_h && hn && (do_g2 || do_g1w);
+  const bool early = h_early && do_h && hn && (do_g2 || do_g1w) && !small;
+  if (small && (do_g2 || do_g1w)) {
+    // b_g2 (the long pole: Fq2 on the device and in the host chain) on the scalar queue right behind z; a, b_g1 and l on queues of their own
+    if (do_g2) {
+      rc = msm_small_enqueue(ctx, sq, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, Z, nz, SL[0], sc2, sr2);
+      if (rc == KG_OK) f_b2 = finish_async(KG_G2, SL[0], b2i);
+    }
+    if (do_g1w) {
+      struct { const uint64_t* b; const uint8_t* inf; const uint64_t* sc; size_t n; int slot, c, r; uint64_t* out; std::future<int>* f; } q3[3] = {
+          {crs->d_a, crs->d_a_inf, Z, nz, SL[1], sc1, sr1, ai, &f_a}, {crs->d_b_g1, crs->d_b_g1_inf, Z, nz, SL[2], sc1, sr1, b1i, &f_b1},
+          {crs->d_l, crs->d_l_inf, Z + 4 * l, m_l_1, SL[3], scl, srl, l_p, &f_l}};
+      for (int k = 0; k < 3 && rc == KG_OK; ++k) {
+        if (q3[k].n == 0) { msm_identity(KG_G1, q3[k].out); continue; }
+        hipStream_t qk = ctx->acc_stream[1 + k];
+        if (!qk) { hip_rc(create_stream(ctx, &ctx->acc_stream[1 + k], false), "queue creation"); qk = ctx->acc_stream[1 + k]; }
+        if (rc != KG_OK) break;
+        hip_rc(hipStreamWaitEvent(qk, ctx->ev_order, 0), "hipStreamWaitEvent(z)");
+        if (rc == KG_OK) rc = msm_small_enqueue(ctx, qk, KG_G1, q3[k].b, q3[k].inf, q3[k].sc, q3[k].n, q3[k].slot, q3[k].c, q3[k].r);
+        if (rc == KG_OK) *q3[k].f = finish_async(KG_G1, q3[k].slot, q3[k].out);
+      }
+    } else msm_identity(KG_G1, l_p);
+  } else
   if (do_g2 || do_g1w) {
     const int rw = msm_sort_wait(ctx, &Sz);                // always: the next sort may not start before this read-back
     if (rc == KG_OK) rc = rw;
@@ -522,6 +554,10 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // (Measured and dropped: h's chain on a service queue under the witness accumulations -- the transform's workgroups only
   // get onto a CU once an accumulation has drained, and then queue behind the reductions: 3.3 -> 3.85 ms per proof.)
   if (do_h && !early) h_front();
+  if (rc == KG_OK && hn && do_h && small) {               // h's coefficients come off the main queue: its MSM right behind them
+    rc = msm_small_enqueue(ctx, st, KG_G1, crs->d_h, crs->d_h_inf, A, hn, SL[4], sch, srh);
+    if (rc == KG_OK) f_q = finish_async(KG_G1, SL[4], q_p);
+  } else
   if (rc == KG_OK && hn && do_h) {
     if (!h_sorted) h_sort(true);
     else { const int rw = msm_sort_wait(ctx, &Sq); if (rc == KG_OK) rc = rw; }
@@ -539,9 +575,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   job->active = true;
   if (defer_assembly) return KG_OK;
   const kg_groth16_crs vk = *crs;                       // the host-resident part (alpha, beta, delta) is read by value
-  job->assembly = std::async(std::launch::async, [job, vk]() -> int {
-    return assemble_proof(vk, job->rr, job->ss, job->rc0, job, job, job, job->proof, job->inf);
-  });
+  job->assembly = pool(ctx).submit([job, vk]() -> int { return assemble_proof(vk, job->rr, job->ss, job->rc0, job, job, job, job->proof, job->inf); });
   return KG_OK;
 }
 
@@ -696,7 +730,7 @@ int kg_groth16_prove_sharded(kg_ctx* const* ctxs, int n_ctx, const kg_groth16_cr
   for (int i = 0; i < n_ctx; ++i) {
     if (!roles[i]) continue;
     who.push_back(i);
-    enq.push_back(std::async(std::launch::async, [=]() -> int {
+    enq.push_back(pool(ctxs[0]).submit([=]() -> int {
       return prove_enqueue(ctxs[i], crs[i], d_a_eval ? d_a_eval[i] : nullptr, d_b_eval ? d_b_eval[i] : nullptr, d_c_eval ? d_c_eval[i] : nullptr,
                            d_x[i], d_w[i], r, s, job_of(ctxs[i], 0), 5, nullptr, roles[i], true, false, own_device);
     }));

@@ -11,6 +11,8 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 using namespace kg;
@@ -175,9 +177,11 @@ static int msm_sliced(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uin
   size_t lo[K + 1];
   for (int j = 0; j <= K; ++j) lo[j] = n / K * j + (j == K ? n % K : 0);
   const int saved_window = ctx->msm_window;
+  struct Restore { kg_ctx* c; int w; ~Restore() { c->msm_window = w; } } restore_window{ctx, saved_window};      // also when a submit below throws
   if (!saved_window) { const int cw = pick_window(n, 0), cs = pick_window(n / K, 0); ctx->msm_window = cw > cs ? cw : cs; }
-  std::future<int> fin[K];
   uint64_t part[K][24];
+  std::future<int> fin[K];
+  kg::WaitAll fin_done{fin, K};                            // the finishes write into part[]
   int rc = KG_OK;
   const int sfield = curve == KG_GRUMPKIN ? KG_FQ : KG_FR;
   for (int j = 0; j < K && rc == KG_OK; ++j) {
@@ -188,7 +192,7 @@ static int msm_sliced(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uin
     rc = kg::msm_run(ctx, S, curve, d_bases + a * pw, d_inf ? d_inf + a : nullptr, cnt, 0, 16 + j);
     if (rc != KG_OK) break;
     uint64_t* out = part[j];
-    fin[j] = std::async(std::launch::async, [ctx, curve, j, out] { return kg::msm_finish(ctx, curve, 16 + j, out); });
+    fin[j] = kg::pool(ctx).submit([ctx, curve, j, out] { return kg::msm_finish(ctx, curve, 16 + j, out); });
   }
   ctx->msm_window = saved_window;
   for (int j = 0; j < K; ++j)
@@ -412,7 +416,7 @@ int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t*
     if (ctx->ticket_fut[ticket].valid()) ctx->ticket_fut[ticket].wait();
     KG_TRY(kg::msm_small_enqueue(ctx, ctx->stream, curve, d_bases, d_inf, d_scalars, n, 1 + ticket, sc, sr));
     uint64_t* out = ctx->ticket_out[ticket];
-    ctx->ticket_fut[ticket] = std::async(std::launch::async, [ctx, curve, ticket, out] { return kg::msm_finish(ctx, curve, 1 + ticket, out); });
+    ctx->ticket_fut[ticket] = kg::pool(ctx).submit([ctx, curve, ticket, out] { return kg::msm_finish(ctx, curve, 1 + ticket, out); });
     return KG_OK;
   }
   kg::MsmSorted S;
@@ -426,7 +430,7 @@ int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t*
   if (ctx->ticket_fut[ticket].valid()) ctx->ticket_fut[ticket].wait();      // a ticket begun twice without its end: drop the older result
   KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 1 + ticket));      // slots 1..4 (slot 0: kg_msm; 6..15: the prover's two jobs)
   uint64_t* out = ctx->ticket_out[ticket];
-  ctx->ticket_fut[ticket] = std::async(std::launch::async, [ctx, curve, ticket, out] { return kg::msm_finish(ctx, curve, 1 + ticket, out); });
+  ctx->ticket_fut[ticket] = kg::pool(ctx).submit([ctx, curve, ticket, out] { return kg::msm_finish(ctx, curve, 1 + ticket, out); });
   return KG_OK;
   });
 }
@@ -540,12 +544,15 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
   const int K = msm_host_plan(ctx->tune, n, bases_on_device, lo);
   // the previous call's readers of the cached buffers are done (every call joins its slices before it returns)
   std::atomic<int> up_s{0}, up_b{0}, up_rc{(int)hipSuccess};
+  std::mutex up_mu;                                        // the enqueuing thread sleeps on up_cv until the uploader has issued the slice's copies
+  std::condition_variable up_cv;
   auto upload_scalars = [&](int j) {
     const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
     hipError_t e = hipMemcpyAsync(d_s + 4 * a, h_scalars + 4 * a, cnt * 32, hipMemcpyHostToDevice, ctx->up_stream);
     if (e == hipSuccess) e = hipEventRecord(ctx->ev_up_s[j], ctx->up_stream);
     if (e != hipSuccess) up_rc = (int)e;
-    up_s = j + 1;
+    { std::lock_guard<std::mutex> lk(up_mu); up_s = j + 1; }
+    up_cv.notify_all();
     host_trace("upload: scalars");
   };
   auto upload_bases = [&](int j) {
@@ -557,7 +564,8 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
       if (e != hipSuccess) up_rc = (int)e;
       host_trace("upload: bases");
     }
-    up_b = j + 1;
+    { std::lock_guard<std::mutex> lk(up_mu); up_b = j + 1; }
+    up_cv.notify_all();
   };
   // The first slice's scalars go up from the calling thread (nothing can start before them: a thread start in front of that copy is
   // 30-40 us on the critical path); everything else from an uploader thread that feeds the pipeline while this thread enqueues
@@ -573,20 +581,22 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
   }
   // (everything that can fail and return comes before the uploader thread exists)
   if (K > 1 && !ctx->acc_stream[1]) { if (create_stream(ctx, &ctx->acc_stream[1], false) != hipSuccess) return set_err(ctx, KG_ERR_HIP, "queue creation"); }
-  std::thread uploader([&] {
+  std::future<int> uploader = kg::pool(ctx).submit([&]() -> int {
     hipSetDevice(ctx->device);
     upload_bases(0);
     for (int j = 1; j < K; ++j) { upload_scalars(j); upload_bases(j); }
+    return KG_OK;
   });
-  kg::JoinGuard uploader_joined{uploader};                 // also when a worker thread below cannot be started (std::async throws)
-  std::future<int> fin[kg_ctx::UP_SLICES];
+  struct WaitGuard { std::future<int>& f; ~WaitGuard() { if (f.valid()) f.wait(); } } uploader_done{uploader};   // the task refers to this frame: also when a later submit throws
   uint64_t part[kg_ctx::UP_SLICES][24];
+  std::future<int> fin[kg_ctx::UP_SLICES];
+  kg::WaitAll fin_done{fin, kg_ctx::UP_SLICES};            // the finishes write into part[]
   int rc = KG_OK;
   const int sfield = curve == KG_GRUMPKIN ? KG_FQ : KG_FR;
   const bool was_alone = ctx->sort_alone;
   for (int j = 0; j < K && rc == KG_OK; ++j) {
     const size_t a = lo[j], cnt = lo[j + 1] - lo[j];
-    while (up_s.load() <= j) std::this_thread::yield();
+    { std::unique_lock<std::mutex> lk(up_mu); up_cv.wait(lk, [&] { return up_s.load() > j; }); }
     if (up_rc != (int)hipSuccess) { rc = set_err(ctx, KG_ERR_HIP, "host-to-device upload", (hipError_t)up_rc.load()); break; }
     if (hipStreamWaitEvent(sq, ctx->ev_up_s[j], 0) != hipSuccess) { rc = KG_ERR_HIP; break; }
     kg::MsmSorted S;
@@ -604,7 +614,7 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
       S.reduce_inline = ctx->tune.group_reduce_inline && K > 1 && j == K - 1;
     }
     if (!bases_on_device) {
-      while (up_b.load() <= j) std::this_thread::yield();
+      { std::unique_lock<std::mutex> lk(up_mu); up_cv.wait(lk, [&] { return up_b.load() > j; }); }
       if (up_rc != (int)hipSuccess) { rc = set_err(ctx, KG_ERR_HIP, "host-to-device upload", (hipError_t)up_rc.load()); break; }
       if (hipStreamWaitEvent(sq, ctx->ev_up_b[j], 0) != hipSuccess) { rc = KG_ERR_HIP; break; }
     }
@@ -612,9 +622,9 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
     rc = kg::msm_run_multi(ctx, S, curve, &job, 1);
     if (rc != KG_OK) break;
     uint64_t* out = part[j];
-    fin[j] = std::async(std::launch::async, [ctx, curve, j, out] { return kg::msm_finish(ctx, curve, 16 + j, out); });
+    fin[j] = kg::pool(ctx).submit([ctx, curve, j, out] { return kg::msm_finish(ctx, curve, 16 + j, out); });
   }
-  if (uploader.joinable()) uploader.join();
+  if (uploader.valid()) uploader.wait();
   hipStreamSynchronize(ctx->up_stream);
   host_trace("host: uploads synced");
   for (int j = 0; j < K; ++j)
@@ -666,11 +676,13 @@ int kg_commit_host_scalars(kg_ctx* ctx, int curve, const uint64_t* d_bases, cons
 
 int kg_commit(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,
               uint64_t* out_xy, uint8_t* out_inf) {
+  return kg::kg_guarded(ctx, [&]() -> int {
   if (!ctx || !out_xy || !out_inf || curve < 0 || curve > KG_G2) return KG_ERR_BAD_ARG;
   uint64_t xyz[24];
   KG_TRY(kg_msm(ctx, curve, d_bases, d_inf, d_scalars, n, xyz));
   xyz_to_commit(curve, xyz, out_xy, out_inf);
   return KG_OK;
+  });
 }
 
 int kg_points_sum_affine(kg_ctx* ctx, int curve, const uint64_t* pts, const uint8_t* inf, size_t count, uint64_t* out_xy, uint8_t* out_inf) {

@@ -9,6 +9,7 @@
 // kg_sharded_key is the resident form of nova/src/pedersen.rs:6-13 PedersenCommitment { g }: slice i of the generators
 // lives on device i in the MSM's internal form (kg_bases_register), the reference re-reads g on every commit.
 #include "common.h"
+#include <future>
 #include <thread>
 #include <vector>
 
@@ -26,20 +27,21 @@ void shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi) {
 
 int words_of(int curve) { return curve == KG_G2 ? 16 : 8; }
 
-// runs fn(i) for every context on a thread of its own; returns the first failing status
+// runs fn(i) for every context at once -- context 0 on the calling thread, the others on worker threads of context 0's pool; returns the
+// first failing status
 template <class Fn>
-int for_each_ctx(int n_ctx, Fn fn) {
+int for_each_ctx(kg_ctx* const* ctxs, int n_ctx, Fn fn) {
   std::vector<int> rc((size_t)n_ctx, KG_OK);
-  std::vector<std::thread> th;
-  th.reserve((size_t)n_ctx);
+  std::vector<std::future<int>> fut;
+  fut.reserve((size_t)n_ctx);
   int started = 1;
   try {
-    for (int i = 1; i < n_ctx; ++i, ++started) th.emplace_back([&rc, &fn, i] { rc[(size_t)i] = fn(i); });
+    for (int i = 1; i < n_ctx; ++i, ++started) fut.push_back(kg::pool(ctxs[0]).submit([&fn, i]() -> int { return fn(i); }));
   } catch (...) {                                        // a thread could not be started: its context and the later ones run here, in turn
   }
   rc[0] = fn(0);
   for (int i = started; i < n_ctx; ++i) rc[(size_t)i] = fn(i);
-  for (auto& t : th) t.join();
+  for (size_t t = 0; t < fut.size(); ++t) rc[t + 1] = fut[t].get();
   for (int i = 0; i < n_ctx; ++i)
     if (rc[(size_t)i] != KG_OK) return rc[(size_t)i];
   return KG_OK;
@@ -87,7 +89,7 @@ int kg_commit_sharded(kg_ctx* const* ctxs, int n_ctx, int curve, const uint64_t*
     if (!ctxs[i] || (n_local[i] && (!d_bases[i] || !d_scalars[i]))) return KG_ERR_BAD_ARG;
   const int E = words_of(curve) / 2;
   std::vector<uint64_t> xyz((size_t)n_ctx * 3 * E);
-  const int rc = for_each_ctx(n_ctx, [&](int i) {
+  const int rc = for_each_ctx(ctxs, n_ctx, [&](int i) {
     return kg_msm(ctxs[i], curve, d_bases[i], d_inf ? d_inf[i] : nullptr, d_scalars[i], n_local[i], xyz.data() + (size_t)i * 3 * E);
   });
   if (rc != KG_OK) return rc;
@@ -126,7 +128,7 @@ int kg_sharded_key_create(kg_ctx* const* ctxs, int n_ctx, int curve, const uint6
   K->lo.resize((size_t)n_ctx); K->hi.resize((size_t)n_ctx);
   K->d_bases.assign((size_t)n_ctx, nullptr); K->d_inf.assign((size_t)n_ctx, nullptr);
   const size_t wb = (size_t)words_of(curve) * 8;
-  const int rc = for_each_ctx(n_ctx, [&](int i) {
+  const int rc = for_each_ctx(ctxs, n_ctx, [&](int i) {
     size_t lo, hi;
     shard_range(n, i, n_ctx, &lo, &hi);
     K->lo[(size_t)i] = lo; K->hi[(size_t)i] = hi;
@@ -166,7 +168,7 @@ int kg_sharded_key_commit(kg_sharded_key* K, const uint64_t* h_scalars, size_t n
   const int n_ctx = (int)K->ctxs.size();
   const int E = words_of(K->curve) / 2;
   std::vector<uint64_t> xyz((size_t)n_ctx * 3 * E);
-  const int rc = for_each_ctx(n_ctx, [&](int i) {
+  const int rc = for_each_ctx(K->ctxs.data(), n_ctx, [&](int i) {
     const size_t lo = K->lo[(size_t)i] < n ? K->lo[(size_t)i] : n, hi = K->hi[(size_t)i] < n ? K->hi[(size_t)i] : n;
     const size_t cnt = hi - lo;
     kg_ctx* c = K->ctxs[(size_t)i];

@@ -58,6 +58,7 @@
   X(ntt_tile, "KG_NTT_TILE", 0, "force log2 of the elements a workgroup holds in LDS; 0 = by size") \
   /* ---- device memory ---------------------------------------------------------------------------------------------------------------- */ \
   X(pool_mb, "KG_POOL_MB", 8192, "MiB of released kg_malloc blocks a context keeps for the next request of the same size (0 = none: every kg_free is a hipFree); kept blocks are given back when the device runs out") \
+  X(pool_max_threads, "KG_POOL_MAX_THREADS", 64, "most host worker threads a context starts (host finishes, proof assemblies, uploaders; started on demand, kept until the context is destroyed); a task that needs one more fails with a status -- 0 makes every such call fail (tests)") \
   /* ---- queues, diagnostics --------------------------------------------------------------------------------------------------------- */ \
   X(queue_placement, "KG_QUEUE_PLACEMENT", 1, "0 = the context's queues in creation order instead of probed over the compute pipes") \
   X(trace_host, "KG_TRACE_HOST", 0, "1 = host-side timestamps of the MSM pipeline's calls on stderr") \

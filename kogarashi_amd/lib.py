@@ -26,7 +26,7 @@ EXPORTS = [
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
     "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_r1cs_begin", "kg_groth16_prove_sharded", "kg_ntt_plan",
     "kg_msm_host_scalars", "kg_commit_host_scalars", "kg_tuning_describe", "kg_mem_info", "kg_groth16_setup_bn254", "kg_experiments_built", "kg_msm_host_slices",
-    "kg_msm_set_small",
+    "kg_msm_set_small", "kg_ctx_worker_threads",
 ]
 
 
@@ -325,6 +325,12 @@ class Context:
     def set_msm_groups(self, groups: int):
         """window groups of a blocking MSM: 0 automatic, 1 none, 2..4 (kg_msm_set_groups)"""
         self._chk(self._lib.kg_msm_set_groups(self._h, int(groups)), "kg_msm_set_groups")
+
+    def worker_threads(self) -> int:
+        """host worker threads the context has started so far (kg_ctx_worker_threads)"""
+        v = C.c_int(0)
+        self._chk(self._lib.kg_ctx_worker_threads(self._h, C.byref(v)), "kg_ctx_worker_threads")
+        return int(v.value)
 
     def set_msm_small(self, max_pairs: int = -2, c: int = 0, r: int = -1):
         """the short-input MSM (kg_msm_set_small): longest MSM it takes (-2: keep, 0: never), window width (0: by length), log2 of the

@@ -293,8 +293,8 @@ def test_contexts_on_one_device_from_concurrent_threads_and_a_context_handed_bet
     base.close()
 
 
-_NPROC_SCRIPT = r"""
-import os, sys, resource
+_POOL_SCRIPT = r"""
+import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
 import kogarashi_amd as K
@@ -304,39 +304,76 @@ n = 1 << 19
 db, ds = ctx.empty((n, 8)), ctx.empty((n, 4))
 ctx.gen_bases(K.KG_G1, 1, 0, n, db.ptr); ctx.gen_scalars(K.KG_FR, 2, 0, n, ds.ptr); ctx.sync()
 hs = ds.numpy()
-want = ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n)
-assert (ctx.msm_host_scalars(K.KG_G1, db.ptr, 0, hs, n) == want).all()
-soft, hard = resource.getrlimit(resource.RLIMIT_NPROC)
-resource.setrlimit(resource.RLIMIT_NPROC, (1, hard))          # from here on no thread of this user can be started
+want = ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n)           # a blocking call on resident arrays needs no worker thread
 out = []
-for f in (lambda: ctx.msm_host_scalars(K.KG_G1, db.ptr, 0, hs, n), lambda: ctx.msm_begin(K.KG_G1, db.ptr, 0, ds.ptr, n, 0)):
+for f in (lambda: ctx.msm_host_scalars(K.KG_G1, db.ptr, 0, hs, n), lambda: ctx.msm_begin(K.KG_G1, db.ptr, 0, ds.ptr, n, 0),
+          lambda: ctx.msm_begin(K.KG_G1, db.ptr, 0, ds.ptr, 100, 1)):
     try:
         f(); out.append("ok")
     except K.KogarashiError as e:
         out.append("status")
-resource.setrlimit(resource.RLIMIT_NPROC, (soft, hard))
-print("OUTCOMES", out, flush=True)
+print("OUTCOMES", out, "THREADS", ctx.worker_threads(), flush=True)
 ctx.sync()
-assert (ctx.msm_host_scalars(K.KG_G1, db.ptr, 0, hs, n) == want).all()
-ctx.msm_begin(K.KG_G1, db.ptr, 0, ds.ptr, n, 0)
-assert (ctx.msm_end(K.KG_G1, 0) == want).all()
+assert (ctx.msm(K.KG_G1, db.ptr, 0, ds.ptr, n) == want).all()
 print("USABLE", flush=True)
 """
 
 
 def test_a_worker_thread_that_cannot_be_started_is_a_status_not_an_abort():
-    """never aborts.  The host side starts threads (the uploader of a host-scalar call, the host finishes of tickets): with
-    RLIMIT_NPROC at 1 std::thread / std::async throw std::system_error -- which must come back through the C ABI as a status (kg_guarded), with
-    the context usable once threads can be started again.  Run in a subprocess (the limit is per process); root is exempt from the limit."""
+    """never aborts.  The host side runs tasks on worker threads (the uploader of a host-scalar call, the host finishes of
+    tickets): a thread that cannot be started is a std::system_error inside the library -- which must come back through the C ABI as a
+    status (kg_guarded), with the context usable for what needs no thread.  The failure is injected through KG_POOL_MAX_THREADS=0 (the
+    pool refuses every start exactly where the OS would: RLIMIT_NPROC does not bind root, which is what this pool's boxes run as)."""
     import os
     import subprocess
     import sys
-    if os.geteuid() == 0:
-        pytest.skip("RLIMIT_NPROC does not bind root")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", _NPROC_SCRIPT], cwd=root, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", _POOL_SCRIPT], cwd=root, env=dict(os.environ, KG_POOL_MAX_THREADS="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    assert "OUTCOMES ['status', 'status']" in r.stdout and "USABLE" in r.stdout, r.stdout[-1500:]
+    assert "OUTCOMES ['status', 'status', 'status'] THREADS 0" in r.stdout and "USABLE" in r.stdout, r.stdout[-1500:]
+    r = subprocess.run([sys.executable, "-c", _POOL_SCRIPT], cwd=root, env=dict(os.environ, KG_POOL_MAX_THREADS="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])       # one thread: the uploader takes it, the first slice's finish has none
+    assert "OUTCOMES ['status'," in r.stdout and "USABLE" in r.stdout, r.stdout[-1500:]
+
+
+def test_worker_threads_are_started_once_and_reused(ctx, oracle):
+    """No thread creation per call (round 5 started a std::async thread per MSM ticket, per slice and per proof part: 30-40 us each on the
+    critical path of short calls): after one warm-up pass over tickets of long and short MSMs, a host-scalar call in slices and proofs in
+    flight, repeating the same calls leaves kg_ctx_worker_threads where it was -- and the results are the same points."""
+    import kogarashi_amd as K
+    from kogarashi_amd import synthetic as syn
+    from kogarashi_amd.api import Prover, groth16_setup
+    c2 = K.Context(0)
+    try:
+        n = 1 << 19
+        db, ds = c2.empty((n, 8)), c2.empty((n, 4))
+        c2.gen_bases(K.KG_G1, 31, 0, n, db.ptr); c2.gen_scalars(K.KG_FR, 32, 0, n, ds.ptr); c2.sync()
+        hs = ds.numpy()
+        assert c2.worker_threads() == 0
+        m = 1 << 8
+        cc = syn.ChainCircuit(m)
+        P = groth16_setup(cc.a, cc.b, cc.c, m, cc.l, cc.m_l_1, syn.fixed_toxic(), syn.FrOps, ctx=c2)
+        pr = Prover(P, m, cc.l, cc.m_l_1, ctx=c2)
+        r, s_ = syn.fixed_rs()
+
+        def one_pass():
+            res = []
+            for i, cnt in enumerate((n, 1000, 1 << 16, 33)):
+                c2.msm_begin(K.KG_G1, db.ptr, 0, ds.ptr, cnt, i)
+            for i in range(4):
+                res.append(c2.msm_end(K.KG_G1, i))
+            res.append(c2.msm_host_scalars(K.KG_G1, db.ptr, 0, hs, n))
+            res.append(np.concatenate([np.asarray(v).reshape(-1) for v in pr.create_proof(cc.a_eval, cc.b_eval, cc.c_eval, cc.x, cc.w, r, s_)[:3]]))
+            return res
+        first = one_pass()
+        warm = c2.worker_threads()
+        assert 1 <= warm <= 16, warm
+        for _ in range(3):
+            again = one_pass()
+            assert all((a == b).all() for a, b in zip(first, again))
+        assert c2.worker_threads() == warm
+    finally:
+        c2.close()
 
 
 def test_profiling_entries_report_the_phases_of_the_calls_between_enable_and_summary(ctx):
