@@ -299,6 +299,7 @@ struct MsmSorted {
   int w0 = 0, group = 0;
   hipStream_t acc_stream = nullptr;   // queue of the group's accumulation (nullptr: the context's main queue)
   bool reduce_inline = false;         // the bucket reduction follows the accumulation on the same queue
+  bool tail_alone = false;            // nothing runs beside this reduction's tail (a blocking call's last reduction): the lane-cooperative tail kernel
   hipStream_t sorted_on = nullptr;    // queue the sort was enqueued on
   // merged sort (bases with window tables): the digits of all windows share ONE set of B buckets; W = 1 above, windows = the
   // real window count, an entry's index field is (window << merged_shift) | scalar index

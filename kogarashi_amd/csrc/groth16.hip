@@ -565,6 +565,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
     // queues may still hold the witness MSMs' reductions (a 0/1-heavy witness: hot-bucket trees; h's reduction waited 0.7 ms for a queue)
     const bool h_inline = ctx->tune.g16_h_inline != 0;
     if (alone_front && h_inline) Sq.reduce_inline = true;
+    if (alone_front) Sq.tail_alone = true;                // a blocking proof: h's reduction is the last thing on the device
     if (rc == KG_OK) rc = msm_run(ctx, Sq, KG_G1, crs->d_h, crs->d_h_inf, hn, 0, SL[4]);
     if (rc == KG_OK) f_q = finish_async(KG_G1, SL[4], q_p);
   } else msm_identity(KG_G1, q_p);

@@ -277,6 +277,7 @@ static int msm_grouped(kg_ctx* ctx, int curve, const uint64_t* d_bases, const ui
     S[g].acc_stream = (accq > 1 && g % accq) ? ctx->acc_stream[g % accq] : nullptr;
     const int rinl = ctx->tune.group_reduce_inline;
     S[g].reduce_inline = rinl && g == NG - 1;
+    S[g].tail_alone = g == NG - 1;                          // the last group's tail has the chip
     const int one_side = ctx->tune.group_one_side;
     slots[g] = one_side ? 16 + 2 * g : 16 + g;
     kg::MsmRunJob job{d_bases, d_inf, n, 0u, slots[g], false, resident ? nullptr : (const uint32_t*)ctx->ws_pb, f64};
@@ -325,6 +326,7 @@ static int msm_blocking(kg_ctx* ctx, int curve, const uint64_t* d_bases, const u
   const int rs = kg::msm_sort(ctx, curve == KG_GRUMPKIN ? KG_FQ : KG_FR, d_scalars, n, &S, false, mc);
   ctx->sort_alone = false;
   KG_TRY(rs);
+  S.tail_alone = true;                                    // a blocking call: nothing runs beside its reduction
   KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 0));
   return kg::msm_finish(ctx, curve, 0, out_xyz);
 }
@@ -612,6 +614,7 @@ static int msm_host_impl(kg_ctx* ctx, int curve, const uint64_t* bases, const ui
       // chip while this one's last waves drain; the last slice's reduction follows its accumulation on the same queue
       if (ctx->tune.host_accq > 1 && (j & 1)) S.acc_stream = ctx->acc_stream[1];
       S.reduce_inline = ctx->tune.group_reduce_inline && K > 1 && j == K - 1;
+      S.tail_alone = j == K - 1;
     }
     if (!bases_on_device) {
       { std::unique_lock<std::mutex> lk(up_mu); up_cv.wait(lk, [&] { return up_b.load() > j; }); }

@@ -2,6 +2,7 @@
 // where every bucket is one task), halving levels, the LDS tail, and the workgroup-wide trees of hot buckets.
 #pragma once
 #include "msm_acc_kernels.h"
+#include "coop_add.h"
 
 namespace kg {
 namespace msm {
@@ -326,6 +327,68 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveW
     export_el(p.y(), dst + E64);
     export_el(p.zz(), dst + 2 * E64);
     export_el(p.zzz(), dst + 3 * E64);
+  }
+}
+
+// The same tail for a reduction that has the chip to itself (a blocking call's last window group, an unsliced short call: nothing runs
+// beside it, so the 96-VGPR budget of k_reduce_tail buys nothing): every addition of a level is computed by a QUAD of lanes (coop_add.h:
+// four steps of one product instead of fourteen products in a row), 4.5 us per level instead of 12.  The workgroup first copies its
+// array into LDS (items [0, L)), then walks the same steps as above -- odd steps write image X (items L ..), even steps image Y (items
+// 0 ..: the input is dead after step 1) -- with 64 quads per round.  F is the one-lane field type (Fq2 for G2: the buffers' layout is the
+// lane-pair type's, c0 planes then c1 planes per coordinate).
+// NT threads per workgroup: 512 for the base-field curves (128 quads: every level of a 256-item array is one round), 256 for G2 (LDS)
+template <class F> struct TailCoopNT { static constexpr int NT = 512; };
+template <class G> struct TailCoopNT<Fp2<G>> { static constexpr int NT = 256; };
+template <class F>
+static size_t tail_coop_lds_bytes(uint32_t L) { return ((size_t)PointIO<F>::NW * 2 * L + (COOP_TMP_SLOTS * CoopEl<F>::E + 1) * (TailCoopNT<F>::NT / 4)) * 4; }
+template <class F, int E64>
+__global__ void __launch_bounds__(TailCoopNT<F>::NT) k_reduce_tail_coop(const uint32_t* in, size_t in_stride, int narr_in, uint32_t L, int c, uint64_t* __restrict__ out) {
+  extern __shared__ uint32_t lds[];
+  constexpr uint32_t NW = (uint32_t)PointIO<F>::NW;
+  constexpr uint32_t NT = (uint32_t)TailCoopNT<F>::NT, NQ = NT / 4;
+  const uint32_t CAP = 2 * L, tid = threadIdx.x, qd = tid >> 2;
+  uint32_t* const img = lds;
+  uint32_t* const ctmp = img + (size_t)NW * CAP;
+  uint32_t* const cflg = ctmp + COOP_TMP_SLOTS * CoopEl<F>::E * NQ;
+  const uint32_t w = blockIdx.x / (uint32_t)narr_in, a = blockIdx.x % (uint32_t)narr_in;
+  const bool spawns = a == 0;
+  int steps = 0;
+  while ((1u << steps) < L) ++steps;
+  const uint32_t src0 = (w * (uint32_t)narr_in + a) * L;
+  for (uint32_t k = 0; k < NW; ++k)
+    for (uint32_t it = tid; it < L; it += NT) img[(size_t)k * CAP + it] = in[(size_t)k * in_stride + src0 + it];
+  __syncthreads();
+  for (int t = 1; t <= steps; ++t) {
+    const uint32_t per = L >> t;
+    const uint32_t live = spawns ? (uint32_t)t : 1u, pairs = live * per;
+    const bool odd_step = (t & 1) != 0;
+    const uint32_t obase = odd_step ? L : 0u, ibase = odd_step ? 0u : L;
+    for (uint32_t base = 0; base < pairs; base += NQ) {
+      const uint32_t pi = base + qd;
+      const bool on = pi < pairs;
+      uint32_t i0 = 0, io = 0;
+      if (on) {
+        const uint32_t k = pi / per, q = pi % per;
+        i0 = ibase + k * 2 * per + 2 * q;
+        io = obase + k * per + q;
+        if (spawns && k == 0) {                          // the odd item of array 0 spawns array t: lane j of the quad copies coordinate j
+          const CoopQuad<F> cq{img, CAP, ctmp, NQ, qd, cflg, i0 + 1, i0 + 1, obase + (uint32_t)t * per + q, (int)(tid & 3u)};
+          cq.st(cq.coord(cq.io, (uint32_t)cq.lane), cq.ld(cq.coord(i0 + 1, (uint32_t)cq.lane)));
+        }
+      }
+      coop_add_level<F>(img, CAP, ctmp, cflg, on, i0, i0 + 1, io);
+    }
+  }
+  const uint32_t nres = spawns ? (uint32_t)steps + 1u : 1u;
+  if (tid < nres) {
+    const uint32_t fin = (steps & 1) ? L : 0u;
+    const XYZZ<F> p = PointIO<F>::load(img, CAP, fin + tid);
+    const int arr = tid == 0 ? (int)a : narr_in - 1 + (int)tid;          // 0 = A, 1 + l = T_l
+    uint64_t* dst = out + ((size_t)w * c + arr) * 4 * E64;
+    export_el(p.x, dst);
+    export_el(p.y, dst + E64);
+    export_el(p.zz, dst + 2 * E64);
+    export_el(p.zzz, dst + 3 * E64);
   }
 }
 
