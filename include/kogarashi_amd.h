@@ -49,7 +49,7 @@ enum { KG_G1 = 0, KG_GRUMPKIN = 1, KG_G2 = 2 };      /* curve ids */
 
 typedef struct kg_ctx kg_ctx;
 
-int kg_version(void);                    /* 6: kg_msm_set_small, kg_ctx_worker_threads; 5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe, kg_mem_info, kg_groth16_setup_bn254, kg_experiments_built, kg_msm_host_slices; 4: kg_msm_set_groups, kg_ctx_queue_placement; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
+int kg_version(void);                    /* 6: kg_msm_set_small, kg_ctx_worker_threads, kg_ctx_trim, kg_ctx_queue_placement2 (kg_ctx_queue_placement is the version-4 entry again); 5: kg_msm_host_scalars, kg_commit_host_scalars, kg_tuning_describe, kg_mem_info, kg_groth16_setup_bn254, kg_experiments_built, kg_msm_host_slices; 4: kg_msm_set_groups, kg_ctx_queue_placement; 3: kg_init, kg_hw_queue_setting, kg_groth16_prove_sharded, kg_ntt_plan; only additions since 1 */
 /* Optional process-level setup; call it (or export the variable yourself) BEFORE anything in the process initialises the
  * HIP runtime -- before the first kg_device_count / kg_ctx_create and before any other HIP user -- and before the host
  * starts threads (it calls setenv).  Sets GPU_MAX_HW_QUEUES=16 unless the variable is already set, so that each of a
@@ -85,15 +85,26 @@ int kg_ctx_set_inputs_complete(kg_ctx* ctx, int on);
  * hardware queues in creation order and hardware queue k is served by pipe k mod 4; a queue that shares the main queue's pipe starts its
  * work only when an accumulation's last round of workgroups is placed (~0.7 ms late), so the context creates eight candidate streams on
  * first use, probes which of them share the main queue's pipe, and puts the scalar queue and the two reduction queues on the three
- * other pipes.  *out_placement: 0 = the probe is switched off (KG_QUEUE_PLACEMENT=0), 1 = the probe gave no clear picture (the queues
- * are then taken in creation order, as up to version 3), 2 + j = probed, candidates j and j + 4 share the main queue's pipe.  Returns
- * KG_OK or a negative kg_status like every other entry (up to version 4 the placement itself was the return value, and "no clear
- * picture" collided with KG_ERR_NO_DEVICE); creates the queues if they do not exist yet. */
-int kg_ctx_queue_placement(kg_ctx* ctx, int* out_placement);
+ * other pipes.  kg_ctx_queue_placement2 (version 6): *out_placement: 0 = the probe is switched off (KG_QUEUE_PLACEMENT=0), 1 = the probe
+ * gave no clear picture (the queues are then taken in creation order, as up to version 3), 2 + j = probed, candidates j and j + 4 share
+ * the main queue's pipe; returns KG_OK or a negative kg_status like every other entry; creates the queues if they do not exist yet.
+ * kg_ctx_queue_placement is the version-4 entry with its version-4 meaning, kept so that a host built against that header keeps working
+ * (version 5 had changed its signature in place): the placement itself is the return value -- 0 = probe off, 1 + j = probed, -1 = no
+ * clear picture (which collides with KG_ERR_NO_DEVICE: why the out-parameter form exists); other negative values are kg_status codes. */
+int kg_ctx_queue_placement(kg_ctx* ctx);
+int kg_ctx_queue_placement2(kg_ctx* ctx, int* out_placement);
 
 /* device memory plumbing so that non-HIP hosts (Rust shim, ctypes) never link the HIP runtime */
 int kg_malloc(kg_ctx* ctx, size_t bytes, void** d_ptr);
 int kg_free(kg_ctx* ctx, void* d_ptr);
+/* kg_free keeps released blocks (up to KG_POOL_MB = 1024 MiB per context) for the next kg_malloc of the same size class: the first DMA
+ * into a fresh allocation pays for mapping its pages (15-28 ms per 32 MiB).  Kept blocks are invisible to other allocators of the
+ * device (hipMemGetInfo, the torch caching allocator, other processes see them as used) until they are given back: by kg_ctx_trim, when
+ * a work-space allocation of ANY context of this process on the device fails (every context's kept blocks are released and the request
+ * repeated), and at kg_ctx_destroy.  kg_free should be given the context that allocated the block; through another context the block is
+ * released instead of kept.  kg_mem_info's free figure counts the context's kept bytes as free (they are, to this library) and so exceeds
+ * hipMemGetInfo's by that amount. */
+int kg_ctx_trim(kg_ctx* ctx);
 /* Free and total memory of the context's device (hipMemGetInfo): a host sizes its resident CRS / keys with it.  Work spaces the
  * library keeps are grow-only and counted as used; an allocation the device refuses makes the call return KG_ERR_OOM with the
  * context intact (the call can be repeated once memory has been released). */

@@ -2,7 +2,10 @@
 #include "common.h"
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <unordered_map>
+#include <vector>
 
 using namespace kg;
 
@@ -23,18 +26,35 @@ static size_t pool_class(size_t bytes) {
   if (bytes <= ((size_t)1 << 20)) { size_t c = 8192; while (c < bytes) c <<= 1; return c; }      // powers of two up to 1 MiB
   return (bytes + (((size_t)1 << 20) - 1)) & ~(((size_t)1 << 20) - 1);                          // whole MiB above
 }
-void pool_trim(kg_ctx* c) {
+// Process-wide bookkeeping of the pool: the live contexts (a device that runs out of memory gets the kept blocks of EVERY context on it
+// back, not only the caller's) and the blocks kg_malloc has handed out, by address -> (owner, size class): kg_free through another
+// context than the allocating one still finds the block (it is released, not kept), and a stale entry cannot outlive its address.
+static std::mutex g_pool_mu;
+static std::vector<kg_ctx*> g_ctxs;
+static std::unordered_map<void*, std::pair<kg_ctx*, size_t>> g_live;
+static void pool_trim_locked(kg_ctx* c) {                  // g_pool_mu held
   for (auto& kv : c->pool_free) hipFree(kv.second);
   c->pool_free.clear();
   c->pool_cached = 0;
 }
+void pool_trim(kg_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  pool_trim_locked(c);
+}
+// the kept blocks of every context of the device (a kept block is idle by construction: its context was drained when it was kept)
+static size_t pool_trim_device(int device) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  size_t freed = 0;
+  for (kg_ctx* o : g_ctxs)
+    if (o->device == device) { freed += o->pool_cached; pool_trim_locked(o); }
+  return freed;
+}
 hipError_t dev_alloc(kg_ctx* c, void** p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes);
-  if (e != hipSuccess && c->pool_cached) {
+  if (e != hipSuccess) {
     (void)hipGetLastError();
     sync_all(c);
-    pool_trim(c);
-    e = hipMalloc(p, bytes);
+    if (pool_trim_device(c->device)) e = hipMalloc(p, bytes);
   }
   return e;
 }
@@ -332,6 +352,7 @@ int kg_ctx_create(int device, kg_ctx** out) {
   c->tune = tuning();
   if (create_stream(c, &c->own_stream, false) != hipSuccess) { delete c; return KG_ERR_HIP; }
   c->stream = c->own_stream;
+  { std::lock_guard<std::mutex> lk(g_pool_mu); g_ctxs.push_back(c); }
   *out = c;
   return KG_OK;
   });
@@ -369,7 +390,12 @@ void kg_ctx_destroy(kg_ctx* c) {
   }
   if (c->ev_pb) hipEventDestroy(c->ev_pb);
   if (c->ev_prep) hipEventDestroy(c->ev_prep);
-  pool_trim(c);                                          // (blocks the host still holds stay allocated, as before the pool: they are the host's)
+  {                                                      // (blocks the host still holds stay allocated, as before the pool: they are the host's -- released through any other context, or with the process)
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    pool_trim_locked(c);
+    for (auto it = g_ctxs.begin(); it != g_ctxs.end(); ++it) if (*it == c) { g_ctxs.erase(it); break; }
+    for (auto& kv : g_live) if (kv.second.first == c) kv.second.first = nullptr;
+  }
   if (c->ws_pb) hipFree(c->ws_pb);
   for (auto& sl : c->slots) { if (sl.host) hipHostFree(sl.host); if (sl.done) hipEventDestroy(sl.done); }
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -408,13 +434,19 @@ int kg_ctx_sync(kg_ctx* c) {
     if (s) KG_HIP(c, hipStreamSynchronize(s));
   return KG_OK;
 }
-int kg_ctx_queue_placement(kg_ctx* c, int* out_placement) {
+int kg_ctx_queue_placement2(kg_ctx* c, int* out_placement) {
   if (!c || !out_placement) return KG_ERR_BAD_ARG;
   KG_HIP(c, hipSetDevice(c->device));
   KG_TRY(make_sort_stream(c));
   // kg_ctx::placement: 0 probe off, -1 no clear picture, 1 + j probed -> the ABI's non-negative codes
   *out_placement = c->placement == 0 ? 0 : (c->placement < 0 ? 1 : 1 + c->placement);
   return KG_OK;
+}
+int kg_ctx_queue_placement(kg_ctx* c) {                 // the version-4 entry, version-4 meaning: the placement is the return value
+  if (!c) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipSetDevice(c->device));
+  KG_TRY(make_sort_stream(c));
+  return c->placement;
 }
 int kg_ctx_set_inputs_complete(kg_ctx* c, int on) {
   if (!c) return KG_ERR_BAD_ARG;
@@ -427,18 +459,30 @@ int kg_malloc(kg_ctx* c, size_t bytes, void** p) {
   KG_HIP(c, hipSetDevice(c->device));
   const size_t cls = pool_class(bytes ? bytes : 1);
   if (cls < bytes) return set_err(c, KG_ERR_OOM, "kg_malloc: size overflow");
-  auto it = c->pool_free.find(cls);
-  if (it != c->pool_free.end()) {                          // a block of this class that has been used before: its pages are mapped
-    *p = it->second;
-    c->pool_free.erase(it);
-    c->pool_cached -= cls;
-  } else {
+  *p = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = c->pool_free.find(cls);
+    if (it != c->pool_free.end()) {                        // a block of this class that has been used before: its pages are mapped
+      *p = it->second;
+      c->pool_free.erase(it);
+      c->pool_cached -= cls;
+    }
+  }
+  if (!*p) {
     const hipError_t e = dev_alloc(c, p, cls);
     if (e != hipSuccess) { *p = nullptr; return set_err(c, e == hipErrorOutOfMemory ? KG_ERR_OOM : KG_ERR_HIP, "kg_malloc", e); }
   }
-  c->pool_live[*p] = cls;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_live[*p] = {c, cls};                                   // (an entry left behind by a block released outside kg_free is overwritten here)
   return KG_OK;
   });
+}
+int kg_ctx_trim(kg_ctx* c) {
+  if (!c) return KG_ERR_BAD_ARG;
+  KG_HIP(c, hipSetDevice(c->device));
+  pool_trim(c);
+  return KG_OK;
 }
 int kg_mem_info(kg_ctx* c, size_t* free_bytes, size_t* total_bytes) {
   if (!c) return KG_ERR_BAD_ARG;
@@ -455,14 +499,22 @@ int kg_free(kg_ctx* c, void* p) {
   if (!p) return KG_OK;
   KG_HIP(c, hipSetDevice(c->device));
   kg_bases_unregister(c, (const uint64_t*)p);     // a freed array must never be served from its registration
-  auto it = c->pool_live.find(p);
-  if (it == c->pool_live.end()) { KG_HIP(c, hipFree(p)); return KG_OK; }       // not from kg_malloc (a foreign HIP allocation): released as before
-  const size_t cls = it->second;
-  c->pool_live.erase(it);
+  kg_ctx* owner = nullptr;
+  size_t cls = 0;
+  bool ours = false;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_live.find(p);
+    if (it != g_live.end()) { owner = it->second.first; cls = it->second.second; ours = true; g_live.erase(it); }
+  }
+  // not from kg_malloc (a foreign HIP allocation), or handed out by ANOTHER context (kept blocks belong to the pool of the context that
+  // drained its queues for them): released
+  if (!ours || owner != c) { KG_HIP(c, hipFree(p)); return KG_OK; }
   const size_t cap = (size_t)(c->tune.pool_mb > 0 ? c->tune.pool_mb : 0) << 20;
   if (c->pool_cached + cls <= cap) {
     // hipFree waits for the device; a kept block must be just as safe to hand out again: nothing of this context may still use it
     sync_all(c);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
     c->pool_free.emplace(cls, p);
     c->pool_cached += cls;
     return KG_OK;

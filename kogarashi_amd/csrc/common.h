@@ -61,7 +61,6 @@ struct kg_ctx {
   // that has been used before at 56 GB/s -- and every host of the boundary allocates per call (DeviceBuf::new in the Rust glue,
   // DeviceBuffer in the C++ mirror, Context.upload in Python)
   std::multimap<size_t, void*> pool_free;            // size class -> released blocks
-  std::unordered_map<void*, size_t> pool_live;       // every block kg_malloc handed out -> its size class
   size_t pool_cached = 0;                            // bytes sitting in pool_free
   void* ws_vec = nullptr;                // kg_r1cs_prod: work list of long rows (grow-only)
   size_t ws_vec_bytes = 0;

@@ -77,7 +77,7 @@ int msm_small_enqueue(kg_ctx* ctx, hipStream_t st, int curve, const uint64_t* d_
   a.planes = nullptr;
 #ifdef KG_EXPERIMENTS
   static uint64_t* stamps = nullptr;                  // KG_SMALL_STAMPS=1: the previous call's phase boundaries (workgroup (0, 0)) on stderr
-  static const bool want_stamps = getenv("KG_SMALL_STAMPS") != nullptr;
+  const bool want_stamps = ctx->tune.small_stamps != 0;
   a.stamps = nullptr;
   if (want_stamps) {
     if (!stamps) { if (hipHostMalloc((void**)&stamps, 64 * 8, hipHostMallocDefault) != hipSuccess) stamps = nullptr; else memset(stamps, 0, 64 * 8); }

@@ -102,6 +102,19 @@ __global__ void __launch_bounds__(256) k_transpose_fill(const uint64_t* __restri
   dst[0] = src[0]; dst[1] = src[1];
 }
 
+// The matrices come from the host as they are: a column index beyond the variables or a row pointer that runs backwards would send the
+// transposition's counters and cursors out of their arrays.  One pass over each matrix raises a flag; the call then fails with
+// KG_ERR_BAD_ARG instead of writing out of bounds (the hosts' mirrors validate on their side; a C caller need not have).
+__global__ void __launch_bounds__(256) k_csr_check(const uint64_t* __restrict__ row_ptr, const uint64_t* __restrict__ col, size_t m, size_t nnz, size_t nv,
+                                                   uint32_t* __restrict__ flag) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool bad = false;
+  if (i == 0 && row_ptr[0] != 0) bad = true;
+  if (i < m && row_ptr[i] > row_ptr[i + 1]) bad = true;
+  if (i < nnz && col[i] >= nv) bad = true;
+  if (bad) atomicOr(flag, 1u);
+}
+
 struct Carve {
   size_t off = 0;
   size_t take(size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; }
@@ -175,6 +188,21 @@ int kg_groth16_setup_bn254(kg_ctx* ctx, const kg_csr* a, const kg_csr* b, const 
   uint64_t* t_ptr = (uint64_t*)(ws + o_tptr);
   uint64_t* t_col = (uint64_t*)(ws + o_tcol);
   uint64_t* t_val = (uint64_t*)(ws + o_tval);
+
+  // ---- the matrices' contents: columns inside the variables, row pointers monotone from zero ---------------------------------------
+  {
+    uint32_t* flag = cnt;                                 // (the counters are cleared again below)
+    KG_HIP(ctx, hipMemsetAsync(flag, 0, 4, st));
+    for (int j = 0; j < 3; ++j) {
+      const size_t span = nnz[j] > m ? nnz[j] : m;
+      hipLaunchKernelGGL(k_csr_check, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, st, mats[j]->d_row_ptr, mats[j]->d_col, m, nnz[j], nv, flag);
+    }
+    KG_HIP(ctx, hipGetLastError());
+    uint32_t h_flag = 0;
+    KG_HIP(ctx, hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, st));
+    KG_HIP(ctx, hipStreamSynchronize(st));
+    if (h_flag) return set_err(ctx, KG_ERR_BAD_ARG, "kg_groth16_setup_bn254: a matrix has a column index beyond l + m_l_1 or row pointers that do not ascend from zero");
+  }
 
   // ---- powers of tau, h's scalars, Lagrange coefficients ------------------------------------------------------------------------
   KG_TRY(kg_field_powers(ctx, KG_FR, w_one, w_tau, pw, m));

@@ -46,6 +46,7 @@
   X(host_slice_tables, "KG_HOST_SLICE_TABLES", 1, "index slices of a host-scalar MSM go through the window tables of registered bases when they have them") \
   X(host_accq, "KG_HOST_ACCQ", 2, "accumulation queues the slices of a host-scalar MSM alternate over (1 = the main queue only)") \
   /* ---- experiments compiled only with -DKG_EXPERIMENTS ----------------------------------------------------------------------------- */ \
+  X(small_stamps, "KG_SMALL_STAMPS", 0, "experiment: 1 = the short-input kernel stamps its phase boundaries; the previous call's phase times go to stderr (tools/dbg/small_stamps.py)") \
   X(acc_prefetch, "KG_ACC_PREFETCH", 0, "experiment: 1 = accumulation with the next base prefetched into LDS (k_acc_tasks_q; measured level)") \
   X(acc_prefetch_log, "KG_ACC_PREFETCH_LOG", 0, "experiment: log2 of the array length from which KG_ACC_PREFETCH applies") \
   X(g2_pair_acc, "KG_G2_PAIR_ACC", 0, "experiment: 1 = G2 accumulation on lane pairs (~150 VGPRs instead of 250; measured level)") \
@@ -58,7 +59,7 @@
   X(ntt_steps, "KG_NTT_STEPS", 0, "force the number of steps (HBM round trips) of a transform, 1..3; 0 = by size") \
   X(ntt_tile, "KG_NTT_TILE", 0, "force log2 of the elements a workgroup holds in LDS; 0 = by size") \
   /* ---- device memory ---------------------------------------------------------------------------------------------------------------- */ \
-  X(pool_mb, "KG_POOL_MB", 8192, "MiB of released kg_malloc blocks a context keeps for the next request of the same size (0 = none: every kg_free is a hipFree); kept blocks are given back when the device runs out") \
+  X(pool_mb, "KG_POOL_MB", 1024, "MiB of released kg_malloc blocks a context keeps for the next request of the same size (0 = none: every kg_free is a hipFree): the per-call upload buffers of the hosts (a 2^24-scalar vector is 512 MiB); kept blocks are given back when ANY context of the device runs out, and by kg_ctx_trim") \
   X(pool_max_threads, "KG_POOL_MAX_THREADS", 64, "most host worker threads a context starts (host finishes, proof assemblies, uploaders; started on demand, kept until the context is destroyed); a task that needs one more fails with a status -- 0 makes every such call fail (tests)") \
   /* ---- queues, diagnostics --------------------------------------------------------------------------------------------------------- */ \
   X(queue_placement, "KG_QUEUE_PLACEMENT", 1, "0 = the context's queues in creation order instead of probed over the compute pipes") \

@@ -26,7 +26,7 @@ EXPORTS = [
     "kg_msm_pick_window", "kg_shard_range", "kg_commit_sharded", "kg_msm_sharded", "kg_sharded_key_create", "kg_sharded_key_destroy",
     "kg_sharded_key_len", "kg_sharded_key_commit", "kg_r1cs_prod", "kg_nova_cross_term", "kg_ctx_set_inputs_complete", "kg_bases_precompute", "kg_msm_table_window", "kg_groth16_prove_r1cs_bn254", "kg_groth16_prove_r1cs_begin", "kg_groth16_prove_sharded", "kg_ntt_plan",
     "kg_msm_host_scalars", "kg_commit_host_scalars", "kg_tuning_describe", "kg_mem_info", "kg_groth16_setup_bn254", "kg_experiments_built", "kg_msm_host_slices",
-    "kg_msm_set_small", "kg_ctx_worker_threads",
+    "kg_msm_set_small", "kg_ctx_worker_threads", "kg_ctx_queue_placement2", "kg_ctx_trim",
 ]
 
 
@@ -187,6 +187,10 @@ class Context:
         self._chk(self._lib.kg_malloc(self._h, C.c_size_t(nbytes), C.byref(p)), "kg_malloc")
         return p.value
 
+    def trim(self):
+        """kg_ctx_trim: give the device memory kg_free has kept back to the driver"""
+        self._chk(self._lib.kg_ctx_trim(self._h), "kg_ctx_trim")
+
     def mem_info(self) -> tuple[int, int]:
         """(free, total) bytes of the context's device (kg_mem_info)"""
         f, t = C.c_size_t(0), C.c_size_t(0)
@@ -316,10 +320,10 @@ class Context:
         self._chk(self._lib.kg_msm_set_window(self._h, int(c)), "kg_msm_set_window")
 
     def queue_placement(self) -> int:
-        """how the service queues were dealt over the compute pipes (kg_ctx_queue_placement): 0 probe off, 1 creation order (no clear picture),
+        """how the service queues were dealt over the compute pipes (kg_ctx_queue_placement2): 0 probe off, 1 creation order (no clear picture),
         2 + j probed"""
         p = C.c_int(0)
-        self._chk(self._lib.kg_ctx_queue_placement(self._h, C.byref(p)), "kg_ctx_queue_placement")
+        self._chk(self._lib.kg_ctx_queue_placement2(self._h, C.byref(p)), "kg_ctx_queue_placement2")
         return int(p.value)
 
     def set_msm_groups(self, groups: int):

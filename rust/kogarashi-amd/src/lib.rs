@@ -327,13 +327,16 @@ pub(crate) fn marshal<C: GpuCurve>(pts: &[C]) -> (Vec<u64>, Vec<u8>) {
 }
 
 /// How `msm` treats the base slice of a call (`KOGARASHI_AMD_MSM_RESIDENT`, read once):
-///   unset / `probe`  keep the slice resident on GPU 0 in the MSM's internal form (`kg_bases_register`), keyed by address, length and
-///                    curve, and re-validate it on EVERY call with a sampled content digest: up to 256 evenly spaced points, every
-///                    coordinate word and the identity flag of each.  The reference's callers pass CRS vectors and commitment keys,
-///                    which are immutable (`groth16/src/params.rs:6-28`, `nova/src/pedersen.rs:6-13`); a caller that rewrites a base
-///                    slice IN PLACE between calls, at an index the sample happens to miss, must use `hash` or `0`.
-///   `hash`           the same cache, validated with a digest of EVERY point on every call: O(n) host work (a few ms per 2^20 points)
-///                    in front of a 1.6 ms MSM -- exact, for hosts that mutate base slices.
+///   unset / `hash`   keep the slice resident on GPU 0 in the MSM's internal form (`kg_bases_register`), keyed by address, length and
+///                    curve, and re-validate it on EVERY call with a digest of EVERY point (all coordinate words and the identity flag):
+///                    exact -- `msm_curve_addition(&[C], ...)` borrows a slice and promises nothing about its content between calls
+///                    (`groth16/src/msm.rs:6`), so a base rewritten in place is seen whichever index it has.  The digest is O(n) host
+///                    work, about 2.5 ms per 2^20 G1 points (one pass over 64 MiB), in front of a 1.6 ms MSM -- the price of keeping
+///                    a borrowed slice resident without a promise; a host that can make the promise uses `register_bases` (no digest
+///                    at all) or `sampled`.
+///   `sampled`        the same cache validated with a digest of up to 256 evenly spaced points (~10 us): for hosts whose base slices are
+///                    immutable in practice (CRS vectors, commitment keys: `groth16/src/params.rs:6-28`, `nova/src/pedersen.rs:6-13`).
+///                    A base rewritten in place at an index the sample misses goes UNSEEN -- opt in only with that promise.
 ///   `0`              nothing is kept: every call marshals and uploads its bases (`kg_msm_host`).
 /// `register_bases` / `ResidentMsmBases::msm` is the explicit alternative: the caller owns the handle and the promise.
 #[derive(Clone, Copy, PartialEq, Eq)]
@@ -350,8 +353,8 @@ fn residency_mode() -> ResidencyMode {
     };
     *m.get_or_insert_with(|| match std::env::var("KOGARASHI_AMD_MSM_RESIDENT").ok().as_deref() {
         Some("0") | Some("off") => ResidencyMode::Off,
-        Some("hash") => ResidencyMode::Hash,
-        _ => ResidencyMode::Probe,
+        Some("sampled") | Some("probe") => ResidencyMode::Probe,
+        _ => ResidencyMode::Hash,
     })
 }
 

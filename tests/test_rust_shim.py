@@ -196,11 +196,15 @@ def test_msm_bases_are_marshalled_once_per_slice():
 
 
 def test_msm_cache_validation_is_content_based_and_residency_can_be_opted_out():
-    """the address-keyed cache is re-validated on every call with a digest over every coordinate word and flag of up to
-    256 evenly spaced points (the whole slice under KOGARASHI_AMD_MSM_RESIDENT=hash), can be switched off (=0: kg_msm_host per call),
-    and an explicit handle exists (register_bases -> ResidentMsmBases::msm)"""
+    """ADVICE r4 / VERDICT r5: the address-keyed cache is re-validated on every call with a digest over every coordinate word and flag of
+    EVERY point by default (exact: msm_curve_addition borrows a slice and promises no immutability, groth16/src/msm.rs:6); the 256-point
+    sample is an opt-in (KOGARASHI_AMD_MSM_RESIDENT=sampled), residency can be switched off (=0: kg_msm_host per call), and an explicit
+    handle exists (register_bases -> ResidentMsmBases::msm)"""
     lib = _glue("lib.rs")
     assert "KOGARASHI_AMD_MSM_RESIDENT" in lib and "ResidencyMode::Off" in lib and "ResidencyMode::Hash" in lib
+    mode = lib.split("fn residency_mode()")[1].split("\n}\n")[0]
+    assert '_ => ResidencyMode::Hash' in mode and 'Some("sampled") | Some("probe") => ResidencyMode::Probe' in mode      # exact unless asked otherwise
+    assert "let step = if mode == ResidencyMode::Hash { 1 }" in lib                                                     # Hash = every point
     dg = lib.split("fn digest<C: GpuCurve>")[1].split("\n}\n")[0]
     assert "put_xy(&mut words)" in dg and "is_identity()" in dg and "take(n - 1" in dg
     assert "const PROBE_POINTS: usize = 256;" in lib and "probe3" not in lib
