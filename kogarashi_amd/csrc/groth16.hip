@@ -350,7 +350,7 @@ static bool g16_h_first() {                               // KG_G16_H_EARLY=2: h
 static bool g16_h_early_pipelined() {                     // KG_G16_H_EARLY_PIPE=0: proofs in flight keep h's chain last (the order up to round 3)
   return tuning().g16_h_early_pipe != 0;
 }
-int assemble_proof(const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t* ss, int rc0, ProofJob* j_g2, ProofJob* j_g1w, ProofJob* j_h,
+int assemble_proof(WorkerPool* workers, const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t* ss, int rc0, ProofJob* j_g2, ProofJob* j_g1w, ProofJob* j_h,
                    uint64_t* proof, uint8_t* inf);
 int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
                   const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
@@ -431,7 +431,10 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // Short proofs (every MSM within the short-input kernel's reach, msm_small.hip; no window tables at these lengths): no sort, no
   // read-back -- each of the five MSMs is one launch (two from 1537 pairs) on a queue of its own behind z, h's behind its transform chain
   int sc2 = 0, sr2 = 0, sc1 = 0, sr1 = 0, scl = 0, srl = 0, sch = 0, srh = 0;
-  const bool small = !tz && (!do_g2 || msm_small_plan(ctx, KG_G2, nz, &sc2, &sr2)) && (!do_g1w || msm_small_plan(ctx, KG_G1, nz, &sc1, &sr1)) &&
+  // (proofs in flight: up to 2048 witness entries -- beyond, two proofs' one-launch MSMs fill the chip in turn where the long pipeline's phases
+  // overlap: 2^12 constraints 1.34 ms per proof against 1.18, 2^10 0.71 against 0.97; a blocking proof gains at every length: 2^12 0.97 against 1.38)
+  const size_t small_cap = alone_front ? (size_t)ctx->tune.small_max : (size_t)(ctx->tune.small_max_flight / 2);
+  const bool small = !tz && nz <= small_cap && hn <= small_cap && (!do_g2 || msm_small_plan(ctx, KG_G2, nz, &sc2, &sr2)) && (!do_g1w || msm_small_plan(ctx, KG_G1, nz, &sc1, &sr1)) &&
                      (!do_g1w || !m_l_1 || msm_small_plan(ctx, KG_G1, m_l_1, &scl, &srl)) && (!(do_h && hn) || msm_small_plan(ctx, KG_G1, hn, &sch, &srh));
   if (small && (do_g2 || do_g1w) && !(mats && do_h)) KG_HIP(ctx, hipEventRecord(ctx->ev_order, sq));      // z is complete
   if ((do_g2 || do_g1w) && !small) {
@@ -576,13 +579,17 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   job->active = true;
   if (defer_assembly) return KG_OK;
   const kg_groth16_crs vk = *crs;                       // the host-resident part (alpha, beta, delta) is read by value
-  job->assembly = pool(ctx).submit([job, vk]() -> int { return assemble_proof(vk, job->rr, job->ss, job->rc0, job, job, job, job->proof, job->inf); });
+  WorkerPool* wp = &pool(ctx);
+  job->assembly = wp->submit([job, vk, wp]() -> int { return assemble_proof(wp, vk, job->rr, job->ss, job->rc0, job, job, job, job->proof, job->inf); });
   return KG_OK;
 }
 
 // prover.rs:75-92 on the host.  The five MSM sums may come from up to three jobs (one per context of a sharded proof):
 // j_g2 holds b2i, j_g1w holds ai / b1i / l_p, j_h holds q_p, each with the futures of its host finishes.
-int assemble_proof(const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t* ss, int rc0, ProofJob* j_g2, ProofJob* j_g1w, ProofJob* j_h,
+// The blinding terms (:75-77) are five scalar multiplications that depend on no MSM result -- a 255-step chain each on the host, the G2
+// one three times as long as a G1 one: they run on worker threads beside each other (the G2 chain | r delta1 and r s delta1 | s alpha +
+// r beta1 as ONE chain on this thread), 0.2 ms instead of 0.44 in a row -- which was the whole critical path of a short proof.
+int assemble_proof(WorkerPool* workers, const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t* ss, int rc0, ProofJob* j_g2, ProofJob* j_g1w, ProofJob* j_h,
                    uint64_t* proof, uint8_t* inf) {
   int rc = rc0;
   uint64_t *q_p = j_h->q_p, *l_p = j_g1w->l_p, *ai = j_g1w->ai, *b1i = j_g1w->b1i, *b2i = j_g2->b2i;
@@ -596,9 +603,21 @@ int assemble_proof(const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t*
   XYZZ<HostFq> g_a = XYZZ<HostFq>::identity(), g_c = g_a;
   XYZZ<HostFq2> g_b = XYZZ<HostFq2>::identity();
   if (rc == KG_OK && !bad_delta) {
-    g_a = add_xyzz(h_scalar_mul(delta1, rk.v), alpha);                                                    // :75
-    g_b = add_xyzz(h_scalar_mul(delta2, sk.v), beta2);                                                    // :76
-    g_c = add_xyzz(add_xyzz(h_scalar_mul(delta1, rsk.v), h_scalar_mul(alpha, sk.v)), h_scalar_mul(beta1, rk.v));   // :77
+    XYZZ<HostFq> rs_delta = XYZZ<HostFq>::identity();
+    std::future<int> t_b, t_a;
+    auto chain_b = [&]() -> int { g_b = add_xyzz(h_scalar_mul(delta2, sk.v), beta2); return KG_OK; };                                   // :76
+    auto chain_a = [&]() -> int { g_a = add_xyzz(h_scalar_mul(delta1, rk.v), alpha); rs_delta = h_scalar_mul(delta1, rsk.v); return KG_OK; };   // :75, first term of :77
+    bool par_b = false, par_a = false;
+    if (workers) {
+      try { t_b = workers->submit(chain_b); par_b = true; t_a = workers->submit(chain_a); par_a = true; } catch (...) {}      // no thread to be had: in a row, here
+    }
+    WaitAll chains_done{&t_b, 1}, chains_done2{&t_a, 1};
+    const XYZZ<HostFq> sa_rb = h_scalar_mul2(alpha, sk.v, beta1, rk.v);                                                                   // s alpha + r beta1 (:77)
+    if (!par_b) chain_b();
+    if (!par_a) chain_a();
+    if (t_b.valid()) t_b.get();
+    if (t_a.valid()) t_a.get();
+    g_c = add_xyzz(rs_delta, sa_rb);                                                                                                       // :77
   }
   auto join = [&](std::future<int>& f) { if (f.valid()) { int r2 = f.get(); if (rc == KG_OK) rc = r2; } };
   auto g1pt = [](const uint64_t* xyz) {
@@ -750,7 +769,7 @@ int kg_groth16_prove_sharded(kg_ctx* const* ctxs, int n_ctx, const kg_groth16_cr
   }
   uint64_t proof[32];
   uint8_t inf[3] = {0, 0, 0};
-  rc = assemble_proof(*crs[0], r, s, rc, jg2, jg1, jh, proof, inf);
+  rc = assemble_proof(&pool(ctxs[0]), *crs[0], r, s, rc, jg2, jg1, jh, proof, inf);
   for (int i : who) {
     ProofJob* j = job_of(ctxs[i], 0);
     for (std::future<int>* f : {&j->f_q, &j->f_l, &j->f_a, &j->f_b1, &j->f_b2})

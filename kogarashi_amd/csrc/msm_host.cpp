@@ -414,7 +414,10 @@ int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t*
   ctx->ticket_n[ticket] = n;
   if (n == 0) return KG_OK;
   int sc = 0, sr = 0;
-  if (kg::msm_small_plan(ctx, curve, n, &sc, &sr)) {      // short inputs: one launch, the host chain on a worker thread
+  // short inputs: one launch, the host chain on a worker thread.  Only up to 4096 pairs for calls in flight: a workgroup of the short-input
+  // kernel owns a CU, from 6144 pairs the grid fills the chip and consecutive calls run one after the other (2^13: 0.24 ms per call against
+  // 0.17 through the long pipeline, whose phases overlap across the tickets; 2^12: 0.16 / 0.17; 2^10: 0.09 / 0.15 -- profiles/r06_small_ab.txt)
+  if (n <= (size_t)ctx->tune.small_max_flight && kg::msm_small_plan(ctx, curve, n, &sc, &sr)) {
     if (ctx->ticket_fut[ticket].valid()) ctx->ticket_fut[ticket].wait();
     KG_TRY(kg::msm_small_enqueue(ctx, ctx->stream, curve, d_bases, d_inf, d_scalars, n, 1 + ticket, sc, sr));
     uint64_t* out = ctx->ticket_out[ticket];
