@@ -629,16 +629,21 @@ int assemble_proof(WorkerPool* workers, const kg_groth16_crs& vk, const uint64_t
     for (int i = 16; i < 24; ++i) pinf = pinf && xyz[i] == 0;
     return h_from_abi<HostFq2>(h_load_aff<HostFq2, 8>(xyz), pinf);
   };
-  // everything that does not need h's MSM is assembled while the device is still working on it
-  join(j_g2->f_b2); join(j_g1w->f_a); join(j_g1w->f_b1); join(j_g1w->f_l);
+  // everything that does not need h's MSM is assembled while the device is still working on it -- s A + r B1 (another 255-step chain) as soon
+  // as the two G1 sums are there, under the G2 MSM's host finish (three times a G1 one: the last of the four to arrive)
+  join(j_g1w->f_a); join(j_g1w->f_b1);
+  XYZZ<HostFq> sa_rb1 = XYZZ<HostFq>::identity();
   if (rc == KG_OK && !bad_delta) {
-    XYZZ<HostFq> a_ans = g1pt(ai), b1_ans = g1pt(b1i);
-    XYZZ<HostFq2> b2_ans = g2pt(b2i);
+    const XYZZ<HostFq> a_ans = g1pt(ai), b1_ans = g1pt(b1i);
     g_a = add_xyzz(g_a, a_ans);                                                                          // :81
-    g_b = add_xyzz(g_b, b2_ans);                                                                         // :88
-    g_c = add_xyzz(g_c, h_scalar_mul2(a_ans, sk.v, b1_ans, rk.v));                                       // :83,90
-    g_c = add_xyzz(g_c, g1pt(l_p));                                                                      // :92 (l part)
+    sa_rb1 = h_scalar_mul2(a_ans, sk.v, b1_ans, rk.v);                                                   // :83,90
     h_store_affine<HostFq, 4>(g_a, proof, inf);
+  }
+  join(j_g1w->f_l); join(j_g2->f_b2);
+  if (rc == KG_OK && !bad_delta) {
+    g_b = add_xyzz(g_b, g2pt(b2i));                                                                      // :88
+    g_c = add_xyzz(g_c, sa_rb1);
+    g_c = add_xyzz(g_c, g1pt(l_p));                                                                      // :92 (l part)
     h_store_affine<HostFq2, 8>(g_b, proof + 8, inf + 1);
   }
   join(j_h->f_q);
