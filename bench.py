@@ -373,7 +373,7 @@ def main():
     line = {
         "metric": "bn254_g1_msm_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 64-bit accumulate)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u32x9 (29-bit limbs)", "data": "synthetic",
         "config": {"workload": f"bn254 G1 MSM, 2^{args.log_n} uniform Fr scalars x uniform G1 bases per GPU, resident in HBM",
                    "pairs_per_gpu": n, "sharding": "index range" if world > 1 else "none"},
         "rounds": args.rounds, "rounds_ms": rounds_ms,
@@ -382,12 +382,14 @@ def main():
                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                           "traffic": traffic["corrected"] if traffic else None, "kernel_ms": acc_avg_ms, "launches": summary["accumulate"][1],
                           "algorithmic_bytes_per_launch": G1_BYTES_PER_PAIR * n,
-                          "traffic_detail": traffic},
+                          "traffic_uncorrected": traffic["uncorrected"] if traffic else None, "traffic_source": traffic["source"] if traffic else None},
                          "VALU-bound kernel (16 n point additions, see valu_roofline); in the timed region its launches overlap the next step's sort "
                          "and the previous steps' reductions (service kernels run at wave priority 3 beside it), so kernel_ms there is longer than "
                          "isolated.kernel_ms while ms_per_step is shorter than their sum; kernel_ms = HIP events over every launch of all timed rounds"),
-        "phases_ms_per_step": phase_avg, "pipelining": f"{depth} in flight",
+        "pipelining": f"{depth} in flight",
     }
+    if NOTES:
+        line["phases_ms_per_step"] = phase_avg
     if args.headline_only:
         if rank == 0:
             print(json.dumps(compact({"summary": {"msm_ms_per_step": r3(line["ms_per_step"]), "msm_pairs_per_s": value, "acc_kernel_ms": r3(acc_avg_ms)}, **line})), flush=True)
@@ -433,8 +435,7 @@ def main():
     line["valu_roofline"] = note({"bound": "valu", "unit": "T v_mad_u64_u32/s", "mads_per_addition": MADS_PER_ADDITION, "additions_per_launch": adds,
                                   "achieved": adds * MADS_PER_ADDITION / (iso_ms * 1e-3) / 1e12, "peak": MAD_PEAK_T,
                                   "frac": adds * MADS_PER_ADDITION / (iso_ms * 1e-3) / 1e12 / MAD_PEAK_T,
-                                  "routine_relative": {"unit": "G point additions/s", "achieved": adds / (iso_ms * 1e-3) / 1e9, "peak": MADD_PEAK_G,
-                                                       "frac": adds / (iso_ms * 1e-3) / 1e9 / MADD_PEAK_G}},
+                                  "routine_frac": adds / (iso_ms * 1e-3) / 1e9 / MADD_PEAK_G},      # against the addition routine with operands in registers (17.3 G/s)
                                  "isolated launches; the remaining ~30 % of issue slots go to the shifts / masks / carries of the 29-bit limbs, "
                                  "the lazy-reduction bookkeeping and the gathers; rocprofv3 SQ counters (profiles/r05_msm_sq_counters.json): VALU issue "
                                  "busy 88 % of the SIMD cycles of a launch")
@@ -493,7 +494,7 @@ def main():
         up_ms = (time.perf_counter() - t0) / 5 * 1e3
         del stage
         line["msm_host_scalars"] = note({"ms_per_msm": r3(host_ms), "resident_blocking_ms": r3(res_ms), "over_resident_ms": r3(host_ms - res_ms),
-                                         "rounds_ms": [round(x, 3) for x in host_rounds], "resident_rounds_ms": [round(x, 3) for x in res_rounds],
+                                         "rounds_ms": [round(x, 2) for x in host_rounds],
                                          "plain_upload_ms": r3(up_ms), "upload_gb_per_s": r3(32 * n / (up_ms * 1e-3) / 1e9),
                                          "matches_resident": bool((hres == rres).all())},
                                         "kg_msm_host_scalars: registered bases, pageable host scalars (32 B per pair over PCIe inside the call), "
@@ -650,7 +651,6 @@ def bench_msm_g2(ctx, torch, dev, K, env, log_n=18, steps=10, rounds=3, cpu=Fals
     iso_gbs = G2_BYTES_PER_PAIR * n / (iso_ms * 1e-3) / 1e9
     out = {"metric": "bn254_g2_msm_pairs_per_sec", "log_n": log_n, "value": world * n * steps / elapsed, "unit": "pairs/s", "ms_per_step": r3(elapsed / steps * 1e3),
            "rounds_ms": rounds_ms, "blocking_ms": r3(sorted(br)[2]), "pipelined_matches_blocking": bool((res == blk).all()),
-           "bases": "k_i * G2 (kg_fixed_base_mul)",
            "roofline": {"bound": "hbm", "kernel": "k_acc_tasks<Fq2>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "kernel_ms": pipe_kernel_ms, "launches": summ[kphase][1], "algorithmic_bytes_per_launch": G2_BYTES_PER_PAIR * n, "traffic": None,
                         "isolated": {"kernel_ms": iso_ms, "achieved": iso_gbs, "frac": iso_gbs / HBM_PEAK_GBS}},
@@ -891,19 +891,19 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, ske
             from oracle import oracle as O
             hg = g.cpu().numpy().view(np.uint64).reshape(nl, 8)
             hm = m.cpu().numpy().view(np.uint64).reshape(nl, 4)
-            # (1) the reference's own commit: a sequential fold of naive scalar multiplications (pedersen.rs:15-20)
-            k = 1 << 12
-            t0 = time.perf_counter()
-            O.commit_naive(cv, hg[:k], hm[:k])
-            cdt = time.perf_counter() - t0
-            if cdt < 1.6 and nl >= (1 << 14):
-                k = 1 << 14
+            # (1) the reference's own commit: a sequential fold of naive scalar multiplications (pedersen.rs:15-20) -- on G1 (Grumpkin's is the same loop)
+            if name == "g1_fr":
+                k = 1 << 12
                 t0 = time.perf_counter()
                 O.commit_naive(cv, hg[:k], hm[:k])
                 cdt = time.perf_counter() - t0
-            leg["cpu_naive_fold"] = {"value": k / cdt, "unit": "pairs/s", "cores": 1, "kind": "port",
-                                     "sample": f"first {k} pairs, {cdt:.2f} s",
-                                     "extrapolated_s_per_commit": r3(cdt * total / k)}
+                if cdt < 1.6 and nl >= (1 << 14):
+                    k = 1 << 14
+                    t0 = time.perf_counter()
+                    O.commit_naive(cv, hg[:k], hm[:k])
+                    cdt = time.perf_counter() - t0
+                leg["cpu_naive_fold"] = {"value": k / cdt, "unit": "pairs/s", "cores": 1, "kind": "port",
+                                         "sample": f"first {k} pairs, {cdt:.2f} s", "extrapolated_s_per_commit": round(cdt * total / k)}
             # (2) like for like at full size: the oracle's restatement of msm_curve_addition, one thread per window
             lg = nl.bit_length()
             c_ref = (lg * 69 // 100) + 2
@@ -976,7 +976,7 @@ def cpu_plumbing(ctx, K, log_n=10):
     for _ in range(reps):
         got = ctx.msm_host(K.KG_G1, hb, inf0, hs, n)
     gdt = (time.perf_counter() - t0) / reps
-    return {"value": n / dt, "unit": "pairs/s", "cores": 1, "kind": "port", "sample": f"{reps} x 2^{log_n} pairs, {dt * 1e3:.2f} ms each, one thread",
+    return {"value": n / dt, "unit": "pairs/s", "cores": 1, "kind": "port", "sample": f"{reps} x 2^{log_n} pairs, {dt * 1e3:.2f} ms each",
             "gpu_host_call_ms": r3(gdt * 1e3), "gpu_matches_cpu": bool(not inf and (got[:8] == xy).all())}
 
 
@@ -1023,7 +1023,7 @@ def bench_msm_skewed(ctx, torch, dev, K, bases, n, run_uniform, barrier, steps, 
     out = {"ms_per_step": r3(ms), "ratio_to_uniform": r3(ms / uniform_ms), "blocking_ms": r3(blocking), "blocking_ratio_to_uniform": r3(blocking / uniform_blocking_ms),
            "partial_rounds_per_msm": (summ["partial_round"][1] / steps) if "partial_round" in summ else 0.0,
            "pipelined_matches_blocking": bool((res == blk).all()),
-           "scalars": "synthetic.witness_like"}
+           }
     if cpu:
         from oracle import oracle as O
         hb = bases.cpu().numpy().view(np.uint64).reshape(n, 8)
@@ -1105,7 +1105,7 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
     sync()
     dt = mx(time.perf_counter() - t0) / k_pipe
     out = {"metric": "groth16_proofs_per_sec", "log_m": log_m, "value": world / dt, "ms_per_proof": r3(dt * 1e3), "replicas": world,
-           "ms_per_proof_blocking": r3(dt_blocking * 1e3), "pipelining": "two in flight", "crs": "registered",
+           "ms_per_proof_blocking": r3(dt_blocking * 1e3),
            "pipelined_matches_blocking": bool(all((proof_p[i] == proof[i]).all() for i in range(4))),
            "algorithmic_bytes_per_proof": (7 * 64 + 4 * 32 + 4 * 96 + 160) * m,      # 1120 B per constraint
            "setup_ms": r3(setup_ms), "setup_first_ms": r3(setup_first_ms)}
