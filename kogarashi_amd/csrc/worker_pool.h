@@ -34,8 +34,8 @@ class WorkerPool {
   }
   // runs fn on a worker thread; the future carries its status.  Throws std::system_error when the task needs a new thread and none can be started.
   std::future<int> submit(std::function<int()> fn) {
-    std::packaged_task<int()> task(std::move(fn));
-    std::future<int> fut = task.get_future();
+    Task task{std::move(fn), std::promise<int>()};
+    std::future<int> fut = task.result.get_future();
     {
       std::lock_guard<std::mutex> lk(mu_);
       if (queue_.size() + 1 > (size_t)(idle_ + spawning_)) {   // no idle (or just started) worker left for this task: one more thread
@@ -55,24 +55,33 @@ class WorkerPool {
   }
 
  private:
+  struct Task { std::function<int()> fn; std::promise<int> result; };
   void run() {
     std::unique_lock<std::mutex> lk(mu_);
     --spawning_;
+    ++idle_;
     for (;;) {
-      ++idle_;
       cv_.wait(lk, [this] { return stop_ || !queue_.empty(); });
+      if (queue_.empty()) { --idle_; return; }              // stop_, nothing left
       --idle_;
-      if (queue_.empty()) return;                           // stop_, nothing left
-      std::packaged_task<int()> task = std::move(queue_.front());
+      Task task = std::move(queue_.front());
       queue_.pop_front();
       lk.unlock();
-      task();
+      int rc = 0;
+      std::exception_ptr err;
+      try { rc = task.fn(); } catch (...) { err = std::current_exception(); }
+      // idle again BEFORE the result is published: whoever has seen a task's result finds its worker counted as free (a caller that
+      // submits, waits and submits again reuses the one thread instead of racing the worker back to its wait)
+      lk.lock();
+      ++idle_;
+      lk.unlock();
+      if (err) task.result.set_exception(err); else task.result.set_value(rc);
       lk.lock();
     }
   }
   mutable std::mutex mu_;
   std::condition_variable cv_;
-  std::deque<std::packaged_task<int()>> queue_;
+  std::deque<Task> queue_;
   std::vector<std::thread> threads_;
   int idle_ = 0, spawning_ = 0, started_ = 0, max_threads_;
   bool stop_ = false;

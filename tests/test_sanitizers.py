@@ -78,3 +78,16 @@ for k, steps in ((5, 0), (11, 0), (12, 0), (13, 0)):
 print('ok')
 """, dict(_asan_env(), KG_ORACLE_SO=""))
     assert "ok" in out
+
+
+def test_worker_pool_under_tsan_and_asan(tmp_path):
+    """kogarashi_amd/csrc/worker_pool.h on its own (tests/host/pool_test.cpp): sequential tasks reuse ONE thread, tasks that wait for tasks
+    of the same pool, no growth with the number of calls, a refused thread start as std::system_error, WaitAll on unwind -- under
+    ThreadSanitizer and under AddressSanitizer + UBSan."""
+    src = os.path.join(ROOT, "tests", "host", "pool_test.cpp")
+    for name, san in (("tsan", "-fsanitize=thread"), ("asan", "-fsanitize=address,undefined")):
+        exe = str(tmp_path / f"pool_{name}")
+        r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", san, "-pthread", src, "-o", exe], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "pool_test ok" in r.stdout, (name, r.stdout[-500:], r.stderr[-3000:])
