@@ -244,8 +244,9 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       // the sums go straight into the slot's pinned host buffer (its device view): no copy kernel behind the tail
       if (S.tail_alone && ctx->tune.coop_tail && len >= 2) {        // nothing beside it: a quad of lanes per addition (k_reduce_tail_coop)
         const size_t lds = tail_coop_lds_bytes<F>(len);
-        static bool attr_set = false;
-        if (!attr_set) { KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_reduce_tail_coop<F, Cfg::E64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+        static std::atomic<uint64_t> attr_devs{0};      // once per device
+        const uint64_t bit = (uint64_t)1 << (ctx->device & 63);
+        if (!(attr_devs.load() & bit)) { KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_reduce_tail_coop<F, Cfg::E64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_devs |= bit; }
         hipLaunchKernelGGL((k_reduce_tail_coop<F, Cfg::E64>), dim3((unsigned)(W * narr)), dim3(TailCoopNT<F>::NT), lds, side, pbuf[cur], in_stride, narr, len, c, (uint64_t*)sl.host_dev);
       } else
       if (len == TL) {

@@ -2,6 +2,7 @@
 // two launches that leave the W window sums in the result slot's pinned buffer.  Replaces, for n <= 2^12 pairs, the launch chain of
 // msm_sort.hip + msm_run.hip behind kg_msm / kg_msm_begin / kg_commit / the prover (groth16/src/msm.rs:6-48 at the lengths of its own tests).
 #include "msm_small_kernels.h"
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -46,11 +47,12 @@ bool msm_small_plan(const kg_ctx* ctx, int curve, size_t n, int* c_out, int* r_o
 
 template <class F, class SP>
 static int small_launch(kg_ctx* ctx, hipStream_t st, const SmallArgs& a, size_t lds, size_t lds2) {
-  static bool attr_set = false;                       // once per process and instance: the kernels may use the whole 160 KiB
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_devs{0};          // once per DEVICE and instance (the attribute belongs to the function on a device): the whole 160 KiB of LDS
+  const uint64_t bit = (uint64_t)1 << (ctx->device & 63);
+  if (!(attr_devs.load() & bit)) {
     KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_msm_small<F, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_msm_small_combine<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_devs |= bit;
   }
   hipLaunchKernelGGL((k_msm_small<F, SP>), dim3((unsigned)a.W, (unsigned)a.NB), dim3(SM_NT), lds, st, a);
   if (a.NB > 1) hipLaunchKernelGGL((k_msm_small_combine<F>), dim3((unsigned)a.W), dim3(SM_NT), lds2, st, a);
