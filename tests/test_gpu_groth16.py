@@ -204,6 +204,18 @@ def test_setup_status_codes(ctx, oracle):
         ctx.groth16_setup(mat, mat, mat, cs.m, cs.l, cs.m_l_1, toxic, Groth16Crs(), 0, 0)       # no output arrays
     with pytest.raises(KogarashiError, match="bad argument"):
         groth16_setup(cs.a, cs.b, cs.c, 0, cs.l, cs.m_l_1, toxic, ctx=ctx)
+    # the matrices' CONTENTS are checked on the device -- a column beyond the l + m_l_1 variables, or row pointers that run
+    # backwards, would send the transposition's counters out of their arrays: KG_ERR_BAD_ARG instead, and the context keeps working
+    nv = cs.l + cs.m_l_1
+    bad_col = (cs.b[0], cs.b[1].copy(), cs.b[2]); bad_col[1][3] = nv
+    with pytest.raises(KogarashiError, match="bad argument"):
+        groth16_setup(cs.a, bad_col, cs.c, cs.m, cs.l, cs.m_l_1, toxic, ctx=ctx)
+    bad_ptr = (cs.a[0].copy(), cs.a[1], cs.a[2]); bad_ptr[0][2], bad_ptr[0][3] = bad_ptr[0][3], bad_ptr[0][2] - 1 if bad_ptr[0][2] else 0
+    if (np.diff(bad_ptr[0].astype(np.int64)) < 0).any():
+        with pytest.raises(KogarashiError, match="bad argument"):
+            groth16_setup(bad_ptr, cs.b, cs.c, cs.m, cs.l, cs.m_l_1, toxic, ctx=ctx)
+    again = groth16_setup(cs.a, cs.b, cs.c, cs.m, cs.l, cs.m_l_1, za, ctx=ctx)
+    assert (again["a"] == want["a"]).all()
 
 
 def test_groth16_two_proofs_in_flight_match_blocking_calls(ctx, oracle):

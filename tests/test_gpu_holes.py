@@ -150,7 +150,7 @@ def test_released_blocks_are_kept_for_the_next_request_and_given_back_under_pres
     c = ctx.malloc(33 << 20)                                        # a second block of the class: a new allocation
     assert c != b
     ctx.free(b); ctx.free(c)
-    big = [ctx.malloc(3 << 30) for _ in range(4)]                   # 12 GiB released with an 8 GiB pool: two blocks are kept, two go back
+    big = [ctx.malloc(3 << 30) for _ in range(4)]                   # 12 GiB released with a 1 GiB pool: none of them is kept
     for p in big:
         ctx.free(p)
     # pressure: filling the device takes the kept blocks' memory too -- a request the device refuses releases them and is repeated
@@ -166,6 +166,49 @@ def test_released_blocks_are_kept_for_the_next_request_and_given_back_under_pres
     ctx.gen_scalars(K.KG_FR, SEED + 91, 0, n, m.ptr)
     assert ctx.msm(K.KG_G1, g.ptr, 0, m.ptr, n)[8:].any()
     ctx.close()
+
+
+def test_kept_blocks_can_be_trimmed_and_a_block_freed_through_another_context_is_released():
+    """kg_ctx_trim gives the kept blocks back to the driver (other allocators of the device -- torch, other contexts -- see them
+    as used until then); a block handed out by context A and freed through context B is released, not kept under A's old entry; a
+    work-space request that context B cannot satisfy releases context A's kept blocks too."""
+    import torch
+    import kogarashi_amd as K
+    a, b = K.Context(0), K.Context(0)
+    torch.cuda.synchronize()
+    p = a.malloc(256 << 20)
+    a.free(p)                                                       # kept by A
+    hip_free_kept = torch.cuda.mem_get_info(0)[0]
+    assert a.mem_info()[0] >= hip_free_kept + (255 << 20)           # the library counts its kept bytes as free; the driver does not
+    a.trim()
+    assert torch.cuda.mem_get_info(0)[0] >= hip_free_kept + (200 << 20)
+    assert abs(a.mem_info()[0] - torch.cuda.mem_get_info(0)[0]) < (64 << 20)
+    q = a.malloc(64 << 20)
+    b.free(q)                                                       # through the other context: released
+    q2 = a.malloc(64 << 20)
+    a.free(q2)
+    # pressure on B releases what A keeps
+    r = a.malloc(512 << 20)
+    a.free(r)                                                       # 512 MiB kept by A
+    held = _hog(b, 128 << 20)
+    big = b.malloc(400 << 20)                                       # does not fit in the 128 MiB that are left: A's kept block is given back
+    b.free(big)
+    for h in held:
+        b.free(h)
+    b.trim(); a.trim()
+    a.close(); b.close()
+
+
+def test_queue_placement_entries_old_and_new(ctx):
+    """kg_ctx_queue_placement is the version-4 entry again (the placement IS the return value: 0 off, 1 + j probed, -1 no clear picture);
+    kg_ctx_queue_placement2 returns a status and the code through its out-parameter (0, 1, 2 + j)"""
+    import ctypes as C
+    L, h = ctx._lib, ctx._h
+    old = L.kg_ctx_queue_placement(h)
+    new = C.c_int(-7)
+    assert L.kg_ctx_queue_placement2(h, C.byref(new)) == 0
+    assert old >= -1 and new.value == (0 if old == 0 else (1 if old < 0 else 1 + old))
+    assert L.kg_ctx_queue_placement2(h, None) == -2 and L.kg_ctx_queue_placement2(None, C.byref(new)) == -2
 
 
 def test_work_space_refused_is_oom_and_the_call_succeeds_once_memory_is_back(oracle):
