@@ -218,10 +218,11 @@ int kg_msm_set_window(kg_ctx* ctx, int c);
  * under the next one's accumulation, and the host's double-and-add chain starts on the top group's sums.  groups: 0 = automatic (two for 2^17 .. 2^21 pairs, three from 2^22, four for the 19- and 20-bit windows of 2^23 .. 2^24 pairs),
  * 1 = none (one accumulation launch per MSM), 2 .. 4.  Results are bit-identical for every setting. */
 int kg_msm_set_groups(kg_ctx* ctx, int groups);
-/* Tuning knob: the short-input MSM (csrc/msm_small.hip).  MSMs of up to max_pairs pairs (default and most: 8192; 0 = never) run as
+/* Tuning knob: the short-input MSM (csrc/msm_small.hip).  Blocking MSMs of up to max_pairs pairs (default and most: 32768, G2: 20480; 0 = never;
+ * calls in flight and proofs in flight: KG_SMALL_MAX_FLIGHT) run as
  * ONE launch -- a workgroup per window: digits, an LDS counting sort, bucket accumulation, the bucket reduction and the window sum in
- * LDS -- two launches from 1537 pairs (a window's buckets spread over several workgroups); the host finishes with one addition per
- * window.  These are the lengths of the reference's own tests and bench (groth16/src/msm.rs:118-135: 32 pairs; bn254/benches: 2^10).
+ * LDS -- two launches from 1537 pairs (a window's buckets spread over several workgroups), three from 2049 (the scalars are converted
+ * once, into word planes, for all workgroups); the host finishes with one addition per window.  These are the lengths of the reference's own tests and bench (groth16/src/msm.rs:118-135: 32 pairs; bn254/benches: 2^10).
  * c: window width, 0 = by length, 2 .. 10; r: log2 of the buckets one workgroup owns, -1 = by length, 0 .. 7.  -2 for max_pairs keeps the
  * current value.  Results are bit-identical for every setting; a forced window (kg_msm_set_window) selects the long pipeline. */
 int kg_msm_set_small(kg_ctx* ctx, int max_pairs, int c, int r);

@@ -559,7 +559,7 @@ int kg_ctx_worker_threads(kg_ctx* c, int* started) {
   return KG_OK;
 }
 int kg_msm_set_small(kg_ctx* c, int max_pairs, int cw, int r) {
-  if (!c || max_pairs < -2 || max_pairs == -1 || max_pairs > 8192 || cw < 0 || cw == 1 || cw > 10 || r < -1 || r > 7) return KG_ERR_BAD_ARG;
+  if (!c || max_pairs < -2 || max_pairs == -1 || max_pairs > 32768 || cw < 0 || cw == 1 || cw > 10 || r < -1 || r > 7) return KG_ERR_BAD_ARG;
   if (max_pairs != -2) c->tune.small_max = max_pairs;
   c->tune.small_c = cw;
   c->tune.small_r = r;

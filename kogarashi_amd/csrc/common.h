@@ -360,6 +360,7 @@ int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz);
 // context, and with which window width c and bucket range 2^r per workgroup; msm_small_enqueue: the launches on queue st, the window
 // sums into the slot (msm_finish is the host half, as for the long pipeline)
 bool msm_small_plan(const kg_ctx* ctx, int curve, size_t n, int* c, int* r);
+bool msm_small_kt(const kg_ctx* ctx, size_t n);      // does an n-pair short MSM convert its scalars once, by a launch of its own (the KT form)?
 int msm_small_enqueue(kg_ctx* ctx, hipStream_t st, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, int slot,
                       int c, int r);
 // the same over the slots of an MSM's window groups, top group first: one double-and-add chain, each slot awaited when the

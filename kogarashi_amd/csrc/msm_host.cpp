@@ -327,6 +327,7 @@ static int msm_blocking(kg_ctx* ctx, int curve, const uint64_t* d_bases, const u
   ctx->sort_alone = false;
   KG_TRY(rs);
   S.tail_alone = true;                                    // a blocking call: nothing runs beside its reduction
+  S.reduce_inline = ctx->tune.blocking_reduce_inline != 0;    // ... and nothing follows its accumulation: the reduction stays on the accumulation's queue (no cross-queue hand-over)
   KG_TRY(kg::msm_run(ctx, S, curve, d_bases, d_inf, n, 0, 0));
   return kg::msm_finish(ctx, curve, 0, out_xyz);
 }

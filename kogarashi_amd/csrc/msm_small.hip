@@ -15,8 +15,9 @@ namespace kg {
 // (2^(c-1-r) workgroups per window).  A forced window (kg_msm_set_window) keeps the long pipeline: the parity tests walk its widths.
 bool msm_small_plan(const kg_ctx* ctx, int curve, size_t n, int* c_out, int* r_out) {
   const kg_tuning& tn = ctx ? ctx->tune : tuning();
-  if (tn.small_max <= 0 || n == 0 || n > (size_t)tn.small_max || n > SM_MAX_N) return false;
+  if (tn.small_max <= 0 || n == 0 || n > (size_t)tn.small_max || n > SM_MAX_N_KT) return false;
   if (ctx && ctx->msm_window) return false;
+  const bool kt = msm_small_kt(ctx, n);
   // Measured on MI355X (profiles/r06_small_shapes*.txt: blocking kg_msm over every width and range).  With the tree levels run by lane quads
   // (coop_add.h: ~4.5 us per level) the widths 2 .. 5 are within a few per cent of each other at every length: a narrow window is a short
   // reduction on the device and more additions on the host (255 doublings + one addition per window).  Up to 1536 pairs the two-bit
@@ -25,24 +26,31 @@ bool msm_small_plan(const kg_ctx* ctx, int curve, size_t n, int* c_out, int* r_o
   // host chain in Fq2): wider windows pay earlier.
   int c, r;
   if (curve == KG_G2) {
+    if (n > (size_t)SM_MAX_N_G2) return false;       // (2^15 G2 pairs: 1.18 ms here, 1.09 ms through the long pipeline)
     if (n <= 32) { c = 3; r = 2; }
     else if (n <= 384) { c = 4; r = 3; }
     else { c = 5; r = 2; }
   } else {
     if (n <= 1536) { c = 2; r = 1; }
-    else if (n <= 3072 || n > 6144) { c = 5; r = 2; }
-    else { c = 5; r = 1; }
+    else if (n <= 6144) { c = 5; r = 2; }
+    else { c = 8; r = 3; }                           // 32 windows x 16 workgroups of eight buckets: fewer passes over the converted scalars
   }
   if (tn.small_c >= 2 && tn.small_c <= 10) { c = tn.small_c; r = c - 1 < SM_MAX_R ? c - 1 : SM_MAX_R; }
   if (tn.small_r >= 0 && tn.small_r <= SM_MAX_R) r = tn.small_r;
   if (r > c - 1) r = c - 1;
   if (c - 1 - r > 5) r = c - 1 - 5;                  // at most 32 workgroups per window
   if (r > SM_MAX_R) return false;
-  auto lds = [&](int rr) { return curve == KG_G2 ? small_lds_bytes<Fq2>((uint32_t)n, rr) : small_lds_bytes<Fq>((uint32_t)n, rr); };
+  auto lds = [&](int rr) { return curve == KG_G2 ? small_lds_bytes<Fq2>((uint32_t)n, rr, kt) : small_lds_bytes<Fq>((uint32_t)n, rr, kt); };
   while (r > 0 && lds(r) > 160 * 1024) --r;          // G2 points are twice the words: smaller bucket ranges, more workgroups per window
   if (lds(r) > 160 * 1024 || c - 1 - r > 5) return false;
   *c_out = c; *r_out = r;
   return true;
+}
+
+// From which length the scalars are converted once by a launch of their own (the KT form of the kernel) instead of by every workgroup
+bool msm_small_kt(const kg_ctx* ctx, size_t n) {
+  const kg_tuning& tn = ctx ? ctx->tune : tuning();
+  return n > (size_t)(tn.small_kt_from > 0 ? tn.small_kt_from : 0) || n > SM_MAX_N;
 }
 
 template <class F, class SP>
@@ -50,11 +58,16 @@ static int small_launch(kg_ctx* ctx, hipStream_t st, const SmallArgs& a, size_t 
   static std::atomic<uint64_t> attr_devs{0};          // once per DEVICE and instance (the attribute belongs to the function on a device): the whole 160 KiB of LDS
   const uint64_t bit = (uint64_t)1 << (ctx->device & 63);
   if (!(attr_devs.load() & bit)) {
-    KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_msm_small<F, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_msm_small<F, SP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_msm_small<F, SP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_msm_small_combine<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_devs |= bit;
   }
-  hipLaunchKernelGGL((k_msm_small<F, SP>), dim3((unsigned)a.W, (unsigned)a.NB), dim3(SM_NT), lds, st, a);
+  if (a.kt) {
+    hipLaunchKernelGGL((k_small_prep<SP>), dim3((a.n + 255) / 256), dim3(256), 0, st, a.scalars, a.n, a.H, const_cast<uint32_t*>(a.kt), a.spill_cursor, a.W);
+    hipLaunchKernelGGL((k_msm_small<F, SP, true>), dim3((unsigned)a.W, (unsigned)a.NB), dim3(SM_NT), lds, st, a);
+  } else
+  hipLaunchKernelGGL((k_msm_small<F, SP, false>), dim3((unsigned)a.W, (unsigned)a.NB), dim3(SM_NT), lds, st, a);
   if (a.NB > 1) hipLaunchKernelGGL((k_msm_small_combine<F>), dim3((unsigned)a.W), dim3(SM_NT), lds2, st, a);
   KG_HIP(ctx, hipGetLastError());
   return KG_OK;
@@ -77,6 +90,8 @@ int msm_small_enqueue(kg_ctx* ctx, hipStream_t st, int curve, const uint64_t* d_
   for (int j = 0; j < 8; ++j) a.H.w[j] = H[j];
   a.out = (uint64_t*)sl.host_dev;
   a.planes = nullptr;
+  a.kt = nullptr; a.spill = nullptr; a.spill_cursor = nullptr;
+  const bool kt = msm_small_kt(ctx, n);
 #ifdef KG_EXPERIMENTS
   static uint64_t* stamps = nullptr;                  // KG_SMALL_STAMPS=1: the previous call's phase boundaries (workgroup (0, 0)) on stderr
   const bool want_stamps = ctx->tune.small_stamps != 0;
@@ -93,22 +108,27 @@ int msm_small_enqueue(kg_ctx* ctx, hipStream_t st, int curve, const uint64_t* d_
   }
 #endif
   size_t lds2 = 0;
-  if (NB > 1) {
-    const size_t bytes = (size_t)W * NB * (SM_MAX_R + 1) * NW * 4;
+  if (NB > 1 || kt) {
+    // scratch of the slot: plane points of split windows | the scalars' word planes | spill cursors | spill space of the lists
+    const size_t b_planes = ((size_t)W * NB * (SM_MAX_R + 1) * NW * 4 + 255) & ~(size_t)255;
+    const size_t b_kt = kt ? (n * 32 + 255) & ~(size_t)255 : 0, b_cur = kt ? 512 : 0, b_spill = kt ? (size_t)W * n * 2 : 0;
+    const size_t bytes = b_planes + b_kt + b_cur + b_spill;
     if (bytes > ctx->ws_small_bytes[slot]) {
       if (ctx->ws_small[slot]) { sync_all(ctx); (void)hipFree(ctx->ws_small[slot]); ctx->ws_small[slot] = nullptr; ctx->ws_small_bytes[slot] = 0; }
       const hipError_t e = dev_alloc(ctx, &ctx->ws_small[slot], bytes);
       if (e != hipSuccess) return set_err(ctx, KG_ERR_OOM, "short-input plane buffer", e);
       ctx->ws_small_bytes[slot] = bytes;
     }
-    a.planes = (uint32_t*)ctx->ws_small[slot];
-    lds2 = curve == KG_G2 ? small_combine_lds_bytes<Fq2>(c, NB) : small_combine_lds_bytes<Fq>(c, NB);
+    char* ws = (char*)ctx->ws_small[slot];
+    a.planes = (uint32_t*)ws;
+    if (kt) { a.kt = (const uint32_t*)(ws + b_planes); a.spill_cursor = (uint32_t*)(ws + b_planes + b_kt); a.spill = (uint16_t*)(ws + b_planes + b_kt + b_cur); }
+    if (NB > 1) lds2 = curve == KG_G2 ? small_combine_lds_bytes<Fq2>(c, NB) : small_combine_lds_bytes<Fq>(c, NB);
   }
   PhaseScope ph(ctx, "small_msm", st);
   int rc;
-  if (curve == KG_G1) rc = small_launch<Fq, FrParams>(ctx, st, a, small_lds_bytes<Fq>(a.n, r), lds2);
-  else if (curve == KG_GRUMPKIN) rc = small_launch<Fr, FqParams>(ctx, st, a, small_lds_bytes<Fr>(a.n, r), lds2);
-  else rc = small_launch<Fq2, FrParams>(ctx, st, a, small_lds_bytes<Fq2>(a.n, r), lds2);
+  if (curve == KG_G1) rc = small_launch<Fq, FrParams>(ctx, st, a, small_lds_bytes<Fq>(a.n, r, kt), lds2);
+  else if (curve == KG_GRUMPKIN) rc = small_launch<Fr, FqParams>(ctx, st, a, small_lds_bytes<Fr>(a.n, r, kt), lds2);
+  else rc = small_launch<Fq2, FrParams>(ctx, st, a, small_lds_bytes<Fq2>(a.n, r, kt), lds2);
   ph.end();
   KG_TRY(rc);
   KG_HIP(ctx, hipEventRecord(sl.done, st));

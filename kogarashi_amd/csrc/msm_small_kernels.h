@@ -47,6 +47,9 @@ struct SmallArgs {
   Words8 H;                   // digit bias (msm_digits.h)
   uint64_t* out;              // NB == 1: W window sums, 4 * E64 words each (x | y | zz | zzz, ABI form) -- the slot's pinned buffer
   uint32_t* planes;           // NB > 1: [W][NB][r + 1] plane points, raw internal form, NW words each
+  const uint32_t* kt;         // KT form (longer inputs): the scalars as biased integers, word j of scalar i at kt[j * n + i] (k_small_prep)
+  uint16_t* spill;            // KT form: W * n list entries of overflow space (a workgroup whose entries outgrow its LDS list takes a run of it)
+  uint32_t* spill_cursor;     // KT form: W counters, zeroed by k_small_prep
 #ifdef KG_EXPERIMENTS
   uint64_t* stamps;           // KG_SMALL_STAMPS=1 (A/B builds): wall-clock ticks (10 ns) of workgroup (0, 0) at its phase boundaries
 #endif
@@ -102,16 +105,64 @@ __device__ __forceinline__ void sm_export(const XYZZ<F>& p, uint64_t* dst) {
   sm_export_el(p.x, dst); sm_export_el(p.y, dst + E); sm_export_el(p.zz, dst + 2 * E); sm_export_el(p.zzz, dst + 3 * E);
 }
 
+constexpr uint32_t SM_LIST_CAP = 4096;   // KT form: list entries a workgroup holds in LDS (more -- a skewed input -- spill to global memory)
+constexpr uint32_t SM_MAX_N_KT = 1u << 15;   // KT form: 15-bit index field
+constexpr uint32_t SM_MAX_N_G2 = 20480;      // G2: beyond, the long pipeline is as fast (profiles/r06_small_shapes_g2.txt)
+
+// The longer short inputs (from 2049 pairs): ONE conversion of the scalars for all workgroups -- k + H as eight word planes -- instead of one
+// per workgroup (n / 256 Montgomery products per lane in each of the W * NB workgroups: 32 us at 2^13 pairs); also clears the spill cursors.
+template <class SP>
+__global__ void __launch_bounds__(256) k_small_prep(const uint64_t* __restrict__ scalars, uint32_t n, Words8 H, uint32_t* __restrict__ kt,
+                                                    uint32_t* __restrict__ spill_cursor, int W) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (uint32_t)W) spill_cursor[i] = 0;
+  if (i >= n) return;
+  uint32_t w[8], k[8];
+  load_words(scalars, i, w);
+  ref_to_int<SP>(w, k);
+  uint64_t cy = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint64_t s = (uint64_t)k[j] + H.w[j] + cy;
+    kt[(size_t)j * n + i] = (uint32_t)s;
+    cy = s >> 32;
+  }
+}
+// the two words of the planes a window's digit lives in, for SM_UN scalars of a lane at once: the loads of a batch are all in flight
+// before the first digit is cut (one at a time their latency -- 0.5-1 us out of L2 / HBM -- is the whole loop: 64 rounds of it at 2^14 pairs)
+constexpr int SM_UN = 8;
+struct SmWords { uint32_t lo[SM_UN], hi[SM_UN]; };
+__device__ __forceinline__ SmWords sm_fetch_kt(const uint32_t* __restrict__ kt, uint32_t n, uint32_t i0, int w, int c, int W) {
+  const int o = w * c, j = o >> 5, sh = o & 31;
+  const bool two = j + 1 < 8 && (sh + c > 32 || w == W - 1);
+  SmWords v;
+#pragma unroll
+  for (int u = 0; u < SM_UN; ++u) {
+    const uint32_t i = i0 + (uint32_t)u * SM_NT;
+    v.lo[u] = i < n ? kt[(size_t)j * n + i] : 0u;
+    v.hi[u] = (two && i < n) ? kt[(size_t)(j + 1) * n + i] : 0u;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t sm_digit_words(uint32_t lo, uint32_t hi, int w, int c, int W, bool& negative) {
+  const int sh = (w * c) & 31;
+  const uint32_t e = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+  if (w == W - 1) { negative = false; return e; }
+  const int32_t d = (int32_t)(e & ((1u << c) - 1u)) - (int32_t)(1u << (c - 1));
+  negative = d < 0;
+  return (uint32_t)(d < 0 ? -d : d);
+}
 // LDS words of the cooperative additions' temporaries and flags (coop_add.h) for a 256-thread workgroup
 template <class F> constexpr uint32_t sm_coop_words() { return COOP_TMP_SLOTS * CoopEl<F>::E * (SM_NT / 4) + SM_NT / 4; }
 constexpr int SM_CLASSES = 9;          // a bucket owns 2^k task slots, k = 0 .. 8
 
 // LDS bytes of k_msm_small for n scalars and 2^r buckets per workgroup
 template <class F>
-static size_t small_lds_bytes(uint32_t n, int r) {
+static size_t small_lds_bytes(uint32_t n, int r, bool kt = false) {
   const size_t R = (size_t)1 << r, cap = SM_TASKS + R + 1;
   const size_t n_pad = (n + 1) & ~(size_t)1;
-  return ((size_t)PointIO<F>::NW * cap + sm_coop_words<F>() + 4 * R + 2 + 80) * 4 + (SM_TASKS + 2 * n_pad) * 2 + 64;
+  const size_t lists = kt ? (size_t)SM_LIST_CAP : 2 * n_pad;        // KT form: no digit codes, a capped list
+  return ((size_t)PointIO<F>::NW * cap + sm_coop_words<F>() + 4 * R + 2 + 80) * 4 + (SM_TASKS + lists) * 2 + 64;
 }
 
 // S = P_0 + sum_{l >= 0} 2^l P_{1 + l} over `np` plane points held as items 0 .. np-1 of an LDS image: quad 1 + l doubles its plane l
@@ -128,7 +179,7 @@ __device__ __forceinline__ void sm_combine_planes(uint32_t* img, uint32_t cap, u
   }
 }
 
-template <class F, class SP>
+template <class F, class SP, bool KT>
 __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
   extern __shared__ uint32_t lds[];
   constexpr int NW = PointIO<F>::NW;
@@ -147,8 +198,8 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
   uint32_t* const tsize = tfirst + R;                       // R + 1: task slots of each bucket (0 or a power of two)
   uint32_t* const misc = tsize + R + 1;                     // 80: scan scratch [0, 40), slot classes: count [40, 49), base [50, 60)
   uint16_t* const task_b = reinterpret_cast<uint16_t*>(misc + 80);    // SM_TASKS: bucket of each task slot
-  uint16_t* const dig = task_b + SM_TASKS;                  // n: (bucket - b0) | sign << 15, or SM_SKIP
-  uint16_t* const sorted = dig + n_pad;                     // n: (index | sign << 15) ordered by bucket
+  uint16_t* const dig = task_b + SM_TASKS;                  // n: (bucket - b0) | sign << 15, or SM_SKIP (not in the KT form: the digit is cut again)
+  uint16_t* sorted = KT ? dig : dig + n_pad;                // (index | sign << 15) ordered by bucket: n entries; KT form: SM_LIST_CAP, or a run of the spill space
 
   KG_SM_STAMP(0);
   // ---- digits of this window; histogram of the workgroup's bucket range
@@ -156,26 +207,45 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
   if (tid < 20) misc[40 + tid] = 0;
   for (uint32_t k = tid; k < (uint32_t)NW; k += SM_NT) pts[(size_t)k * CAP + IDENT] = 0u;
   __syncthreads();
-  for (uint32_t i = tid; i < n; i += SM_NT) {
-    uint32_t sw[8], k[8];
-    load_words(a.scalars, i, sw);
-    ref_to_int<SP>(sw, k);
-    uint64_t cy = 0;
+  if constexpr (KT) {
+    for (uint32_t i0 = tid; i0 < n; i0 += SM_UN * SM_NT) {
+      const SmWords v = sm_fetch_kt(a.kt, n, i0, (int)w, c, W);
+      uint32_t fl[SM_UN];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint64_t s = (uint64_t)k[j] + a.H.w[j] + cy;
-      k[j] = (uint32_t)s;
-      cy = s >> 32;
+      for (int u = 0; u < SM_UN; ++u) { const uint32_t i = i0 + (uint32_t)u * SM_NT; fl[u] = (a.inf && i < n) ? a.inf[i] : 0u; }
+#pragma unroll
+      for (int u = 0; u < SM_UN; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * SM_NT;
+        if (i >= n) break;
+        bool neg;
+        const uint32_t m = fl[u] ? 0u : sm_digit_words(v.lo[u], v.hi[u], (int)w, c, W, neg);
+        if (m && ((m - 1) >> r) == jb) atomicAdd(&hist[m - 1 - b0], 1u);
+      }
     }
+  } else
+  for (uint32_t i = tid; i < n; i += SM_NT) {
     bool neg;
-    uint32_t m = small_window_digit(k, (int)w, c, W, neg);
+    uint32_t m;
+    {
+      uint32_t sw[8], k[8];
+      load_words(a.scalars, i, sw);
+      ref_to_int<SP>(sw, k);
+      uint64_t cy = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint64_t s = (uint64_t)k[j] + a.H.w[j] + cy;
+        k[j] = (uint32_t)s;
+        cy = s >> 32;
+      }
+      m = small_window_digit(k, (int)w, c, W, neg);
+    }
     if (a.inf && a.inf[i]) m = 0;                          // identity base (msm.rs adds it as a no-op)
     uint32_t code = SM_SKIP;
     if (m && ((m - 1) >> r) == jb) {
       code = (m - 1 - b0) | (neg ? 0x8000u : 0u);
       atomicAdd(&hist[m - 1 - b0], 1u);
     }
-    dig[i] = (uint16_t)code;
+    if constexpr (!KT) dig[i] = (uint16_t)code;
   }
   __syncthreads();
   KG_SM_STAMP(1);
@@ -186,10 +256,23 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
   const uint32_t cnt = tid < R ? hist[tid] : 0u;
   uint32_t total = 0;
   const uint32_t off = block_exclusive_scan_1024(cnt, misc, total);
-  uint32_t T = (2 * total + (SM_TASKS - R) - 1) / (SM_TASKS - R);
+  // T: the shortest task length whose power-of-two slot counts fit -- from total / (slots - R) (no rounding loss) upwards by a quarter per
+  // try; 2 total / (slots - R) always fits (2^k < 2 cnt / T for k >= 1), so at most four tries
+  uint32_t T = (total + (SM_TASKS - R) - 1) / (SM_TASKS - R);
   if (T < 1) T = 1;
+  const uint32_t T_safe = (2 * total + (SM_TASKS - R) - 1) / (SM_TASKS - R);
   uint32_t kcls = 0;
-  while (((cnt + T - 1) / T) > (1u << kcls)) ++kcls;        // ceil(cnt / T) <= 2^kcls
+  for (;;) {
+    kcls = 0;
+    while (((cnt + T - 1) / T) > (1u << kcls)) ++kcls;      // ceil(cnt / T) <= 2^kcls
+    if (T >= T_safe) break;
+    uint32_t slots = 0;
+    (void)block_exclusive_scan_1024((tid < R && cnt) ? 1u << kcls : 0u, misc, slots);
+    __syncthreads();
+    if (slots <= SM_TASKS) break;
+    T = T + (T + 3) / 4;
+    if (T > T_safe) T = T_safe;
+  }
   uint32_t rank = 0;
   if (tid < R && cnt) rank = atomicAdd(&misc[40 + kcls], 1u);
   __syncthreads();
@@ -208,9 +291,32 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
     tsize[tid] = cnt ? 1u << kcls : 0u;
     if (cnt) for (uint32_t k = 0; k < (1u << kcls); ++k) task_b[tf + k] = (uint16_t)tid;
   }
-  if (tid == 0) boff[R] = total;
+  if (tid == 0) {
+    boff[R] = total;
+    if (KT && total > SM_LIST_CAP) misc[60] = atomicAdd(&a.spill_cursor[w], total);      // a skewed input: this workgroup's list lives in the window's spill run
+  }
   __syncthreads();
+  if (KT && total > SM_LIST_CAP) sorted = a.spill + (size_t)w * n + misc[60];             // (a window's workgroups hold at most n entries together)
   // ---- scatter
+  if constexpr (KT) {                                       // the digits again (two word loads each): no digit codes are kept for 2^15 scalars
+    for (uint32_t i0 = tid; i0 < n; i0 += SM_UN * SM_NT) {
+      const SmWords v = sm_fetch_kt(a.kt, n, i0, (int)w, c, W);
+      uint32_t fl[SM_UN];
+#pragma unroll
+      for (int u = 0; u < SM_UN; ++u) { const uint32_t i = i0 + (uint32_t)u * SM_NT; fl[u] = (a.inf && i < n) ? a.inf[i] : 0u; }
+#pragma unroll
+      for (int u = 0; u < SM_UN; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * SM_NT;
+        if (i >= n) break;
+        bool neg;
+        const uint32_t m = fl[u] ? 0u : sm_digit_words(v.lo[u], v.hi[u], (int)w, c, W, neg);
+        if (m && ((m - 1) >> r) == jb) {
+          const uint32_t pos = atomicAdd(&hist[m - 1 - b0], 1u);
+          sorted[pos] = (uint16_t)(i | (neg ? 0x8000u : 0u));
+        }
+      }
+    }
+  } else
   for (uint32_t i = tid; i < n; i += SM_NT) {
     const uint32_t code = dig[i];
     if (code != SM_SKIP) {
@@ -218,6 +324,7 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
       sorted[pos] = (uint16_t)(i | (code & 0x8000u));
     }
   }
+  if (KT && total > SM_LIST_CAP) __threadfence_block();     // the spilled list is read back by this workgroup
   __syncthreads();
   KG_SM_STAMP(2);
   // ---- accumulate: one lane per task slot (slot i of a bucket with 2^k slots takes entries [i * per, (i + 1) * per), per = ceil(cnt / 2^k))

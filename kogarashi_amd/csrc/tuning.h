@@ -25,8 +25,9 @@
   X(table64, "KG_TABLE64", 1, "0 = window tables in the 72-byte limb form") \
   X(pipe_accq, "KG_PIPE_ACCQ", 1, "2 = MSM tickets alternate between two accumulation queues (measured level; off)") \
   X(coop_tail, "KG_COOP_TAIL", 1, "0 = the last reduction of a blocking MSM runs the streamed tail kernel (96 VGPRs) instead of the lane-cooperative one") \
-  X(small_max, "KG_SMALL_MAX", 8192, "longest MSM (pairs) that runs as the one-launch short-input kernel (msm_small.hip): 0 = never, at most 8192") \
+  X(small_max, "KG_SMALL_MAX", 32768, "longest MSM (pairs) that runs as the short-input kernel (msm_small.hip): 0 = never, at most 32768 (G2: 20480)") \
   X(small_max_flight, "KG_SMALL_MAX_FLIGHT", 4096, "longest MSM begun with kg_msm_begin that runs as the short-input kernel (a call in flight shares the chip with its neighbours: the one-launch kernel fills it from 6144 pairs); proofs in flight: half of it") \
+  X(small_kt_from, "KG_SMALL_KT_FROM", 2048, "short-input MSMs LONGER than this convert their scalars once, by a launch of their own, instead of in every workgroup (0 = always)") \
   X(small_c, "KG_SMALL_C", 0, "window width of the short-input kernel: 0 = by length, 2..10") \
   X(small_r, "KG_SMALL_R", -1, "log2 of the buckets a workgroup of the short-input kernel owns: -1 = by length, 0..7 (2^(c-1-r) workgroups per window)") \
   /* ---- MSM: sort shaping ----------------------------------------------------------------------------------------------------------- */ \
@@ -39,6 +40,7 @@
   X(group_main_first, "KG_GROUP_MAIN_FIRST", 0, "1 / 2 = conversion and first group's sort on the main queue (measured slower; off)") \
   X(group_accq, "KG_GROUP_ACCQ", 2, "accumulation queues the window groups rotate over") \
   X(group_reduce_inline, "KG_GROUP_REDUCE_INLINE", 1, "the last group's bucket reduction follows its accumulation on the same queue") \
+  X(blocking_reduce_inline, "KG_BLOCKING_REDUCE_INLINE", 1, "an unsplit blocking MSM (8193 .. 2^17 pairs, window tables) runs its bucket reduction behind the accumulation on the main queue instead of handing it to a reduction queue") \
   X(group_one_side, "KG_GROUP_ONE_SIDE", 0, "1 = all groups reduce on one side queue") \
   /* ---- host-scalar entries (kg_msm_host_scalars, kg_sharded_key_commit) ------------------------------------------------------------ */ \
   X(host_slices, "KG_HOST_SLICES", 0, "index slices a host-scalar MSM is uploaded and run in: 0 = automatic (by length), 1..8") \

@@ -119,8 +119,15 @@ def test_msm_matches_oracle(ctx, oracle, cv, curve, sfd, n):
     got = ctx.msm_host(curve, bases, inf, scal, n)
     assert gpu_aff(got, 4) == want
     # without flags
-    want = aff(O, cv, O.msm(cv, bases, scal, None, threads=8))
-    assert gpu_aff(ctx.msm_host(curve, bases, None, scal, n), 4) == want
+    want2 = aff(O, cv, O.msm(cv, bases, scal, None, threads=8))
+    assert gpu_aff(ctx.msm_host(curve, bases, None, scal, n), 4) == want2
+    # these lengths run as the short-input kernel by default (tests/test_gpu_small.py): the long pipeline on the same inputs
+    ctx.set_msm_small(0)
+    try:
+        assert gpu_aff(ctx.msm_host(curve, bases, inf, scal, n), 4) == want
+        assert gpu_aff(ctx.msm_host(curve, bases, None, scal, n), 4) == want2
+    finally:
+        ctx.set_msm_small(32768)
 
 
 def test_msm_special_sums(ctx, oracle):

@@ -1,5 +1,5 @@
-"""The short-input MSM (csrc/msm_small.hip: one launch up to 2^10 pairs, two above; kg_msm / kg_msm_host / kg_msm_begin / kg_commit take it
-for n <= 8192 by default) against the oracle's restatement of msm_curve_addition (groth16/src/msm.rs:6-48) -- at the lengths the
+"""The short-input MSM (csrc/msm_small.hip: one launch up to 1536 pairs, two or three above; blocking kg_msm / kg_msm_host / kg_commit take it
+for n <= 32768 by default, kg_msm_begin for n <= 4096) against the oracle's restatement of msm_curve_addition (groth16/src/msm.rs:6-48) -- at the lengths the
 reference's own tests and bench use (msm.rs:118-135: 32 pairs; bn254/benches: 2^10), every length 1 .. 64, every window width and
 bucket-range shape the knob admits, all three curves, the edge mixes, maximally skewed inputs, and against the long pipeline."""
 import numpy as np
@@ -8,6 +8,7 @@ import pytest
 from test_gpu_parity import SEED, aff, edge_mix, gpu_aff
 
 pytestmark = pytest.mark.gpu
+SMALL_DEFAULT = 32768       # KG_SMALL_MAX
 
 
 @pytest.fixture(scope="module")
@@ -69,19 +70,19 @@ def test_every_shape_gives_the_long_pipelines_point(ctx, oracle):
         try:
             assert gpu_aff(ctx.msm_host(0, bases, inf, scal, n), 4) == want
         finally:
-            ctx.set_msm_small(8192)
+            ctx.set_msm_small(SMALL_DEFAULT)
         for c in range(2, 11):
             for r in sorted({-1, 0, 1, min(c - 1, 3), min(c - 1, 5), min(c - 1, 7)}):
-                ctx.set_msm_small(8192, c, r)
+                ctx.set_msm_small(SMALL_DEFAULT, c, r)
                 try:
                     assert gpu_aff(ctx.msm_host(0, bases, inf, scal, n), 4) == want, (n, c, r)
                 finally:
-                    ctx.set_msm_small(8192, 0, -1)
+                    ctx.set_msm_small(SMALL_DEFAULT, 0, -1)
 
 
 def test_longest_inputs_of_the_short_path(ctx, oracle):
-    """8192 pairs (the entry's 13-bit index field: the default limit), the lengths around it and around the rows of the shape table, and
-    a lower limit set through the knob"""
+    """the lengths around the rows of the shape table and around 8192 (the longest input of the form whose workgroups convert the scalars
+    themselves: a 13-bit index field), and a lower limit set through the knob"""
     O = oracle
     for n in (1536, 1537, 3072, 3073, 6144, 6145, 8191, 8192, 8193):
         bases, scal, inf = edge_mix(O, "gk", 1, 1, n, SEED + 940 + n)
@@ -91,7 +92,64 @@ def test_longest_inputs_of_the_short_path(ctx, oracle):
         try:
             assert gpu_aff(ctx.msm_host(1, bases, inf, scal, n), 4) == want, n
         finally:
-            ctx.set_msm_small(8192)
+            ctx.set_msm_small(SMALL_DEFAULT)
+
+
+def test_the_form_with_scalars_converted_once_up_to_2_15_pairs(ctx, oracle):
+    """beyond 2048 pairs the scalars are converted by a launch of their own and the workgroups cut digits from the word planes (the KT
+    form; its lists hold 4096 entries in LDS and spill to global memory beyond): the lengths up to the 15-bit index field, the
+    automatic shape and a few forced ones, uniform scalars and ONE scalar repeated (every entry of a window in one workgroup: the spill)"""
+    O = oracle
+    ctx.set_msm_small(32768)
+    try:
+        for n in (2049, 5000, 12000, 16384, 32767, 32768):
+            bases, scal, inf = edge_mix(O, "g1", 0, 0, n, SEED + 970 + n)
+            want = aff(O, "g1", O.msm("g1", bases, scal, inf, threads=8))
+            assert gpu_aff(ctx.msm_host(0, bases, inf, scal, n), 4) == want, n
+            for c, r in ((8, 3), (9, 4), (5, 1)):
+                ctx.set_msm_small(32768, c, r)
+                assert gpu_aff(ctx.msm_host(0, bases, inf, scal, n), 4) == want, (n, c, r)
+            ctx.set_msm_small(32768, 0, -1)
+        n = 20000
+        bases = O.gen_bases(1, SEED + 975, 0, n)
+        k = O.gen_scalars(1, SEED + 976, 0, 1)[0]
+        scal = np.tile(k, (n, 1))
+        assert gpu_aff(ctx.msm_host(1, bases, None, scal, n), 4) == aff(O, "gk", O.msm("gk", bases, scal, None, threads=8))
+        one = np.tile(O.f_consts(1)["r"], (n, 1))
+        assert gpu_aff(ctx.msm_host(1, bases, None, one, n), 4) == aff(O, "gk", O.msm("gk", bases, one, None, threads=8))
+    finally:
+        ctx.set_msm_small(SMALL_DEFAULT, 0, -1)
+
+
+def test_both_forms_over_each_others_lengths(oracle):
+    """KG_SMALL_KT_FROM moves the length from which the scalars are converted once: at 8192 the workgroups convert them themselves up to
+    8192 pairs (the form the short lengths run, with its 13-bit index field full), at 1 the word planes serve every length from 2 pairs"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import kogarashi_amd as K
+from oracle import oracle as O
+from test_gpu_parity import aff, edge_mix, gpu_aff
+ctx = K.Context(0)
+for cv, curve, sfd, lens in (("g1", 0, 0, LENS), ("gk", 1, 1, LENS[1::2])):
+    for n in lens:
+        bases, scal, inf = edge_mix(O, cv, curve, sfd, n, 5150 + n)
+        want = aff(O, cv, O.msm(cv, bases, scal, inf, threads=8))
+        assert gpu_aff(ctx.msm_host(curve, bases, inf, scal, n), 4) == want, (cv, n)
+        for c, r in SHAPES:
+            ctx.set_msm_small(32768, c, r)
+            assert gpu_aff(ctx.msm_host(curve, bases, inf, scal, n), 4) == want, (cv, n, c, r)
+        ctx.set_msm_small(32768, 0, -1)
+print("ok")
+""" % (root, os.path.join(root, "tests"))
+    for kt_from, lens, shapes in (("8192", "[2049, 3000, 4097, 6145, 8191, 8192]", "[(5, 1), (8, 3), (3, 0)]"),
+                                  ("1", "[2, 3, 33, 257, 1024, 2048]", "[(2, 1), (5, 2), (8, 3)]")):
+        r = subprocess.run([sys.executable, "-c", script.replace("LENS", lens).replace("SHAPES", shapes)], env=dict(os.environ, KG_SMALL_KT_FROM=kt_from),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (kt_from, r.stdout[-500:], r.stderr[-2000:])
 
 
 def test_skewed_and_degenerate_inputs(ctx, oracle):
@@ -151,7 +209,7 @@ def test_calls_in_flight_and_commitments(ctx, oracle):
 
 def test_bad_shapes_are_status_codes(ctx):
     L, h = ctx._lib, ctx._h
-    for args in ((9000, 0, -1), (-1, 0, -1), (4096, 1, -1), (4096, 11, -1), (4096, 0, 8), (4096, 0, -2)):
+    for args in ((40000, 0, -1), (-1, 0, -1), (4096, 1, -1), (4096, 11, -1), (4096, 0, 8), (4096, 0, -2)):
         assert L.kg_msm_set_small(h, *args) == -2, args
     assert L.kg_msm_set_small(None, 4096, 0, -1) == -2
     assert L.kg_msm_set_small(h, -2, 0, -1) == 0 and L.kg_msm_set_small(h, 8192, 0, -1) == 0

@@ -51,7 +51,7 @@ def lat(n, reps=8):
 for n in lens:
     ctx.set_msm_small(0)
     base, _ = lat(n)
-    ctx.set_msm_small(8192, 0, -1)
+    ctx.set_msm_small(32768, 0, -1)
     auto, k_auto = lat(n)
     print(f"n = {n:5d}  long pipeline {base:.3f} ms   automatic shape {auto:.3f} ms (kernels {k_auto:.0f} us, host finish {lat.host_us:.0f} us)")
     row = []
@@ -60,7 +60,7 @@ for n in lens:
             if c - 1 - r > 5:
                 continue
             try:
-                ctx.set_msm_small(8192, c, r)
+                ctx.set_msm_small(32768, c, r)
                 ms, k_us = lat(n, reps=4)
             except Exception as e:
                 continue

@@ -15,7 +15,7 @@ b = torch.empty(n * 8, dtype=torch.int64, device=dev)
 ctx.gen_scalars(1 if curve == 1 else 0, 77, 0, n, s.data_ptr())
 ctx.gen_bases(curve, 76, 0, n, b.data_ptr())
 ctx.sync()
-ctx.set_msm_small(8192, c, r)
+ctx.set_msm_small(32768, c, r)
 print(f"n = {n} c = {c} r = {r}", file=sys.stderr)
 for _ in range(6):
     ctx.msm(curve, b.data_ptr(), 0, s.data_ptr(), n)
