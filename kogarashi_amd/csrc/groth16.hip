@@ -431,9 +431,11 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // Short proofs (every MSM within the short-input kernel's reach, msm_small.hip; no window tables at these lengths): no sort, no
   // read-back -- each of the five MSMs is one launch (two from 1537 pairs) on a queue of its own behind z, h's behind its transform chain
   int sc2 = 0, sr2 = 0, sc1 = 0, sr1 = 0, scl = 0, srl = 0, sch = 0, srh = 0;
-  // (proofs in flight: up to 2048 witness entries -- beyond, two proofs' one-launch MSMs fill the chip in turn where the long pipeline's phases
-  // overlap: 2^12 constraints 1.34 ms per proof against 1.18, 2^10 0.71 against 0.97; a blocking proof gains at every length: 2^12 0.97 against 1.38)
-  const size_t small_cap = alone_front ? (size_t)ctx->tune.small_max : (size_t)(ctx->tune.small_max_flight / 2);
+  // A blocking proof gains at every length the kernel takes (2^12 constraints 0.80 ms against 1.38, 2^14 1.33 against 1.49), and so do proofs
+  // in flight whose inputs are complete at the call (kg_ctx_set_inputs_complete: proof i + 1 starts beside proof i -- 2^12 0.57 ms per proof
+  // against 1.17, 2^14 1.11 against 1.26).  Proofs in flight ORDERED behind the caller's queue run one after the other on the device: up
+  // to 2048 witness entries only (beyond, the long pipeline's phases overlap better than five chip-wide launches: 2^13 1.24 ms against 1.52)
+  const size_t small_cap = alone_front || ctx->inputs_complete ? (size_t)ctx->tune.small_max : (size_t)(ctx->tune.small_max_flight / 2);
   const bool small = !tz && nz <= small_cap && hn <= small_cap && (!do_g2 || msm_small_plan(ctx, KG_G2, nz, &sc2, &sr2)) && (!do_g1w || msm_small_plan(ctx, KG_G1, nz, &sc1, &sr1)) &&
                      (!do_g1w || !m_l_1 || msm_small_plan(ctx, KG_G1, m_l_1, &scl, &srl)) && (!(do_h && hn) || msm_small_plan(ctx, KG_G1, hn, &sch, &srh));
   if (small && (do_g2 || do_g1w) && !(mats && do_h)) KG_HIP(ctx, hipEventRecord(ctx->ev_order, sq));      // z is complete

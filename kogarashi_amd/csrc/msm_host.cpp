@@ -415,10 +415,11 @@ int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t*
   ctx->ticket_n[ticket] = n;
   if (n == 0) return KG_OK;
   int sc = 0, sr = 0;
-  // short inputs: one launch, the host chain on a worker thread.  Only up to 4096 pairs for calls in flight: a workgroup of the short-input
-  // kernel owns a CU, from 6144 pairs the grid fills the chip and consecutive calls run one after the other (2^13: 0.24 ms per call against
-  // 0.17 through the long pipeline, whose phases overlap across the tickets; 2^12: 0.16 / 0.17; 2^10: 0.09 / 0.15 -- profiles/r06_small_ab.txt)
-  if (n <= (size_t)ctx->tune.small_max_flight && kg::msm_small_plan(ctx, curve, n, &sc, &sr)) {
+  // short inputs: one launch, the host chain on a worker thread.  Only up to 8192 pairs (G2: 4096) for calls in flight: the kernel's grid
+  // fills the chip at these lengths and consecutive calls run one after the other, where the long pipeline's phases overlap across the
+  // tickets (per call, four in flight, short kernel / long pipeline: 2^10 0.09 / 0.15 ms, 2^12 0.14 / 0.17, 2^13 0.172 / 0.174, 2^14 0.21 / 0.18;
+  // G2 2^12 0.32 / 0.33, 2^13 0.44 / 0.37 -- profiles/r06_small_ab.txt)
+  if (n <= (size_t)(curve == KG_G2 ? ctx->tune.small_max_flight / 2 : ctx->tune.small_max_flight) && kg::msm_small_plan(ctx, curve, n, &sc, &sr)) {
     if (ctx->ticket_fut[ticket].valid()) ctx->ticket_fut[ticket].wait();
     KG_TRY(kg::msm_small_enqueue(ctx, ctx->stream, curve, d_bases, d_inf, d_scalars, n, 1 + ticket, sc, sr));
     uint64_t* out = ctx->ticket_out[ticket];

@@ -1,5 +1,5 @@
 """The short-input MSM (csrc/msm_small.hip: one launch up to 1536 pairs, two or three above; blocking kg_msm / kg_msm_host / kg_commit take it
-for n <= 32768 by default, kg_msm_begin for n <= 4096) against the oracle's restatement of msm_curve_addition (groth16/src/msm.rs:6-48) -- at the lengths the
+for n <= 32768 by default, kg_msm_begin for n <= 8192) against the oracle's restatement of msm_curve_addition (groth16/src/msm.rs:6-48) -- at the lengths the
 reference's own tests and bench use (msm.rs:118-135: 32 pairs; bn254/benches: 2^10), every length 1 .. 64, every window width and
 bucket-range shape the knob admits, all three curves, the edge mixes, maximally skewed inputs, and against the long pipeline."""
 import numpy as np
@@ -121,6 +121,29 @@ def test_the_form_with_scalars_converted_once_up_to_2_15_pairs(ctx, oracle):
         ctx.set_msm_small(SMALL_DEFAULT, 0, -1)
 
 
+def test_g2_up_to_its_longest_short_input(ctx, oracle):
+    """G2 beyond the lengths the oracle's scalar multiplication makes bases for in seconds: generator multiples from kg_fixed_base_mul
+    (== the oracle's scalar_point, tests/test_gpu_groth16.py), one identity with its flag; 2049 .. 20480 pairs (the form with converted
+    scalars; 20480 is msm_small_plan's longest G2 input, 20481 the long pipeline's), witness-like scalars at one length"""
+    import kogarashi_amd as K
+    from test_gpu_large import _g2_bases as dev_g2_bases, _witness_like
+    O = oracle
+    for n in (1537, 2049, 6000, 16385, 20480, 20481):
+        dxy, dinf = dev_g2_bases(ctx, O, n, SEED + 980 + n)
+        scal = O.gen_scalars(0, SEED + 981 + n, 0, n)
+        if n == 6000:
+            scal = _witness_like(O, scal, 6)
+        ds = ctx.upload(scal)
+        wxy, winf = O.to_affine("g2", O.msm("g2", dxy.numpy(), scal, dinf.numpy(), threads=8))
+        got = ctx.msm(K.KG_G2, dxy.ptr, dinf.ptr, ds.ptr, n)
+        assert not winf and (got[:16] == wxy).all(), n
+        ctx.set_msm_small(0)
+        try:
+            assert (ctx.msm(K.KG_G2, dxy.ptr, dinf.ptr, ds.ptr, n) == got).all(), n
+        finally:
+            ctx.set_msm_small(SMALL_DEFAULT)
+
+
 def test_both_forms_over_each_others_lengths(oracle):
     """KG_SMALL_KT_FROM moves the length from which the scalars are converted once: at 8192 the workgroups convert them themselves up to
     8192 pairs (the form the short lengths run, with its 13-bit index field full), at 1 the word planes serve every length from 2 pairs"""
@@ -212,4 +235,4 @@ def test_bad_shapes_are_status_codes(ctx):
     for args in ((40000, 0, -1), (-1, 0, -1), (4096, 1, -1), (4096, 11, -1), (4096, 0, 8), (4096, 0, -2)):
         assert L.kg_msm_set_small(h, *args) == -2, args
     assert L.kg_msm_set_small(None, 4096, 0, -1) == -2
-    assert L.kg_msm_set_small(h, -2, 0, -1) == 0 and L.kg_msm_set_small(h, 8192, 0, -1) == 0
+    assert L.kg_msm_set_small(h, -2, 0, -1) == 0 and L.kg_msm_set_small(h, SMALL_DEFAULT, 0, -1) == 0
