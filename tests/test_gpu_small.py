@@ -236,3 +236,12 @@ def test_bad_shapes_are_status_codes(ctx):
         assert L.kg_msm_set_small(h, *args) == -2, args
     assert L.kg_msm_set_small(None, 4096, 0, -1) == -2
     assert L.kg_msm_set_small(h, -2, 0, -1) == 0 and L.kg_msm_set_small(h, SMALL_DEFAULT, 0, -1) == 0
+
+
+def test_randomised_lengths_shapes_and_patterns_against_the_long_pipeline():
+    """tools/dbg/stress_small.py: 300 random (curve, length 1 .. 32768, window of the stored bases, scalar pattern, identity flags) cases,
+    each through the automatic shape and two random (c, r) shapes, blocking and three in flight, against the long pipeline's point"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg", "stress_small.py"), "300", "606"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
