@@ -7,6 +7,7 @@
 // three proof points touch the host, which also runs the six short scalar multiplications of the assembly
 // (sequential double-and-add, as in the reference).
 #include "common.h"
+#include "msm_internal.h"
 #include <chrono>
 #include "host_fp.h"
 #include <future>
@@ -314,8 +315,22 @@ int kg_fixed_base_mul(kg_ctx* ctx, int curve, const uint64_t* d_k, size_t n, uin
 }  // extern "C"
 
 namespace {
+// The blinding terms of prover.rs:75-77 -- five scalar multiplications of CRS points by r, s and r s that depend on no MSM result: three
+// 255-step chains on worker threads (the G2 one three times as long as a G1 one), started when the proof is ENQUEUED (until round 5 by the
+// assembly, i.e. behind the ~0.1 ms of launches of a short proof, whose critical path they were: 0.25 ms of Fq2 doublings).
+struct Blinding {
+  XYZZ<HostFq> g_a, rs_delta, sa_rb;         // r delta1 + alpha (:75), r s delta1 and s alpha + r beta1 (:77)
+  XYZZ<HostFq2> g_b;                         // s delta2 + beta2 (:76)
+  HostFr rk, sk;                             // r, s out of Montgomery form
+  std::future<int> t[3];
+  bool started = false;
+  void wait() { for (std::future<int>& f : t) if (f.valid()) f.wait(); }
+  ~Blinding() { wait(); }                    // the tasks write into this object
+};
+void start_blinding(WorkerPool* workers, const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t* ss, Blinding* bl);
 // One proof in flight: everything the host side needs between "all device work enqueued" and "proof read".
 struct ProofJob {
+  Blinding blind;
   uint64_t q_p[12], l_p[12], ai[12], b1i[12], b2i[24];
   std::future<int> f_q, f_l, f_a, f_b1, f_b2, assembly;
   uint64_t proof[32];
@@ -351,7 +366,7 @@ static bool g16_h_early_pipelined() {                     // KG_G16_H_EARLY_PIPE
   return tuning().g16_h_early_pipe != 0;
 }
 int assemble_proof(WorkerPool* workers, const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t* ss, int rc0, ProofJob* j_g2, ProofJob* j_g1w, ProofJob* j_h,
-                   uint64_t* proof, uint8_t* inf);
+                   uint64_t* proof, uint8_t* inf, Blinding* early = nullptr);
 int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_eval, const uint64_t* d_b_eval,
                   const uint64_t* d_c_eval, const uint64_t* d_x, const uint64_t* d_w, const uint64_t* r,
                   const uint64_t* s, ProofJob* job, int slot_base, const kg_csr* const* mats = nullptr, int roles = ROLE_ALL,
@@ -367,6 +382,11 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   const size_t m = crs->m, l = crs->l, m_l_1 = crs->m_l_1;
   if (m < 1 || l < 1 || (need_z && m_l_1 && !d_w)) return KG_ERR_BAD_ARG;
   KG_HIP(ctx, hipSetDevice(ctx->device));
+  if (roles == ROLE_ALL && !defer_assembly) {             // the blinding terms first: three host chains that need nothing from the device
+    job->blind.wait();
+    job->blind.started = false;
+    if (!(crs->delta_g1_inf || crs->delta_g2_inf)) start_blinding(&pool(ctx), *crs, r, s, &job->blind);
+  }
   uint32_t k = 0;
   size_t n = 1;
   while (n < m) { n <<= 1; ++k; }                       // cs.m().next_power_of_two() (prover.rs:28-29)
@@ -449,6 +469,21 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   auto hip_rc = [&](hipError_t e, const char* what) {
     if (e != hipSuccess && rc == KG_OK) rc = set_err(ctx, e == hipErrorOutOfMemory ? KG_ERR_OOM : KG_ERR_HIP, what, e);
   };
+  uint64_t *q_p = job->q_p, *l_p = job->l_p, *ai = job->ai, *b1i = job->b1i, *b2i = job->b2i;
+  std::future<int>&f_q = job->f_q, &f_l = job->f_l, &f_a = job->f_a, &f_b1 = job->f_b1, &f_b2 = job->f_b2;
+  auto finish_async = [&](int curve, int slot, uint64_t* out) {
+    return pool(ctx).submit([ctx, curve, slot, out] { return msm_finish(ctx, curve, slot, out); });
+  };
+  // result slots: consecutive MSMs alternate between the two reduction queues (slot parity), each with run space of
+  // its own (slot mod 8); measured against giving G2's long reduction a queue of its own: 3.67 vs 3.84 ms per proof
+  const int SL[5] = {slot_base + 1, slot_base + 2, slot_base + 3, slot_base + 4, slot_base + 5};
+  // (from the first finish_async on host finishes may be running on worker threads: no early return below -- failures travel through rc)
+  if (small && do_g2) {
+    // a short proof's long pole, issued first: b_g2's one-launch MSM (Fq2 on the device) on the scalar queue right behind z, its host
+    // chain (255 doublings in Fq2, ~170 us -- three G1 chains) on a worker thread while this thread is still enqueuing the transforms
+    rc = msm_small_enqueue(ctx, sq, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, Z, nz, SL[0], sc2, sr2);
+    if (rc == KG_OK) f_b2 = finish_async(KG_G2, SL[0], b2i);
+  }
   const uint64_t* src[3] = {d_a_eval, d_b_eval, d_c_eval};
   uint64_t* dst[3] = {A, B, C};
   // the chains share the two reduction queues (queues of their own: 3.31 ms per proof against 2.83 -- transforms and halving
@@ -472,14 +507,6 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // q keeps its trailing zeros: zero scalars are skipped by the MSM, which is what Coefficients::new's trimming plus zip
   // achieves in the reference (poly.rs:61-63, msm.rs:25).  Each MSM's 255-step host finish runs on a worker thread while the
   // device continues with the next one.
-  uint64_t *q_p = job->q_p, *l_p = job->l_p, *ai = job->ai, *b1i = job->b1i, *b2i = job->b2i;
-  std::future<int>&f_q = job->f_q, &f_l = job->f_l, &f_a = job->f_a, &f_b1 = job->f_b1, &f_b2 = job->f_b2;
-  auto finish_async = [&](int curve, int slot, uint64_t* out) {
-    return pool(ctx).submit([ctx, curve, slot, out] { return msm_finish(ctx, curve, slot, out); });
-  };
-  // result slots: consecutive MSMs alternate between the two reduction queues (slot parity), each with run space of
-  // its own (slot mod 8); measured against giving G2's long reduction a queue of its own: 3.67 vs 3.84 ms per proof
-  const int SL[5] = {slot_base + 1, slot_base + 2, slot_base + 3, slot_base + 4, slot_base + 5};
   // Order of the main queue (h_early, the default since round 4): G2 accumulation, h's point-wise step and coset_idft, the fused G1
   // accumulation with h's sort beside it, h's accumulation directly behind.  Up to round 3 h's whole chain went LAST (the point-wise
   // step, coset_idft, h's sort, h's MSM: ~1.4 ms in a row behind the G1 accumulation, on a chip that only the reductions used)
@@ -514,11 +541,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   };
   const bool early = h_early && do_h && hn && (do_g2 || do_g1w) && !small;
   if (small && (do_g2 || do_g1w)) {
-    // b_g2 (the long pole: Fq2 on the device and in the host chain) on the scalar queue right behind z; a, b_g1 and l on queues of their own
-    if (do_g2) {
-      rc = msm_small_enqueue(ctx, sq, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, Z, nz, SL[0], sc2, sr2);
-      if (rc == KG_OK) f_b2 = finish_async(KG_G2, SL[0], b2i);
-    }
+    // (b_g2 went out in front of the transform chains); a, b_g1 and l on queues of their own
     if (do_g1w) {
       struct { const uint64_t* b; const uint8_t* inf; const uint64_t* sc; size_t n; int slot, c, r; uint64_t* out; std::future<int>* f; } q3[3] = {
           {crs->d_a, crs->d_a_inf, Z, nz, SL[1], sc1, sr1, ai, &f_a}, {crs->d_b_g1, crs->d_b_g1_inf, Z, nz, SL[2], sc1, sr1, b1i, &f_b1},
@@ -582,45 +605,49 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   if (defer_assembly) return KG_OK;
   const kg_groth16_crs vk = *crs;                       // the host-resident part (alpha, beta, delta) is read by value
   WorkerPool* wp = &pool(ctx);
-  job->assembly = wp->submit([job, vk, wp]() -> int { return assemble_proof(wp, vk, job->rr, job->ss, job->rc0, job, job, job, job->proof, job->inf); });
+  job->assembly = wp->submit([job, vk, wp]() -> int { return assemble_proof(wp, vk, job->rr, job->ss, job->rc0, job, job, job, job->proof, job->inf, &job->blind); });
   return KG_OK;
 }
 
+void start_blinding(WorkerPool* workers, const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t* ss, Blinding* bl) {
+  bl->wait();                                            // (tasks of a proof that failed while it was enqueued)
+  const HostFr rm = HostFr::from_words(rr), sm = HostFr::from_words(ss), raw_one{{1, 0, 0, 0}};
+  const HostFr rk = mul(rm, raw_one), sk = mul(sm, raw_one), rsk = mul(mul(rm, sm), raw_one);   // out of Montgomery form
+  bl->rk = rk; bl->sk = sk;
+  bl->started = true;
+  const XYZZ<HostFq> alpha = from_affine(h_load_aff<HostFq, 4>(vk.alpha_g1)), beta1 = from_affine(h_load_aff<HostFq, 4>(vk.beta_g1)),
+                     delta1 = from_affine(h_load_aff<HostFq, 4>(vk.delta_g1));
+  const XYZZ<HostFq2> beta2 = from_affine(h_load_aff<HostFq2, 8>(vk.beta_g2)), delta2 = from_affine(h_load_aff<HostFq2, 8>(vk.delta_g2));
+  auto chain_b = [bl, delta2, beta2, sk]() -> int { bl->g_b = add_xyzz(h_scalar_mul(delta2, sk.v), beta2); return KG_OK; };              // :76
+  auto chain_a = [bl, delta1, alpha, rk, rsk]() -> int {                                                                                  // :75, first term of :77
+    bl->g_a = add_xyzz(h_scalar_mul(delta1, rk.v), alpha);
+    bl->rs_delta = h_scalar_mul(delta1, rsk.v);
+    return KG_OK;
+  };
+  auto chain_c = [bl, alpha, beta1, sk, rk]() -> int { bl->sa_rb = h_scalar_mul2(alpha, sk.v, beta1, rk.v); return KG_OK; };             // s alpha + r beta1 (:77)
+  // the longest first; a chain no thread is to be had for runs here, in a row
+  int on_pool = 0;
+  if (workers) {
+    try { bl->t[0] = workers->submit(chain_b); ++on_pool; bl->t[1] = workers->submit(chain_a); ++on_pool; bl->t[2] = workers->submit(chain_c); ++on_pool; } catch (...) {}
+  }
+  if (on_pool < 1) chain_b();
+  if (on_pool < 2) chain_a();
+  if (on_pool < 3) chain_c();
+}
+
 // prover.rs:75-92 on the host.  The five MSM sums may come from up to three jobs (one per context of a sharded proof):
-// j_g2 holds b2i, j_g1w holds ai / b1i / l_p, j_h holds q_p, each with the futures of its host finishes.
-// The blinding terms (:75-77) are five scalar multiplications that depend on no MSM result -- a 255-step chain each on the host, the G2
-// one three times as long as a G1 one: they run on worker threads beside each other (the G2 chain | r delta1 and r s delta1 | s alpha +
-// r beta1 as ONE chain on this thread), 0.2 ms instead of 0.44 in a row -- which was the whole critical path of a short proof.
+// j_g2 holds b2i, j_g1w holds ai / b1i / l_p, j_h holds q_p, each with the futures of its host finishes.  early: the blinding terms a
+// single-context proof started when it was enqueued; a sharded proof starts them here.
 int assemble_proof(WorkerPool* workers, const kg_groth16_crs& vk, const uint64_t* rr, const uint64_t* ss, int rc0, ProofJob* j_g2, ProofJob* j_g1w, ProofJob* j_h,
-                   uint64_t* proof, uint8_t* inf) {
+                   uint64_t* proof, uint8_t* inf, Blinding* early) {
   int rc = rc0;
   uint64_t *q_p = j_h->q_p, *l_p = j_g1w->l_p, *ai = j_g1w->ai, *b1i = j_g1w->b1i, *b2i = j_g2->b2i;
-  HostFr rm = HostFr::from_words(rr), sm = HostFr::from_words(ss);
-  HostFr raw_one{{1, 0, 0, 0}};
-  HostFr rk = mul(rm, raw_one), sk = mul(sm, raw_one), rsk = mul(mul(rm, sm), raw_one);   // out of Montgomery form
-  XYZZ<HostFq> alpha = from_affine(h_load_aff<HostFq, 4>(vk.alpha_g1)), beta1 = from_affine(h_load_aff<HostFq, 4>(vk.beta_g1)),
-               delta1 = from_affine(h_load_aff<HostFq, 4>(vk.delta_g1));
-  XYZZ<HostFq2> beta2 = from_affine(h_load_aff<HostFq2, 8>(vk.beta_g2)), delta2 = from_affine(h_load_aff<HostFq2, 8>(vk.delta_g2));
   const bool bad_delta = vk.delta_g1_inf || vk.delta_g2_inf;
+  Blinding local;
+  Blinding* bl = early && early->started ? early : &local;
+  if (rc == KG_OK && !bad_delta && !bl->started) start_blinding(workers, vk, rr, ss, bl);
   XYZZ<HostFq> g_a = XYZZ<HostFq>::identity(), g_c = g_a;
   XYZZ<HostFq2> g_b = XYZZ<HostFq2>::identity();
-  if (rc == KG_OK && !bad_delta) {
-    XYZZ<HostFq> rs_delta = XYZZ<HostFq>::identity();
-    std::future<int> t_b, t_a;
-    auto chain_b = [&]() -> int { g_b = add_xyzz(h_scalar_mul(delta2, sk.v), beta2); return KG_OK; };                                   // :76
-    auto chain_a = [&]() -> int { g_a = add_xyzz(h_scalar_mul(delta1, rk.v), alpha); rs_delta = h_scalar_mul(delta1, rsk.v); return KG_OK; };   // :75, first term of :77
-    bool par_b = false, par_a = false;
-    if (workers) {
-      try { t_b = workers->submit(chain_b); par_b = true; t_a = workers->submit(chain_a); par_a = true; } catch (...) {}      // no thread to be had: in a row, here
-    }
-    WaitAll chains_done{&t_b, 1}, chains_done2{&t_a, 1};
-    const XYZZ<HostFq> sa_rb = h_scalar_mul2(alpha, sk.v, beta1, rk.v);                                                                   // s alpha + r beta1 (:77)
-    if (!par_b) chain_b();
-    if (!par_a) chain_a();
-    if (t_b.valid()) t_b.get();
-    if (t_a.valid()) t_a.get();
-    g_c = add_xyzz(rs_delta, sa_rb);                                                                                                       // :77
-  }
   auto join = [&](std::future<int>& f) { if (f.valid()) { int r2 = f.get(); if (rc == KG_OK) rc = r2; } };
   auto g1pt = [](const uint64_t* xyz) {
     bool pinf = !(xyz[8] | xyz[9] | xyz[10] | xyz[11]);
@@ -634,25 +661,35 @@ int assemble_proof(WorkerPool* workers, const kg_groth16_crs& vk, const uint64_t
   // everything that does not need h's MSM is assembled while the device is still working on it -- s A + r B1 (another 255-step chain) as soon
   // as the two G1 sums are there, under the G2 MSM's host finish (three times a G1 one: the last of the four to arrive)
   join(j_g1w->f_a); join(j_g1w->f_b1);
+  host_trace("proof: a, b1 in");
   XYZZ<HostFq> sa_rb1 = XYZZ<HostFq>::identity();
-  if (rc == KG_OK && !bad_delta) {
-    const XYZZ<HostFq> a_ans = g1pt(ai), b1_ans = g1pt(b1i);
-    g_a = add_xyzz(g_a, a_ans);                                                                          // :81
-    sa_rb1 = h_scalar_mul2(a_ans, sk.v, b1_ans, rk.v);                                                   // :83,90
+  const bool go = rc == KG_OK && !bad_delta;
+  if (go) sa_rb1 = h_scalar_mul2(g1pt(ai), bl->sk.v, g1pt(b1i), bl->rk.v);                               // s * a_answer + r * b1_answer (:83,90), under the blinding chains
+  host_trace("proof: sA + rB1");
+  bl->wait();
+  host_trace("proof: chains done");
+  if (go) {
+    g_a = add_xyzz(bl->g_a, g1pt(ai));                                                                   // :81
     h_store_affine<HostFq, 4>(g_a, proof, inf);
+    g_b = bl->g_b;
+    g_c = add_xyzz(bl->rs_delta, bl->sa_rb);                                                             // :77
   }
   join(j_g1w->f_l); join(j_g2->f_b2);
+  host_trace("proof: l, b2 in");
   if (rc == KG_OK && !bad_delta) {
     g_b = add_xyzz(g_b, g2pt(b2i));                                                                      // :88
     g_c = add_xyzz(g_c, sa_rb1);
     g_c = add_xyzz(g_c, g1pt(l_p));                                                                      // :92 (l part)
     h_store_affine<HostFq2, 8>(g_b, proof + 8, inf + 1);
   }
+  host_trace("proof: B stored");
   join(j_h->f_q);
+  host_trace("proof: h in");
   if (rc != KG_OK) return rc;
   if (bad_delta) return KG_ERR_CRS;                     // prover.rs:67-69 (the message is set by prove_collect, on the caller's thread)
   g_c = add_xyzz(g_c, g1pt(q_p));                                                                        // :92 (h part)
   h_store_affine<HostFq, 4>(g_c, proof + 24, inf + 2);
+  host_trace("proof: assembled");
   return KG_OK;
 }
 
@@ -677,7 +714,9 @@ int kg_groth16_prove_bn254(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_
   if (!ctx || !proof_out || !proof_inf) return KG_ERR_BAD_ARG;
   ProofJob* job = job_of(ctx, 0);
   if (job->active) return KG_ERR_BAD_ARG;                // a proof begun with ticket 0 has not been collected
+  host_trace("proof: enter");
   KG_TRY(prove_enqueue(ctx, crs, d_a_eval, d_b_eval, d_c_eval, d_x, d_w, r, s, job, 5, nullptr, ROLE_ALL, false, g16_h_early(), true));
+  host_trace("proof: enqueued");
   return prove_collect(ctx, job, proof_out, proof_inf);
   });
 }
