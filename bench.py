@@ -677,7 +677,7 @@ def bench_msm_g2(ctx, torch, dev, K, env, log_n=18, steps=10, rounds=3, cpu=Fals
 
 def bench_small(ctx, torch, dev, K):
     """Short BLOCKING calls, the sizes the reference's own tests and BASELINE configs[0] live at (groth16/src/msm.rs:118-135: 32 pairs;
-    bn254/benches: 2^10; groth16/src/lib.rs:29-77: a handful of constraints): latency of kg_msm on resident arrays for n = 16 ... 2^12 on
+    bn254/benches: 2^10; groth16/src/lib.rs:29-77: a handful of constraints): latency of kg_msm on resident arrays for n = 16 ... 2^14 on
     the three curves, and a blocking proof of 2^10 constraints.  Median of five rounds of eight calls."""
     import numpy as np
     out = {"msm_blocking_ms": {}, "grumpkin_blocking_ms": {}, "g2_blocking_ms": {}}
@@ -692,14 +692,14 @@ def bench_small(ctx, torch, dev, K):
                 fn()
             rr.append((time.perf_counter() - t0) / reps * 1e3)
         return r3(sorted(rr)[2])
-    nmax = 1 << 12
+    nmax = 1 << 14
     for name, curve, fld in (("msm_blocking_ms", K.KG_G1, K.KG_FR), ("grumpkin_blocking_ms", K.KG_GRUMPKIN, K.KG_FQ)):
         b = torch.empty(nmax * 8, dtype=torch.int64, device=dev)
         s = torch.empty(nmax * 4, dtype=torch.int64, device=dev)
         ctx.gen_bases(curve, SEED + 80, 0, nmax, b.data_ptr())
         ctx.gen_scalars(fld, SEED + 81, 0, nmax, s.data_ptr())
         ctx.sync()
-        for nn in ((16, 32, 256, 1024, 4096) if curve == K.KG_G1 else (32, 1024)):
+        for nn in ((16, 32, 256, 1024, 4096, 16384) if curve == K.KG_G1 else (32, 1024)):
             out[name][str(nn)] = lat(lambda: ctx.msm(curve, b.data_ptr(), 0, s.data_ptr(), nn))
         del b, s
     k = torch.empty(1024 * 4, dtype=torch.int64, device=dev)
