@@ -23,6 +23,7 @@ means is in DESIGN.md section 8.
 Profiling aids (tools/collect_profiles.sh): --headline-only (pre-warm, warm-up and the timed rounds, nothing else: the
 k_acc_tasks average of a kernel trace of this command is roofline.kernel_ms), --ntt-only, --msm-g2-only, --groth16-only."""
 import argparse
+import gc
 import json
 import os
 import sys
@@ -102,6 +103,7 @@ def timed_rounds(env, fn, steps, rounds):
     """`rounds` timed rounds of fn(steps), each bracketed by the rank barrier + device synchronisation, max over ranks per round;
     returns (median seconds per round, [ms per step of every round], the last result)"""
     out, res = [], None
+    gc.collect()
     for _ in range(rounds):
         env["barrier"]()
         t0 = time.perf_counter()
@@ -117,6 +119,7 @@ def bench_msm_strong(ctx, torch, dev, K, env, log_n, steps):
     rank runs a BLOCKING kg_msm on its contiguous slice (2^log_n / N pairs: latency-bound below ~2^18) and the N affine partial sums
     meet in one all_gather of 9 words per rank (kogarashi_amd/dist.py) -- strong scaling of a fixed job, beside the weak-scaled headline.
     Unmeasured on multi-GPU hardware until the driver has an 8-GPU node; the point is the same for every N (tests/test_gpu_bench_multirank.py)."""
+    gc.collect()
     from kogarashi_amd.lib import shard_range
     world, rank, kdist, xdev = env["world"], env["rank"], env["kdist"], env["xdev"]
     total = 1 << log_n
@@ -229,6 +232,9 @@ def main():
     ap.add_argument("--prewarm", type=int, default=200, help="untimed steps before the W warm-up steps (first touch, clock ramp)")
     ap.add_argument("--stream-ordered-inputs", action="store_true", help="do not declare the (static, synchronised) inputs complete")
     args = ap.parse_args()
+    # like timeit: no cyclic garbage collection inside timed loops (a generation-2 pass is a 30-40 ms pause that lands in whichever call
+    # happens to allocate the object that triggers it -- tools/dbg/anom_1024.py); every leg collects before it starts its clock
+    gc.disable()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if args.rounds < 1:
@@ -600,6 +606,7 @@ def bench_msm_g2(ctx, torch, dev, K, env, log_n=18, steps=10, rounds=3, cpu=Fals
     four in flight and blocking.  160 algorithmic bytes per pair; the dominant kernel is k_acc_tasks<Fq2> (250 VGPRs, two
     waves per SIMD), timed alone (one launch per MSM) for `roofline.isolated` and `valu_roofline`.  CPU leg: the oracle's Pippenger
     restatement on the same pairs, which also checks the GPU point."""
+    gc.collect()
     import numpy as np
     world, rank = env["world"], env["rank"]
     n = 1 << log_n
@@ -679,6 +686,7 @@ def bench_small(ctx, torch, dev, K):
     """Short BLOCKING calls, the sizes the reference's own tests and BASELINE configs[0] live at (groth16/src/msm.rs:118-135: 32 pairs;
     bn254/benches: 2^10; groth16/src/lib.rs:29-77: a handful of constraints): latency of kg_msm on resident arrays for n = 16 ... 2^14 on
     the three curves, and a blocking proof of 2^10 constraints.  Median of five rounds of eight calls."""
+    gc.collect()
     import numpy as np
     out = {"msm_blocking_ms": {}, "grumpkin_blocking_ms": {}, "g2_blocking_ms": {}}
 
@@ -747,6 +755,7 @@ def bench_ntt(ctx, torch, dev, K, env, log_n=22, steps=10, warmup=100, variants=
     other three transforms of groth16/src/fft.rs:100-127 (idft, coset_dft, coset_idft: the n^-1 scale and the coset shifts are fused
     into the first load / last store of the same kernels) at the same size.  The transform does not shard (it would need an
     all-to-all transpose): with N ranks every rank transforms its own vector (replicas) and `value` is the aggregate."""
+    gc.collect()
     world, rank = env["world"], env["rank"]
     n = 1 << log_n
     data = torch.empty(n * 4, dtype=torch.int64, device=dev)
@@ -817,6 +826,7 @@ def bench_nova_commit(ctx, torch, dev, K, env, log_n=24, cpu=False, steps=5, ske
     g is fixed by PedersenCommitment::new, so it is registered (resident internal form) like a CRS vector.
     CPU legs (N = 1 only): the reference's naive fold timed on a prefix and extrapolated (2^24 of it would take hours), and
     the oracle's Pippenger restatement (msm_curve_addition) on all 2^24 pairs -- which also checks the GPU point."""
+    gc.collect()
     import numpy as np
     from kogarashi_amd.lib import shard_range
     world, rank, kdist, xdev = env["world"], env["rank"], env["kdist"], env["xdev"]
@@ -1037,6 +1047,7 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
     """secondary line: Groth16 prove at m = 2^log_m constraints (BASELINE.json configs[3]).  Circuit: the chain
     t_{i+1} = t_i * (t_i + 1) (x = [1, t_0], w = t_1..t_m); CRS:
     a real CRS from a fixed toxic waste, generated on the device; fixed (r, s).  The CPU leg runs the oracle's create_proof on the same inputs and compares the proof."""
+    gc.collect()
     import numpy as np
     from kogarashi_amd.lib import Groth16Crs
     world, sync, mx = env["world"], env["barrier"], env["max_over_ranks"]     # N ranks: one prover per rank (replicas), aggregate proofs/s

@@ -403,6 +403,8 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
   }
   if (a.NB > 1) {                                           // a bucket range of a split window: the planes go to global memory
     if (tid < np) PointAoS<F>::store(my_planes + (size_t)tid * NW, 0, PointIO<F>::load(pts, CAP, fin + tid));
+    KG_SM_STAMP(6);                                         // (a split window: "combine" is the planes' store, the second launch is not in the stamps)
+    KG_SM_STAMP(7);
     return;
   }
   sm_combine_planes<F>(pts + fin, CAP, ctmp, cflg, np);

@@ -1,9 +1,10 @@
 """Groth16 proof time against the constraint count (chain circuit, device setup): python tools/dbg/g16_sizes.py 8 10 12 ..."""
-import os, sys
+import gc, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import kogarashi_amd as K
 K.init()
+gc.disable()         # no cyclic collection inside a timed loop (a 35 ms pause: tools/dbg/anom_1024.py)
 import bench
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 ctx = K.Context(0)

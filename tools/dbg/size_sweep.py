@@ -1,11 +1,12 @@
 """Blocking kg_msm and the four-deep pipelined step over a ladder of lengths (powers of two and the points between), G1, unregistered bases:
 cliffs in ms per pair point at thresholds of the automatic choices (window, sort form, window groups, slices).  usage: size_sweep.py [lo hi]"""
-import os, sys, time
+import gc, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import kogarashi_amd as K
 from kogarashi_amd import lib as LIB
 K.init()
+gc.disable()         # no cyclic collection inside a timed loop (a 35 ms pause: tools/dbg/anom_1024.py)
 SEED = 0x4B6F676172617368
 ctx = K.Context(0)
 ctx.set_inputs_complete(True)

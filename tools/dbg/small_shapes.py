@@ -1,11 +1,12 @@
 """Latency of the short-input MSM (csrc/msm_small.hip) against its shape: python tools/dbg/small_shapes.py [curve] -> for every length the blocking
 kg_msm time (median of 5 rounds of 8), the kernels' HIP-event time and the host finish, for every window width c and bucket range r."""
-import os, sys, time
+import gc, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import kogarashi_amd as K
 K.init()
+gc.disable()         # no cyclic collection inside a timed loop (a 35 ms pause: tools/dbg/anom_1024.py)
 curve = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 lens = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192]
 dev = torch.device("cuda", 0)
