@@ -219,7 +219,7 @@ int kg_msm_set_window(kg_ctx* ctx, int c);
  * 1 = none (one accumulation launch per MSM), 2 .. 4.  Results are bit-identical for every setting. */
 int kg_msm_set_groups(kg_ctx* ctx, int groups);
 /* Tuning knob: the short-input MSM (csrc/msm_small.hip).  Blocking MSMs of up to max_pairs pairs (default and most: 32768, G2: 20480; 0 = never;
- * calls in flight and proofs in flight: KG_SMALL_MAX_FLIGHT) run as
+ * kg_msm_begin: KG_SMALL_MAX_FLIGHT, 8192) run as
  * ONE launch -- a workgroup per window: digits, an LDS counting sort, bucket accumulation, the bucket reduction and the window sum in
  * LDS -- two launches from 1537 pairs (a window's buckets spread over several workgroups), three from 2049 (the scalars are converted
  * once, into word planes, for all workgroups); the host finishes with one addition per window.  These are the lengths of the reference's own tests and bench (groth16/src/msm.rs:118-135: 32 pairs; bn254/benches: 2^10).

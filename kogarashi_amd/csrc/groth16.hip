@@ -452,10 +452,9 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // read-back -- each of the five MSMs is one launch (two from 1537 pairs) on a queue of its own behind z, h's behind its transform chain
   int sc2 = 0, sr2 = 0, sc1 = 0, sr1 = 0, scl = 0, srl = 0, sch = 0, srh = 0;
   // A blocking proof gains at every length the kernel takes (2^12 constraints 0.80 ms against 1.38, 2^14 1.33 against 1.49), and so do proofs
-  // in flight whose inputs are complete at the call (kg_ctx_set_inputs_complete: proof i + 1 starts beside proof i -- 2^12 0.57 ms per proof
-  // against 1.17, 2^14 1.11 against 1.26).  Proofs in flight ORDERED behind the caller's queue run one after the other on the device: up
-  // to 2048 witness entries only (beyond, the long pipeline's phases overlap better than five chip-wide launches: 2^13 1.24 ms against 1.52)
-  const size_t small_cap = alone_front || ctx->inputs_complete ? (size_t)ctx->tune.small_max : (size_t)(ctx->tune.small_max_flight / 2);
+  // in flight: proof i + 1 starts beside proof i (inputs complete at the call: 2^12 0.57 ms per proof against 1.17, 2^14 1.11 against 1.26; ordered
+  // behind the caller's queue, with h's chain on a queue of the library's own -- see hq below: 2^12 0.69 against 1.18, 2^14 1.19 against 1.37)
+  const size_t small_cap = (size_t)ctx->tune.small_max;
   const bool small = !tz && nz <= small_cap && hn <= small_cap && (!do_g2 || msm_small_plan(ctx, KG_G2, nz, &sc2, &sr2)) && (!do_g1w || msm_small_plan(ctx, KG_G1, nz, &sc1, &sr1)) &&
                      (!do_g1w || !m_l_1 || msm_small_plan(ctx, KG_G1, m_l_1, &scl, &srl)) && (!(do_h && hn) || msm_small_plan(ctx, KG_G1, hn, &sch, &srh));
   if (small && (do_g2 || do_g1w) && !(mats && do_h)) KG_HIP(ctx, hipEventRecord(ctx->ev_order, sq));      // z is complete
@@ -515,8 +514,17 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // neither holds.  Measured: blocking proof 3.34 -> 3.18 ms, two in flight 2.91 -> 2.86 ms (same box, alternating runs).
   MsmSorted Sq;
   bool h_sorted = false;
+  // The queue of h's point-wise step, coset_idft and MSM: the main queue -- except for a SHORT proof in flight ordered behind the caller's queue
+  // (no kg_ctx_set_inputs_complete): with h's chain on the main queue the next proof's fork event would sit behind it and the device would run
+  // the proofs one after the other (2^10 constraints: 0.75 ms per proof against 0.59 blocking; now 0.48); on a queue of the library's own, behind the
+  // fork event like every other part of the proof, the caller's queue carries nothing of ours and proof i + 1 starts beside proof i.
+  hipStream_t hq = st;
+  if (small && fork && !alone_front && do_h) {
+    if (!ctx->acc_stream[0]) hip_rc(create_stream(ctx, &ctx->acc_stream[0], false), "queue creation");
+    if (ctx->acc_stream[0]) { hq = ctx->acc_stream[0]; hip_rc(hipStreamWaitEvent(hq, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)"); }
+  }
   auto h_front = [&]() {                                  // h = (a o b - c) / Z on the coset, back to coefficients (prover.rs:43-47)
-    for (int v = 1; v < 3; ++v) hip_rc(hipStreamWaitEvent(st, ctx->ev_join[v], 0), "hipStreamWaitEvent(join)");   // chain 0 shares chain 2's queue, in front of it
+    for (int v = 1; v < 3; ++v) hip_rc(hipStreamWaitEvent(hq, ctx->ev_join[v], 0), "hipStreamWaitEvent(join)");   // chain 0 shares chain 2's queue, in front of it
     HostFr seven = HostFr::one();                         // (7^n - 1)^-1 on the host: n = 2^k squarings of 7
     {
       HostFr one = HostFr::one(), acc = HostFr::zero();
@@ -528,9 +536,9 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
     z = inv(sub<4, 1>(z, HostFr::one()));                 // z_on_coset().invert() (fft.rs:141-151)
     Words8 zw;
     for (int i = 0; i < 4; ++i) { zw.w[2 * i] = (uint32_t)z.v[i]; zw.w[2 * i + 1] = (uint32_t)(z.v[i] >> 32); }
-    hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, B, C, n, zw);
+    hipLaunchKernelGGL(k_qap_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hq, A, B, C, n, zw);
     hip_rc(hipGetLastError(), "k_qap_combine launch");
-    if (rc == KG_OK) rc = ntt_enqueue(ctx, st, TMP, A, k, 1, 1);             // coset_idft (prover.rs:47)
+    if (rc == KG_OK) rc = ntt_enqueue(ctx, hq, TMP, A, k, 1, 1);             // coset_idft (prover.rs:47)
   };
   auto h_sort = [&](bool wait) {                           // h's coefficients come off the main queue
     hip_rc(hipEventRecord(ctx->ev_order, st), "hipEventRecord(order)");
@@ -583,7 +591,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // get onto a CU once an accumulation has drained, and then queue behind the reductions: 3.3 -> 3.85 ms per proof.)
   if (do_h && !early) h_front();
   if (rc == KG_OK && hn && do_h && small) {               // h's coefficients come off the main queue: its MSM right behind them
-    rc = msm_small_enqueue(ctx, st, KG_G1, crs->d_h, crs->d_h_inf, A, hn, SL[4], sch, srh);
+    rc = msm_small_enqueue(ctx, hq, KG_G1, crs->d_h, crs->d_h_inf, A, hn, SL[4], sch, srh);
     if (rc == KG_OK) f_q = finish_async(KG_G1, SL[4], q_p);
   } else
   if (rc == KG_OK && hn && do_h) {

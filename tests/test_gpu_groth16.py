@@ -218,14 +218,16 @@ def test_setup_status_codes(ctx, oracle):
     assert (again["a"] == want["a"]).all()
 
 
-def test_groth16_two_proofs_in_flight_match_blocking_calls(ctx, oracle):
+@pytest.mark.parametrize("m,njobs", [(300, 5), (6000, 4)])
+def test_groth16_two_proofs_in_flight_match_blocking_calls(ctx, oracle, m, njobs):
     """kg_groth16_prove_begin / _end with two proofs in flight (different witnesses and blinding scalars, alternating
-    tickets) return exactly the proofs of the blocking call; an identity delta surfaces at the matching _end."""
+    tickets) return exactly the proofs of the blocking call; an identity delta surfaces at the matching _end.  The context is in
+    its default mode (inputs ordered behind the caller's queue): h's chain of these short proofs runs on a queue of the library's own so
+    that the proofs overlap; 6000 constraints: the one-launch MSMs with their scalars converted once, windows split over workgroups."""
     import kogarashi_amd as K
     from kogarashi_amd.lib import ProverSubVersionCrsAttack
     O = oracle
-    m = 300
-    css = [O.chain_r1cs(m, O.gen_scalars(0, SEED + 450 + j, 0, 1)[0]) for j in range(5)]
+    css = [O.chain_r1cs(m, O.gen_scalars(0, SEED + 450 + j, 0, 1)[0]) for j in range(njobs)]
     full = O.groth16_params(css[0], O.gen_scalars(0, SEED + 451, 0, 5), threads=8)
     params = dict(full)
     params["vk_g2"] = full["vk_g2"][:2]
