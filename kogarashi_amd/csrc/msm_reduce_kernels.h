@@ -210,10 +210,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HalveWa
   const BufRsrc rin = soa_rsrc(pin), rout = soa_rsrc(pout);
   const AosDst<KF> dst{rout, t * NWB};
   const AosSrc<KF> cur{rout, t * NWB, true};
-  copy_xyzz_stream<KF>(AosSrc<KF>{rin, (first + lo) * NWB, true}, dst);
-  for (uint32_t j = lo + 1; j < hi; ++j) {
+  // byte offsets walked instead of indices multiplied, the loop kept rolled: with `(first + j) * NWB` inside an unrolled loop the kernel
+  // spilled 44 B per lane under its 96-VGPR cap (G2: 72 B, now 40)
+  uint32_t off = (first + lo) * NWB;
+  const uint32_t end = (first + hi) * NWB;
+  copy_xyzz_stream<KF>(AosSrc<KF>{rin, off, true}, dst);
+#pragma clang loop unroll(disable)
+  for (off += NWB; off < end; off += NWB) {
     KG_STREAM_FENCE();
-    add_xyzz_stream<KF>(cur, AosSrc<KF>{rin, (first + j) * NWB, true}, dst);
+    add_xyzz_stream<KF>(cur, AosSrc<KF>{rin, off, true}, dst);
   }
 }
 
@@ -281,8 +286,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveW
   extern __shared__ uint32_t lds[];
   constexpr uint32_t LPT = Lanes<F>::N;
   const uint32_t L = LT ? (uint32_t)LT : Lrt;
-  const uint32_t capA = L * LPT, capB = (3 * L / 4 ? 3 * L / 4 : 1) * LPT;       // lane-items per image
-  const uint32_t S = capA + capB;                    // the images are interleaved: word k of image A's item q at lds[k * S + q], of image B's at lds[k * S + capA + q]
+  const uint32_t capA = L * LPT;                     // lane-items of image A
+  // the images are interleaved: word k of image A's item q at lds[k * S + q], of image B's at lds[k * S + capA + q].  The stride S is a
+  // compile-time constant in both forms -- for a run-time length (a small window: L <= TailCfg::L / 2) that of the longest such array:
+  // 36 word offsets per point are then immediates instead of registers (the run-time stride cost 60 B of scratch per lane, G2 224 B)
+  constexpr uint32_t LS = LT ? (uint32_t)LT : (uint32_t)TailCfg<F>::L / 2;
+  constexpr uint32_t S = (LS + (3 * LS / 4 ? 3 * LS / 4 : 1)) * LPT;
   uint32_t* const imgA = lds;
   uint32_t* const imgB = lds + capA;
   const uint32_t w = blockIdx.x / (uint32_t)narr_in, a = blockIdx.x % (uint32_t)narr_in;

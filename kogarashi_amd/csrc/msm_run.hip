@@ -252,9 +252,11 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
       if (len == TL) {
         KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_reduce_tail<KF, Cfg::E64, (int)TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
         hipLaunchKernelGGL((k_reduce_tail<KF, Cfg::E64, (int)TL>), dim3((unsigned)(W * narr)), dim3(tail_threads), tail_lds, side, pbuf[cur], in_stride, narr, len, c, (uint64_t*)sl.host_dev);
-      } else {
-        KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_reduce_tail<KF, Cfg::E64, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
-        hipLaunchKernelGGL((k_reduce_tail<KF, Cfg::E64, 0>), dim3((unsigned)(W * narr)), dim3(tail_threads), tail_lds, side, pbuf[cur], in_stride, narr, len, c, (uint64_t*)sl.host_dev);
+      } else {                                           // a small window (len <= TL / 2): the images keep the stride of the longest such array
+        if (len > TL / 2) return set_err(ctx, KG_ERR_UNSUPPORTED, "reduction tail: array length");     // (B is a power of two: never)
+        const size_t lds0 = tail_lds_bytes(TL / 2, (int)LPT);
+        KG_HIP(ctx, hipFuncSetAttribute((const void*)(k_reduce_tail<KF, Cfg::E64, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0));
+        hipLaunchKernelGGL((k_reduce_tail<KF, Cfg::E64, 0>), dim3((unsigned)(W * narr)), dim3(tail_threads), lds0, side, pbuf[cur], in_stride, narr, len, c, (uint64_t*)sl.host_dev);
       }
       ph.end();
     }
