@@ -156,7 +156,7 @@ int msm_run_multi_t(kg_ctx* ctx, const MsmSorted& S, const RunJob* jobs, int njo
     uint32_t* misc = (uint32_t*)(ws + Y.o_misc);
     kg_ctx::Slot& sl = ctx->slots[slot];
     // two reduction queues, by slot parity: a long reduction (G2: ~4x a G1 one) does not hold up the next MSM's
-    hipStream_t side = S.reduce_inline ? st : ((slot & 1) ? ctx->side2_stream : ctx->side_stream);     // reduce_inline: behind the accumulation on its own queue (the last window group: no cross-queue hand-over on the critical path)     // reduce_inline: behind the accumulation on its own queue (the last window group: no cross-queue hand-over on the critical path)
+    hipStream_t side = S.reduce_inline ? st : ((slot & 1) ? ctx->side2_stream : ctx->side_stream);     // reduce_inline: behind the accumulation on its own queue (a blocking call's last or only window group: no cross-queue hand-over on the critical path)
     // Everything after the accumulation runs on a reduction queue, so that the main queue goes from one accumulation straight
     // to the next: the partial-sum rounds, the dense bucket array (gather) and the c-1 latency-bound halving levels.
     if (side != st) {

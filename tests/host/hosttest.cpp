@@ -10,6 +10,7 @@
 #include "../../kogarashi_amd/csrc/vecops.h"
 #include "../../kogarashi_amd/csrc/msm_digits.h"
 #include "../../kogarashi_amd/csrc/coop_add.h"
+#include "../../kogarashi_amd/csrc/host_fp.h"
 
 using namespace kg;
 
@@ -59,12 +60,33 @@ static void field_ops(int op, const uint32_t* a, const uint32_t* b, uint32_t* o,
   }
 }
 
+// The HOST field type of the product (host_fp.h: 4 x 64-bit Montgomery words, the ABI form itself; the MSM's host finish and the
+// prover's assembly run on it).  field: 0 Fr, 1 Fq; op: 0 mul, 1 sqr, 2 add, 3 sub, 4 inv, 5 dbl
+template <class HF>
+static void hostfp_ops(int op, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    const HF x = HF::from_words(a + 4 * i), y = HF::from_words(b + 4 * i);
+    HF r = x;
+    switch (op) {
+      case 0: r = mul(x, y); break;
+      case 1: r = sqr(x); break;
+      case 2: r = add(x, y); break;
+      case 3: r = sub<4, 1>(x, y); break;
+      case 4: r = inv(x); break;
+      case 5: r = dbl(x); break;
+    }
+    r.to_words(o + 4 * i);
+  }
+}
 extern "C" {
 // field: 0 Fr, 1 Fq, 2 Fq2 ; checked: run with the bound-tracking shadow type
 void ht_field_ops(int field, int checked, int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n) {
   if (field == 0) { if (checked) field_ops<FrC>(op, a, b, o, n); else field_ops<Fr>(op, a, b, o, n); }
   else if (field == 1) { if (checked) field_ops<FqC>(op, a, b, o, n); else field_ops<Fq>(op, a, b, o, n); }
   else { if (checked) field_ops<Fq2C>(op, a, b, o, n); else field_ops<Fq2>(op, a, b, o, n); }
+}
+void ht_hostfp_ops(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) {
+  if (field == 0) hostfp_ops<kg::HostFr>(op, a, b, o, n); else hostfp_ops<kg::HostFq>(op, a, b, o, n);
 }
 void ht_ref_to_int(int field, const uint32_t* a, uint32_t* o, size_t n) {
   for (size_t i = 0; i < n; ++i) { if (field == 0) ref_to_int<FrParams>(a + 8 * i, o + 8 * i); else ref_to_int<FqParams>(a + 8 * i, o + 8 * i); }

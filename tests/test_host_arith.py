@@ -46,6 +46,31 @@ def test_prime_field_ops_match_oracle(hostlib, oracle, fd):
 
 
 @pytest.mark.parametrize("fd", [0, 1])
+def test_host_field_type_matches_oracle(hostlib, oracle, fd):
+    """host_fp.h (4 x 64-bit Montgomery words: the type of the MSM's host finish and of the prover's assembly) against the oracle: the
+    no-carry product on random operands and on the edges (0, 1, -1, (p - 1)^2, operands with all-ones low words), sums, differences, inverses"""
+    O, n = oracle, 3000
+    a, b = O.gen_scalars(fd, SEED + 5, 0, n), O.gen_scalars(fd, SEED + 6, 0, n)
+    c = O.f_consts(fd)
+    pm1 = c["p"].copy(); pm1[0] -= 1                    # p - 1 as a raw word pattern: the largest operand the type holds
+    a[0] = 0; b[1] = 0; a[2] = c["r"]; a[3] = O.f_neg(fd, c["r"]); b[3] = a[3]; a[4] = pm1; b[4] = pm1; a[5] = pm1; b[6] = pm1
+    a[7] = np.array([2**64 - 1, 2**64 - 1, 2**64 - 1, 0], dtype=np.uint64); b[7] = a[7]
+    a[8] = np.array([2**64 - 1, 2**64 - 1, 2**64 - 1, int(c["p"][3]) - 1], dtype=np.uint64); b[8] = a[8]
+    u64p = lambda x: x.ctypes.data_as(C.POINTER(C.c_uint64))
+    ops = {0: lambda x, y: O.f_mul(fd, x, y), 1: lambda x, y: O.f_square(fd, x), 2: lambda x, y: O.f_add(fd, x, y),
+           3: lambda x, y: O.f_sub(fd, x, y), 5: lambda x, y: O.f_double(fd, x)}
+    for op, f in ops.items():
+        got = np.empty_like(a)
+        hostlib.ht_hostfp_ops(fd, op, u64p(a), u64p(b), u64p(got), C.c_size_t(n))
+        assert (got == np.stack([f(a[i], b[i]) for i in range(n)])).all(), (fd, op)
+    m = 24
+    got = np.empty_like(a[:m])
+    am, bm = a[:m].copy(), b[:m].copy()
+    hostlib.ht_hostfp_ops(fd, 4, u64p(am), u64p(bm), u64p(got), C.c_size_t(m))
+    assert (got == np.stack([O.f_invert(fd, a[i]) if a[i].any() else np.zeros(4, dtype=np.uint64) for i in range(m)])).all()
+
+
+@pytest.mark.parametrize("fd", [0, 1])
 def test_montgomery_domain_conversions(hostlib, oracle, fd):
     O, n = oracle, 500
     a = O.gen_scalars(fd, SEED + 3, 0, n)
