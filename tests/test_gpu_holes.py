@@ -172,8 +172,11 @@ def test_kept_blocks_can_be_trimmed_and_a_block_freed_through_another_context_is
     """kg_ctx_trim gives the kept blocks back to the driver (other allocators of the device -- torch, other contexts -- see them
     as used until then); a block handed out by context A and freed through context B is released, not kept under A's old entry; a
     work-space request that context B cannot satisfy releases context A's kept blocks too."""
+    import os
     import torch
     import kogarashi_amd as K
+    if os.environ.get("KG_POOL_MB"):
+        pytest.skip("the test keeps a 256 MiB block: it assumes the default cap of the block pool (KG_POOL_MB is set)")
     a, b = K.Context(0), K.Context(0)
     torch.cuda.synchronize()
     p = a.malloc(256 << 20)
