@@ -54,6 +54,7 @@ struct kg_ctx {
   int ws_idle_n[2] = {0, 0};
   hipEvent_t ev_bases = nullptr;                    // per-call base conversion on the scalar queue complete
   hipEvent_t ev_order = nullptr;         // stream-order hand-over main -> scalar queue
+  bool small_glv_off = false;            // set by the prover around a proof's one-launch MSMs beyond 128 pairs: five launches at once are bound by their kernels, not by the host chains GLV halves
   bool inputs_complete = false;          // kg_ctx_set_inputs_complete: MSM inputs are complete when the call is made
 
   // kg_malloc / kg_free keep released blocks for the next request of the same size class (capi.cpp): the first DMA into a FRESH
@@ -360,6 +361,7 @@ int msm_finish(kg_ctx* ctx, int curve, int slot, uint64_t* out_xyz);
 // context, and with which window width c and bucket range 2^r per workgroup; msm_small_enqueue: the launches on queue st, the window
 // sums into the slot (msm_finish is the host half, as for the long pipeline)
 bool msm_small_plan(const kg_ctx* ctx, int curve, size_t n, int* c, int* r);
+bool msm_small_glv(const kg_ctx* ctx, int curve, size_t n);   // does an n-pair short MSM split its scalars into two 127-bit halves (msm_digits.h)?
 bool msm_small_kt(const kg_ctx* ctx, size_t n);      // does an n-pair short MSM convert its scalars once, by a launch of its own (the KT form)?
 int msm_small_enqueue(kg_ctx* ctx, hipStream_t st, int curve, const uint64_t* d_bases, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, int slot,
                       int c, int r);

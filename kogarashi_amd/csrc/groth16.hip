@@ -455,6 +455,11 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // in flight: proof i + 1 starts beside proof i (inputs complete at the call: 2^12 0.57 ms per proof against 1.17, 2^14 1.11 against 1.26; ordered
   // behind the caller's queue, with h's chain on a queue of the library's own -- see hq below: 2^12 0.69 against 1.18, 2^14 1.19 against 1.37)
   const size_t small_cap = (size_t)ctx->tune.small_max;
+  // The halved scalars (GLV, msm_digits.h) shorten the host chains and lengthen the kernels: a single blocking MSM gains at every length, but a
+  // proof's five launches run at once and are bound by their kernels -- 2^10 constraints 0.575 -> 0.64 ms with them, 2^12 0.76 -> 0.88; up to
+  // 256 witness entries the chains are the critical path (2^4 .. 2^7 constraints: 0.44 -> 0.35 ms)
+  struct GlvGuard { kg_ctx* c; bool old; ~GlvGuard() { c->small_glv_off = old; } } glv_guard{ctx, ctx->small_glv_off};
+  if (nz > 256 || hn > 256) ctx->small_glv_off = true;
   const bool small = !tz && nz <= small_cap && hn <= small_cap && (!do_g2 || msm_small_plan(ctx, KG_G2, nz, &sc2, &sr2)) && (!do_g1w || msm_small_plan(ctx, KG_G1, nz, &sc1, &sr1)) &&
                      (!do_g1w || !m_l_1 || msm_small_plan(ctx, KG_G1, m_l_1, &scl, &srl)) && (!(do_h && hn) || msm_small_plan(ctx, KG_G1, hn, &sch, &srh));
   if (small && (do_g2 || do_g1w) && !(mats && do_h)) KG_HIP(ctx, hipEventRecord(ctx->ev_order, sq));      // z is complete

@@ -9,6 +9,7 @@
 #pragma once
 #include <cstdint>
 #include "fp29.h"
+#include "glv_consts.h"
 
 namespace kg {
 
@@ -35,6 +36,72 @@ KG_HD uint32_t small_window_digit(const uint32_t kb[8], int w, int c, int W, boo
   const int32_t d = (int32_t)(e & ((1u << c) - 1u)) - (int32_t)(1u << (c - 1));
   negative = d < 0;
   return (uint32_t)(d < 0 ? -d : d);
+}
+
+// ---- GLV: k = k1 + k2 lambda (mod n), |k1|, |k2| < 2^127 (glv_consts.h; tools/gen/glv_consts.py states the bounds it measured) ------------
+// All three curves of the path have j = 0, so (x, y) -> (beta x, y) is multiplication by lambda on the prime-order group: a pair (k, P)
+// becomes two pairs (|k1|, +-P), (|k2|, +-(beta x, y)) with scalars of half the length -- half the windows on the device and half the
+// doublings of the host chain.  The rounding uses c_i = (G_i k) >> 256 (floor instead of round: k1, k2 grow by at most one basis vector and
+// stay below 2^127); k1 = k - c1 a1 - c2 a2 and k2 = -c1 b1 - c2 b2 are computed modulo 2^160 in two's complement.
+// words [lo, lo + nr) of a (na words) * b (nb words)
+template <int NA, int NB, int LO, int NR>
+KG_HD void glv_mul_words(const uint32_t* a, const uint32_t* b, uint32_t* r) {
+  uint64_t carry = 0;                                  // column sums of up to NB products of 2^64: hi parts are carried as a second word
+  uint64_t carry_hi = 0;
+#pragma unroll
+  for (int col = 0; col < LO + NR; ++col) {
+    uint64_t lo = carry, hi = carry_hi;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int j = col - i;
+      if (j < 0 || j >= NB) continue;
+      const uint64_t pr = (uint64_t)a[i] * b[j];
+      lo += pr & 0xffffffffu;
+      hi += pr >> 32;
+    }
+    if (col >= LO) r[col - LO] = (uint32_t)lo;
+    carry = (lo >> 32) + (hi & 0xffffffffu);
+    carry_hi = hi >> 32;
+  }
+}
+template <class L>
+KG_HD void glv_decompose_with(const uint32_t k[8], uint32_t k1[4], bool& neg1, uint32_t k2[4], bool& neg2) {
+  uint32_t c1[3], c2[5];
+  glv_mul_words<8, 3, 8, 3>(k, L::G1, c1);
+  glv_mul_words<8, 5, 8, 5>(k, L::G2, c2);
+  uint32_t t1[5], t2[5], r1[5], r2[5];
+  glv_mul_words<3, 5, 0, 5>(c1, L::A1, t1);
+  glv_mul_words<5, 5, 0, 5>(c2, L::A2, t2);
+  {
+    int64_t br = 0;                                    // r1 = k - t1 - t2 (mod 2^160)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int64_t d = (int64_t)k[i] - (int64_t)t1[i] - (int64_t)t2[i] + br;
+      r1[i] = (uint32_t)d;
+      br = d >> 32;                                    // arithmetic shift: -2 .. 0
+    }
+  }
+  glv_mul_words<3, 5, 0, 5>(c1, L::B1, t1);
+  glv_mul_words<5, 5, 0, 5>(c2, L::B2, t2);
+  {
+    int64_t br = 0;                                    // r2 = -t1 - t2
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int64_t d = -(int64_t)t1[i] - (int64_t)t2[i] + br;
+      r2[i] = (uint32_t)d;
+      br = d >> 32;
+    }
+  }
+  neg1 = (r1[4] >> 31) != 0;
+  neg2 = (r2[4] >> 31) != 0;
+  uint64_t cy1 = neg1 ? 1 : 0, cy2 = neg2 ? 1 : 0;     // |x| = neg ? ~x + 1 : x; the fifth word is the sign extension
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint64_t s1 = (uint64_t)(neg1 ? ~r1[i] : r1[i]) + cy1;
+    k1[i] = (uint32_t)s1; cy1 = s1 >> 32;
+    const uint64_t s2 = (uint64_t)(neg2 ? ~r2[i] : r2[i]) + cy2;
+    k2[i] = (uint32_t)s2; cy2 = s2 >> 32;
+  }
 }
 
 }  // namespace kg

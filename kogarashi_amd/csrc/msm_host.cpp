@@ -419,6 +419,10 @@ int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t*
   // fills the chip at these lengths and consecutive calls run one after the other, where the long pipeline's phases overlap across the
   // tickets (per call, four in flight, short kernel / long pipeline: 2^10 0.09 / 0.15 ms, 2^12 0.14 / 0.17, 2^13 0.172 / 0.174, 2^14 0.21 / 0.18;
   // G2 2^12 0.32 / 0.33, 2^13 0.44 / 0.37 -- profiles/r06_small_ab.txt)
+  // (calls in flight are bound by their kernels, which the halved scalars of msm_digits.h lengthen for the base-field curves -- 2^10 pairs 0.091 -> 0.114 ms
+  // per call, their host chains run on worker threads beside each other; G2: level)
+  struct GlvGuard { kg_ctx* c; bool old; ~GlvGuard() { c->small_glv_off = old; } } glv_guard{ctx, ctx->small_glv_off};
+  if (curve != KG_G2) ctx->small_glv_off = true;
   if (n <= (size_t)(curve == KG_G2 ? ctx->tune.small_max_flight / 2 : ctx->tune.small_max_flight) && kg::msm_small_plan(ctx, curve, n, &sc, &sr)) {
     if (ctx->ticket_fut[ticket].valid()) ctx->ticket_fut[ticket].wait();
     KG_TRY(kg::msm_small_enqueue(ctx, ctx->stream, curve, d_bases, d_inf, d_scalars, n, 1 + ticket, sc, sr));

@@ -25,6 +25,23 @@ bool msm_small_plan(const kg_ctx* ctx, int curve, size_t n, int* c_out, int* r_o
   // are idle otherwise) and a second launch adds the ranges' planes.  G2 (three times the arithmetic per addition on the device, the
   // host chain in Fq2): wider windows pay earlier.
   int c, r;
+  const bool glv = msm_small_glv(ctx, curve, n);
+  if (glv) {
+    // two 127-bit halves per scalar (msm_digits.h): widths that divide 128 -- the top window of any other width holds one or two bits, i.e. two
+    // or four buckets with a quarter of all entries each (c = 5 at 4096 pairs: 0.38 ms against 0.19).  profiles/r06_small_shapes*_glv.txt
+    if (curve == KG_G2) {
+      if (n <= 48) { c = 2; r = 1; }
+      else if (n <= 160) { c = 2; r = 0; }
+      else if (n <= 6144) { c = 4; r = 0; }
+      else { c = 8; r = 3; }
+    } else {
+      if (n <= 160) { c = 2; r = 1; }
+      else if (n <= 384) { c = 4; r = 3; }
+      else if (n <= 1536) { c = 4; r = 1; }
+      else if (n <= 4096) { c = 4; r = 0; }
+      else { c = 8; r = 3; }
+    }
+  } else
   if (curve == KG_G2) {
     if (n > (size_t)SM_MAX_N_G2) return false;       // (2^15 G2 pairs: 1.18 ms here, 1.09 ms through the long pipeline)
     if (n <= 32) { c = 3; r = 2; }
@@ -40,11 +57,23 @@ bool msm_small_plan(const kg_ctx* ctx, int curve, size_t n, int* c_out, int* r_o
   if (r > c - 1) r = c - 1;
   if (c - 1 - r > 5) r = c - 1 - 5;                  // at most 32 workgroups per window
   if (r > SM_MAX_R) return false;
-  auto lds = [&](int rr) { return curve == KG_G2 ? small_lds_bytes<Fq2>((uint32_t)n, rr, kt) : small_lds_bytes<Fq>((uint32_t)n, rr, kt); };
+  const uint32_t nv = glv ? 2 * (uint32_t)n : (uint32_t)n;        // list entries per window
+  auto lds = [&](int rr) { return curve == KG_G2 ? small_lds_bytes<Fq2>(nv, rr, kt) : small_lds_bytes<Fq>(nv, rr, kt); };
   while (r > 0 && lds(r) > 160 * 1024) --r;          // G2 points are twice the words: smaller bucket ranges, more workgroups per window
   if (lds(r) > 160 * 1024 || c - 1 - r > 5) return false;
   *c_out = c; *r_out = r;
   return true;
+}
+
+// GLV (msm_digits.h): every scalar as two 127-bit halves k1 + k2 lambda against P and (beta x, y) -- half the windows on the device, half the
+// doublings of the host chain.  The list entries hold a 15-bit index of the halves: up to 16384 pairs.
+bool msm_small_glv(const kg_ctx* ctx, int curve, size_t n) {
+  const kg_tuning& tn = ctx ? ctx->tune : tuning();
+  if (tn.small_glv == 0 || 2 * n > SM_MAX_N_KT || (ctx && ctx->small_glv_off)) return false;
+  // where it pays (blocking kg_msm, same box): G1 / Grumpkin up to 6144 pairs (16 pairs 0.114 -> 0.095 ms, 2^12 0.198 -> 0.186, 6144 0.217 -> 0.209;
+  // 2^13 0.224 -> 0.232), G2 -- whose host chain is Fq2 and whose tree levels cost three times a G1 level -- at every length the entries'
+  // index field holds (32 pairs 0.32 -> 0.25 ms, 2^13 0.64 -> 0.52, 2^14 0.86 -> 0.62)
+  return tn.small_glv == 2 || curve == KG_G2 || n <= 6144;
 }
 
 // From which length the scalars are converted once by a launch of their own (the KT form of the kernel) instead of by every workgroup
@@ -64,7 +93,8 @@ static int small_launch(kg_ctx* ctx, hipStream_t st, const SmallArgs& a, size_t 
     attr_devs |= bit;
   }
   if (a.kt) {
-    hipLaunchKernelGGL((k_small_prep<SP>), dim3((a.n + 255) / 256), dim3(256), 0, st, a.scalars, a.n, a.H, const_cast<uint32_t*>(a.kt), a.spill_cursor, a.W);
+    hipLaunchKernelGGL((k_small_prep<SP>), dim3((a.nr + 255) / 256), dim3(256), 0, st, a.scalars, a.nr, a.H, const_cast<uint32_t*>(a.kt), a.spill_cursor, a.W, a.glv, a.inf,
+                       const_cast<uint8_t*>(a.meta));
     hipLaunchKernelGGL((k_msm_small<F, SP, true>), dim3((unsigned)a.W, (unsigned)a.NB), dim3(SM_NT), lds, st, a);
   } else
   hipLaunchKernelGGL((k_msm_small<F, SP, false>), dim3((unsigned)a.W, (unsigned)a.NB), dim3(SM_NT), lds, st, a);
@@ -79,12 +109,15 @@ int msm_small_enqueue(kg_ctx* ctx, hipStream_t st, int curve, const uint64_t* d_
                       int c, int r) {
   if (slot < 0 || slot >= kg_ctx::NSLOTS) return set_err(ctx, KG_ERR_BAD_ARG, "bad result slot");
   KG_HIP(ctx, hipSetDevice(ctx->device));
-  const int W = (255 + c - 1) / c, NB = 1 << (c - 1 - r), E64 = curve == KG_G2 ? 8 : 4;
+  const bool glv = msm_small_glv(ctx, curve, n);
+  const int W = ((glv ? 128 : 255) + c - 1) / c, NB = 1 << (c - 1 - r), E64 = curve == KG_G2 ? 8 : 4;     // glv: |k1|, |k2| < 2^127
+  const size_t nv = glv ? 2 * n : n;
   const int NW = curve == KG_G2 ? PointIO<Fq2>::NW : PointIO<Fq>::NW;
   KG_TRY(ensure_slot(ctx, slot, (size_t)W * 4 * E64 * 8));
   kg_ctx::Slot& sl = ctx->slots[slot];
   SmallArgs a;
-  a.bases = d_bases; a.inf = d_inf; a.scalars = d_scalars; a.n = (uint32_t)n; a.c = c; a.W = W; a.r = r; a.NB = NB;
+  a.bases = d_bases; a.inf = d_inf; a.scalars = d_scalars; a.n = (uint32_t)nv; a.nr = (uint32_t)n; a.glv = glv ? 1 : 0; a.npl = glv ? 4 : 8; a.meta = nullptr;
+  a.c = c; a.W = W; a.r = r; a.NB = NB;
   uint32_t H[8];
   small_bias(c, W, H);
   for (int j = 0; j < 8; ++j) a.H.w[j] = H[j];
@@ -111,8 +144,9 @@ int msm_small_enqueue(kg_ctx* ctx, hipStream_t st, int curve, const uint64_t* d_
   if (NB > 1 || kt) {
     // scratch of the slot: plane points of split windows | the scalars' word planes | spill cursors | spill space of the lists
     const size_t b_planes = ((size_t)W * NB * (SM_MAX_R + 1) * NW * 4 + 255) & ~(size_t)255;
-    const size_t b_kt = kt ? (n * 32 + 255) & ~(size_t)255 : 0, b_cur = kt ? 512 : 0, b_spill = kt ? (size_t)W * n * 2 : 0;
-    const size_t bytes = b_planes + b_kt + b_cur + b_spill;
+    const size_t b_kt = kt ? (nv * 4 * (glv ? 4 : 8) + 255) & ~(size_t)255 : 0, b_cur = kt ? 512 : 0, b_spill = kt ? ((size_t)W * nv * 2 + 255) & ~(size_t)255 : 0;
+    const size_t b_meta = (kt && glv) ? (nv + 255) & ~(size_t)255 : 0;
+    const size_t bytes = b_planes + b_kt + b_cur + b_spill + b_meta;
     if (bytes > ctx->ws_small_bytes[slot]) {
       if (ctx->ws_small[slot]) { sync_all(ctx); (void)hipFree(ctx->ws_small[slot]); ctx->ws_small[slot] = nullptr; ctx->ws_small_bytes[slot] = 0; }
       const hipError_t e = dev_alloc(ctx, &ctx->ws_small[slot], bytes);
@@ -122,6 +156,7 @@ int msm_small_enqueue(kg_ctx* ctx, hipStream_t st, int curve, const uint64_t* d_
     char* ws = (char*)ctx->ws_small[slot];
     a.planes = (uint32_t*)ws;
     if (kt) { a.kt = (const uint32_t*)(ws + b_planes); a.spill_cursor = (uint32_t*)(ws + b_planes + b_kt); a.spill = (uint16_t*)(ws + b_planes + b_kt + b_cur); }
+    if (kt && glv) a.meta = (const uint8_t*)(ws + b_planes + b_kt + b_cur + b_spill);
     if (NB > 1) lds2 = curve == KG_G2 ? small_combine_lds_bytes<Fq2>(c, NB) : small_combine_lds_bytes<Fq>(c, NB);
   }
   PhaseScope ph(ctx, "small_msm", st);

@@ -42,7 +42,11 @@ struct SmallArgs {
   const uint64_t* bases;      // ABI affine points (x | y), Montgomery R = 2^256
   const uint8_t* inf;         // identity flags or nullptr
   const uint64_t* scalars;    // ABI scalars
-  uint32_t n;
+  uint32_t n;                 // scalars the windows are cut from: the input's, or -- glv -- two half-length ones per input scalar (entry v: input v >> 1)
+  uint32_t nr;                // pairs of the input
+  int glv;                    // 1: every scalar as k1 + k2 lambda (msm_digits.h glv_decompose_with), sub-scalar v & 1 = 1 meets (beta x, y)
+  int npl;                    // word planes of the KT form: 8, or 4 (glv: 128-bit sub-scalars)
+  const uint8_t* meta;        // glv, KT form: per sub-scalar its sign (bit 0) and the base's identity flag (bit 1), written by k_small_prep
   int c, W, r, NB;            // window width, windows, log2(buckets per workgroup), workgroups per window (NB << r == 2^(c-1))
   Words8 H;                   // digit bias (msm_digits.h)
   uint64_t* out;              // NB == 1: W window sums, 4 * E64 words each (x | y | zz | zzz, ABI form) -- the slot's pinned buffer
@@ -112,19 +116,38 @@ constexpr uint32_t SM_MAX_N_G2 = 20480;      // G2: beyond, the long pipeline is
 // The longer short inputs (from 2049 pairs): ONE conversion of the scalars for all workgroups -- k + H as eight word planes -- instead of one
 // per workgroup (n / 256 Montgomery products per lane in each of the W * NB workgroups: 32 us at 2^13 pairs); also clears the spill cursors.
 template <class SP>
-__global__ void __launch_bounds__(256) k_small_prep(const uint64_t* __restrict__ scalars, uint32_t n, Words8 H, uint32_t* __restrict__ kt,
-                                                    uint32_t* __restrict__ spill_cursor, int W) {
+__global__ void __launch_bounds__(256) k_small_prep(const uint64_t* __restrict__ scalars, uint32_t nr, Words8 H, uint32_t* __restrict__ kt,
+                                                    uint32_t* __restrict__ spill_cursor, int W, int glv, const uint8_t* __restrict__ inf, uint8_t* __restrict__ meta) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (uint32_t)W) spill_cursor[i] = 0;
-  if (i >= n) return;
+  if (i >= nr) return;
   uint32_t w[8], k[8];
   load_words(scalars, i, w);
   ref_to_int<SP>(w, k);
+  if (glv) {                                                // two sub-scalars of 127 bits: |k_e| + H as four word planes, sign and identity flag aside
+    uint32_t ks[2][4];
+    bool ng[2];
+    glv_decompose_with<GlvLattice<SP>>(k, ks[0], ng[0], ks[1], ng[1]);
+    const size_t nv = (size_t)2 * nr;
+    const uint32_t fl = (inf && inf[i]) ? 2u : 0u;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      uint64_t cy = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint64_t s = (uint64_t)ks[e][j] + H.w[j] + cy;
+        kt[(size_t)j * nv + 2 * i + e] = (uint32_t)s;
+        cy = s >> 32;
+      }
+      meta[2 * i + e] = (uint8_t)(fl | (ng[e] ? 1u : 0u));
+    }
+    return;
+  }
   uint64_t cy = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const uint64_t s = (uint64_t)k[j] + H.w[j] + cy;
-    kt[(size_t)j * n + i] = (uint32_t)s;
+    kt[(size_t)j * nr + i] = (uint32_t)s;
     cy = s >> 32;
   }
 }
@@ -132,9 +155,9 @@ __global__ void __launch_bounds__(256) k_small_prep(const uint64_t* __restrict__
 // before the first digit is cut (one at a time their latency -- 0.5-1 us out of L2 / HBM -- is the whole loop: 64 rounds of it at 2^14 pairs)
 constexpr int SM_UN = 8;
 struct SmWords { uint32_t lo[SM_UN], hi[SM_UN]; };
-__device__ __forceinline__ SmWords sm_fetch_kt(const uint32_t* __restrict__ kt, uint32_t n, uint32_t i0, int w, int c, int W) {
+__device__ __forceinline__ SmWords sm_fetch_kt(const uint32_t* __restrict__ kt, uint32_t n, uint32_t i0, int w, int c, int W, int npl) {
   const int o = w * c, j = o >> 5, sh = o & 31;
-  const bool two = j + 1 < 8 && (sh + c > 32 || w == W - 1);
+  const bool two = j + 1 < npl && (sh + c > 32 || w == W - 1);
   SmWords v;
 #pragma unroll
   for (int u = 0; u < SM_UN; ++u) {
@@ -179,6 +202,23 @@ __device__ __forceinline__ void sm_combine_planes(uint32_t* img, uint32_t cap, u
   }
 }
 
+// KT form: bit 1 = the entry's base is the identity (skip), bit 0 = the sub-scalar is negative (glv)
+__device__ __forceinline__ uint32_t sm_flags(const SmallArgs& a, uint32_t i) {
+  if (a.glv) return a.meta[i];
+  return (a.inf && a.inf[i]) ? 2u : 0u;
+}
+// (beta x, y): the endomorphism's image of an affine point
+template <class P, class SP>
+__device__ __forceinline__ void sm_endo(Affine<Fp<P>>& pt) { pt.x = mul(pt.x, Fp<P>::from_const(GlvBeta<P, SP>::BETA)); }
+template <class G, class SP>
+__device__ __forceinline__ void sm_endo(Affine<Fp2<G>>& pt) {
+  const G beta = G::from_const(GlvBetaG2::BETA);
+  pt.x = {mul(pt.x.c0, beta), mul(pt.x.c1, beta)};
+}
+template <class F, class SP> struct SmEndo;
+template <class P, class SP> struct SmEndo<Fp<P>, SP> { static __device__ __forceinline__ void apply(Affine<Fp<P>>& pt) { sm_endo<P, SP>(pt); } };
+template <class G, class SP> struct SmEndo<Fp2<G>, SP> { static __device__ __forceinline__ void apply(Affine<Fp2<G>>& pt) { sm_endo<G, SP>(pt); } };
+
 template <class F, class SP, bool KT>
 __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
   extern __shared__ uint32_t lds[];
@@ -209,17 +249,50 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
   __syncthreads();
   if constexpr (KT) {
     for (uint32_t i0 = tid; i0 < n; i0 += SM_UN * SM_NT) {
-      const SmWords v = sm_fetch_kt(a.kt, n, i0, (int)w, c, W);
+      const SmWords v = sm_fetch_kt(a.kt, n, i0, (int)w, c, W, a.npl);
       uint32_t fl[SM_UN];
 #pragma unroll
-      for (int u = 0; u < SM_UN; ++u) { const uint32_t i = i0 + (uint32_t)u * SM_NT; fl[u] = (a.inf && i < n) ? a.inf[i] : 0u; }
+      for (int u = 0; u < SM_UN; ++u) { const uint32_t i = i0 + (uint32_t)u * SM_NT; fl[u] = i < n ? sm_flags(a, i) : 0u; }
 #pragma unroll
       for (int u = 0; u < SM_UN; ++u) {
         const uint32_t i = i0 + (uint32_t)u * SM_NT;
         if (i >= n) break;
         bool neg;
-        const uint32_t m = fl[u] ? 0u : sm_digit_words(v.lo[u], v.hi[u], (int)w, c, W, neg);
+        const uint32_t m = (fl[u] & 2u) ? 0u : sm_digit_words(v.lo[u], v.hi[u], (int)w, c, W, neg);
         if (m && ((m - 1) >> r) == jb) atomicAdd(&hist[m - 1 - b0], 1u);
+      }
+    }
+  } else if (a.glv) {
+    for (uint32_t i = tid; i < a.nr; i += SM_NT) {          // two sub-scalars per scalar: entries 2 i and 2 i + 1
+      uint32_t ks[2][8];
+      bool ng[2];
+      {
+        uint32_t sw[8], k[8];
+        load_words(a.scalars, i, sw);
+        ref_to_int<SP>(sw, k);
+        glv_decompose_with<GlvLattice<SP>>(k, ks[0], ng[0], ks[1], ng[1]);
+      }
+      const bool ident = a.inf && a.inf[i];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        uint64_t cy = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint64_t s = (uint64_t)ks[e][j] + a.H.w[j] + cy;
+          ks[e][j] = (uint32_t)s;
+          cy = s >> 32;
+        }
+#pragma unroll
+        for (int j = 4; j < 8; ++j) ks[e][j] = 0;
+        bool neg;
+        uint32_t m = small_window_digit(ks[e], (int)w, c, W, neg);
+        if (ident) m = 0;
+        uint32_t code = SM_SKIP;
+        if (m && ((m - 1) >> r) == jb) {
+          code = (m - 1 - b0) | ((neg != ng[e]) ? 0x8000u : 0u);
+          atomicAdd(&hist[m - 1 - b0], 1u);
+        }
+        if constexpr (!KT) dig[2 * i + e] = (uint16_t)code;
       }
     }
   } else
@@ -300,19 +373,19 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
   // ---- scatter
   if constexpr (KT) {                                       // the digits again (two word loads each): no digit codes are kept for 2^15 scalars
     for (uint32_t i0 = tid; i0 < n; i0 += SM_UN * SM_NT) {
-      const SmWords v = sm_fetch_kt(a.kt, n, i0, (int)w, c, W);
+      const SmWords v = sm_fetch_kt(a.kt, n, i0, (int)w, c, W, a.npl);
       uint32_t fl[SM_UN];
 #pragma unroll
-      for (int u = 0; u < SM_UN; ++u) { const uint32_t i = i0 + (uint32_t)u * SM_NT; fl[u] = (a.inf && i < n) ? a.inf[i] : 0u; }
+      for (int u = 0; u < SM_UN; ++u) { const uint32_t i = i0 + (uint32_t)u * SM_NT; fl[u] = i < n ? sm_flags(a, i) : 0u; }
 #pragma unroll
       for (int u = 0; u < SM_UN; ++u) {
         const uint32_t i = i0 + (uint32_t)u * SM_NT;
         if (i >= n) break;
         bool neg;
-        const uint32_t m = fl[u] ? 0u : sm_digit_words(v.lo[u], v.hi[u], (int)w, c, W, neg);
+        const uint32_t m = (fl[u] & 2u) ? 0u : sm_digit_words(v.lo[u], v.hi[u], (int)w, c, W, neg);
         if (m && ((m - 1) >> r) == jb) {
           const uint32_t pos = atomicAdd(&hist[m - 1 - b0], 1u);
-          sorted[pos] = (uint16_t)(i | (neg ? 0x8000u : 0u));
+          sorted[pos] = (uint16_t)(i | ((neg != ((fl[u] & 1u) != 0)) ? 0x8000u : 0u));     // the digit's sign times the sub-scalar's
         }
       }
     }
@@ -336,15 +409,18 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
     if (hi > boff[b + 1]) hi = boff[b + 1];
     XYZZ<F> acc = XYZZ<F>::identity();
     if (lo < hi) {
+      const uint32_t g = (uint32_t)a.glv;                   // glv: entry v is sub-scalar v & 1 of pair v >> 1
       uint32_t e = sorted[lo];
-      typename SmIO<F>::Raw raw = SmIO<F>::fetch(a.bases, e & 0x7fffu);
+      typename SmIO<F>::Raw raw = SmIO<F>::fetch(a.bases, (e & 0x7fffu) >> g);
       for (uint32_t j = lo; j < hi; ++j) {
         const bool neg = (e & 0x8000u) != 0;
-        const Affine<F> pt = SmIO<F>::convert(raw);
+        const bool endo = (e & g) != 0;
+        Affine<F> pt = SmIO<F>::convert(raw);
         if (j + 1 < hi) {                                   // the next base travels while this addition runs
           e = sorted[j + 1];
-          raw = SmIO<F>::fetch(a.bases, e & 0x7fffu);
+          raw = SmIO<F>::fetch(a.bases, (e & 0x7fffu) >> g);
         }
+        if (endo) SmEndo<F, SP>::apply(pt);                 // k2's half: lambda P = (beta x, y)
         acc = add_mixed_signed(acc, pt, neg);
       }
     }

@@ -27,6 +27,7 @@
   X(coop_tail, "KG_COOP_TAIL", 1, "0 = the last reduction of a blocking MSM runs the streamed tail kernel (96 VGPRs) instead of the lane-cooperative one") \
   X(small_max, "KG_SMALL_MAX", 32768, "longest MSM (pairs) that runs as the short-input kernel (msm_small.hip): 0 = never, at most 32768 (G2: 20480)") \
   X(small_max_flight, "KG_SMALL_MAX_FLIGHT", 8192, "longest MSM begun with kg_msm_begin that runs as the short-input kernel (a call in flight shares the chip with its neighbours, and the kernel's grid fills it at these lengths); G2: half of it") \
+  X(small_glv, "KG_SMALL_GLV", 1, "short-input MSMs of up to 16384 pairs split every scalar into two 127-bit halves k1 + k2 lambda against P and (beta x, y): half the windows, half the host chain (0 = off, 1 = where it pays: G1 / Grumpkin up to 6144 pairs, G2 up to 16384, 2 = wherever the index field allows)") \
   X(small_kt_from, "KG_SMALL_KT_FROM", 2048, "short-input MSMs LONGER than this convert their scalars once, by a launch of their own, instead of in every workgroup (0 = always)") \
   X(small_c, "KG_SMALL_C", 0, "window width of the short-input kernel: 0 = by length, 2..10") \
   X(small_r, "KG_SMALL_R", -1, "log2 of the buckets a workgroup of the short-input kernel owns: -1 = by length, 0..7 (2^(c-1-r) workgroups per window)") \

@@ -276,6 +276,15 @@ extern "C" int ht_curve_sum(int curve, int checked, int mode, const uint32_t* pt
 }
 
 // signed window digits of canonical integers k (msm_digits.h): digits[i * 128 + w], w < W = ceil(255 / c) <= 128; returns W
+// GLV decomposition (msm_digits.h): k (canonical, 8 words each) -> |k1|, |k2| (4 words each) and their signs; field: 0 Fr, 1 Fq
+extern "C" void ht_glv_decompose(int field, const uint32_t* k, size_t n, uint32_t* k1, uint32_t* k2, uint8_t* neg) {
+  for (size_t i = 0; i < n; ++i) {
+    bool n1, n2;
+    if (field == 0) kg::glv_decompose_with<kg::GlvLattice<kg::FrParams>>(k + 8 * i, k1 + 4 * i, n1, k2 + 4 * i, n2);
+    else kg::glv_decompose_with<kg::GlvLattice<kg::FqParams>>(k + 8 * i, k1 + 4 * i, n1, k2 + 4 * i, n2);
+    neg[2 * i] = n1; neg[2 * i + 1] = n2;
+  }
+}
 extern "C" int ht_small_digits(const uint32_t* k, size_t n, int c, int32_t* digits) {
   const int W = (255 + c - 1) / c;
   uint32_t H[8];

@@ -240,8 +240,13 @@ def test_bad_shapes_are_status_codes(ctx):
 
 def test_randomised_lengths_shapes_and_patterns_against_the_long_pipeline():
     """tools/dbg/stress_small.py: 300 random (curve, length 1 .. 32768, window of the stored bases, scalar pattern, identity flags) cases,
-    each through the automatic shape and two random (c, r) shapes, blocking and three in flight, against the long pipeline's point"""
+    each through the automatic shape and two random (c, r) shapes, blocking and three in flight, against the long pipeline's point -- with
+    the scalars halved by the endomorphism where the plan says so, never, and wherever possible"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg", "stress_small.py"), "300", "606"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "mismatches: 0" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+    # KG_SMALL_GLV: 1 = the default (every scalar as two 127-bit halves k1 + k2 lambda where it pays: msm_digits.h), 0 = never (the form
+    # calls in flight and the proofs' MSMs beyond 256 pairs keep), 2 = wherever the entries' index field allows (up to 16384 pairs)
+    for glv, seed in (("1", "606"), ("0", "607"), ("2", "608")):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg", "stress_small.py"), "300", seed], env=dict(os.environ, KG_SMALL_GLV=glv),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "mismatches: 0" in r.stdout, (glv, r.stdout[-1500:], r.stderr[-1500:])

@@ -246,3 +246,27 @@ def test_signed_window_digits_recompose_the_scalar(hostlib, c):
     for k, row in zip(ks, dig):
         assert sum(int(row[w]) << (w * c) for w in range(W)) == k
         assert all(abs(int(row[w])) <= 1 << (c - 1) for w in range(W)) and row[W - 1] >= 0
+
+
+@pytest.mark.parametrize("fd,name", [(0, "g1"), (1, "gk")])
+def test_glv_decomposition_recomposes_the_scalar(hostlib, pyoracle, fd, name):
+    """msm_digits.h glv_decompose_with: k = k1 + k2 lambda (mod n) with |k1|, |k2| < 2^127 for random scalars and the edges (0, 1, n - 1,
+    lambda, n - lambda, 2^253, the largest 254-bit value below n) -- lambda and the lattice from tools/gen/glv_consts.py, recomputed here"""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("glv_consts", os.path.join(root, "tools", "gen", "glv_consts.py"))
+    G = importlib.util.module_from_spec(spec); spec.loader.exec_module(G)
+    curve = pyoracle.G1 if fd == 0 else pyoracle.GRUMPKIN
+    n = curve.n
+    lam = G.consts(curve)[0]
+    rnd = random.Random(77 + fd)
+    ks = [0, 1, 2, n - 1, n - 2, n // 2, n // 3, lam, n - lam, 1 << 253, n - 3, (1 << 128) - 1, 1 << 128, (1 << 127) + 5] + [rnd.randrange(n) for _ in range(20000)]
+    kw = np.array([[(k >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for k in ks], dtype=np.uint32)
+    k1 = np.zeros((len(ks), 4), dtype=np.uint32); k2 = np.zeros_like(k1); neg = np.zeros((len(ks), 2), dtype=np.uint8)
+    hostlib.ht_glv_decompose(fd, p32(kw), C.c_size_t(len(ks)), p32(k1), p32(k2), neg.ctypes.data_as(U8P))
+    val = lambda w: sum(int(w[j]) << (32 * j) for j in range(4))
+    for i, k in enumerate(ks):
+        a, b = val(k1[i]), val(k2[i])
+        assert a < 1 << 127 and b < 1 << 127, (i, hex(k))
+        sa, sb = (-a if neg[i, 0] else a), (-b if neg[i, 1] else b)
+        assert (sa + sb * lam - k) % n == 0, (i, hex(k))
