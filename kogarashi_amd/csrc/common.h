@@ -54,7 +54,7 @@ struct kg_ctx {
   int ws_idle_n[2] = {0, 0};
   hipEvent_t ev_bases = nullptr;                    // per-call base conversion on the scalar queue complete
   hipEvent_t ev_order = nullptr;         // stream-order hand-over main -> scalar queue
-  bool small_glv_off = false;            // set by the prover around a proof's one-launch MSMs beyond 128 pairs: five launches at once are bound by their kernels, not by the host chains GLV halves
+  unsigned small_glv_off = 0;            // bit per curve: no halved scalars (GLV) for that curve's one-launch MSMs -- set by the prover and by kg_msm_begin around their launches, which are bound by the kernels and not by the host chains GLV halves
   bool inputs_complete = false;          // kg_ctx_set_inputs_complete: MSM inputs are complete when the call is made
 
   // kg_malloc / kg_free keep released blocks for the next request of the same size class (capi.cpp): the first DMA into a FRESH

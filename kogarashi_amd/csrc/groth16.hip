@@ -9,6 +9,7 @@
 #include "common.h"
 #include "msm_internal.h"
 #include <chrono>
+#include <cstdlib>
 #include "host_fp.h"
 #include <future>
 #include <vector>
@@ -456,10 +457,13 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // behind the caller's queue, with h's chain on a queue of the library's own -- see hq below: 2^12 0.69 against 1.18, 2^14 1.19 against 1.37)
   const size_t small_cap = (size_t)ctx->tune.small_max;
   // The halved scalars (GLV, msm_digits.h) shorten the host chains and lengthen the kernels: a single blocking MSM gains at every length, but a
-  // proof's five launches run at once and are bound by their kernels -- 2^10 constraints 0.575 -> 0.64 ms with them, 2^12 0.76 -> 0.88; up to
-  // 256 witness entries the chains are the critical path (2^4 .. 2^7 constraints: 0.44 -> 0.35 ms)
-  struct GlvGuard { kg_ctx* c; bool old; ~GlvGuard() { c->small_glv_off = old; } } glv_guard{ctx, ctx->small_glv_off};
-  if (nz > 256 || hn > 256) ctx->small_glv_off = true;
+  // proof's five launches run at once and the G1 ones are bound by their kernels -- 2^10 constraints 0.575 -> 0.64 ms with them, 2^12 0.76 -> 0.88;
+  // up to 256 witness entries the chains are the critical path (2^4 .. 2^7 constraints: 0.44 -> 0.35 ms).  b_g2 keeps them (its Fq2 host chain is a
+  // proof's long pole: 0.19 -> 0.10 ms) up to KG_G16_G2_GLV_MAX entries, in fewer and longer workgroups than a lone MSM would take (r = 2: 64
+  // workgroups instead of 256 -- the other four launches need CUs too): 2^8 constraints 0.47 -> 0.42 ms, 2^10 0.58 -> 0.52, 2^12 0.80 -> 0.71
+  struct GlvGuard { kg_ctx* c; unsigned old; ~GlvGuard() { c->small_glv_off = old; } } glv_guard{ctx, ctx->small_glv_off};
+  const bool proof_glv = nz <= 256 && hn <= 256;
+  if (!proof_glv) ctx->small_glv_off |= (1u << KG_G1) | (nz > (size_t)ctx->tune.g16_g2_glv_max ? (1u << KG_G2) : 0u);
   const bool small = !tz && nz <= small_cap && hn <= small_cap && (!do_g2 || msm_small_plan(ctx, KG_G2, nz, &sc2, &sr2)) && (!do_g1w || msm_small_plan(ctx, KG_G1, nz, &sc1, &sr1)) &&
                      (!do_g1w || !m_l_1 || msm_small_plan(ctx, KG_G1, m_l_1, &scl, &srl)) && (!(do_h && hn) || msm_small_plan(ctx, KG_G1, hn, &sch, &srh));
   if (small && (do_g2 || do_g1w) && !(mats && do_h)) KG_HIP(ctx, hipEventRecord(ctx->ev_order, sq));      // z is complete
@@ -485,6 +489,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   if (small && do_g2) {
     // a short proof's long pole, issued first: b_g2's one-launch MSM (Fq2 on the device) on the scalar queue right behind z, its host
     // chain (255 doublings in Fq2, ~170 us -- three G1 chains) on a worker thread while this thread is still enqueuing the transforms
+    if (!proof_glv && msm_small_glv(ctx, KG_G2, nz) && sc2 == 4 && sr2 < 2) sr2 = 2;
     rc = msm_small_enqueue(ctx, sq, KG_G2, crs->d_b_g2, crs->d_b_g2_inf, Z, nz, SL[0], sc2, sr2);
     if (rc == KG_OK) f_b2 = finish_async(KG_G2, SL[0], b2i);
   }

@@ -421,8 +421,8 @@ int kg_msm_begin(kg_ctx* ctx, int curve, const uint64_t* d_bases, const uint8_t*
   // G2 2^12 0.32 / 0.33, 2^13 0.44 / 0.37 -- profiles/r06_small_ab.txt)
   // (calls in flight are bound by their kernels, which the halved scalars of msm_digits.h lengthen for the base-field curves -- 2^10 pairs 0.091 -> 0.114 ms
   // per call, their host chains run on worker threads beside each other; G2: level)
-  struct GlvGuard { kg_ctx* c; bool old; ~GlvGuard() { c->small_glv_off = old; } } glv_guard{ctx, ctx->small_glv_off};
-  if (curve != KG_G2) ctx->small_glv_off = true;
+  struct GlvGuard { kg_ctx* c; unsigned old; ~GlvGuard() { c->small_glv_off = old; } } glv_guard{ctx, ctx->small_glv_off};
+  ctx->small_glv_off |= (1u << KG_G1) | (1u << KG_GRUMPKIN);
   if (n <= (size_t)(curve == KG_G2 ? ctx->tune.small_max_flight / 2 : ctx->tune.small_max_flight) && kg::msm_small_plan(ctx, curve, n, &sc, &sr)) {
     if (ctx->ticket_fut[ticket].valid()) ctx->ticket_fut[ticket].wait();
     KG_TRY(kg::msm_small_enqueue(ctx, ctx->stream, curve, d_bases, d_inf, d_scalars, n, 1 + ticket, sc, sr));

@@ -69,7 +69,7 @@ bool msm_small_plan(const kg_ctx* ctx, int curve, size_t n, int* c_out, int* r_o
 // doublings of the host chain.  The list entries hold a 15-bit index of the halves: up to 16384 pairs.
 bool msm_small_glv(const kg_ctx* ctx, int curve, size_t n) {
   const kg_tuning& tn = ctx ? ctx->tune : tuning();
-  if (tn.small_glv == 0 || 2 * n > SM_MAX_N_KT || (ctx && ctx->small_glv_off)) return false;
+  if (tn.small_glv == 0 || 2 * n > SM_MAX_N_KT || (ctx && ((ctx->small_glv_off >> curve) & 1u))) return false;
   // where it pays (blocking kg_msm, same box): G1 / Grumpkin up to 6144 pairs (16 pairs 0.114 -> 0.095 ms, 2^12 0.198 -> 0.186, 6144 0.217 -> 0.209;
   // 2^13 0.224 -> 0.232), G2 -- whose host chain is Fq2 and whose tree levels cost three times a G1 level -- at every length the entries'
   // index field holds (32 pairs 0.32 -> 0.25 ms, 2^13 0.64 -> 0.52, 2^14 0.86 -> 0.62)
