@@ -222,7 +222,9 @@ int kg_msm_set_groups(kg_ctx* ctx, int groups);
  * kg_msm_begin: KG_SMALL_MAX_FLIGHT, 8192) run as
  * ONE launch -- a workgroup per window: digits, an LDS counting sort, bucket accumulation, the bucket reduction and the window sum in
  * LDS -- two launches from 1537 pairs (a window's buckets spread over several workgroups), three from 2049 (the scalars are converted
- * once, into word planes, for all workgroups); the host finishes with one addition per window.  These are the lengths of the reference's own tests and bench (groth16/src/msm.rs:118-135: 32 pairs; bn254/benches: 2^10).
+ * once, into word planes, for all workgroups); the host finishes with one addition per window.  Where it pays (G1 / Grumpkin up to 6144
+ * pairs, G2 up to 16384; KG_SMALL_GLV) every scalar is split by the curve's endomorphism into two 127-bit halves: half the windows, half the
+ * host chain.  These are the lengths of the reference's own tests and bench (groth16/src/msm.rs:118-135: 32 pairs; bn254/benches: 2^10).
  * c: window width, 0 = by length, 2 .. 10; r: log2 of the buckets one workgroup owns, -1 = by length, 0 .. 7.  -2 for max_pairs keeps the
  * current value.  Results are bit-identical for every setting; a forced window (kg_msm_set_window) selects the long pipeline. */
 int kg_msm_set_small(kg_ctx* ctx, int max_pairs, int c, int r);

@@ -386,7 +386,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   if (roles == ROLE_ALL && !defer_assembly) {             // the blinding terms first: three host chains that need nothing from the device
     job->blind.wait();
     job->blind.started = false;
-    if (!(crs->delta_g1_inf || crs->delta_g2_inf)) start_blinding(&pool(ctx), *crs, r, s, &job->blind);
+    if (ctx->tune.g16_blind_early && !(crs->delta_g1_inf || crs->delta_g2_inf)) start_blinding(&pool(ctx), *crs, r, s, &job->blind);
   }
   uint32_t k = 0;
   size_t n = 1;

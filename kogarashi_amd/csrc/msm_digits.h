@@ -41,8 +41,10 @@ KG_HD uint32_t small_window_digit(const uint32_t kb[8], int w, int c, int W, boo
 // ---- GLV: k = k1 + k2 lambda (mod n), |k1|, |k2| < 2^127 (glv_consts.h; tools/gen/glv_consts.py states the bounds it measured) ------------
 // All three curves of the path have j = 0, so (x, y) -> (beta x, y) is multiplication by lambda on the prime-order group: a pair (k, P)
 // becomes two pairs (|k1|, +-P), (|k2|, +-(beta x, y)) with scalars of half the length -- half the windows on the device and half the
-// doublings of the host chain.  The rounding uses c_i = (G_i k) >> 256 (floor instead of round: k1, k2 grow by at most one basis vector and
-// stay below 2^127); k1 = k - c1 a1 - c2 a2 and k2 = -c1 b1 - c2 b2 are computed modulo 2^160 in two's complement.
+// doublings of the host chain.  c_i = (G_i k + 2^255) >> 256 rounds k (b2, -b1) / n to the nearest integer up to the truncation of G_i (an
+// error in [0, 1/4) for k < 2^254): k1 = e1 a1 + e2 a2, k2 = e1 b1 + e2 b2 with e_i in (-1/2, 3/4), so |k1|, |k2| <= 3/4 (|a1| + |a2|) < 2^126.4
+// -- every window width keeps its top digit within 2^(c-1) buckets (the top window starts at bit 120 .. 126 and |k_i| + H < 2^127).  k1 = k - c1 a1
+// - c2 a2 and k2 = -c1 b1 - c2 b2 are computed modulo 2^160 in two's complement.
 // words [lo, lo + nr) of a (na words) * b (nb words)
 template <int NA, int NB, int LO, int NR>
 KG_HD void glv_mul_words(const uint32_t* a, const uint32_t* b, uint32_t* r) {
@@ -67,8 +69,17 @@ KG_HD void glv_mul_words(const uint32_t* a, const uint32_t* b, uint32_t* r) {
 template <class L>
 KG_HD void glv_decompose_with(const uint32_t k[8], uint32_t k1[4], bool& neg1, uint32_t k2[4], bool& neg2) {
   uint32_t c1[3], c2[5];
-  glv_mul_words<8, 3, 8, 3>(k, L::G1, c1);
-  glv_mul_words<8, 5, 8, 5>(k, L::G2, c2);
+  {                                                    // c_i = (G_i k + 2^255) >> 256: ROUNDED -- with a plain floor the halves reach 1.25 (a1 + a2) = 2^127.1
+    uint32_t t[6];                                     // and the top window's digit can leave its bucket range (c = 4, 8)
+    glv_mul_words<8, 3, 7, 4>(k, L::G1, t);
+    uint64_t cy = ((uint64_t)t[0] + 0x80000000u) >> 32;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const uint64_t v = (uint64_t)t[1 + i] + cy; c1[i] = (uint32_t)v; cy = v >> 32; }
+    glv_mul_words<8, 5, 7, 6>(k, L::G2, t);
+    cy = ((uint64_t)t[0] + 0x80000000u) >> 32;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { const uint64_t v = (uint64_t)t[1 + i] + cy; c2[i] = (uint32_t)v; cy = v >> 32; }
+  }
   uint32_t t1[5], t2[5], r1[5], r2[5];
   glv_mul_words<3, 5, 0, 5>(c1, L::A1, t1);
   glv_mul_words<5, 5, 0, 5>(c2, L::A2, t2);

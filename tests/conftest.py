@@ -36,7 +36,7 @@ def hostlib():
     d = os.path.join(ROOT, "tests", "host")
     so = os.path.join(d, "libhosttest.so")
     srcs = [os.path.join(d, "hosttest.cpp")] + [
-        os.path.join(ROOT, "kogarashi_amd", "csrc", f) for f in ("fp29.h", "fp29_checked.h", "curve.h", "fp_consts.h", "fp_inv.h", "ntt_core.h", "vecops.h")]
+        os.path.join(ROOT, "kogarashi_amd", "csrc", f) for f in ("fp29.h", "fp29_checked.h", "curve.h", "fp_consts.h", "fp_inv.h", "ntt_core.h", "vecops.h", "msm_digits.h", "glv_consts.h", "coop_add.h", "host_fp.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]])
     return ctypes.CDLL(so)
@@ -50,7 +50,7 @@ def hostlib_pm():
     d = os.path.join(ROOT, "tests", "host")
     so = os.path.join(d, "libhosttest_pm.so")
     srcs = [os.path.join(d, "hosttest.cpp")] + [
-        os.path.join(ROOT, "kogarashi_amd", "csrc", f) for f in ("fp29.h", "fp29_checked.h", "curve.h", "fp_consts.h", "fp_inv.h", "ntt_core.h", "vecops.h")]
+        os.path.join(ROOT, "kogarashi_amd", "csrc", f) for f in ("fp29.h", "fp29_checked.h", "curve.h", "fp_consts.h", "fp_inv.h", "ntt_core.h", "vecops.h", "msm_digits.h", "glv_consts.h", "coop_add.h", "host_fp.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DKG_FP2_MUL_VIA_PM", "-o", so, srcs[0]])
     return ctypes.CDLL(so)

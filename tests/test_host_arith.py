@@ -250,7 +250,7 @@ def test_signed_window_digits_recompose_the_scalar(hostlib, c):
 
 @pytest.mark.parametrize("fd,name", [(0, "g1"), (1, "gk")])
 def test_glv_decomposition_recomposes_the_scalar(hostlib, pyoracle, fd, name):
-    """msm_digits.h glv_decompose_with: k = k1 + k2 lambda (mod n) with |k1|, |k2| < 2^127 for random scalars and the edges (0, 1, n - 1,
+    """msm_digits.h glv_decompose_with: k = k1 + k2 lambda (mod n) with |k1|, |k2| < 2^126.6 for random scalars and the edges (0, 1, n - 1,
     lambda, n - lambda, 2^253, the largest 254-bit value below n) -- lambda and the lattice from tools/gen/glv_consts.py, recomputed here"""
     import importlib.util, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -267,6 +267,14 @@ def test_glv_decomposition_recomposes_the_scalar(hostlib, pyoracle, fd, name):
     val = lambda w: sum(int(w[j]) << (32 * j) for j in range(4))
     for i, k in enumerate(ks):
         a, b = val(k1[i]), val(k2[i])
-        assert a < 1 << 127 and b < 1 << 127, (i, hex(k))
+        assert a < 3 << 125 and b < 3 << 125, (i, hex(k))      # 3/4 (|a1| + |a2|) < 2^126.4: what keeps every width's top digit in range
         sa, sb = (-a if neg[i, 0] else a), (-b if neg[i, 1] else b)
         assert (sa + sb * lam - k) % n == 0, (i, hex(k))
+    # every window width: with W = ceil(128 / c) windows and the bias H of msm_digits.h the unsigned top window of |k_i| + H stays within its
+    # 2^(c-1) buckets (an entry beyond them would belong to no workgroup of the short-input kernel)
+    worst = max(max(val(k1[i]), val(k2[i])) for i in range(len(ks)))
+    for c in range(2, 11):
+        W = (128 + c - 1) // c
+        H = sum(1 << (w * c + c - 1) for w in range(W - 1))
+        assert (worst + H) >> ((W - 1) * c) <= 1 << (c - 1), c
+        assert ((3 << 125) + H) >> ((W - 1) * c) <= 1 << (c - 1), c        # and for the proven bound

@@ -19,12 +19,15 @@ def piped(n, steps, rec=None):
         t0 = time.perf_counter(); ctx.msm_end(0, i % 4)
         if rec is not None: rec.append((-1, (time.perf_counter() - t0) * 1e6))
 piped(min(nmax, 1 << 20), 200)
-for k in range(4, 12):
+gc.disable()
+for k in range(4, 14):
   for n in [1 << k, (1 << k) + 1, 3 << (k - 1)]:
     reps = max(3, min(30, (64 << 20) // n))
     for _ in range(2): ctx.msm(0, db.ptr, 0, ds.ptr, n)
-    for _ in range(reps): ctx.msm(0, db.ptr, 0, ds.ptr, n)
+    bt = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); ctx.msm(0, db.ptr, 0, ds.ptr, n); bt.append((time.perf_counter() - t0) * 1e6)
     piped(n, 4)
     rec = []
     t0 = time.perf_counter(); piped(n, reps + 3, rec); p = (time.perf_counter() - t0) / (reps + 3) * 1e3
-    print(n, f"{p:.3f} ms", " ".join(f"{a:.0f}/{b:.0f}" for a, b in rec) if p > 0.3 else "")
+    if n >= 4096: print(n, f"blocking {sum(bt) / len(bt) / 1e3:.3f} ms:", " ".join(f"{v:.0f}" for v in bt), f"\n   pipelined {p:.3f} ms", " ".join(f"{a:.0f}/{b:.0f}" for a, b in rec))
