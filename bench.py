@@ -1043,6 +1043,19 @@ def bench_msm_skewed(ctx, torch, dev, K, bases, n, run_uniform, barrier, steps, 
     return out
 
 
+def median_rounds(fn, sync, mx, rounds=3):
+    """fn() -> (units, result) timed `rounds` times between synchronisations; (median seconds per unit, [ms per unit of every round], last result).
+    One timed window of 25-50 ms catches a runtime stall of a few milliseconds every few runs (profiles/r06_stalls.txt): +10 % on the figure."""
+    secs, res = [], None
+    for _ in range(rounds):
+        sync()
+        t0 = time.perf_counter()
+        units, res = fn()
+        sync()
+        secs.append(mx(time.perf_counter() - t0) / units)
+    return sorted(secs)[len(secs) // 2], [round(x * 1e3, 4) for x in secs], res
+
+
 def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=True, tickets=2, circuit="chain", from_witness=True):
     """secondary line: Groth16 prove at m = 2^log_m constraints (BASELINE.json configs[3]).  Circuit: the chain
     t_{i+1} = t_i * (t_i + 1) (x = [1, t_0], w = t_1..t_m); CRS:
@@ -1091,12 +1104,12 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
     proof = prove()
     for _ in range(WARM_PROOFS):          # untimed: the GPU idled behind the CPU legs; ~60 ms of load bring it back to its clock
         prove()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        proof = prove()
-    sync()
-    dt_blocking = mx(time.perf_counter() - t0) / steps
+    def blocking_round():
+        pr = None
+        for _ in range(steps):
+            pr = prove()
+        return steps, pr
+    dt_blocking, blocking_rounds, proof = median_rounds(blocking_round, sync, mx)
     # throughput: proofs issued back to back, two in flight (kg_groth16_prove_begin / _end) -- proof i+1's transforms and
     # sorts run under proof i's last reduction and host assembly; every proof is produced inside the timed region
     def run(k, depth=tickets):
@@ -1109,14 +1122,10 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
             last = ctx.groth16_prove_end(i % depth)
         return last
     run(2)
-    sync()
     k_pipe = max(2 * steps, 4)
-    t0 = time.perf_counter()
-    proof_p = run(k_pipe)
-    sync()
-    dt = mx(time.perf_counter() - t0) / k_pipe
+    dt, flight_rounds, proof_p = median_rounds(lambda: (k_pipe, run(k_pipe)), sync, mx)
     out = {"metric": "groth16_proofs_per_sec", "log_m": log_m, "value": world / dt, "ms_per_proof": r3(dt * 1e3), "replicas": world,
-           "ms_per_proof_blocking": r3(dt_blocking * 1e3),
+           "ms_per_proof_blocking": r3(dt_blocking * 1e3), "rounds_ms": flight_rounds, "blocking_rounds_ms": blocking_rounds,
            "pipelined_matches_blocking": bool(all((proof_p[i] == proof[i]).all() for i in range(4))),
            "algorithmic_bytes_per_proof": (7 * 64 + 4 * 32 + 4 * 96 + 160) * m,      # 1120 B per constraint
            "setup_ms": r3(setup_ms), "setup_first_ms": r3(setup_first_ms)}
@@ -1137,18 +1146,9 @@ def bench_groth16(ctx, torch, dev, K, env, log_m=18, steps=8, cpu=True, tables=T
         proof_t = prove()
         for _ in range(WARM_PROOFS):
             prove()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            proof_t = prove()
-        sync()
-        dt_tb = mx(time.perf_counter() - t0) / steps
+        dt_tb, _, proof_t = median_rounds(blocking_round, sync, mx)
         run(2)
-        sync()
-        t0 = time.perf_counter()
-        proof_tp = run(k_pipe)
-        sync()
-        dt_t = mx(time.perf_counter() - t0) / k_pipe
+        dt_t, _, proof_tp = median_rounds(lambda: (k_pipe, run(k_pipe)), sync, mx)
         out["window_tables"] = {"ms_per_proof": r3(dt_t * 1e3), "ms_per_proof_blocking": r3(dt_tb * 1e3), "value": world / dt_t, "build_ms": r3(build_ms),
                                 "proofs_match": bool(all((proof_t[i] == proof[i]).all() and (proof_tp[i] == proof[i]).all() for i in range(4)))}
     if tables and from_witness:
