@@ -1,5 +1,6 @@
-// msm_small_kernels.h -- the MSM of SHORT inputs (n <= 2^13 pairs) in ONE launch (two from 2^11): the reference's own tests and its bench
-// live at these lengths (groth16/src/msm.rs:118-135: 32 pairs; bn254/benches: 2^10; groth16/src/lib.rs:29-77: a handful of constraints).
+// msm_small_kernels.h -- the MSM of SHORT inputs (n <= 2^15 pairs; G2 20480) as ONE kernel shape: one launch up to 1536 pairs, a second one that
+// adds the bucket ranges of split windows beyond, a third in front that converts the scalars once from 2049 pairs.  The reference's own tests and
+// its bench live at these lengths (groth16/src/msm.rs:118-135: 32 pairs; bn254/benches: 2^10; groth16/src/lib.rs:29-77: a handful of constraints).
 //
 // The long-input pipeline (msm_sort.hip / msm_run.hip) is a chain of 15-20 dependent launches with one read-back in the middle: 0.24 ms
 // for 16 pairs, 0.44 ms for 2^10 .. 2^13.  Short inputs are latency, so here a workgroup owns a (window, bucket range) and does everything
@@ -7,14 +8,17 @@
 //
 //   digits      every lane converts scalars to integers (one Montgomery product) and cuts THIS window's signed digit (msm_digits.h);
 //               entries of the workgroup's bucket range are counted in an LDS histogram              [replaces get_at, msm.rs:75-91]
+//               glv: every scalar first becomes two 127-bit halves k1 + k2 lambda (glv_decompose_with) -- two list entries against P and
+//               (beta x, y), half the windows; KT form: the (half-)scalars come as word planes from k_small_prep, two loads per digit
 //   sort        exclusive scan, scatter of (index | sign) into an LDS list ordered by bucket
 //   tasks       the bucket lists are cut into <= 256 tasks of at most T entries (T from the entry count: a skewed input -- every scalar
 //               equal -- still fills the lanes)
 //   accumulate  one lane per task: XYZZ += +-P (madd-2008-s), bases read in the ABI form and converted on the fly, the next base on its way
 //               while the current addition runs                                                       [bucket fill, msm.rs:25-35]
 //   merge       partial sums of one bucket are added by a tree in LDS (depth log2 of the most tasks a bucket has)
-//   halve       sum_b (b + 1) B_b by halving levels (pair sums + odd items = bit planes of b), depth log2(buckets), operands in REGISTERS
-//               (the workgroup is alone on its CU: one wave per SIMD, 4.8 us per dependent addition)   [summation by parts, msm.rs:37-45]
+//   merge, halve, combine run on QUADS of lanes (coop_add.h: the 14 products of an addition in four steps of one product, 4.5 us per level)
+//   halve       sum_b (b + 1) B_b by halving levels (pair sums + odd items = bit planes of b), depth log2(buckets)
+//                                                                                                       [summation by parts, msm.rs:37-45]
 //   combine     window sum S_w = A + sum_l 2^l T_l: lane l doubles its plane l times, a tree adds the planes -- the host's chain then has
 //               ONE addition per window instead of c (255 doublings + W additions: ~65 us instead of ~130)
 //   export      S_w -> ABI words in the slot's pinned host buffer
@@ -35,7 +39,7 @@ namespace {        // internal linkage: the kernels of a header exist once per t
 constexpr int SM_NT = 256;            // threads per workgroup: one wave per SIMD of its CU
 constexpr uint32_t SM_TASKS = 256;    // tasks per workgroup (one per lane)
 constexpr uint32_t SM_SKIP = 0xffffu;
-constexpr uint32_t SM_MAX_N = 1u << 13;      // index field of a list entry: 13 bits (+ sign in bit 15)
+constexpr uint32_t SM_MAX_N = 1u << 13;      // longest input whose workgroups convert the scalars themselves (LDS: a digit code and a list entry per scalar)
 constexpr int SM_MAX_R = 7;           // at most 128 buckets per workgroup
 
 struct SmallArgs {
