@@ -459,8 +459,10 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // The halved scalars (GLV, msm_digits.h) shorten the host chains and lengthen the kernels: a single blocking MSM gains at every length, but a
   // proof's five launches run at once and the G1 ones are bound by their kernels -- 2^10 constraints 0.575 -> 0.64 ms with them, 2^12 0.76 -> 0.88;
   // up to 256 witness entries the chains are the critical path (2^4 .. 2^7 constraints: 0.44 -> 0.35 ms).  b_g2 keeps them (its Fq2 host chain is a
-  // proof's long pole: 0.19 -> 0.10 ms) up to KG_G16_G2_GLV_MAX entries, in fewer and longer workgroups than a lone MSM would take (r = 2: 64
-  // workgroups instead of 256 -- the other four launches need CUs too): 2^8 constraints 0.47 -> 0.42 ms, 2^10 0.58 -> 0.52, 2^12 0.80 -> 0.71
+  // proof's long pole: 0.19 -> 0.10 ms) up to KG_G16_G2_GLV_MAX = 1100 entries, in fewer and longer workgroups than a lone MSM would take (r = 2: 64
+  // workgroups instead of 256 -- the other four launches need CUs too): 2^8 constraints 0.47 -> 0.41 ms, 2^9 0.51 -> 0.44, 2^10 0.57 -> 0.53.  Beyond,
+  // such a workgroup's list outgrows LDS (2^12 constraints: 0.78 -> 1.03 ms) and the lone MSM's shape fills the chip (0.78 -> 0.86): off
+  // (h's MSM, the last launch of a proof, with halved scalars: level at 2^8 .. 2^12 -- measured, not kept)
   struct GlvGuard { kg_ctx* c; unsigned old; ~GlvGuard() { c->small_glv_off = old; } } glv_guard{ctx, ctx->small_glv_off};
   const bool proof_glv = nz <= 256 && hn <= 256;
   if (!proof_glv) ctx->small_glv_off |= (1u << KG_G1) | (nz > (size_t)ctx->tune.g16_g2_glv_max ? (1u << KG_G2) : 0u);

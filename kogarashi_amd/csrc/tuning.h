@@ -57,7 +57,7 @@
   /* ---- Groth16 prover -------------------------------------------------------------------------------------------------------------- */ \
   X(g16_h_early, "KG_G16_H_EARLY", 1, "order of h's transform chain in a proof: 1 = before the fused G1 accumulation, 0 = last (the order up to round 3), 2 = in front of the G2 accumulation") \
   X(g16_h_early_pipe, "KG_G16_H_EARLY_PIPE", 1, "0 = the early-h order only for blocking proofs") \
-  X(g16_g2_glv_max, "KG_G16_G2_GLV_MAX", 6144, "a proof's b_g2 MSM keeps the halved scalars (KG_SMALL_GLV) up to this many witness entries") \
+  X(g16_g2_glv_max, "KG_G16_G2_GLV_MAX", 1100, "a proof's b_g2 MSM keeps the halved scalars (KG_SMALL_GLV) up to this many witness entries") \
   X(g16_blind_early, "KG_G16_BLIND_EARLY", 1, "a proof's blinding chains (prover.rs:75-77, three 255-step host chains) start when the proof is enqueued; 0 = when its assembly starts") \
   X(g16_h_inline, "KG_G16_H_INLINE", 1, "a blocking proof runs h's reduction behind h's accumulation on the main queue") \
   /* ---- NTT ------------------------------------------------------------------------------------------------------------------------- */ \
