@@ -51,6 +51,20 @@ template <class P> struct CoopEl<Fp<P>> {
     return r;
   }
 };
+#if defined(__HIP_DEVICE_COMPILE__)
+// lane i of every quad of the wave receives the element held by lane PERM[i] of its quad (DPP quad_perm: one v_mov per word, no LDS)
+template <int PERM, class P>
+__device__ __forceinline__ Fp<P> coop_xchg(const Fp<P>& v) {
+  Fp<P> r;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r.l[k] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[k], PERM, 0xf, 0xf, true);
+  return r;
+}
+template <int PERM, class G>
+__device__ __forceinline__ Fp2<G> coop_xchg(const Fp2<G>& v) { return {coop_xchg<PERM>(v.c0), coop_xchg<PERM>(v.c1)}; }
+#endif
+constexpr int coop_perm(int p0, int p1, int p2, int p3) { return p0 | (p1 << 2) | (p2 << 4) | (p3 << 6); }
+
 template <class G> struct CoopEl<Fp2<G>> {
   static constexpr uint32_t E = 18;
   static KG_HD Fp2<G> ld(const uint32_t* base, uint32_t stride) { return {CoopEl<G>::ld(base, stride), CoopEl<G>::ld(base + 9 * stride, stride)}; }
@@ -205,13 +219,107 @@ KG_HD void coop_dbl_s3(const Q& q) {
   q.st(q.coord(q.io, l0 ? 1u : 3u), r);
 }
 
+// ---- the same steps with the values BETWEEN them in registers: pure per-lane functions of (lane, the operands' coordinates in the image,
+// the values handed in).  The driver moves values between the lanes of a quad -- DPP on the device (coop_add_level below: no LDS
+// temporaries, one workgroup barrier per level instead of four), array indexing in tests/host/hosttest.cpp (host_coop_add_regs).
+// Exchange schedule of an addition (r1, d, r2, r3: what a lane returned from steps 1, 2, 2, 3):
+//   before step 2:  a = r1 of lanes [1, 3, -, -],  b = r1 of lanes [0, 2, -, -]          (U2, S2 | U1, S1; lanes 2, 3 read the image)
+//   before step 3:  u1 = r1 of lane 0, pp = r2 of lane 0 (all lanes); lane 0 multiplies its own d, lane 2 its own r2
+//   before step 4:  e0 = r3 of [1, -, -, -] (Q), e1 = (lane 0: d of lane 1 = R | lane 1: r3 of lane 0 = PPP), e2 = r2 of [1, 3, -, -] (RR | ZZZ12),
+//                   e3 = r1 of [2, -, -, -] (S1)
+template <class Q>
+KG_HD typename Q::Field coop_a1(const Q& q) {
+  const int l = q.lane;
+  // lane 0: X1 ZZ2 (U1)   lane 1: X2 ZZ1 (U2)   lane 2: Y1 ZZZ2 (S1)   lane 3: Y2 ZZZ1 (S2)
+  const uint32_t first = (l & 1) ? q.ib : q.ia, second = (l & 1) ? q.ia : q.ib;
+  const uint32_t cd = (uint32_t)(l >> 1);
+  return mul(q.ld(q.coord(first, cd)), q.ld(q.coord(second, 2 + cd)));
+}
+template <class Q>
+KG_HD void coop_a2(const Q& q, const typename Q::Field& ta, const typename Q::Field& tb, typename Q::Field& d, typename Q::Field& r) {
+  using F = typename Q::Field;
+  const int l = q.lane;
+  const bool diff = l < 2;                             // lanes 0, 1: d = ta - tb (P, R) and its square (PP, RR); lanes 2, 3: ZZ1 ZZ2, ZZZ1 ZZZ2
+  const F a = Q::pick(diff, ta, q.ld(q.coord(q.ia, (uint32_t)(l | 2))));
+  const F b = Q::pick(diff, tb, q.ld(q.coord(q.ib, (uint32_t)(l | 2))));
+  d = norm(sub<4, 1>(a, b));
+  r = mul(Q::pick(diff, d, a), Q::pick(diff, d, b));
+}
+template <class Q>
+KG_HD typename Q::Field coop_a3(const Q& q, const typename Q::Field& d, const typename Q::Field& r2, const typename Q::Field& u1, const typename Q::Field& pp) {
+  using F = typename Q::Field;
+  const int l = q.lane;
+  // lane 0: P PP (PPP)   lane 1: U1 PP (Q)   lane 2: ZZ12 PP -> ZZ3   lane 3: (idle: computes lane 2's product, stores nothing)
+  const F a = Q::pick(l == 0, d, Q::pick(l == 1, u1, r2));
+  const F r = mul(a, pp);
+  if (l == 2) q.st(q.coord(q.io, 2), r);
+  return r;
+}
+template <class Q>
+KG_HD void coop_a4(const Q& q, const typename Q::Field& r3, const typename Q::Field& e0, const typename Q::Field& e1, const typename Q::Field& e2,
+                   const typename Q::Field& e3) {
+  using F = typename Q::Field;
+  if (q.lane >= 2) return;
+  const bool l0 = q.lane == 0;
+  // lane 0: X3 = RR - PPP - 2Q, Y3 = R (Q - X3) - S1 PPP;   lane 1: ZZZ3 = ZZZ12 PPP, the same double product with a zero subtrahend
+  const F ppp = Q::pick(l0, r3, e1);
+  const F x3 = vred(norm(sub<8, 3>(e2, add(ppp, dbl(e0)))));                      // (lane 1: a value nobody reads)
+  const F a = Q::pick(l0, e1, e2);
+  const F b = Q::pick(l0, norm(sub<4, 1>(e0, x3)), ppp);
+  const F c = Q::pick(l0, e3, F::zero());
+  const F r = mul2sub(a, b, c, ppp);
+  if (l0) q.st(q.coord(q.io, 0), x3);
+  q.st(q.coord(q.io, l0 ? 1u : 3u), r);
+}
+// doubling: r1, r2 = what a lane returned from steps 1, 2.  before step 2: v = r1 of lanes [0, 0, 0, 1] (V | XX for lane 3);
+// before step 3: e0 = r2 of [3, 0, -, -] (MM | W), e1 = r2 of [1, -, -, -] (S), e2 = r1 of [1, -, -, -] (XX)
+template <class Q>
+KG_HD typename Q::Field coop_d1(const Q& q) {
+  using F = typename Q::Field;
+  const bool l0 = (q.lane & 1) == 0;                   // lanes 0 (and 2): V = (2Y)^2   lanes 1 (and 3): XX = X^2
+  const F a = q.ld(q.coord(q.ia, l0 ? 1u : 0u));
+  const F u = Q::pick(l0, norm(dbl(a)), a);
+  return mul(u, u);
+}
+template <class Q>
+KG_HD typename Q::Field coop_d2(const Q& q, const typename Q::Field& v) {
+  using F = typename Q::Field;
+  const int l = q.lane;
+  // lane 0: (2Y) V (W)   lane 1: X V (S)   lane 2: V ZZ -> ZZ3   lane 3: (3 XX)^2 (MM), v = XX there
+  const F a = Q::pick(l == 3, v, q.ld(q.coord(q.ia, l == 0 ? 1u : (l == 1 ? 0u : 2u))));
+  const F two = norm(dbl(a)), three = norm(add(dbl(a), a));
+  const F u = Q::pick(l == 0, two, Q::pick(l == 3, three, a));
+  const F r = mul(u, Q::pick(l == 3, three, v));
+  if (l == 2) q.st(q.coord(q.io, 2), r);
+  return r;
+}
+template <class Q>
+KG_HD void coop_d3(const Q& q, const typename Q::Field& r2, const typename Q::Field& e0, const typename Q::Field& e1, const typename Q::Field& e2) {
+  using F = typename Q::Field;
+  if (q.lane >= 2) return;
+  const bool l0 = q.lane == 0;
+  // lane 0: X3 = MM - 2S, Y3 = M (S - X3) - W Y, M = 3 XX;   lane 1: ZZZ3 = W ZZZ
+  const F m = norm(add(dbl(e2), e2));
+  const F x3 = vred(norm(sub<4, 1>(e0, norm(dbl(e1)))));
+  const F w = Q::pick(l0, r2, e0);
+  const F a = Q::pick(l0, m, w);
+  const F b = Q::pick(l0, norm(sub<4, 1>(e1, x3)), q.ld(q.coord(q.ia, 3)));
+  const F c = Q::pick(l0, w, F::zero());
+  const F r = mul2sub(a, b, c, q.ld(q.coord(q.ia, 1)));
+  if (l0) q.st(q.coord(q.io, 0), x3);
+  q.st(q.coord(q.io, l0 ? 1u : 3u), r);
+}
+
 #if defined(__HIPCC__)
 // One level of additions over a workgroup: quad t of the workgroup (lanes 4t .. 4t+3) adds items ia + ib -> io when `active`.  Every
-// thread of the workgroup must call it (four barriers).  tmp: COOP_TMP_SLOTS * E * nquads words, flg: nquads words (nquads = blockDim.x / 4).
+// thread of the workgroup must call it (one workgroup barrier, at its end: between the steps only the quad's own lanes exchange values, by
+// DPP).  tmp, flg: unused since the values between the steps live in registers (kept in the signature: the LDS layout of the callers).
+// KG_COOP_LDS builds keep the older form (temporaries in LDS, four barriers) for A/B runs.
 template <class F>
 __device__ __forceinline__ void coop_add_level(uint32_t* img, uint32_t cap, uint32_t* tmp, uint32_t* flg, bool active, uint32_t ia, uint32_t ib, uint32_t io) {
   const CoopQuad<F> q{img, cap, tmp, blockDim.x >> 2, threadIdx.x >> 2, flg, ia, ib, io, (int)(threadIdx.x & 3u)};
   const int mode = active ? coop_add_mode(q) : COOP_IDLE;
+#if defined(KG_COOP_LDS) || !defined(__HIP_DEVICE_COMPILE__)
   if (mode == COOP_ADD) coop_add_s1(q);
   __syncthreads();
   if (mode == COOP_ADD) coop_add_s2(q);
@@ -220,6 +328,29 @@ __device__ __forceinline__ void coop_add_level(uint32_t* img, uint32_t cap, uint
   __syncthreads();
   coop_add_s4(q, mode);
   __syncthreads();
+#else
+  if (mode == COOP_ADD) {                                   // (uniform over the quad: all four lanes are here together)
+    const F r1 = coop_a1(q);
+    F d, r2;
+    coop_a2(q, coop_xchg<coop_perm(1, 3, 2, 3)>(r1), coop_xchg<coop_perm(0, 2, 2, 3)>(r1), d, r2);
+    const F pp = coop_xchg<coop_perm(0, 0, 0, 0)>(r2);
+    const F rr = coop_xchg<coop_perm(1, 1, 1, 1)>(d);     // R, for the test of the exceptional case and step 4
+    if (is_zero_2p(pp)) {                                   // equal x (weierstrass.rs:114-120): the one-lane formulas; rare
+      if (q.lane == 0) {
+        if (is_zero(rr)) coop_set_point(q, q.io, double_xyzz(coop_point(q, q.ia)));
+        else coop_set_point(q, q.io, XYZZ<F>::identity());
+      }
+    } else {
+      const F r3 = coop_a3(q, d, r2, coop_xchg<coop_perm(0, 0, 0, 0)>(r1), pp);
+      const F e1 = CoopQuad<F>::pick(q.lane == 0, rr, coop_xchg<coop_perm(0, 0, 0, 0)>(r3));
+      coop_a4(q, r3, coop_xchg<coop_perm(1, 1, 1, 1)>(r3), e1, coop_xchg<coop_perm(1, 3, 2, 3)>(r2), coop_xchg<coop_perm(2, 2, 2, 2)>(r1));
+    }
+  } else if (mode == COOP_TAKE_A || mode == COOP_TAKE_B) {
+    const uint32_t src = mode == COOP_TAKE_A ? q.ia : q.ib;
+    if (src != q.io) q.st(q.coord(q.io, (uint32_t)q.lane), q.ld(q.coord(src, (uint32_t)q.lane)));
+  }
+  __syncthreads();
+#endif
 }
 // `times` doublings in place of item `it` by quad t (times may differ between quads; uniform trip count `max_times` for the barriers)
 template <class F>
@@ -227,12 +358,21 @@ __device__ __forceinline__ void coop_dbl_level(uint32_t* img, uint32_t cap, uint
   const CoopQuad<F> q{img, cap, tmp, blockDim.x >> 2, threadIdx.x >> 2, flg, it, it, it, (int)(threadIdx.x & 3u)};
   for (uint32_t k = 0; k < max_times; ++k) {
     const bool on = k < times && coop_dbl_active(q);
+#if defined(KG_COOP_LDS) || !defined(__HIP_DEVICE_COMPILE__)
     if (on) coop_dbl_s1(q);
     __syncthreads();
     if (on) coop_dbl_s2(q);
     __syncthreads();
     if (on) coop_dbl_s3(q);
     __syncthreads();
+#else
+    if (on) {
+      const F r1 = coop_d1(q);
+      const F r2 = coop_d2(q, coop_xchg<coop_perm(0, 0, 0, 1)>(r1));
+      coop_d3(q, r2, coop_xchg<coop_perm(3, 0, 2, 3)>(r2), coop_xchg<coop_perm(1, 1, 1, 1)>(r2), coop_xchg<coop_perm(1, 1, 1, 1)>(r1));
+    }
+    __syncthreads();                                        // the next doubling reads the item this one wrote (its lanes 0 .. 2 wrote, all four read)
+#endif
   }
 }
 #endif

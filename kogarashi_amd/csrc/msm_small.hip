@@ -32,13 +32,11 @@ bool msm_small_plan(const kg_ctx* ctx, int curve, size_t n, int* c_out, int* r_o
     if (curve == KG_G2) {
       if (n <= 48) { c = 2; r = 1; }
       else if (n <= 160) { c = 2; r = 0; }
-      else if (n <= 6144) { c = 4; r = 0; }
+      else if (n <= 2048) { c = 4; r = 1; }
       else { c = 8; r = 3; }
     } else {
-      if (n <= 160) { c = 2; r = 1; }
-      else if (n <= 384) { c = 4; r = 3; }
-      else if (n <= 1536) { c = 4; r = 1; }
-      else if (n <= 4096) { c = 4; r = 0; }
+      if (n <= 384) { c = 2; r = 1; }
+      else if (n <= 2048) { c = 4; r = 1; }
       else { c = 8; r = 3; }
     }
   } else
@@ -50,7 +48,8 @@ bool msm_small_plan(const kg_ctx* ctx, int curve, size_t n, int* c_out, int* r_o
   } else {
     if (n <= 1536) { c = 2; r = 1; }
     else if (n <= 6144) { c = 5; r = 2; }
-    else { c = 8; r = 3; }                           // 32 windows x 16 workgroups of eight buckets: fewer passes over the converted scalars
+    else if (n <= 28672) { c = 8; r = 4; }           // 32 windows x 8 workgroups of sixteen buckets (interleaved): fewer passes over the converted scalars
+    else { c = 8; r = 3; }
   }
   if (tn.small_c >= 2 && tn.small_c <= 10) { c = tn.small_c; r = c - 1 < SM_MAX_R ? c - 1 : SM_MAX_R; }
   if (tn.small_r >= 0 && tn.small_r <= SM_MAX_R) r = tn.small_r;

@@ -230,7 +230,10 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
   const uint32_t tid = threadIdx.x, qd = tid >> 2;
   const int c = a.c, W = a.W, r = a.r;
   const uint32_t R = 1u << r;
-  const uint32_t w = blockIdx.x, jb = blockIdx.y, b0 = jb << r;
+  // A split window's buckets are dealt to its NB workgroups INTERLEAVED: bucket b (0-based) belongs to workgroup b mod NB, local index b / NB.
+  // The top window holds fewer bits than the others (values 0 .. 83 of 128 buckets for eight-bit windows over 127-bit halves): in contiguous
+  // ranges its first workgroups would carry 1.5 times the entries of any other workgroup of the launch, and the rest none.
+  const uint32_t w = blockIdx.x, jb = blockIdx.y, nbm = (uint32_t)a.NB - 1u, nbs = (uint32_t)(c - 1 - r);      // NB = 2^nbs
   const uint32_t n = a.n, n_pad = (n + 1u) & ~1u;
   const uint32_t CAP = SM_TASKS + R + 1, IDENT = SM_TASKS + R;      // the last item stays the identity (an empty bucket's sum)
   uint32_t* const pts = lds;                                // NW planes x CAP items: items [0, SM_TASKS) task sums / image Y, [SM_TASKS, SM_TASKS + R) image X
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
   uint32_t* const tsize = tfirst + R;                       // R + 1: task slots of each bucket (0 or a power of two)
   uint32_t* const misc = tsize + R + 1;                     // 80: scan scratch [0, 40), slot classes: count [40, 49), base [50, 60)
   uint16_t* const task_b = reinterpret_cast<uint16_t*>(misc + 80);    // SM_TASKS: bucket of each task slot
-  uint16_t* const dig = task_b + SM_TASKS;                  // n: (bucket - b0) | sign << 15, or SM_SKIP (not in the KT form: the digit is cut again)
+  uint16_t* const dig = task_b + SM_TASKS;                  // n: (local bucket index) | sign << 15, or SM_SKIP (not in the KT form: the digit is cut again)
   uint16_t* sorted = KT ? dig : dig + n_pad;                // (index | sign << 15) ordered by bucket: n entries; KT form: SM_LIST_CAP, or a run of the spill space
 
   KG_SM_STAMP(0);
@@ -263,7 +266,7 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
         if (i >= n) break;
         bool neg;
         const uint32_t m = (fl[u] & 2u) ? 0u : sm_digit_words(v.lo[u], v.hi[u], (int)w, c, W, neg);
-        if (m && ((m - 1) >> r) == jb) atomicAdd(&hist[m - 1 - b0], 1u);
+        if (m && ((m - 1) & nbm) == jb) atomicAdd(&hist[(m - 1) >> nbs], 1u);
       }
     }
   } else if (a.glv) {
@@ -292,9 +295,9 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
         uint32_t m = small_window_digit(ks[e], (int)w, c, W, neg);
         if (ident) m = 0;
         uint32_t code = SM_SKIP;
-        if (m && ((m - 1) >> r) == jb) {
-          code = (m - 1 - b0) | ((neg != ng[e]) ? 0x8000u : 0u);
-          atomicAdd(&hist[m - 1 - b0], 1u);
+        if (m && ((m - 1) & nbm) == jb) {
+          code = ((m - 1) >> nbs) | ((neg != ng[e]) ? 0x8000u : 0u);
+          atomicAdd(&hist[(m - 1) >> nbs], 1u);
         }
         if constexpr (!KT) dig[2 * i + e] = (uint16_t)code;
       }
@@ -318,9 +321,9 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
     }
     if (a.inf && a.inf[i]) m = 0;                          // identity base (msm.rs adds it as a no-op)
     uint32_t code = SM_SKIP;
-    if (m && ((m - 1) >> r) == jb) {
-      code = (m - 1 - b0) | (neg ? 0x8000u : 0u);
-      atomicAdd(&hist[m - 1 - b0], 1u);
+    if (m && ((m - 1) & nbm) == jb) {
+      code = ((m - 1) >> nbs) | (neg ? 0x8000u : 0u);
+      atomicAdd(&hist[(m - 1) >> nbs], 1u);
     }
     if constexpr (!KT) dig[i] = (uint16_t)code;
   }
@@ -387,8 +390,8 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
         if (i >= n) break;
         bool neg;
         const uint32_t m = (fl[u] & 2u) ? 0u : sm_digit_words(v.lo[u], v.hi[u], (int)w, c, W, neg);
-        if (m && ((m - 1) >> r) == jb) {
-          const uint32_t pos = atomicAdd(&hist[m - 1 - b0], 1u);
+        if (m && ((m - 1) & nbm) == jb) {
+          const uint32_t pos = atomicAdd(&hist[(m - 1) >> nbs], 1u);
           sorted[pos] = (uint16_t)(i | ((neg != ((fl[u] & 1u) != 0)) ? 0x8000u : 0u));     // the digit's sign times the sub-scalar's
         }
       }
@@ -493,9 +496,9 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
   KG_SM_STAMP(7);
 }
 
-// Second launch of a split window (NB > 1 bucket ranges of 2^r buckets): plane l < r is the sum of the ranges' local planes, plane
-// r + h the sum of the totals A_j of the ranges whose index has bit h set (the high bits of the bucket number), the total the sum of
-// all A_j.  LDS: c planes x NB items; a tree of cooperative additions along the ranges, then the combine of the fused kernel.
+// Second launch of a split window (its 2^(c-1) buckets dealt to NB workgroups, bucket b to workgroup b mod NB): the plane of bucket bit
+// h < log2 NB is the sum of the totals A_j of the workgroups whose index j has bit h set, the plane of bit log2 NB + l the sum of the
+// workgroups' local planes l, the total the sum of all A_j.  LDS: c planes x NB items; a tree of cooperative additions along the ranges, then the combine of the fused kernel.
 template <class F>
 __global__ void __launch_bounds__(SM_NT) k_msm_small_combine(SmallArgs a) {
   extern __shared__ uint32_t lds[];
@@ -511,8 +514,12 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small_combine(SmallArgs a) {
     const uint32_t p = it / NB, j = it % NB;
     XYZZ<F> v = XYZZ<F>::identity();
     const uint32_t* src = a.planes + (size_t)(w * NB + j) * (SM_MAX_R + 1) * NW;
-    if (p <= (uint32_t)r) v = PointAoS<F>::load(src + (size_t)p * NW, 0);                       // total (p = 0) and the local planes
-    else if ((j >> (p - 1 - (uint32_t)r)) & 1u) v = PointAoS<F>::load(src, 0);                  // high bucket bit h = p - 1 - r: the range's total
+    // bucket b = local * NB + j (interleaved): bit h < log2 NB of b is bit h of the workgroup's index j -- plane 1 + h is the sum of the totals
+    // of the workgroups whose j has it set; bit log2 NB + l is the local plane l
+    const uint32_t nbs = (uint32_t)c - 1u - (uint32_t)r;
+    if (p == 0) v = PointAoS<F>::load(src, 0);                                                    // the total
+    else if (p <= nbs) { if ((j >> (p - 1)) & 1u) v = PointAoS<F>::load(src, 0); }                // low bucket bit h = p - 1: the workgroup's total
+    else v = PointAoS<F>::load(src + (size_t)(p - nbs) * NW, 0);                                  // local plane l = p - nbs - 1: item 1 + l
     PointIO<F>::store(lds, CAP, it, v);
   }
   __syncthreads();

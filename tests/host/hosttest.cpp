@@ -162,6 +162,46 @@ static void host_coop_dbl(std::vector<XYZZ<F>>& img, uint32_t it) {
   for (int l = 3; l >= 0; --l) coop_dbl_s2(quad(l));
   for (int l = 0; l < 4; ++l) coop_dbl_s3(quad(l));
 }
+// The register form of the same steps (coop_a1 .. a4, coop_d1 .. d3: what the device runs): the four lanes' values between the steps are
+// arrays here, the exchange schedule of coop_add.h's comment is the indexing below (the device's DPP patterns in coop_add_level).
+template <class F>
+static void host_coop_add_regs(std::vector<XYZZ<F>>& img, uint32_t ia, uint32_t ib, uint32_t io) {
+  std::vector<F> tmp(COOP_TMP_SLOTS, F::zero());
+  uint32_t flag = 0;
+  auto quad = [&](int lane) { return HostQuad<F>{&img, &tmp, &flag, ia, ib, io, lane}; };
+  const int mode = coop_add_mode(quad(0));
+  if (mode == COOP_TAKE_A || mode == COOP_TAKE_B) { for (int l = 0; l < 4; ++l) coop_add_s3(quad(l), mode); return; }
+  if (mode != COOP_ADD) return;
+  F r1[4], d[4], r2[4], r3[4];
+  for (int l = 0; l < 4; ++l) r1[l] = coop_a1(quad(l));
+  const int pa[4] = {1, 3, 2, 3}, pb[4] = {0, 2, 2, 3};
+  for (int l = 3; l >= 0; --l) coop_a2(quad(l), r1[pa[l]], r1[pb[l]], d[l], r2[l]);
+  const F pp = r2[0], rr = d[1];
+  if (is_zero_2p(pp)) {
+    if (is_zero(rr)) coop_set_point(quad(0), io, double_xyzz(coop_point(quad(0), ia)));
+    else coop_set_point(quad(0), io, XYZZ<F>::identity());
+    return;
+  }
+  for (int l = 0; l < 4; ++l) r3[l] = coop_a3(quad(l), d[l], r2[l], r1[0], pp);
+  const int pe2[4] = {1, 3, 2, 3};
+  for (int l = 3; l >= 0; --l) coop_a4(quad(l), r3[l], r3[1], l == 0 ? rr : r3[0], r2[pe2[l]], r1[2]);
+}
+template <class F>
+static void host_coop_dbl_regs(std::vector<XYZZ<F>>& img, uint32_t it) {
+  std::vector<F> tmp(COOP_TMP_SLOTS, F::zero());
+  uint32_t flag = 0;
+  auto quad = [&](int lane) { return HostQuad<F>{&img, &tmp, &flag, it, it, it, lane}; };
+  if (!coop_dbl_active(quad(0))) return;
+  F r1[4], r2[4];
+  for (int l = 0; l < 4; ++l) r1[l] = coop_d1(quad(l));
+  const int pv[4] = {0, 0, 0, 1};
+  // (the device's lanes read the item before any lane of the quad writes it: step 2's reads of all lanes come before lane 2's store in
+  // program order; here the loop order does the same -- lane 2 last)
+  const int order2[4] = {0, 1, 3, 2};
+  for (int k = 0; k < 4; ++k) { const int l = order2[k]; r2[l] = coop_d2(quad(l), r1[pv[l]]); }
+  const int pe0[4] = {3, 0, 2, 3};
+  for (int l = 1; l >= 0; --l) coop_d3(quad(l), r2[l], r2[pe0[l]], r2[1], r1[1]);
+}
 // mode 0: left fold with add_mixed; 1: pairwise tree with add_xyzz; 2: fold of add_xyzz(from_affine);
 // 3: sum_i 2*P_i via double_affine + add_xyzz; 4: double_xyzz applied `n` times to point 0; 5: fold, negated;
 // 7: fold of add_mixed_signed(acc, -P_i, negate = true), i.e. the sign folded back: equals mode 0;
@@ -242,6 +282,23 @@ static int curve_sum(int mode, const uint32_t* pts, const uint8_t* inf, size_t n
       v.swap(w);
     }
     if (!v.empty()) acc = v[0];
+  } else if (mode == 14 || mode == 15) {                   // 12 / 13 through the register form of the steps (what the device runs)
+    std::vector<XYZZ<F>> v;
+    XYZZ<F> part = XYZZ<F>::identity();
+    size_t cnt = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (!(inf && inf[i])) {
+        Affine<F> a = ld_aff<F>(pts + W2 * i);
+        part = (i & 1) ? add_mixed_signed(part, neg_affine(a), true) : add_mixed_signed(part, a, false);
+      }
+      if (++cnt == 3 || i + 1 == n) { v.push_back(part); part = XYZZ<F>::identity(); cnt = 0; }
+    }
+    for (size_t s_ = 1; s_ < v.size(); s_ <<= 1)
+      for (size_t i = 0; i + s_ < v.size(); i += 2 * s_) host_coop_add_regs(v, (uint32_t)i, (uint32_t)(i + s_), (uint32_t)i);
+    if (!v.empty()) {
+      if (mode == 15) { host_coop_dbl_regs(v, 0); host_coop_dbl_regs(v, 0); }
+      acc = v[0];
+    }
   } else if (mode == 12 || mode == 13) {
     // coop_add.h: 12 = chunks of three folded with add_mixed_signed (X not value-reduced), then a pairwise tree of COOPERATIVE additions
     // in place on the left operand (the kernels' merge / halving / combine levels); 13 = the same tree, then the sum doubled twice by the

@@ -142,9 +142,10 @@ def _check_point_formulas(hostlib, pyoracle, name):
                 if not f:
                     exp = cur.add(exp, pt)
             for chk in (0, 1):
-                for mode in (0, 1, 2, 7, 8, 9, 12):     # 9: the streaming formulas in place on their first operand; 12: the lane-cooperative addition (coop_add.h)
+                for mode in (0, 1, 2, 7, 8, 9, 12, 14):     # 9: the streaming formulas in place on their first operand; 12 / 14: the lane-cooperative addition (coop_add.h), temporaries in LDS / in registers
                     assert curve_sum(hostlib, cid, cur, chk, mode, pts, inf) == exp, (name, ci, some_inf, chk, mode)
                 assert curve_sum(hostlib, cid, cur, chk, 13, pts, inf) == cur.mul(exp, 4), (name, ci, "coop dbl")
+                assert curve_sum(hostlib, cid, cur, chk, 15, pts, inf) == cur.mul(exp, 4), (name, ci, "coop dbl, register form")
                 assert curve_sum(hostlib, cid, cur, chk, 5, pts, inf) == cur.neg(exp)
                 assert curve_sum(hostlib, cid, cur, chk, 3, pts, inf) == cur.add(exp, exp), (name, ci, "dbl")
     # mode 11: the short-input kernel's shape (msm_small_kernels.h) -- task sums by add_mixed_signed whose X is not value-reduced, doubled as

@@ -16,7 +16,7 @@ for v in "$@"; do
   for d in ${defs//+/ }; do D="$D -D$d"; done
   ( hipcc -x hip $FL $D -c $C/$SRC -o build/exp/${STEM}_$name.o
     OBJS=""
-    for o in capi tuning sharded msm_host vec msm_sort msm_run ntt groth16 setup; do
+    for o in capi tuning sharded msm_host vec msm_sort msm_run msm_small ntt groth16 setup; do
       if [ $o = $STEM ]; then OBJS="$OBJS build/exp/${STEM}_$name.o"; else OBJS="$OBJS $C/$o.o"; fi
     done
     hipcc --offload-arch=gfx950 -shared -fPIC -o build/exp/libkg_$name.so $OBJS && echo built $name ) &
