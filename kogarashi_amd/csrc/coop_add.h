@@ -75,7 +75,15 @@ template <class G> struct CoopEl<Fp2<G>> {
   static KG_HD Fp2<G> pick(bool first, const Fp2<G>& a, const Fp2<G>& b) { return {CoopEl<G>::pick(first, a.c0, b.c0), CoopEl<G>::pick(first, a.c1, b.c1)}; }
 };
 
-constexpr uint32_t COOP_TMP_SLOTS = 10;            // temporaries per quad
+constexpr uint32_t COOP_TMP_SLOTS = 10;            // temporaries per quad (the LDS form of the steps: KG_COOP_LDS builds, tests/host)
+// LDS words a kernel sets aside for the temporaries and flags of nquads quads: none in the register form
+template <class F> constexpr uint32_t coop_lds_words(uint32_t nquads) {
+#ifdef KG_COOP_LDS
+  return (COOP_TMP_SLOTS * CoopEl<F>::E + 1) * nquads;
+#else
+  return 0 * nquads;
+#endif
+}
 
 // What one lane of a quad works on.  ia, ib: operand items; io: result item (may be ia or ib: every read of an operand coordinate comes
 // before the step that writes the same coordinate of the result).  Ref: where an element lives (first word, stride between its words).

@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HalveW
 template <class F> struct TailCoopNT { static constexpr int NT = 512; };
 template <class G> struct TailCoopNT<Fp2<G>> { static constexpr int NT = 256; };
 template <class F>
-static size_t tail_coop_lds_bytes(uint32_t L) { return ((size_t)PointIO<F>::NW * 2 * L + (COOP_TMP_SLOTS * CoopEl<F>::E + 1) * (TailCoopNT<F>::NT / 4)) * 4; }
+static size_t tail_coop_lds_bytes(uint32_t L) { return ((size_t)PointIO<F>::NW * 2 * L + coop_lds_words<F>(TailCoopNT<F>::NT / 4)) * 4; }
 template <class F, int E64>
 __global__ void __launch_bounds__(TailCoopNT<F>::NT) k_reduce_tail_coop(const uint32_t* in, size_t in_stride, int narr_in, uint32_t L, int c, uint64_t* __restrict__ out) {
   extern __shared__ uint32_t lds[];

@@ -180,7 +180,7 @@ __device__ __forceinline__ uint32_t sm_digit_words(uint32_t lo, uint32_t hi, int
   return (uint32_t)(d < 0 ? -d : d);
 }
 // LDS words of the cooperative additions' temporaries and flags (coop_add.h) for a 256-thread workgroup
-template <class F> constexpr uint32_t sm_coop_words() { return COOP_TMP_SLOTS * CoopEl<F>::E * (SM_NT / 4) + SM_NT / 4; }
+template <class F> constexpr uint32_t sm_coop_words() { return coop_lds_words<F>(SM_NT / 4); }      // (none since the steps keep their values in registers)
 constexpr int SM_CLASSES = 9;          // a bucket owns 2^k task slots, k = 0 .. 8
 
 // LDS bytes of k_msm_small for n scalars and 2^r buckets per workgroup
@@ -238,8 +238,8 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small(SmallArgs a) {
   const uint32_t CAP = SM_TASKS + R + 1, IDENT = SM_TASKS + R;      // the last item stays the identity (an empty bucket's sum)
   uint32_t* const pts = lds;                                // NW planes x CAP items: items [0, SM_TASKS) task sums / image Y, [SM_TASKS, SM_TASKS + R) image X
   uint32_t* const ctmp = pts + (size_t)NW * CAP;            // temporaries of the cooperative additions
-  uint32_t* const cflg = ctmp + COOP_TMP_SLOTS * CoopEl<F>::E * (SM_NT / 4);
-  uint32_t* const hist = cflg + SM_NT / 4;                  // R: entries per bucket, then the scatter cursors
+  uint32_t* const cflg = ctmp + (sm_coop_words<F>() ? COOP_TMP_SLOTS * CoopEl<F>::E * (SM_NT / 4) : 0u);
+  uint32_t* const hist = ctmp + sm_coop_words<F>();                  // R: entries per bucket, then the scatter cursors
   uint32_t* const boff = hist + R;                          // R + 1: first list position of each bucket
   uint32_t* const tfirst = boff + R + 1;                    // R: first task slot of each bucket (IDENT for an empty one)
   uint32_t* const tsize = tfirst + R;                       // R + 1: task slots of each bucket (0 or a power of two)
@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(SM_NT) k_msm_small_combine(SmallArgs a) {
   const uint32_t NB = (uint32_t)a.NB, np = (uint32_t)c;     // planes of the whole window: total, T_0 .. T_{c-2}
   const uint32_t CAP = np * NB;
   uint32_t* const ctmp = lds + (size_t)NW * (CAP + np);
-  uint32_t* const cflg = ctmp + COOP_TMP_SLOTS * CoopEl<F>::E * (SM_NT / 4);
+  uint32_t* const cflg = ctmp + (sm_coop_words<F>() ? COOP_TMP_SLOTS * CoopEl<F>::E * (SM_NT / 4) : 0u);
   // item (p, j) at p * NB + j
   for (uint32_t it = tid; it < CAP; it += SM_NT) {
     const uint32_t p = it / NB, j = it % NB;
