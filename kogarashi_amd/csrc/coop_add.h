@@ -1,4 +1,4 @@
-// coop_add.h -- one XYZZ point addition (or doubling) computed by FOUR lanes (a quad), operands and intermediate values in an LDS image.
+// coop_add.h -- one XYZZ point addition (or doubling) computed by FOUR lanes (a quad): operands and results in an LDS image, intermediate values in registers.
 //
 // Why: the reduction trees of an MSM (partial sums of a bucket, the halving levels, the window sum) are chains of DEPENDENT point
 // additions run by few lanes on an otherwise idle CU.  A wave issues ~one VALU instruction every 5 cycles whatever the number of active
@@ -14,7 +14,11 @@
 // (dbl-2008-s-1) is three steps.  SIMT: the lanes of a wave share one instruction stream, so a step is written as ONE product whose
 // operands every lane picks by ADDRESS (per-lane element references into the image), with the cheap linear pre-operations (a lazy
 // subtraction, a doubling) computed by all lanes and selected -- a `switch (lane)` around four different products would run them one after
-// the other.  The lanes exchange values through ten temporaries per quad in LDS; a step ends with a workgroup barrier.
+// the other.  Between the steps only the quad's own lanes exchange values: each lane keeps what it computed in registers and the next step's
+// operands arrive by DPP quad_perm (one v_mov per word; coop_a1 .. a4, coop_d1 .. d3 and the exchange schedule further down) -- a level ends
+// with ONE workgroup barrier, for the readers of its results.  (The first form kept ten temporaries per quad in LDS and ended every step with a
+// barrier: coop_add_s1 .. s4, still what KG_COOP_LDS builds and two of the host test modes run; the register form took the short-input kernel
+// from 217 to 149 VGPRs.)
 //
 // The exceptional cases of the reference's formulas (zkstd/src/arithmetic/points/weierstrass.rs:102-123: identity operands, equal x =>
 // doubling or the identity) are kept: identity operands turn the addition into a copy, PP = 0 sends lane 0 of the quad through the one-lane
