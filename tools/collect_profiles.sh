@@ -17,9 +17,9 @@ timeout -s KILL 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/
 #    roofline.kernel_ms of the line printed under the profiler (the pre-warm's cold-clock launches are a sixth of the launches)
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_msm" -- python3 bench.py --headline-only --steps 200 --warmup 10 > "$O/msm_under_rocprof.json" 2> "$O/kt_msm.err"
 python3 tools/kernel_table.py "$O/kt_msm" --per 1210 --last-of k_acc_tasks 1000 --title "bench.py --headline-only --steps 200 --warmup 10 under rocprofv3 --kernel-trace (1210 MSMs of 2^20 pairs, the last 1000 timed); us per unit = per MSM" > "$O/msm_kernel_table.txt" 2>&1
-# 3b. the prover alone (bench.py --groth16-only: setup, 16 + 16 blocking proofs, 34 proofs two in flight): the phase table behind DESIGN.md section 10
+# 3b. the prover alone (bench.py --groth16-only: setup, 17 warm + 3 x 16 blocking proofs, 2 + 3 x 32 proofs two in flight): the phase table behind DESIGN.md section 10
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_g16" -- python3 bench.py --groth16-only --steps 16 > "$O/g16_under_rocprof.json" 2> "$O/kt_g16.err"
-python3 tools/kernel_table.py "$O/kt_g16" --per 67 --split-grid k_acc_tasks --title "bench.py --groth16-only --steps 16 under rocprofv3 --kernel-trace: 2 setups + 67 proofs of 2^18 constraints (1 + 16 warm + 16 blocking, 2 + 32 two in flight); us per unit = per proof (setup kernels included in the list, not in a proof)" > "$O/g16_phase_table.txt" 2>&1
+python3 tools/kernel_table.py "$O/kt_g16" --per 163 --split-grid k_acc_tasks --title "bench.py --groth16-only --steps 16 under rocprofv3 --kernel-trace: 2 setups + 163 proofs of 2^18 constraints (1 + 16 warm, 3 x 16 blocking, 2 + 3 x 32 two in flight: medians of three rounds); us per unit = per proof (setup kernels included in the list, not in a proof)" > "$O/g16_phase_table.txt" 2>&1
 # 3c. the G2 MSM alone (2^18 pairs: 24 + 3 x 20 four in flight, 1 + 5 alone, 2 + 20 blocking in two window groups)
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_g2" -- python3 bench.py --msm-g2-only --steps 20 --rounds 3 --no-cpu-baseline > "$O/g2_under_rocprof.json" 2> "$O/kt_g2.err"
 python3 tools/kernel_table.py "$O/kt_g2" --split-grid k_acc_tasks --title "bench.py --msm-g2-only --steps 20 --rounds 3 under rocprofv3 --kernel-trace" > "$O/g2_kernel_table.txt" 2>&1
