@@ -359,6 +359,31 @@ extern "C" int ht_small_digits(const uint32_t* k, size_t n, int c, int32_t* digi
   return W;
 }
 
+// The whole digit path of a scalar with halved scalars (glv): decomposition, |k_e| + H over W = ceil(128 / c) windows, signed digits with the
+// half's sign folded in.  digits: [n][2][64] (window w of half e); returns W.
+extern "C" int ht_glv_digits(int field, const uint32_t* k, size_t n, int c, int32_t* digits) {
+  const int W = (128 + c - 1) / c;
+  uint32_t H[8];
+  small_bias(c, W, H);
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t ks[2][8];
+    bool ng[2];
+    if (field == 0) kg::glv_decompose_with<kg::GlvLattice<kg::FrParams>>(k + 8 * i, ks[0], ng[0], ks[1], ng[1]);
+    else kg::glv_decompose_with<kg::GlvLattice<kg::FqParams>>(k + 8 * i, ks[0], ng[0], ks[1], ng[1]);
+    for (int e = 0; e < 2; ++e) {
+      uint64_t cy = 0;
+      for (int j = 0; j < 4; ++j) { const uint64_t s_ = (uint64_t)ks[e][j] + H[j] + cy; ks[e][j] = (uint32_t)s_; cy = s_ >> 32; }
+      for (int j = 4; j < 8; ++j) ks[e][j] = 0;
+      for (int w = 0; w < W; ++w) {
+        bool neg;
+        const uint32_t m = small_window_digit(ks[e], w, c, W, neg);
+        digits[(i * 2 + e) * 64 + w] = (neg != ng[e]) ? -(int32_t)m : (int32_t)m;
+      }
+    }
+  }
+  return W;
+}
+
 // ---- NTT butterfly network (ntt_core.h) ---------------------------------------------------------------
 // data: 8 raw elements (any 256-bit value, as loaded by the kernel without a domain change), tw: 7 twiddles in the
 // ABI's Montgomery form (stage 1: tw[0]; stage 2: tw[1..2]; stage 3: tw[3..6]); `rounds` networks are chained with a

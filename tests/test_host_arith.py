@@ -279,3 +279,28 @@ def test_glv_decomposition_recomposes_the_scalar(hostlib, pyoracle, fd, name):
         H = sum(1 << (w * c + c - 1) for w in range(W - 1))
         assert (worst + H) >> ((W - 1) * c) <= 1 << (c - 1), c
         assert ((3 << 125) + H) >> ((W - 1) * c) <= 1 << (c - 1), c        # and for the proven bound
+
+
+@pytest.mark.parametrize("c", [2, 3, 4, 5, 8, 10])
+def test_glv_digit_path_recomposes_the_scalar(hostlib, pyoracle, c):
+    """what k_msm_small / k_small_prep do to a scalar with halved scalars, on the host: decompose, bias, cut W = ceil(128 / c) windows per half,
+    fold the half's sign into the digit's -- sum_w d1_w 2^(cw) + lambda sum_w d2_w 2^(cw) = k (mod n), every |digit| a bucket number <= 2^(c-1)"""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("glv_consts", os.path.join(root, "tools", "gen", "glv_consts.py"))
+    G = importlib.util.module_from_spec(spec); spec.loader.exec_module(G)
+    for fd, curve in ((0, pyoracle.G1), (1, pyoracle.GRUMPKIN)):
+        n = curve.n
+        lam = G.consts(curve)[0]
+        rnd = random.Random(500 + 10 * c + fd)
+        ks = [0, 1, n - 1, n // 2, lam, n - lam, (1 << 253) + 1, n - 3] + [rnd.randrange(n) for _ in range(3000)]
+        kw = np.array([[(k >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for k in ks], dtype=np.uint32)
+        dig = np.zeros((len(ks), 2, 64), dtype=np.int32)
+        hostlib.ht_glv_digits.restype = C.c_int
+        W = hostlib.ht_glv_digits(fd, p32(kw), C.c_size_t(len(ks)), c, dig.ctypes.data_as(C.POINTER(C.c_int32)))
+        assert W == (128 + c - 1) // c
+        for k, row in zip(ks, dig):
+            k1 = sum(int(row[0][w]) << (w * c) for w in range(W))
+            k2 = sum(int(row[1][w]) << (w * c) for w in range(W))
+            assert (k1 + k2 * lam - k) % n == 0
+            assert all(abs(int(row[e][w])) <= 1 << (c - 1) for e in range(2) for w in range(W))
