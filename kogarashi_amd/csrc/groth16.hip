@@ -560,6 +560,19 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
     h_sorted = rc == KG_OK;
   };
   const bool early = h_early && do_h && hn && (do_g2 || do_g1w) && !small;
+  bool h_out = false;
+  if (small && do_h && nz > (size_t)ctx->tune.g16_small_h_first) {
+    // The order in which this thread issues a short proof's ~35 launches (5 us each) decides what starts when.  h's chain -- transforms,
+    // point-wise step, coset_idft, h's MSM -- is the longest chain of dependent launches: from 2^13 constraints all of it goes out before the
+    // three G1 witness MSMs, which need nothing but z (2^14 constraints: 1.11 -> 1.05 ms blocking).  Shorter proofs keep the witness MSMs
+    // first: their host finishes feed the assembly's s A + r B1 chain, which is the critical path there (2^4: 0.34 -> 0.37 ms with h first).
+    h_front();
+    if (rc == KG_OK && hn) {
+      rc = msm_small_enqueue(ctx, hq, KG_G1, crs->d_h, crs->d_h_inf, A, hn, SL[4], sch, srh);
+      if (rc == KG_OK) f_q = finish_async(KG_G1, SL[4], q_p);
+    } else if (!hn) msm_identity(KG_G1, q_p);
+    h_out = true;
+  }
   if (small && (do_g2 || do_g1w)) {
     // (b_g2 went out in front of the transform chains); a, b_g1 and l on queues of their own
     if (do_g1w) {
@@ -601,6 +614,8 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
   // through rc into the assembly task below, which joins all of them before it reports.
   // (Measured and dropped: h's chain on a service queue under the witness accumulations -- the transform's workgroups only
   // get onto a CU once an accumulation has drained, and then queue behind the reductions: 3.3 -> 3.85 ms per proof.)
+  if (h_out) {
+  } else {
   if (do_h && !early) h_front();
   if (rc == KG_OK && hn && do_h && small) {               // h's coefficients come off the main queue: its MSM right behind them
     rc = msm_small_enqueue(ctx, hq, KG_G1, crs->d_h, crs->d_h_inf, A, hn, SL[4], sch, srh);
@@ -617,6 +632,7 @@ int prove_enqueue(kg_ctx* ctx, const kg_groth16_crs* crs, const uint64_t* d_a_ev
     if (rc == KG_OK) rc = msm_run(ctx, Sq, KG_G1, crs->d_h, crs->d_h_inf, hn, 0, SL[4]);
     if (rc == KG_OK) f_q = finish_async(KG_G1, SL[4], q_p);
   } else msm_identity(KG_G1, q_p);
+  }
   // Host side of the proof on a worker thread: first the parts of the assembly (prover.rs:75-77) that depend on no MSM
   // result, then A, B and C up to h's term as the witness MSMs' host finishes arrive, then h's term.
   for (int i = 0; i < 4; ++i) { job->rr[i] = r[i]; job->ss[i] = s[i]; }

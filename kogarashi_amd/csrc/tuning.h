@@ -59,6 +59,7 @@
   X(g16_h_early_pipe, "KG_G16_H_EARLY_PIPE", 1, "0 = the early-h order only for blocking proofs") \
   X(g16_g2_glv_max, "KG_G16_G2_GLV_MAX", 1100, "a proof's b_g2 MSM keeps the halved scalars (KG_SMALL_GLV) up to this many witness entries") \
   X(g16_blind_early, "KG_G16_BLIND_EARLY", 1, "a proof's blinding chains (prover.rs:75-77, three 255-step host chains) start when the proof is enqueued; 0 = when its assembly starts") \
+  X(g16_small_h_first, "KG_G16_SMALL_H_FIRST", 4096, "a short proof (one-launch MSMs) with more witness entries than this issues h's whole chain before the three G1 witness MSMs") \
   X(g16_h_inline, "KG_G16_H_INLINE", 1, "a blocking proof runs h's reduction behind h's accumulation on the main queue") \
   /* ---- NTT ------------------------------------------------------------------------------------------------------------------------- */ \
   X(ntt_direct_max_log, "KG_NTT_DIRECT_MAX_LOG", 22, "largest log2 of a direct inter-step twiddle table, 0..22 (beyond it, and when the allocation fails: composed twiddles)") \
